@@ -1,0 +1,135 @@
+/*
+ * mjpl_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C float64 restatement of the reference hot path
+ *     CollisionConstraint.valid_config          (src/mjpl/constraint/collision_constraint.py:26-30)
+ *     CollisionRuleset.obeys_ruleset            (src/mjpl/constraint/collision_constraint.py:66-95)
+ *     _step / _valid_collision_interval         (src/mjpl/planning/utils.py:167-216)
+ * whose arithmetic lives in the un-vendored third-party wheel `mujoco >= 3`
+ * (pyproject.toml:12; call sites collision_constraint.py:28-29).  MuJoCo's C
+ * sources are not present in /root/reference nor installed, so the engine
+ * routines (mj_kinematics, mj_collision, the primitive narrowphase) are restated
+ * from their published algorithm -- every such function is tagged [MJ-recalled].
+ *
+ * PARITY PINNING: pinned against the analytic known-answer tests the reference's
+ * own test-suite holds for this path (tests/golden/kat_reference.json, from
+ * test/test_collision_constraint.py:16-33 and test/test_planning_utils.py:207-344)
+ * and against independent closed-form FK fixtures (tests/golden/fk_*.json).
+ * Capsule/box narrowphase and 6/7-DoF verdicts are NOT pinned by any reference
+ * test: for those this oracle is "parity unpinned".
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (mjpl_amd/, libmjpl_hip.so) never does.
+ */
+#ifndef MJPL_ORACLE_H
+#define MJPL_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MuJoCo enums (mjtJoint / mjtGeom) -- values as in mujoco/mjmodel.h [MJ-recalled] */
+enum { ORC_JNT_FREE = 0, ORC_JNT_BALL = 1, ORC_JNT_SLIDE = 2, ORC_JNT_HINGE = 3 };
+enum {
+  ORC_GEOM_PLANE = 0, ORC_GEOM_HFIELD = 1, ORC_GEOM_SPHERE = 2, ORC_GEOM_CAPSULE = 3,
+  ORC_GEOM_ELLIPSOID = 4, ORC_GEOM_CYLINDER = 5, ORC_GEOM_BOX = 6, ORC_GEOM_MESH = 7
+};
+
+/* The subset of mjModel the path reads.  All arrays are borrowed. */
+typedef struct orc_model {
+  int32_t nq, njnt, nbody, ngeom;
+  const int32_t *body_parentid;   /* [nbody] */
+  const int32_t *body_weldid;     /* [nbody] */
+  const int32_t *body_jntadr;     /* [nbody] (-1 if none) */
+  const int32_t *body_jntnum;     /* [nbody] */
+  const double  *body_pos;        /* [nbody*3] */
+  const double  *body_quat;       /* [nbody*4] */
+  const int32_t *jnt_type;        /* [njnt] */
+  const int32_t *jnt_qposadr;     /* [njnt] */
+  const double  *jnt_axis;        /* [njnt*3] */
+  const double  *jnt_pos;         /* [njnt*3] */
+  const double  *qpos0;           /* [nq] */
+  const int32_t *geom_type;       /* [ngeom] */
+  const int32_t *geom_bodyid;     /* [ngeom] */
+  const int32_t *geom_contype;    /* [ngeom] */
+  const int32_t *geom_conaffinity;/* [ngeom] */
+  const double  *geom_size;       /* [ngeom*3] */
+  const double  *geom_pos;        /* [ngeom*3] */
+  const double  *geom_quat;       /* [ngeom*4] */
+  const double  *geom_rbound;     /* [ngeom] */
+  const double  *geom_margin;     /* [ngeom] */
+} orc_model;
+
+/* A batch request: planning columns are scattered into a full-qpos template. */
+typedef struct orc_batch {
+  const double  *qpos_base;   /* [nq]   values of the non-planning joints      */
+  const int32_t *qidx;        /* [nplan] qpos index of each planning column    */
+  int32_t        nplan;
+  int32_t        layout;      /* 0: SoA [nplan][N]   1: AoS [N][nplan]         */
+  const int32_t *allowed;     /* [nallowed*2] sorted body-id pairs (a6)        */
+  int32_t        nallowed;
+} orc_batch;
+
+/* status codes */
+#define ORC_OK            0
+#define ORC_E_JOINT      -2   /* joint type outside {slide,hinge}               */
+#define ORC_E_PAIRTYPE   -3   /* geom pair with no restated narrowphase routine */
+#define ORC_E_OVERFLOW   -4   /* contact buffer too small                       */
+#define ORC_E_NONFINITE  -5   /* NaN/inf in an edge (reference would spin)      */
+
+/* a3: mj_kinematics -- body and geom world poses for one qpos. Outputs may be NULL. */
+int orc_kinematics(const orc_model *m, const double *qpos,
+                   double *xpos, double *xquat, double *xmat,
+                   double *geom_xpos, double *geom_xmat);
+
+/* a4+a5: mj_collision -- fills contact_geom[ncon][2]; returns status. */
+int orc_collision(const orc_model *m, const double *geom_xpos, const double *geom_xmat,
+                  int32_t *contact_geom, int32_t maxcon, int32_t *ncon);
+
+/* a6: CollisionRuleset.obeys_ruleset on a contact list. returns 1/0. */
+int orc_obeys_ruleset(const orc_model *m, const int32_t *contact_geom, int32_t ncon,
+                      const int32_t *allowed, int32_t nallowed);
+
+/* a1: CollisionConstraint.valid_config(qpos[nq]) -> 1 valid, 0 in collision, <0 error */
+int orc_valid_config(const orc_model *m, const int32_t *allowed, int32_t nallowed,
+                     const double *qpos);
+
+/* a8: _step(start, target, max_step_dist) -> out[n]  (sequential-sum 2-norm) */
+void orc_step(const double *start, const double *target, int32_t n, double max_step,
+              double *out);
+
+/* a9: _valid_collision_interval on full-nq vectors: 1/0, <0 error.
+ * nwaypoints (nullable) receives the number of interior waypoints generated,
+ * first_bad (nullable) the 1-based index of the first colliding one (0 if none). */
+int orc_valid_collision_interval(const orc_model *m, const int32_t *allowed, int32_t nallowed,
+                                 const double *start, const double *end, double step_dist,
+                                 int32_t *nwaypoints, int32_t *first_bad);
+
+/* batched a1 over N configurations (nthreads >= 1: static partition, pthreads) */
+int orc_valid_configs(const orc_model *m, const orc_batch *b, const double *Q, int64_t N,
+                      int32_t nthreads, uint8_t *valid);
+
+/* batched "validated edge" (SURVEY 8d): endpoint QB checked first (index 0), then the
+ * interior waypoints of _valid_collision_interval(QA,QB,step) in order (1..K).
+ * valid[e] = AND.  first_bad (nullable): -1 if valid else index of first failing check.
+ * ncheck (nullable): number of configuration checks actually performed per edge. */
+int orc_valid_edges(const orc_model *m, const orc_batch *b, const double *QA, const double *QB,
+                    int64_t E, double step_dist, int32_t nthreads,
+                    uint8_t *valid, int32_t *first_bad, int32_t *ncheck);
+
+/* batched a3 for FK parity: outputs are [N][nbody*3], [N][nbody*4], [N][ngeom*3], [N][ngeom*9] */
+int orc_fk_batch(const orc_model *m, const orc_batch *b, const double *Q, int64_t N,
+                 double *xpos, double *xquat, double *geom_xpos, double *geom_xmat);
+
+/* single primitive pair test, for unit tests: returns 1 contact / 0 none / <0 unsupported.
+ * pos[3], mat[9] row-major, size[3]; types as ORC_GEOM_*; argument order free. */
+int orc_pair_test(int32_t type1, const double *pos1, const double *mat1, const double *size1,
+                  int32_t type2, const double *pos2, const double *mat2, const double *size2,
+                  double margin);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

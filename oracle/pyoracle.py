@@ -1,0 +1,240 @@
+"""ctypes binding of the CPU ORACLE (test infrastructure, NOT the product).
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this
+module.  It wraps ``oracle/libmjpl_oracle.so`` (built by ``oracle/Makefile``), the plain-C
+restatement of the reference path ``CollisionConstraint.valid_config``
+(src/mjpl/constraint/collision_constraint.py:26-30) and ``_valid_collision_interval``
+(src/mjpl/planning/utils.py:188-216).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmjpl_oracle.so")
+
+_I32P = C.POINTER(C.c_int32)
+_F64P = C.POINTER(C.c_double)
+
+
+class _OrcModel(C.Structure):
+    _fields_ = [
+        ("nq", C.c_int32), ("njnt", C.c_int32), ("nbody", C.c_int32), ("ngeom", C.c_int32),
+        ("body_parentid", _I32P), ("body_weldid", _I32P), ("body_jntadr", _I32P),
+        ("body_jntnum", _I32P), ("body_pos", _F64P), ("body_quat", _F64P),
+        ("jnt_type", _I32P), ("jnt_qposadr", _I32P), ("jnt_axis", _F64P), ("jnt_pos", _F64P),
+        ("qpos0", _F64P),
+        ("geom_type", _I32P), ("geom_bodyid", _I32P), ("geom_contype", _I32P),
+        ("geom_conaffinity", _I32P), ("geom_size", _F64P), ("geom_pos", _F64P),
+        ("geom_quat", _F64P), ("geom_rbound", _F64P), ("geom_margin", _F64P),
+    ]
+
+
+class _OrcBatch(C.Structure):
+    _fields_ = [
+        ("qpos_base", _F64P), ("qidx", _I32P), ("nplan", C.c_int32), ("layout", C.c_int32),
+        ("allowed", _I32P), ("nallowed", C.c_int32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("mjpl_oracle.c", "mjpl_oracle.h"))
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
+        subprocess.run(["make", "-C", _HERE, "-B", "libmjpl_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_kinematics.restype = C.c_int
+        _lib.orc_collision.restype = C.c_int
+        _lib.orc_obeys_ruleset.restype = C.c_int
+        _lib.orc_valid_config.restype = C.c_int
+        _lib.orc_step.restype = None
+        _lib.orc_valid_collision_interval.restype = C.c_int
+        _lib.orc_valid_configs.restype = C.c_int
+        _lib.orc_valid_edges.restype = C.c_int
+        _lib.orc_fk_batch.restype = C.c_int
+        _lib.orc_pair_test.restype = C.c_int
+    return _lib
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def sorted_allowed(model, allowed_collision_bodies) -> np.ndarray:
+    """np.sort(body_ids, axis=1) of collision_constraint.py:60-64."""
+    if not allowed_collision_bodies:
+        return np.zeros((0, 2), np.int32)
+    ids = [(model.body(a).id, model.body(b).id) for a, b in allowed_collision_bodies]
+    return np.sort(np.asarray(ids, dtype=np.int32), axis=1)
+
+
+class Oracle:
+    """Float64 CPU restatement of the collision-validation path for one model."""
+
+    def __init__(self, model, allowed_collision_bodies=(), planning_qidx=None, qpos_base=None):
+        self.model = model
+        self._keep = {}
+        m = _OrcModel()
+        m.nq, m.njnt, m.nbody, m.ngeom = model.nq, model.njnt, model.nbody, model.ngeom
+        for name, typ in _OrcModel._fields_[4:]:
+            arr = getattr(model, name)
+            arr = _i32(arr) if typ is _I32P else _f64(arr)
+            self._keep[name] = arr
+            setattr(m, name, _p(arr, typ))
+        self._m = m
+        self.allowed = _i32(sorted_allowed(model, list(allowed_collision_bodies)))
+        self.set_planning(planning_qidx, qpos_base)
+
+    def set_planning(self, planning_qidx=None, qpos_base=None):
+        nq = self.model.nq
+        self.qidx = _i32(np.arange(nq) if planning_qidx is None else planning_qidx)
+        self.qbase = _f64(np.zeros(nq) if qpos_base is None else qpos_base)
+        assert self.qbase.shape == (nq,)
+
+    def _batch(self, layout):
+        b = _OrcBatch()
+        b.qpos_base = _p(self.qbase, _F64P)
+        b.qidx = _p(self.qidx, _I32P)
+        b.nplan = len(self.qidx)
+        b.layout = layout
+        b.allowed = _p(self.allowed, _I32P)
+        b.nallowed = len(self.allowed)
+        return b
+
+    # ---- single-configuration entry points (full nq vectors, like the reference)
+    def kinematics(self, qpos):
+        m = self.model
+        q = _f64(qpos)
+        xpos, xquat = np.zeros((m.nbody, 3)), np.zeros((m.nbody, 4))
+        xmat = np.zeros((m.nbody, 9))
+        gx, gm = np.zeros((m.ngeom, 3)), np.zeros((m.ngeom, 9))
+        st = lib().orc_kinematics(C.byref(self._m), _p(q, _F64P), _p(xpos, _F64P), _p(xquat, _F64P),
+                                  _p(xmat, _F64P), _p(gx, _F64P), _p(gm, _F64P))
+        if st != 0:
+            raise RuntimeError(f"orc_kinematics status {st}")
+        return dict(xpos=xpos, xquat=xquat, xmat=xmat, geom_xpos=gx, geom_xmat=gm)
+
+    def contacts(self, qpos) -> np.ndarray:
+        """``data.contact.geom`` after mj_kinematics + mj_collision: int32 [ncon, 2]."""
+        k = self.kinematics(qpos)
+        con = np.zeros((4096, 2), np.int32)
+        n = C.c_int32(0)
+        st = lib().orc_collision(C.byref(self._m), _p(k["geom_xpos"], _F64P),
+                                 _p(k["geom_xmat"], _F64P), _p(con, _I32P), 4096, C.byref(n))
+        if st != 0:
+            raise RuntimeError(f"orc_collision status {st}")
+        return con[: n.value].copy()
+
+    def obeys_ruleset(self, collision_geometries) -> bool:
+        cg = np.asarray(collision_geometries)
+        if cg.ndim != 2 or cg.shape[1] != 2:
+            raise ValueError("`collision_geometries` must be a nx2 matrix.")
+        cg = _i32(cg)
+        return bool(lib().orc_obeys_ruleset(C.byref(self._m), _p(cg, _I32P), len(cg),
+                                            _p(self.allowed, _I32P), len(self.allowed)))
+
+    def valid_config(self, qpos) -> bool:
+        q = _f64(qpos)
+        assert q.shape == (self.model.nq,)
+        v = lib().orc_valid_config(C.byref(self._m), _p(self.allowed, _I32P), len(self.allowed),
+                                   _p(q, _F64P))
+        if v < 0:
+            raise RuntimeError(f"orc_valid_config status {v}")
+        return bool(v)
+
+    def valid_collision_interval(self, start, end, step_dist, info=False):
+        if step_dist <= 0.0:
+            raise ValueError("`step_dist` must be > 0")
+        s, e = _f64(start), _f64(end)
+        nwp, bad = C.c_int32(0), C.c_int32(0)
+        v = lib().orc_valid_collision_interval(
+            C.byref(self._m), _p(self.allowed, _I32P), len(self.allowed), _p(s, _F64P),
+            _p(e, _F64P), C.c_double(step_dist), C.byref(nwp), C.byref(bad))
+        if v < 0:
+            raise RuntimeError(f"orc_valid_collision_interval status {v}")
+        return (bool(v), nwp.value, bad.value) if info else bool(v)
+
+    # ---- batched entry points (planning columns)
+    def valid_configs(self, Q, layout=1, nthreads=1) -> np.ndarray:
+        Q = _f64(Q)
+        n = Q.shape[1] if layout == 0 else Q.shape[0]
+        assert Q.shape == ((len(self.qidx), n) if layout == 0 else (n, len(self.qidx)))
+        out = np.zeros(n, np.uint8)
+        b = self._batch(layout)
+        st = lib().orc_valid_configs(C.byref(self._m), C.byref(b), _p(Q, _F64P), C.c_int64(n),
+                                     nthreads, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if st != 0:
+            raise RuntimeError(f"orc_valid_configs status {st}")
+        return out
+
+    def valid_edges(self, QA, QB, step_dist, layout=1, nthreads=1, info=False):
+        if step_dist <= 0.0:
+            raise ValueError("`step_dist` must be > 0")
+        QA, QB = _f64(QA), _f64(QB)
+        assert QA.shape == QB.shape
+        n = QA.shape[1] if layout == 0 else QA.shape[0]
+        out = np.zeros(n, np.uint8)
+        fb = np.zeros(n, np.int32)
+        nc = np.zeros(n, np.int32)
+        b = self._batch(layout)
+        st = lib().orc_valid_edges(C.byref(self._m), C.byref(b), _p(QA, _F64P), _p(QB, _F64P),
+                                   C.c_int64(n), C.c_double(step_dist), nthreads,
+                                   out.ctypes.data_as(C.POINTER(C.c_uint8)), _p(fb, _I32P),
+                                   _p(nc, _I32P))
+        if st != 0:
+            raise RuntimeError(f"orc_valid_edges status {st}")
+        return (out, fb, nc) if info else out
+
+    def fk(self, Q, layout=1):
+        m = self.model
+        Q = _f64(Q)
+        n = Q.shape[1] if layout == 0 else Q.shape[0]
+        xpos, xquat = np.zeros((n, m.nbody, 3)), np.zeros((n, m.nbody, 4))
+        gx, gm = np.zeros((n, m.ngeom, 3)), np.zeros((n, m.ngeom, 9))
+        b = self._batch(layout)
+        st = lib().orc_fk_batch(C.byref(self._m), C.byref(b), _p(Q, _F64P), C.c_int64(n),
+                                _p(xpos, _F64P), _p(xquat, _F64P), _p(gx, _F64P), _p(gm, _F64P))
+        if st != 0:
+            raise RuntimeError(f"orc_fk_batch status {st}")
+        return dict(xpos=xpos, xquat=xquat, geom_xpos=gx, geom_xmat=gm)
+
+
+def step(start, target, max_step_dist) -> np.ndarray:
+    """_step (planning/utils.py:167-185) with the sequential-sum norm."""
+    if max_step_dist <= 0.0:
+        raise ValueError("`max_step_dist` must be > 0.0")
+    s, t = _f64(start), _f64(target)
+    out = np.zeros_like(s)
+    lib().orc_step(_p(s, _F64P), _p(t, _F64P), len(s), C.c_double(max_step_dist), _p(out, _F64P))
+    return out
+
+
+def pair_test(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0) -> int:
+    a = [_f64(x) for x in (pos1, np.asarray(mat1).reshape(9), size1, pos2,
+                           np.asarray(mat2).reshape(9), size2)]
+    return lib().orc_pair_test(type1, _p(a[0], _F64P), _p(a[1], _F64P), _p(a[2], _F64P),
+                               type2, _p(a[3], _F64P), _p(a[4], _F64P), _p(a[5], _F64P),
+                               C.c_double(margin))
