@@ -1,0 +1,191 @@
+/*
+ * mjpl_hip.h -- C ABI of libmjpl_hip.so, the MI355X (gfx950) batched collision-validation
+ * engine that sits behind mjpl's Constraint plug-in surface.
+ *
+ * The reference (adlarkin/mjpl, pure Python) has no FFI for this path: its
+ * CollisionConstraint calls the third-party MuJoCo engine through pybind, one
+ * configuration at a time.  Each entry point below names the reference interface
+ * (file:line under /root/reference) whose work it replaces; INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions: plain pointers and sizes, caller owns every buffer, every function returns
+ * an int status (MJPL_OK = 0) and never throws; mjpl_last_error() returns a thread-local
+ * message for the last non-zero status.  One engine per thread/stream.  There is NO CPU
+ * fallback: without a gfx950 device mjpl_create fails with MJPL_E_NODEVICE.
+ *
+ * Batch layout: a batch holds only the nplan PLANNING columns of qpos (the joints a
+ * planner samples, rrt.py:162-206); the remaining qpos entries come from the template
+ * given to mjpl_set_planning.  layout = MJPL_SOA: Q[c*N + i] (coalesced column reads,
+ * the native layout); layout = MJPL_AOS: Q[i*nplan + c] (numpy row-major, transposed
+ * through LDS inside the kernel).
+ */
+#ifndef MJPL_HIP_H
+#define MJPL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJPL_OK            0
+#define MJPL_E_ARG        -1   /* bad argument (NULL, negative size, step_dist <= 0 ...)      */
+#define MJPL_E_JOINT      -2   /* joint type outside {slide, hinge} (reference README.md:20)  */
+#define MJPL_E_PAIRTYPE   -3   /* a colliding geom pair has no primitive narrowphase routine  */
+#define MJPL_E_CAPACITY   -4   /* model exceeds a compiled-in limit (slots, LDS)              */
+#define MJPL_E_NODEVICE   -5   /* no usable HIP device                                        */
+#define MJPL_E_HIP        -6   /* HIP runtime error (message in mjpl_last_error)              */
+#define MJPL_E_NONFINITE  -7   /* NaN/inf edge (the reference's waypoint loop would not end)  */
+
+#define MJPL_SOA 0
+#define MJPL_AOS 1
+
+/* mjpl_check_edges flags */
+#define MJPL_EDGE_INTERIOR_ONLY 1  /* skip check 0 (the endpoint): exactly _valid_collision_interval */
+
+/* mjtJoint / mjtGeom values */
+#define MJPL_JNT_SLIDE 2
+#define MJPL_JNT_HINGE 3
+#define MJPL_GEOM_PLANE 0
+#define MJPL_GEOM_SPHERE 2
+#define MJPL_GEOM_CAPSULE 3
+#define MJPL_GEOM_BOX 6
+
+/* The mjModel subset the path reads; field names as in mjModel.  Replaces the
+ * `model: mujoco.MjModel` argument of CollisionConstraint.__init__
+ * (src/mjpl/constraint/collision_constraint.py:10-24).  Arrays are borrowed for the
+ * duration of mjpl_create only. */
+typedef struct mjpl_model_desc {
+  int32_t nq, njnt, nbody, ngeom;
+  const int32_t *body_parentid;    /* [nbody]   */
+  const int32_t *body_weldid;      /* [nbody]   */
+  const int32_t *body_jntadr;      /* [nbody]   */
+  const int32_t *body_jntnum;      /* [nbody]   */
+  const double  *body_pos;         /* [nbody*3] */
+  const double  *body_quat;        /* [nbody*4] */
+  const int32_t *jnt_type;         /* [njnt]    */
+  const int32_t *jnt_qposadr;      /* [njnt]    */
+  const double  *jnt_axis;         /* [njnt*3]  */
+  const double  *jnt_pos;          /* [njnt*3]  */
+  const double  *qpos0;            /* [nq]      */
+  const int32_t *geom_type;        /* [ngeom]   */
+  const int32_t *geom_bodyid;      /* [ngeom]   */
+  const int32_t *geom_contype;     /* [ngeom]   */
+  const int32_t *geom_conaffinity; /* [ngeom]   */
+  const double  *geom_size;        /* [ngeom*3] */
+  const double  *geom_pos;         /* [ngeom*3] */
+  const double  *geom_quat;        /* [ngeom*4] */
+  const double  *geom_rbound;      /* [ngeom]   */
+  const double  *geom_margin;      /* [ngeom]   */
+} mjpl_model_desc;
+
+typedef struct mjpl_engine mjpl_engine;
+
+typedef struct mjpl_info {
+  int32_t device;            /* HIP device ordinal                                   */
+  int32_t nplan;             /* planning columns per configuration                    */
+  int32_t nmoving_geoms;     /* geoms on bodies below a joint                         */
+  int32_t nstatic_geoms;     /* geoms welded to the world (poses folded at create)    */
+  int32_t npairs;            /* geom pairs left after the mj_collision filters + a6   */
+  int32_t npairs_world;      /* ... of which moving-vs-static                         */
+  int32_t nslots;            /* register slots holding earlier moving geoms           */
+  int32_t nsaves;            /* LDS pose saves for branching bodies                   */
+  int32_t lds_bytes_configs; /* dynamic LDS per block, configs kernel                 */
+  int32_t lds_bytes_edges;   /* dynamic LDS per block, edges kernel                   */
+  int32_t block_threads;
+  int32_t compute_units;
+  char    arch[32];          /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"            */
+} mjpl_info;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+
+/* CollisionConstraint.__init__ + CollisionRuleset.__init__
+ * (collision_constraint.py:10-24, :42-64).  allowed_bodies: nallowed body-id pairs
+ * (any order inside a pair).  The mj_collision pair filters (contype/conaffinity,
+ * same weld body, weld parent-child) and the allowed-body-pair ruleset
+ * (collision_constraint.py:66-95) are folded into a static pair list here. */
+int mjpl_create(const mjpl_model_desc *model, const int32_t *allowed_bodies, int32_t nallowed,
+                int32_t device, mjpl_engine **out);
+void mjpl_destroy(mjpl_engine *e);
+
+/* Which qpos entries a batch column feeds, and the template for all others
+ * (planners keep non-planning joints at q_init, rrt.py:205-206; :162-172).
+ * Default after create: nplan = nq, qidx = 0..nq-1, template = qpos0. */
+int mjpl_set_planning(mjpl_engine *e, const int32_t *qidx, int32_t nplan, const double *qpos_base);
+
+int mjpl_get_info(const mjpl_engine *e, mjpl_info *out);
+
+/* ---- host-buffer entry points (stage H2D, run, copy back, synchronise) ---------- */
+
+/* Batched CollisionConstraint.valid_config (collision_constraint.py:26-30):
+ * valid[i] = 1 iff configuration i has no contact outside the allowed body pairs. */
+int mjpl_check_configs(mjpl_engine *e, const double *Q, int64_t N, int32_t layout,
+                       uint8_t *valid);
+
+/* Batched "validated edge" of _constrained_extend (planning/utils.py:143-158): the endpoint
+ * QB is collision-checked (check index 0), then the interior waypoints of
+ * _valid_collision_interval(QA, QB, step_dist) (planning/utils.py:188-216) in order
+ * (check index 1..K).  valid[e] = AND of all checks.  first_bad (nullable): -1 if valid,
+ * else the index of the first failing check.  flags = MJPL_EDGE_INTERIOR_ONLY drops check 0,
+ * which is _valid_collision_interval itself.  step_dist <= 0 -> MJPL_E_ARG
+ * (the reference raises ValueError("`step_dist` must be > 0"), utils.py:207-208). */
+int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t E,
+                     double step_dist, int32_t layout, int32_t flags, uint8_t *valid,
+                     int32_t *first_bad);
+
+/* Batched mj_kinematics (call site collision_constraint.py:28) for the FK parity check:
+ * xpos [N][nbody*3], xquat [N][nbody*4], geom_xpos [N][ngeom*3], geom_xmat [N][ngeom*9];
+ * any output may be NULL. */
+int mjpl_fk(mjpl_engine *e, const double *Q, int64_t N, int32_t layout,
+            double *xpos, double *xquat, double *geom_xpos, double *geom_xmat);
+
+/* ---- device-resident entry points (asynchronous on the engine's stream) --------- */
+
+int mjpl_check_configs_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout,
+                           uint8_t *dvalid);
+int mjpl_check_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E,
+                         double step_dist, int32_t layout, int32_t flags, uint8_t *dvalid,
+                         int32_t *dfirst_bad);
+/* as mjpl_check_configs_dev but one bit per configuration, packed by wavefront ballot:
+ * bit (i & 63) of dbits[i >> 6]. */
+int mjpl_check_configs_bits_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout,
+                                uint64_t *dbits);
+
+/* Brute-force nearest neighbour of each query among tree nodes (Tree.nearest_neighbor,
+ * planning/tree.py:57-66): nodes SoA [nplan][cap] with n valid, queries SoA [nplan][M];
+ * out_idx[j] = argmin_i ||node_i - query_j||, ties to the lowest index. */
+int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap,
+                     const double *dqueries, int64_t M, int32_t *dout_idx, double *dout_dist2);
+
+/* ---- device memory and stream helpers (so that hosts need no other GPU runtime) -- */
+
+int mjpl_dev_alloc(mjpl_engine *e, size_t bytes, void **out);
+int mjpl_dev_free(mjpl_engine *e, void *p);
+int mjpl_h2d(mjpl_engine *e, void *dst, const void *src, size_t bytes);  /* async */
+int mjpl_d2h(mjpl_engine *e, void *dst, const void *src, size_t bytes);  /* async */
+int mjpl_sync(mjpl_engine *e);
+/* raw hipStream_t of the engine, for interop with other runtimes */
+void *mjpl_stream(mjpl_engine *e);
+
+/* ---- measurement ---------------------------------------------------------------- */
+
+/* Launch the edge kernel `iters` times on the engine's stream, each launch bracketed by
+ * HIP events recorded on that stream; ms[k] receives launch k's duration.  Inputs and
+ * outputs are device-resident.  Used by bench.py for roofline.achieved. */
+int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E,
+                        double step_dist, int32_t layout, uint8_t *dvalid, int32_t iters,
+                        float *ms);
+int mjpl_time_configs_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout,
+                          uint8_t *dvalid, int32_t iters, float *ms);
+
+/* ---- misc ------------------------------------------------------------------------ */
+
+int mjpl_device_count(void);
+const char *mjpl_last_error(void);
+const char *mjpl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

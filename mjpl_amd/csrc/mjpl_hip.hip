@@ -1,0 +1,1011 @@
+// mjpl_hip.hip -- libmjpl_hip.so: gfx950 kernels + the C ABI of include/mjpl_hip.h.
+//
+// Replaces, for whole batches, the per-configuration body of the reference's
+// CollisionConstraint.valid_config (src/mjpl/constraint/collision_constraint.py:26-30) and the
+// edge discretisation of _valid_collision_interval (src/mjpl/planning/utils.py:188-216).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.py).
+// There is deliberately no CPU fallback in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <set>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../../include/mjpl_hip.h"
+#include "mjpl_device.h"
+
+namespace {
+
+using namespace mjpl;
+
+constexpr int kBlock = 256;           // threads per workgroup: 4 wavefronts
+constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
+constexpr int kStatusNonFinite = 1;
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return fail(MJPL_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                  __FILE__, __LINE__);                                                  \
+  } while (0)
+
+// ------------------------------------------------------------------------------- kernels
+
+// LDS carve shared by all kernels: [dp | columns... | saves | ip].  With the default build the
+// tables stay in global memory (scalar loads) and ndp = nip = 0 here.
+struct Carve {
+  double *dpl, *col0, *col1, *save;
+  int *ipl;
+  IP ip;
+  DP dp;
+};
+
+__device__ __forceinline__ Carve carve_lds(double *smem, const int *__restrict__ gip, int nip,
+                                           const double *__restrict__ gdp, int ndp, int nplan,
+                                           int nsave, int ncolsets, int B) {
+  Carve c;
+#if MJPL_TABLES_LDS
+  const int ndl = ndp, nil = nip;
+#else
+  const int ndl = 0, nil = 0;
+#endif
+  c.dpl = smem;
+  c.col0 = c.dpl + ndl;
+  c.col1 = c.col0 + (size_t)nplan * B;
+  c.save = c.col0 + (size_t)ncolsets * nplan * B;
+  c.ipl = reinterpret_cast<int *>(c.save + (size_t)nsave * 7 * B);
+#if MJPL_TABLES_LDS
+  for (int k = threadIdx.x; k < ndl; k += blockDim.x) c.dpl[k] = gdp[k];
+  for (int k = threadIdx.x; k < nil; k += blockDim.x) c.ipl[k] = gip[k];
+  c.ip = c.ipl;
+  c.dp = c.dpl;
+#else
+  (void)nil;
+  c.ip = (IP)gip;
+  c.dp = (DP)gdp;
+#endif
+  return c;
+}
+
+// planning columns of configuration i -> this lane's LDS column slice
+__device__ __forceinline__ void load_columns(double *col, int B, const double *__restrict__ Q,
+                                             int64_t N, int64_t i, int nplan, int layout, bool active) {
+  for (int c = 0; c < nplan; c++) {
+    double v = 0.0;
+    if (active) v = (layout == MJPL_SOA) ? Q[(int64_t)c * N + i] : Q[i * nplan + c];
+    col[c * B] = v;
+  }
+}
+
+template <int MAXS, int BOXLVL>
+__global__ void __launch_bounds__(kBlock)
+k_check_configs(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
+                const double *__restrict__ Q, int64_t N, int layout, uint8_t *__restrict__ valid,
+                unsigned long long *__restrict__ bits) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  const int nplan = gip[H_NPLAN], nsave = gip[H_NSAVE];
+  Carve c = carve_lds(smem, gip, nip, gdp, ndp, nplan, nsave, 1, B);
+  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
+  const bool active = i < N;
+  load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
+  __syncthreads();
+
+  FkOut none = {};
+  bool hit = run_config<MAXS, false, BOXLVL>(c.ip, c.dp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B,
+                                     active, none, i);
+  if (valid && active) valid[i] = hit ? 0 : 1;
+  if (bits) {
+    unsigned long long m = __ballot(active && !hit);
+    if ((threadIdx.x & 63) == 0 && active) bits[i >> 6] = m;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fk(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
+     const double *__restrict__ Q, int64_t N, int layout, FkOut out) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  const int nplan = gip[H_NPLAN], nsave = gip[H_NSAVE];
+  Carve c = carve_lds(smem, gip, nip, gdp, ndp, nplan, nsave, 1, B);
+  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
+  const bool active = i < N;
+  load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
+  __syncthreads();
+  run_config<1, true, 2>(c.ip, c.dp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B, active, out, i);
+}
+
+// One lane per edge.  Check 0 is the endpoint QB; checks 1..K are the interior waypoints of
+// _valid_collision_interval(QA, QB, step) generated on chip by the reference's own recurrence
+//   w <- w + ((QB - w)/||QB - w||) * min(step, ||QB - w||)      (planning/utils.py:182-185)
+// until w == QB (np.array_equal, :211).  ||.|| is the sequential-sum 2-norm over qpos
+// addresses in ascending order (see DESIGN.md "waypoint semantics").
+template <int MAXS, int BOXLVL>
+__global__ void __launch_bounds__(kBlock)
+k_check_edges(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
+              const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, double step,
+              int layout, int flags, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
+              int *__restrict__ status) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  const int nplan = gip[H_NPLAN], nsave = gip[H_NSAVE];
+  Carve c = carve_lds(smem, gip, nip, gdp, ndp, nplan, nsave, 2, B);
+  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
+  const bool active = i < E;
+  double *qe = c.col0 + threadIdx.x;  // edge end (QB)
+  double *qw = c.col1 + threadIdx.x;  // walking waypoint, starts at QA
+  load_columns(qe, B, QB, E, i, nplan, layout, active);
+  load_columns(qw, B, QA, E, i, nplan, layout, active);
+  __syncthreads();
+  IP perm = c.ip + c.ip[H_OFF_PERM];
+  FkOut none = {};
+
+  bool finite = true, at_end = true;
+  for (int k = 0; k < nplan; k++) {
+    double a = qw[k * B], b = qe[k * B];
+    finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
+    at_end = at_end && (a == b);
+  }
+  bool done = !active;
+  bool ok = true;
+  int fb = -1;
+  if (active && !finite) {
+    done = true; ok = false; fb = -2;
+    atomicOr(status, kStatusNonFinite);
+  }
+
+  // Iteration 0 checks the endpoint (apply_constraints validates q before the interval,
+  // utils.py:144); every later iteration advances the waypoint and checks it.  One call site
+  // of run_config keeps a single copy of the interpreter in the instruction stream.
+  int idx = 0;
+  bool first = (flags & MJPL_EDGE_INTERIOR_ONLY) == 0;
+  if (!first && !done && at_end) done = true;
+  while (__ballot(!done) != 0ull) {
+    if (!first && !done) {
+      // _step(w, QB, step)
+      double s = 0;
+      for (int k = 0; k < nplan; k++) {
+        const int col = perm[k];
+        double d = qe[col * B] - qw[col * B];
+        s = s + d * d;
+      }
+      const double mag = sqrt(s);
+      const double sm = step < mag ? step : mag;
+      bool eq = true;
+      for (int k = 0; k < nplan; k++) {
+        double d = qe[k * B] - qw[k * B];
+        double nw = qw[k * B] + (d / mag) * sm;
+        qw[k * B] = nw;
+        eq = eq && (nw == qe[k * B]);
+      }
+      if (eq) {
+        done = true;  // reached QB: that element is dropped by waypoints[1:-1]
+      } else {
+        idx++;
+        if (idx > kMaxWaypoints) {
+          done = true; ok = false; fb = -2;
+          atomicOr(status, kStatusNonFinite);
+        }
+      }
+    }
+    const bool hit = run_config<MAXS, false, BOXLVL>(c.ip, c.dp, first ? qe : qw, B, c.save + threadIdx.x, B,
+                                             !done, none, i);
+    if (!done && hit) { done = true; ok = false; fb = idx; }
+    if (first && !done && at_end) done = true;  // waypoints == [start]: nothing interior
+    first = false;
+  }
+  if (active) {
+    valid[i] = ok ? 1 : 0;
+    if (first_bad) first_bad[i] = fb;
+  }
+}
+
+// Tree.nearest_neighbor (planning/tree.py:57-66) for a batch of queries: squared Euclidean
+// distance in float64, node tiles staged through LDS, ties to the lowest node index.
+__global__ void __launch_bounds__(kBlock)
+k_nearest(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
+          int64_t M, int nplan, int32_t *__restrict__ out_idx, double *__restrict__ out_d2) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  double *qs = smem;                       // [nplan][B] this block's queries
+  double *tile = smem + (size_t)nplan * B; // [nplan][B] node tile
+  const int64_t j = (int64_t)blockIdx.x * B + threadIdx.x;
+  for (int c = 0; c < nplan; c++) qs[c * B + threadIdx.x] = (j < M) ? queries[(int64_t)c * M + j] : 0.0;
+  double best = std::numeric_limits<double>::infinity();
+  int32_t besti = -1;
+  for (int64_t base = 0; base < n; base += B) {
+    __syncthreads();
+    const int64_t src = base + threadIdx.x;
+    for (int c = 0; c < nplan; c++) tile[c * B + threadIdx.x] = (src < n) ? nodes[(int64_t)c * cap + src] : 0.0;
+    __syncthreads();
+    const int lim = (int)((n - base) < B ? (n - base) : B);
+    for (int t = 0; t < lim; t++) {
+      double s = 0;
+      for (int c = 0; c < nplan; c++) {
+        double d = tile[c * B + t] - qs[c * B + threadIdx.x];
+        s = s + d * d;
+      }
+      if (s < best) { best = s; besti = (int32_t)(base + t); }
+    }
+  }
+  if (j < M) {
+    out_idx[j] = besti;
+    if (out_d2) out_d2[j] = best;
+  }
+}
+
+// ------------------------------------------------------------------------------- host model
+
+struct HostModel {
+  int nq = 0, njnt = 0, nbody = 0, ngeom = 0;
+  std::vector<int> body_parentid, body_weldid, body_jntadr, body_jntnum;
+  std::vector<double> body_pos, body_quat;
+  std::vector<int> jnt_type, jnt_qposadr;
+  std::vector<double> jnt_axis, jnt_pos, qpos0;
+  std::vector<int> geom_type, geom_bodyid, geom_contype, geom_conaffinity;
+  std::vector<double> geom_size, geom_pos, geom_quat, geom_rbound, geom_margin;
+};
+
+template <class T>
+std::vector<T> copy_n(const T *p, size_t n) {
+  return std::vector<T>(p, p + n);
+}
+
+}  // namespace
+
+struct mjpl_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop{};
+  HostModel m;
+  std::set<std::pair<int, int>> allowed;  // sorted body-id pairs (collision_constraint.py:60-64)
+  std::vector<int> qidx;
+  std::vector<double> qbase;
+  // compiled program
+  std::vector<int> ip;
+  std::vector<double> dp;
+  int *d_ip = nullptr;
+  double *d_dp = nullptr;
+  int *d_status = nullptr;
+  int nslots = 0, nsave = 0, maxs = 4, boxlvl = 0;
+  int npairs = 0, npairs_world = 0, nmoving = 0, nstatic = 0;
+  // static poses for FK output
+  std::vector<double> st_xpos, st_xquat, st_gxpos, st_gxmat;
+  std::vector<char> body_static, geom_static;
+  // grow-only staging buffers for the host-pointer entry points
+  void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int stage_reserve(mjpl_engine *e, int k, size_t bytes) {
+  if (bytes <= e->stage_bytes[k]) return MJPL_OK;
+  if (e->stage[k]) HIP_TRY(hipFree(e->stage[k]));
+  e->stage[k] = nullptr;
+  e->stage_bytes[k] = 0;
+  size_t want = std::max<size_t>(bytes, 1 << 16);
+  HIP_TRY(hipMalloc(&e->stage[k], want));
+  e->stage_bytes[k] = want;
+  return MJPL_OK;
+}
+
+// mj_collision pair filters [MJ-recalled: engine_collision_driver.c filterBitmask /
+// filterBodyPair] + the a6 ruleset folded in.  returns true if the pair is tested.
+bool pair_enabled(const mjpl_engine *e, int g1, int g2) {
+  const HostModel &m = e->m;
+  const int ct1 = m.geom_contype[g1], ca1 = m.geom_conaffinity[g1];
+  const int ct2 = m.geom_contype[g2], ca2 = m.geom_conaffinity[g2];
+  if (!(ct1 & ca2) && !(ct2 & ca1)) return false;
+  const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+  const int w1 = m.body_weldid[b1], w2 = m.body_weldid[b2];
+  if (w1 == w2) return false;
+  const int wp1 = m.body_weldid[m.body_parentid[w1]];
+  const int wp2 = m.body_weldid[m.body_parentid[w2]];
+  if (w1 != 0 && w2 != 0 && (w1 == wp2 || w2 == wp1)) return false;
+  const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+  if (t1 == GT_PLANE && t2 == GT_PLANE) return false;  // no collision function
+  // CollisionRuleset: a contact between an allowed body pair never invalidates
+  if (e->allowed.count({std::min(b1, b2), std::max(b1, b2)})) return false;
+  return true;
+}
+
+bool type_supported(int t) { return t == GT_PLANE || t == GT_SPHERE || t == GT_CAPSULE || t == GT_BOX; }
+
+// Compile the model into the ip/dp program the kernels interpret.
+int compile_program(mjpl_engine *e) {
+  const HostModel &m = e->m;
+  const int nb = m.nbody, ng = m.ngeom;
+
+  for (int j = 0; j < m.njnt; j++)
+    if (m.jnt_type[j] != JT_SLIDE && m.jnt_type[j] != JT_HINGE)
+      return fail(MJPL_E_JOINT, "joint %d has type %d; only slide(2)/hinge(3) are supported", j,
+                  m.jnt_type[j]);
+
+  // ---- static (world-welded) bodies: poses folded here with the kernels' own arithmetic
+  e->body_static.assign(nb, 0);
+  e->st_xpos.assign(3 * nb, 0.0);
+  e->st_xquat.assign(4 * nb, 0.0);
+  std::vector<double> st_xmat(9 * nb, 0.0);
+  e->st_xquat[0] = 1.0;
+  st_xmat[0] = st_xmat[4] = st_xmat[8] = 1.0;
+  e->body_static[0] = 1;
+  for (int b = 1; b < nb; b++) {
+    if (m.body_weldid[b] != 0) continue;
+    if (m.body_jntnum[b] != 0) return fail(MJPL_E_ARG, "body %d is welded to the world but has joints", b);
+    const int p = m.body_parentid[b];
+    if (!e->body_static[p]) return fail(MJPL_E_ARG, "body %d: weld id 0 below a moving parent", b);
+    e->body_static[b] = 1;
+    double np[3], nq[4];
+    mul_mat_vec3(np, &st_xmat[9 * p], &m.body_pos[3 * b]);
+    for (int k = 0; k < 3; k++) np[k] += e->st_xpos[3 * p + k];
+    mul_quat(nq, &e->st_xquat[4 * p], &m.body_quat[4 * b]);
+    normalize4(nq);
+    for (int k = 0; k < 3; k++) e->st_xpos[3 * b + k] = np[k];
+    for (int k = 0; k < 4; k++) e->st_xquat[4 * b + k] = nq[k];
+    quat2mat(&st_xmat[9 * b], nq);
+  }
+
+  // ---- geoms
+  e->geom_static.assign(ng, 0);
+  e->st_gxpos.assign(3 * ng, 0.0);
+  e->st_gxmat.assign(9 * ng, 0.0);
+  std::vector<int> world_row(ng, -1);
+  std::vector<double> world_tab;
+  e->nstatic = e->nmoving = 0;
+  for (int g = 0; g < ng; g++) {
+    const int b = m.geom_bodyid[g];
+    if (!type_supported(m.geom_type[g])) {
+      // a geom that can never collide is harmless; otherwise refuse
+      bool used = false;
+      for (int h = 0; h < ng && !used; h++)
+        if (h != g) used = pair_enabled(e, std::min(g, h), std::max(g, h));
+      if (used) return fail(MJPL_E_PAIRTYPE, "geom %d has unsupported type %d", g, m.geom_type[g]);
+    }
+    if (!e->body_static[b]) { e->nmoving++; continue; }
+    e->geom_static[g] = 1;
+    e->nstatic++;
+    double gp[3], gq[4];
+    mul_mat_vec3(gp, &st_xmat[9 * b], &m.geom_pos[3 * g]);
+    for (int k = 0; k < 3; k++) e->st_gxpos[3 * g + k] = gp[k] + e->st_xpos[3 * b + k];
+    mul_quat(gq, &e->st_xquat[4 * b], &m.geom_quat[4 * g]);
+    quat2mat(&e->st_gxmat[9 * g], gq);
+    world_row[g] = (int)(world_tab.size() / W_LEN);
+    for (int k = 0; k < 3; k++) world_tab.push_back(e->st_gxpos[3 * g + k]);
+    for (int k = 0; k < 9; k++) world_tab.push_back(e->st_gxmat[9 * g + k]);
+    for (int k = 0; k < 3; k++) world_tab.push_back(m.geom_size[3 * g + k]);
+  }
+  if (world_tab.size() / W_LEN > 4095) return fail(MJPL_E_CAPACITY, "more than 4095 static geoms");
+
+  // ---- moving bodies in id order (parents precede children)
+  std::vector<int> order;
+  for (int b = 1; b < nb; b++)
+    if (!e->body_static[b]) order.push_back(b);
+  std::vector<int> save_slot(nb, -1);
+  int nsave = 0;
+  for (size_t k = 0; k < order.size(); k++) {
+    const int p = m.body_parentid[order[k]];
+    if (e->body_static[p]) continue;
+    if (k > 0 && order[k - 1] == p) continue;
+    if (save_slot[p] < 0) save_slot[p] = nsave++;
+  }
+
+  // moving geoms in processing order, their partners, and register-slot allocation
+  std::vector<int> mgeoms;
+  for (int b : order)
+    for (int g = 0; g < ng; g++)
+      if (m.geom_bodyid[g] == b) mgeoms.push_back(g);
+  const int nm = (int)mgeoms.size();
+  std::vector<std::vector<int>> stored_partners(nm), world_partners(nm);
+  std::vector<int> last_user(nm, -1);
+  e->npairs = e->npairs_world = 0;
+  e->boxlvl = 0;
+  auto note_pair = [&](int ga, int gb) {
+    const bool ba = m.geom_type[ga] == GT_BOX, bb = m.geom_type[gb] == GT_BOX;
+    e->boxlvl = std::max(e->boxlvl, (ba && bb) ? 2 : ((ba || bb) ? 1 : 0));
+  };
+  for (int k = 0; k < nm; k++) {
+    const int g = mgeoms[k];
+    for (int s = 0; s < ng; s++)
+      if (e->geom_static[s] && pair_enabled(e, std::min(g, s), std::max(g, s))) {
+        world_partners[k].push_back(s);
+        note_pair(g, s);
+        e->npairs++; e->npairs_world++;
+      }
+    for (int k2 = 0; k2 < k; k2++) {
+      const int h = mgeoms[k2];
+      if (!pair_enabled(e, std::min(g, h), std::max(g, h))) continue;
+      if (m.geom_type[h] == GT_BOX)
+        return fail(MJPL_E_PAIRTYPE,
+                    "moving box geom %d must be kept for a later moving geom %d: box slots are not "
+                    "implemented in this build", h, g);
+      stored_partners[k].push_back(k2);
+      note_pair(g, h);
+      last_user[k2] = k;
+      e->npairs++;
+    }
+    if (m.geom_type[g] == GT_PLANE) return fail(MJPL_E_PAIRTYPE, "plane geom %d on a moving body", g);
+  }
+  std::vector<int> slot_of(nm, -1);
+  {
+    std::vector<int> free_at;  // slot -> index of the geom after which it is free (-1: free)
+    for (int k = 0; k < nm; k++) {
+      if (last_user[k] < 0) continue;
+      int s = -1;
+      for (size_t t = 0; t < free_at.size(); t++)
+        if (free_at[t] <= k) { s = (int)t; break; }  // last user is done (a geom is stored after its own tests)
+      if (s < 0) { s = (int)free_at.size(); free_at.push_back(-1); }
+      free_at[s] = last_user[k];
+      slot_of[k] = s;
+    }
+    e->nslots = (int)free_at.size();
+  }
+  if (e->nslots > 16)
+    return fail(MJPL_E_CAPACITY, "%d moving geoms must be held at once; this build has 16 register slots",
+                e->nslots);
+  e->maxs = e->nslots <= 4 ? 4 : (e->nslots <= 8 ? 8 : (e->nslots <= 12 ? 12 : 16));
+  e->nsave = nsave;
+
+  // ---- emit
+  std::vector<int> &ip = e->ip;
+  std::vector<double> &dp = e->dp;
+  ip.assign(H_SIZE, 0);
+  dp.clear();
+  const int nplan = (int)e->qidx.size();
+  std::vector<int> col_of(m.nq, -1);
+  for (int c = 0; c < nplan; c++) col_of[e->qidx[c]] = c;
+
+  ip[H_NPLAN] = nplan;
+  ip[H_NSAVE] = nsave;
+  ip[H_NSLOTS] = e->nslots;
+  ip[H_NBODYOPS] = (int)order.size();
+  ip[H_OFF_WORLD] = 0;
+  dp = world_tab;
+
+  // column permutation: ascending qpos address (the order np.linalg.norm sums the full vector)
+  ip[H_OFF_PERM] = (int)ip.size();
+  {
+    std::vector<int> perm(nplan);
+    for (int c = 0; c < nplan; c++) perm[c] = c;
+    std::sort(perm.begin(), perm.end(), [&](int a, int b) { return e->qidx[a] < e->qidx[b]; });
+    for (int c : perm) ip.push_back(c);
+  }
+
+  ip[H_OFF_BODYOPS] = (int)ip.size();
+  int gk = 0;  // index into mgeoms
+  for (size_t k = 0; k < order.size(); k++) {
+    const int b = order[k], p = m.body_parentid[b];
+    int parent_src;
+    if (e->body_static[p]) parent_src = PARENT_STATIC;
+    else if (k > 0 && order[k - 1] == p) parent_src = PARENT_CUR;
+    else parent_src = save_slot[p] + 1;
+    const size_t base = ip.size();
+    ip.resize(base + B_SIZE);
+    ip[base + B_PARENT] = parent_src;
+    ip[base + B_DOFF] = (int)dp.size();
+    ip[base + B_BODYID] = b;
+    ip[base + B_NJNT] = m.body_jntnum[b];
+    ip[base + B_SAVE] = save_slot[b];
+    for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.body_pos[3 * b + k3]);
+    for (int k4 = 0; k4 < 4; k4++) dp.push_back(m.body_quat[4 * b + k4]);
+    if (parent_src == PARENT_STATIC) {
+      for (int k3 = 0; k3 < 3; k3++) dp.push_back(e->st_xpos[3 * p + k3]);
+      for (int k4 = 0; k4 < 4; k4++) dp.push_back(e->st_xquat[4 * p + k4]);
+      for (int k9 = 0; k9 < 9; k9++) dp.push_back(st_xmat[9 * p + k9]);
+    }
+    for (int j = 0; j < m.body_jntnum[b]; j++) {
+      const int jid = m.body_jntadr[b] + j;
+      const int qadr = m.jnt_qposadr[jid];
+      const double *jp = &m.jnt_pos[3 * jid];
+      ip.push_back(m.jnt_type[jid]);
+      ip.push_back(col_of[qadr]);
+      ip.push_back((jp[0] != 0 || jp[1] != 0 || jp[2] != 0) ? JF_POS_NONZERO : 0);
+      ip.push_back((int)dp.size());
+      for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.jnt_axis[3 * jid + k3]);
+      for (int k3 = 0; k3 < 3; k3++) dp.push_back(jp[k3]);
+      dp.push_back(m.qpos0[qadr]);
+      dp.push_back(e->qbase[qadr]);
+    }
+    int ngeom_here = 0;
+    for (; gk < nm && m.geom_bodyid[mgeoms[gk]] == b; gk++, ngeom_here++) {
+      const int g = mgeoms[gk];
+      const double *gp = &m.geom_pos[3 * g], *gq = &m.geom_quat[4 * g];
+      int flags = 0;
+      if (gp[0] == 0 && gp[1] == 0 && gp[2] == 0) flags |= GF_SAMEPOS;
+      if (gq[0] == 1 && gq[1] == 0 && gq[2] == 0 && gq[3] == 0) flags |= GF_SAMEROT;
+      ip.push_back(m.geom_type[g]);
+      ip.push_back(flags);
+      ip.push_back((int)dp.size());
+      ip.push_back(slot_of[gk]);
+      ip.push_back(g);
+      ip.push_back((int)(world_partners[gk].size() + stored_partners[gk].size()));
+      for (int k3 = 0; k3 < 3; k3++) dp.push_back(gp[k3]);
+      for (int k4 = 0; k4 < 4; k4++) dp.push_back(gq[k4]);
+      for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * g + k3]);
+
+      auto emit_partner = [&](int h, bool stored, int index) {
+        // mj_collision order: (g1 < g2 by id), swapped when type1 > type2
+        int g1 = std::min(g, h), g2 = std::max(g, h);
+        const double margin = std::fmax(m.geom_margin[g1], m.geom_margin[g2]);
+        int first = (m.geom_type[g1] > m.geom_type[g2]) ? g2 : g1;
+        int word = index | (m.geom_type[h] << 12) | (stored ? P_STORED : 0) | (first == h ? P_FIRST : 0);
+        ip.push_back(word);
+        ip.push_back((int)dp.size());
+        const double r1 = m.geom_rbound[g1], r2 = m.geom_rbound[g2];
+        double bound = std::numeric_limits<double>::infinity();
+        if (r1 > 0 && r2 > 0) {
+          double bsum = r1 + r2 + margin;
+          bound = bsum * bsum;
+        } else if (m.geom_type[h] == GT_PLANE && m.geom_rbound[g] > 0) {
+          bound = margin + m.geom_rbound[g];
+        }
+        dp.push_back(bound);
+        dp.push_back(margin);
+        if (stored)
+          for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * h + k3]);
+      };
+      for (int s : world_partners[gk]) emit_partner(s, false, world_row[s]);
+      for (int k2 : stored_partners[gk]) emit_partner(mgeoms[k2], true, slot_of[k2]);
+    }
+    ip[base + B_NGEOM] = ngeom_here;
+  }
+
+  // ---- upload
+  if (e->d_ip) (void)hipFree(e->d_ip);
+  if (e->d_dp) (void)hipFree(e->d_dp);
+  e->d_ip = nullptr;
+  e->d_dp = nullptr;
+  if (dp.empty()) dp.push_back(0.0);
+  HIP_TRY(hipMalloc(&e->d_ip, ip.size() * sizeof(int)));
+  HIP_TRY(hipMalloc(&e->d_dp, dp.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(e->d_ip, ip.data(), ip.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_dp, dp.data(), dp.size() * sizeof(double), hipMemcpyHostToDevice));
+  return MJPL_OK;
+}
+
+size_t lds_bytes(const mjpl_engine *e, int ncolsets) {
+  const size_t nplan = e->qidx.size();
+  size_t bytes = (size_t)ncolsets * nplan * kBlock * sizeof(double) +
+                 (size_t)e->nsave * 7 * kBlock * sizeof(double);
+#if MJPL_TABLES_LDS
+  bytes += e->dp.size() * sizeof(double) + e->ip.size() * sizeof(int);
+#endif
+  return bytes ? bytes : 8;
+}
+
+template <class K>
+int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return fail(MJPL_E_CAPACITY, "model needs %zu B of LDS per workgroup (> 160 KiB)", bytes);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return MJPL_OK;
+}
+
+// pick the <MAXS, BOXLVL> instantiation for this model
+template <class F>
+int dispatch_variant(const mjpl_engine *e, F &&f) {
+  auto with_box = [&](auto S) -> int {
+    switch (e->boxlvl) {
+      case 0: return f(S, std::integral_constant<int, 0>{});
+      case 1: return f(S, std::integral_constant<int, 1>{});
+      default: return f(S, std::integral_constant<int, 2>{});
+    }
+  };
+  switch (e->maxs) {
+    case 4: return with_box(std::integral_constant<int, 4>{});
+    case 8: return with_box(std::integral_constant<int, 8>{});
+    case 12: return with_box(std::integral_constant<int, 12>{});
+    default: return with_box(std::integral_constant<int, 16>{});
+  }
+}
+
+int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint8_t *dvalid,
+                   unsigned long long *dbits) {
+  if (N == 0) return MJPL_OK;
+  const size_t lds = lds_bytes(e, 1);
+  const unsigned grid = (unsigned)((N + kBlock - 1) / kBlock);
+  int rc = dispatch_variant(e, [&](auto S, auto X) -> int {
+    auto kern = k_check_configs<decltype(S)::value, decltype(X)::value>;
+    int r = allow_lds(kern, lds);
+    if (r != MJPL_OK) return r;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, e->stream, e->d_ip, (int)e->ip.size(),
+                       e->d_dp, (int)e->dp.size(), dQ, N, layout, dvalid, dbits);
+    return MJPL_OK;
+  });
+  if (rc != MJPL_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+
+int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step,
+                 int layout, int flags, uint8_t *dvalid, int32_t *dfb) {
+  if (E == 0) return MJPL_OK;
+  const size_t lds = lds_bytes(e, 2);
+  const unsigned grid = (unsigned)((E + kBlock - 1) / kBlock);
+  int rc = dispatch_variant(e, [&](auto S, auto X) -> int {
+    auto kern = k_check_edges<decltype(S)::value, decltype(X)::value>;
+    int r = allow_lds(kern, lds);
+    if (r != MJPL_OK) return r;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, e->stream, e->d_ip, (int)e->ip.size(),
+                       e->d_dp, (int)e->dp.size(), dQA, dQB, E, step, layout, flags, dvalid, dfb, e->d_status);
+    return MJPL_OK;
+  });
+  if (rc != MJPL_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+
+int check_common(const mjpl_engine *e, const void *a, int64_t n, int layout) {
+  if (!e) return fail(MJPL_E_ARG, "engine is NULL");
+  if (n < 0) return fail(MJPL_E_ARG, "negative batch size");
+  if (n > 0 && !a) return fail(MJPL_E_ARG, "NULL batch pointer");
+  if (layout != MJPL_SOA && layout != MJPL_AOS) return fail(MJPL_E_ARG, "layout must be MJPL_SOA or MJPL_AOS");
+  return MJPL_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- C ABI
+
+extern "C" {
+
+const char *mjpl_last_error(void) { return g_err.c_str(); }
+const char *mjpl_version(void) { return "mjpl_hip 0.1 (gfx950)"; }
+
+int mjpl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t nallowed,
+                int32_t device, mjpl_engine **out) {
+  if (!d || !out) return fail(MJPL_E_ARG, "mjpl_create: NULL argument");
+  *out = nullptr;
+  if (d->nq < 0 || d->njnt < 0 || d->nbody < 1 || d->ngeom < 0 || nallowed < 0)
+    return fail(MJPL_E_ARG, "mjpl_create: negative size");
+  if (d->nq != d->njnt) return fail(MJPL_E_JOINT, "nq != njnt: only 1-DoF joints are supported");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MJPL_E_NODEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(MJPL_E_NODEVICE, "device %d out of range [0,%d)", device, ndev);
+
+  mjpl_engine *e = new mjpl_engine();
+  e->device = device;
+  auto bail = [&](int rc) { mjpl_destroy(e); return rc; };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipSetDevice(%d) failed", device));
+  if (hipGetDeviceProperties(&e->prop, device) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipGetDeviceProperties failed"));
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipStreamCreate failed"));
+  if (hipMalloc(&e->d_status, sizeof(int)) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipMalloc failed"));
+  (void)hipMemset(e->d_status, 0, sizeof(int));
+
+  HostModel &m = e->m;
+  m.nq = d->nq; m.njnt = d->njnt; m.nbody = d->nbody; m.ngeom = d->ngeom;
+  m.body_parentid = copy_n(d->body_parentid, m.nbody);
+  m.body_weldid = copy_n(d->body_weldid, m.nbody);
+  m.body_jntadr = copy_n(d->body_jntadr, m.nbody);
+  m.body_jntnum = copy_n(d->body_jntnum, m.nbody);
+  m.body_pos = copy_n(d->body_pos, 3 * (size_t)m.nbody);
+  m.body_quat = copy_n(d->body_quat, 4 * (size_t)m.nbody);
+  m.jnt_type = copy_n(d->jnt_type, m.njnt);
+  m.jnt_qposadr = copy_n(d->jnt_qposadr, m.njnt);
+  m.jnt_axis = copy_n(d->jnt_axis, 3 * (size_t)m.njnt);
+  m.jnt_pos = copy_n(d->jnt_pos, 3 * (size_t)m.njnt);
+  m.qpos0 = copy_n(d->qpos0, m.nq);
+  m.geom_type = copy_n(d->geom_type, m.ngeom);
+  m.geom_bodyid = copy_n(d->geom_bodyid, m.ngeom);
+  m.geom_contype = copy_n(d->geom_contype, m.ngeom);
+  m.geom_conaffinity = copy_n(d->geom_conaffinity, m.ngeom);
+  m.geom_size = copy_n(d->geom_size, 3 * (size_t)m.ngeom);
+  m.geom_pos = copy_n(d->geom_pos, 3 * (size_t)m.ngeom);
+  m.geom_quat = copy_n(d->geom_quat, 4 * (size_t)m.ngeom);
+  m.geom_rbound = copy_n(d->geom_rbound, m.ngeom);
+  m.geom_margin = copy_n(d->geom_margin, m.ngeom);
+  for (int b = 0; b < m.nbody; b++)
+    if (m.body_parentid[b] < 0 || m.body_parentid[b] > b || m.body_weldid[b] < 0 || m.body_weldid[b] > b)
+      return bail(fail(MJPL_E_ARG, "body %d: parent/weld ids must precede the body", b));
+  for (int g = 0; g < m.ngeom; g++)
+    if (m.geom_bodyid[g] < 0 || m.geom_bodyid[g] >= m.nbody)
+      return bail(fail(MJPL_E_ARG, "geom %d: body id out of range", g));
+  for (int a = 0; a < nallowed; a++) {
+    int b1 = allowed_bodies[2 * a], b2 = allowed_bodies[2 * a + 1];
+    if (b1 < 0 || b2 < 0 || b1 >= m.nbody || b2 >= m.nbody)
+      return bail(fail(MJPL_E_ARG, "allowed body pair %d out of range", a));
+    e->allowed.insert({std::min(b1, b2), std::max(b1, b2)});
+  }
+  e->qidx.resize(m.nq);
+  for (int k = 0; k < m.nq; k++) e->qidx[k] = k;
+  e->qbase = m.qpos0;
+  int rc = compile_program(e);
+  if (rc != MJPL_OK) return bail(rc);
+  *out = e;
+  return MJPL_OK;
+}
+
+void mjpl_destroy(mjpl_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (int k = 0; k < 6; k++)
+    if (e->stage[k]) (void)hipFree(e->stage[k]);
+  if (e->d_ip) (void)hipFree(e->d_ip);
+  if (e->d_dp) (void)hipFree(e->d_dp);
+  if (e->d_status) (void)hipFree(e->d_status);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int mjpl_set_planning(mjpl_engine *e, const int32_t *qidx, int32_t nplan, const double *qpos_base) {
+  if (!e || nplan < 0 || (nplan > 0 && !qidx)) return fail(MJPL_E_ARG, "mjpl_set_planning: bad argument");
+  std::vector<int> q(qidx, qidx + nplan);
+  std::vector<char> seen(e->m.nq, 0);
+  for (int c : q) {
+    if (c < 0 || c >= e->m.nq || seen[c]) return fail(MJPL_E_ARG, "planning index %d invalid or repeated", c);
+    seen[c] = 1;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->qidx = q;
+  if (qpos_base) e->qbase.assign(qpos_base, qpos_base + e->m.nq);
+  return compile_program(e);
+}
+
+int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
+  if (!e || !out) return fail(MJPL_E_ARG, "mjpl_get_info: NULL argument");
+  memset(out, 0, sizeof(*out));
+  out->device = e->device;
+  out->nplan = (int)e->qidx.size();
+  out->nmoving_geoms = e->nmoving;
+  out->nstatic_geoms = e->nstatic;
+  out->npairs = e->npairs;
+  out->npairs_world = e->npairs_world;
+  out->nslots = e->nslots;
+  out->nsaves = e->nsave;
+  out->lds_bytes_configs = (int)lds_bytes(e, 1);
+  out->lds_bytes_edges = (int)lds_bytes(e, 2);
+  out->block_threads = kBlock;
+  out->compute_units = e->prop.multiProcessorCount;
+  strncpy(out->arch, e->prop.gcnArchName, sizeof(out->arch) - 1);
+  return MJPL_OK;
+}
+
+// ---- device-resident
+
+int mjpl_check_configs_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout, uint8_t *dvalid) {
+  int rc = check_common(e, dQ, N, layout);
+  if (rc != MJPL_OK) return rc;
+  if (N > 0 && !dvalid) return fail(MJPL_E_ARG, "NULL output pointer");
+  HIP_TRY(hipSetDevice(e->device));
+  return launch_configs(e, dQ, N, layout, dvalid, nullptr);
+}
+
+int mjpl_check_configs_bits_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout, uint64_t *dbits) {
+  int rc = check_common(e, dQ, N, layout);
+  if (rc != MJPL_OK) return rc;
+  if (N > 0 && !dbits) return fail(MJPL_E_ARG, "NULL output pointer");
+  HIP_TRY(hipSetDevice(e->device));
+  return launch_configs(e, dQ, N, layout, nullptr, reinterpret_cast<unsigned long long *>(dbits));
+}
+
+int mjpl_check_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step_dist,
+                         int32_t layout, int32_t flags, uint8_t *dvalid, int32_t *dfirst_bad) {
+  int rc = check_common(e, dQA, E, layout);
+  if (rc != MJPL_OK) return rc;
+  if (E > 0 && (!dQB || !dvalid)) return fail(MJPL_E_ARG, "NULL pointer");
+  if (!(step_dist > 0.0)) return fail(MJPL_E_ARG, "`step_dist` must be > 0");
+  HIP_TRY(hipSetDevice(e->device));
+  return launch_edges(e, dQA, dQB, E, step_dist, layout, flags, dvalid, dfirst_bad);
+}
+
+int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap, const double *dqueries,
+                     int64_t M, int32_t *dout_idx, double *dout_dist2) {
+  if (!e || n < 0 || M < 0 || cap < n) return fail(MJPL_E_ARG, "mjpl_nearest_dev: bad sizes");
+  if (M == 0) return MJPL_OK;
+  if (!dnodes || !dqueries || !dout_idx) return fail(MJPL_E_ARG, "mjpl_nearest_dev: NULL pointer");
+  HIP_TRY(hipSetDevice(e->device));
+  const int nplan = (int)e->qidx.size();
+  const size_t lds = 2 * (size_t)nplan * kBlock * sizeof(double);
+  int rc = allow_lds(k_nearest, lds);
+  if (rc != MJPL_OK) return rc;
+  const unsigned grid = (unsigned)((M + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_nearest, dim3(grid), dim3(kBlock), lds, e->stream, dnodes, n, cap, dqueries, M, nplan,
+                     dout_idx, dout_dist2);
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+
+// ---- host-buffer
+
+int mjpl_check_configs(mjpl_engine *e, const double *Q, int64_t N, int32_t layout, uint8_t *valid) {
+  int rc = check_common(e, Q, N, layout);
+  if (rc != MJPL_OK) return rc;
+  if (N == 0) return MJPL_OK;
+  if (!valid) return fail(MJPL_E_ARG, "NULL output pointer");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t qb = (size_t)N * e->qidx.size() * sizeof(double);
+  if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 2, (size_t)N)) != MJPL_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(e->stage[0], Q, qb, hipMemcpyHostToDevice, e->stream));
+  if ((rc = launch_configs(e, (const double *)e->stage[0], N, layout, (uint8_t *)e->stage[2], nullptr)) != MJPL_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(valid, e->stage[2], (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MJPL_OK;
+}
+
+int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t E, double step_dist,
+                     int32_t layout, int32_t flags, uint8_t *valid, int32_t *first_bad) {
+  int rc = check_common(e, QA, E, layout);
+  if (rc != MJPL_OK) return rc;
+  if (!(step_dist > 0.0)) return fail(MJPL_E_ARG, "`step_dist` must be > 0");
+  if (E == 0) return MJPL_OK;
+  if (!QB || !valid) return fail(MJPL_E_ARG, "NULL pointer");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t qb = (size_t)E * e->qidx.size() * sizeof(double);
+  if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 1, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 2, (size_t)E)) != MJPL_OK) return rc;
+  if (first_bad && (rc = stage_reserve(e, 3, (size_t)E * sizeof(int32_t))) != MJPL_OK) return rc;
+  HIP_TRY(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
+  HIP_TRY(hipMemcpyAsync(e->stage[0], QA, qb, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->stage[1], QB, qb, hipMemcpyHostToDevice, e->stream));
+  if ((rc = launch_edges(e, (const double *)e->stage[0], (const double *)e->stage[1], E, step_dist, layout, flags,
+                         (uint8_t *)e->stage[2], first_bad ? (int32_t *)e->stage[3] : nullptr)) != MJPL_OK)
+    return rc;
+  int status = 0;
+  HIP_TRY(hipMemcpyAsync(valid, e->stage[2], (size_t)E, hipMemcpyDeviceToHost, e->stream));
+  if (first_bad) HIP_TRY(hipMemcpyAsync(first_bad, e->stage[3], (size_t)E * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(&status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (status & kStatusNonFinite)
+    return fail(MJPL_E_NONFINITE, "an edge holds NaN/inf or needs more than %d waypoints", kMaxWaypoints);
+  return MJPL_OK;
+}
+
+int mjpl_fk(mjpl_engine *e, const double *Q, int64_t N, int32_t layout, double *xpos, double *xquat,
+            double *geom_xpos, double *geom_xmat) {
+  int rc = check_common(e, Q, N, layout);
+  if (rc != MJPL_OK) return rc;
+  if (N == 0) return MJPL_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const HostModel &m = e->m;
+  const size_t qb = (size_t)N * e->qidx.size() * sizeof(double);
+  const size_t sz[4] = {(size_t)N * m.nbody * 3 * 8, (size_t)N * m.nbody * 4 * 8, (size_t)N * m.ngeom * 3 * 8,
+                        (size_t)N * m.ngeom * 9 * 8};
+  double *host[4] = {xpos, xquat, geom_xpos, geom_xmat};
+  if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
+  for (int k = 0; k < 4; k++)
+    if (host[k] && (rc = stage_reserve(e, 2 + k, sz[k])) != MJPL_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(e->stage[0], Q, qb, hipMemcpyHostToDevice, e->stream));
+  FkOut out;
+  out.xpos = xpos ? (double *)e->stage[2] : nullptr;
+  out.xquat = xquat ? (double *)e->stage[3] : nullptr;
+  out.geom_xpos = geom_xpos ? (double *)e->stage[4] : nullptr;
+  out.geom_xmat = geom_xmat ? (double *)e->stage[5] : nullptr;
+  out.nbody = m.nbody;
+  out.ngeom = m.ngeom;
+  const size_t lds = lds_bytes(e, 1);
+  const unsigned grid = (unsigned)((N + kBlock - 1) / kBlock);
+  rc = allow_lds(k_fk, lds);
+  if (rc == MJPL_OK)
+    hipLaunchKernelGGL(k_fk, dim3(grid), dim3(kBlock), lds, e->stream, e->d_ip, (int)e->ip.size(), e->d_dp,
+                       (int)e->dp.size(), (const double *)e->stage[0], N, layout, out);
+  if (rc != MJPL_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  for (int k = 0; k < 4; k++)
+    if (host[k]) HIP_TRY(hipMemcpyAsync(host[k], e->stage[2 + k], sz[k], hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  // bodies/geoms welded to the world do not depend on qpos: poses folded at create
+  for (int64_t i = 0; i < N; i++) {
+    for (int b = 0; b < m.nbody; b++) {
+      if (!e->body_static[b]) continue;
+      if (xpos) memcpy(xpos + (i * m.nbody + b) * 3, &e->st_xpos[3 * b], 3 * sizeof(double));
+      if (xquat) memcpy(xquat + (i * m.nbody + b) * 4, &e->st_xquat[4 * b], 4 * sizeof(double));
+    }
+    for (int g = 0; g < m.ngeom; g++) {
+      if (!e->geom_static[g]) continue;
+      if (geom_xpos) memcpy(geom_xpos + (i * m.ngeom + g) * 3, &e->st_gxpos[3 * g], 3 * sizeof(double));
+      if (geom_xmat) memcpy(geom_xmat + (i * m.ngeom + g) * 9, &e->st_gxmat[9 * g], 9 * sizeof(double));
+    }
+  }
+  return MJPL_OK;
+}
+
+// ---- memory / stream helpers
+
+int mjpl_dev_alloc(mjpl_engine *e, size_t bytes, void **out) {
+  if (!e || !out) return fail(MJPL_E_ARG, "mjpl_dev_alloc: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+  return MJPL_OK;
+}
+
+int mjpl_dev_free(mjpl_engine *e, void *p) {
+  if (!e) return fail(MJPL_E_ARG, "mjpl_dev_free: NULL engine");
+  HIP_TRY(hipSetDevice(e->device));
+  if (p) HIP_TRY(hipFree(p));
+  return MJPL_OK;
+}
+
+int mjpl_h2d(mjpl_engine *e, void *dst, const void *src, size_t bytes) {
+  if (!e || (bytes && (!dst || !src))) return fail(MJPL_E_ARG, "mjpl_h2d: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+  return MJPL_OK;
+}
+
+int mjpl_d2h(mjpl_engine *e, void *dst, const void *src, size_t bytes) {
+  if (!e || (bytes && (!dst || !src))) return fail(MJPL_E_ARG, "mjpl_d2h: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+  return MJPL_OK;
+}
+
+int mjpl_sync(mjpl_engine *e) {
+  if (!e) return fail(MJPL_E_ARG, "mjpl_sync: NULL engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MJPL_OK;
+}
+
+void *mjpl_stream(mjpl_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+// ---- measurement: per-launch HIP-event timing on the engine's own stream
+
+int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step_dist,
+                        int32_t layout, uint8_t *dvalid, int32_t iters, float *ms) {
+  if (!e || iters < 0 || (iters > 0 && !ms)) return fail(MJPL_E_ARG, "mjpl_time_edges_dev: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  std::vector<hipEvent_t> ev(2 * (size_t)iters);
+  for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
+  int rc = MJPL_OK;
+  for (int k = 0; k < iters && rc == MJPL_OK; k++) {
+    HIP_TRY(hipEventRecord(ev[2 * k], e->stream));
+    rc = mjpl_check_edges_dev(e, dQA, dQB, E, step_dist, layout, 0, dvalid, nullptr);
+    HIP_TRY(hipEventRecord(ev[2 * k + 1], e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < iters && rc == MJPL_OK; k++) HIP_TRY(hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]));
+  for (auto &x : ev) (void)hipEventDestroy(x);
+  return rc;
+}
+
+int mjpl_time_configs_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout, uint8_t *dvalid,
+                          int32_t iters, float *ms) {
+  if (!e || iters < 0 || (iters > 0 && !ms)) return fail(MJPL_E_ARG, "mjpl_time_configs_dev: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  std::vector<hipEvent_t> ev(2 * (size_t)iters);
+  for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
+  int rc = MJPL_OK;
+  for (int k = 0; k < iters && rc == MJPL_OK; k++) {
+    HIP_TRY(hipEventRecord(ev[2 * k], e->stream));
+    rc = mjpl_check_configs_dev(e, dQ, N, layout, dvalid);
+    HIP_TRY(hipEventRecord(ev[2 * k + 1], e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < iters && rc == MJPL_OK; k++) HIP_TRY(hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]));
+  for (auto &x : ev) (void)hipEventDestroy(x);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+"""ctypes binding of ``libmjpl_hip.so`` (include/mjpl_hip.h) -- the only compute backend.
+
+There is no CPU path in this package: if the library is missing, cannot be loaded, or finds
+no gfx950 device, construction raises.  (The CPU restatement under ``oracle/`` is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from .model import Model
+
+SOA, AOS = 0, 1
+EDGE_INTERIOR_ONLY = 1
+
+_I32P = C.POINTER(C.c_int32)
+_F64P = C.POINTER(C.c_double)
+_U8P = C.POINTER(C.c_uint8)
+
+
+class MjplError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libmjpl_hip status {code}: {msg}")
+        self.code = code
+
+
+class _ModelDesc(C.Structure):
+    _fields_ = [
+        ("nq", C.c_int32), ("njnt", C.c_int32), ("nbody", C.c_int32), ("ngeom", C.c_int32),
+        ("body_parentid", _I32P), ("body_weldid", _I32P), ("body_jntadr", _I32P),
+        ("body_jntnum", _I32P), ("body_pos", _F64P), ("body_quat", _F64P),
+        ("jnt_type", _I32P), ("jnt_qposadr", _I32P), ("jnt_axis", _F64P), ("jnt_pos", _F64P),
+        ("qpos0", _F64P),
+        ("geom_type", _I32P), ("geom_bodyid", _I32P), ("geom_contype", _I32P),
+        ("geom_conaffinity", _I32P), ("geom_size", _F64P), ("geom_pos", _F64P),
+        ("geom_quat", _F64P), ("geom_rbound", _F64P), ("geom_margin", _F64P),
+    ]
+
+
+class Info(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("nplan", C.c_int32), ("nmoving_geoms", C.c_int32),
+        ("nstatic_geoms", C.c_int32), ("npairs", C.c_int32), ("npairs_world", C.c_int32),
+        ("nslots", C.c_int32), ("nsaves", C.c_int32), ("lds_bytes_configs", C.c_int32),
+        ("lds_bytes_edges", C.c_int32), ("block_threads", C.c_int32), ("compute_units", C.c_int32),
+        ("arch", C.c_char * 32),
+    ]
+
+    def as_dict(self) -> dict:
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["arch"] = self.arch.decode()
+        return d
+
+
+# every symbol include/mjpl_hip.h declares: (restype, argtypes)
+_VP = C.c_void_p
+ABI = {
+    "mjpl_create": (C.c_int, [C.POINTER(_ModelDesc), _I32P, C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "mjpl_destroy": (None, [_VP]),
+    "mjpl_set_planning": (C.c_int, [_VP, _I32P, C.c_int32, _F64P]),
+    "mjpl_get_info": (C.c_int, [_VP, C.POINTER(Info)]),
+    "mjpl_check_configs": (C.c_int, [_VP, _F64P, C.c_int64, C.c_int32, _U8P]),
+    "mjpl_check_edges": (C.c_int, [_VP, _F64P, _F64P, C.c_int64, C.c_double, C.c_int32, C.c_int32, _U8P,
+                                   _I32P]),
+    "mjpl_fk": (C.c_int, [_VP, _F64P, C.c_int64, C.c_int32, _F64P, _F64P, _F64P, _F64P]),
+    "mjpl_check_configs_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP]),
+    "mjpl_check_edges_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int32, C.c_int32, _VP,
+                                       _VP]),
+    "mjpl_check_configs_bits_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP]),
+    "mjpl_nearest_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, _VP, _VP]),
+    "mjpl_dev_alloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
+    "mjpl_dev_free": (C.c_int, [_VP, _VP]),
+    "mjpl_h2d": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "mjpl_d2h": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "mjpl_sync": (C.c_int, [_VP]),
+    "mjpl_stream": (_VP, [_VP]),
+    "mjpl_time_edges_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int32, _VP, C.c_int32,
+                                      C.POINTER(C.c_float)]),
+    "mjpl_time_configs_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.c_int32,
+                                        C.POINTER(C.c_float)]),
+    "mjpl_device_count": (C.c_int, []),
+    "mjpl_last_error": (C.c_char_p, []),
+    "mjpl_version": (C.c_char_p, []),
+}
+
+_libs: dict[str, C.CDLL] = {}
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen libmjpl_hip.so and bind every declared entry point (fails loudly)."""
+    path = path or os.environ.get("MJPL_HIP_LIB") or _build.LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(mjpl_amd has no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _libs[path] = lib
+    return lib
+
+
+def device_count() -> int:
+    return int(load_library().mjpl_device_count())
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed block owned by an :class:`Engine`."""
+
+    def __init__(self, eng: "Engine", nbytes: int):
+        self.eng, self.nbytes = eng, int(nbytes)
+        p = _VP()
+        eng._ok(eng.lib.mjpl_dev_alloc(eng.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self._keep = arr  # async copy: keep the source alive until the next sync
+        self.eng._ok(self.eng.lib.mjpl_h2d(self.eng.h, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.eng._ok(self.eng.lib.mjpl_d2h(self.eng.h, out.ctypes.data, self.ptr, out.nbytes))
+        self.eng.sync()
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.eng.lib.mjpl_dev_free(self.eng.h, self.ptr)
+            self.ptr = None
+
+
+class Engine:
+    """One compiled model on one MI355X (one HIP stream).  Not thread-safe, like the
+    reference's per-constraint MjData (collision_constraint.py:23)."""
+
+    def __init__(self, model: Model, allowed_collision_bodies=(), device: int = 0,
+                 lib_path: str | None = None):
+        self.lib = load_library(lib_path)
+        self.model = model
+        self.h = None
+        d = _ModelDesc()
+        d.nq, d.njnt, d.nbody, d.ngeom = model.nq, model.njnt, model.nbody, model.ngeom
+        keep = []
+        for name, typ in _ModelDesc._fields_[4:]:
+            arr = getattr(model, name)
+            arr = _i32(arr) if typ is _I32P else _f64(arr)
+            keep.append(arr)
+            setattr(d, name, arr.ctypes.data_as(typ))
+        # body names -> ids (unknown names raise KeyError from model.body, as mujoco does)
+        pairs = _i32([(model.body(a).id, model.body(b).id) for a, b in allowed_collision_bodies]
+                     ).reshape(-1, 2)
+        h = _VP()
+        rc = self.lib.mjpl_create(C.byref(d), pairs.ctypes.data_as(_I32P), len(pairs), device, C.byref(h))
+        self._ok(rc)
+        self.h = h
+        self.nplan = model.nq
+
+    # -- plumbing
+    def _ok(self, rc: int):
+        if rc != 0:
+            raise MjplError(rc, self.lib.mjpl_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.mjpl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._ok(self.lib.mjpl_sync(self.h))
+
+    def info(self) -> dict:
+        i = Info()
+        self._ok(self.lib.mjpl_get_info(self.h, C.byref(i)))
+        return i.as_dict()
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def set_planning(self, qidx, qpos_base):
+        qidx = _i32(qidx)
+        base = _f64(qpos_base)
+        if base.shape != (self.model.nq,):
+            raise ValueError(f"qpos_base must have {self.model.nq} entries")
+        self._ok(self.lib.mjpl_set_planning(self.h, qidx.ctypes.data_as(_I32P), len(qidx),
+                                            base.ctypes.data_as(_F64P)))
+        self.nplan = len(qidx)
+
+    def _batch(self, Q, layout):
+        Q = _f64(Q)
+        want_cols = self.nplan
+        if Q.ndim != 2 or (Q.shape[0] if layout == SOA else Q.shape[1]) != want_cols:
+            raise ValueError(f"batch must be [{'nplan, N' if layout == SOA else 'N, nplan'}] "
+                             f"with nplan={want_cols}, got {Q.shape}")
+        return Q, (Q.shape[1] if layout == SOA else Q.shape[0])
+
+    # -- host-buffer entry points
+    def check_configs(self, Q, layout=AOS) -> np.ndarray:
+        Q, n = self._batch(Q, layout)
+        out = np.zeros(n, np.uint8)
+        self._ok(self.lib.mjpl_check_configs(self.h, Q.ctypes.data_as(_F64P), n, layout,
+                                             out.ctypes.data_as(_U8P)))
+        return out
+
+    def check_edges(self, QA, QB, step_dist, layout=AOS, first_bad=False, interior_only=False):
+        QA, n = self._batch(QA, layout)
+        QB, n2 = self._batch(QB, layout)
+        if n != n2:
+            raise ValueError("QA and QB must hold the same number of edges")
+        out = np.zeros(n, np.uint8)
+        fb = np.zeros(n, np.int32) if first_bad else None
+        self._ok(self.lib.mjpl_check_edges(
+            self.h, QA.ctypes.data_as(_F64P), QB.ctypes.data_as(_F64P), n, float(step_dist), layout,
+            EDGE_INTERIOR_ONLY if interior_only else 0,
+            out.ctypes.data_as(_U8P), fb.ctypes.data_as(_I32P) if first_bad else None))
+        return (out, fb) if first_bad else out
+
+    def fk(self, Q, layout=AOS) -> dict:
+        Q, n = self._batch(Q, layout)
+        m = self.model
+        xpos, xquat = np.zeros((n, m.nbody, 3)), np.zeros((n, m.nbody, 4))
+        gx, gm = np.zeros((n, m.ngeom, 3)), np.zeros((n, m.ngeom, 9))
+        self._ok(self.lib.mjpl_fk(self.h, Q.ctypes.data_as(_F64P), n, layout,
+                                  xpos.ctypes.data_as(_F64P), xquat.ctypes.data_as(_F64P),
+                                  gx.ctypes.data_as(_F64P), gm.ctypes.data_as(_F64P)))
+        return dict(xpos=xpos, xquat=xquat, geom_xpos=gx, geom_xmat=gm)
+
+    # -- device-resident entry points (pointers are DeviceBuffer.ptr or foreign device pointers)
+    def check_configs_dev(self, dQ, n, layout, dvalid):
+        self._ok(self.lib.mjpl_check_configs_dev(self.h, dQ, n, layout, dvalid))
+
+    def check_configs_bits_dev(self, dQ, n, layout, dbits):
+        self._ok(self.lib.mjpl_check_configs_bits_dev(self.h, dQ, n, layout, dbits))
+
+    def check_edges_dev(self, dQA, dQB, n, step_dist, layout, dvalid, dfirst_bad=None, flags=0):
+        self._ok(self.lib.mjpl_check_edges_dev(self.h, dQA, dQB, n, float(step_dist), layout, flags,
+                                               dvalid, dfirst_bad))
+
+    def nearest_dev(self, dnodes, n, cap, dqueries, m, dout_idx, dout_d2=None):
+        self._ok(self.lib.mjpl_nearest_dev(self.h, dnodes, n, cap, dqueries, m, dout_idx, dout_d2))
+
+    def time_edges_dev(self, dQA, dQB, n, step_dist, layout, dvalid, iters) -> np.ndarray:
+        ms = np.zeros(iters, np.float32)
+        self._ok(self.lib.mjpl_time_edges_dev(self.h, dQA, dQB, n, float(step_dist), layout, dvalid,
+                                              iters, ms.ctypes.data_as(C.POINTER(C.c_float))))
+        return ms
+
+    def time_configs_dev(self, dQ, n, layout, dvalid, iters) -> np.ndarray:
+        ms = np.zeros(iters, np.float32)
+        self._ok(self.lib.mjpl_time_configs_dev(self.h, dQ, n, layout, dvalid, iters,
+                                                ms.ctypes.data_as(C.POINTER(C.c_float))))
+        return ms

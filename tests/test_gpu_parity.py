@@ -1,0 +1,126 @@
+"""GPU parity: libmjpl_hip.so (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bar (BASELINE.json north_star): per-configuration / per-edge verdict bit-exact,
+FK positions within 1e-6."""
+import numpy as np
+import pytest
+
+from mjpl_amd import engine as eng_mod
+from mjpl_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+FK_TOL = 1e-6  # north_star tolerance on FK positions
+
+
+def _uniform_configs(model, n, seed, fingers=0.04):
+    rng = np.random.default_rng(seed)
+    Q = rng.uniform(model.jnt_range[:, 0], model.jnt_range[:, 1], size=(n, model.nq))
+    if model.nq == 9:
+        Q[:, 7:] = fingers
+    return Q
+
+
+def _edges(model, qidx, n, seed, eps=0.05):
+    rng = np.random.default_rng(seed)
+    lo, hi = model.jnt_range[qidx, 0], model.jnt_range[qidx, 1]
+    qa = rng.uniform(lo, hi, size=(n, len(qidx)))
+    d = rng.normal(size=(n, len(qidx)))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    qb = np.clip(qa + eps * d, lo, hi)
+    return qa, qb
+
+
+@pytest.fixture(scope="module")
+def franka_obs():
+    return scenes.franka_p(obstacles=True)
+
+
+def test_kat_two_dof_ball(oracle_mod):
+    # test/test_collision_constraint.py:16-33
+    m = scenes.two_dof_ball()
+    e = eng_mod.Engine(m)
+    v = e.check_configs(np.array([[0.0, 0.0], [0.6, 0.0]]))
+    assert v.tolist() == [1, 0]
+    orc = oracle_mod.Oracle(m)
+    rng = np.random.default_rng(0)
+    Q = rng.uniform(-2, 2, size=(4096, 2))
+    np.testing.assert_array_equal(e.check_configs(Q), orc.valid_configs(Q))
+
+
+def test_kat_interval_one_dof(oracle_mod):
+    # test/test_planning_utils.py:321-344
+    m = scenes.one_dof_ball()
+    e = eng_mod.Engine(m)
+    qa = np.array([[0.8], [0.8], [0.0]])
+    qb = np.array([[1.5], [1.5], [0.2]])
+    assert e.check_edges(qa[:1], qb[:1], 0.1, interior_only=True).tolist() == [0]
+    assert e.check_edges(qa[1:2], qb[1:2], 0.2, interior_only=True).tolist() == [1]
+    assert e.check_edges(qa[2:], qb[2:], 0.01, interior_only=True).tolist() == [1]
+    with pytest.raises(eng_mod.MjplError, match="step_dist"):
+        e.check_edges(qa, qb, 0.0)
+
+
+def test_franka_self_collision_64k(oracle_mod):
+    """BASELINE config 2: 64k uniform configs, self-collision only, verdict bit-exact + FK."""
+    m = scenes.franka_p()
+    e = eng_mod.Engine(m)
+    orc = oracle_mod.Oracle(m)
+    Q = _uniform_configs(m, 65536, seed=1)
+    got = e.check_configs(Q)
+    want = orc.valid_configs(Q, nthreads=8)
+    assert 0.05 < want.mean() < 0.95
+    np.testing.assert_array_equal(got, want)
+    # FK parity on a slice
+    fk_g = e.fk(Q[:4096])
+    fk_o = orc.fk(Q[:4096])
+    for k in ("xpos", "xquat", "geom_xpos", "geom_xmat"):
+        err = np.abs(fk_g[k] - fk_o[k]).max()
+        assert err < FK_TOL, (k, err)
+        assert err < 1e-12, (k, err)  # what the arithmetic actually delivers
+
+
+def test_franka_planning_columns_layouts(oracle_mod, franka_obs):
+    m = franka_obs
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    e = eng_mod.Engine(m)
+    e.set_planning(qidx, base)
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    Q = _uniform_configs(m, 30000, seed=3)[:, qidx]
+    want = orc.valid_configs(Q, nthreads=8)
+    np.testing.assert_array_equal(e.check_configs(Q, layout=eng_mod.AOS), want)
+    np.testing.assert_array_equal(e.check_configs(np.ascontiguousarray(Q.T), layout=eng_mod.SOA), want)
+    assert 0.05 < want.mean() < 0.95
+
+
+def test_franka_edges_vs_oracle(oracle_mod, franka_obs):
+    """BASELINE config 3 at oracle-sized E: verdict and first-bad index bit-exact."""
+    m = franka_obs
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    e = eng_mod.Engine(m)
+    e.set_planning(qidx, base)
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    qa, qb = _edges(m, qidx, 20000, seed=2)
+    want, want_fb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
+    got, got_fb = e.check_edges(qa, qb, 0.01, first_bad=True)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got_fb, want_fb)
+    assert 0.05 < want.mean() < 0.95
+    # ragged: long edges with different waypoint counts per lane
+    qa2, qb2 = _edges(m, qidx, 4096, seed=5, eps=0.4)
+    qb2[::7] = qa2[::7]  # zero-length edges
+    want2, fb2, _ = orc.valid_edges(qa2, qb2, 0.013, nthreads=8, info=True)
+    got2, gfb2 = e.check_edges(qa2, qb2, 0.013, first_bad=True)
+    np.testing.assert_array_equal(got2, want2)
+    np.testing.assert_array_equal(gfb2, fb2)
+
+
+def test_empty_and_tail(franka_obs):
+    m = franka_obs
+    e = eng_mod.Engine(m)
+    assert e.check_configs(np.zeros((0, m.nq))).shape == (0,)
+    Q = np.tile(m.keyframe("home").qpos, (257, 1))
+    assert e.check_configs(Q).tolist() == [1] * 257
+    info = e.info()
+    assert info["arch"].startswith("gfx950")
