@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: validated RRT edges/sec on the Franka 7-DoF 16-obstacle scene.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (the edge kernel: endpoint + interior waypoints of
+every edge, FK + narrowphase per waypoint) over one batch of E synthetic edges that is
+already resident in HBM.  Weak scaling: every rank owns its own E edges (independent units,
+no data-path collective).  Rank 0 prints ONE JSON line.
+
+The timed K steps are launched through mjpl_time_edges_dev, which brackets every launch
+with HIP events on the stream the kernel runs on; roofline.achieved comes from those.
+torch is imported only for N > 1 (rendezvous, barrier, max-reduce over RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "validated RRT edges/sec, Franka 7-DoF 16-geom scene, at 1/2/4/8 MI355X"
+EDGES_PER_GPU = 262144       # BASELINE.json configs[2]
+EPS, STEP = 0.05, 0.01       # rrt.py:30 epsilon; 4 interior waypoints + endpoint per edge
+BYTES_PER_EDGE = 113         # 2 x 7 x 8 B read + 1 B verdict written
+FLOPS_PER_EDGE = 80e3        # SURVEY.md 8(d) estimate, FP64
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64 (half of the 157.3 TF FP32 vector peak)
+
+
+def make_edges(model, qidx, n, seed):
+    """Seeded synthetic edges: q_a uniform in the joint ranges,
+    direction ~ normalised N(0, I), ||q_b - q_a|| = eps, clipped to the joint ranges."""
+    rng = np.random.default_rng(seed)
+    lo, hi = model.jnt_range[qidx, 0], model.jnt_range[qidx, 1]
+    qa = rng.uniform(lo, hi, size=(n, len(qidx)))
+    d = rng.normal(size=qa.shape)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    qb = np.clip(qa + EPS * d, lo, hi)
+    return qa, qb
+
+
+def cpu_baseline(model, qidx, base, qa, qb):
+    """The oracle (a port, not the reference) timed on this box's host cores on a bounded
+    sample of the same edges; reported, never the target."""
+    from oracle import pyoracle
+    orc = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
+    cores = os.cpu_count() or 1
+    pilot = min(2048, len(qa))
+    t0 = time.perf_counter()
+    orc.valid_edges(qa[:pilot], qb[:pilot], STEP, nthreads=1)
+    per_edge = (time.perf_counter() - t0) / pilot
+    # aim at ~15 core-seconds... spread over all cores, bounded by the batch
+    n = int(min(len(qa), max(pilot, 15.0 / per_edge)))
+    t0 = time.perf_counter()
+    v = orc.valid_edges(qa[:n], qb[:n], STEP, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} of the {len(qa)} edges of rank 0, oracle/libmjpl_oracle.so "
+                      f"(gcc -O2 -ffp-contract=off), {cores} pthreads; 1-thread pilot "
+                      f"{1.0 / per_edge:.0f} edges/s"}, v, n
+
+
+def traffic_from_profile(workload_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass of this same command
+    (profiles/*_traffic.json, written by tools/pmc_summary.py); None if absent."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get(workload_key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--edges", type=int, default=EDGES_PER_GPU)
+    ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    dist = torch = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mjpl_amd import engine, scenes
+
+    model = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(model, scenes.FRANKA_ARM_JOINTS)
+    base = model.keyframe("home").qpos.copy()
+    eng = engine.Engine(model, device=local_rank)
+    eng.set_planning(qidx, base)
+    info = eng.info()
+
+    E = args.edges
+    qa, qb = make_edges(model, qidx, E, seed=2 + rank)
+    layout = engine.SOA if args.layout == "soa" else engine.AOS
+    ha = np.ascontiguousarray(qa.T) if layout == engine.SOA else qa
+    hb = np.ascontiguousarray(qb.T) if layout == engine.SOA else qb
+    dqa, dqb = eng.alloc(ha.nbytes).upload(ha), eng.alloc(hb.nbytes).upload(hb)
+    dvalid = eng.alloc(E)
+    eng.sync()
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    # warmup (untimed)
+    if args.warmup > 0:
+        eng.time_edges_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    ms = eng.time_edges_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, args.steps)  # syncs
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    valid = dvalid.download(np.uint8, E)
+
+    if rank == 0:
+        total_edges = E * world * args.steps
+        value = total_edges / elapsed
+        launch_ms = float(np.mean(ms))
+        achieved = BYTES_PER_EDGE * E / (launch_ms * 1e-3) / 1e9
+        workload = (f"configs[2]: Franka-P 7-DoF + 16 box/sphere obstacles + floor, {E} edges/GPU, "
+                    f"eps {EPS}, step {STEP} (endpoint + interior waypoints per edge)")
+        out = {
+            "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": workload, "edges_per_gpu": E, "layout": args.layout,
+                       "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
+                       "parallelism": f"edge-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic_from_profile("edges_%d_%s" % (E, args.layout)),
+                         "kernel": "k_check_edges", "launch_ms": launch_ms,
+                         "algorithmic_bytes_per_edge": BYTES_PER_EDGE,
+                         "note": "FP64-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_fp64"},
+            "roofline_fp64": {"bound": "fp64_valu", "achieved": FLOPS_PER_EDGE * E / (launch_ms * 1e-3) / 1e12,
+                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": FLOPS_PER_EDGE * E / (launch_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                              "flops_per_edge_estimate": FLOPS_PER_EDGE},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, v_cpu, n = cpu_baseline(model, qidx, base, qa, qb)
+            out["cpu_baseline"] = cb
+            if not np.array_equal(v_cpu, valid[:n]):
+                sys.exit("bench.py: GPU verdicts differ from the CPU oracle on the baseline sample")
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

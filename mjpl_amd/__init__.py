@@ -1,0 +1,16 @@
+"""mjpl_amd -- MI355X-native batched RRT collision validation behind mjpl's Constraint /
+planner plug-in surface.  The compute path is ``libmjpl_hip.so``
+(mjpl_amd/csrc, C ABI in include/mjpl_hip.h); there is no CPU fallback in this package.
+"""
+from .constraint import (CollisionConstraint, CollisionRuleset, Constraint, JointLimitConstraint,
+                         apply_constraints, obeys_constraints)
+from .model import Model, ModelBuilder, load_mjcf, parse_mjcf
+from .planning import RRT, Node, Tree, path_length, smooth_path
+from .utils import all_joints, qpos_idx, qvel_idx, random_config
+
+__all__ = (
+    "CollisionConstraint", "CollisionRuleset", "Constraint", "JointLimitConstraint",
+    "apply_constraints", "obeys_constraints", "Model", "ModelBuilder", "load_mjcf", "parse_mjcf",
+    "RRT", "Node", "Tree", "path_length", "smooth_path",
+    "all_joints", "qpos_idx", "qvel_idx", "random_config",
+)

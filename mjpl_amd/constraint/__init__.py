@@ -1,0 +1,7 @@
+from .collision_constraint import CollisionConstraint, CollisionRuleset
+from .constraint_interface import Constraint
+from .joint_limit_constraint import JointLimitConstraint
+from .utils import apply_constraints, obeys_constraints
+
+__all__ = ("CollisionConstraint", "CollisionRuleset", "Constraint", "JointLimitConstraint",
+           "apply_constraints", "obeys_constraints")

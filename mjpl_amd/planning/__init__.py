@@ -1,0 +1,5 @@
+from .rrt import RRT
+from .tree import Node, Tree
+from .utils import path_length, smooth_path
+
+__all__ = ("RRT", "Node", "Tree", "path_length", "smooth_path")

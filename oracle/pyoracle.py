@@ -235,6 +235,6 @@ def step(start, target, max_step_dist) -> np.ndarray:
 def pair_test(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0) -> int:
     a = [_f64(x) for x in (pos1, np.asarray(mat1).reshape(9), size1, pos2,
                            np.asarray(mat2).reshape(9), size2)]
-    return lib().orc_pair_test(type1, _p(a[0], _F64P), _p(a[1], _F64P), _p(a[2], _F64P),
-                               type2, _p(a[3], _F64P), _p(a[4], _F64P), _p(a[5], _F64P),
+    return lib().orc_pair_test(int(type1), _p(a[0], _F64P), _p(a[1], _F64P), _p(a[2], _F64P),
+                               int(type2), _p(a[3], _F64P), _p(a[4], _F64P), _p(a[5], _F64P),
                                C.c_double(margin))

@@ -1,0 +1,107 @@
+"""The C-ABI library loads and exports every symbol include/mjpl_hip.h declares (no compute
+without a GPU), the product fails loudly without a device, and the model compiler behaves."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mjpl_amd as mjpl
+from mjpl_amd import build, engine, scenes
+from mjpl_amd.model import GEOM_CAPSULE, JNT_HINGE, JNT_SLIDE, ModelBuilder, load_mjcf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mjpl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mjpl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    build.build_hip()
+    lib = ctypes.CDLL(build.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/mjpl_hip.h but not exported"
+    assert set(names) == set(engine.ABI), "mjpl_amd.engine.ABI must bind exactly the declared entry points"
+    assert engine.load_library().mjpl_version().startswith(b"mjpl_hip")
+
+
+def test_product_has_no_cpu_fallback():
+    if engine.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(engine.MjplError, match="no HIP device"):
+        engine.Engine(scenes.two_dof_ball())
+    with pytest.raises(engine.MjplError):
+        mjpl.CollisionConstraint(scenes.two_dof_ball())
+    with pytest.raises(FileNotFoundError, match="no CPU fallback"):
+        engine.load_library("/nonexistent/libmjpl_hip.so")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mjpl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in src and "libmjpl_oracle" not in src and "mjpl_oracle.h" not in src, f
+
+
+def test_model_compile_conventions():
+    m = scenes.franka_p(obstacles=True)
+    assert (m.nq, m.njnt, m.nbody) == (9, 9, 12)
+    assert m.ngeom == 12 + 16
+    assert m.body_names[:3] == ["world", "link0", "link1"]
+    # link0 and the hand carry no joint: welded to their parents
+    assert m.body_weldid[m.body("link0").id] == 0
+    assert m.body_weldid[m.body("hand").id] == m.body("link7").id
+    # geoms are numbered by body id: every world geom (floor + obstacles) first
+    assert (m.geom_bodyid[:17] == 0).all() and m.geom_bodyid[17] == 1
+    np.testing.assert_allclose(m.body_quat[m.body("link2").id], [np.sqrt(0.5), -np.sqrt(0.5), 0, 0], atol=1e-15)
+    np.testing.assert_allclose(m.jnt_range[m.joint("joint4").id], [-3.0718, -0.0698])
+    assert m.jnt_type[m.joint("finger_joint1").id] == JNT_SLIDE and m.jnt_type[0] == JNT_HINGE
+    g = m.geom("link1_c").id  # fromto capsule -> pos / half-length / rbound
+    np.testing.assert_allclose(m.geom_pos[g], [0, 0, -0.075], atol=1e-15)
+    np.testing.assert_allclose(m.geom_size[g][:2], [0.055, 0.055], atol=1e-15)
+    np.testing.assert_allclose(m.geom_rbound[g], 0.11, atol=1e-15)
+    assert m.geom_type[g] == GEOM_CAPSULE
+    np.testing.assert_allclose(m.keyframe("home").qpos[:7], [0, 0, 0, -1.57079, 0, 1.57079, -0.7853])
+    with pytest.raises(KeyError):
+        m.body("no_such_body")
+
+
+def test_mjcf_reader_features(tmp_path):
+    (tmp_path / "inc.xml").write_text('<mujoco><worldbody><geom name="floor" type="plane" size="1 1 .1"/></worldbody></mujoco>')
+    xml = tmp_path / "m.xml"
+    xml.write_text("""
+    <mujoco>
+      <include file="inc.xml"/>
+      <default><geom type="capsule" size="0.05 0.1"/><default class="s"><joint type="slide" axis="1 0 0" range="-1 1"/></default></default>
+      <worldbody>
+        <body name="a" pos="0 0 1" euler="0 0 90">
+          <joint name="h" range="-90 90"/>
+          <geom name="vis" type="mesh" contype="0" conaffinity="0"/>
+          <geom name="ca"/>
+          <body name="b" childclass="s" pos="0.5 0 0">
+            <joint name="sl"/>
+            <geom name="cb" type="sphere" size="0.02"/>
+          </body>
+        </body>
+      </worldbody>
+    </mujoco>""")
+    m = load_mjcf(str(xml))
+    assert m.geom_names == ["floor", "ca", "cb"]          # non-colliding mesh dropped
+    assert m.jnt_type.tolist() == [JNT_HINGE, JNT_SLIDE]
+    np.testing.assert_allclose(m.jnt_range[0], [-np.pi / 2, np.pi / 2])   # degrees by default
+    np.testing.assert_allclose(m.jnt_range[1], [-1, 1])
+    np.testing.assert_allclose(m.body_quat[1], [np.sqrt(0.5), 0, 0, np.sqrt(0.5)], atol=1e-15)
+    with pytest.raises(ValueError, match="primitive path"):
+        load_mjcf('<mujoco><worldbody><body><geom type="mesh"/></body></worldbody></mujoco>')
+    with pytest.raises(ValueError, match="1-DoF"):
+        mb = ModelBuilder()
+        mb.add_body("x")
+        mb.add_joint("x", "j", "ball")

@@ -1,0 +1,291 @@
+"""Host-side planner logic on CPU, driven by the oracle-backed test constraint.  The cases
+follow the reference's own tests (cited per test) so that a maintainer can read them side by
+side; expected values come from tests/golden/kat_reference.json where the reference pins one."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import mjpl_amd as mjpl
+from mjpl_amd import scenes
+from mjpl_amd.planning.tree import Node, Tree
+from mjpl_amd.planning.utils import (_combine_paths, _constrained_extend, _step,
+                                     _valid_collision_interval)
+from helpers import OracleCollisionConstraint
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_reference.json")))
+
+
+def _num(x):
+    return float("inf") if x == "inf" else x
+
+
+@pytest.fixture()
+def one_dof(oracle_mod):
+    m = scenes.one_dof_ball()
+    cc = OracleCollisionConstraint(m, pyoracle=oracle_mod)
+    return m, [mjpl.JointLimitConstraint(m), cc], cc
+
+
+@pytest.fixture()
+def two_dof(oracle_mod):
+    m = scenes.two_dof_ball()
+    cc = OracleCollisionConstraint(m, pyoracle=oracle_mod)
+    return m, [mjpl.JointLimitConstraint(m), cc], cc
+
+
+# ---- tree (test/test_tree.py)
+def test_node_identity():
+    a, b = Node(np.array([0.0, 1.0])), Node(np.array([0.0, 1.0]), Node(np.array([5.0, 5.0])))
+    c = Node(np.array([1.0, 1.0]))
+    assert a == b and a != c and a != 5 and hash(a) == hash(b)
+    with pytest.raises(AttributeError):
+        a.q = np.zeros(2)
+
+
+def test_tree_rules_and_queries():
+    root = Node(np.array([0.0, 0.0]))
+    n1 = Node(np.array([1.0, 0.0]), root)
+    n2 = Node(np.array([0.0, 1.0]), root)
+    n3 = Node(np.array([2.0, 0.5]), n1)
+    with pytest.raises(ValueError, match="root node should have no parent"):
+        Tree(n1)
+    tree = Tree(root)
+    for n in (n1, n2, n3):
+        tree.add_node(n)
+    assert len(tree.nodes) == 4 and root in tree and n3 in tree
+    with pytest.raises(ValueError, match="already exists in the tree"):
+        tree.add_node(Node(n1.q.copy(), root))
+    with pytest.raises(ValueError, match="Node does not have a parent"):
+        tree.add_node(Node(np.array([9.0, 9.0])))
+    with pytest.raises(ValueError, match="parent is not in the tree"):
+        tree.add_node(Node(np.array([3.0, 3.0]), Node(np.array([7.0, 7.0]))))
+    assert tree.nearest_neighbor(np.array([2.1, 0.4])) == n3
+    assert tree.nearest_neighbor(np.array([1.0, 1.0])) in {n1, n2}
+    assert tree.nearest_neighbor(n2.q) == n2
+    assert tree.get_path(n3) == [n3, n1, root] and tree.get_path(root) == [root]
+    with pytest.raises(ValueError, match="Node is not in the tree"):
+        tree.get_path(Node(np.array([4.0, 4.0]), root))
+    # a +inf sink is never the nearest neighbour (rrt.py:180-184)
+    sink = Node(np.full(2, np.inf))
+    t2 = Tree(sink)
+    g = Node(np.array([1.0, 1.0]), sink)
+    t2.add_node(g)
+    assert t2.nearest_neighbor(np.zeros(2)) == g
+    for k in range(200):  # growth of the backing matrix
+        t2.add_node(Node(np.array([float(k), -1.0]), g))
+    assert t2.nearest_neighbor(np.array([150.2, -1.0])).q.tolist() == [150.0, -1.0]
+
+
+# ---- _step / interval (test/test_planning_utils.py:304-344)
+@pytest.mark.parametrize("case", KAT["step"], ids=lambda c: str(c["max_step"]))
+def test_step(case):
+    got = _step(np.array(case["start"]), np.array(case["target"]), _num(case["max_step"]))
+    np.testing.assert_allclose(got, case["expect"], rtol=0, atol=case["atol"])
+    for bad in (0.0, -1.0):
+        with pytest.raises(ValueError, match="`max_step_dist` must be > 0.0"):
+            _step(np.array(case["start"]), np.array(case["target"]), bad)
+
+
+@pytest.mark.parametrize("case", KAT["valid_collision_interval"], ids=lambda c: f"{c['start']}@{c['step']}")
+def test_valid_collision_interval(one_dof, case):
+    _, _, cc = one_dof
+    assert _valid_collision_interval(np.array(case["start"]), np.array(case["end"]), case["step"], cc) is case["valid"]
+
+    class Plain:  # a constraint without the batched hook takes the host walk
+        def valid_config(self, q):
+            return cc.valid_config(q)
+
+    assert _valid_collision_interval(np.array(case["start"]), np.array(case["end"]), case["step"], Plain()) is case["valid"]
+    with pytest.raises(ValueError, match="step_dist"):
+        _valid_collision_interval(np.array(case["start"]), np.array(case["end"]), 0.0, cc)
+
+
+# ---- _constrained_extend (test/test_planning_utils.py:207-302)
+@pytest.mark.parametrize("case", KAT["constrained_extend"], ids=lambda c: c["source"][-7:] + str(c.get("interval_step", "")))
+def test_constrained_extend(one_dof, case):
+    _, constraints, cc = one_dof
+    tree = Tree(Node(np.array(case["q_init"])))
+    ivl = (case["interval_step"], cc) if "interval_step" in case else None
+    reached = _constrained_extend(np.array(case["q_goal"]), tree, _num(case["eps"]), constraints, ivl)
+    if "reached" in case:
+        np.testing.assert_equal(reached, np.array(case["reached"]))
+    else:
+        assert case["reached_gt"] < reached[0] < case["reached_lt"] < case["q_goal"][0]
+    if "path_from_goal" in case:
+        path = [n.q for n in tree.get_path(tree.nearest_neighbor(np.array(case["q_goal"])))]
+        assert len(path) == len(case["path_from_goal"])
+        for got, want in zip(path, case["path_from_goal"]):
+            np.testing.assert_allclose(got, want, rtol=0, atol=case["atol"])
+
+
+def test_constrained_extend_towards_existing_config(one_dof):
+    _, constraints, _ = one_dof
+    root = Node(np.array([0.0]))
+    tree = Tree(root)
+    np.testing.assert_equal(_constrained_extend(root.q, tree, 0.1, constraints), root.q)
+    assert tree.nodes == {root}
+
+
+def test_combine_paths():
+    # test/test_planning_utils.py:346-382
+    r1 = Node(np.array([0.0]))
+    a = Node(np.array([1.0]), r1)
+    t1 = Tree(r1)
+    t1.add_node(a)
+    r2 = Node(np.array([5.0]))
+    b = Node(np.array([4.0]), r2)
+    c = Node(np.array([3.0]), b)
+    t2 = Tree(r2)
+    t2.add_node(b)
+    t2.add_node(c)
+    assert [q.tolist() for q in _combine_paths(t1, a, t2, c)] == [[0.0], [1.0], [3.0], [4.0], [5.0]]
+    dup = Node(np.array([1.0]), b)  # junction shared by both trees appears once
+    t2.add_node(dup)
+    assert [q.tolist() for q in _combine_paths(t1, a, t2, dup)] == [[0.0], [1.0], [4.0], [5.0]]
+
+
+# ---- RRT (test/test_rrt.py:16-179)
+def _check_plan(waypoints, q_init, q_goal, eps, constraints):
+    assert len(waypoints) > 2
+    np.testing.assert_equal(waypoints[0], q_init)
+    np.testing.assert_equal(waypoints[-1], q_goal)
+    for a, b in zip(waypoints[:-1], waypoints[1:]):
+        assert np.linalg.norm(b - a) <= eps + 1e-15
+    assert all(mjpl.obeys_constraints(w, constraints) for w in waypoints)
+
+
+def test_rrt_one_dof(one_dof):
+    m, constraints, _ = one_dof
+    q_init, q_goal = np.array([-0.2]), np.array([0.35])
+    planner = mjpl.RRT(m, mjpl.all_joints(m), constraints, max_planning_time=5.0, epsilon=0.1, seed=42)
+    _check_plan(planner.plan_to_config(q_init, q_goal), q_init, q_goal, 0.1, constraints)
+    # same seed, same plan (success paths are deterministic)
+    again = mjpl.RRT(m, mjpl.all_joints(m), constraints, max_planning_time=5.0, epsilon=0.1, seed=42)
+    a, b = planner.plan_to_config(q_init, q_goal), again.plan_to_config(q_init, q_goal)
+    assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_rrt_subset_joints_and_trivial(two_dof):
+    m, constraints, _ = two_dof
+    q_init, q_goal = np.array([0.0, 0.0]), np.array([0.3, 0.0])
+    planner = mjpl.RRT(m, ["ball_slide_x"], constraints, max_planning_time=5.0, epsilon=0.1, seed=42)
+    wps = planner.plan_to_config(q_init, q_goal)
+    _check_plan(wps, q_init, q_goal, 0.1, constraints)
+    assert all(w[1] == 0.0 for w in wps)  # the non-planning joint never moves
+    triv = planner.plan_to_config(q_init, np.array([0.05, 0.0]))
+    assert len(triv) == 2 and np.array_equal(triv[0], q_init) and np.array_equal(triv[1], [0.05, 0.0])
+
+
+def test_rrt_argument_validation(two_dof):
+    m, constraints, _ = two_dof
+    joints = mjpl.all_joints(m)
+    with pytest.raises(ValueError, match="planning_joints"):
+        mjpl.RRT(m, [], constraints)
+    with pytest.raises(ValueError, match="max_planning_time"):
+        mjpl.RRT(m, joints, constraints, max_planning_time=0.0)
+    with pytest.raises(ValueError, match="epsilon"):
+        mjpl.RRT(m, joints, constraints, epsilon=-1.0)
+    with pytest.raises(ValueError, match="goal_biasing_probability"):
+        mjpl.RRT(m, joints, constraints, goal_biasing_probability=1.5)
+    planner = mjpl.RRT(m, ["ball_slide_x"], constraints, max_planning_time=1.0)
+    with pytest.raises(ValueError, match="q_init is not a valid configuration"):
+        planner.plan_to_config(np.array([0.6, 0.0]), np.array([0.0, 0.0]))
+    with pytest.raises(ValueError, match="goal config is not a valid configuration"):
+        planner.plan_to_config(np.array([0.0, 0.0]), np.array([0.6, 0.0]))
+    with pytest.raises(ValueError, match="outside of the planner's planning joints"):
+        planner.plan_to_config(np.array([0.0, 0.0]), np.array([0.2, 0.3]))
+    with pytest.raises(NotImplementedError):
+        planner.plan_to_pose(np.array([0.0, 0.0]), None, "ball_site")
+
+
+# ---- utils (test/test_utils.py, test/test_joint_limit_constraint.py)
+def test_joint_helpers_and_random_config(two_dof):
+    m, constraints, _ = two_dof
+    assert mjpl.all_joints(m) == ["ball_slide_x", "ball_slide_y"]
+    assert mjpl.qpos_idx(m, mjpl.all_joints(m)) == [0, 1] and mjpl.qvel_idx(m, ["ball_slide_y"]) == [1]
+    jl = mjpl.JointLimitConstraint(m)
+    assert jl.valid_config(np.array([0.0, 0.0])) and not jl.valid_config(np.array([2.5, 0.0]))
+    assert jl.apply(None, np.array([2.5, 0.0])) is None
+    q_init = np.array([0.0, 0.1])
+    a = mjpl.random_config(m, q_init, ["ball_slide_x"], seed=5, constraints=constraints)
+    b = mjpl.random_config(m, q_init, ["ball_slide_x"], seed=5, constraints=constraints)
+    np.testing.assert_equal(a, b)
+    assert a[1] == 0.1 and mjpl.obeys_constraints(a, constraints)
+    # same PCG64 consumption as the reference: njnt uniforms per attempt, indexed by qpos index
+    rng = np.random.default_rng(5)
+    while True:
+        draw = rng.uniform(*m.jnt_range.T)
+        cand = np.array([draw[0], 0.1])
+        if mjpl.obeys_constraints(cand, constraints):
+            break
+    np.testing.assert_equal(a, cand)
+
+
+def test_apply_constraints_order_and_revalidation():
+    class Shift(mjpl.Constraint):  # a projection that breaks the limit constraint placed before it
+        def valid_config(self, q):
+            return True
+
+        def apply(self, q_old, q):
+            return q + 10.0
+
+    class Limit(mjpl.Constraint):
+        def valid_config(self, q):
+            return bool(np.all(np.abs(q) < 5))
+
+        def apply(self, q_old, q):
+            return q if self.valid_config(q) else None
+
+    q = np.array([1.0])
+    assert mjpl.apply_constraints(q, q, [Limit(), Shift()]) is None      # re-validation catches it
+    assert mjpl.apply_constraints(q, q, [Shift(), Limit()]) is None      # rejected in order
+    out = mjpl.apply_constraints(q, q, [Limit()])
+    assert out is q                                                        # same object on success
+    assert mjpl.obeys_constraints(q, []) is True
+
+
+# ---- smooth_path (test/test_planning_utils.py:72-203)
+def test_smooth_path(two_dof):
+    m, constraints, cc = two_dof
+    # a detour around nothing: dense and sparse shortcutting both shorten it and stay valid
+    wps = [np.array([-1.0, -1.0]), np.array([-1.0, 1.0]), np.array([0.2, 1.2]), np.array([0.3, -0.2]),
+           np.array([0.35, -1.0])]
+    before = mjpl.path_length(wps)
+    for sparse in (False, True):
+        out = mjpl.smooth_path(wps, constraints, eps=0.1, num_tries=60, seed=3, sparse=sparse)
+        np.testing.assert_equal(out[0], wps[0])
+        np.testing.assert_equal(out[-1], wps[-1])
+        assert mjpl.path_length(out) < before
+        assert all(mjpl.obeys_constraints(w, constraints) for w in out)
+        if sparse:
+            assert all(any(np.array_equal(w, o) for o in wps) for w in out)
+        else:
+            assert all(np.linalg.norm(b - a) <= 0.1 + 1e-12 or any(np.array_equal(b, o) for o in wps)
+                       for a, b in zip(out[:-1], out[1:]))
+    with pytest.raises(ValueError, match="waypoints"):
+        mjpl.smooth_path([], [])
+    with pytest.raises(ValueError, match="eps"):
+        mjpl.smooth_path(wps, [], eps=0.0)
+    with pytest.raises(ValueError, match="num_tries"):
+        mjpl.smooth_path(wps, [], num_tries=0)
+    assert mjpl.path_length([np.zeros(3), np.array([1.0, 0, 0]), np.array([1.0, 1, 0]), np.ones(3)]) == pytest.approx(3.0)
+
+
+# ---- BASELINE config 1: UR5e plan-to-config bi-RRT on CPU (examples/ur5_move_to_config.py:24-53)
+def test_ur5e_plan_to_config_cpu(oracle_mod):
+    m = scenes.ur5e()
+    joints = mjpl.all_joints(m)
+    cc = OracleCollisionConstraint(m, pyoracle=oracle_mod)
+    constraints = [mjpl.JointLimitConstraint(m), cc]
+    q_init = m.keyframe("home").qpos.copy()
+    assert mjpl.obeys_constraints(q_init, constraints)
+    q_goal = mjpl.random_config(m, q_init, joints, 3, constraints)
+    planner = mjpl.RRT(m, joints, constraints, seed=3, goal_biasing_probability=0.1, max_planning_time=30.0)
+    wps = planner.plan_to_config(q_init, q_goal)
+    assert wps, "planning failed"
+    _check_plan(wps, q_init, q_goal, planner.epsilon, constraints)
+    assert len(wps) <= 1000
+    short = mjpl.smooth_path(wps, constraints, eps=planner.epsilon, seed=3, sparse=True)
+    assert mjpl.path_length(short) <= mjpl.path_length(wps)

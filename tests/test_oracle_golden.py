@@ -1,0 +1,109 @@
+"""The oracle against (1) the reference tests' own known answers and (2) independent
+closed-form FK fixtures.  CPU only.  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mjpl_amd import scenes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def _num(x):
+    return float("inf") if x == "inf" else x
+
+
+KAT = _load("kat_reference.json")
+SCENES = {"one_dof_ball": scenes.one_dof_ball, "two_dof_ball": scenes.two_dof_ball}
+
+
+@pytest.mark.parametrize("case", KAT["valid_config"], ids=lambda c: str(c["q"]))
+def test_kat_valid_config(oracle_mod, case):
+    orc = oracle_mod.Oracle(SCENES[case["scene"]]())
+    assert orc.valid_config(case["q"]) is case["valid"]
+
+
+@pytest.mark.parametrize("case", KAT["valid_collision_interval"], ids=lambda c: f"{c['start']}-{c['end']}@{c['step']}")
+def test_kat_interval(oracle_mod, case):
+    orc = oracle_mod.Oracle(SCENES[case["scene"]]())
+    assert orc.valid_collision_interval(case["start"], case["end"], case["step"]) is case["valid"]
+
+
+def test_kat_interval_bad_step(oracle_mod):
+    orc = oracle_mod.Oracle(scenes.one_dof_ball())
+    for bad in (0.0, -1.0):
+        with pytest.raises(ValueError, match="step_dist"):
+            orc.valid_collision_interval([0.0], [0.2], bad)
+
+
+@pytest.mark.parametrize("case", KAT["step"], ids=lambda c: str(c["max_step"]))
+def test_kat_step(oracle_mod, case):
+    got = oracle_mod.step(case["start"], case["target"], _num(case["max_step"]))
+    np.testing.assert_allclose(got, case["expect"], rtol=0, atol=case["atol"])
+    with pytest.raises(ValueError, match="`max_step_dist` must be > 0.0"):
+        oracle_mod.step(case["start"], case["target"], 0.0)
+
+
+def test_kat_ruleset(oracle_mod):
+    """CollisionRuleset truth table on the oracle's C restatement AND the host class."""
+    from mjpl_amd.constraint import CollisionRuleset
+    from mjpl_amd.model import ModelBuilder
+    table = KAT["ruleset"]
+    mb = ModelBuilder()
+    mb.add_geom("world", "plane", (1, 1, 0.1))
+    parent = "world"
+    for b, ngeom in enumerate((2, 1, 2, 1, 1), start=1):  # chain b1..b5, some with two geoms
+        mb.add_body(f"b{b}", parent, pos=(0, 0, 0.3))
+        mb.add_joint(f"b{b}", f"j{b}", "hinge", axis=(0, 1, 0), range=(-1, 1))
+        for _ in range(ngeom):
+            mb.add_geom(f"b{b}", "sphere", (0.05,))
+        parent = f"b{b}"
+    model = mb.compile()
+    assert model.geom_bodyid.tolist() == table["geom_bodyid"]
+    for case in table["cases"]:
+        names = [(model.body(a).name, model.body(b).name) for a, b in case["allowed"]]
+        orc = oracle_mod.Oracle(model, names)
+        contacts = np.asarray(case["contacts"], dtype=np.int32).reshape(-1, 2)
+        assert orc.obeys_ruleset(contacts) is case["obeys"], case
+        assert CollisionRuleset(model, names).obeys_ruleset(contacts) is case["obeys"], case
+    for bad in (np.zeros((3,)), np.zeros((2, 3)), np.zeros((2, 2, 2))):
+        with pytest.raises(ValueError, match="nx2"):
+            oracle_mod.Oracle(model).obeys_ruleset(bad)
+        with pytest.raises(ValueError, match="nx2"):
+            CollisionRuleset(model).obeys_ruleset(bad)
+
+
+@pytest.mark.parametrize("name,factory", [("franka_p", lambda: scenes.franka_p(obstacles=True)),
+                                          ("ur5e_c", scenes.ur5e), ("two_dof_ball", scenes.two_dof_ball)])
+def test_fk_against_independent_fixture(oracle_mod, name, factory):
+    model = factory()
+    orc = oracle_mod.Oracle(model)
+    for case in _load(f"fk_{name}.json")["cases"]:
+        k = orc.kinematics(case["qpos"])
+        for key in ("xpos", "xmat", "geom_xpos", "geom_xmat"):
+            np.testing.assert_allclose(k[key], np.asarray(case[key]), rtol=0, atol=1e-12, err_msg=key)
+
+
+def test_franka_home_is_valid_and_floor_contact_detected(oracle_mod):
+    model = scenes.franka_p(obstacles=True)
+    orc = oracle_mod.Oracle(model)
+    home = model.keyframe("home").qpos
+    assert orc.valid_config(home)
+    assert len(orc.contacts(home)) == 0
+    q = home.copy()
+    q[1], q[3] = 1.7, -0.1  # arm swung down and stretched: the hand goes through the floor
+    con = orc.contacts(q)
+    floor = model.geom("floor").id
+    assert any(floor in pair for pair in con.tolist())
+    assert not orc.valid_config(q)
+    # allowed pairs only silence the named bodies (a6): fingers touching each other
+    q2 = home.copy()
+    q2[7:] = 0.0
+    assert orc.valid_config(q2)  # 3 mm gap when closed
