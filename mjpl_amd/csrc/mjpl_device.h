@@ -70,7 +70,8 @@ enum : int { GF_SAMEPOS = 1, GF_SAMEROT = 2 };
 // geom dp: lpos[3] lquat[4] size[3]
 
 // partner entry: one packed int + one dp offset
-//   bits 0..11  index (register slot, or row of the world table) ; bits 12..15 partner type
+//   bits 0..11  row of the world table, or register slots first | (second << 6) ;
+//   bits 12..15 partner type
 //   bit 16      stored (earlier moving geom) else world (static geom)
 //   bit 17      partner is the FIRST geom of the pair in mj_collision's (g1,g2) order
 enum : int { P_STORED = 1 << 16, P_FIRST = 1 << 17 };
@@ -472,17 +473,20 @@ struct SlotFile {
 #define MJPL_SLOT_PUT(n)                                                          \
   if constexpr (MAXS > n) {                                                       \
     if (slot_ == n) {                                                             \
-      sf.v[n][0] = cur.pos[0]; sf.v[n][1] = cur.pos[1]; sf.v[n][2] = cur.pos[2];  \
-      sf.v[n][3] = cur.m[2];   sf.v[n][4] = cur.m[5];   sf.v[n][5] = cur.m[8];    \
+      sf.v[n][0] = t6[0]; sf.v[n][1] = t6[1]; sf.v[n][2] = t6[2];                 \
+      sf.v[n][3] = t6[3]; sf.v[n][4] = t6[4]; sf.v[n][5] = t6[5];                 \
     }                                                                             \
   }
 #define MJPL_SLOT_GET(n)                                                          \
   if constexpr (MAXS > n) {                                                       \
     if (slot_ == n) {                                                             \
-      par.pos[0] = sf.v[n][0]; par.pos[1] = sf.v[n][1]; par.pos[2] = sf.v[n][2];  \
-      par.m[2] = sf.v[n][3];   par.m[5] = sf.v[n][4];   par.m[8] = sf.v[n][5];    \
+      t6[0] = sf.v[n][0]; t6[1] = sf.v[n][1]; t6[2] = sf.v[n][2];                 \
+      t6[3] = sf.v[n][3]; t6[4] = sf.v[n][4]; t6[5] = sf.v[n][5];                 \
     }                                                                             \
   }
+// A sphere/capsule occupies one slot (pos, z axis); a box a second one (x and y axes).
+// Slot ids are packed as  first | (second << 6), second == SLOT_NONE when unused.
+enum : int { SLOT_NONE = 63 };
 
 // control words are wave-uniform: pin them to SGPRs so the interpreter's branches are scalar
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -655,9 +659,11 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
         // bounding cull (mj_collideSphere): squared centre distance, or signed plane distance
         Geom par;
         if (stored) {
-          const int slot_ = pw & 4095;
-          par.pos[0] = par.pos[1] = par.pos[2] = 0; par.m[2] = par.m[5] = par.m[8] = 0;
+          double t6[6] = {0, 0, 0, 0, 0, 0};
+          const int slot_ = pw & 63;
           MJPL_FOR_SLOTS(MJPL_SLOT_GET)
+          par.pos[0] = t6[0]; par.pos[1] = t6[1]; par.pos[2] = t6[2];
+          par.m[2] = t6[3]; par.m[5] = t6[4]; par.m[8] = t6[5];
         } else {
           par.pos[0] = wd[W_POS]; par.pos[1] = wd[W_POS + 1]; par.pos[2] = wd[W_POS + 2];
           par.m[2] = wd[W_MAT + 2]; par.m[5] = wd[W_MAT + 5]; par.m[8] = wd[W_MAT + 8];
@@ -672,7 +678,13 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
         double psize[3];
         if (stored) {
           psize[0] = pd[PD_SIZE]; psize[1] = pd[PD_SIZE + 1]; psize[2] = pd[PD_SIZE + 2];
-          par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;  // sphere/capsule
+          double t6[6] = {0, 0, 0, 0, 0, 0};
+          if (BOXLVL > 0 && ((pw >> 6) & 63) != SLOT_NONE) {  // stored box: x and y axes
+            const int slot_ = (pw >> 6) & 63;
+            MJPL_FOR_SLOTS(MJPL_SLOT_GET)
+          }
+          par.m[0] = t6[0]; par.m[3] = t6[1]; par.m[6] = t6[2];
+          par.m[1] = t6[3]; par.m[4] = t6[4]; par.m[7] = t6[5];
         } else {
           psize[0] = wd[W_SIZE]; psize[1] = wd[W_SIZE + 1]; psize[2] = wd[W_SIZE + 2];
           par.m[0] = wd[W_MAT + 0]; par.m[1] = wd[W_MAT + 1]; par.m[3] = wd[W_MAT + 3];
@@ -683,8 +695,16 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
       }
 
       if (!EMIT && store >= 0) {
-        const int slot_ = store;
-        MJPL_FOR_SLOTS(MJPL_SLOT_PUT)
+        {
+          const double t6[6] = {cur.pos[0], cur.pos[1], cur.pos[2], cur.m[2], cur.m[5], cur.m[8]};
+          const int slot_ = store & 63;
+          MJPL_FOR_SLOTS(MJPL_SLOT_PUT)
+        }
+        if (BOXLVL > 0 && ((store >> 6) & 63) != SLOT_NONE) {
+          const double t6[6] = {cur.m[0], cur.m[3], cur.m[6], cur.m[1], cur.m[4], cur.m[7]};
+          const int slot_ = (store >> 6) & 63;
+          MJPL_FOR_SLOTS(MJPL_SLOT_PUT)
+        }
       }
     }
   }

@@ -436,10 +436,6 @@ int compile_program(mjpl_engine *e) {
     for (int k2 = 0; k2 < k; k2++) {
       const int h = mgeoms[k2];
       if (!pair_enabled(e, std::min(g, h), std::max(g, h))) continue;
-      if (m.geom_type[h] == GT_BOX)
-        return fail(MJPL_E_PAIRTYPE,
-                    "moving box geom %d must be kept for a later moving geom %d: box slots are not "
-                    "implemented in this build", h, g);
       stored_partners[k].push_back(k2);
       note_pair(g, h);
       last_user[k2] = k;
@@ -447,17 +443,22 @@ int compile_program(mjpl_engine *e) {
     }
     if (m.geom_type[g] == GT_PLANE) return fail(MJPL_E_PAIRTYPE, "plane geom %d on a moving body", g);
   }
+  // register slots: one per kept sphere/capsule, two per kept box; a slot is reusable once the
+  // last geom that needs its occupant has been processed (a geom is stored after its own tests)
   std::vector<int> slot_of(nm, -1);
   {
-    std::vector<int> free_at;  // slot -> index of the geom after which it is free (-1: free)
+    std::vector<int> free_at;  // slot -> index of the last geom that reads it
+    auto take = [&](int k) {
+      for (size_t t = 0; t < free_at.size(); t++)
+        if (free_at[t] <= k) { free_at[t] = last_user[k]; return (int)t; }
+      free_at.push_back(last_user[k]);
+      return (int)free_at.size() - 1;
+    };
     for (int k = 0; k < nm; k++) {
       if (last_user[k] < 0) continue;
-      int s = -1;
-      for (size_t t = 0; t < free_at.size(); t++)
-        if (free_at[t] <= k) { s = (int)t; break; }  // last user is done (a geom is stored after its own tests)
-      if (s < 0) { s = (int)free_at.size(); free_at.push_back(-1); }
-      free_at[s] = last_user[k];
-      slot_of[k] = s;
+      const int s1 = take(k);
+      const int s2 = (m.geom_type[mgeoms[k]] == GT_BOX) ? take(k) : (int)SLOT_NONE;
+      slot_of[k] = s1 | (s2 << 6);
     }
     e->nslots = (int)free_at.size();
   }

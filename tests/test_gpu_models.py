@@ -1,0 +1,160 @@
+"""GPU parity over randomly generated models: every joint/geom/pair type the engine accepts,
+branching trees, off-centre hinges, margins, contype/conaffinity masks and allowed body pairs,
+each checked bit-exact (verdicts) / 1e-6 (FK) against the CPU oracle through the C ABI."""
+import numpy as np
+import pytest
+
+import mjpl_amd as mjpl
+from mjpl_amd import engine as eng_mod
+from mjpl_amd import scenes
+from mjpl_amd.model import ModelBuilder
+from helpers import OracleCollisionConstraint, random_edges, uniform_configs
+
+pytestmark = pytest.mark.gpu
+
+
+def random_model(seed):
+    rng = np.random.default_rng(seed)
+    mb = ModelBuilder()
+    if rng.random() < 0.8:
+        mb.add_geom("world", "plane", (1, 1, 0.1), pos=(0, 0, -0.4))
+
+    def rq():
+        q = rng.normal(size=4)
+        return q / np.linalg.norm(q)
+
+    def add_geoms(body, n, allow_box):
+        for _ in range(n):
+            kind = rng.choice(["sphere", "capsule", "box"] if allow_box else ["sphere", "capsule"])
+            size = {"sphere": (rng.uniform(0.03, 0.12),), "capsule": (rng.uniform(0.03, 0.08), rng.uniform(0.02, 0.2)),
+                    "box": tuple(rng.uniform(0.03, 0.15, 3))}[kind]
+            pos = rng.uniform(-0.15, 0.15, 3) if rng.random() < 0.7 else (0, 0, 0)
+            quat = rq() if rng.random() < 0.7 else (1, 0, 0, 0)
+            mb.add_geom(body, kind, size, pos=pos, quat=quat, contype=int(rng.choice([1, 1, 1, 2, 3])),
+                        conaffinity=int(rng.choice([1, 1, 1, 2, 3])), margin=float(rng.choice([0, 0, 0, 0.01, 0.03])))
+
+    add_geoms("world", int(rng.integers(2, 7)), allow_box=True)
+    for g in mb.world.geoms[1:]:
+        g["pos"] = rng.uniform(-0.7, 0.7, 3)
+    nstatic = int(rng.integers(0, 2))
+    nbody = int(rng.integers(3, 9))
+    names = ["world"]
+    for b in range(nbody):
+        parent = names[int(rng.integers(max(0, len(names) - 3), len(names)))]
+        name = f"b{b}"
+        mb.add_body(name, parent, pos=rng.uniform(-0.25, 0.25, 3), quat=rq() if rng.random() < 0.8 else (1, 0, 0, 0))
+        static = b < nstatic and parent == "world"
+        if not static:
+            for j in range(int(rng.choice([1, 1, 1, 2]))):
+                jt = "hinge" if rng.random() < 0.75 else "slide"
+                axis = rng.normal(size=3) if rng.random() < 0.6 else np.eye(3)[rng.integers(0, 3)]
+                pos = rng.uniform(-0.1, 0.1, 3) if rng.random() < 0.4 else (0, 0, 0)
+                rngj = (-2.5, 2.5) if jt == "hinge" else (-0.3, 0.3)
+                mb.add_joint(name, f"j{b}_{j}", jt, axis=axis, pos=pos, range=rngj, ref=float(rng.choice([0, 0, 0.2])))
+        add_geoms(name, int(rng.integers(1, 3)), allow_box=True)
+        names.append(name)
+    model = mb.compile()
+    nallowed = int(rng.integers(0, 3))
+    allowed = [(model.body_names[int(rng.integers(0, model.nbody))], model.body_names[int(rng.integers(0, model.nbody))])
+               for _ in range(nallowed)]
+    return model, allowed
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_models_match_oracle(oracle_mod, seed):
+    model, allowed = random_model(seed)
+    e = eng_mod.Engine(model, allowed)
+    orc = oracle_mod.Oracle(model, allowed)
+    Q = uniform_configs(model, 4096, seed=100 + seed)
+    Q[::97] = model.qpos0  # exact reference pose: the angle == 0 shortcut of mju_axisAngle2Quat
+    want = orc.valid_configs(Q, nthreads=8)
+    np.testing.assert_array_equal(e.check_configs(Q), want)
+    np.testing.assert_array_equal(e.check_configs(np.ascontiguousarray(Q.T), layout=eng_mod.SOA), want)
+    fk_g, fk_o = e.fk(Q[:512]), orc.fk(Q[:512])
+    for k in fk_g:
+        assert np.abs(fk_g[k] - fk_o[k]).max() < 1e-6, k
+        assert np.abs(fk_g[k] - fk_o[k]).max() < 1e-12, k
+    qa, qb = random_edges(model, np.arange(model.nq), 1024, seed=200 + seed, eps=0.2)
+    w, wfb, _ = orc.valid_edges(qa, qb, 0.03, nthreads=8, info=True)
+    g, gfb = e.check_edges(qa, qb, 0.03, first_bad=True)
+    np.testing.assert_array_equal(g, w)
+    np.testing.assert_array_equal(gfb, wfb)
+    gi = e.check_edges(qa, qb, 0.03, interior_only=True)
+    wi = np.array([orc.valid_collision_interval(a, b, 0.03) for a, b in zip(qa[:128], qb[:128])])
+    np.testing.assert_array_equal(gi[:128].astype(bool), wi)
+
+
+def test_unsupported_models_fail_loudly():
+    mb = ModelBuilder()
+    mb.add_body("a")
+    mb.add_joint("a", "ja")
+    mb.add_geom("a", "cylinder", (0.1, 0.1))
+    mb.add_geom("world", "sphere", (0.1,), pos=(1, 0, 0))
+    with pytest.raises(eng_mod.MjplError, match="unsupported type"):
+        eng_mod.Engine(mb.compile())
+
+
+def test_bits_output_matches_bytes():
+    m = scenes.franka_p(obstacles=True)
+    e = eng_mod.Engine(m)
+    Q = uniform_configs(m, 10007, seed=9)
+    want = e.check_configs(Q)
+    dq = e.alloc(Q.nbytes).upload(Q)
+    nwords = (len(Q) + 63) // 64
+    dbits = e.alloc(8 * nwords)
+    e.check_configs_bits_dev(dq.ptr, len(Q), eng_mod.AOS, dbits.ptr)
+    words = dbits.download(np.uint64, nwords)
+    bits = ((words[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).reshape(-1)[: len(Q)]
+    np.testing.assert_array_equal(bits.astype(np.uint8), want)
+
+
+def test_nearest_neighbour_kernel():
+    m = scenes.franka_p()
+    e = eng_mod.Engine(m)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    e.set_planning(qidx, m.keyframe("home").qpos)
+    rng = np.random.default_rng(4)
+    n, cap, M = 5000, 8192, 777
+    nodes = np.zeros((7, cap))
+    nodes[:, :n] = rng.uniform(-2, 2, size=(7, n))
+    nodes[:, 17] = np.inf  # a sink node is never nearest
+    queries = rng.uniform(-2, 2, size=(7, M))
+    queries[:, 5] = nodes[:, 123]
+    dn, dq = e.alloc(nodes.nbytes).upload(nodes), e.alloc(queries.nbytes).upload(queries)
+    di, dd = e.alloc(4 * M), e.alloc(8 * M)
+    e.nearest_dev(dn.ptr, n, cap, dq.ptr, M, di.ptr, dd.ptr)
+    idx, d2 = di.download(np.int32, M), dd.download(np.float64, M)
+    ref = ((nodes[:, None, :n] - queries[:, :, None]) ** 2)
+    ref = np.where(np.isfinite(ref), ref, np.inf).sum(0)
+    np.testing.assert_array_equal(idx, ref.argmin(1))
+    assert idx[5] == 123 and d2[5] == 0.0
+
+
+def test_dropin_constraint_and_planner_equivalence(oracle_mod):
+    """The HIP CollisionConstraint dropped into the reference-shaped planner makes the same
+    decisions as the CPU path: identical waypoint lists for a fixed seed (UR5e, config 1)."""
+    m = scenes.ur5e()
+    joints = mjpl.all_joints(m)
+    gpu_cc = mjpl.CollisionConstraint(m)
+    cpu_cc = OracleCollisionConstraint(m, pyoracle=oracle_mod)
+    q_init = m.keyframe("home").qpos.copy()
+    plans = []
+    for cc in (gpu_cc, cpu_cc):
+        constraints = [mjpl.JointLimitConstraint(m), cc]
+        q_goal = mjpl.random_config(m, q_init, joints, 3, constraints)
+        planner = mjpl.RRT(m, joints, constraints, collision_interval_check=(0.02, cc), seed=3,
+                           goal_biasing_probability=0.1, max_planning_time=60.0)
+        wps = planner.plan_to_config(q_init, q_goal)
+        assert wps
+        plans.append(mjpl.smooth_path(wps, constraints, (0.02, cc), eps=planner.epsilon, seed=3, sparse=True))
+    assert len(plans[0]) == len(plans[1])
+    for a, b in zip(*plans):
+        np.testing.assert_array_equal(a, b)
+    # scalar surface semantics (collision_constraint.py:26-33)
+    q = q_init.copy()
+    assert gpu_cc.valid_config(q) is True and gpu_cc.apply(None, q) is q
+    q_bad = q.copy()
+    q_bad[1] = 0.0  # upper arm horizontal, forearm folded into the floor/base region
+    assert gpu_cc.valid_config(q_bad) == cpu_cc.valid_config(q_bad)
+    with pytest.raises(ValueError, match="step_dist"):
+        gpu_cc.valid_interval(q, q_bad, 0.0)
