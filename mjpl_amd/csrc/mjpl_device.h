@@ -199,7 +199,8 @@ MJPL_HD bool plane_box(double margin, const Geom &pl, const Geom &box, const dou
   double dif[3] = {box.pos[0] - pl.pos[0], box.pos[1] - pl.pos[1], box.pos[2] - pl.pos[2]};
   double dist = dot3(dif, norm);
   bool any = false;
-#pragma unroll
+  // rolled on purpose: unrolling the 8 corners keeps ~40 extra VGPRs live
+#pragma unroll 1
   for (int i = 0; i < 8; i++) {
     double vec[3], corner[3];
     vec[0] = (i & 1) ? size2[0] : -size2[0];
@@ -322,21 +323,26 @@ __device__ __forceinline__ bool capsule_box(double margin, const Geom &cap, cons
   double ghi = capbox_g(p, h, size2, hi);
   const bool at_lo = glo >= 0;
   const bool at_hi = !at_lo && ghi <= 0;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-#pragma unroll
-    for (int sgn = -1; sgn <= 1; sgn += 2) {
-      // h[k] == 0 gives tb = +-inf or NaN, which fails the bracket test like the scalar `continue`
-      double tb = (sgn * size2[k] - p[k]) / h[k];
-      bool inside = (tb > lo && tb < hi);
-      double gb = capbox_g(p, h, size2, tb);
-      bool below = inside && gb <= 0;
-      bool above = inside && !(gb <= 0);
-      lo = below ? tb : lo;
-      glo = below ? gb : glo;
-      hi = above ? tb : hi;
-      ghi = above ? gb : ghi;
-    }
+  // six face breakpoints in the scalar routine's order (k = 0,1,2; sign = -,+).  The loop is
+  // kept rolled (operands picked with wave-uniform selects) so that the six divisions are not
+  // hoisted and kept live at once: that alone costs ~60 VGPRs.
+#pragma unroll 1
+  for (int i = 0; i < 6; i++) {
+    const int k = i >> 1;
+    const double pk = (k == 0) ? p[0] : ((k == 1) ? p[1] : p[2]);
+    const double hk = (k == 0) ? h[0] : ((k == 1) ? h[1] : h[2]);
+    const double sk = (k == 0) ? size2[0] : ((k == 1) ? size2[1] : size2[2]);
+    const double face = (i & 1) ? sk : -sk;
+    // h[k] == 0 gives tb = +-inf or NaN, which fails the bracket test like the scalar `continue`
+    double tb = (face - pk) / hk;
+    bool inside = (tb > lo && tb < hi);
+    double gb = capbox_g(p, h, size2, tb);
+    bool below = inside && gb <= 0;
+    bool above = inside && !(gb <= 0);
+    lo = below ? tb : lo;
+    glo = below ? gb : glo;
+    hi = above ? tb : hi;
+    ghi = above ? gb : ghi;
   }
   double den = ghi - glo;
   double t = (den > 0) ? lo + (hi - lo) * ((0 - glo) / den) : lo;
@@ -392,15 +398,18 @@ __device__ __forceinline__ bool box_box(double margin, const Geom &b1, const dou
 // pairs are ordered by type inside each routine's signature, so only the symmetric-type
 // routines whose rounding depends on the argument order (sphere-sphere's radius sum,
 // capsule-capsule, box-box) look at `pfirst`, with wave-uniform selects.
-template <int BOXLVL>
+// WBOX: some static geom is a box.  MBOX: some moving geom is a box.  The flags only remove
+// dead narrowphase code (and its registers) from an instantiation.
+template <bool WBOX, bool MBOX>
 __device__ __forceinline__ bool pair_contact(int tcur, const Geom &cur, const double *scur, int tpar,
                                              const Geom &par, const double *spar, bool pfirst,
                                              double margin) {
+  constexpr bool PBOX = WBOX || MBOX;  // the partner may be a box
   bool r = false;
   if (tpar == GT_PLANE) {
     if (tcur == GT_SPHERE) r = plane_sphere(margin, par, cur.pos, scur[0]);
     else if (tcur == GT_CAPSULE) r = plane_capsule(margin, par, cur, scur);
-    else if (BOXLVL > 0) r = plane_box(margin, par, cur, scur);
+    else if (MBOX) r = plane_box(margin, par, cur, scur);
   } else if (tcur == GT_SPHERE && tpar == GT_SPHERE) {
     const double r1 = pfirst ? spar[0] : scur[0], r2 = pfirst ? scur[0] : spar[0];
     r = sphere_sphere(margin, cur.pos, r1, par.pos, r2);  // (a-b)^2 == (b-a)^2 exactly
@@ -408,13 +417,13 @@ __device__ __forceinline__ bool pair_contact(int tcur, const Geom &cur, const do
     r = sphere_capsule(margin, cur.pos, scur[0], par, spar);
   } else if (tcur == GT_CAPSULE && tpar == GT_SPHERE) {
     r = sphere_capsule(margin, par.pos, spar[0], cur, scur);
-  } else if (BOXLVL > 0 && tcur == GT_SPHERE && tpar == GT_BOX) {
+  } else if (PBOX && tcur == GT_SPHERE && tpar == GT_BOX) {
     r = sphere_box(margin, cur.pos, scur[0], par, spar);
-  } else if (BOXLVL > 0 && tcur == GT_BOX && tpar == GT_SPHERE) {
+  } else if (MBOX && tcur == GT_BOX && tpar == GT_SPHERE) {
     r = sphere_box(margin, par.pos, spar[0], cur, scur);
-  } else if (BOXLVL > 0 && tcur == GT_CAPSULE && tpar == GT_BOX) {
+  } else if (PBOX && tcur == GT_CAPSULE && tpar == GT_BOX) {
     r = capsule_box(margin, cur, scur, par, spar);
-  } else if (BOXLVL > 0 && tcur == GT_BOX && tpar == GT_CAPSULE) {
+  } else if (MBOX && tcur == GT_BOX && tpar == GT_CAPSULE) {
     r = capsule_box(margin, par, spar, cur, scur);
   } else if (tcur == GT_CAPSULE && tpar == GT_CAPSULE) {
     Geom c1, c2;
@@ -432,7 +441,7 @@ __device__ __forceinline__ bool pair_contact(int tcur, const Geom &cur, const do
       s2[k] = pfirst ? scur[k] : spar[k];
     }
     r = capsule_capsule(margin, c1, s1, c2, s2);
-  } else if (BOXLVL > 1) {
+  } else if (MBOX) {
     Geom b1, b2;
     double s1[3], s2[3];
 #pragma unroll
@@ -497,10 +506,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // Returns true iff the configuration has a contact outside the allowed body pairs.
 // `active` = false lanes run along (wave-uniform control flow) but never report a hit.
 // EMIT: also write body/geom world poses to `out` row `row` (FK parity kernel).
-// BOXLVL: 0 = no box geoms in the model, 1 = boxes only among the static geoms / against
-// spheres and capsules, 2 = box-box pairs present.  It only removes dead narrowphase code
-// (and its register pressure) from the instantiation.
-template <int MAXS, bool EMIT, int BOXLVL>
+template <int MAXS, bool EMIT, bool WBOX, bool MBOX>
 __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qstride, double *save,
                                            int sstride, bool active, const FkOut &out, int64_t row) {
   SlotFile<MAXS> sf;
@@ -631,12 +637,16 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
         cur.pos[0] += p[0]; cur.pos[1] += p[1]; cur.pos[2] += p[2];
       }
       if (gflags & GF_SAMEROT) {
+        if (EMIT || MBOX) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) cur.m[k] = R[k];
+          for (int k = 0; k < 9; k++) cur.m[k] = R[k];
+        } else {
+          cur.m[2] = R[2]; cur.m[5] = R[5]; cur.m[8] = R[8];
+        }
       } else {
         double lq[4] = {gd[3], gd[4], gd[5], gd[6]}, gq[4];
         mul_quat(gq, qt, lq);
-        if (EMIT || (BOXLVL > 0 && gtype == GT_BOX)) quat2mat(cur.m, gq);
+        if (EMIT || (MBOX && gtype == GT_BOX)) quat2mat(cur.m, gq);
         else quat2zaxis(cur.m, gq);
       }
       if (EMIT) {
@@ -679,7 +689,7 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
         if (stored) {
           psize[0] = pd[PD_SIZE]; psize[1] = pd[PD_SIZE + 1]; psize[2] = pd[PD_SIZE + 2];
           double t6[6] = {0, 0, 0, 0, 0, 0};
-          if (BOXLVL > 0 && ((pw >> 6) & 63) != SLOT_NONE) {  // stored box: x and y axes
+          if (MBOX && ((pw >> 6) & 63) != SLOT_NONE) {  // stored box: x and y axes
             const int slot_ = (pw >> 6) & 63;
             MJPL_FOR_SLOTS(MJPL_SLOT_GET)
           }
@@ -687,10 +697,14 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
           par.m[1] = t6[3]; par.m[4] = t6[4]; par.m[7] = t6[5];
         } else {
           psize[0] = wd[W_SIZE]; psize[1] = wd[W_SIZE + 1]; psize[2] = wd[W_SIZE + 2];
-          par.m[0] = wd[W_MAT + 0]; par.m[1] = wd[W_MAT + 1]; par.m[3] = wd[W_MAT + 3];
-          par.m[4] = wd[W_MAT + 4]; par.m[6] = wd[W_MAT + 6]; par.m[7] = wd[W_MAT + 7];
+          if (WBOX) {
+            par.m[0] = wd[W_MAT + 0]; par.m[1] = wd[W_MAT + 1]; par.m[3] = wd[W_MAT + 3];
+            par.m[4] = wd[W_MAT + 4]; par.m[6] = wd[W_MAT + 6]; par.m[7] = wd[W_MAT + 7];
+          } else {
+            par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
+          }
         }
-        bool contact = pair_contact<BOXLVL>(gtype, cur, gsize, ptype, par, psize, pfirst, pd[PD_MARGIN]);
+        bool contact = pair_contact<WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst, pd[PD_MARGIN]);
         hit = hit || (pass && contact);
       }
 
@@ -700,7 +714,7 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
           const int slot_ = store & 63;
           MJPL_FOR_SLOTS(MJPL_SLOT_PUT)
         }
-        if (BOXLVL > 0 && ((store >> 6) & 63) != SLOT_NONE) {
+        if (MBOX && ((store >> 6) & 63) != SLOT_NONE) {
           const double t6[6] = {cur.m[0], cur.m[3], cur.m[6], cur.m[1], cur.m[4], cur.m[7]};
           const int slot_ = (store >> 6) & 63;
           MJPL_FOR_SLOTS(MJPL_SLOT_PUT)

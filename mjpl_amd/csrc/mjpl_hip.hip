@@ -98,7 +98,7 @@ __device__ __forceinline__ void load_columns(double *col, int B, const double *_
   }
 }
 
-template <int MAXS, int BOXLVL>
+template <int MAXS, bool WBOX, bool MBOX>
 __global__ void __launch_bounds__(kBlock)
 k_check_configs(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
                 const double *__restrict__ Q, int64_t N, int layout, uint8_t *__restrict__ valid,
@@ -113,7 +113,7 @@ k_check_configs(const int *__restrict__ gip, int nip, const double *__restrict__
   __syncthreads();
 
   FkOut none = {};
-  bool hit = run_config<MAXS, false, BOXLVL>(c.ip, c.dp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B,
+  bool hit = run_config<MAXS, false, WBOX, MBOX>(c.ip, c.dp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B,
                                      active, none, i);
   if (valid && active) valid[i] = hit ? 0 : 1;
   if (bits) {
@@ -133,7 +133,7 @@ k_fk(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int n
   const bool active = i < N;
   load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
   __syncthreads();
-  run_config<1, true, 2>(c.ip, c.dp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B, active, out, i);
+  run_config<1, true, true, true>(c.ip, c.dp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B, active, out, i);
 }
 
 // One lane per edge.  Check 0 is the endpoint QB; checks 1..K are the interior waypoints of
@@ -141,7 +141,7 @@ k_fk(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int n
 //   w <- w + ((QB - w)/||QB - w||) * min(step, ||QB - w||)      (planning/utils.py:182-185)
 // until w == QB (np.array_equal, :211).  ||.|| is the sequential-sum 2-norm over qpos
 // addresses in ascending order (see DESIGN.md "waypoint semantics").
-template <int MAXS, int BOXLVL>
+template <int MAXS, bool WBOX, bool MBOX>
 __global__ void __launch_bounds__(kBlock)
 k_check_edges(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
               const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, double step,
@@ -209,7 +209,7 @@ k_check_edges(const int *__restrict__ gip, int nip, const double *__restrict__ g
         }
       }
     }
-    const bool hit = run_config<MAXS, false, BOXLVL>(c.ip, c.dp, first ? qe : qw, B, c.save + threadIdx.x, B,
+    const bool hit = run_config<MAXS, false, WBOX, MBOX>(c.ip, c.dp, first ? qe : qw, B, c.save + threadIdx.x, B,
                                              !done, none, i);
     if (!done && hit) { done = true; ok = false; fb = idx; }
     if (first && !done && at_end) done = true;  // waypoints == [start]: nothing interior
@@ -288,7 +288,8 @@ struct mjpl_engine {
   int *d_ip = nullptr;
   double *d_dp = nullptr;
   int *d_status = nullptr;
-  int nslots = 0, nsave = 0, maxs = 4, boxlvl = 0;
+  int nslots = 0, nsave = 0, maxs = 4;
+  bool wbox = false, mbox = false;
   int npairs = 0, npairs_world = 0, nmoving = 0, nstatic = 0;
   // static poses for FK output
   std::vector<double> st_xpos, st_xquat, st_gxpos, st_gxmat;
@@ -420,10 +421,10 @@ int compile_program(mjpl_engine *e) {
   std::vector<std::vector<int>> stored_partners(nm), world_partners(nm);
   std::vector<int> last_user(nm, -1);
   e->npairs = e->npairs_world = 0;
-  e->boxlvl = 0;
-  auto note_pair = [&](int ga, int gb) {
-    const bool ba = m.geom_type[ga] == GT_BOX, bb = m.geom_type[gb] == GT_BOX;
-    e->boxlvl = std::max(e->boxlvl, (ba && bb) ? 2 : ((ba || bb) ? 1 : 0));
+  e->wbox = e->mbox = false;
+  auto note_pair = [&](int ga, int gb) {  // ga is the moving geom being placed
+    if (m.geom_type[ga] == GT_BOX) e->mbox = true;
+    if (m.geom_type[gb] == GT_BOX) (e->geom_static[gb] ? e->wbox : e->mbox) = true;
   };
   for (int k = 0; k < nm; k++) {
     const int g = mgeoms[k];
@@ -603,15 +604,13 @@ int allow_lds(K kernel, size_t bytes) {
   return MJPL_OK;
 }
 
-// pick the <MAXS, BOXLVL> instantiation for this model
+// pick the <MAXS, WBOX, MBOX> instantiation for this model
 template <class F>
 int dispatch_variant(const mjpl_engine *e, F &&f) {
   auto with_box = [&](auto S) -> int {
-    switch (e->boxlvl) {
-      case 0: return f(S, std::integral_constant<int, 0>{});
-      case 1: return f(S, std::integral_constant<int, 1>{});
-      default: return f(S, std::integral_constant<int, 2>{});
-    }
+    if (e->mbox) return f(S, std::true_type{}, std::true_type{});  // moving boxes: general build
+    if (e->wbox) return f(S, std::true_type{}, std::false_type{});
+    return f(S, std::false_type{}, std::false_type{});
   };
   switch (e->maxs) {
     case 4: return with_box(std::integral_constant<int, 4>{});
@@ -626,8 +625,8 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
   if (N == 0) return MJPL_OK;
   const size_t lds = lds_bytes(e, 1);
   const unsigned grid = (unsigned)((N + kBlock - 1) / kBlock);
-  int rc = dispatch_variant(e, [&](auto S, auto X) -> int {
-    auto kern = k_check_configs<decltype(S)::value, decltype(X)::value>;
+  int rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+    auto kern = k_check_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
     int r = allow_lds(kern, lds);
     if (r != MJPL_OK) return r;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, e->stream, e->d_ip, (int)e->ip.size(),
@@ -644,8 +643,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
   if (E == 0) return MJPL_OK;
   const size_t lds = lds_bytes(e, 2);
   const unsigned grid = (unsigned)((E + kBlock - 1) / kBlock);
-  int rc = dispatch_variant(e, [&](auto S, auto X) -> int {
-    auto kern = k_check_edges<decltype(S)::value, decltype(X)::value>;
+  int rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+    auto kern = k_check_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
     int r = allow_lds(kern, lds);
     if (r != MJPL_OK) return r;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, e->stream, e->d_ip, (int)e->ip.size(),
