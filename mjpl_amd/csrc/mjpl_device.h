@@ -52,7 +52,8 @@ enum : int {
   H_NSLOTS,        // register slots in use
   H_OFF_BODYOPS,   // int offset of the first body op
   H_OFF_PERM,      // int offset of the ascending-qpos-address column permutation
-  H_OFF_WORLD,     // double offset of the static ("world") geom table, 15 doubles per geom
+  H_OFF_WORLD,     // double offset of the static ("world") geom table, W_LEN doubles per row
+  H_NWORLD,        // rows in the world table
   H_SIZE
 };
 
@@ -65,21 +66,24 @@ enum : int { J_TYPE = 0, J_QSRC, J_FLAGS, J_DOFF, J_SIZE };  // qsrc >= 0: plann
 enum : int { JF_POS_NONZERO = 1 };
 // joint dp: axis[3] pos[3] qpos0 qconst
 
-enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_NPARTNER, G_SIZE };
+enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_NSTORED, G_WMASK_LO, G_WMASK_HI, G_SIZE };
 enum : int { GF_SAMEPOS = 1, GF_SAMEROT = 2 };
-// geom dp: lpos[3] lquat[4] size[3]
+// geom dp: lpos[3] lquat[4] size[3] pad[2] | wbound[nworld] | wmargin[nworld] | stored[nstored][5]
+//   wbound[w]  cull bound against static geom w: (r1+r2+margin)^2, or margin + rbound for a plane
+//   wmargin[w] pair margin max(margin_cur, margin_w)
+//   stored[k]  = bound, margin, psize[3] of the k-th earlier moving partner
+enum : int { GD_LPOS = 0, GD_LQUAT = 3, GD_SIZE = 7, GD_WBOUND = 12 };
+enum : int { SD_BOUND = 0, SD_MARGIN, SD_SIZE, SD_LEN = 5 };
 
-// partner entry: one packed int + one dp offset
-//   bits 0..11  row of the world table, or register slots first | (second << 6) ;
-//   bits 12..15 partner type
-//   bit 16      stored (earlier moving geom) else world (static geom)
-//   bit 17      partner is the FIRST geom of the pair in mj_collision's (g1,g2) order
-enum : int { P_STORED = 1 << 16, P_FIRST = 1 << 17 };
-// partner dp: bound (sphere cull: (r1+r2+margin)^2 ; plane: margin + rbound_cur), margin;
-//             stored partners add psize[3] (world partners read size from the world table)
-enum : int { PD_BOUND = 0, PD_MARGIN, PD_SIZE, PD_WORLD_LEN = 2, PD_STORED_LEN = 5 };
-// world table row: pos[3] mat[9] size[3]
-enum : int { W_POS = 0, W_MAT = 3, W_SIZE = 12, W_LEN = 15 };
+// static partners: G_WMASK is a bit mask over the rows of the world table (<= 64 static geoms).
+// stored partners: one packed int each, right after the geom record:
+//   bits 0..5 first slot ; bits 6..11 second slot (boxes, else SLOT_NONE) ; bits 12..15 type
+//   bit 17    partner is the FIRST geom of the pair in mj_collision's (g1,g2) order
+enum : int { P_FIRST = 1 << 17 };
+// world table row (fixed stride so that the next row can be requested before it is needed):
+//   [0..2] pos  [3..5] z axis  [6] info word (type | geom id << 8)  [7] pad   <- cull part, 64 B
+//   [8..10] x axis  [11..13] y axis  [14..16] size  [17..19] pad              <- narrowphase part
+enum : int { W_POS = 0, W_ZAXIS = 3, W_INFO = 6, W_XAXIS = 8, W_YAXIS = 11, W_SIZE = 14, W_LEN = 20 };
 
 enum : int { GT_PLANE = 0, GT_SPHERE = 2, GT_CAPSULE = 3, GT_BOX = 6 };
 enum : int { JT_SLIDE = 2, JT_HINGE = 3 };
@@ -624,11 +628,14 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
       DP gd = dp + uni(ip[pc + G_DOFF]);
       const int store = uni(ip[pc + G_STORE]);
       const int geom_id = uni(ip[pc + G_GEOMID]);
-      const int npartner = uni(ip[pc + G_NPARTNER]);
+      const int nstored = uni(ip[pc + G_NSTORED]);
+      const unsigned long long wmask_all =
+          (unsigned long long)(unsigned)uni(ip[pc + G_WMASK_LO]) |
+          ((unsigned long long)(unsigned)uni(ip[pc + G_WMASK_HI]) << 32);
       pc += G_SIZE;
 
       Geom cur;
-      const double gsize[3] = {gd[7], gd[8], gd[9]};
+      const double gsize[3] = {gd[GD_SIZE], gd[GD_SIZE + 1], gd[GD_SIZE + 2]};
       if (gflags & GF_SAMEPOS) {
         cur.pos[0] = p[0]; cur.pos[1] = p[1]; cur.pos[2] = p[2];
       } else {
@@ -656,57 +663,102 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
           for (int k = 0; k < 9; k++) out.geom_xmat[(row * out.ngeom + geom_id) * 9 + k] = cur.m[k];
       }
 
-      for (int e = 0; e < npartner; e++) {
-        const int pw = uni(ip[pc]);
-        DP pd = dp + uni(ip[pc + 1]);
-        pc += 2;
-        if (EMIT) continue;
-        const int ptype = (pw >> 12) & 15;
-        const bool stored = (pw & P_STORED) != 0;
-        const bool pfirst = (pw & P_FIRST) != 0;
-        DP wd = world + (pw & 4095) * W_LEN;  // only read for world partners
-
-        // bounding cull (mj_collideSphere): squared centre distance, or signed plane distance
-        Geom par;
-        if (stored) {
-          double t6[6] = {0, 0, 0, 0, 0, 0};
-          const int slot_ = pw & 63;
-          MJPL_FOR_SLOTS(MJPL_SLOT_GET)
-          par.pos[0] = t6[0]; par.pos[1] = t6[1]; par.pos[2] = t6[2];
-          par.m[2] = t6[3]; par.m[5] = t6[4]; par.m[8] = t6[5];
-        } else {
-          par.pos[0] = wd[W_POS]; par.pos[1] = wd[W_POS + 1]; par.pos[2] = wd[W_POS + 2];
-          par.m[2] = wd[W_MAT + 2]; par.m[5] = wd[W_MAT + 5]; par.m[8] = wd[W_MAT + 8];
+      if (!EMIT) {
+        // ---- static partners: rows of the world table selected by the enable mask.  The row
+        // (64 B) and the cull bound of the NEXT enabled row are requested before the current
+        // one is tested, so a wave never sits on a scalar-load round trip per pair.
+        const int nworld = uni(ip[H_NWORLD]);
+        DP wbound = gd + GD_WBOUND;
+        unsigned long long wmask = wmask_all;
+        int w = wmask ? (int)__builtin_ctzll(wmask) : -1;
+        double nx_pos[3], nx_z[3], nx_bound = 0;
+        int nx_info = 0;
+        if (w >= 0) {
+          DP r = world + w * W_LEN;
+          nx_pos[0] = r[W_POS]; nx_pos[1] = r[W_POS + 1]; nx_pos[2] = r[W_POS + 2];
+          nx_z[0] = r[W_ZAXIS]; nx_z[1] = r[W_ZAXIS + 1]; nx_z[2] = r[W_ZAXIS + 2];
+          nx_info = ((IP)(r + W_INFO))[0];
+          nx_bound = wbound[w];
         }
-        double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
-        double n[3] = {par.m[2], par.m[5], par.m[8]};
-        // (a-b)^2 == (b-a)^2 exactly, so the pair order does not matter for the sphere cull
-        double measure = (ptype == GT_PLANE) ? dot3(dif, n) : dot3(dif, dif);
-        bool pass = !(measure > pd[PD_BOUND]) && active && !hit;
-        if (__ballot(pass) == 0ull) continue;  // nobody in the wave needs the narrowphase
-
-        double psize[3];
-        if (stored) {
-          psize[0] = pd[PD_SIZE]; psize[1] = pd[PD_SIZE + 1]; psize[2] = pd[PD_SIZE + 2];
-          double t6[6] = {0, 0, 0, 0, 0, 0};
-          if (MBOX && ((pw >> 6) & 63) != SLOT_NONE) {  // stored box: x and y axes
-            const int slot_ = (pw >> 6) & 63;
-            MJPL_FOR_SLOTS(MJPL_SLOT_GET)
+        while (w >= 0) {
+          Geom par;
+          par.pos[0] = nx_pos[0]; par.pos[1] = nx_pos[1]; par.pos[2] = nx_pos[2];
+          par.m[2] = nx_z[0]; par.m[5] = nx_z[1]; par.m[8] = nx_z[2];
+          const int info = uni(nx_info);
+          const double bound = nx_bound;
+          const int wc = w;
+          wmask &= wmask - 1;
+          w = wmask ? (int)__builtin_ctzll(wmask) : -1;
+          if (w >= 0) {
+            DP r = world + w * W_LEN;
+            nx_pos[0] = r[W_POS]; nx_pos[1] = r[W_POS + 1]; nx_pos[2] = r[W_POS + 2];
+            nx_z[0] = r[W_ZAXIS]; nx_z[1] = r[W_ZAXIS + 1]; nx_z[2] = r[W_ZAXIS + 2];
+            nx_info = ((IP)(r + W_INFO))[0];
+            nx_bound = wbound[w];
           }
-          par.m[0] = t6[0]; par.m[3] = t6[1]; par.m[6] = t6[2];
-          par.m[1] = t6[3]; par.m[4] = t6[4]; par.m[7] = t6[5];
-        } else {
-          psize[0] = wd[W_SIZE]; psize[1] = wd[W_SIZE + 1]; psize[2] = wd[W_SIZE + 2];
+          const int ptype = info & 255;
+          // bounding cull (mj_collideSphere): signed plane distance, or squared centre distance
+          // ((a-b)^2 == (b-a)^2 exactly, so the pair order does not matter)
+          double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
+          double measure;
+          if (ptype == GT_PLANE) {
+            double n[3] = {par.m[2], par.m[5], par.m[8]};
+            measure = dot3(dif, n);
+          } else {
+            measure = dot3(dif, dif);
+          }
+          const bool pass = !(measure > bound) && active && !hit;
+          if (__ballot(pass) == 0ull) continue;  // nobody in the wave needs the narrowphase
+
+          DP r = world + wc * W_LEN;
+          const double psize[3] = {r[W_SIZE], r[W_SIZE + 1], r[W_SIZE + 2]};
           if (WBOX) {
-            par.m[0] = wd[W_MAT + 0]; par.m[1] = wd[W_MAT + 1]; par.m[3] = wd[W_MAT + 3];
-            par.m[4] = wd[W_MAT + 4]; par.m[6] = wd[W_MAT + 6]; par.m[7] = wd[W_MAT + 7];
+            par.m[0] = r[W_XAXIS]; par.m[3] = r[W_XAXIS + 1]; par.m[6] = r[W_XAXIS + 2];
+            par.m[1] = r[W_YAXIS]; par.m[4] = r[W_YAXIS + 1]; par.m[7] = r[W_YAXIS + 2];
           } else {
             par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
           }
+          // mj_collision order: smaller geom type first, geom id breaks ties
+          const int pgid = info >> 8;
+          const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < geom_id);
+          const double margin = wbound[nworld + wc];
+          const bool contact = pair_contact<WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst, margin);
+          hit = hit || (pass && contact);
         }
-        bool contact = pair_contact<WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst, pd[PD_MARGIN]);
-        hit = hit || (pass && contact);
+
+        // ---- earlier moving partners, held in the register slot file
+        DP sd = gd + GD_WBOUND + 2 * nworld;
+        for (int e = 0; e < nstored; e++, sd += SD_LEN) {
+          const int pw = uni(ip[pc + e]);
+          const int ptype = (pw >> 12) & 15;
+          const bool pfirst = (pw & P_FIRST) != 0;
+          Geom par;
+          {
+            double t6[6] = {0, 0, 0, 0, 0, 0};
+            const int slot_ = pw & 63;
+            MJPL_FOR_SLOTS(MJPL_SLOT_GET)
+            par.pos[0] = t6[0]; par.pos[1] = t6[1]; par.pos[2] = t6[2];
+            par.m[2] = t6[3]; par.m[5] = t6[4]; par.m[8] = t6[5];
+          }
+          double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
+          const bool pass = !(dot3(dif, dif) > sd[SD_BOUND]) && active && !hit;
+          if (__ballot(pass) == 0ull) continue;
+
+          const double psize[3] = {sd[SD_SIZE], sd[SD_SIZE + 1], sd[SD_SIZE + 2]};
+          {
+            double t6[6] = {0, 0, 0, 0, 0, 0};
+            if (MBOX && ((pw >> 6) & 63) != SLOT_NONE) {  // stored box: x and y axes
+              const int slot_ = (pw >> 6) & 63;
+              MJPL_FOR_SLOTS(MJPL_SLOT_GET)
+            }
+            par.m[0] = t6[0]; par.m[3] = t6[1]; par.m[6] = t6[2];
+            par.m[1] = t6[3]; par.m[4] = t6[4]; par.m[7] = t6[5];
+          }
+          const bool contact = pair_contact<WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst, sd[SD_MARGIN]);
+          hit = hit || (pass && contact);
+        }
       }
+      pc += nstored;
 
       if (!EMIT && store >= 0) {
         {

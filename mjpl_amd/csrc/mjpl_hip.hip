@@ -393,11 +393,24 @@ int compile_program(mjpl_engine *e) {
     mul_quat(gq, &e->st_xquat[4 * b], &m.geom_quat[4 * g]);
     quat2mat(&e->st_gxmat[9 * g], gq);
     world_row[g] = (int)(world_tab.size() / W_LEN);
-    for (int k = 0; k < 3; k++) world_tab.push_back(e->st_gxpos[3 * g + k]);
-    for (int k = 0; k < 9; k++) world_tab.push_back(e->st_gxmat[9 * g + k]);
-    for (int k = 0; k < 3; k++) world_tab.push_back(m.geom_size[3 * g + k]);
+    {
+      const double *gmx = &e->st_gxmat[9 * g];
+      double row[W_LEN] = {0};
+      for (int k = 0; k < 3; k++) {
+        row[W_POS + k] = e->st_gxpos[3 * g + k];
+        row[W_XAXIS + k] = gmx[3 * k + 0];
+        row[W_YAXIS + k] = gmx[3 * k + 1];
+        row[W_ZAXIS + k] = gmx[3 * k + 2];
+        row[W_SIZE + k] = m.geom_size[3 * g + k];
+      }
+      const int32_t info[2] = {m.geom_type[g] | (g << 8), 0};
+      memcpy(&row[W_INFO], info, sizeof(double));
+      world_tab.insert(world_tab.end(), row, row + W_LEN);
+    }
   }
-  if (world_tab.size() / W_LEN > 4095) return fail(MJPL_E_CAPACITY, "more than 4095 static geoms");
+  const int nworld = (int)(world_tab.size() / W_LEN);
+  if (nworld > 64) return fail(MJPL_E_CAPACITY, "%d static geoms; this build enables at most 64 per moving geom", nworld);
+  if (ng >= (1 << 23)) return fail(MJPL_E_CAPACITY, "too many geoms");
 
   // ---- moving bodies in id order (parents precede children)
   std::vector<int> order;
@@ -483,6 +496,7 @@ int compile_program(mjpl_engine *e) {
   ip[H_NSLOTS] = e->nslots;
   ip[H_NBODYOPS] = (int)order.size();
   ip[H_OFF_WORLD] = 0;
+  ip[H_NWORLD] = nworld;
   dp = world_tab;
 
   // column permutation: ascending qpos address (the order np.linalg.norm sums the full vector)
@@ -536,39 +550,52 @@ int compile_program(mjpl_engine *e) {
       int flags = 0;
       if (gp[0] == 0 && gp[1] == 0 && gp[2] == 0) flags |= GF_SAMEPOS;
       if (gq[0] == 1 && gq[1] == 0 && gq[2] == 0 && gq[3] == 0) flags |= GF_SAMEROT;
+      unsigned long long wmask = 0;
+      for (int sgeom : world_partners[gk]) wmask |= 1ull << world_row[sgeom];
       ip.push_back(m.geom_type[g]);
       ip.push_back(flags);
       ip.push_back((int)dp.size());
       ip.push_back(slot_of[gk]);
       ip.push_back(g);
-      ip.push_back((int)(world_partners[gk].size() + stored_partners[gk].size()));
+      ip.push_back((int)stored_partners[gk].size());
+      ip.push_back((int)(uint32_t)(wmask & 0xffffffffull));
+      ip.push_back((int)(uint32_t)(wmask >> 32));
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(gp[k3]);
       for (int k4 = 0; k4 < 4; k4++) dp.push_back(gq[k4]);
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * g + k3]);
+      dp.push_back(0.0);
+      dp.push_back(0.0);
 
-      auto emit_partner = [&](int h, bool stored, int index) {
-        // mj_collision order: (g1 < g2 by id), swapped when type1 > type2
-        int g1 = std::min(g, h), g2 = std::max(g, h);
-        const double margin = std::fmax(m.geom_margin[g1], m.geom_margin[g2]);
-        int first = (m.geom_type[g1] > m.geom_type[g2]) ? g2 : g1;
-        int word = index | (m.geom_type[h] << 12) | (stored ? P_STORED : 0) | (first == h ? P_FIRST : 0);
-        ip.push_back(word);
-        ip.push_back((int)dp.size());
+      // cull bound and margin of the pair (g, h) in mj_collision's (g1 < g2) order
+      auto pair_bound = [&](int h, double *bound, double *margin) {
+        const int g1 = std::min(g, h), g2 = std::max(g, h);
+        *margin = std::fmax(m.geom_margin[g1], m.geom_margin[g2]);
         const double r1 = m.geom_rbound[g1], r2 = m.geom_rbound[g2];
-        double bound = std::numeric_limits<double>::infinity();
+        *bound = std::numeric_limits<double>::infinity();
         if (r1 > 0 && r2 > 0) {
-          double bsum = r1 + r2 + margin;
-          bound = bsum * bsum;
+          const double bsum = r1 + r2 + *margin;
+          *bound = bsum * bsum;
         } else if (m.geom_type[h] == GT_PLANE && m.geom_rbound[g] > 0) {
-          bound = margin + m.geom_rbound[g];
+          *bound = *margin + m.geom_rbound[g];
         }
+      };
+      {
+        std::vector<double> wb(nworld, std::numeric_limits<double>::infinity()), wm(nworld, 0.0);
+        for (int sgeom : world_partners[gk]) pair_bound(sgeom, &wb[world_row[sgeom]], &wm[world_row[sgeom]]);
+        dp.insert(dp.end(), wb.begin(), wb.end());
+        dp.insert(dp.end(), wm.begin(), wm.end());
+      }
+      for (int k2 : stored_partners[gk]) {
+        const int h = mgeoms[k2];
+        const int g1 = std::min(g, h), g2 = std::max(g, h);
+        const int first = (m.geom_type[g1] > m.geom_type[g2]) ? g2 : g1;
+        ip.push_back(slot_of[k2] | (m.geom_type[h] << 12) | (first == h ? P_FIRST : 0));
+        double bound, margin;
+        pair_bound(h, &bound, &margin);
         dp.push_back(bound);
         dp.push_back(margin);
-        if (stored)
-          for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * h + k3]);
-      };
-      for (int s : world_partners[gk]) emit_partner(s, false, world_row[s]);
-      for (int k2 : stored_partners[gk]) emit_partner(mgeoms[k2], true, slot_of[k2]);
+        for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * h + k3]);
+      }
     }
     ip[base + B_NGEOM] = ngeom_here;
   }
