@@ -66,7 +66,8 @@ enum : int { J_TYPE = 0, J_QSRC, J_FLAGS, J_DOFF, J_SIZE };  // qsrc >= 0: plann
 enum : int { JF_POS_NONZERO = 1 };
 // joint dp: axis[3] pos[3] qpos0 qconst
 
-enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_NSTORED, G_WMASK_LO, G_WMASK_HI, G_SIZE };
+enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_NSTORED, G_WMASK_LO, G_WMASK_HI,
+             G_PMASK_LO, G_PMASK_HI, G_SIZE };
 enum : int { GF_SAMEPOS = 1, GF_SAMEROT = 2 };
 // geom dp: lpos[3] lquat[4] size[3] pad[2] | wbound[nworld] | wmargin[nworld] | stored[nstored][5]
 //   wbound[w]  cull bound against static geom w: (r1+r2+margin)^2, or margin + rbound for a plane
@@ -75,7 +76,8 @@ enum : int { GF_SAMEPOS = 1, GF_SAMEROT = 2 };
 enum : int { GD_LPOS = 0, GD_LQUAT = 3, GD_SIZE = 7, GD_WBOUND = 12 };
 enum : int { SD_BOUND = 0, SD_MARGIN, SD_SIZE, SD_LEN = 5 };
 
-// static partners: G_WMASK is a bit mask over the rows of the world table (<= 64 static geoms).
+// static partners: G_WMASK (non-plane) and G_PMASK (plane) are bit masks over the rows of the
+// world table (<= 64 static geoms).
 // stored partners: one packed int each, right after the geom record:
 //   bits 0..5 first slot ; bits 6..11 second slot (boxes, else SLOT_NONE) ; bits 12..15 type
 //   bit 17    partner is the FIRST geom of the pair in mj_collision's (g1,g2) order
@@ -632,6 +634,9 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
       const unsigned long long wmask_all =
           (unsigned long long)(unsigned)uni(ip[pc + G_WMASK_LO]) |
           ((unsigned long long)(unsigned)uni(ip[pc + G_WMASK_HI]) << 32);
+      const unsigned long long pmask_all =
+          (unsigned long long)(unsigned)uni(ip[pc + G_PMASK_LO]) |
+          ((unsigned long long)(unsigned)uni(ip[pc + G_PMASK_HI]) << 32);
       pc += G_SIZE;
 
       Geom cur;
@@ -664,50 +669,59 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
       }
 
       if (!EMIT) {
-        // ---- static partners: rows of the world table selected by the enable mask.  The row
-        // (64 B) and the cull bound of the NEXT enabled row are requested before the current
-        // one is tested, so a wave never sits on a scalar-load round trip per pair.
         const int nworld = uni(ip[H_NWORLD]);
         DP wbound = gd + GD_WBOUND;
-        unsigned long long wmask = wmask_all;
-        int w = wmask ? (int)__builtin_ctzll(wmask) : -1;
-        double nx_pos[3], nx_z[3], nx_bound = 0;
-        int nx_info = 0;
-        if (w >= 0) {
-          DP r = world + w * W_LEN;
-          nx_pos[0] = r[W_POS]; nx_pos[1] = r[W_POS + 1]; nx_pos[2] = r[W_POS + 2];
-          nx_z[0] = r[W_ZAXIS]; nx_z[1] = r[W_ZAXIS + 1]; nx_z[2] = r[W_ZAXIS + 2];
-          nx_info = ((IP)(r + W_INFO))[0];
-          nx_bound = wbound[w];
+
+        // ---- static planes (few): signed-distance cull, then the plane routines
+        for (unsigned long long pm = pmask_all; pm; pm &= pm - 1) {
+          const int wc = (int)__builtin_ctzll(pm);
+          DP r = world + wc * W_LEN;
+          Geom par;
+          par.pos[0] = r[W_POS]; par.pos[1] = r[W_POS + 1]; par.pos[2] = r[W_POS + 2];
+          par.m[2] = r[W_ZAXIS]; par.m[5] = r[W_ZAXIS + 1]; par.m[8] = r[W_ZAXIS + 2];
+          par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
+          double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
+          double n[3] = {par.m[2], par.m[5], par.m[8]};
+          const bool pass = !(dot3(dif, n) > wbound[wc]) && active && !hit;
+          if (__ballot(pass) == 0ull) continue;
+          const double psize[3] = {0, 0, 0};
+          const bool contact = pair_contact<WBOX, MBOX>(gtype, cur, gsize, GT_PLANE, par, psize, true,
+                                                        wbound[nworld + wc]);
+          hit = hit || (pass && contact);
         }
-        while (w >= 0) {
+
+        // ---- other static partners: rows of the world table selected by the enable mask.
+        // The cull part of the NEXT enabled row (64 B) and its bound are requested, without a
+        // branch, before the current row is tested, so that the scalar-load round trip of a
+        // pair overlaps the previous pair's arithmetic.
+        unsigned long long wmask = wmask_all;
+        int w = wmask ? (int)__builtin_ctzll(wmask) : 0;
+        DP rn = world + w * W_LEN;
+        double nx_pos[3] = {rn[W_POS], rn[W_POS + 1], rn[W_POS + 2]};
+        double nx_z[3] = {rn[W_ZAXIS], rn[W_ZAXIS + 1], rn[W_ZAXIS + 2]};
+        int nx_info = ((IP)(rn + W_INFO))[0];
+        double nx_bound = wbound[w];
+        while (wmask) {
           Geom par;
           par.pos[0] = nx_pos[0]; par.pos[1] = nx_pos[1]; par.pos[2] = nx_pos[2];
           par.m[2] = nx_z[0]; par.m[5] = nx_z[1]; par.m[8] = nx_z[2];
-          const int info = uni(nx_info);
+          const int info = nx_info;
           const double bound = nx_bound;
           const int wc = w;
           wmask &= wmask - 1;
-          w = wmask ? (int)__builtin_ctzll(wmask) : -1;
-          if (w >= 0) {
-            DP r = world + w * W_LEN;
-            nx_pos[0] = r[W_POS]; nx_pos[1] = r[W_POS + 1]; nx_pos[2] = r[W_POS + 2];
-            nx_z[0] = r[W_ZAXIS]; nx_z[1] = r[W_ZAXIS + 1]; nx_z[2] = r[W_ZAXIS + 2];
-            nx_info = ((IP)(r + W_INFO))[0];
-            nx_bound = wbound[w];
-          }
+          w = wmask ? (int)__builtin_ctzll(wmask) : 0;
+          rn = world + w * W_LEN;
+          nx_pos[0] = rn[W_POS]; nx_pos[1] = rn[W_POS + 1]; nx_pos[2] = rn[W_POS + 2];
+          nx_z[0] = rn[W_ZAXIS]; nx_z[1] = rn[W_ZAXIS + 1]; nx_z[2] = rn[W_ZAXIS + 2];
+          nx_info = ((IP)(rn + W_INFO))[0];
+          nx_bound = wbound[w];
+
           const int ptype = info & 255;
-          // bounding cull (mj_collideSphere): signed plane distance, or squared centre distance
-          // ((a-b)^2 == (b-a)^2 exactly, so the pair order does not matter)
+          __builtin_assume(ptype != GT_PLANE);
+          // bounding cull (mj_collideSphere): squared centre distance; (a-b)^2 == (b-a)^2 exactly,
+          // so the pair order does not matter
           double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
-          double measure;
-          if (ptype == GT_PLANE) {
-            double n[3] = {par.m[2], par.m[5], par.m[8]};
-            measure = dot3(dif, n);
-          } else {
-            measure = dot3(dif, dif);
-          }
-          const bool pass = !(measure > bound) && active && !hit;
+          const bool pass = !(dot3(dif, dif) > bound) && active && !hit;
           if (__ballot(pass) == 0ull) continue;  // nobody in the wave needs the narrowphase
 
           DP r = world + wc * W_LEN;

@@ -550,8 +550,9 @@ int compile_program(mjpl_engine *e) {
       int flags = 0;
       if (gp[0] == 0 && gp[1] == 0 && gp[2] == 0) flags |= GF_SAMEPOS;
       if (gq[0] == 1 && gq[1] == 0 && gq[2] == 0 && gq[3] == 0) flags |= GF_SAMEROT;
-      unsigned long long wmask = 0;
-      for (int sgeom : world_partners[gk]) wmask |= 1ull << world_row[sgeom];
+      unsigned long long wmask = 0, pmask = 0;
+      for (int sgeom : world_partners[gk])
+        (m.geom_type[sgeom] == GT_PLANE ? pmask : wmask) |= 1ull << world_row[sgeom];
       ip.push_back(m.geom_type[g]);
       ip.push_back(flags);
       ip.push_back((int)dp.size());
@@ -560,6 +561,8 @@ int compile_program(mjpl_engine *e) {
       ip.push_back((int)stored_partners[gk].size());
       ip.push_back((int)(uint32_t)(wmask & 0xffffffffull));
       ip.push_back((int)(uint32_t)(wmask >> 32));
+      ip.push_back((int)(uint32_t)(pmask & 0xffffffffull));
+      ip.push_back((int)(uint32_t)(pmask >> 32));
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(gp[k3]);
       for (int k4 = 0; k4 < 4; k4++) dp.push_back(gq[k4]);
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * g + k3]);
