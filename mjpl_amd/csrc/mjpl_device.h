@@ -308,7 +308,7 @@ MJPL_HD double capbox_g(const double *p, const double *h, const double *s, doubl
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     double x = p[k] + t * h[k];
-    double e = x - clipd(x, -s[k], s[k]);
+    double e = x - fmin(fmax(x, -s[k]), s[k]);
     g = g + h[k] * e;
   }
   return g;
@@ -319,40 +319,38 @@ __device__ __forceinline__ bool capsule_box(double margin, const Geom &cap, cons
                                             const Geom &box, const double *size2) {
   double tmp[3] = {cap.pos[0] - box.pos[0], cap.pos[1] - box.pos[1], cap.pos[2] - box.pos[2]};
   double axis[3] = {cap.m[2], cap.m[5], cap.m[8]};
-  double p[3], a[3], h[3];
+  double p[3], a[3], h[3], inv[3];
   mul_matT_vec3(p, box.m, tmp);
   mul_matT_vec3(a, box.m, axis);
-  h[0] = a[0] * size1[1]; h[1] = a[1] * size1[1]; h[2] = a[2] * size1[1];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    h[k] = a[k] * size1[1];
+    inv[k] = 1 / h[k];  // h == 0: +-inf, the breakpoint becomes +-inf or NaN and is skipped
+  }
 
   double lo = -1, hi = 1;
-  double glo = capbox_g(p, h, size2, lo);
-  double ghi = capbox_g(p, h, size2, hi);
-  const bool at_lo = glo >= 0;
-  const bool at_hi = !at_lo && ghi <= 0;
-  // six face breakpoints in the scalar routine's order (k = 0,1,2; sign = -,+).  The loop is
-  // kept rolled (operands picked with wave-uniform selects) so that the six divisions are not
-  // hoisted and kept live at once: that alone costs ~60 VGPRs.
-#pragma unroll 1
-  for (int i = 0; i < 6; i++) {
-    const int k = i >> 1;
-    const double pk = (k == 0) ? p[0] : ((k == 1) ? p[1] : p[2]);
-    const double hk = (k == 0) ? h[0] : ((k == 1) ? h[1] : h[2]);
-    const double sk = (k == 0) ? size2[0] : ((k == 1) ? size2[1] : size2[2]);
-    const double face = (i & 1) ? sk : -sk;
-    // h[k] == 0 gives tb = +-inf or NaN, which fails the bracket test like the scalar `continue`
-    double tb = (face - pk) / hk;
-    bool inside = (tb > lo && tb < hi);
-    double gb = capbox_g(p, h, size2, tb);
-    bool below = inside && gb <= 0;
-    bool above = inside && !(gb <= 0);
-    lo = below ? tb : lo;
-    glo = below ? gb : glo;
-    hi = above ? tb : hi;
-    ghi = above ? gb : ghi;
+  const double g_m1 = capbox_g(p, h, size2, lo);
+  const double g_p1 = capbox_g(p, h, size2, hi);
+  double glo = g_m1, ghi = g_p1;
+  // six face breakpoints in the scalar routine's order (k = 0,1,2; minus before plus)
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+      double tb = (sgn * size2[k] - p[k]) * inv[k];
+      bool inside = (tb > lo && tb < hi);
+      double gb = capbox_g(p, h, size2, tb);
+      bool below = inside && gb <= 0;
+      bool above = inside && !(gb <= 0);
+      lo = below ? tb : lo;
+      glo = below ? gb : glo;
+      hi = above ? tb : hi;
+      ghi = above ? gb : ghi;
+    }
   }
   double den = ghi - glo;
   double t = (den > 0) ? lo + (hi - lo) * ((0 - glo) / den) : lo;
-  t = at_lo ? -1.0 : (at_hi ? 1.0 : t);
+  t = (g_m1 >= 0) ? -1.0 : ((g_p1 <= 0) ? 1.0 : t);
   double c[3] = {p[0] + t * h[0], p[1] + t * h[1], p[2] + t * h[2]};
   return sphere_box_local(margin, c, size1[0], size2);
 }
@@ -486,22 +484,30 @@ struct SlotFile {
 // selected address and the file ends up in scratch memory.)
 #define MJPL_FOR_SLOTS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define MJPL_SLOT_PUT(n)                                                          \
-  if constexpr (MAXS > n) {                                                       \
-    if (slot_ == n) {                                                             \
+  case n:                                                                         \
+    if constexpr (MAXS > n) {                                                     \
       sf.v[n][0] = t6[0]; sf.v[n][1] = t6[1]; sf.v[n][2] = t6[2];                 \
       sf.v[n][3] = t6[3]; sf.v[n][4] = t6[4]; sf.v[n][5] = t6[5];                 \
     }                                                                             \
-  }
+    break;
 #define MJPL_SLOT_GET(n)                                                          \
-  if constexpr (MAXS > n) {                                                       \
-    if (slot_ == n) {                                                             \
+  case n:                                                                         \
+    if constexpr (MAXS > n) {                                                     \
       t6[0] = sf.v[n][0]; t6[1] = sf.v[n][1]; t6[2] = sf.v[n][2];                 \
       t6[3] = sf.v[n][3]; t6[4] = sf.v[n][4]; t6[5] = sf.v[n][5];                 \
     }                                                                             \
-  }
+    break;
 // A sphere/capsule occupies one slot (pos, z axis); a box a second one (x and y axes).
 // Slot ids are packed as  first | (second << 6), second == SLOT_NONE when unused.
 enum : int { SLOT_NONE = 63 };
+
+// Optimisation barrier: makes the compiler treat a per-lane value as redefined here, so that
+// expressions of it are not hoisted out of the partner loops (loop-invariant code motion of the
+// narrowphase prologues costs tens of VGPRs that stay live across the whole loop).
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin_geom(Geom &g) {
+  pin(g.pos[0]); pin(g.pos[1]); pin(g.pos[2]); pin(g.m[2]); pin(g.m[5]); pin(g.m[8]);
+}
 
 // control words are wave-uniform: pin them to SGPRs so the interpreter's branches are scalar
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -694,7 +700,11 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
         // The cull part of the NEXT enabled row (64 B) and its bound are requested, without a
         // branch, before the current row is tested, so that the scalar-load round trip of a
         // pair overlaps the previous pair's arithmetic.
+#ifdef MJPL_X_SKIP_WORLD
+        unsigned long long wmask = 0;
+#else
         unsigned long long wmask = wmask_all;
+#endif
         int w = wmask ? (int)__builtin_ctzll(wmask) : 0;
         DP rn = world + w * W_LEN;
         double nx_pos[3] = {rn[W_POS], rn[W_POS + 1], rn[W_POS + 2]};
@@ -718,11 +728,16 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
 
           const int ptype = info & 255;
           __builtin_assume(ptype != GT_PLANE);
+          pin_geom(cur);
           // bounding cull (mj_collideSphere): squared centre distance; (a-b)^2 == (b-a)^2 exactly,
           // so the pair order does not matter
           double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
           const bool pass = !(dot3(dif, dif) > bound) && active && !hit;
           if (__ballot(pass) == 0ull) continue;  // nobody in the wave needs the narrowphase
+#ifdef MJPL_X_SKIP_NARROW
+          hit = hit || (pass && dif[0] == 12345.0);
+          continue;
+#endif
 
           DP r = world + wc * W_LEN;
           const double psize[3] = {r[W_SIZE], r[W_SIZE + 1], r[W_SIZE + 2]};
@@ -742,28 +757,44 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
 
         // ---- earlier moving partners, held in the register slot file
         DP sd = gd + GD_WBOUND + 2 * nworld;
+        // same software pipeline as above: word and bound of the next entry are in flight
+        // while the current one is tested (entry 0 of the next geom record is harmless to read)
+        int nx_pw = ip[pc];
+        double nx_sb = sd[SD_BOUND];
+#ifdef MJPL_X_SKIP_STORED
+        for (int e = 0; e < 0; e++, sd += SD_LEN) {
+#else
         for (int e = 0; e < nstored; e++, sd += SD_LEN) {
-          const int pw = uni(ip[pc + e]);
+#endif
+          const int pw = uni(nx_pw);
+          const double sbound = nx_sb;
+          nx_pw = ip[pc + e + 1];
+          nx_sb = sd[SD_LEN + SD_BOUND];
           const int ptype = (pw >> 12) & 15;
           const bool pfirst = (pw & P_FIRST) != 0;
+          pin_geom(cur);
           Geom par;
           {
             double t6[6] = {0, 0, 0, 0, 0, 0};
             const int slot_ = pw & 63;
-            MJPL_FOR_SLOTS(MJPL_SLOT_GET)
+            switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_GET) default: break; }
             par.pos[0] = t6[0]; par.pos[1] = t6[1]; par.pos[2] = t6[2];
             par.m[2] = t6[3]; par.m[5] = t6[4]; par.m[8] = t6[5];
           }
           double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
-          const bool pass = !(dot3(dif, dif) > sd[SD_BOUND]) && active && !hit;
+          const bool pass = !(dot3(dif, dif) > sbound) && active && !hit;
           if (__ballot(pass) == 0ull) continue;
+#ifdef MJPL_X_SKIP_NARROW
+          hit = hit || (pass && dif[0] == 12345.0);
+          continue;
+#endif
 
           const double psize[3] = {sd[SD_SIZE], sd[SD_SIZE + 1], sd[SD_SIZE + 2]};
           {
             double t6[6] = {0, 0, 0, 0, 0, 0};
             if (MBOX && ((pw >> 6) & 63) != SLOT_NONE) {  // stored box: x and y axes
               const int slot_ = (pw >> 6) & 63;
-              MJPL_FOR_SLOTS(MJPL_SLOT_GET)
+              switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_GET) default: break; }
             }
             par.m[0] = t6[0]; par.m[3] = t6[1]; par.m[6] = t6[2];
             par.m[1] = t6[3]; par.m[4] = t6[4]; par.m[7] = t6[5];
@@ -778,12 +809,12 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
         {
           const double t6[6] = {cur.pos[0], cur.pos[1], cur.pos[2], cur.m[2], cur.m[5], cur.m[8]};
           const int slot_ = store & 63;
-          MJPL_FOR_SLOTS(MJPL_SLOT_PUT)
+          switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_PUT) default: break; }
         }
         if (MBOX && ((store >> 6) & 63) != SLOT_NONE) {
           const double t6[6] = {cur.m[0], cur.m[3], cur.m[6], cur.m[1], cur.m[4], cur.m[7]};
           const int slot_ = (store >> 6) & 63;
-          MJPL_FOR_SLOTS(MJPL_SLOT_PUT)
+          switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_PUT) default: break; }
         }
       }
     }

@@ -603,6 +603,10 @@ int compile_program(mjpl_engine *e) {
     ip[base + B_NGEOM] = ngeom_here;
   }
 
+  // the kernels prefetch one entry past the one they test: keep that read inside the tables
+  ip.insert(ip.end(), 16, 0);
+  dp.insert(dp.end(), 16, 0.0);
+
   // ---- upload
   if (e->d_ip) (void)hipFree(e->d_ip);
   if (e->d_dp) (void)hipFree(e->d_dp);

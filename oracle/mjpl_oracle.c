@@ -373,7 +373,7 @@ static double capbox_g(const double *p, const double *h, const double *s, double
   double g = 0;
   for (int k = 0; k < 3; k++) {
     double x = p[k] + t * h[k];
-    double e = x - clipd(x, -s[k], s[k]);
+    double e = x - fmin(fmax(x, -s[k]), s[k]);
     g = g + h[k] * e;
   }
   return g;
@@ -383,37 +383,34 @@ static int capsule_box(double margin, const double *pos1, const double *mat1,
                        const double *size1, const double *pos2, const double *mat2,
                        const double *size2) {
   double tmp[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
-  double p[3], a[3], h[3];
+  double p[3], a[3], h[3], inv[3];
   double axis[3] = {mat1[2], mat1[5], mat1[8]};
   mul_matT_vec3(p, mat2, tmp);
   mul_matT_vec3(a, mat2, axis);
-  h[0] = a[0] * size1[1]; h[1] = a[1] * size1[1]; h[2] = a[2] * size1[1];
+  for (int k = 0; k < 3; k++) {
+    h[k] = a[k] * size1[1];
+    inv[k] = 1 / h[k]; /* h == 0: +-inf, the breakpoint becomes +-inf or NaN and is skipped */
+  }
 
   double lo = -1, hi = 1;
   double glo = capbox_g(p, h, size2, lo);
   double ghi = capbox_g(p, h, size2, hi);
-  double t;
-  if (glo >= 0) {
-    t = -1;
-  } else if (ghi <= 0) {
-    t = 1;
-  } else {
-    for (int k = 0; k < 3; k++) {
-      if (h[k] == 0) continue;
-      for (int sgn = -1; sgn <= 1; sgn += 2) {
-        double tb = (sgn * size2[k] - p[k]) / h[k];
-        if (!(tb > lo && tb < hi)) continue;
-        double gb = capbox_g(p, h, size2, tb);
-        if (gb <= 0) {
-          lo = tb; glo = gb;
-        } else {
-          hi = tb; ghi = gb;
-        }
-      }
+  /* the six face breakpoints t = (+-s_k - p_k)/h_k, k = 0,1,2, minus before plus */
+  for (int k = 0; k < 3; k++) {
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+      double tb = (sgn * size2[k] - p[k]) * inv[k];
+      int inside = (tb > lo && tb < hi);
+      double gb = capbox_g(p, h, size2, tb);
+      if (inside && gb <= 0) { lo = tb; glo = gb; }
+      if (inside && !(gb <= 0)) { hi = tb; ghi = gb; }
     }
-    double den = ghi - glo;
-    t = (den > 0) ? lo + (hi - lo) * ((0 - glo) / den) : lo;
   }
+  double den = ghi - glo;
+  double t = (den > 0) ? lo + (hi - lo) * ((0 - glo) / den) : lo;
+  /* minimum at an end of the segment (decided on the values at -1 and +1) */
+  double g_m1 = capbox_g(p, h, size2, -1), g_p1 = capbox_g(p, h, size2, 1);
+  if (g_m1 >= 0) t = -1;
+  else if (g_p1 <= 0) t = 1;
   double c[3] = {p[0] + t * h[0], p[1] + t * h[1], p[2] + t * h[2]};
   return sphere_box_local(margin, c, size1[0], size2);
 }
