@@ -5,12 +5,13 @@ planner plug-in surface.  The compute path is ``libmjpl_hip.so``
 from .constraint import (CollisionConstraint, CollisionRuleset, Constraint, JointLimitConstraint,
                          apply_constraints, obeys_constraints)
 from .model import Model, ModelBuilder, load_mjcf, parse_mjcf
-from .planning import RRT, Node, Tree, path_length, smooth_path
+from .planning import (RRT, EdgeValidator, HipEdgeValidator, Node, ParallelBiRRT, Tree, path_length,
+                       smooth_path)
 from .utils import all_joints, qpos_idx, qvel_idx, random_config
 
 __all__ = (
     "CollisionConstraint", "CollisionRuleset", "Constraint", "JointLimitConstraint",
     "apply_constraints", "obeys_constraints", "Model", "ModelBuilder", "load_mjcf", "parse_mjcf",
-    "RRT", "Node", "Tree", "path_length", "smooth_path",
+    "RRT", "Node", "Tree", "path_length", "smooth_path", "ParallelBiRRT", "EdgeValidator", "HipEdgeValidator",
     "all_joints", "qpos_idx", "qvel_idx", "random_config",
 )

@@ -1,0 +1,263 @@
+"""Frontier-sharded bi-directional RRT (BASELINE config 4).
+
+The reference grows its two trees one candidate edge at a time (rrt.py:195-235,
+planning/utils.py:139-164).  Here every rank draws its own batch of samples per round, runs
+the reference's extend loop on all of its lanes at once -- each step of every lane is one
+row of a single batched edge validation -- and the new nodes of all ranks are exchanged once
+per round with ONE all-gather of a fixed-size slab (RCCL over xGMI on GPUs, gloo in the CPU
+tests).  Every rank appends the slabs in rank order, so all ranks hold bit-identical trees
+and node ids; the first connection in (rank, lane) order wins on every rank.
+
+Per-edge accept/stop rules are those of ``_constrained_extend`` for constraints that do not
+project (joint limits + collision): stop when the step is invalid, when it moves less than
+1e-8, when it does not approach the target, or when the interval check fails.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .. import utils as _utils
+
+
+class EdgeValidator:
+    """What the planner needs from a collision backend: ``valid_edges(QA, QB, step)`` over
+    planning columns -> bool[N] (endpoint QB + interior waypoints; ``step=None`` = endpoint only)."""
+
+    def valid_edges(self, QA: np.ndarray, QB: np.ndarray, step: float | None) -> np.ndarray:
+        raise NotImplementedError
+
+
+class HipEdgeValidator(EdgeValidator):
+    """mjpl_amd.CollisionConstraint behind the EdgeValidator interface."""
+
+    def __init__(self, constraint, qidx, qpos_base):
+        self.c = constraint
+        self.c.set_planning(qidx, qpos_base)
+
+    def valid_edges(self, QA, QB, step):
+        if step is None:
+            return self.c.valid_configs_planning(QB)
+        return self.c.valid_edges_planning(QA, QB, step)
+
+
+def _row_norm(d: np.ndarray) -> np.ndarray:
+    return np.sqrt(np.einsum("ij,ij->i", d, d))
+
+
+class ParallelBiRRT:
+    def __init__(self, model, planning_joints: list[str], validator: EdgeValidator, q_template: np.ndarray,
+                 epsilon: float = 0.05, interval_step: float | None = None, seed: int = 0,
+                 goal_biasing_probability: float = 0.05, batch: int = 256, max_rounds: int = 1000,
+                 max_planning_time: float = 10.0, max_new_per_round: int = 1 << 20, group=None):
+        if not planning_joints:
+            raise ValueError("`planning_joints` cannot be empty.")
+        if epsilon <= 0.0:
+            raise ValueError("`epsilon` must be > 0.0")
+        if not 0.0 <= goal_biasing_probability <= 1.0:
+            raise ValueError("`goal_biasing_probability` must be within [0.0, 1.0].")
+        if batch <= 0 or max_rounds <= 0 or max_planning_time <= 0.0:
+            raise ValueError("`batch`, `max_rounds` and `max_planning_time` must be > 0")
+        self.model = model
+        self.qidx = np.asarray(_utils.qpos_idx(model, planning_joints), dtype=np.int64)
+        self.validator = validator
+        self.q_template = np.asarray(q_template, dtype=np.float64).copy()
+        self.eps, self.interval_step = float(epsilon), interval_step
+        self.seed, self.p_goal = int(seed), float(goal_biasing_probability)
+        self.batch, self.max_rounds, self.max_time = int(batch), int(max_rounds), float(max_planning_time)
+        self.slab_rows = int(max_new_per_round)
+        self.lo = np.asarray(model.jnt_range[self.qidx, 0], dtype=np.float64)
+        self.hi = np.asarray(model.jnt_range[self.qidx, 1], dtype=np.float64)
+        self.group = group
+        self.rank, self.world = 0, 1
+        if group is not None:
+            import torch.distributed as dist
+            self._dist = dist
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.stats = {}
+
+    # ------------------------------------------------------------------ replicated tree store
+    def _reset(self, q_init_p, q_goal_p):
+        n = len(self.qidx)
+        self.Q = np.empty((1024, n))
+        self.parent = np.empty(1024, np.int64)
+        self.tree = np.empty(1024, np.int8)
+        self.n = 0
+        self.index: dict[bytes, int] = {}
+        self._append(q_init_p, -1, 0)
+        self._append(q_goal_p, -1, 1)
+
+    def _append(self, q, parent, tree) -> int:
+        key = q.tobytes() + bytes([tree])
+        hit = self.index.get(key)
+        if hit is not None:
+            return hit
+        if self.n == len(self.Q):
+            self.Q = np.concatenate([self.Q, np.empty_like(self.Q)])
+            self.parent = np.concatenate([self.parent, np.empty_like(self.parent)])
+            self.tree = np.concatenate([self.tree, np.empty_like(self.tree)])
+        i = self.n
+        self.Q[i], self.parent[i], self.tree[i] = q, parent, tree
+        self.index[key] = i
+        self.n += 1
+        return i
+
+    def _nearest(self, targets, tree):
+        ids = np.flatnonzero(self.tree[: self.n] == tree)
+        nodes = self.Q[ids]
+        out = np.empty(len(targets), np.int64)
+        for s in range(0, len(targets), 256):  # chunked [chunk, n_tree] distance matrix
+            t = targets[s:s + 256]
+            d2 = (np.einsum("ij,ij->i", t, t)[:, None] - 2.0 * t @ nodes.T
+                  + np.einsum("ij,ij->i", nodes, nodes)[None, :])
+            out[s:s + 256] = ids[np.argmin(d2, axis=1)]
+        return out
+
+    # ------------------------------------------------------------------ batched extend
+    def _extend(self, targets, tree, pending):
+        """Reference extend loop on every lane at once.  ``pending`` collects this rank's new
+        nodes as (q, parent_ref, tree): parent_ref >= 0 is a global node id, < 0 refers to
+        pending[-1 - parent_ref].  Returns (q_reached, ref_reached) per lane."""
+        B = len(targets)
+        near = self._nearest(targets, tree)
+        cur = self.Q[near].copy()
+        ref = near.copy()
+        active = ~np.all(cur == targets, axis=1)
+        pend_index: dict[bytes, int] = {}
+        while active.any():
+            a = np.flatnonzero(active)
+            d = targets[a] - cur[a]
+            dist = _row_norm(d)
+            q_new = cur[a] + d / dist[:, None] * np.minimum(self.eps, dist)[:, None]
+            reach = np.all(q_new == targets[a], axis=1) | (dist <= self.eps)
+            q_new[reach] = targets[a][reach]  # `_step` lands on the target within one step
+            ok = np.all((q_new >= self.lo) & (q_new <= self.hi), axis=1)
+            moved = _row_norm(q_new - cur[a])
+            ok &= ~(moved < 1e-8)
+            ok &= ~(_row_norm(targets[a] - q_new) > dist)
+            if ok.any():
+                sel = np.flatnonzero(ok)
+                ok[sel] = self.validator.valid_edges(cur[a][sel], q_new[sel], self.interval_step)
+            for k in np.flatnonzero(ok):
+                lane = a[k]
+                key = q_new[k].tobytes() + bytes([tree])
+                gid = self.index.get(key)
+                if gid is not None:
+                    new_ref = gid
+                elif key in pend_index:
+                    new_ref = pend_index[key]
+                else:
+                    pending.append((q_new[k].copy(), int(ref[lane]), tree))
+                    new_ref = -len(pending)
+                    pend_index[key] = new_ref
+                cur[lane], ref[lane] = q_new[k], new_ref
+            done = ~ok | reach
+            active[a[done]] = False
+        return cur, ref
+
+    # ------------------------------------------------------------------ exchange
+    def _allgather(self, arr: np.ndarray) -> np.ndarray:
+        """[rows, cols] float64 per rank -> [world, rows, cols] (rank order)."""
+        if self.world == 1:
+            return arr[None]
+        import torch
+        dev = "cuda" if self._dist.get_backend(self.group) == "nccl" else "cpu"
+        mine = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        out = torch.empty((self.world * arr.shape[0], arr.shape[1]), dtype=mine.dtype, device=dev)
+        self._dist.all_gather_into_tensor(out, mine, group=self.group)
+        return out.cpu().numpy().reshape((self.world,) + arr.shape)
+
+    def _exchange(self, pending, connection):
+        """One exchange step per round: a 4-double header per rank (count, connection refs, stop
+        flag), then ONE all-gather of the new-node slabs, padded to the round's largest count
+        rounded up to a power of two (few distinct message sizes).  Slabs are merged in rank
+        order on every rank, so node ids are global and identical everywhere."""
+        n = len(self.qidx)
+        head = np.array([[len(pending), np.nan, np.nan, float(time.time() - self._t0 >= self.max_time)]])
+        if connection is not None:
+            head[0, 1:3] = connection
+        heads = self._allgather(head)[:, 0, :]
+        most = int(heads[:, 0].max())
+        if most > self.slab_rows:
+            raise RuntimeError("more new nodes in one round than `max_new_per_round`")
+        rows = 1 << max(most - 1, 0).bit_length() if most else 0
+        slab = np.zeros((max(rows, 1), n + 2))
+        for k, (q, pref, tree) in enumerate(pending):
+            slab[k, :n] = q
+            slab[k, n] = pref
+            slab[k, n + 1] = tree
+        slabs = self._allgather(slab) if rows else np.zeros((self.world, 1, n + 2))
+        winner, stop = None, False
+        for r in range(self.world):
+            cnt = int(heads[r, 0])
+            local_to_global = np.empty(cnt, np.int64)
+            for k in range(cnt):
+                row = slabs[r, k]
+                pref = int(row[n])
+                par = pref if pref >= 0 else int(local_to_global[-1 - pref])
+                local_to_global[k] = self._append(row[:n].copy(), par, int(row[n + 1]))
+            if winner is None and not np.isnan(heads[r, 1]):
+                refs = [int(heads[r, 1]), int(heads[r, 2])]
+                winner = tuple(x if x >= 0 else int(local_to_global[-1 - x]) for x in refs)
+            stop = stop or bool(heads[r, 3])
+        return winner, stop
+
+    # ------------------------------------------------------------------ driver
+    def plan_to_config(self, q_init: np.ndarray, q_goal: np.ndarray) -> list[np.ndarray]:
+        q_init, q_goal = np.asarray(q_init, float), np.asarray(q_goal, float)
+        fixed = np.setdiff1d(np.arange(self.model.nq), self.qidx)
+        if not np.allclose(q_init[fixed], q_goal[fixed], rtol=0, atol=1e-12):
+            raise ValueError("goal config differs from q_init outside of the planning joints")
+        a, b = q_init[self.qidx], q_goal[self.qidx]
+        ends = np.stack([a, b])
+        in_lim = np.all((ends >= self.lo) & (ends <= self.hi), axis=1)
+        if not (in_lim.all() and self.validator.valid_edges(ends, ends, None).all()):
+            raise ValueError("q_init or q_goal is not a valid configuration")
+        if np.linalg.norm(b - a) <= self.eps:
+            return [q_init, q_goal]
+
+        self._reset(a, b)
+        rng = np.random.default_rng(self.seed + 1000003 * self.rank)
+        self._t0 = time.time()
+        winner = None
+        rounds = checks = 0
+        for rounds in range(1, self.max_rounds + 1):
+            grow = (rounds - 1) % 2          # tree swap every round (rrt.py:234-235)
+            other = 1 - grow
+            targets = rng.uniform(self.lo, self.hi, size=(self.batch, len(self.qidx)))
+            bias = rng.random(self.batch) <= self.p_goal
+            targets[bias] = b if grow == 0 else a  # goal bias: the other tree's root
+            pending: list = []
+            reached_a, ref_a = self._extend(targets, grow, pending)
+            reached_b, ref_b = self._extend(reached_a, other, pending)
+            checks += 2 * self.batch
+            hit = np.flatnonzero(np.all(reached_a == reached_b, axis=1))
+            conn = None
+            if len(hit):
+                k = hit[0]
+                conn = (ref_a[k], ref_b[k]) if grow == 0 else (ref_b[k], ref_a[k])
+            winner, stop = self._exchange(pending, conn)
+            if winner is not None or stop:
+                break
+        self.stats = dict(rounds=rounds, nodes=self.n, world=self.world,
+                          seconds=time.time() - self._t0)
+        if winner is None:
+            return []
+        ia, ib = winner  # node in the start tree, node in the goal tree (same configuration)
+        head = []
+        while ia >= 0:
+            head.append(ia)
+            ia = self.parent[ia]
+        tail = []
+        ib = self.parent[ib]  # the junction configuration appears once
+        while ib >= 0:
+            tail.append(ib)
+            ib = self.parent[ib]
+        out = []
+        for i in list(reversed(head)) + tail:
+            q = self.q_template.copy()
+            q[self.qidx] = self.Q[i]
+            out.append(q)
+        out[0], out[-1] = q_init, q_goal
+        return out

@@ -158,3 +158,41 @@ def test_dropin_constraint_and_planner_equivalence(oracle_mod):
     assert gpu_cc.valid_config(q_bad) == cpu_cc.valid_config(q_bad)
     with pytest.raises(ValueError, match="step_dist"):
         gpu_cc.valid_interval(q, q_bad, 0.0)
+
+
+def test_parallel_birrt_hip_matches_oracle_backend(oracle_mod):
+    """BASELINE config 4 shape on one GPU: the frontier planner validated by the HIP engine
+    returns the same path as when validated by the CPU oracle (same seed, same samples)."""
+    from mjpl_amd.planning.parallel_rrt import EdgeValidator
+
+    class OracleValidator(EdgeValidator):
+        def __init__(self, model, qidx, base):
+            self.o = oracle_mod.Oracle(model, planning_qidx=qidx, qpos_base=base)
+
+        def valid_edges(self, QA, QB, step):
+            if step is None:
+                return self.o.valid_configs(QB, nthreads=8).astype(bool)
+            return self.o.valid_edges(QA, QB, step, nthreads=8).astype(bool)
+
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    cpu = OracleValidator(m, qidx, q_init)
+    gpu = mjpl.HipEdgeValidator(mjpl.CollisionConstraint(m), qidx, q_init)
+    rng = np.random.default_rng(11)
+    goals = []
+    while len(goals) < 3:
+        g = q_init.copy()
+        g[qidx] = rng.uniform(m.jnt_range[qidx, 0], m.jnt_range[qidx, 1])
+        if cpu.valid_edges(g[qidx][None], g[qidx][None], None)[0]:
+            goals.append(g)
+    for k, g in enumerate(goals):
+        paths = []
+        for v in (gpu, cpu):
+            p = mjpl.ParallelBiRRT(m, joints, v, q_init, epsilon=0.05, interval_step=0.01, seed=k, batch=256,
+                                   goal_biasing_probability=0.1, max_planning_time=120.0)
+            paths.append(p.plan_to_config(q_init, g))
+        assert len(paths[0]) == len(paths[1]) > 2
+        for a, b in zip(*paths):
+            np.testing.assert_array_equal(a, b)

@@ -1,0 +1,113 @@
+"""Frontier-sharded bi-RRT: single process and world_size-2 over gloo on CPU.
+The collision backend here is the CPU oracle behind the EdgeValidator interface (tests only)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make(world_group=None, seed=1, batch=48):
+    from mjpl_amd import scenes
+    from mjpl_amd.planning.parallel_rrt import EdgeValidator, ParallelBiRRT
+    from oracle import pyoracle
+
+    class OracleValidator(EdgeValidator):
+        def __init__(self, model, qidx, base):
+            self.o = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
+
+        def valid_edges(self, QA, QB, step):
+            if step is None:
+                return self.o.valid_configs(QB, nthreads=2).astype(bool)
+            return self.o.valid_edges(QA, QB, step, nthreads=2).astype(bool)
+
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    v = OracleValidator(m, qidx, q_init)
+    rng = np.random.default_rng(5)
+    while True:
+        g = q_init.copy()
+        g[qidx] = rng.uniform(m.jnt_range[qidx, 0], m.jnt_range[qidx, 1])
+        if v.valid_edges(g[qidx][None], g[qidx][None], None)[0]:
+            break
+    p = ParallelBiRRT(m, joints, v, q_init, epsilon=0.05, interval_step=0.01, seed=seed, batch=batch,
+                      goal_biasing_probability=0.1, max_planning_time=120.0, group=world_group)
+    return m, qidx, v, p, q_init, g
+
+
+def _check_path(m, qidx, v, path, q_init, q_goal, eps=0.05):
+    assert len(path) >= 2
+    np.testing.assert_array_equal(path[0], q_init)
+    np.testing.assert_array_equal(path[-1], q_goal)
+    P = np.array(path)
+    assert np.all(np.linalg.norm(P[1:] - P[:-1], axis=1) <= eps + 1e-12)
+    fixed = np.setdiff1d(np.arange(m.nq), qidx)
+    assert np.all(P[:, fixed] == q_init[fixed])
+    assert v.valid_edges(P[:-1, qidx], P[1:, qidx], 0.01).all()
+
+
+def test_single_process_plan_is_valid_and_deterministic():
+    m, qidx, v, p, q_init, g = _make()
+    path = p.plan_to_config(q_init, g)
+    _check_path(m, qidx, v, path, q_init, g)
+    _, _, _, p2, _, _ = _make()
+    again = p2.plan_to_config(q_init, g)
+    assert len(again) == len(path) and all(np.array_equal(a, b) for a, b in zip(path, again))
+    # every node's parent precedes it and the two trees never mix
+    assert np.all(p.parent[2:p.n] < np.arange(2, p.n))
+    assert np.all(p.tree[p.parent[2:p.n]] == p.tree[2:p.n])
+
+
+def test_argument_validation_and_trivial_goal():
+    m, qidx, v, p, q_init, g = _make()
+    near = q_init.copy()
+    near[qidx[0]] += 0.01
+    assert len(p.plan_to_config(q_init, near)) == 2
+    bad = g.copy()
+    bad[8] += 0.01  # a non-planning joint differs
+    with pytest.raises(ValueError, match="outside of the planning joints"):
+        p.plan_to_config(q_init, bad)
+    out = q_init.copy()
+    out[qidx[1]] = 5.0  # beyond the joint range
+    with pytest.raises(ValueError, match="not a valid configuration"):
+        p.plan_to_config(q_init, out)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, qidx, v, p, q_init, g = _make(world_group=dist.group.WORLD, batch=24)
+        path = p.plan_to_config(q_init, g)
+        _check_path(m, qidx, v, path, q_init, g)
+        q.put((rank, np.array(path).tobytes(), p.n, p.Q[: p.n].tobytes(), p.parent[: p.n].tobytes(), p.stats["world"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_two_gloo_ranks_agree():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, path0, n0, Q0, par0, w0), (r1, path1, n1, Q1, par1, w1) = res
+    assert (r0, r1, w0, w1) == (0, 1, 2, 2)
+    assert path0 == path1, "both ranks must return the same path"
+    assert n0 == n1 and Q0 == Q1 and par0 == par1, "replicated trees must be bit-identical"
