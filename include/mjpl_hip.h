@@ -95,6 +95,8 @@ typedef struct mjpl_info {
   int32_t lds_bytes_edges;   /* dynamic LDS per block, edges kernel                   */
   int32_t block_threads;
   int32_t compute_units;
+  int32_t filter_enabled;    /* float32 filter in front of the exact kernels              */
+  float   filter_tol;        /* its tolerance band, metres                                */
   char    arch[32];          /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"            */
 } mjpl_info;
 
@@ -115,6 +117,16 @@ void mjpl_destroy(mjpl_engine *e);
 int mjpl_set_planning(mjpl_engine *e, const int32_t *qidx, int32_t nplan, const double *qpos_base);
 
 int mjpl_get_info(const mjpl_engine *e, mjpl_info *out);
+
+/* Verdicts are always those of the exact float64 kernels.  By default a float32 FILTER kernel
+ * runs first: the same algorithms in binary32, every comparison against a contact threshold
+ * classified with a tolerance `tol` (metres) as certain / uncertain; only the items it cannot
+ * decide are re-run by the float64 kernel (same stream, no host round trip).  enable = 0
+ * sends everything through the float64 kernels.  Environment overrides at create:
+ * MJPL_FILTER=0|1, MJPL_FILTER_TOL=<metres>. */
+int mjpl_set_filter(mjpl_engine *e, int32_t enable, double tol);
+/* how many items of the most recent launch went to the float64 kernel (synchronises) */
+int64_t mjpl_filter_last_undecided(mjpl_engine *e);
 
 /* ---- host-buffer entry points (stage H2D, run, copy back, synchronise) ---------- */
 

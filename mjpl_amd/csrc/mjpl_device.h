@@ -36,10 +36,23 @@ namespace mjpl {
 #if MJPL_TABLES_LDS
 typedef const int *IP;
 typedef const double *DP;
+typedef const float *FP;
 #else
 typedef const __attribute__((address_space(4))) int *IP;
 typedef const __attribute__((address_space(4))) double *DP;
+typedef const __attribute__((address_space(4))) float *FP;
 #endif
+
+// Scalar type of an instantiation.  double = the exact path (MuJoCo's arithmetic, one rounding
+// per operation; verdicts are final).  float = the FILTER path: the same algorithms in binary32,
+// every comparison against a contact threshold classified with a tolerance into
+// certain-no-contact / certain-contact / uncertain; uncertain items are re-run on the exact path.
+template <class T> struct Real;
+template <> struct Real<double> { static constexpr bool exact = true; typedef DP Tab; };
+template <> struct Real<float> { static constexpr bool exact = false; typedef FP Tab; };
+
+// verdict codes of the narrowphase (the exact path only produces 0 and 1)
+enum : int { V_NONE = 0, V_CONTACT = 1, V_UNSURE = 2 };
 
 // ----------------------------------------------------------------------------- program layout
 // The model is compiled on the host (mjpl_hip.hip: compile_program) into two flat tables that
@@ -93,56 +106,85 @@ enum : int { JT_SLIDE = 2, JT_HINGE = 3 };
 // ----------------------------------------------------------------------------- small math
 // [MJ-recalled: engine_util_blas.c, engine_util_spatial.c]
 
-MJPL_HD double dot3(const double *a, const double *b) {
+template <class T>
+MJPL_HD T dot3(const T *a, const T *b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 
-MJPL_HD void mul_mat_vec3(double *res, const double *mat, const double *vec) {
+template <class T>
+MJPL_HD void mul_mat_vec3(T *res, const T *mat, const T *vec) {
   res[0] = mat[0] * vec[0] + mat[1] * vec[1] + mat[2] * vec[2];
   res[1] = mat[3] * vec[0] + mat[4] * vec[1] + mat[5] * vec[2];
   res[2] = mat[6] * vec[0] + mat[7] * vec[1] + mat[8] * vec[2];
 }
 
-MJPL_HD void mul_matT_vec3(double *res, const double *mat, const double *vec) {
+template <class T>
+MJPL_HD void mul_matT_vec3(T *res, const T *mat, const T *vec) {
   res[0] = mat[0] * vec[0] + mat[3] * vec[1] + mat[6] * vec[2];
   res[1] = mat[1] * vec[0] + mat[4] * vec[1] + mat[7] * vec[2];
   res[2] = mat[2] * vec[0] + mat[5] * vec[1] + mat[8] * vec[2];
 }
 
-MJPL_HD void mul_quat(double *res, const double *a, const double *b) {
-  double t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-  double t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-  double t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-  double t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+template <class T>
+MJPL_HD void mul_quat(T *res, const T *a, const T *b) {
+  T t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  T t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  T t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  T t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
   res[0] = t0; res[1] = t1; res[2] = t2; res[3] = t3;
 }
 
-MJPL_HD void rot_vec_quat(double *res, const double *vec, const double *quat) {
-  double t0 = quat[0] * vec[0] + quat[2] * vec[2] - quat[3] * vec[1];
-  double t1 = quat[0] * vec[1] + quat[3] * vec[0] - quat[1] * vec[2];
-  double t2 = quat[0] * vec[2] + quat[1] * vec[1] - quat[2] * vec[0];
-  double r0 = vec[0] + 2 * (quat[2] * t2 - quat[3] * t1);
-  double r1 = vec[1] + 2 * (quat[3] * t0 - quat[1] * t2);
-  double r2 = vec[2] + 2 * (quat[1] * t1 - quat[2] * t0);
+template <class T>
+MJPL_HD void rot_vec_quat(T *res, const T *vec, const T *quat) {
+  T t0 = quat[0] * vec[0] + quat[2] * vec[2] - quat[3] * vec[1];
+  T t1 = quat[0] * vec[1] + quat[3] * vec[0] - quat[1] * vec[2];
+  T t2 = quat[0] * vec[2] + quat[1] * vec[1] - quat[2] * vec[0];
+  T r0 = vec[0] + 2 * (quat[2] * t2 - quat[3] * t1);
+  T r1 = vec[1] + 2 * (quat[3] * t0 - quat[1] * t2);
+  T r2 = vec[2] + 2 * (quat[1] * t1 - quat[2] * t0);
   res[0] = r0; res[1] = r1; res[2] = r2;
 }
 
-MJPL_HD void normalize4(double *v) {
-  double norm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-  bool tiny = norm < MJPL_MINVAL;
-  bool scale = fabs(norm - 1) > MJPL_MINVAL;
-  double inv = 1 / norm;
-  double s0 = v[0] * inv, s1 = v[1] * inv, s2 = v[2] * inv, s3 = v[3] * inv;
-  v[0] = tiny ? 1.0 : (scale ? s0 : v[0]);
-  v[1] = tiny ? 0.0 : (scale ? s1 : v[1]);
-  v[2] = tiny ? 0.0 : (scale ? s2 : v[2]);
-  v[3] = tiny ? 0.0 : (scale ? s3 : v[3]);
+// a / b: IEEE division on the exact path, reciprocal-multiply (v_rcp_f32, 1 ulp) on the filter
+template <class T>
+MJPL_HD T rdiv(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (!Real<T>::exact) return a * __builtin_amdgcn_rcpf(b);
+#endif
+  return a / b;
 }
 
-MJPL_HD void quat2mat(double *res, const double *q) {
-  const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
-  const double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
-  const double q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+template <class T>
+MJPL_HD T rsqrt_val(T x) {  // sqrt: correctly rounded on the exact path, v_sqrt_f32 on the filter
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (!Real<T>::exact) return __builtin_amdgcn_sqrtf(x);
+#endif
+  return sqrt(x);
+}
+
+template <class T>
+MJPL_HD void normalize4(T *v) {
+  T norm = rsqrt_val(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+  if constexpr (Real<T>::exact) {
+    bool tiny = norm < MJPL_MINVAL;
+    bool scale = fabs(norm - 1) > MJPL_MINVAL;
+    T inv = 1 / norm;
+    T s0 = v[0] * inv, s1 = v[1] * inv, s2 = v[2] * inv, s3 = v[3] * inv;
+    v[0] = tiny ? T(1) : (scale ? s0 : v[0]);
+    v[1] = tiny ? T(0) : (scale ? s1 : v[1]);
+    v[2] = tiny ? T(0) : (scale ? s2 : v[2]);
+    v[3] = tiny ? T(0) : (scale ? s3 : v[3]);
+  } else {
+    T inv = rdiv(T(1), norm);  // always rescale: the two thresholds are far below the tolerance
+    v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+  }
+}
+
+template <class T>
+MJPL_HD void quat2mat(T *res, const T *q) {
+  const T q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  const T q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
+  const T q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
   res[0] = q00 + q11 - q22 - q33;
   res[4] = q00 - q11 + q22 - q33;
   res[8] = q00 - q11 - q22 + q33;
@@ -155,191 +197,226 @@ MJPL_HD void quat2mat(double *res, const double *q) {
 }
 
 // third column of quat2mat only (capsule axis); same expressions as res[2], res[5], res[8]
-MJPL_HD void quat2zaxis(double *m, const double *q) {
-  const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2];
-  const double q11 = q[1] * q[1], q13 = q[1] * q[3];
-  const double q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+template <class T>
+MJPL_HD void quat2zaxis(T *m, const T *q) {
+  const T q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2];
+  const T q11 = q[1] * q[1], q13 = q[1] * q[3];
+  const T q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
   m[2] = 2 * (q13 + q02);
   m[5] = 2 * (q23 - q01);
   m[8] = q00 - q11 - q22 + q33;
 }
 
-MJPL_HD double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+template <class T>
+MJPL_HD T clipd(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// classify a surplus s = (distance) - (contact threshold): contact iff s <= 0 on the exact path
+template <class T>
+MJPL_HD int classify(T s, T tol) {
+  if constexpr (Real<T>::exact) return !(s > 0) ? V_CONTACT : V_NONE;
+  return s > tol ? V_NONE : (s < -tol ? V_CONTACT : V_UNSURE);
+}
+MJPL_HD int v_or(int a, int b) {  // "any contact" over several tests
+  return (a == V_CONTACT || b == V_CONTACT) ? V_CONTACT : ((a == V_UNSURE || b == V_UNSURE) ? V_UNSURE : V_NONE);
+}
 
 // ----------------------------------------------------------------------------- narrowphase
 // Verdict-only ("ncon > 0") primitives.  [MJ-recalled: engine_collision_primitive.c,
 // engine_collision_box.c]; capsule-box / box-box follow the oracle's documented deviations.
 // A geom is (pos[3], m[9]) with m row-major; capsules use only the z column m[2],m[5],m[8].
+// Every routine returns V_NONE / V_CONTACT, plus V_UNSURE on the filter path (T = float) when
+// the decision lies inside the tolerance band or the computation is ill-conditioned.
 
-struct Geom {
-  double pos[3];
-  double m[9];
+template <class T>
+struct GeomT {
+  T pos[3];
+  T m[9];
 };
 
-MJPL_HD bool sphere_sphere(double margin, const double *pos1, double r1, const double *pos2,
-                           double r2) {
-  double dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
-  double cdist_sqr = dot3(dif, dif);
-  double min_dist = margin + r1 + r2;
-  return !(cdist_sqr > min_dist * min_dist);
+template <class T>
+MJPL_HD int sphere_sphere(T margin, const T *pos1, T r1, const T *pos2, T r2, T tol) {
+  T dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  T cdist_sqr = dot3(dif, dif);
+  T min_dist = margin + r1 + r2;
+  if constexpr (Real<T>::exact) return !(cdist_sqr > min_dist * min_dist) ? V_CONTACT : V_NONE;
+  return classify(rsqrt_val(cdist_sqr) - min_dist, tol);
 }
 
-MJPL_HD bool plane_sphere(double margin, const Geom &pl, const double *pos2, double r2) {
-  double n[3] = {pl.m[2], pl.m[5], pl.m[8]};
-  double tmp[3] = {pos2[0] - pl.pos[0], pos2[1] - pl.pos[1], pos2[2] - pl.pos[2]};
-  double cdist = dot3(tmp, n);
-  return !(cdist > margin + r2);
+template <class T>
+MJPL_HD int plane_sphere(T margin, const GeomT<T> &pl, const T *pos2, T r2, T tol) {
+  T n[3] = {pl.m[2], pl.m[5], pl.m[8]};
+  T tmp[3] = {pos2[0] - pl.pos[0], pos2[1] - pl.pos[1], pos2[2] - pl.pos[2]};
+  T cdist = dot3(tmp, n);
+  if constexpr (Real<T>::exact) return !(cdist > margin + r2) ? V_CONTACT : V_NONE;
+  return classify(cdist - (margin + r2), tol);
 }
 
-MJPL_HD bool plane_capsule(double margin, const Geom &pl, const Geom &cap, const double *size2) {
-  double seg[3] = {size2[1] * cap.m[2], size2[1] * cap.m[5], size2[1] * cap.m[8]};
-  double e1[3] = {cap.pos[0] + seg[0], cap.pos[1] + seg[1], cap.pos[2] + seg[2]};
-  double e2[3] = {cap.pos[0] - seg[0], cap.pos[1] - seg[1], cap.pos[2] - seg[2]};
-  bool n1 = plane_sphere(margin, pl, e1, size2[0]);
-  bool n2 = plane_sphere(margin, pl, e2, size2[0]);
-  return n1 || n2;
+template <class T>
+MJPL_HD int plane_capsule(T margin, const GeomT<T> &pl, const GeomT<T> &cap, const T *size2, T tol) {
+  T seg[3] = {size2[1] * cap.m[2], size2[1] * cap.m[5], size2[1] * cap.m[8]};
+  T e1[3] = {cap.pos[0] + seg[0], cap.pos[1] + seg[1], cap.pos[2] + seg[2]};
+  T e2[3] = {cap.pos[0] - seg[0], cap.pos[1] - seg[1], cap.pos[2] - seg[2]};
+  return v_or(plane_sphere(margin, pl, e1, size2[0], tol), plane_sphere(margin, pl, e2, size2[0], tol));
 }
 
-MJPL_HD bool plane_box(double margin, const Geom &pl, const Geom &box, const double *size2) {
-  double norm[3] = {pl.m[2], pl.m[5], pl.m[8]};
-  double dif[3] = {box.pos[0] - pl.pos[0], box.pos[1] - pl.pos[1], box.pos[2] - pl.pos[2]};
-  double dist = dot3(dif, norm);
-  bool any = false;
+template <class T>
+MJPL_HD int plane_box(T margin, const GeomT<T> &pl, const GeomT<T> &box, const T *size2, T tol) {
+  T norm[3] = {pl.m[2], pl.m[5], pl.m[8]};
+  T dif[3] = {box.pos[0] - pl.pos[0], box.pos[1] - pl.pos[1], box.pos[2] - pl.pos[2]};
+  T dist = dot3(dif, norm);
+  int res = V_NONE;
   // rolled on purpose: unrolling the 8 corners keeps ~40 extra VGPRs live
 #pragma unroll 1
   for (int i = 0; i < 8; i++) {
-    double vec[3], corner[3];
+    T vec[3], corner[3];
     vec[0] = (i & 1) ? size2[0] : -size2[0];
     vec[1] = (i & 2) ? size2[1] : -size2[1];
     vec[2] = (i & 4) ? size2[2] : -size2[2];
     mul_mat_vec3(corner, box.m, vec);
-    double ldist = dot3(norm, corner);
-    any = any || !(dist + ldist > margin || ldist > 0);
+    T ldist = dot3(norm, corner);
+    if constexpr (Real<T>::exact) {
+      res = (res == V_CONTACT || !(dist + ldist > margin || ldist > 0)) ? V_CONTACT : V_NONE;
+    } else {
+      // a corner counts iff it is below the centre (ldist <= 0) and within the margin
+      const bool sure_out = (dist + ldist - margin > tol) || (ldist > tol);
+      const bool sure_in = (dist + ldist - margin < -tol) && (ldist < -tol);
+      res = v_or(res, sure_in ? V_CONTACT : (sure_out ? V_NONE : V_UNSURE));
+    }
   }
-  return any;
+  return res;
 }
 
-MJPL_HD bool sphere_capsule(double margin, const double *pos1, double r1, const Geom &cap,
-                            const double *size2) {
-  double len = size2[1];
-  double axis[3] = {cap.m[2], cap.m[5], cap.m[8]};
-  double vec[3] = {pos1[0] - cap.pos[0], pos1[1] - cap.pos[1], pos1[2] - cap.pos[2]};
-  double x = clipd(dot3(axis, vec), -len, len);
+template <class T>
+MJPL_HD int sphere_capsule(T margin, const T *pos1, T r1, const GeomT<T> &cap, const T *size2, T tol) {
+  T len = size2[1];
+  T axis[3] = {cap.m[2], cap.m[5], cap.m[8]};
+  T vec[3] = {pos1[0] - cap.pos[0], pos1[1] - cap.pos[1], pos1[2] - cap.pos[2]};
+  T x = clipd(dot3(axis, vec), -len, len);
   vec[0] = axis[0] * x + cap.pos[0];
   vec[1] = axis[1] * x + cap.pos[1];
   vec[2] = axis[2] * x + cap.pos[2];
-  return sphere_sphere(margin, pos1, r1, vec, size2[0]);
+  return sphere_sphere(margin, pos1, r1, vec, size2[0], tol);
 }
 
-__device__ __forceinline__ bool capsule_capsule(double margin, const Geom &c1, const double *size1,
-                                                const Geom &c2, const double *size2) {
-  double axis1[3] = {c1.m[2] * size1[1], c1.m[5] * size1[1], c1.m[8] * size1[1]};
-  double axis2[3] = {c2.m[2] * size2[1], c2.m[5] * size2[1], c2.m[8] * size2[1]};
-  double dif[3] = {c1.pos[0] - c2.pos[0], c1.pos[1] - c2.pos[1], c1.pos[2] - c2.pos[2]};
-  double ma = dot3(axis1, axis1);
-  double mb = -dot3(axis1, axis2);
-  double mc = dot3(axis2, axis2);
-  double u = -dot3(axis1, dif);
-  double v = dot3(axis2, dif);
-  double det = ma * mc - mb * mb;
-  double vec1[3], vec2[3];
-  bool general = fabs(det) >= MJPL_MINVAL;
-  bool res = false;
+template <class T>
+__device__ __forceinline__ int capsule_capsule(T margin, const GeomT<T> &c1, const T *size1,
+                                               const GeomT<T> &c2, const T *size2, T tol) {
+  T axis1[3] = {c1.m[2] * size1[1], c1.m[5] * size1[1], c1.m[8] * size1[1]};
+  T axis2[3] = {c2.m[2] * size2[1], c2.m[5] * size2[1], c2.m[8] * size2[1]};
+  T dif[3] = {c1.pos[0] - c2.pos[0], c1.pos[1] - c2.pos[1], c1.pos[2] - c2.pos[2]};
+  T ma = dot3(axis1, axis1);
+  T mb = -dot3(axis1, axis2);
+  T mc = dot3(axis2, axis2);
+  T u = -dot3(axis1, dif);
+  T v = dot3(axis2, dif);
+  T det = ma * mc - mb * mb;
+  T vec1[3], vec2[3];
+  int res = V_NONE;
 
+  if constexpr (!Real<T>::exact) {
+    // The closest-point parameters are ill-conditioned for nearly parallel axes (and the exact
+    // path has its own branch there): leave those pairs, and degenerate capsules, to it.
+    if (!(det > T(1e-3) * ma * mc)) return V_UNSURE;
+  }
+  const bool general = Real<T>::exact ? (fabs(det) >= T(MJPL_MINVAL)) : true;
   if (general) {
     // same divisions as the scalar routine, sign-selected numerators instead of branches
-    double x1 = (mc * u - mb * v) / det;
-    double x2 = (ma * v - mb * u) / det;
+    T x1 = rdiv(mc * u - mb * v, det);
+    T x2 = rdiv(ma * v - mb * u, det);
     bool hi1 = x1 > 1, lo1 = x1 < -1;
-    double x2c = (hi1 ? (v - mb) : (v + mb)) / mc;
-    x1 = hi1 ? 1.0 : (lo1 ? -1.0 : x1);
+    T x2c = rdiv(hi1 ? (v - mb) : (v + mb), mc);
+    x1 = hi1 ? T(1) : (lo1 ? T(-1) : x1);
     x2 = (hi1 || lo1) ? x2c : x2;
     bool hi2 = x2 > 1, lo2 = x2 < -1;
-    double x1c = clipd((hi2 ? (u - mb) : (u + mb)) / ma, -1, 1);
-    x2 = hi2 ? 1.0 : (lo2 ? -1.0 : x2);
+    T x1c = clipd(rdiv(hi2 ? (u - mb) : (u + mb), ma), T(-1), T(1));
+    x2 = hi2 ? T(1) : (lo2 ? T(-1) : x2);
     x1 = (hi2 || lo2) ? x1c : x1;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       vec1[k] = c1.pos[k] + axis1[k] * x1;
       vec2[k] = c2.pos[k] + axis2[k] * x2;
     }
-    res = sphere_sphere(margin, vec1, size1[0], vec2, size2[0]);
+    res = sphere_sphere(margin, vec1, size1[0], vec2, size2[0], tol);
   } else {
-    // parallel axes (rare): any of the four end tests
-    double x1, x2;
+    // parallel axes (rare, exact path only): any of the four end tests
+    T x1, x2;
     for (int k = 0; k < 3; k++) vec1[k] = c1.pos[k] + axis1[k];
-    x2 = clipd((v - mb) / mc, -1, 1);
+    x2 = clipd((v - mb) / mc, T(-1), T(1));
     for (int k = 0; k < 3; k++) vec2[k] = c2.pos[k] + axis2[k] * x2;
-    res = sphere_sphere(margin, vec1, size1[0], vec2, size2[0]);
+    res = sphere_sphere(margin, vec1, size1[0], vec2, size2[0], tol);
     for (int k = 0; k < 3; k++) vec1[k] = c1.pos[k] - axis1[k];
-    x2 = clipd((v + mb) / mc, -1, 1);
+    x2 = clipd((v + mb) / mc, T(-1), T(1));
     for (int k = 0; k < 3; k++) vec2[k] = c2.pos[k] + axis2[k] * x2;
-    res = res || sphere_sphere(margin, vec1, size1[0], vec2, size2[0]);
+    res = v_or(res, sphere_sphere(margin, vec1, size1[0], vec2, size2[0], tol));
     for (int k = 0; k < 3; k++) vec2[k] = c2.pos[k] + axis2[k];
-    x1 = clipd((u - mb) / ma, -1, 1);
+    x1 = clipd((u - mb) / ma, T(-1), T(1));
     for (int k = 0; k < 3; k++) vec1[k] = c1.pos[k] + axis1[k] * x1;
-    res = res || sphere_sphere(margin, vec1, size1[0], vec2, size2[0]);
+    res = v_or(res, sphere_sphere(margin, vec1, size1[0], vec2, size2[0], tol));
     for (int k = 0; k < 3; k++) vec2[k] = c2.pos[k] - axis2[k];
-    x1 = clipd((u + mb) / ma, -1, 1);
+    x1 = clipd((u + mb) / ma, T(-1), T(1));
     for (int k = 0; k < 3; k++) vec1[k] = c1.pos[k] + axis1[k] * x1;
-    res = res || sphere_sphere(margin, vec1, size1[0], vec2, size2[0]);
+    res = v_or(res, sphere_sphere(margin, vec1, size1[0], vec2, size2[0], tol));
   }
   return res;
 }
 
-MJPL_HD bool sphere_box_local(double margin, const double *c, double r, const double *size2) {
-  double d[3];
+template <class T>
+MJPL_HD int sphere_box_local(T margin, const T *c, T r, const T *size2, T tol) {
+  T d[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) d[k] = clipd(c[k], -size2[k], size2[k]) - c[k];
-  double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  return !(dist - r > margin);
+  T dist = rsqrt_val(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if constexpr (Real<T>::exact) return !(dist - r > margin) ? V_CONTACT : V_NONE;
+  return classify(dist - r - margin, tol);
 }
 
-MJPL_HD bool sphere_box(double margin, const double *pos1, double r1, const Geom &box,
-                        const double *size2) {
-  double tmp[3] = {pos1[0] - box.pos[0], pos1[1] - box.pos[1], pos1[2] - box.pos[2]};
-  double center[3];
+template <class T>
+MJPL_HD int sphere_box(T margin, const T *pos1, T r1, const GeomT<T> &box, const T *size2, T tol) {
+  T tmp[3] = {pos1[0] - box.pos[0], pos1[1] - box.pos[1], pos1[2] - box.pos[2]};
+  T center[3];
   mul_matT_vec3(center, box.m, tmp);
-  return sphere_box_local(margin, center, r1, size2);
+  return sphere_box_local(margin, center, r1, size2, tol);
 }
 
-MJPL_HD double capbox_g(const double *p, const double *h, const double *s, double t) {
-  double g = 0;
+template <class T>
+MJPL_HD T capbox_g(const T *p, const T *h, const T *s, T t) {
+  T g = 0;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    double x = p[k] + t * h[k];
-    double e = x - fmin(fmax(x, -s[k]), s[k]);
+    T x = p[k] + t * h[k];
+    T e = x - fmin(fmax(x, -s[k]), s[k]);
     g = g + h[k] * e;
   }
   return g;
 }
 
 // exact 1-D convex minimisation of dist^2(segment point, box); see oracle/mjpl_oracle.c
-__device__ __forceinline__ bool capsule_box(double margin, const Geom &cap, const double *size1,
-                                            const Geom &box, const double *size2) {
-  double tmp[3] = {cap.pos[0] - box.pos[0], cap.pos[1] - box.pos[1], cap.pos[2] - box.pos[2]};
-  double axis[3] = {cap.m[2], cap.m[5], cap.m[8]};
-  double p[3], a[3], h[3], inv[3];
+template <class T>
+__device__ __forceinline__ int capsule_box(T margin, const GeomT<T> &cap, const T *size1,
+                                           const GeomT<T> &box, const T *size2, T tol) {
+  T tmp[3] = {cap.pos[0] - box.pos[0], cap.pos[1] - box.pos[1], cap.pos[2] - box.pos[2]};
+  T axis[3] = {cap.m[2], cap.m[5], cap.m[8]};
+  T p[3], a[3], h[3], inv[3];
   mul_matT_vec3(p, box.m, tmp);
   mul_matT_vec3(a, box.m, axis);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     h[k] = a[k] * size1[1];
-    inv[k] = 1 / h[k];  // h == 0: +-inf, the breakpoint becomes +-inf or NaN and is skipped
+    inv[k] = rdiv(T(1), h[k]);  // h == 0: +-inf, the breakpoint becomes +-inf or NaN and is skipped
   }
 
-  double lo = -1, hi = 1;
-  const double g_m1 = capbox_g(p, h, size2, lo);
-  const double g_p1 = capbox_g(p, h, size2, hi);
-  double glo = g_m1, ghi = g_p1;
+  T lo = -1, hi = 1;
+  const T g_m1 = capbox_g(p, h, size2, lo);
+  const T g_p1 = capbox_g(p, h, size2, hi);
+  T glo = g_m1, ghi = g_p1;
   // six face breakpoints in the scalar routine's order (k = 0,1,2; minus before plus)
 #pragma unroll
   for (int k = 0; k < 3; k++) {
 #pragma unroll
     for (int sgn = -1; sgn <= 1; sgn += 2) {
-      double tb = (sgn * size2[k] - p[k]) * inv[k];
+      T tb = (sgn * size2[k] - p[k]) * inv[k];
       bool inside = (tb > lo && tb < hi);
-      double gb = capbox_g(p, h, size2, tb);
+      T gb = capbox_g(p, h, size2, tb);
       bool below = inside && gb <= 0;
       bool above = inside && !(gb <= 0);
       lo = below ? tb : lo;
@@ -348,18 +425,19 @@ __device__ __forceinline__ bool capsule_box(double margin, const Geom &cap, cons
       ghi = above ? gb : ghi;
     }
   }
-  double den = ghi - glo;
-  double t = (den > 0) ? lo + (hi - lo) * ((0 - glo) / den) : lo;
-  t = (g_m1 >= 0) ? -1.0 : ((g_p1 <= 0) ? 1.0 : t);
-  double c[3] = {p[0] + t * h[0], p[1] + t * h[1], p[2] + t * h[2]};
-  return sphere_box_local(margin, c, size1[0], size2);
+  T den = ghi - glo;
+  T t = (den > 0) ? lo + (hi - lo) * rdiv(0 - glo, den) : lo;
+  t = (g_m1 >= 0) ? T(-1) : ((g_p1 <= 0) ? T(1) : t);
+  T c[3] = {p[0] + t * h[0], p[1] + t * h[1], p[2] + t * h[2]};
+  return sphere_box_local(margin, c, size1[0], size2, tol);
 }
 
 // 15-axis separating-axis verdict; see oracle/mjpl_oracle.c box_box
-__device__ __forceinline__ bool box_box(double margin, const Geom &b1, const double *size1,
-                                        const Geom &b2, const double *size2) {
-  double d[3] = {b2.pos[0] - b1.pos[0], b2.pos[1] - b1.pos[1], b2.pos[2] - b1.pos[2]};
-  double R[9], A[9], t[3];
+template <class T>
+__device__ __forceinline__ int box_box(T margin, const GeomT<T> &b1, const T *size1,
+                                       const GeomT<T> &b2, const T *size2, T tol) {
+  T d[3] = {b2.pos[0] - b1.pos[0], b2.pos[1] - b1.pos[1], b2.pos[2] - b1.pos[2]};
+  T R[9], A[9], t[3];
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -368,17 +446,22 @@ __device__ __forceinline__ bool box_box(double margin, const Geom &b1, const dou
   mul_matT_vec3(t, b1.m, d);
 #pragma unroll
   for (int k = 0; k < 9; k++) A[k] = fabs(R[k]);
-  bool sep = false;
+  // exact path: separated iff some axis has gap > margin.  filter: gaps classified with tol
+  bool sep = false, near = false;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    double rb = size2[0] * A[3 * i] + size2[1] * A[3 * i + 1] + size2[2] * A[3 * i + 2];
-    sep = sep || (fabs(t[i]) - (size1[i] + rb) > margin);
+    T rb = size2[0] * A[3 * i] + size2[1] * A[3 * i + 1] + size2[2] * A[3 * i + 2];
+    T gap = fabs(t[i]) - (size1[i] + rb);
+    if constexpr (Real<T>::exact) sep = sep || (gap > margin);
+    else { sep = sep || (gap - margin > tol); near = near || !(gap - margin < -tol); }
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    double ra = size1[0] * A[j] + size1[1] * A[3 + j] + size1[2] * A[6 + j];
-    double tj = t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j];
-    sep = sep || (fabs(tj) - (ra + size2[j]) > margin);
+    T ra = size1[0] * A[j] + size1[1] * A[3 + j] + size1[2] * A[6 + j];
+    T tj = t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j];
+    T gap = fabs(tj) - (ra + size2[j]);
+    if constexpr (Real<T>::exact) sep = sep || (gap > margin);
+    else { sep = sep || (gap - margin > tol); near = near || !(gap - margin < -tol); }
   }
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -386,15 +469,25 @@ __device__ __forceinline__ bool box_box(double margin, const Geom &b1, const dou
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-      double len2 = 1 - R[3 * i + j] * R[3 * i + j];
-      double ra = size1[i1] * A[3 * i2 + j] + size1[i2] * A[3 * i1 + j];
-      double rb = size2[j1] * A[3 * i + j2] + size2[j2] * A[3 * i + j1];
-      double tl = t[i2] * R[3 * i1 + j] - t[i1] * R[3 * i2 + j];
-      bool s = !(len2 < 1e-12) && (fabs(tl) - (ra + rb) > margin * sqrt(len2));
-      sep = sep || s;
+      T len2 = 1 - R[3 * i + j] * R[3 * i + j];
+      T ra = size1[i1] * A[3 * i2 + j] + size1[i2] * A[3 * i1 + j];
+      T rb = size2[j1] * A[3 * i + j2] + size2[j2] * A[3 * i + j1];
+      T tl = t[i2] * R[3 * i1 + j] - t[i1] * R[3 * i2 + j];
+      if constexpr (Real<T>::exact) {
+        bool s = !(len2 < T(1e-12)) && (fabs(tl) - (ra + rb) > margin * sqrt(len2));
+        sep = sep || s;
+      } else {
+        // nearly parallel edges: the exact path skips this axis below 1e-12, which binary32
+        // cannot resolve -> such a pair can only be certain through another axis
+        const bool skew = len2 > T(1e-3);
+        T gap = fabs(tl) - (ra + rb) - margin * rsqrt_val(fmax(len2, T(0)));
+        sep = sep || (skew && gap > tol);
+        near = near || !skew || !(gap < -tol);
+      }
     }
   }
-  return !sep;
+  if constexpr (Real<T>::exact) return sep ? V_NONE : V_CONTACT;
+  return sep ? V_NONE : (near ? V_UNSURE : V_CONTACT);
 }
 
 // Pair dispatch.  mj_collision calls its function table with (g1, g2) ordered by geom type,
@@ -404,34 +497,34 @@ __device__ __forceinline__ bool box_box(double margin, const Geom &b1, const dou
 // capsule-capsule, box-box) look at `pfirst`, with wave-uniform selects.
 // WBOX: some static geom is a box.  MBOX: some moving geom is a box.  The flags only remove
 // dead narrowphase code (and its registers) from an instantiation.
-template <bool WBOX, bool MBOX>
-__device__ __forceinline__ bool pair_contact(int tcur, const Geom &cur, const double *scur, int tpar,
-                                             const Geom &par, const double *spar, bool pfirst,
-                                             double margin) {
+template <class T, bool WBOX, bool MBOX>
+__device__ __forceinline__ int pair_contact(int tcur, const GeomT<T> &cur, const T *scur, int tpar,
+                                            const GeomT<T> &par, const T *spar, bool pfirst, T margin,
+                                            T tol) {
   constexpr bool PBOX = WBOX || MBOX;  // the partner may be a box
-  bool r = false;
+  int r = V_NONE;
   if (tpar == GT_PLANE) {
-    if (tcur == GT_SPHERE) r = plane_sphere(margin, par, cur.pos, scur[0]);
-    else if (tcur == GT_CAPSULE) r = plane_capsule(margin, par, cur, scur);
-    else if (MBOX) r = plane_box(margin, par, cur, scur);
+    if (tcur == GT_SPHERE) r = plane_sphere(margin, par, cur.pos, scur[0], tol);
+    else if (tcur == GT_CAPSULE) r = plane_capsule(margin, par, cur, scur, tol);
+    else if (MBOX) r = plane_box(margin, par, cur, scur, tol);
   } else if (tcur == GT_SPHERE && tpar == GT_SPHERE) {
-    const double r1 = pfirst ? spar[0] : scur[0], r2 = pfirst ? scur[0] : spar[0];
-    r = sphere_sphere(margin, cur.pos, r1, par.pos, r2);  // (a-b)^2 == (b-a)^2 exactly
+    const T r1 = pfirst ? spar[0] : scur[0], r2 = pfirst ? scur[0] : spar[0];
+    r = sphere_sphere(margin, cur.pos, r1, par.pos, r2, tol);  // (a-b)^2 == (b-a)^2 exactly
   } else if (tcur == GT_SPHERE && tpar == GT_CAPSULE) {
-    r = sphere_capsule(margin, cur.pos, scur[0], par, spar);
+    r = sphere_capsule(margin, cur.pos, scur[0], par, spar, tol);
   } else if (tcur == GT_CAPSULE && tpar == GT_SPHERE) {
-    r = sphere_capsule(margin, par.pos, spar[0], cur, scur);
+    r = sphere_capsule(margin, par.pos, spar[0], cur, scur, tol);
   } else if (PBOX && tcur == GT_SPHERE && tpar == GT_BOX) {
-    r = sphere_box(margin, cur.pos, scur[0], par, spar);
+    r = sphere_box(margin, cur.pos, scur[0], par, spar, tol);
   } else if (MBOX && tcur == GT_BOX && tpar == GT_SPHERE) {
-    r = sphere_box(margin, par.pos, spar[0], cur, scur);
+    r = sphere_box(margin, par.pos, spar[0], cur, scur, tol);
   } else if (PBOX && tcur == GT_CAPSULE && tpar == GT_BOX) {
-    r = capsule_box(margin, cur, scur, par, spar);
+    r = capsule_box(margin, cur, scur, par, spar, tol);
   } else if (MBOX && tcur == GT_BOX && tpar == GT_CAPSULE) {
-    r = capsule_box(margin, par, spar, cur, scur);
+    r = capsule_box(margin, par, spar, cur, scur, tol);
   } else if (tcur == GT_CAPSULE && tpar == GT_CAPSULE) {
-    Geom c1, c2;
-    double s1[2], s2[2];
+    GeomT<T> c1, c2;
+    T s1[2], s2[2];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       c1.pos[k] = pfirst ? par.pos[k] : cur.pos[k];
@@ -444,10 +537,10 @@ __device__ __forceinline__ bool pair_contact(int tcur, const Geom &cur, const do
       s1[k] = pfirst ? spar[k] : scur[k];
       s2[k] = pfirst ? scur[k] : spar[k];
     }
-    r = capsule_capsule(margin, c1, s1, c2, s2);
+    r = capsule_capsule(margin, c1, s1, c2, s2, tol);
   } else if (MBOX) {
-    Geom b1, b2;
-    double s1[3], s2[3];
+    GeomT<T> b1, b2;
+    T s1[3], s2[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       b1.pos[k] = pfirst ? par.pos[k] : cur.pos[k];
@@ -460,7 +553,7 @@ __device__ __forceinline__ bool pair_contact(int tcur, const Geom &cur, const do
       b1.m[k] = pfirst ? par.m[k] : cur.m[k];
       b2.m[k] = pfirst ? cur.m[k] : par.m[k];
     }
-    r = box_box(margin, b1, s1, b2, s2);
+    r = box_box(margin, b1, s1, b2, s2, tol);
   }
   return r;
 }
@@ -472,9 +565,9 @@ struct FkOut {  // global-memory destinations of the FK parity kernel (any may b
   int nbody, ngeom;
 };
 
-template <int MAXS>
+template <class T, int MAXS>
 struct SlotFile {
-  double v[MAXS > 0 ? MAXS : 1][6];  // pos[3], zaxis[3] of earlier moving sphere/capsule geoms
+  T v[MAXS > 0 ? MAXS : 1][6];  // pos[3], zaxis[3] of earlier moving sphere/capsule geoms
 };
 
 // Slot access is expanded in place by macros, with a literal index per slot: the slot file is
@@ -505,42 +598,56 @@ enum : int { SLOT_NONE = 63 };
 // expressions of it are not hoisted out of the partner loops (loop-invariant code motion of the
 // narrowphase prologues costs tens of VGPRs that stay live across the whole loop).
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin_geom(Geom &g) {
+__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
+template <class T>
+__device__ __forceinline__ void pin_geom(GeomT<T> &g) {
   pin(g.pos[0]); pin(g.pos[1]); pin(g.pos[2]); pin(g.m[2]); pin(g.m[5]); pin(g.m[8]);
 }
 
 // control words are wave-uniform: pin them to SGPRs so the interpreter's branches are scalar
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+template <class T>
+__device__ __forceinline__ void sincos_half(T x, T *s, T *c) {
+  if constexpr (Real<T>::exact) sincos_pi2(x, s, c);
+  else sincosf(x, s, c);
+}
+
 // Walk the moving part of the body tree for this lane's configuration.
-//   ip, dp : program tables in LDS            q : this lane's planning columns, q[c*qstride]
+//   ip, tp : program tables (control words; constants in the instantiation's scalar type)
+//   q      : this lane's planning columns (always float64), q[c*qstride]
 //   save   : this lane's LDS pose-save area, save[(slot*7+k)*sstride]
-// Returns true iff the configuration has a contact outside the allowed body pairs.
-// `active` = false lanes run along (wave-uniform control flow) but never report a hit.
-// EMIT: also write body/geom world poses to `out` row `row` (FK parity kernel).
-template <int MAXS, bool EMIT, bool WBOX, bool MBOX>
-__device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qstride, double *save,
-                                           int sstride, bool active, const FkOut &out, int64_t row) {
-  SlotFile<MAXS> sf;
-  double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  bool hit = false;
+// Returns V_CONTACT iff the configuration has a contact outside the allowed body pairs,
+// V_NONE if it has none, and -- filter path only -- V_UNSURE if that cannot be told within
+// `tol` (the caller then re-runs the configuration on the exact path).
+// `active` = false lanes run along (wave-uniform control flow) but never report anything.
+// EMIT: also write body/geom world poses to `out` row `row` (FK parity kernel, exact path).
+template <class T, int MAXS, bool EMIT, bool WBOX, bool MBOX>
+__device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const double *q, int qstride,
+                                          T *save, int sstride, bool active, T tol, const FkOut &out,
+                                          int64_t row) {
+  typedef typename Real<T>::Tab Tab;
+  typedef GeomT<T> Geom;
+  SlotFile<T, MAXS> sf;
+  T p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  bool hit = false, unsure = false;
   const int nbodyops = uni(ip[H_NBODYOPS]);
-  DP world = dp + uni(ip[H_OFF_WORLD]);
+  Tab world = tp + uni(ip[H_OFF_WORLD]);
   int pc = uni(ip[H_OFF_BODYOPS]);
 
   for (int b = 0; b < nbodyops; b++) {
     // a wave whose every lane is already decided skips the rest of the tree
-    if (!EMIT && __ballot(active && !hit) == 0ull) break;
+    if (!EMIT && __ballot(active && !hit && !unsure) == 0ull) break;
 
     const int parent = uni(ip[pc + B_PARENT]);
-    DP bd = dp + uni(ip[pc + B_DOFF]);
+    Tab bd = tp + uni(ip[pc + B_DOFF]);
     const int njnt = uni(ip[pc + B_NJNT]);
     const int save_slot = uni(ip[pc + B_SAVE]);
     const int ngeom = uni(ip[pc + B_NGEOM]);
     const int body_id = uni(ip[pc + B_BODYID]);
     pc += B_SIZE;
 
-    double pp[3], pq[4], pR[9];
+    T pp[3], pq[4], pR[9];
     if (parent == PARENT_CUR) {
 #pragma unroll
       for (int k = 0; k < 3; k++) pp[k] = p[k];
@@ -556,7 +663,7 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
 #pragma unroll
       for (int k = 0; k < 9; k++) pR[k] = bd[14 + k];
     } else {
-      const double *sv = save + (size_t)(parent - 1) * 7 * sstride;
+      const T *sv = save + (size_t)(parent - 1) * 7 * sstride;
 #pragma unroll
       for (int k = 0; k < 3; k++) pp[k] = sv[k * sstride];
 #pragma unroll
@@ -565,10 +672,10 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
     }
 
     // fixed offset relative to the parent
-    double np[3], nq[4];
+    T np[3], nq[4];
     {
-      double bpos[3] = {bd[0], bd[1], bd[2]};
-      double bquat[4] = {bd[3], bd[4], bd[5], bd[6]};
+      T bpos[3] = {bd[0], bd[1], bd[2]};
+      T bquat[4] = {bd[3], bd[4], bd[5], bd[6]};
       mul_mat_vec3(np, pR, bpos);
       np[0] += pp[0]; np[1] += pp[1]; np[2] += pp[2];
       mul_quat(nq, pq, bquat);
@@ -579,28 +686,28 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
       const int jtype = uni(ip[pc + J_TYPE]);
       const int qsrc = uni(ip[pc + J_QSRC]);
       const int jflags = uni(ip[pc + J_FLAGS]);
-      DP jd = dp + uni(ip[pc + J_DOFF]);
+      Tab jd = tp + uni(ip[pc + J_DOFF]);
       pc += J_SIZE;
-      const double qv = (qsrc >= 0) ? q[qsrc * qstride] : jd[7];
-      const double dq = qv - jd[6];
-      double jaxis[3] = {jd[0], jd[1], jd[2]};
-      double jpos[3] = {jd[3], jd[4], jd[5]};
+      const T qv = (qsrc >= 0) ? (T)q[qsrc * qstride] : jd[7];
+      const T dq = qv - jd[6];
+      T jaxis[3] = {jd[0], jd[1], jd[2]};
+      T jpos[3] = {jd[3], jd[4], jd[5]};
       if (jtype == JT_SLIDE) {
-        double xaxis[3];
+        T xaxis[3];
         rot_vec_quat(xaxis, jaxis, nq);
         np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq;
       } else {
-        double xanchor[3] = {np[0], np[1], np[2]};
+        T xanchor[3] = {np[0], np[1], np[2]};
         if (jflags & JF_POS_NONZERO) {
           rot_vec_quat(xanchor, jpos, nq);
           xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];
         }
-        double s, c;
-        sincos_pi2(dq * 0.5, &s, &c);
-        double qloc[4] = {c, jaxis[0] * s, jaxis[1] * s, jaxis[2] * s};
+        T sn, cs;
+        sincos_half(dq * T(0.5), &sn, &cs);
+        T qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};
         mul_quat(nq, nq, qloc);
         if (jflags & JF_POS_NONZERO) {
-          double vec[3];
+          T vec[3];
           rot_vec_quat(vec, jpos, nq);
           np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2];
         }
@@ -615,25 +722,25 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
     quat2mat(R, qt);
 
     if (save_slot >= 0) {
-      double *sv = save + (size_t)save_slot * 7 * sstride;
+      T *sv = save + (size_t)save_slot * 7 * sstride;
 #pragma unroll
       for (int k = 0; k < 3; k++) sv[k * sstride] = p[k];
 #pragma unroll
       for (int k = 0; k < 4; k++) sv[(3 + k) * sstride] = qt[k];
     }
-    if (EMIT) {
+    if constexpr (EMIT) {
       if (active && out.xpos)
         for (int k = 0; k < 3; k++) out.xpos[(row * out.nbody + body_id) * 3 + k] = p[k];
       if (active && out.xquat)
         for (int k = 0; k < 4; k++) out.xquat[(row * out.nbody + body_id) * 4 + k] = qt[k];
     }
 
-    // geoms of this body: world pose, then every enabled pair against world geoms and
+    // geoms of this body: world pose, then every enabled pair against static geoms and
     // against earlier moving geoms held in register slots
     for (int g = 0; g < ngeom; g++) {
       const int gtype = uni(ip[pc + G_TYPE]);
       const int gflags = uni(ip[pc + G_FLAGS]);
-      DP gd = dp + uni(ip[pc + G_DOFF]);
+      Tab gd = tp + uni(ip[pc + G_DOFF]);
       const int store = uni(ip[pc + G_STORE]);
       const int geom_id = uni(ip[pc + G_GEOMID]);
       const int nstored = uni(ip[pc + G_NSTORED]);
@@ -646,11 +753,11 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
       pc += G_SIZE;
 
       Geom cur;
-      const double gsize[3] = {gd[GD_SIZE], gd[GD_SIZE + 1], gd[GD_SIZE + 2]};
+      const T gsize[3] = {gd[GD_SIZE], gd[GD_SIZE + 1], gd[GD_SIZE + 2]};
       if (gflags & GF_SAMEPOS) {
         cur.pos[0] = p[0]; cur.pos[1] = p[1]; cur.pos[2] = p[2];
       } else {
-        double lpos[3] = {gd[0], gd[1], gd[2]};
+        T lpos[3] = {gd[0], gd[1], gd[2]};
         mul_mat_vec3(cur.pos, R, lpos);
         cur.pos[0] += p[0]; cur.pos[1] += p[1]; cur.pos[2] += p[2];
       }
@@ -662,12 +769,12 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
           cur.m[2] = R[2]; cur.m[5] = R[5]; cur.m[8] = R[8];
         }
       } else {
-        double lq[4] = {gd[3], gd[4], gd[5], gd[6]}, gq[4];
+        T lq[4] = {gd[3], gd[4], gd[5], gd[6]}, gq[4];
         mul_quat(gq, qt, lq);
         if (EMIT || (MBOX && gtype == GT_BOX)) quat2mat(cur.m, gq);
         else quat2zaxis(cur.m, gq);
       }
-      if (EMIT) {
+      if constexpr (EMIT) {
         if (active && out.geom_xpos)
           for (int k = 0; k < 3; k++) out.geom_xpos[(row * out.ngeom + geom_id) * 3 + k] = cur.pos[k];
         if (active && out.geom_xmat)
@@ -676,24 +783,25 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
 
       if (!EMIT) {
         const int nworld = uni(ip[H_NWORLD]);
-        DP wbound = gd + GD_WBOUND;
+        Tab wbound = gd + GD_WBOUND;
 
         // ---- static planes (few): signed-distance cull, then the plane routines
         for (unsigned long long pm = pmask_all; pm; pm &= pm - 1) {
           const int wc = (int)__builtin_ctzll(pm);
-          DP r = world + wc * W_LEN;
+          Tab r = world + wc * W_LEN;
           Geom par;
           par.pos[0] = r[W_POS]; par.pos[1] = r[W_POS + 1]; par.pos[2] = r[W_POS + 2];
           par.m[2] = r[W_ZAXIS]; par.m[5] = r[W_ZAXIS + 1]; par.m[8] = r[W_ZAXIS + 2];
           par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
-          double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
-          double n[3] = {par.m[2], par.m[5], par.m[8]};
-          const bool pass = !(dot3(dif, n) > wbound[wc]) && active && !hit;
+          T dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
+          T n[3] = {par.m[2], par.m[5], par.m[8]};
+          const bool pass = !(dot3(dif, n) > wbound[wc]) && active && !hit && !unsure;
           if (__ballot(pass) == 0ull) continue;
-          const double psize[3] = {0, 0, 0};
-          const bool contact = pair_contact<WBOX, MBOX>(gtype, cur, gsize, GT_PLANE, par, psize, true,
-                                                        wbound[nworld + wc]);
-          hit = hit || (pass && contact);
+          const T psize[3] = {0, 0, 0};
+          const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, GT_PLANE, par, psize, true,
+                                                       wbound[nworld + wc], tol);
+          hit = hit || (pass && code == V_CONTACT);
+          unsure = unsure || (pass && code == V_UNSURE);
         }
 
         // ---- other static partners: rows of the world table selected by the enable mask.
@@ -706,17 +814,17 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
         unsigned long long wmask = wmask_all;
 #endif
         int w = wmask ? (int)__builtin_ctzll(wmask) : 0;
-        DP rn = world + w * W_LEN;
-        double nx_pos[3] = {rn[W_POS], rn[W_POS + 1], rn[W_POS + 2]};
-        double nx_z[3] = {rn[W_ZAXIS], rn[W_ZAXIS + 1], rn[W_ZAXIS + 2]};
+        Tab rn = world + w * W_LEN;
+        T nx_pos[3] = {rn[W_POS], rn[W_POS + 1], rn[W_POS + 2]};
+        T nx_z[3] = {rn[W_ZAXIS], rn[W_ZAXIS + 1], rn[W_ZAXIS + 2]};
         int nx_info = ((IP)(rn + W_INFO))[0];
-        double nx_bound = wbound[w];
+        T nx_bound = wbound[w];
         while (wmask) {
           Geom par;
           par.pos[0] = nx_pos[0]; par.pos[1] = nx_pos[1]; par.pos[2] = nx_pos[2];
           par.m[2] = nx_z[0]; par.m[5] = nx_z[1]; par.m[8] = nx_z[2];
           const int info = nx_info;
-          const double bound = nx_bound;
+          const T bound = nx_bound;
           const int wc = w;
           wmask &= wmask - 1;
           w = wmask ? (int)__builtin_ctzll(wmask) : 0;
@@ -730,17 +838,17 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
           __builtin_assume(ptype != GT_PLANE);
           pin_geom(cur);
           // bounding cull (mj_collideSphere): squared centre distance; (a-b)^2 == (b-a)^2 exactly,
-          // so the pair order does not matter
-          double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
-          const bool pass = !(dot3(dif, dif) > bound) && active && !hit;
+          // so the pair order does not matter.  (The filter's table holds bounds widened by tol.)
+          T dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
+          const bool pass = !(dot3(dif, dif) > bound) && active && !hit && !unsure;
           if (__ballot(pass) == 0ull) continue;  // nobody in the wave needs the narrowphase
 #ifdef MJPL_X_SKIP_NARROW
-          hit = hit || (pass && dif[0] == 12345.0);
+          hit = hit || (pass && dif[0] == T(12345.0));
           continue;
 #endif
 
-          DP r = world + wc * W_LEN;
-          const double psize[3] = {r[W_SIZE], r[W_SIZE + 1], r[W_SIZE + 2]};
+          Tab r = world + wc * W_LEN;
+          const T psize[3] = {r[W_SIZE], r[W_SIZE + 1], r[W_SIZE + 2]};
           if (WBOX) {
             par.m[0] = r[W_XAXIS]; par.m[3] = r[W_XAXIS + 1]; par.m[6] = r[W_XAXIS + 2];
             par.m[1] = r[W_YAXIS]; par.m[4] = r[W_YAXIS + 1]; par.m[7] = r[W_YAXIS + 2];
@@ -750,24 +858,25 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
           // mj_collision order: smaller geom type first, geom id breaks ties
           const int pgid = info >> 8;
           const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < geom_id);
-          const double margin = wbound[nworld + wc];
-          const bool contact = pair_contact<WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst, margin);
-          hit = hit || (pass && contact);
+          const T margin = wbound[nworld + wc];
+          const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
+          hit = hit || (pass && code == V_CONTACT);
+          unsure = unsure || (pass && code == V_UNSURE);
         }
 
         // ---- earlier moving partners, held in the register slot file
-        DP sd = gd + GD_WBOUND + 2 * nworld;
+        Tab sd = gd + GD_WBOUND + 2 * nworld;
         // same software pipeline as above: word and bound of the next entry are in flight
-        // while the current one is tested (entry 0 of the next geom record is harmless to read)
+        // while the current one is tested (the tables are padded past their last entry)
         int nx_pw = ip[pc];
-        double nx_sb = sd[SD_BOUND];
+        T nx_sb = sd[SD_BOUND];
 #ifdef MJPL_X_SKIP_STORED
         for (int e = 0; e < 0; e++, sd += SD_LEN) {
 #else
         for (int e = 0; e < nstored; e++, sd += SD_LEN) {
 #endif
           const int pw = uni(nx_pw);
-          const double sbound = nx_sb;
+          const T sbound = nx_sb;
           nx_pw = ip[pc + e + 1];
           nx_sb = sd[SD_LEN + SD_BOUND];
           const int ptype = (pw >> 12) & 15;
@@ -775,23 +884,23 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
           pin_geom(cur);
           Geom par;
           {
-            double t6[6] = {0, 0, 0, 0, 0, 0};
+            T t6[6] = {0, 0, 0, 0, 0, 0};
             const int slot_ = pw & 63;
             switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_GET) default: break; }
             par.pos[0] = t6[0]; par.pos[1] = t6[1]; par.pos[2] = t6[2];
             par.m[2] = t6[3]; par.m[5] = t6[4]; par.m[8] = t6[5];
           }
-          double dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
-          const bool pass = !(dot3(dif, dif) > sbound) && active && !hit;
+          T dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
+          const bool pass = !(dot3(dif, dif) > sbound) && active && !hit && !unsure;
           if (__ballot(pass) == 0ull) continue;
 #ifdef MJPL_X_SKIP_NARROW
-          hit = hit || (pass && dif[0] == 12345.0);
+          hit = hit || (pass && dif[0] == T(12345.0));
           continue;
 #endif
 
-          const double psize[3] = {sd[SD_SIZE], sd[SD_SIZE + 1], sd[SD_SIZE + 2]};
+          const T psize[3] = {sd[SD_SIZE], sd[SD_SIZE + 1], sd[SD_SIZE + 2]};
           {
-            double t6[6] = {0, 0, 0, 0, 0, 0};
+            T t6[6] = {0, 0, 0, 0, 0, 0};
             if (MBOX && ((pw >> 6) & 63) != SLOT_NONE) {  // stored box: x and y axes
               const int slot_ = (pw >> 6) & 63;
               switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_GET) default: break; }
@@ -799,27 +908,29 @@ __device__ __forceinline__ bool run_config(IP ip, DP dp, const double *q, int qs
             par.m[0] = t6[0]; par.m[3] = t6[1]; par.m[6] = t6[2];
             par.m[1] = t6[3]; par.m[4] = t6[4]; par.m[7] = t6[5];
           }
-          const bool contact = pair_contact<WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst, sd[SD_MARGIN]);
-          hit = hit || (pass && contact);
+          const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst,
+                                                       sd[SD_MARGIN], tol);
+          hit = hit || (pass && code == V_CONTACT);
+          unsure = unsure || (pass && code == V_UNSURE);
         }
       }
       pc += nstored;
 
       if (!EMIT && store >= 0) {
         {
-          const double t6[6] = {cur.pos[0], cur.pos[1], cur.pos[2], cur.m[2], cur.m[5], cur.m[8]};
+          const T t6[6] = {cur.pos[0], cur.pos[1], cur.pos[2], cur.m[2], cur.m[5], cur.m[8]};
           const int slot_ = store & 63;
           switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_PUT) default: break; }
         }
         if (MBOX && ((store >> 6) & 63) != SLOT_NONE) {
-          const double t6[6] = {cur.m[0], cur.m[3], cur.m[6], cur.m[1], cur.m[4], cur.m[7]};
+          const T t6[6] = {cur.m[0], cur.m[3], cur.m[6], cur.m[1], cur.m[4], cur.m[7]};
           const int slot_ = (store >> 6) & 63;
           switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_PUT) default: break; }
         }
       }
     }
   }
-  return hit;
+  return hit ? V_CONTACT : (unsure ? V_UNSURE : V_NONE);
 }
 
 }  // namespace mjpl

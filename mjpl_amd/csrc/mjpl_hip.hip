@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <set>
@@ -52,38 +53,40 @@ int fail(int code, const char *fmt, ...) {
 
 // ------------------------------------------------------------------------------- kernels
 
-// LDS carve shared by all kernels: [dp | columns... | saves | ip].  With the default build the
-// tables stay in global memory (scalar loads) and ndp = nip = 0 here.
+// LDS carve shared by all kernels: [tables (A/B build only) | float64 columns | pose saves].
+// With the default build the tables stay in global memory (scalar loads).
+template <class T>
 struct Carve {
-  double *dpl, *col0, *col1, *save;
-  int *ipl;
+  double *col0, *col1;
+  T *save;
   IP ip;
-  DP dp;
+  typename Real<T>::Tab tp;
 };
 
-__device__ __forceinline__ Carve carve_lds(double *smem, const int *__restrict__ gip, int nip,
-                                           const double *__restrict__ gdp, int ndp, int nplan,
-                                           int nsave, int ncolsets, int B) {
-  Carve c;
+template <class T>
+__device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restrict__ gip, int nip,
+                                              const T *__restrict__ gtp, int ntp, int nplan, int ncolsets,
+                                              int B) {
+  Carve<T> c;
 #if MJPL_TABLES_LDS
-  const int ndl = ndp, nil = nip;
+  T *tl = reinterpret_cast<T *>(smem);
+  const int tdoubles = (int)((ntp * sizeof(T) + 7) / 8);
+  c.col0 = smem + tdoubles;
 #else
-  const int ndl = 0, nil = 0;
+  c.col0 = smem;
 #endif
-  c.dpl = smem;
-  c.col0 = c.dpl + ndl;
   c.col1 = c.col0 + (size_t)nplan * B;
-  c.save = c.col0 + (size_t)ncolsets * nplan * B;
-  c.ipl = reinterpret_cast<int *>(c.save + (size_t)nsave * 7 * B);
+  c.save = reinterpret_cast<T *>(c.col0 + (size_t)ncolsets * nplan * B);
 #if MJPL_TABLES_LDS
-  for (int k = threadIdx.x; k < ndl; k += blockDim.x) c.dpl[k] = gdp[k];
-  for (int k = threadIdx.x; k < nil; k += blockDim.x) c.ipl[k] = gip[k];
-  c.ip = c.ipl;
-  c.dp = c.dpl;
+  const int nsave = gip[H_NSAVE];
+  int *il = reinterpret_cast<int *>(c.save + (size_t)nsave * 7 * B);
+  for (int k = threadIdx.x; k < ntp; k += blockDim.x) tl[k] = gtp[k];
+  for (int k = threadIdx.x; k < nip; k += blockDim.x) il[k] = gip[k];
+  c.ip = il;
+  c.tp = tl;
 #else
-  (void)nil;
   c.ip = (IP)gip;
-  c.dp = (DP)gdp;
+  c.tp = (typename Real<T>::Tab)gtp;
 #endif
   return c;
 }
@@ -98,23 +101,42 @@ __device__ __forceinline__ void load_columns(double *col, int B, const double *_
   }
 }
 
+// Work assignment shared by the exact kernels: lane j takes item j, or -- when re-running the
+// filter's uncertain items -- item ulist[j] for j < *ucount.
+__device__ __forceinline__ bool pick_item(int64_t n, const int *__restrict__ ulist,
+                                          const int *__restrict__ ucount, int64_t *item) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ulist) {
+    const bool a = j < (int64_t)*ucount;
+    *item = a ? (int64_t)ulist[j] : 0;
+    return a;
+  }
+  *item = j;
+  return j < n;
+}
+
+// ---- exact path (float64): final verdicts --------------------------------------------------
+
 template <int MAXS, bool WBOX, bool MBOX>
 __global__ void __launch_bounds__(kBlock)
 k_check_configs(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
                 const double *__restrict__ Q, int64_t N, int layout, uint8_t *__restrict__ valid,
-                unsigned long long *__restrict__ bits) {
+                unsigned long long *__restrict__ bits, const int *__restrict__ ulist,
+                const int *__restrict__ ucount) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
-  const int nplan = gip[H_NPLAN], nsave = gip[H_NSAVE];
-  Carve c = carve_lds(smem, gip, nip, gdp, ndp, nplan, nsave, 1, B);
-  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
-  const bool active = i < N;
+  if (ulist && (int64_t)blockIdx.x * B >= (int64_t)*ucount) return;  // nothing left to re-run
+  const int nplan = gip[H_NPLAN];
+  Carve<double> c = carve_lds<double>(smem, gip, nip, gdp, ndp, nplan, 1, B);
+  int64_t i;
+  const bool active = pick_item(N, ulist, ucount, &i);
   load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
   __syncthreads();
 
   FkOut none = {};
-  bool hit = run_config<MAXS, false, WBOX, MBOX>(c.ip, c.dp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B,
-                                     active, none, i);
+  const bool hit = run_config<double, MAXS, false, WBOX, MBOX>(c.ip, c.tp, c.col0 + threadIdx.x, B,
+                                                               c.save + threadIdx.x, B, active, 0.0, none,
+                                                               i) == V_CONTACT;
   if (valid && active) valid[i] = hit ? 0 : 1;
   if (bits) {
     unsigned long long m = __ballot(active && !hit);
@@ -127,32 +149,39 @@ k_fk(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int n
      const double *__restrict__ Q, int64_t N, int layout, FkOut out) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
-  const int nplan = gip[H_NPLAN], nsave = gip[H_NSAVE];
-  Carve c = carve_lds(smem, gip, nip, gdp, ndp, nplan, nsave, 1, B);
+  const int nplan = gip[H_NPLAN];
+  Carve<double> c = carve_lds<double>(smem, gip, nip, gdp, ndp, nplan, 1, B);
   const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
   const bool active = i < N;
   load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
   __syncthreads();
-  run_config<1, true, true, true>(c.ip, c.dp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B, active, out, i);
+  run_config<double, 1, true, true, true>(c.ip, c.tp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B,
+                                          active, 0.0, out, i);
 }
 
 // One lane per edge.  Check 0 is the endpoint QB; checks 1..K are the interior waypoints of
 // _valid_collision_interval(QA, QB, step) generated on chip by the reference's own recurrence
 //   w <- w + ((QB - w)/||QB - w||) * min(step, ||QB - w||)      (planning/utils.py:182-185)
 // until w == QB (np.array_equal, :211).  ||.|| is the sequential-sum 2-norm over qpos
-// addresses in ascending order (see DESIGN.md "waypoint semantics").
-template <int MAXS, bool WBOX, bool MBOX>
-__global__ void __launch_bounds__(kBlock)
-k_check_edges(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
-              const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, double step,
-              int layout, int flags, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
-              int *__restrict__ status) {
+// addresses in ascending order (see DESIGN.md "waypoint semantics").  The recurrence always
+// runs in float64, also in the filter kernel (FILTER = true), whose per-configuration checks
+// run in float32 and which hands every edge it cannot decide within `tol` to the exact kernel
+// through `ulist` / `ucount`.
+template <class T, int MAXS, bool WBOX, bool MBOX>
+__device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, const T *__restrict__ gtp,
+                                          int ntp, const double *__restrict__ QA,
+                                          const double *__restrict__ QB, int64_t E, double step, int layout,
+                                          int flags, T tol, uint8_t *__restrict__ valid,
+                                          int32_t *__restrict__ first_bad, int *__restrict__ status,
+                                          int *__restrict__ ulist, int *__restrict__ ucount,
+                                          const int *__restrict__ rlist, const int *__restrict__ rcount) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
-  const int nplan = gip[H_NPLAN], nsave = gip[H_NSAVE];
-  Carve c = carve_lds(smem, gip, nip, gdp, ndp, nplan, nsave, 2, B);
-  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
-  const bool active = i < E;
+  if (rlist && (int64_t)blockIdx.x * B >= (int64_t)*rcount) return;
+  const int nplan = gip[H_NPLAN];
+  Carve<T> c = carve_lds<T>(smem, gip, nip, gtp, ntp, nplan, 2, B);
+  int64_t i;
+  const bool active = pick_item(E, rlist, rcount, &i);
   double *qe = c.col0 + threadIdx.x;  // edge end (QB)
   double *qw = c.col1 + threadIdx.x;  // walking waypoint, starts at QA
   load_columns(qe, B, QB, E, i, nplan, layout, active);
@@ -168,7 +197,7 @@ k_check_edges(const int *__restrict__ gip, int nip, const double *__restrict__ g
     at_end = at_end && (a == b);
   }
   bool done = !active;
-  bool ok = true;
+  bool ok = true, unsure = false;
   int fb = -1;
   if (active && !finite) {
     done = true; ok = false; fb = -2;
@@ -209,15 +238,65 @@ k_check_edges(const int *__restrict__ gip, int nip, const double *__restrict__ g
         }
       }
     }
-    const bool hit = run_config<MAXS, false, WBOX, MBOX>(c.ip, c.dp, first ? qe : qw, B, c.save + threadIdx.x, B,
-                                             !done, none, i);
-    if (!done && hit) { done = true; ok = false; fb = idx; }
+    const int code = run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, first ? qe : qw, B,
+                                                            c.save + threadIdx.x, B, !done, tol, none, i);
+    if (!done && code == V_CONTACT) { done = true; ok = false; fb = idx; }
+    if (!done && code == V_UNSURE) { done = true; unsure = true; }
     if (first && !done && at_end) done = true;  // waypoints == [start]: nothing interior
     first = false;
   }
   if (active) {
-    valid[i] = ok ? 1 : 0;
-    if (first_bad) first_bad[i] = fb;
+    if (unsure) {
+      ulist[atomicAdd(ucount, 1)] = (int)i;  // the exact kernel writes valid / first_bad
+    } else {
+      valid[i] = ok ? 1 : 0;
+      if (first_bad) first_bad[i] = fb;
+    }
+  }
+}
+
+template <int MAXS, bool WBOX, bool MBOX>
+__global__ void __launch_bounds__(kBlock)
+k_check_edges(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
+              const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, double step,
+              int layout, int flags, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
+              int *__restrict__ status, const int *__restrict__ rlist, const int *__restrict__ rcount) {
+  edge_body<double, MAXS, WBOX, MBOX>(gip, nip, gdp, ndp, QA, QB, E, step, layout, flags, 0.0, valid,
+                                      first_bad, status, nullptr, nullptr, rlist, rcount);
+}
+
+// ---- filter path (float32): decides what it can, lists the rest ----------------------------
+
+template <int MAXS, bool WBOX, bool MBOX>
+__global__ void __launch_bounds__(kBlock)
+k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
+               const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, double step,
+               int layout, int flags, float tol, uint8_t *__restrict__ valid,
+               int32_t *__restrict__ first_bad, int *__restrict__ status, int *__restrict__ ulist,
+               int *__restrict__ ucount) {
+  edge_body<float, MAXS, WBOX, MBOX>(gip, nip, gfp, nfp, QA, QB, E, step, layout, flags, tol, valid,
+                                     first_bad, status, ulist, ucount, nullptr, nullptr);
+}
+
+template <int MAXS, bool WBOX, bool MBOX>
+__global__ void __launch_bounds__(kBlock)
+k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
+                 const double *__restrict__ Q, int64_t N, int layout, float tol,
+                 uint8_t *__restrict__ valid, int *__restrict__ ulist, int *__restrict__ ucount) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  const int nplan = gip[H_NPLAN];
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B);
+  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
+  const bool active = i < N;
+  load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
+  __syncthreads();
+  FkOut none = {};
+  const int code = run_config<float, MAXS, false, WBOX, MBOX>(c.ip, c.tp, c.col0 + threadIdx.x, B,
+                                                              c.save + threadIdx.x, B, active, tol, none, i);
+  if (active) {
+    if (code == V_UNSURE) ulist[atomicAdd(ucount, 1)] = (int)i;
+    else valid[i] = (code == V_CONTACT) ? 0 : 1;
   }
 }
 
@@ -285,9 +364,17 @@ struct mjpl_engine {
   // compiled program
   std::vector<int> ip;
   std::vector<double> dp;
+  std::vector<float> fp;  // the filter's float32 image of dp (cull bounds widened by filter_tol)
   int *d_ip = nullptr;
   double *d_dp = nullptr;
+  float *d_fp = nullptr;
   int *d_status = nullptr;
+  // float32 filter + exact re-run of what it cannot decide
+  bool filter = true;
+  float filter_tol = 1e-4f;
+  int *d_ulist = nullptr;   // indices the filter left undecided
+  int *d_ucount = nullptr;  // how many
+  size_t ulist_cap = 0;
   int nslots = 0, nsave = 0, maxs = 4;
   bool wbox = false, mbox = false;
   int npairs = 0, npairs_world = 0, nmoving = 0, nstatic = 0;
@@ -374,6 +461,8 @@ int compile_program(mjpl_engine *e) {
   e->st_gxmat.assign(9 * ng, 0.0);
   std::vector<int> world_row(ng, -1);
   std::vector<double> world_tab;
+  std::vector<std::pair<size_t, int>> info_at;  // dp index -> int stored there (first 4 bytes)
+  std::vector<size_t> sq_bound_at, plane_bound_at;  // dp indices of cull bounds
   e->nstatic = e->nmoving = 0;
   for (int g = 0; g < ng; g++) {
     const int b = m.geom_bodyid[g];
@@ -405,6 +494,7 @@ int compile_program(mjpl_engine *e) {
       }
       const int32_t info[2] = {m.geom_type[g] | (g << 8), 0};
       memcpy(&row[W_INFO], info, sizeof(double));
+      info_at.push_back({world_tab.size() + W_INFO, info[0]});
       world_tab.insert(world_tab.end(), row, row + W_LEN);
     }
   }
@@ -584,7 +674,10 @@ int compile_program(mjpl_engine *e) {
       };
       {
         std::vector<double> wb(nworld, std::numeric_limits<double>::infinity()), wm(nworld, 0.0);
-        for (int sgeom : world_partners[gk]) pair_bound(sgeom, &wb[world_row[sgeom]], &wm[world_row[sgeom]]);
+        for (int sgeom : world_partners[gk]) {
+          pair_bound(sgeom, &wb[world_row[sgeom]], &wm[world_row[sgeom]]);
+          (m.geom_type[sgeom] == GT_PLANE ? plane_bound_at : sq_bound_at).push_back(dp.size() + world_row[sgeom]);
+        }
         dp.insert(dp.end(), wb.begin(), wb.end());
         dp.insert(dp.end(), wm.begin(), wm.end());
       }
@@ -595,6 +688,7 @@ int compile_program(mjpl_engine *e) {
         ip.push_back(slot_of[k2] | (m.geom_type[h] << 12) | (first == h ? P_FIRST : 0));
         double bound, margin;
         pair_bound(h, &bound, &margin);
+        sq_bound_at.push_back(dp.size());
         dp.push_back(bound);
         dp.push_back(margin);
         for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * h + k3]);
@@ -607,27 +701,57 @@ int compile_program(mjpl_engine *e) {
   ip.insert(ip.end(), 16, 0);
   dp.insert(dp.end(), 16, 0.0);
 
+  // ---- the filter's float32 image: same offsets; cull bounds widened by the tolerance so that
+  // a pair culled in float32 is certainly culled (or contact-free) in float64
+  std::vector<float> &fp = e->fp;
+  fp.resize(dp.size());
+  for (size_t k = 0; k < dp.size(); k++) fp[k] = (float)dp[k];
+  const double tol = e->filter_tol;
+  for (size_t k : sq_bound_at)
+    if (std::isfinite(dp[k])) {
+      const double r = std::sqrt(dp[k]) + tol;
+      fp[k] = (float)(r * r * (1.0 + 1e-6));
+    }
+  for (size_t k : plane_bound_at)
+    if (std::isfinite(dp[k])) fp[k] = (float)(dp[k] + tol + 1e-6 * std::fabs(dp[k]));
+  for (auto &kv : info_at) memcpy(&fp[kv.first], &kv.second, sizeof(float));
+
   // ---- upload
   if (e->d_ip) (void)hipFree(e->d_ip);
   if (e->d_dp) (void)hipFree(e->d_dp);
+  if (e->d_fp) (void)hipFree(e->d_fp);
   e->d_ip = nullptr;
   e->d_dp = nullptr;
-  if (dp.empty()) dp.push_back(0.0);
+  e->d_fp = nullptr;
   HIP_TRY(hipMalloc(&e->d_ip, ip.size() * sizeof(int)));
   HIP_TRY(hipMalloc(&e->d_dp, dp.size() * sizeof(double)));
+  HIP_TRY(hipMalloc(&e->d_fp, fp.size() * sizeof(float)));
   HIP_TRY(hipMemcpy(e->d_ip, ip.data(), ip.size() * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_dp, dp.data(), dp.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_fp, fp.data(), fp.size() * sizeof(float), hipMemcpyHostToDevice));
   return MJPL_OK;
 }
 
-size_t lds_bytes(const mjpl_engine *e, int ncolsets) {
+size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(double)) {
   const size_t nplan = e->qidx.size();
   size_t bytes = (size_t)ncolsets * nplan * kBlock * sizeof(double) +
-                 (size_t)e->nsave * 7 * kBlock * sizeof(double);
+                 (size_t)e->nsave * 7 * kBlock * scalar;
 #if MJPL_TABLES_LDS
-  bytes += e->dp.size() * sizeof(double) + e->ip.size() * sizeof(int);
+  bytes += ((e->dp.size() * scalar + 7) / 8) * 8 + e->ip.size() * sizeof(int);
 #endif
   return bytes ? bytes : 8;
+}
+
+int ulist_reserve(mjpl_engine *e, int64_t n) {
+  if (!e->d_ucount) HIP_TRY(hipMalloc(&e->d_ucount, sizeof(int)));
+  if ((size_t)n > e->ulist_cap) {
+    if (e->d_ulist) HIP_TRY(hipFree(e->d_ulist));
+    e->d_ulist = nullptr;
+    e->ulist_cap = 0;
+    HIP_TRY(hipMalloc(&e->d_ulist, (size_t)n * sizeof(int)));
+    e->ulist_cap = (size_t)n;
+  }
+  return MJPL_OK;
 }
 
 template <class K>
@@ -657,14 +781,32 @@ int dispatch_variant(const mjpl_engine *e, F &&f) {
 int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint8_t *dvalid,
                    unsigned long long *dbits) {
   if (N == 0) return MJPL_OK;
-  const size_t lds = lds_bytes(e, 1);
   const unsigned grid = (unsigned)((N + kBlock - 1) / kBlock);
+  const bool filter = e->filter && dvalid && !dbits && N < (int64_t)1 << 31;
+  if (filter) {
+    int rc = ulist_reserve(e, N);
+    if (rc != MJPL_OK) return rc;
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, sizeof(int), e->stream));
+    const size_t ldsf = lds_bytes(e, 1, sizeof(float));
+    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+      auto kern = k_filter_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+      int r = allow_lds(kern, ldsf);
+      if (r != MJPL_OK) return r;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
+                         e->d_fp, (int)e->fp.size(), dQ, N, layout, e->filter_tol, dvalid, e->d_ulist,
+                         e->d_ucount);
+      return MJPL_OK;
+    });
+    if (rc != MJPL_OK) return rc;
+  }
+  const size_t lds = lds_bytes(e, 1);
   int rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
     auto kern = k_check_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
     int r = allow_lds(kern, lds);
     if (r != MJPL_OK) return r;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, e->stream, e->d_ip, (int)e->ip.size(),
-                       e->d_dp, (int)e->dp.size(), dQ, N, layout, dvalid, dbits);
+                       e->d_dp, (int)e->dp.size(), dQ, N, layout, dvalid, dbits,
+                       filter ? e->d_ulist : nullptr, filter ? e->d_ucount : nullptr);
     return MJPL_OK;
   });
   if (rc != MJPL_OK) return rc;
@@ -675,14 +817,32 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
 int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step,
                  int layout, int flags, uint8_t *dvalid, int32_t *dfb) {
   if (E == 0) return MJPL_OK;
-  const size_t lds = lds_bytes(e, 2);
   const unsigned grid = (unsigned)((E + kBlock - 1) / kBlock);
+  const bool filter = e->filter && E < (int64_t)1 << 31;
+  if (filter) {
+    int rc = ulist_reserve(e, E);
+    if (rc != MJPL_OK) return rc;
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, sizeof(int), e->stream));
+    const size_t ldsf = lds_bytes(e, 2, sizeof(float));
+    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+      auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+      int r = allow_lds(kern, ldsf);
+      if (r != MJPL_OK) return r;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
+                         e->d_fp, (int)e->fp.size(), dQA, dQB, E, step, layout, flags, e->filter_tol, dvalid,
+                         dfb, e->d_status, e->d_ulist, e->d_ucount);
+      return MJPL_OK;
+    });
+    if (rc != MJPL_OK) return rc;
+  }
+  const size_t lds = lds_bytes(e, 2);
   int rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
     auto kern = k_check_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
     int r = allow_lds(kern, lds);
     if (r != MJPL_OK) return r;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, e->stream, e->d_ip, (int)e->ip.size(),
-                       e->d_dp, (int)e->dp.size(), dQA, dQB, E, step, layout, flags, dvalid, dfb, e->d_status);
+                       e->d_dp, (int)e->dp.size(), dQA, dQB, E, step, layout, flags, dvalid, dfb, e->d_status,
+                       filter ? (const int *)e->d_ulist : nullptr, filter ? (const int *)e->d_ucount : nullptr);
     return MJPL_OK;
   });
   if (rc != MJPL_OK) return rc;
@@ -771,6 +931,11 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
   e->qidx.resize(m.nq);
   for (int k = 0; k < m.nq; k++) e->qidx[k] = k;
   e->qbase = m.qpos0;
+  if (const char *f = getenv("MJPL_FILTER")) e->filter = atoi(f) != 0;
+  if (const char *t = getenv("MJPL_FILTER_TOL")) {
+    const double v = atof(t);
+    if (v > 0.0 && v < 1.0) e->filter_tol = (float)v;
+  }
   int rc = compile_program(e);
   if (rc != MJPL_OK) return bail(rc);
   *out = e;
@@ -785,6 +950,9 @@ void mjpl_destroy(mjpl_engine *e) {
     if (e->stage[k]) (void)hipFree(e->stage[k]);
   if (e->d_ip) (void)hipFree(e->d_ip);
   if (e->d_dp) (void)hipFree(e->d_dp);
+  if (e->d_fp) (void)hipFree(e->d_fp);
+  if (e->d_ulist) (void)hipFree(e->d_ulist);
+  if (e->d_ucount) (void)hipFree(e->d_ucount);
   if (e->d_status) (void)hipFree(e->d_status);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -805,6 +973,28 @@ int mjpl_set_planning(mjpl_engine *e, const int32_t *qidx, int32_t nplan, const 
   return compile_program(e);
 }
 
+int mjpl_set_filter(mjpl_engine *e, int32_t enable, double tol) {
+  if (!e) return fail(MJPL_E_ARG, "mjpl_set_filter: NULL engine");
+  if (enable && !(tol > 0.0 && tol < 1.0)) return fail(MJPL_E_ARG, "filter tolerance must be in (0, 1) metres");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->filter = enable != 0;
+  if (enable && (float)tol != e->filter_tol) {
+    e->filter_tol = (float)tol;
+    return compile_program(e);
+  }
+  return MJPL_OK;
+}
+
+int64_t mjpl_filter_last_undecided(mjpl_engine *e) {
+  if (!e || !e->filter || !e->d_ucount) return 0;
+  int n = 0;
+  if (hipSetDevice(e->device) != hipSuccess) return -1;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+  if (hipMemcpy(&n, e->d_ucount, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
+
 int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   if (!e || !out) return fail(MJPL_E_ARG, "mjpl_get_info: NULL argument");
   memset(out, 0, sizeof(*out));
@@ -818,6 +1008,8 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   out->nsaves = e->nsave;
   out->lds_bytes_configs = (int)lds_bytes(e, 1);
   out->lds_bytes_edges = (int)lds_bytes(e, 2);
+  out->filter_enabled = e->filter ? 1 : 0;
+  out->filter_tol = e->filter_tol;
   out->block_threads = kBlock;
   out->compute_units = e->prop.multiProcessorCount;
   strncpy(out->arch, e->prop.gcnArchName, sizeof(out->arch) - 1);

@@ -47,6 +47,7 @@ class Info(C.Structure):
         ("nstatic_geoms", C.c_int32), ("npairs", C.c_int32), ("npairs_world", C.c_int32),
         ("nslots", C.c_int32), ("nsaves", C.c_int32), ("lds_bytes_configs", C.c_int32),
         ("lds_bytes_edges", C.c_int32), ("block_threads", C.c_int32), ("compute_units", C.c_int32),
+        ("filter_enabled", C.c_int32), ("filter_tol", C.c_float),
         ("arch", C.c_char * 32),
     ]
 
@@ -63,6 +64,8 @@ ABI = {
     "mjpl_destroy": (None, [_VP]),
     "mjpl_set_planning": (C.c_int, [_VP, _I32P, C.c_int32, _F64P]),
     "mjpl_get_info": (C.c_int, [_VP, C.POINTER(Info)]),
+    "mjpl_set_filter": (C.c_int, [_VP, C.c_int32, C.c_double]),
+    "mjpl_filter_last_undecided": (C.c_int64, [_VP]),
     "mjpl_check_configs": (C.c_int, [_VP, _F64P, C.c_int64, C.c_int32, _U8P]),
     "mjpl_check_edges": (C.c_int, [_VP, _F64P, _F64P, C.c_int64, C.c_double, C.c_int32, C.c_int32, _U8P,
                                    _I32P]),
@@ -198,6 +201,13 @@ class Engine:
         i = Info()
         self._ok(self.lib.mjpl_get_info(self.h, C.byref(i)))
         return i.as_dict()
+
+    def set_filter(self, enable: bool, tol: float = 1e-4):
+        """Float32 filter in front of the exact kernels (verdicts are always the exact ones)."""
+        self._ok(self.lib.mjpl_set_filter(self.h, 1 if enable else 0, float(tol)))
+
+    def last_undecided(self) -> int:
+        return int(self.lib.mjpl_filter_last_undecided(self.h))
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

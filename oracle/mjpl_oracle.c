@@ -21,6 +21,19 @@
 #define ORC_MINVAL 1e-15 /* mjMINVAL [MJ-recalled: mjmodel.h] */
 #define ORC_MAXCON 4096
 
+/* per-thread scratch, grown on demand (a malloc per configuration serialises 256 threads) */
+static __thread double *tls_buf[3];
+static __thread size_t tls_cap[3];
+
+static double *scratch(int slot, size_t ndoubles) {
+  if (tls_cap[slot] < ndoubles) {
+    free(tls_buf[slot]);
+    tls_buf[slot] = (double *)malloc(sizeof(double) * ndoubles);
+    tls_cap[slot] = tls_buf[slot] ? ndoubles : 0;
+  }
+  return tls_buf[slot];
+}
+
 /* ------------------------------------------------------------------ small vector helpers
  * [MJ-recalled: engine_util_blas.c / engine_util_spatial.c]; operation order is the contract. */
 
@@ -123,7 +136,7 @@ int orc_kinematics(const orc_model *m, const double *qpos,
                    double *xpos_out, double *xquat_out, double *xmat_out,
                    double *geom_xpos, double *geom_xmat) {
   const int nb = m->nbody;
-  double *xpos = (double *)malloc(sizeof(double) * (size_t)nb * 16);
+  double *xpos = scratch(0, (size_t)nb * 16);
   if (!xpos) return ORC_E_OVERFLOW;
   double *xquat = xpos + 3 * nb;
   double *xmat = xquat + 4 * nb;
@@ -197,7 +210,6 @@ int orc_kinematics(const orc_model *m, const double *qpos,
   if (xpos_out) memcpy(xpos_out, xpos, sizeof(double) * 3 * (size_t)nb);
   if (xquat_out) memcpy(xquat_out, xquat, sizeof(double) * 4 * (size_t)nb);
   if (xmat_out) memcpy(xmat_out, xmat, sizeof(double) * 9 * (size_t)nb);
-  free(xpos);
   return status;
 }
 
@@ -591,16 +603,14 @@ int orc_obeys_ruleset(const orc_model *m, const int32_t *contact_geom, int32_t n
  * collision_constraint.py:26-30: qpos <- q; mj_kinematics; mj_collision; ruleset. */
 int orc_valid_config(const orc_model *m, const int32_t *allowed, int32_t nallowed,
                      const double *qpos) {
-  double *buf = (double *)malloc(sizeof(double) * (size_t)m->ngeom * 12);
-  int32_t *con = (int32_t *)malloc(sizeof(int32_t) * 2 * ORC_MAXCON);
-  if (!buf || !con) { free(buf); free(con); return ORC_E_OVERFLOW; }
+  double *buf = scratch(1, (size_t)m->ngeom * 12);
+  int32_t *con = (int32_t *)scratch(2, ORC_MAXCON);
+  if (!buf || !con) return ORC_E_OVERFLOW;
   double *gx = buf, *gm = buf + 3 * m->ngeom;
   int32_t ncon = 0;
   int st = orc_kinematics(m, qpos, NULL, NULL, NULL, gx, gm);
   if (st == ORC_OK) st = orc_collision(m, gx, gm, con, ORC_MAXCON, &ncon);
   int res = (st == ORC_OK) ? orc_obeys_ruleset(m, con, ncon, allowed, nallowed) : st;
-  free(buf);
-  free(con);
   return res;
 }
 
