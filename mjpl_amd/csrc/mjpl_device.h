@@ -65,8 +65,10 @@ enum : int {
   H_NSLOTS,        // register slots in use
   H_OFF_BODYOPS,   // int offset of the first body op
   H_OFF_PERM,      // int offset of the ascending-qpos-address column permutation
-  H_OFF_WORLD,     // double offset of the static ("world") geom table, W_LEN doubles per row
-  H_NWORLD,        // rows in the world table
+  H_OFF_WCULL,     // constant-table offset of the world cull table
+  H_OFF_WNARROW,   // constant-table offset of the world narrowphase table
+  H_NWORLD,        // static geoms
+  H_NWPAD,         // ... rounded up to a multiple of 4
   H_SIZE
 };
 
@@ -79,26 +81,29 @@ enum : int { J_TYPE = 0, J_QSRC, J_FLAGS, J_DOFF, J_SIZE };  // qsrc >= 0: plann
 enum : int { JF_POS_NONZERO = 1 };
 // joint dp: axis[3] pos[3] qpos0 qconst
 
-enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_NSTORED, G_WMASK_LO, G_WMASK_HI,
+// geom record: 10 header ints, then MAX_SLOTS stored-partner words (0 where the slot is no partner)
+enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_SMASK, G_WMASK_LO, G_WMASK_HI,
              G_PMASK_LO, G_PMASK_HI, G_SIZE };
 enum : int { GF_SAMEPOS = 1, GF_SAMEROT = 2 };
-// geom dp: lpos[3] lquat[4] size[3] pad[2] | wbound[nworld] | wmargin[nworld] | stored[nstored][5]
-//   wbound[w]  cull bound against static geom w: (r1+r2+margin)^2, or margin + rbound for a plane
+enum : int { MAX_SLOTS = 16 };
+// geom constants: lpos[3] lquat[4] size[3] pad[2] | wbound[nwpad] | wmargin[nwpad]
+//                 | sbound[16] | smargin[16] | ssize[16][3]
+//   wbound[w]  cull bound against static geom w: (r1+r2+margin)^2, or margin + rbound for a
+//              plane; +inf where the pair is disabled.  nwpad = rows rounded up to a multiple of 4
 //   wmargin[w] pair margin max(margin_cur, margin_w)
-//   stored[k]  = bound, margin, psize[3] of the k-th earlier moving partner
+//   sbound[s]  cull bound against the earlier moving geom held in register slot s (+inf if none)
 enum : int { GD_LPOS = 0, GD_LQUAT = 3, GD_SIZE = 7, GD_WBOUND = 12 };
-enum : int { SD_BOUND = 0, SD_MARGIN, SD_SIZE, SD_LEN = 5 };
 
 // static partners: G_WMASK (non-plane) and G_PMASK (plane) are bit masks over the rows of the
-// world table (<= 64 static geoms).
-// stored partners: one packed int each, right after the geom record:
-//   bits 0..5 first slot ; bits 6..11 second slot (boxes, else SLOT_NONE) ; bits 12..15 type
-//   bit 17    partner is the FIRST geom of the pair in mj_collision's (g1,g2) order
+// world tables (<= 64 static geoms); G_SMASK is a bit mask over register slots.
+// stored-partner word s:  bits 0..5 second slot (boxes, else SLOT_NONE) ; bits 12..15 type ;
+//   bit 17 = the partner is the FIRST geom of the pair in mj_collision's (g1,g2) order
 enum : int { P_FIRST = 1 << 17 };
-// world table row (fixed stride so that the next row can be requested before it is needed):
-//   [0..2] pos  [3..5] z axis  [6] info word (type | geom id << 8)  [7] pad   <- cull part, 64 B
-//   [8..10] x axis  [11..13] y axis  [14..16] size  [17..19] pad              <- narrowphase part
-enum : int { W_POS = 0, W_ZAXIS = 3, W_INFO = 6, W_XAXIS = 8, W_YAXIS = 11, W_SIZE = 14, W_LEN = 20 };
+// world tables (fixed strides so that a chunk of four rows is one wide scalar load):
+//   cull table   [nwpad][4] : pos[3], info word (type | geom id << 8)
+//   narrow table [nworld][12]: z axis[3], x axis[3], y axis[3], size[3]
+enum : int { WC_POS = 0, WC_INFO = 3, WC_LEN = 4 };
+enum : int { WN_ZAXIS = 0, WN_XAXIS = 3, WN_YAXIS = 6, WN_SIZE = 9, WN_LEN = 12 };
 
 enum : int { GT_PLANE = 0, GT_SPHERE = 2, GT_CAPSULE = 3, GT_BOX = 6 };
 enum : int { JT_SLIDE = 2, JT_HINGE = 3 };
@@ -632,7 +637,9 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
   T p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   bool hit = false, unsure = false;
   const int nbodyops = uni(ip[H_NBODYOPS]);
-  Tab world = tp + uni(ip[H_OFF_WORLD]);
+  Tab wcull = tp + uni(ip[H_OFF_WCULL]);
+  Tab wnarrow = tp + uni(ip[H_OFF_WNARROW]);
+  const int nwpad = uni(ip[H_NWPAD]);
   int pc = uni(ip[H_OFF_BODYOPS]);
 
   for (int b = 0; b < nbodyops; b++) {
@@ -743,14 +750,15 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
       Tab gd = tp + uni(ip[pc + G_DOFF]);
       const int store = uni(ip[pc + G_STORE]);
       const int geom_id = uni(ip[pc + G_GEOMID]);
-      const int nstored = uni(ip[pc + G_NSTORED]);
+      const unsigned smask = (unsigned)uni(ip[pc + G_SMASK]);
       const unsigned long long wmask_all =
           (unsigned long long)(unsigned)uni(ip[pc + G_WMASK_LO]) |
           ((unsigned long long)(unsigned)uni(ip[pc + G_WMASK_HI]) << 32);
       const unsigned long long pmask_all =
           (unsigned long long)(unsigned)uni(ip[pc + G_PMASK_LO]) |
           ((unsigned long long)(unsigned)uni(ip[pc + G_PMASK_HI]) << 32);
-      pc += G_SIZE;
+      IP swords = ip + pc + G_SIZE;  // MAX_SLOTS stored-partner words
+      pc += G_SIZE + MAX_SLOTS;
 
       Geom cur;
       const T gsize[3] = {gd[GD_SIZE], gd[GD_SIZE + 1], gd[GD_SIZE + 2]};
@@ -782,139 +790,153 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
       }
 
       if (!EMIT) {
-        const int nworld = uni(ip[H_NWORLD]);
-        Tab wbound = gd + GD_WBOUND;
+        Tab wbound = gd + GD_WBOUND;            // [nwpad] bounds, then [nwpad] margins
+        Tab sbound = wbound + 2 * nwpad;        // [16] bounds, [16] margins, [16][3] sizes
+        bool live = active && !hit && !unsure;  // lanes that still need an answer
 
         // ---- static planes (few): signed-distance cull, then the plane routines
         for (unsigned long long pm = pmask_all; pm; pm &= pm - 1) {
           const int wc = (int)__builtin_ctzll(pm);
-          Tab r = world + wc * W_LEN;
+          Tab rc = wcull + wc * WC_LEN;
+          Tab rw = wnarrow + wc * WN_LEN;
           Geom par;
-          par.pos[0] = r[W_POS]; par.pos[1] = r[W_POS + 1]; par.pos[2] = r[W_POS + 2];
-          par.m[2] = r[W_ZAXIS]; par.m[5] = r[W_ZAXIS + 1]; par.m[8] = r[W_ZAXIS + 2];
+          par.pos[0] = rc[WC_POS]; par.pos[1] = rc[WC_POS + 1]; par.pos[2] = rc[WC_POS + 2];
+          par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
           par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
           T dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
           T n[3] = {par.m[2], par.m[5], par.m[8]};
-          const bool pass = !(dot3(dif, n) > wbound[wc]) && active && !hit && !unsure;
-          if (__ballot(pass) == 0ull) continue;
+          const bool pass = !(dot3(dif, n) > wbound[wc]) && live;
+          if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
           const T psize[3] = {0, 0, 0};
           const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, GT_PLANE, par, psize, true,
-                                                       wbound[nworld + wc], tol);
+                                                       wbound[nwpad + wc], tol);
           hit = hit || (pass && code == V_CONTACT);
           unsure = unsure || (pass && code == V_UNSURE);
+          live = live && !(pass && code != V_NONE);
         }
 
-        // ---- other static partners: rows of the world table selected by the enable mask.
-        // The cull part of the NEXT enabled row (64 B) and its bound are requested, without a
-        // branch, before the current row is tested, so that the scalar-load round trip of a
-        // pair overlaps the previous pair's arithmetic.
+        // ---- other static partners, four rows of the world cull table at a time.  The four
+        // bounding culls (mj_collideSphere: squared centre distance; (a-b)^2 == (b-a)^2 exactly,
+        // so the pair order does not matter; the filter's bounds are widened by tol) are
+        // unrolled with their operands in SGPRs; the narrowphase is a rolled loop over the
+        // rows some lane still needs, so there is one copy of it in the instruction stream.
 #ifdef MJPL_X_SKIP_WORLD
-        unsigned long long wmask = 0;
+        const unsigned long long wmask = 0;
 #else
-        unsigned long long wmask = wmask_all;
+        const unsigned long long wmask = wmask_all;
 #endif
-        int w = wmask ? (int)__builtin_ctzll(wmask) : 0;
-        Tab rn = world + w * W_LEN;
-        T nx_pos[3] = {rn[W_POS], rn[W_POS + 1], rn[W_POS + 2]};
-        T nx_z[3] = {rn[W_ZAXIS], rn[W_ZAXIS + 1], rn[W_ZAXIS + 2]};
-        int nx_info = ((IP)(rn + W_INFO))[0];
-        T nx_bound = wbound[w];
-        while (wmask) {
-          Geom par;
-          par.pos[0] = nx_pos[0]; par.pos[1] = nx_pos[1]; par.pos[2] = nx_pos[2];
-          par.m[2] = nx_z[0]; par.m[5] = nx_z[1]; par.m[8] = nx_z[2];
-          const int info = nx_info;
-          const T bound = nx_bound;
-          const int wc = w;
-          wmask &= wmask - 1;
-          w = wmask ? (int)__builtin_ctzll(wmask) : 0;
-          rn = world + w * W_LEN;
-          nx_pos[0] = rn[W_POS]; nx_pos[1] = rn[W_POS + 1]; nx_pos[2] = rn[W_POS + 2];
-          nx_z[0] = rn[W_ZAXIS]; nx_z[1] = rn[W_ZAXIS + 1]; nx_z[2] = rn[W_ZAXIS + 2];
-          nx_info = ((IP)(rn + W_INFO))[0];
-          nx_bound = wbound[w];
-
-          const int ptype = info & 255;
-          __builtin_assume(ptype != GT_PLANE);
+        for (int base = 0; base < nwpad; base += 4) {
+          const unsigned bits = (unsigned)(wmask >> base) & 15u;
+          if (bits == 0) continue;
+          Tab rc = wcull + base * WC_LEN;
+          Tab bc = wbound + base;
           pin_geom(cur);
-          // bounding cull (mj_collideSphere): squared centre distance; (a-b)^2 == (b-a)^2 exactly,
-          // so the pair order does not matter.  (The filter's table holds bounds widened by tol.)
-          T dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
-          const bool pass = !(dot3(dif, dif) > bound) && active && !hit && !unsure;
-          if (__ballot(pass) == 0ull) continue;  // nobody in the wave needs the narrowphase
+          bool ps0, ps1, ps2, ps3;
+#define MJPL_WCULL(k, out)                                                              \
+          {                                                                             \
+            T dx = cur.pos[0] - rc[(k) * WC_LEN], dy = cur.pos[1] - rc[(k) * WC_LEN + 1],  \
+              dz = cur.pos[2] - rc[(k) * WC_LEN + 2];                                   \
+            out = !(dx * dx + dy * dy + dz * dz > bc[k]) && live && ((bits >> (k)) & 1u); \
+          }
+          MJPL_WCULL(0, ps0) MJPL_WCULL(1, ps1) MJPL_WCULL(2, ps2) MJPL_WCULL(3, ps3)
+#undef MJPL_WCULL
+          if (__builtin_amdgcn_ballot_w64(ps0 || ps1 || ps2 || ps3) == 0ull) continue;
 #ifdef MJPL_X_SKIP_NARROW
-          hit = hit || (pass && dif[0] == T(12345.0));
+          hit = hit || ((ps0 || ps1 || ps2 || ps3) && cur.pos[0] == T(12345.0));
           continue;
 #endif
-
-          Tab r = world + wc * W_LEN;
-          const T psize[3] = {r[W_SIZE], r[W_SIZE + 1], r[W_SIZE + 2]};
-          if (WBOX) {
-            par.m[0] = r[W_XAXIS]; par.m[3] = r[W_XAXIS + 1]; par.m[6] = r[W_XAXIS + 2];
-            par.m[1] = r[W_YAXIS]; par.m[4] = r[W_YAXIS + 1]; par.m[7] = r[W_YAXIS + 2];
-          } else {
-            par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
+#pragma unroll 1
+          for (int k = 0; k < 4; k++) {
+            const bool pk = (k == 0 ? ps0 : (k == 1 ? ps1 : (k == 2 ? ps2 : ps3))) && live;
+            if (__builtin_amdgcn_ballot_w64(pk) == 0ull) continue;
+            const int wc = base + k;
+            Tab r4 = wcull + wc * WC_LEN;
+            Tab rw = wnarrow + wc * WN_LEN;
+            const int info = ((IP)(r4 + WC_INFO))[0];
+            const int ptype = info & 255;
+            __builtin_assume(ptype != GT_PLANE);
+            Geom par;
+            par.pos[0] = r4[WC_POS]; par.pos[1] = r4[WC_POS + 1]; par.pos[2] = r4[WC_POS + 2];
+            par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
+            if (WBOX) {
+              par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
+              par.m[1] = rw[WN_YAXIS]; par.m[4] = rw[WN_YAXIS + 1]; par.m[7] = rw[WN_YAXIS + 2];
+            } else {
+              par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
+            }
+            const T psize[3] = {rw[WN_SIZE], rw[WN_SIZE + 1], rw[WN_SIZE + 2]};
+            // mj_collision order: smaller geom type first, geom id breaks ties
+            const int pgid = info >> 8;
+            const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < geom_id);
+            const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst,
+                                                         wbound[nwpad + wc], tol);
+            hit = hit || (pk && code == V_CONTACT);
+            unsure = unsure || (pk && code == V_UNSURE);
+            live = live && !(pk && code != V_NONE);
           }
-          // mj_collision order: smaller geom type first, geom id breaks ties
-          const int pgid = info >> 8;
-          const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < geom_id);
-          const T margin = wbound[nworld + wc];
-          const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
-          hit = hit || (pass && code == V_CONTACT);
-          unsure = unsure || (pass && code == V_UNSURE);
         }
 
-        // ---- earlier moving partners, held in the register slot file
-        Tab sd = gd + GD_WBOUND + 2 * nworld;
-        // same software pipeline as above: word and bound of the next entry are in flight
-        // while the current one is tested (the tables are padded past their last entry)
-        int nx_pw = ip[pc];
-        T nx_sb = sd[SD_BOUND];
+        // ---- earlier moving partners, held in the register slot file: same scheme, four
+        // slots at a time, the slot registers addressed by literal index
 #ifdef MJPL_X_SKIP_STORED
-        for (int e = 0; e < 0; e++, sd += SD_LEN) {
+        const unsigned smask_use = 0;
 #else
-        for (int e = 0; e < nstored; e++, sd += SD_LEN) {
+        const unsigned smask_use = smask;
 #endif
-          const int pw = uni(nx_pw);
-          const T sbound = nx_sb;
-          nx_pw = ip[pc + e + 1];
-          nx_sb = sd[SD_LEN + SD_BOUND];
+        // culls are expanded per slot (literal register index); each lane records the slots
+        // it passed in `lanebits`, the wave records them in `anybits`
+        unsigned lanebits = 0, anybits = 0;
+#define MJPL_SCULL(n)                                                                      \
+        if constexpr (MAXS > n) {                                                         \
+          if ((smask_use >> (n)) & 1u) {                                                  \
+            T dx = cur.pos[0] - sf.v[n][0], dy = cur.pos[1] - sf.v[n][1], dz = cur.pos[2] - sf.v[n][2]; \
+            const bool ps = !(dx * dx + dy * dy + dz * dz > sbound[n]) && live;           \
+            lanebits |= ps ? (1u << (n)) : 0u;                                            \
+            anybits |= (__builtin_amdgcn_ballot_w64(ps) != 0ull) ? (1u << (n)) : 0u;      \
+          }                                                                               \
+        }
+        if (smask_use != 0) {
+          pin_geom(cur);
+          MJPL_FOR_SLOTS(MJPL_SCULL)
+        }
+#undef MJPL_SCULL
+#ifdef MJPL_X_SKIP_NARROW
+        hit = hit || (lanebits != 0 && cur.pos[0] == T(12345.0));
+        anybits = 0;
+#endif
+        for (unsigned ab = anybits; ab; ab &= ab - 1) {  // rolled: one copy of the narrowphase
+          const int slot = (int)__builtin_ctz(ab);
+          const bool pk = ((lanebits >> slot) & 1u) && live;
+          if (__builtin_amdgcn_ballot_w64(pk) == 0ull) continue;
+          const int pw = uni(swords[slot]);
           const int ptype = (pw >> 12) & 15;
           const bool pfirst = (pw & P_FIRST) != 0;
-          pin_geom(cur);
           Geom par;
           {
             T t6[6] = {0, 0, 0, 0, 0, 0};
-            const int slot_ = pw & 63;
+            const int slot_ = slot;
             switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_GET) default: break; }
             par.pos[0] = t6[0]; par.pos[1] = t6[1]; par.pos[2] = t6[2];
             par.m[2] = t6[3]; par.m[5] = t6[4]; par.m[8] = t6[5];
           }
-          T dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
-          const bool pass = !(dot3(dif, dif) > sbound) && active && !hit && !unsure;
-          if (__ballot(pass) == 0ull) continue;
-#ifdef MJPL_X_SKIP_NARROW
-          hit = hit || (pass && dif[0] == T(12345.0));
-          continue;
-#endif
-
-          const T psize[3] = {sd[SD_SIZE], sd[SD_SIZE + 1], sd[SD_SIZE + 2]};
           {
             T t6[6] = {0, 0, 0, 0, 0, 0};
-            if (MBOX && ((pw >> 6) & 63) != SLOT_NONE) {  // stored box: x and y axes
-              const int slot_ = (pw >> 6) & 63;
+            if (MBOX && (pw & 63) != SLOT_NONE) {  // stored box: x and y axes
+              const int slot_ = pw & 63;
               switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_GET) default: break; }
             }
             par.m[0] = t6[0]; par.m[3] = t6[1]; par.m[6] = t6[2];
             par.m[1] = t6[3]; par.m[4] = t6[4]; par.m[7] = t6[5];
           }
+          Tab sz = sbound + 2 * MAX_SLOTS + 3 * slot;
+          const T psize[3] = {sz[0], sz[1], sz[2]};
           const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst,
-                                                       sd[SD_MARGIN], tol);
-          hit = hit || (pass && code == V_CONTACT);
-          unsure = unsure || (pass && code == V_UNSURE);
+                                                       sbound[MAX_SLOTS + slot], tol);
+          hit = hit || (pk && code == V_CONTACT);
+          unsure = unsure || (pk && code == V_UNSURE);
+          live = live && !(pk && code != V_NONE);
         }
       }
-      pc += nstored;
 
       if (!EMIT && store >= 0) {
         {

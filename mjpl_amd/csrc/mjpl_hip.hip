@@ -460,7 +460,8 @@ int compile_program(mjpl_engine *e) {
   e->st_gxpos.assign(3 * ng, 0.0);
   e->st_gxmat.assign(9 * ng, 0.0);
   std::vector<int> world_row(ng, -1);
-  std::vector<double> world_tab;
+  std::vector<double> wcull_tab, wnarrow_tab;
+  std::vector<int> winfo;
   std::vector<std::pair<size_t, int>> info_at;  // dp index -> int stored there (first 4 bytes)
   std::vector<size_t> sq_bound_at, plane_bound_at;  // dp indices of cull bounds
   e->nstatic = e->nmoving = 0;
@@ -481,24 +482,27 @@ int compile_program(mjpl_engine *e) {
     for (int k = 0; k < 3; k++) e->st_gxpos[3 * g + k] = gp[k] + e->st_xpos[3 * b + k];
     mul_quat(gq, &e->st_xquat[4 * b], &m.geom_quat[4 * g]);
     quat2mat(&e->st_gxmat[9 * g], gq);
-    world_row[g] = (int)(world_tab.size() / W_LEN);
+    world_row[g] = (int)(wcull_tab.size() / WC_LEN);
     {
       const double *gmx = &e->st_gxmat[9 * g];
-      double row[W_LEN] = {0};
+      double rc[WC_LEN] = {0}, rn[WN_LEN] = {0};
       for (int k = 0; k < 3; k++) {
-        row[W_POS + k] = e->st_gxpos[3 * g + k];
-        row[W_XAXIS + k] = gmx[3 * k + 0];
-        row[W_YAXIS + k] = gmx[3 * k + 1];
-        row[W_ZAXIS + k] = gmx[3 * k + 2];
-        row[W_SIZE + k] = m.geom_size[3 * g + k];
+        rc[WC_POS + k] = e->st_gxpos[3 * g + k];
+        rn[WN_XAXIS + k] = gmx[3 * k + 0];
+        rn[WN_YAXIS + k] = gmx[3 * k + 1];
+        rn[WN_ZAXIS + k] = gmx[3 * k + 2];
+        rn[WN_SIZE + k] = m.geom_size[3 * g + k];
       }
       const int32_t info[2] = {m.geom_type[g] | (g << 8), 0};
-      memcpy(&row[W_INFO], info, sizeof(double));
-      info_at.push_back({world_tab.size() + W_INFO, info[0]});
-      world_tab.insert(world_tab.end(), row, row + W_LEN);
+      memcpy(&rc[WC_INFO], info, sizeof(double));
+      winfo.push_back(info[0]);
+      wcull_tab.insert(wcull_tab.end(), rc, rc + WC_LEN);
+      wnarrow_tab.insert(wnarrow_tab.end(), rn, rn + WN_LEN);
     }
   }
-  const int nworld = (int)(world_tab.size() / W_LEN);
+  const int nworld = (int)(wcull_tab.size() / WC_LEN);
+  const int nwpad = (nworld + 3) / 4 * 4;
+  wcull_tab.resize((size_t)nwpad * WC_LEN, 0.0);
   if (nworld > 64) return fail(MJPL_E_CAPACITY, "%d static geoms; this build enables at most 64 per moving geom", nworld);
   if (ng >= (1 << 23)) return fail(MJPL_E_CAPACITY, "too many geoms");
 
@@ -566,9 +570,9 @@ int compile_program(mjpl_engine *e) {
     }
     e->nslots = (int)free_at.size();
   }
-  if (e->nslots > 16)
-    return fail(MJPL_E_CAPACITY, "%d moving geoms must be held at once; this build has 16 register slots",
-                e->nslots);
+  if (e->nslots > MAX_SLOTS)
+    return fail(MJPL_E_CAPACITY, "%d moving geoms must be held at once; this build has %d register slots",
+                e->nslots, (int)MAX_SLOTS);
   e->maxs = e->nslots <= 4 ? 4 : (e->nslots <= 8 ? 8 : (e->nslots <= 12 ? 12 : 16));
   e->nsave = nsave;
 
@@ -585,9 +589,13 @@ int compile_program(mjpl_engine *e) {
   ip[H_NSAVE] = nsave;
   ip[H_NSLOTS] = e->nslots;
   ip[H_NBODYOPS] = (int)order.size();
-  ip[H_OFF_WORLD] = 0;
+  ip[H_OFF_WCULL] = 0;
   ip[H_NWORLD] = nworld;
-  dp = world_tab;
+  ip[H_NWPAD] = nwpad;
+  dp = wcull_tab;
+  for (int w = 0; w < nworld; w++) info_at.push_back({(size_t)w * WC_LEN + WC_INFO, winfo[w]});
+  ip[H_OFF_WNARROW] = (int)dp.size();
+  dp.insert(dp.end(), wnarrow_tab.begin(), wnarrow_tab.end());
 
   // column permutation: ascending qpos address (the order np.linalg.norm sums the full vector)
   ip[H_OFF_PERM] = (int)ip.size();
@@ -643,16 +651,20 @@ int compile_program(mjpl_engine *e) {
       unsigned long long wmask = 0, pmask = 0;
       for (int sgeom : world_partners[gk])
         (m.geom_type[sgeom] == GT_PLANE ? pmask : wmask) |= 1ull << world_row[sgeom];
+      unsigned smask = 0;
+      for (int k2 : stored_partners[gk]) smask |= 1u << (slot_of[k2] & 63);
       ip.push_back(m.geom_type[g]);
       ip.push_back(flags);
       ip.push_back((int)dp.size());
       ip.push_back(slot_of[gk]);
       ip.push_back(g);
-      ip.push_back((int)stored_partners[gk].size());
+      ip.push_back((int)smask);
       ip.push_back((int)(uint32_t)(wmask & 0xffffffffull));
       ip.push_back((int)(uint32_t)(wmask >> 32));
       ip.push_back((int)(uint32_t)(pmask & 0xffffffffull));
       ip.push_back((int)(uint32_t)(pmask >> 32));
+      const size_t swords_at = ip.size();
+      ip.insert(ip.end(), MAX_SLOTS, 0);
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(gp[k3]);
       for (int k4 = 0; k4 < 4; k4++) dp.push_back(gq[k4]);
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * g + k3]);
@@ -672,8 +684,9 @@ int compile_program(mjpl_engine *e) {
           *bound = *margin + m.geom_rbound[g];
         }
       };
+      const double inf = std::numeric_limits<double>::infinity();
       {
-        std::vector<double> wb(nworld, std::numeric_limits<double>::infinity()), wm(nworld, 0.0);
+        std::vector<double> wb(nwpad, inf), wm(nwpad, 0.0);
         for (int sgeom : world_partners[gk]) {
           pair_bound(sgeom, &wb[world_row[sgeom]], &wm[world_row[sgeom]]);
           (m.geom_type[sgeom] == GT_PLANE ? plane_bound_at : sq_bound_at).push_back(dp.size() + world_row[sgeom]);
@@ -681,17 +694,21 @@ int compile_program(mjpl_engine *e) {
         dp.insert(dp.end(), wb.begin(), wb.end());
         dp.insert(dp.end(), wm.begin(), wm.end());
       }
-      for (int k2 : stored_partners[gk]) {
-        const int h = mgeoms[k2];
-        const int g1 = std::min(g, h), g2 = std::max(g, h);
-        const int first = (m.geom_type[g1] > m.geom_type[g2]) ? g2 : g1;
-        ip.push_back(slot_of[k2] | (m.geom_type[h] << 12) | (first == h ? P_FIRST : 0));
-        double bound, margin;
-        pair_bound(h, &bound, &margin);
-        sq_bound_at.push_back(dp.size());
-        dp.push_back(bound);
-        dp.push_back(margin);
-        for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * h + k3]);
+      {
+        std::vector<double> sb(MAX_SLOTS, inf), sm(MAX_SLOTS, 0.0), ss(3 * MAX_SLOTS, 0.0);
+        for (int k2 : stored_partners[gk]) {
+          const int h = mgeoms[k2];
+          const int s1 = slot_of[k2] & 63, s2 = (slot_of[k2] >> 6) & 63;
+          const int g1 = std::min(g, h), g2 = std::max(g, h);
+          const int first = (m.geom_type[g1] > m.geom_type[g2]) ? g2 : g1;
+          ip[swords_at + s1] = s2 | (m.geom_type[h] << 12) | (first == h ? P_FIRST : 0);
+          pair_bound(h, &sb[s1], &sm[s1]);
+          sq_bound_at.push_back(dp.size() + s1);
+          for (int k3 = 0; k3 < 3; k3++) ss[3 * s1 + k3] = m.geom_size[3 * h + k3];
+        }
+        dp.insert(dp.end(), sb.begin(), sb.end());
+        dp.insert(dp.end(), sm.begin(), sm.end());
+        dp.insert(dp.end(), ss.begin(), ss.end());
       }
     }
     ip[base + B_NGEOM] = ngeom_here;
