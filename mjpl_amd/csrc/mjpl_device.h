@@ -83,7 +83,7 @@ enum : int { JF_POS_NONZERO = 1 };
 
 // geom record: 10 header ints, then MAX_SLOTS stored-partner words (0 where the slot is no partner)
 enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_SMASK, G_WMASK_LO, G_WMASK_HI,
-             G_PMASK_LO, G_PMASK_HI, G_SIZE };
+             G_PMASK_LO, G_PMASK_HI, G_NENT, G_ENT_OFF, G_SIZE };
 enum : int { GF_SAMEPOS = 1, GF_SAMEROT = 2 };
 enum : int { MAX_SLOTS = 16 };
 // geom constants: lpos[3] lquat[4] size[3] pad[2] | wbound[nwpad] | wmargin[nwpad]
@@ -103,6 +103,15 @@ enum : int { P_FIRST = 1 << 17 };
 //   cull table   [nwpad][4] : pos[3], info word (type | geom id << 8)
 //   narrow table [nworld][12]: z axis[3], x axis[3], y axis[3], size[3]
 enum : int { WC_POS = 0, WC_INFO = 3, WC_LEN = 4 };
+// unified partner entries of a geom (queued kernels): one fixed-stride record per enabled pair,
+// planes first, then the other static geoms, then the register slots -- everything a bounding
+// cull and a queue push need, so the next entry is a single wide scalar load
+//   [0] word  [1] cull bound  [2..4] partner pos (static)  [5] pair margin
+//   [6..8] partner z axis (static: plane normal / capsule axis)  [9..11] partner size
+//   word: bits 0..1 kind (0 plane, 1 other static, 2 register slot) ; bits 2..9 row or slot ;
+//         bits 12..15 partner type ; bit 17 = the partner is g1 of mj_collision's (g1, g2)
+enum : int { E_WORD = 0, E_BOUND, E_POS, E_MARGIN = 5, E_ZAXIS = 6, E_SIZE = 9, E_LEN = 12 };
+enum : int { EK_PLANE = 0, EK_STATIC = 1, EK_SLOT = 2 };
 enum : int { WN_ZAXIS = 0, WN_XAXIS = 3, WN_YAXIS = 6, WN_SIZE = 9, WN_LEN = 12 };
 
 enum : int { GT_PLANE = 0, GT_SPHERE = 2, GT_CAPSULE = 3, GT_BOX = 6 };
@@ -570,31 +579,27 @@ struct FkOut {  // global-memory destinations of the FK parity kernel (any may b
   int nbody, ngeom;
 };
 
+// Register slot file: six MAXS-wide vectors (pos x/y/z, z-axis x/y/z) held in VGPRs.  A slot is
+// selected with a wave-uniform index, which the compiler turns into indirect VGPR addressing
+// (s_set_gpr_idx_on + v_mov): a handful of instructions, against a compare tree for a switch.
 template <class T, int MAXS>
 struct SlotFile {
-  T v[MAXS > 0 ? MAXS : 1][6];  // pos[3], zaxis[3] of earlier moving sphere/capsule geoms
+  typedef T Vec __attribute__((ext_vector_type(MAXS)));
+  Vec f[6];
 };
 
-// Slot access is expanded in place by macros, with a literal index per slot: the slot file is
-// a local of run_config whose every access has a constant index from the start, so the first
-// SROA pass promotes it to VGPRs.  (Behind a helper function taking it by reference, or
-// indexed by a loop variable, SimplifyCFG merges the per-slot loads into one load with a
-// selected address and the file ends up in scratch memory.)
-#define MJPL_FOR_SLOTS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
-#define MJPL_SLOT_PUT(n)                                                          \
-  case n:                                                                         \
-    if constexpr (MAXS > n) {                                                     \
-      sf.v[n][0] = t6[0]; sf.v[n][1] = t6[1]; sf.v[n][2] = t6[2];                 \
-      sf.v[n][3] = t6[3]; sf.v[n][4] = t6[4]; sf.v[n][5] = t6[5];                 \
-    }                                                                             \
-    break;
-#define MJPL_SLOT_GET(n)                                                          \
-  case n:                                                                         \
-    if constexpr (MAXS > n) {                                                     \
-      t6[0] = sf.v[n][0]; t6[1] = sf.v[n][1]; t6[2] = sf.v[n][2];                 \
-      t6[3] = sf.v[n][3]; t6[4] = sf.v[n][4]; t6[5] = sf.v[n][5];                 \
-    }                                                                             \
-    break;
+template <class T, int MAXS>
+__device__ __forceinline__ void slot_put6(SlotFile<T, MAXS> &sf, int slot, const T *t6) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) sf.f[k][slot] = t6[k];
+}
+
+template <class T, int MAXS>
+__device__ __forceinline__ void slot_get6(const SlotFile<T, MAXS> &sf, int slot, T *t6) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) t6[k] = sf.f[k][slot];
+}
+
 // A sphere/capsule occupies one slot (pos, z axis); a box a second one (x and y axes).
 // Slot ids are packed as  first | (second << 6), second == SLOT_NONE when unused.
 enum : int { SLOT_NONE = 63 };
@@ -886,20 +891,18 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
         // culls are expanded per slot (literal register index); each lane records the slots
         // it passed in `lanebits`, the wave records them in `anybits`
         unsigned lanebits = 0, anybits = 0;
-#define MJPL_SCULL(n)                                                                      \
-        if constexpr (MAXS > n) {                                                         \
-          if ((smask_use >> (n)) & 1u) {                                                  \
-            T dx = cur.pos[0] - sf.v[n][0], dy = cur.pos[1] - sf.v[n][1], dz = cur.pos[2] - sf.v[n][2]; \
-            const bool ps = !(dx * dx + dy * dy + dz * dz > sbound[n]) && live;           \
-            lanebits |= ps ? (1u << (n)) : 0u;                                            \
-            anybits |= (__builtin_amdgcn_ballot_w64(ps) != 0ull) ? (1u << (n)) : 0u;      \
-          }                                                                               \
-        }
         if (smask_use != 0) {
           pin_geom(cur);
-          MJPL_FOR_SLOTS(MJPL_SCULL)
+#pragma unroll
+          for (int n = 0; n < MAXS; n++) {  // literal register operands after unrolling
+            if ((smask_use >> n) & 1u) {
+              T dx = cur.pos[0] - sf.f[0][n], dy = cur.pos[1] - sf.f[1][n], dz = cur.pos[2] - sf.f[2][n];
+              const bool ps = !(dx * dx + dy * dy + dz * dz > sbound[n]) && live;
+              lanebits |= ps ? (1u << n) : 0u;
+              anybits |= (__builtin_amdgcn_ballot_w64(ps) != 0ull) ? (1u << n) : 0u;
+            }
+          }
         }
-#undef MJPL_SCULL
 #ifdef MJPL_X_SKIP_NARROW
         hit = hit || (lanebits != 0 && cur.pos[0] == T(12345.0));
         anybits = 0;
@@ -913,18 +916,14 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
           const bool pfirst = (pw & P_FIRST) != 0;
           Geom par;
           {
-            T t6[6] = {0, 0, 0, 0, 0, 0};
-            const int slot_ = slot;
-            switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_GET) default: break; }
+            T t6[6];
+            slot_get6(sf, slot, t6);
             par.pos[0] = t6[0]; par.pos[1] = t6[1]; par.pos[2] = t6[2];
             par.m[2] = t6[3]; par.m[5] = t6[4]; par.m[8] = t6[5];
           }
           {
             T t6[6] = {0, 0, 0, 0, 0, 0};
-            if (MBOX && (pw & 63) != SLOT_NONE) {  // stored box: x and y axes
-              const int slot_ = pw & 63;
-              switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_GET) default: break; }
-            }
+            if (MBOX && (pw & 63) != SLOT_NONE) slot_get6(sf, pw & 63, t6);  // stored box: x and y axes
             par.m[0] = t6[0]; par.m[3] = t6[1]; par.m[6] = t6[2];
             par.m[1] = t6[3]; par.m[4] = t6[4]; par.m[7] = t6[5];
           }
@@ -941,18 +940,287 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
       if (!EMIT && store >= 0) {
         {
           const T t6[6] = {cur.pos[0], cur.pos[1], cur.pos[2], cur.m[2], cur.m[5], cur.m[8]};
-          const int slot_ = store & 63;
-          switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_PUT) default: break; }
+          slot_put6(sf, store & 63, t6);
         }
         if (MBOX && ((store >> 6) & 63) != SLOT_NONE) {
           const T t6[6] = {cur.m[0], cur.m[3], cur.m[6], cur.m[1], cur.m[4], cur.m[7]};
-          const int slot_ = (store >> 6) & 63;
-          switch (slot_) { MJPL_FOR_SLOTS(MJPL_SLOT_PUT) default: break; }
+          slot_put6(sf, (store >> 6) & 63, t6);
         }
       }
     }
   }
   return hit ? V_CONTACT : (unsure ? V_UNSURE : V_NONE);
+}
+
+
+// ----------------------------------------------------------------------------- queued narrowphase
+// The immediate interpreter above runs a narrowphase routine as soon as ANY lane of the wave
+// passes a bounding cull: with 64 unrelated configurations per wave that is the case for ~28 %
+// of the 213 Franka pairs although only ~2 % of the (lane, pair) tests pass, so ~95 % of the
+// lanes idle through every narrowphase call.  The queued interpreter separates the two: culls
+// run lane-per-configuration; every (lane, pair) that passes is PUSHED into a per-wave LDS
+// queue (both geoms' poses + what identifies the pair); when 64 candidates are waiting (and
+// at the end of the configuration) the wave DRAINS the queue with one candidate per lane, so
+// the narrowphase runs with full lanes, and reports contacts back to the owning lanes through
+// a per-wave flag word.  Arithmetic per pair is unchanged, only which lane executes it.
+
+enum : int { Q_CAP = 128, Q_FIELDS = 13 };  // record: cur pos/axis, partner pos/axis, margin
+// i0: bits 0..5 owner lane, 6..9 cur type, 10..13 partner type, 14 pfirst, 15..16 kind, 17..24 index
+// i1: constant-table offset of the cur geom's block (sizes; slot sizes)
+
+template <class T>
+struct WaveQueue {
+  T *f;        // [Q_FIELDS][Q_CAP]
+  int *i0, *i1;  // i0[Q_CAP]; i1[2][Q_CAP]: geom block offset, partner-size offset inside it
+  int *flags;  // [64] : bit0 contact, bit1 unsure, per owning lane
+  static __host__ __device__ constexpr size_t bytes() {
+    return (size_t)Q_FIELDS * Q_CAP * sizeof(T) + 3 * Q_CAP * sizeof(int) + 64 * sizeof(int);
+  }
+};
+
+template <class T, bool WBOX>
+__device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, typename Real<T>::Tab tp,
+                                            typename Real<T>::Tab wnarrow, T tol) {
+  typedef typename Real<T>::Tab Tab;
+  typedef GeomT<T> Geom;
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  while (qn > 0) {  // wave-uniform
+    const int n = qn < 64 ? qn : 64;
+    const int j = qn - n + lane;
+    const bool on = lane < n;
+    qn -= n;
+    const int jj = on ? j : 0;
+    const int i0 = wq.i0[jj];
+    Tab gd = tp + wq.i1[jj];
+    Geom cur, par;
+    cur.pos[0] = wq.f[0 * Q_CAP + jj]; cur.pos[1] = wq.f[1 * Q_CAP + jj]; cur.pos[2] = wq.f[2 * Q_CAP + jj];
+    cur.m[2] = wq.f[3 * Q_CAP + jj]; cur.m[5] = wq.f[4 * Q_CAP + jj]; cur.m[8] = wq.f[5 * Q_CAP + jj];
+    par.pos[0] = wq.f[6 * Q_CAP + jj]; par.pos[1] = wq.f[7 * Q_CAP + jj]; par.pos[2] = wq.f[8 * Q_CAP + jj];
+    par.m[2] = wq.f[9 * Q_CAP + jj]; par.m[5] = wq.f[10 * Q_CAP + jj]; par.m[8] = wq.f[11 * Q_CAP + jj];
+    const T margin = wq.f[12 * Q_CAP + jj];
+    cur.m[0] = cur.m[1] = cur.m[3] = cur.m[4] = cur.m[6] = cur.m[7] = 0;
+    par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
+    const int owner = i0 & 63, gtype = (i0 >> 6) & 15, ptype = (i0 >> 10) & 15;
+    const bool pfirst = (i0 >> 14) & 1;
+    const int kind = (i0 >> 15) & 3, index = (i0 >> 17) & 255;
+    // per-lane gathers of the sizes (and a static box's other two axes)
+    const T gsize[3] = {gd[GD_SIZE], gd[GD_SIZE + 1], gd[GD_SIZE + 2]};
+    // partner sizes: static -> world narrow table; slot -> the cur geom's ssize[slot], whose
+    // offset inside the geom block was pushed next to i1
+    Tab ps = (kind == EK_SLOT) ? (gd + wq.i1[Q_CAP + jj]) : (wnarrow + index * WN_LEN + WN_SIZE);
+    const T psize[3] = {ps[0], ps[1], ps[2]};
+    if (WBOX && kind == EK_STATIC && ptype == GT_BOX) {
+      Tab rw = wnarrow + index * WN_LEN;
+      par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
+      par.m[1] = rw[WN_YAXIS]; par.m[4] = rw[WN_YAXIS + 1]; par.m[7] = rw[WN_YAXIS + 2];
+    }
+    int code = V_NONE;
+    if (on) code = pair_contact<T, WBOX, false>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
+    if (on && code != V_NONE) atomicOr(&wq.flags[owner], code == V_CONTACT ? 1 : 2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Queued version of run_config for models without moving boxes (slots hold pos + z axis).
+template <class T, int MAXS, bool WBOX>
+__device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp, const double *q,
+                                                 int qstride, T *save, int sstride, bool active, T tol,
+                                                 const WaveQueue<T> &wq) {
+  typedef typename Real<T>::Tab Tab;
+  typedef GeomT<T> Geom;
+  SlotFile<T, MAXS> sf;
+  T p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const int lane = threadIdx.x & 63;
+  // Lane state lives in VGPR values, not in bools: loop-carried lane masks cost three scalar
+  // instructions per mask per iteration.  `dead` is +inf for lanes that need no more tests; it is
+  // added to the cull measure so that one compare yields the pass mask.  `fl` mirrors flags[lane].
+  const T kInf = __builtin_inff();
+  T dead = active ? T(0) : kInf;
+  int fl = 0;
+  int qn = 0;  // wave-uniform queue fill
+  wq.flags[lane] = 0;
+  const int nbodyops = uni(ip[H_NBODYOPS]);
+  Tab wnarrow = tp + uni(ip[H_OFF_WNARROW]);
+  const int nwpad = uni(ip[H_NWPAD]);
+  int pc = uni(ip[H_OFF_BODYOPS]);
+
+  for (int b = 0; b < nbodyops; b++) {
+    if (__builtin_amdgcn_ballot_w64(dead == T(0)) == 0ull && qn == 0) break;  // every lane decided
+
+    const int parent = uni(ip[pc + B_PARENT]);
+    Tab bd = tp + uni(ip[pc + B_DOFF]);
+    const int njnt = uni(ip[pc + B_NJNT]);
+    const int save_slot = uni(ip[pc + B_SAVE]);
+    const int ngeom = uni(ip[pc + B_NGEOM]);
+    pc += B_SIZE;
+
+    T pp[3], pq[4], pR[9];
+    if (parent == PARENT_CUR) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = p[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = qt[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) pR[k] = R[k];
+    } else if (parent == PARENT_STATIC) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = bd[7 + k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = bd[10 + k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) pR[k] = bd[14 + k];
+    } else {
+      const T *sv = save + (size_t)(parent - 1) * 7 * sstride;
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = sv[k * sstride];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = sv[(3 + k) * sstride];
+      quat2mat(pR, pq);
+    }
+    T np[3], nq[4];
+    {
+      T bpos[3] = {bd[0], bd[1], bd[2]};
+      T bquat[4] = {bd[3], bd[4], bd[5], bd[6]};
+      mul_mat_vec3(np, pR, bpos);
+      np[0] += pp[0]; np[1] += pp[1]; np[2] += pp[2];
+      mul_quat(nq, pq, bquat);
+    }
+    for (int j = 0; j < njnt; j++) {
+      const int jtype = uni(ip[pc + J_TYPE]);
+      const int qsrc = uni(ip[pc + J_QSRC]);
+      const int jflags = uni(ip[pc + J_FLAGS]);
+      Tab jd = tp + uni(ip[pc + J_DOFF]);
+      pc += J_SIZE;
+      const T qv = (qsrc >= 0) ? (T)q[qsrc * qstride] : jd[7];
+      const T dq = qv - jd[6];
+      T jaxis[3] = {jd[0], jd[1], jd[2]};
+      T jpos[3] = {jd[3], jd[4], jd[5]};
+      if (jtype == JT_SLIDE) {
+        T xaxis[3];
+        rot_vec_quat(xaxis, jaxis, nq);
+        np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq;
+      } else {
+        T xanchor[3] = {np[0], np[1], np[2]};
+        if (jflags & JF_POS_NONZERO) {
+          rot_vec_quat(xanchor, jpos, nq);
+          xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];
+        }
+        T sn, cs;
+        sincos_half(dq * T(0.5), &sn, &cs);
+        T qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};
+        mul_quat(nq, nq, qloc);
+        if (jflags & JF_POS_NONZERO) {
+          T vec[3];
+          rot_vec_quat(vec, jpos, nq);
+          np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2];
+        }
+      }
+    }
+    normalize4(nq);
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = np[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) qt[k] = nq[k];
+    quat2mat(R, qt);
+    if (save_slot >= 0) {
+      T *sv = save + (size_t)save_slot * 7 * sstride;
+#pragma unroll
+      for (int k = 0; k < 3; k++) sv[k * sstride] = p[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) sv[(3 + k) * sstride] = qt[k];
+    }
+
+    for (int g = 0; g < ngeom; g++) {
+      const int gtype = uni(ip[pc + G_TYPE]);
+      const int gflags = uni(ip[pc + G_FLAGS]);
+      const int gdoff = uni(ip[pc + G_DOFF]);
+      Tab gd = tp + gdoff;
+      const int store = uni(ip[pc + G_STORE]);
+      const int nent = uni(ip[pc + G_NENT]);
+      Tab ent = tp + uni(ip[pc + G_ENT_OFF]);
+      pc += G_SIZE + MAX_SLOTS;
+
+      Geom cur;
+      if (gflags & GF_SAMEPOS) {
+        cur.pos[0] = p[0]; cur.pos[1] = p[1]; cur.pos[2] = p[2];
+      } else {
+        T lpos[3] = {gd[0], gd[1], gd[2]};
+        mul_mat_vec3(cur.pos, R, lpos);
+        cur.pos[0] += p[0]; cur.pos[1] += p[1]; cur.pos[2] += p[2];
+      }
+      if (gflags & GF_SAMEROT) {
+        cur.m[2] = R[2]; cur.m[5] = R[5]; cur.m[8] = R[8];
+      } else {
+        T lq[4] = {gd[3], gd[4], gd[5], gd[6]}, gq[4];
+        mul_quat(gq, qt, lq);
+        quat2zaxis(cur.m, gq);
+      }
+
+      // one rolled loop over this geom's enabled pairs; the next entry is already in flight
+      int nx_word = ((IP)(ent + E_WORD))[0];
+      T nx_bound = ent[E_BOUND];
+      T nx_pos[3] = {ent[E_POS], ent[E_POS + 1], ent[E_POS + 2]};
+      T nx_z[3] = {ent[E_ZAXIS], ent[E_ZAXIS + 1], ent[E_ZAXIS + 2]};
+      T nx_margin = ent[E_MARGIN];
+      for (int e = 0; e < nent; e++) {
+        const int word = uni(nx_word);
+        const T bound = nx_bound, margin = nx_margin;
+        T ppos[3] = {nx_pos[0], nx_pos[1], nx_pos[2]};
+        T pz[3] = {nx_z[0], nx_z[1], nx_z[2]};
+        Tab en = ent + (e + 1) * E_LEN;  // the tables are padded past their last entry
+        nx_word = ((IP)(en + E_WORD))[0];
+        nx_bound = en[E_BOUND];
+        nx_pos[0] = en[E_POS]; nx_pos[1] = en[E_POS + 1]; nx_pos[2] = en[E_POS + 2];
+        nx_z[0] = en[E_ZAXIS]; nx_z[1] = en[E_ZAXIS + 1]; nx_z[2] = en[E_ZAXIS + 2];
+        nx_margin = en[E_MARGIN];
+
+        const int kind = word & 3, index = (word >> 2) & 255, ptype = (word >> 12) & 15;
+        pin_geom(cur);
+        if (kind == EK_SLOT) {
+          T t6[6];
+          slot_get6(sf, index, t6);
+          ppos[0] = t6[0]; ppos[1] = t6[1]; ppos[2] = t6[2];
+          pz[0] = t6[3]; pz[1] = t6[4]; pz[2] = t6[5];
+        }
+        // bounding cull (mj_collideSphere): signed plane distance, or squared centre distance
+        T dif[3] = {cur.pos[0] - ppos[0], cur.pos[1] - ppos[1], cur.pos[2] - ppos[2]};
+        const T measure = (kind == EK_PLANE) ? dot3(dif, pz) : dot3(dif, dif);
+        const bool pass = !(measure + dead > bound);
+        const unsigned long long pm = __builtin_amdgcn_ballot_w64(pass);
+        if (pm == 0ull) continue;
+
+        // push the passing lanes' candidates
+        const int off = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+        if (pass) {
+          wq.f[0 * Q_CAP + off] = cur.pos[0]; wq.f[1 * Q_CAP + off] = cur.pos[1]; wq.f[2 * Q_CAP + off] = cur.pos[2];
+          wq.f[3 * Q_CAP + off] = cur.m[2]; wq.f[4 * Q_CAP + off] = cur.m[5]; wq.f[5 * Q_CAP + off] = cur.m[8];
+          wq.f[6 * Q_CAP + off] = ppos[0]; wq.f[7 * Q_CAP + off] = ppos[1]; wq.f[8 * Q_CAP + off] = ppos[2];
+          wq.f[9 * Q_CAP + off] = pz[0]; wq.f[10 * Q_CAP + off] = pz[1]; wq.f[11 * Q_CAP + off] = pz[2];
+          wq.f[12 * Q_CAP + off] = margin;
+          wq.i0[off] = lane | (gtype << 6) | (ptype << 10) | (((word >> 17) & 1) << 14) | (kind << 15) | (index << 17);
+          wq.i1[off] = gdoff;
+          // where the partner's sizes live relative to gd (slot partners only)
+          wq.i1[Q_CAP + off] = GD_WBOUND + 2 * nwpad + 2 * MAX_SLOTS + 3 * index;
+        }
+        qn += (int)__builtin_popcountll(pm);
+        if (qn >= 64) {
+          queue_drain<T, WBOX>(wq, qn, tp, wnarrow, tol);
+          fl = wq.flags[lane];
+          dead = (fl != 0 || !active) ? kInf : T(0);
+        }
+      }
+
+      if (store >= 0) {
+        const T t6[6] = {cur.pos[0], cur.pos[1], cur.pos[2], cur.m[2], cur.m[5], cur.m[8]};
+        slot_put6(sf, store & 63, t6);
+      }
+    }
+  }
+  queue_drain<T, WBOX>(wq, qn, tp, wnarrow, tol);
+  fl = wq.flags[lane];
+  return !active ? V_NONE : ((fl & 1) ? V_CONTACT : ((fl & 2) ? V_UNSURE : V_NONE));
 }
 
 }  // namespace mjpl

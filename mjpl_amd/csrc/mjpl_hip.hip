@@ -28,6 +28,7 @@ namespace {
 using namespace mjpl;
 
 constexpr int kBlock = 256;           // threads per workgroup: 4 wavefronts
+constexpr int kFilterBlock = 64;      // queued filter kernels: one wavefront, one candidate queue
 constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
 constexpr int kStatusNonFinite = 1;
 
@@ -59,9 +60,38 @@ template <class T>
 struct Carve {
   double *col0, *col1;
   T *save;
+  char *qmem;  // per-wave candidate queues (queued kernels), after the pose saves
   IP ip;
   typename Real<T>::Tab tp;
 };
+
+// queued narrowphase: the float32 filter of models without moving boxes
+template <class T, bool MBOX>
+constexpr bool kQueued = !Real<T>::exact && !MBOX;
+
+template <class T>
+__device__ __forceinline__ WaveQueue<T> wave_queue(char *qmem) {
+  char *base = qmem + (size_t)(threadIdx.x >> 6) * WaveQueue<T>::bytes();
+  WaveQueue<T> wq;
+  wq.f = reinterpret_cast<T *>(base);
+  wq.i0 = reinterpret_cast<int *>(base + (size_t)Q_FIELDS * Q_CAP * sizeof(T));
+  wq.i1 = wq.i0 + Q_CAP;
+  wq.flags = wq.i1 + 2 * Q_CAP;
+  return wq;
+}
+
+template <class T, int MAXS, bool WBOX, bool MBOX>
+__device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int B, bool active, T tol,
+                                         int64_t row) {
+  if constexpr (kQueued<T, MBOX>) {
+    WaveQueue<T> wq = wave_queue<T>(c.qmem);
+    return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, q, B, c.save + threadIdx.x, B, active, tol, wq);
+  } else {
+    FkOut none = {};
+    return run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, q, B, c.save + threadIdx.x, B, active, tol,
+                                                  none, row);
+  }
+}
 
 template <class T>
 __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restrict__ gip, int nip,
@@ -77,8 +107,11 @@ __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restric
 #endif
   c.col1 = c.col0 + (size_t)nplan * B;
   c.save = reinterpret_cast<T *>(c.col0 + (size_t)ncolsets * nplan * B);
-#if MJPL_TABLES_LDS
   const int nsave = gip[H_NSAVE];
+  // queue memory starts 8-byte aligned after the saves
+  c.qmem = reinterpret_cast<char *>(c.col0) +
+           (((size_t)ncolsets * nplan * B * sizeof(double) + (size_t)nsave * 7 * B * sizeof(T) + 7) & ~(size_t)7);
+#if MJPL_TABLES_LDS
   int *il = reinterpret_cast<int *>(c.save + (size_t)nsave * 7 * B);
   for (int k = threadIdx.x; k < ntp; k += blockDim.x) tl[k] = gtp[k];
   for (int k = threadIdx.x; k < nip; k += blockDim.x) il[k] = gip[k];
@@ -188,7 +221,6 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
   load_columns(qw, B, QA, E, i, nplan, layout, active);
   __syncthreads();
   IP perm = c.ip + c.ip[H_OFF_PERM];
-  FkOut none = {};
 
   bool finite = true, at_end = true;
   for (int k = 0; k < nplan; k++) {
@@ -238,8 +270,7 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
         }
       }
     }
-    const int code = run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, first ? qe : qw, B,
-                                                            c.save + threadIdx.x, B, !done, tol, none, i);
+    const int code = check_one<T, MAXS, WBOX, MBOX>(c, first ? qe : qw, B, !done, tol, i);
     if (!done && code == V_CONTACT) { done = true; ok = false; fb = idx; }
     if (!done && code == V_UNSURE) { done = true; unsure = true; }
     if (first && !done && at_end) done = true;  // waypoints == [start]: nothing interior
@@ -291,9 +322,7 @@ k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__
   const bool active = i < N;
   load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
   __syncthreads();
-  FkOut none = {};
-  const int code = run_config<float, MAXS, false, WBOX, MBOX>(c.ip, c.tp, c.col0 + threadIdx.x, B,
-                                                              c.save + threadIdx.x, B, active, tol, none, i);
+  const int code = check_one<float, MAXS, WBOX, MBOX>(c, c.col0 + threadIdx.x, B, active, tol, i);
   if (active) {
     if (code == V_UNSURE) ulist[atomicAdd(ucount, 1)] = (int)i;
     else valid[i] = (code == V_CONTACT) ? 0 : 1;
@@ -573,7 +602,7 @@ int compile_program(mjpl_engine *e) {
   if (e->nslots > MAX_SLOTS)
     return fail(MJPL_E_CAPACITY, "%d moving geoms must be held at once; this build has %d register slots",
                 e->nslots, (int)MAX_SLOTS);
-  e->maxs = e->nslots <= 4 ? 4 : (e->nslots <= 8 ? 8 : (e->nslots <= 12 ? 12 : 16));
+  e->maxs = e->nslots <= 4 ? 4 : (e->nslots <= 8 ? 8 : 16);  // vector widths with indirect addressing
   e->nsave = nsave;
 
   // ---- emit
@@ -663,6 +692,9 @@ int compile_program(mjpl_engine *e) {
       ip.push_back((int)(uint32_t)(wmask >> 32));
       ip.push_back((int)(uint32_t)(pmask & 0xffffffffull));
       ip.push_back((int)(uint32_t)(pmask >> 32));
+      const size_t nent_at = ip.size();
+      ip.push_back(0);  // G_NENT
+      ip.push_back(0);  // G_ENT_OFF
       const size_t swords_at = ip.size();
       ip.insert(ip.end(), MAX_SLOTS, 0);
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(gp[k3]);
@@ -710,13 +742,43 @@ int compile_program(mjpl_engine *e) {
         dp.insert(dp.end(), sm.begin(), sm.end());
         dp.insert(dp.end(), ss.begin(), ss.end());
       }
+      // unified entry list (queued kernels): planes, other statics, register slots
+      {
+        ip[nent_at + 1] = (int)dp.size();
+        int nent = 0;
+        auto entry = [&](int kind, int index, int h, bool plane_bound) {
+          const int g1 = std::min(g, h), g2 = std::max(g, h);
+          const int first = (m.geom_type[g1] > m.geom_type[g2]) ? g2 : g1;
+          const int32_t word[2] = {kind | (index << 2) | (m.geom_type[h] << 12) | (first == h ? P_FIRST : 0), 0};
+          double rec[E_LEN] = {0};
+          memcpy(&rec[E_WORD], word, sizeof(double));
+          info_at.push_back({dp.size() + E_WORD, word[0]});
+          pair_bound(h, &rec[E_BOUND], &rec[E_MARGIN]);
+          (plane_bound ? plane_bound_at : sq_bound_at).push_back(dp.size() + E_BOUND);
+          if (kind != EK_SLOT) {
+            for (int k3 = 0; k3 < 3; k3++) {
+              rec[E_POS + k3] = e->st_gxpos[3 * h + k3];
+              rec[E_ZAXIS + k3] = e->st_gxmat[9 * h + 3 * k3 + 2];
+            }
+          }
+          for (int k3 = 0; k3 < 3; k3++) rec[E_SIZE + k3] = m.geom_size[3 * h + k3];
+          dp.insert(dp.end(), rec, rec + E_LEN);
+          nent++;
+        };
+        for (int sgeom : world_partners[gk])
+          if (m.geom_type[sgeom] == GT_PLANE) entry(EK_PLANE, world_row[sgeom], sgeom, true);
+        for (int sgeom : world_partners[gk])
+          if (m.geom_type[sgeom] != GT_PLANE) entry(EK_STATIC, world_row[sgeom], sgeom, false);
+        for (int k2 : stored_partners[gk]) entry(EK_SLOT, slot_of[k2] & 63, mgeoms[k2], false);
+        ip[nent_at] = nent;
+      }
     }
     ip[base + B_NGEOM] = ngeom_here;
   }
 
   // the kernels prefetch one entry past the one they test: keep that read inside the tables
-  ip.insert(ip.end(), 16, 0);
-  dp.insert(dp.end(), 16, 0.0);
+  ip.insert(ip.end(), 32, 0);
+  dp.insert(dp.end(), 2 * E_LEN, 0.0);
 
   // ---- the filter's float32 image: same offsets; cull bounds widened by the tolerance so that
   // a pair culled in float32 is certainly culled (or contact-free) in float64
@@ -749,10 +811,12 @@ int compile_program(mjpl_engine *e) {
   return MJPL_OK;
 }
 
-size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(double)) {
+size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(double), int block = kBlock,
+                 bool queued = false) {
   const size_t nplan = e->qidx.size();
-  size_t bytes = (size_t)ncolsets * nplan * kBlock * sizeof(double) +
-                 (size_t)e->nsave * 7 * kBlock * scalar;
+  size_t bytes = (size_t)ncolsets * nplan * block * sizeof(double) + (size_t)e->nsave * 7 * block * scalar;
+  bytes = (bytes + 7) & ~(size_t)7;
+  if (queued) bytes += (size_t)(block / 64) * WaveQueue<float>::bytes();
 #if MJPL_TABLES_LDS
   bytes += ((e->dp.size() * scalar + 7) / 8) * 8 + e->ip.size() * sizeof(int);
 #endif
@@ -790,7 +854,6 @@ int dispatch_variant(const mjpl_engine *e, F &&f) {
   switch (e->maxs) {
     case 4: return with_box(std::integral_constant<int, 4>{});
     case 8: return with_box(std::integral_constant<int, 8>{});
-    case 12: return with_box(std::integral_constant<int, 12>{});
     default: return with_box(std::integral_constant<int, 16>{});
   }
 }
@@ -804,12 +867,14 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
     int rc = ulist_reserve(e, N);
     if (rc != MJPL_OK) return rc;
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, sizeof(int), e->stream));
-    const size_t ldsf = lds_bytes(e, 1, sizeof(float));
+    const int fblock = e->mbox ? kBlock : kFilterBlock;
+    const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
+    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
       if (r != MJPL_OK) return r;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
+      hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                          e->d_fp, (int)e->fp.size(), dQ, N, layout, e->filter_tol, dvalid, e->d_ulist,
                          e->d_ucount);
       return MJPL_OK;
@@ -840,12 +905,14 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     int rc = ulist_reserve(e, E);
     if (rc != MJPL_OK) return rc;
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, sizeof(int), e->stream));
-    const size_t ldsf = lds_bytes(e, 2, sizeof(float));
+    const int fblock = e->mbox ? kBlock : kFilterBlock;
+    const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
+    const size_t ldsf = lds_bytes(e, 2, sizeof(float), fblock, !e->mbox);
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
       if (r != MJPL_OK) return r;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
+      hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                          e->d_fp, (int)e->fp.size(), dQA, dQB, E, step, layout, flags, e->filter_tol, dvalid,
                          dfb, e->d_status, e->d_ulist, e->d_ucount);
       return MJPL_OK;
