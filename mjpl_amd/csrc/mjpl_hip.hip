@@ -148,6 +148,15 @@ __device__ __forceinline__ bool pick_item(int64_t n, const int *__restrict__ uli
   return j < n;
 }
 
+// Configurations the filter could not decide, handed to the exact configuration kernel.
+struct UndecidedConfigs {
+  double *q;    // [cap][nplan] waypoint, row-major
+  int *edge;    // [cap] edge it belongs to
+  int *idx;     // [cap] its check index inside that edge
+  int *count;   // entries written (may exceed cap: the overflow went to the edge-level list)
+  int cap;
+};
+
 // ---- exact path (float64): final verdicts --------------------------------------------------
 
 template <int MAXS, bool WBOX, bool MBOX>
@@ -155,10 +164,16 @@ __global__ void __launch_bounds__(kBlock)
 k_check_configs(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
                 const double *__restrict__ Q, int64_t N, int layout, uint8_t *__restrict__ valid,
                 unsigned long long *__restrict__ bits, const int *__restrict__ ulist,
-                const int *__restrict__ ucount) {
+                const int *__restrict__ ucount, UndecidedConfigs uc, int32_t *__restrict__ first_bad) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
   if (ulist && (int64_t)blockIdx.x * B >= (int64_t)*ucount) return;  // nothing left to re-run
+  if (uc.count) {
+    // patch mode: the rows of uc.q are undecided waypoints of edges; N is read on the device
+    const int64_t n = *uc.count < uc.cap ? *uc.count : uc.cap;
+    if ((int64_t)blockIdx.x * B >= n) return;
+    N = n;
+  }
   const int nplan = gip[H_NPLAN];
   Carve<double> c = carve_lds<double>(smem, gip, nip, gdp, ndp, nplan, 1, B);
   int64_t i;
@@ -170,6 +185,15 @@ k_check_configs(const int *__restrict__ gip, int nip, const double *__restrict__
   const bool hit = run_config<double, MAXS, false, WBOX, MBOX>(c.ip, c.tp, c.col0 + threadIdx.x, B,
                                                                c.save + threadIdx.x, B, active, 0.0, none,
                                                                i) == V_CONTACT;
+  if (uc.count) {
+    if (active && hit) {
+      const int ed = uc.edge[i];
+      valid[ed] = 0;
+      // first_bad holds -1 (= UINT_MAX) for "valid so far": an unsigned min keeps the lowest index
+      if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)uc.idx[i]);
+    }
+    return;
+  }
   if (valid && active) valid[i] = hit ? 0 : 1;
   if (bits) {
     unsigned long long m = __ballot(active && !hit);
@@ -207,7 +231,8 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
                                           int flags, T tol, uint8_t *__restrict__ valid,
                                           int32_t *__restrict__ first_bad, int *__restrict__ status,
                                           int *__restrict__ ulist, int *__restrict__ ucount,
-                                          const int *__restrict__ rlist, const int *__restrict__ rcount) {
+                                          const int *__restrict__ rlist, const int *__restrict__ rcount,
+                                          UndecidedConfigs uc) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
   if (rlist && (int64_t)blockIdx.x * B >= (int64_t)*rcount) return;
@@ -272,7 +297,21 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
     }
     const int code = check_one<T, MAXS, WBOX, MBOX>(c, first ? qe : qw, B, !done, tol, i);
     if (!done && code == V_CONTACT) { done = true; ok = false; fb = idx; }
-    if (!done && code == V_UNSURE) { done = true; unsure = true; }
+    if (!done && code == V_UNSURE) {
+      // the filter cannot decide this configuration: hand IT (not the whole edge) to the exact
+      // configuration kernel and walk on as if it were valid; that kernel lowers first_bad and
+      // clears valid if it finds a contact.  Only if the hand-off buffer is full does the whole
+      // edge go to the exact edge kernel.
+      const int j = atomicAdd(uc.count, 1);
+      if (j < uc.cap) {
+        const double *src = first ? qe : qw;
+        for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = src[k * B];
+        uc.edge[j] = (int)i;
+        uc.idx[j] = idx;
+      } else {
+        done = true; unsure = true;
+      }
+    }
     if (first && !done && at_end) done = true;  // waypoints == [start]: nothing interior
     first = false;
   }
@@ -292,8 +331,9 @@ k_check_edges(const int *__restrict__ gip, int nip, const double *__restrict__ g
               const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, double step,
               int layout, int flags, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
               int *__restrict__ status, const int *__restrict__ rlist, const int *__restrict__ rcount) {
+  UndecidedConfigs none = {};
   edge_body<double, MAXS, WBOX, MBOX>(gip, nip, gdp, ndp, QA, QB, E, step, layout, flags, 0.0, valid,
-                                      first_bad, status, nullptr, nullptr, rlist, rcount);
+                                      first_bad, status, nullptr, nullptr, rlist, rcount, none);
 }
 
 // ---- filter path (float32): decides what it can, lists the rest ----------------------------
@@ -304,9 +344,9 @@ k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ g
                const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, double step,
                int layout, int flags, float tol, uint8_t *__restrict__ valid,
                int32_t *__restrict__ first_bad, int *__restrict__ status, int *__restrict__ ulist,
-               int *__restrict__ ucount) {
+               int *__restrict__ ucount, UndecidedConfigs uc) {
   edge_body<float, MAXS, WBOX, MBOX>(gip, nip, gfp, nfp, QA, QB, E, step, layout, flags, tol, valid,
-                                     first_bad, status, ulist, ucount, nullptr, nullptr);
+                                     first_bad, status, ulist, ucount, nullptr, nullptr, uc);
 }
 
 template <int MAXS, bool WBOX, bool MBOX>
@@ -401,9 +441,12 @@ struct mjpl_engine {
   // float32 filter + exact re-run of what it cannot decide
   bool filter = true;
   float filter_tol = 1e-4f;
-  int *d_ulist = nullptr;   // indices the filter left undecided
-  int *d_ucount = nullptr;  // how many
+  int *d_ulist = nullptr;   // items (configurations / whole edges) the filter left undecided
+  int *d_ucount = nullptr;  // [0] how many of those, [1] undecided waypoints of edges
   size_t ulist_cap = 0;
+  double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
+  int *d_ucedge = nullptr, *d_ucidx = nullptr;
+  size_t uc_cap = 0;
   int nslots = 0, nsave = 0, maxs = 4;
   bool wbox = false, mbox = false;
   int npairs = 0, npairs_world = 0, nmoving = 0, nstatic = 0;
@@ -823,8 +866,22 @@ size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(doub
   return bytes ? bytes : 8;
 }
 
+int uc_reserve(mjpl_engine *e, int64_t n) {
+  const size_t want = (size_t)std::max<int64_t>(4096, n);
+  if (want <= e->uc_cap) return MJPL_OK;
+  if (e->d_ucq) HIP_TRY(hipFree(e->d_ucq));
+  if (e->d_ucedge) HIP_TRY(hipFree(e->d_ucedge));
+  if (e->d_ucidx) HIP_TRY(hipFree(e->d_ucidx));
+  e->d_ucq = nullptr; e->d_ucedge = e->d_ucidx = nullptr; e->uc_cap = 0;
+  HIP_TRY(hipMalloc(&e->d_ucq, want * std::max<size_t>(1, e->m.nq) * sizeof(double)));
+  HIP_TRY(hipMalloc(&e->d_ucedge, want * sizeof(int)));
+  HIP_TRY(hipMalloc(&e->d_ucidx, want * sizeof(int)));
+  e->uc_cap = want;
+  return MJPL_OK;
+}
+
 int ulist_reserve(mjpl_engine *e, int64_t n) {
-  if (!e->d_ucount) HIP_TRY(hipMalloc(&e->d_ucount, sizeof(int)));
+  if (!e->d_ucount) HIP_TRY(hipMalloc(&e->d_ucount, 2 * sizeof(int)));
   if ((size_t)n > e->ulist_cap) {
     if (e->d_ulist) HIP_TRY(hipFree(e->d_ulist));
     e->d_ulist = nullptr;
@@ -866,7 +923,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
   if (filter) {
     int rc = ulist_reserve(e, N);
     if (rc != MJPL_OK) return rc;
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 2 * sizeof(int), e->stream));
     const int fblock = e->mbox ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
@@ -888,7 +945,8 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
     if (r != MJPL_OK) return r;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, e->stream, e->d_ip, (int)e->ip.size(),
                        e->d_dp, (int)e->dp.size(), dQ, N, layout, dvalid, dbits,
-                       filter ? e->d_ulist : nullptr, filter ? e->d_ucount : nullptr);
+                       filter ? e->d_ulist : nullptr, filter ? e->d_ucount : nullptr, UndecidedConfigs{},
+                       (int32_t *)nullptr);
     return MJPL_OK;
   });
   if (rc != MJPL_OK) return rc;
@@ -901,10 +959,15 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
   if (E == 0) return MJPL_OK;
   const unsigned grid = (unsigned)((E + kBlock - 1) / kBlock);
   const bool filter = e->filter && E < (int64_t)1 << 31;
+  UndecidedConfigs uc = {};
   if (filter) {
     int rc = ulist_reserve(e, E);
+    if (rc == MJPL_OK) rc = uc_reserve(e, E);
     if (rc != MJPL_OK) return rc;
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, sizeof(int), e->stream));
+    uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
+    uc.count = e->d_ucount + 1;
+    uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 2 * sizeof(int), e->stream));
     const int fblock = e->mbox ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 2, sizeof(float), fblock, !e->mbox);
@@ -914,7 +977,21 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       if (r != MJPL_OK) return r;
       hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                          e->d_fp, (int)e->fp.size(), dQA, dQB, E, step, layout, flags, e->filter_tol, dvalid,
-                         dfb, e->d_status, e->d_ulist, e->d_ucount);
+                         dfb, e->d_status, e->d_ulist, e->d_ucount, uc);
+      return MJPL_OK;
+    });
+    if (rc != MJPL_OK) return rc;
+    // undecided waypoints: exact configuration kernel in patch mode (grid sized for a generous
+    // share of the batch; surplus blocks return at once)
+    const size_t ldsc = lds_bytes(e, 1);
+    const unsigned pgrid = (unsigned)std::min<size_t>((uc.cap + kBlock - 1) / kBlock, 1024);
+    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+      auto kern = k_check_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+      int r = allow_lds(kern, ldsc);
+      if (r != MJPL_OK) return r;
+      hipLaunchKernelGGL(kern, dim3(pgrid), dim3(kBlock), ldsc, e->stream, e->d_ip, (int)e->ip.size(),
+                         e->d_dp, (int)e->dp.size(), (const double *)uc.q, (int64_t)0, (int)MJPL_AOS, dvalid,
+                         (unsigned long long *)nullptr, (const int *)nullptr, (const int *)nullptr, uc, dfb);
       return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
@@ -1037,6 +1114,9 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_fp) (void)hipFree(e->d_fp);
   if (e->d_ulist) (void)hipFree(e->d_ulist);
   if (e->d_ucount) (void)hipFree(e->d_ucount);
+  if (e->d_ucq) (void)hipFree(e->d_ucq);
+  if (e->d_ucedge) (void)hipFree(e->d_ucedge);
+  if (e->d_ucidx) (void)hipFree(e->d_ucidx);
   if (e->d_status) (void)hipFree(e->d_status);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1072,11 +1152,11 @@ int mjpl_set_filter(mjpl_engine *e, int32_t enable, double tol) {
 
 int64_t mjpl_filter_last_undecided(mjpl_engine *e) {
   if (!e || !e->filter || !e->d_ucount) return 0;
-  int n = 0;
+  int n[2] = {0, 0};
   if (hipSetDevice(e->device) != hipSuccess) return -1;
   if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
-  if (hipMemcpy(&n, e->d_ucount, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return n;
+  if (hipMemcpy(n, e->d_ucount, 2 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)n[0] + n[1];
 }
 
 int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
