@@ -614,6 +614,17 @@ __device__ __forceinline__ void pin_geom(GeomT<T> &g) {
   pin(g.pos[0]); pin(g.pos[1]); pin(g.pos[2]); pin(g.m[2]); pin(g.m[5]); pin(g.m[8]);
 }
 
+// value of `v` in lane `l` (wave-uniform l) as a scalar: v_readlane_b32
+__device__ __forceinline__ float bcast(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double bcast(double v, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // control words are wave-uniform: pin them to SGPRs so the interpreter's branches are scalar
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -1041,6 +1052,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   int qn = 0;  // wave-uniform queue fill
   wq.flags[lane] = 0;
   const int nbodyops = uni(ip[H_NBODYOPS]);
+  Tab wcull = tp + uni(ip[H_OFF_WCULL]);
   Tab wnarrow = tp + uni(ip[H_OFF_WNARROW]);
   const int nwpad = uni(ip[H_NWPAD]);
   int pc = uni(ip[H_OFF_BODYOPS]);
@@ -1137,8 +1149,14 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       const int gdoff = uni(ip[pc + G_DOFF]);
       Tab gd = tp + gdoff;
       const int store = uni(ip[pc + G_STORE]);
-      const int nent = uni(ip[pc + G_NENT]);
-      Tab ent = tp + uni(ip[pc + G_ENT_OFF]);
+      const unsigned smask = (unsigned)uni(ip[pc + G_SMASK]);
+      const unsigned long long wmask_all =
+          (unsigned long long)(unsigned)uni(ip[pc + G_WMASK_LO]) |
+          ((unsigned long long)(unsigned)uni(ip[pc + G_WMASK_HI]) << 32);
+      const unsigned long long pmask_all =
+          (unsigned long long)(unsigned)uni(ip[pc + G_PMASK_LO]) |
+          ((unsigned long long)(unsigned)uni(ip[pc + G_PMASK_HI]) << 32);
+      IP swords = ip + pc + G_SIZE;
       pc += G_SIZE + MAX_SLOTS;
 
       Geom cur;
@@ -1157,58 +1175,122 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         quat2zaxis(cur.m, gq);
       }
 
-      // one rolled loop over this geom's enabled pairs; the next entry is already in flight
-      int nx_word = ((IP)(ent + E_WORD))[0];
-      T nx_bound = ent[E_BOUND];
-      T nx_pos[3] = {ent[E_POS], ent[E_POS + 1], ent[E_POS + 2]};
-      T nx_z[3] = {ent[E_ZAXIS], ent[E_ZAXIS + 1], ent[E_ZAXIS + 2]};
-      T nx_margin = ent[E_MARGIN];
-      for (int e = 0; e < nent; e++) {
-        const int word = uni(nx_word);
-        const T bound = nx_bound, margin = nx_margin;
-        T ppos[3] = {nx_pos[0], nx_pos[1], nx_pos[2]};
-        T pz[3] = {nx_z[0], nx_z[1], nx_z[2]};
-        Tab en = ent + (e + 1) * E_LEN;  // the tables are padded past their last entry
-        nx_word = ((IP)(en + E_WORD))[0];
-        nx_bound = en[E_BOUND];
-        nx_pos[0] = en[E_POS]; nx_pos[1] = en[E_POS + 1]; nx_pos[2] = en[E_POS + 2];
-        nx_z[0] = en[E_ZAXIS]; nx_z[1] = en[E_ZAXIS + 1]; nx_z[2] = en[E_ZAXIS + 2];
-        nx_margin = en[E_MARGIN];
-
-        const int kind = word & 3, index = (word >> 2) & 255, ptype = (word >> 12) & 15;
-        pin_geom(cur);
-        if (kind == EK_SLOT) {
-          T t6[6];
-          slot_get6(sf, index, t6);
-          ppos[0] = t6[0]; ppos[1] = t6[1]; ppos[2] = t6[2];
-          pz[0] = t6[3]; pz[1] = t6[4]; pz[2] = t6[5];
-        }
-        // bounding cull (mj_collideSphere): signed plane distance, or squared centre distance
-        T dif[3] = {cur.pos[0] - ppos[0], cur.pos[1] - ppos[1], cur.pos[2] - ppos[2]};
-        const T measure = (kind == EK_PLANE) ? dot3(dif, pz) : dot3(dif, dif);
-        const bool pass = !(measure + dead > bound);
-        const unsigned long long pm = __builtin_amdgcn_ballot_w64(pass);
-        if (pm == 0ull) continue;
-
-        // push the passing lanes' candidates
+      // ---- culls: straight-line code, four static rows (then four register slots) at a time;
+      // a pair costs ~9 VALU and no branch.  Pushes are a rolled loop over the few rows of a
+      // chunk that some lane passed.  (A rolled per-pair loop spends most of its time in scalar
+      // control flow: ~5 branches and ~35 instructions per pair.)
+      Tab wbound = gd + GD_WBOUND;            // [nwpad] bounds, then [nwpad] margins
+      Tab sbound = wbound + 2 * nwpad;        // [16] bounds, [16] margins, [16][3] sizes
+      auto push = [&](unsigned long long pm, int kind, int index, int ptype, bool pfirst, const T *ppos,
+                      const T *pz, T margin) {
+        const bool mine = (pm >> lane) & 1ull;
         const int off = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
-        if (pass) {
+        if (mine) {
           wq.f[0 * Q_CAP + off] = cur.pos[0]; wq.f[1 * Q_CAP + off] = cur.pos[1]; wq.f[2 * Q_CAP + off] = cur.pos[2];
           wq.f[3 * Q_CAP + off] = cur.m[2]; wq.f[4 * Q_CAP + off] = cur.m[5]; wq.f[5 * Q_CAP + off] = cur.m[8];
           wq.f[6 * Q_CAP + off] = ppos[0]; wq.f[7 * Q_CAP + off] = ppos[1]; wq.f[8 * Q_CAP + off] = ppos[2];
           wq.f[9 * Q_CAP + off] = pz[0]; wq.f[10 * Q_CAP + off] = pz[1]; wq.f[11 * Q_CAP + off] = pz[2];
           wq.f[12 * Q_CAP + off] = margin;
-          wq.i0[off] = lane | (gtype << 6) | (ptype << 10) | (((word >> 17) & 1) << 14) | (kind << 15) | (index << 17);
+          wq.i0[off] = lane | (gtype << 6) | (ptype << 10) | ((pfirst ? 1 : 0) << 14) | (kind << 15) | (index << 17);
           wq.i1[off] = gdoff;
           // where the partner's sizes live relative to gd (slot partners only)
           wq.i1[Q_CAP + off] = GD_WBOUND + 2 * nwpad + 2 * MAX_SLOTS + 3 * index;
         }
         qn += (int)__builtin_popcountll(pm);
+      };
+      auto drain_if_full = [&]() {
         if (qn >= 64) {
           queue_drain<T, WBOX>(wq, qn, tp, wnarrow, tol);
           fl = wq.flags[lane];
           dead = (fl != 0 || !active) ? kInf : T(0);
+        }
+      };
+#ifdef MJPL_X_Q_FKONLY
+      const unsigned long long pmask_use = 0, wmask_use = 0;
+      const unsigned smask_use = 0;
+#else
+      const unsigned long long pmask_use = pmask_all, wmask_use = wmask_all;
+      const unsigned smask_use = smask;
+#endif
+      // static planes (few)
+      for (unsigned long long pm_ = pmask_use; pm_; pm_ &= pm_ - 1) {
+        const int wc = (int)__builtin_ctzll(pm_);
+        Tab rc = wcull + wc * WC_LEN;
+        Tab rw = wnarrow + wc * WN_LEN;
+        const T ppos[3] = {rc[WC_POS], rc[WC_POS + 1], rc[WC_POS + 2]};
+        const T pz[3] = {rw[WN_ZAXIS], rw[WN_ZAXIS + 1], rw[WN_ZAXIS + 2]};
+        T dif[3] = {cur.pos[0] - ppos[0], cur.pos[1] - ppos[1], cur.pos[2] - ppos[2]};
+        const unsigned long long pm = __builtin_amdgcn_ballot_w64(!(dot3(dif, pz) + dead > wbound[wc]));
+        if (pm == 0ull) continue;
+        push(pm, EK_PLANE, wc, GT_PLANE, true, ppos, pz, wbound[nwpad + wc]);
+        drain_if_full();
+      }
+      // other static geoms
+      for (int base = 0; base < nwpad; base += 4) {
+        const unsigned bits = (unsigned)(wmask_use >> base) & 15u;
+        if (bits == 0) continue;
+        Tab rc = wcull + base * WC_LEN;
+        Tab bc = wbound + base;
+        pin_geom(cur);
+        unsigned long long m0, m1, m2, m3;
+#define MJPL_QCULL(k, out)                                                              \
+        {                                                                               \
+          T dx = cur.pos[0] - rc[(k) * WC_LEN], dy = cur.pos[1] - rc[(k) * WC_LEN + 1],  \
+            dz = cur.pos[2] - rc[(k) * WC_LEN + 2];                                     \
+          const T bk = ((bits >> (k)) & 1u) ? bc[k] : -kInf;                            \
+          out = __builtin_amdgcn_ballot_w64(!(dx * dx + dy * dy + dz * dz + dead > bk)); \
+        }
+        MJPL_QCULL(0, m0) MJPL_QCULL(1, m1) MJPL_QCULL(2, m2) MJPL_QCULL(3, m3)
+#undef MJPL_QCULL
+#ifdef MJPL_X_Q_NOPUSH
+        continue;
+#endif
+        if ((m0 | m1 | m2 | m3) == 0ull) continue;
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+          const unsigned long long pm = k == 0 ? m0 : (k == 1 ? m1 : (k == 2 ? m2 : m3));
+          if (pm == 0ull) continue;
+          const int wc = base + k;
+          Tab r4 = wcull + wc * WC_LEN;
+          Tab rw = wnarrow + wc * WN_LEN;
+          const int info = ((IP)(r4 + WC_INFO))[0];
+          const int ptype = info & 255, pgid = info >> 8;
+          const T ppos[3] = {r4[WC_POS], r4[WC_POS + 1], r4[WC_POS + 2]};
+          const T pz[3] = {rw[WN_ZAXIS], rw[WN_ZAXIS + 1], rw[WN_ZAXIS + 2]};
+          // mj_collision order: smaller geom type first, geom id breaks ties
+          const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < uni(ip[pc - (G_SIZE + MAX_SLOTS) + G_GEOMID]));
+          push(pm, EK_STATIC, wc, ptype, pfirst, ppos, pz, wbound[nwpad + wc]);
+          drain_if_full();
+        }
+      }
+      // earlier moving geoms in the register slots
+      if (smask_use != 0) {
+        pin_geom(cur);
+        unsigned anybits = 0;
+        unsigned lanebits = 0;
+#pragma unroll
+        for (int n = 0; n < MAXS; n++) {  // literal register operands after unrolling
+          if ((smask_use >> n) & 1u) {
+            T dx = cur.pos[0] - sf.f[0][n], dy = cur.pos[1] - sf.f[1][n], dz = cur.pos[2] - sf.f[2][n];
+            const bool ps = !(dx * dx + dy * dy + dz * dz + dead > sbound[n]);
+            lanebits |= ps ? (1u << n) : 0u;
+            anybits |= (__builtin_amdgcn_ballot_w64(ps) != 0ull) ? (1u << n) : 0u;
+          }
+        }
+#ifdef MJPL_X_Q_NOPUSH
+        anybits = 0;
+#endif
+        for (unsigned ab = anybits; ab; ab &= ab - 1) {
+          const int slot = (int)__builtin_ctz(ab);
+          const unsigned long long pm = __builtin_amdgcn_ballot_w64((lanebits >> slot) & 1u);
+          const int pw = uni(swords[slot]);
+          T t6[6];
+          slot_get6(sf, slot, t6);
+          const T ppos[3] = {t6[0], t6[1], t6[2]};
+          const T pz[3] = {t6[3], t6[4], t6[5]};
+          push(pm, EK_SLOT, slot, (pw >> 12) & 15, (pw & P_FIRST) != 0, ppos, pz, sbound[MAX_SLOTS + slot]);
+          drain_if_full();
         }
       }
 
