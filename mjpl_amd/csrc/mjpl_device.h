@@ -614,6 +614,10 @@ __device__ __forceinline__ void pin_geom(GeomT<T> &g) {
   pin(g.pos[0]); pin(g.pos[1]); pin(g.pos[2]); pin(g.m[2]); pin(g.m[5]); pin(g.m[8]);
 }
 
+// the int stored in the first four bytes of a table scalar
+__device__ __forceinline__ int info_bits(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ int info_bits(double v) { return (int)(unsigned)__builtin_bit_cast(unsigned long long, v); }
+
 // value of `v` in lane `l` (wave-uniform l) as a scalar: v_readlane_b32
 __device__ __forceinline__ float bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -975,23 +979,24 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
 // the narrowphase runs with full lanes, and reports contacts back to the owning lanes through
 // a per-wave flag word.  Arithmetic per pair is unchanged, only which lane executes it.
 
-enum : int { Q_CAP = 128, Q_FIELDS = 13 };  // record: cur pos/axis, partner pos/axis, margin
+enum : int { Q_CAP = 128, Q_FIELDS = 12 };  // record: cur pos/axis, (slot partner) pos/axis
 // i0: bits 0..5 owner lane, 6..9 cur type, 10..13 partner type, 14 pfirst, 15..16 kind, 17..24 index
 // i1: constant-table offset of the cur geom's block (sizes; slot sizes)
 
 template <class T>
 struct WaveQueue {
   T *f;        // [Q_FIELDS][Q_CAP]
-  int *i0, *i1;  // i0[Q_CAP]; i1[2][Q_CAP]: geom block offset, partner-size offset inside it
+  int *i0, *i1;  // [Q_CAP] each: packed pair id, constant-table offset of the cur geom's block
   int *flags;  // [64] : bit0 contact, bit1 unsure, per owning lane
   static __host__ __device__ constexpr size_t bytes() {
-    return (size_t)Q_FIELDS * Q_CAP * sizeof(T) + 3 * Q_CAP * sizeof(int) + 64 * sizeof(int);
+    return (size_t)Q_FIELDS * Q_CAP * sizeof(T) + 2 * Q_CAP * sizeof(int) + 64 * sizeof(int);
   }
 };
 
 template <class T, bool WBOX>
 __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, typename Real<T>::Tab tp,
-                                            typename Real<T>::Tab wnarrow, T tol) {
+                                            typename Real<T>::Tab wcull, typename Real<T>::Tab wnarrow,
+                                            int nwpad, T tol) {
   typedef typename Real<T>::Tab Tab;
   typedef GeomT<T> Geom;
   const int lane = threadIdx.x & 63;
@@ -1004,27 +1009,36 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, typ
     const int jj = on ? j : 0;
     const int i0 = wq.i0[jj];
     Tab gd = tp + wq.i1[jj];
-    Geom cur, par;
-    cur.pos[0] = wq.f[0 * Q_CAP + jj]; cur.pos[1] = wq.f[1 * Q_CAP + jj]; cur.pos[2] = wq.f[2 * Q_CAP + jj];
-    cur.m[2] = wq.f[3 * Q_CAP + jj]; cur.m[5] = wq.f[4 * Q_CAP + jj]; cur.m[8] = wq.f[5 * Q_CAP + jj];
-    par.pos[0] = wq.f[6 * Q_CAP + jj]; par.pos[1] = wq.f[7 * Q_CAP + jj]; par.pos[2] = wq.f[8 * Q_CAP + jj];
-    par.m[2] = wq.f[9 * Q_CAP + jj]; par.m[5] = wq.f[10 * Q_CAP + jj]; par.m[8] = wq.f[11 * Q_CAP + jj];
-    const T margin = wq.f[12 * Q_CAP + jj];
-    cur.m[0] = cur.m[1] = cur.m[3] = cur.m[4] = cur.m[6] = cur.m[7] = 0;
-    par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
     const int owner = i0 & 63, gtype = (i0 >> 6) & 15, ptype = (i0 >> 10) & 15;
     const bool pfirst = (i0 >> 14) & 1;
     const int kind = (i0 >> 15) & 3, index = (i0 >> 17) & 255;
-    // per-lane gathers of the sizes (and a static box's other two axes)
+    Geom cur, par;
+    cur.pos[0] = wq.f[0 * Q_CAP + jj]; cur.pos[1] = wq.f[1 * Q_CAP + jj]; cur.pos[2] = wq.f[2 * Q_CAP + jj];
+    cur.m[2] = wq.f[3 * Q_CAP + jj]; cur.m[5] = wq.f[4 * Q_CAP + jj]; cur.m[8] = wq.f[5 * Q_CAP + jj];
+    cur.m[0] = cur.m[1] = cur.m[3] = cur.m[4] = cur.m[6] = cur.m[7] = 0;
+    par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
+    // Per-lane gathers: the cur geom's size, and for a static partner its whole pose and size
+    // from the world tables (a slot partner's pose travelled in the record).
     const T gsize[3] = {gd[GD_SIZE], gd[GD_SIZE + 1], gd[GD_SIZE + 2]};
-    // partner sizes: static -> world narrow table; slot -> the cur geom's ssize[slot], whose
-    // offset inside the geom block was pushed next to i1
-    Tab ps = (kind == EK_SLOT) ? (gd + wq.i1[Q_CAP + jj]) : (wnarrow + index * WN_LEN + WN_SIZE);
-    const T psize[3] = {ps[0], ps[1], ps[2]};
-    if (WBOX && kind == EK_STATIC && ptype == GT_BOX) {
+    T psize[3], margin;
+    if (kind == EK_SLOT) {
+      par.pos[0] = wq.f[6 * Q_CAP + jj]; par.pos[1] = wq.f[7 * Q_CAP + jj]; par.pos[2] = wq.f[8 * Q_CAP + jj];
+      par.m[2] = wq.f[9 * Q_CAP + jj]; par.m[5] = wq.f[10 * Q_CAP + jj]; par.m[8] = wq.f[11 * Q_CAP + jj];
+      Tab sb = gd + GD_WBOUND + 2 * nwpad;
+      margin = sb[MAX_SLOTS + index];
+      psize[0] = sb[2 * MAX_SLOTS + 3 * index]; psize[1] = sb[2 * MAX_SLOTS + 3 * index + 1];
+      psize[2] = sb[2 * MAX_SLOTS + 3 * index + 2];
+    } else {
+      Tab rc = wcull + index * WC_LEN;
       Tab rw = wnarrow + index * WN_LEN;
-      par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
-      par.m[1] = rw[WN_YAXIS]; par.m[4] = rw[WN_YAXIS + 1]; par.m[7] = rw[WN_YAXIS + 2];
+      par.pos[0] = rc[WC_POS]; par.pos[1] = rc[WC_POS + 1]; par.pos[2] = rc[WC_POS + 2];
+      par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
+      if (WBOX) {
+        par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
+        par.m[1] = rw[WN_YAXIS]; par.m[4] = rw[WN_YAXIS + 1]; par.m[7] = rw[WN_YAXIS + 2];
+      }
+      psize[0] = rw[WN_SIZE]; psize[1] = rw[WN_SIZE + 1]; psize[2] = rw[WN_SIZE + 2];
+      margin = gd[GD_WBOUND + nwpad + index];
     }
     int code = V_NONE;
     if (on) code = pair_contact<T, WBOX, false>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
@@ -1149,6 +1163,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       const int gdoff = uni(ip[pc + G_DOFF]);
       Tab gd = tp + gdoff;
       const int store = uni(ip[pc + G_STORE]);
+      const int geom_id = uni(ip[pc + G_GEOMID]);
       const unsigned smask = (unsigned)uni(ip[pc + G_SMASK]);
       const unsigned long long wmask_all =
           (unsigned long long)(unsigned)uni(ip[pc + G_WMASK_LO]) |
@@ -1181,27 +1196,25 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       // control flow: ~5 branches and ~35 instructions per pair.)
       Tab wbound = gd + GD_WBOUND;            // [nwpad] bounds, then [nwpad] margins
       Tab sbound = wbound + 2 * nwpad;        // [16] bounds, [16] margins, [16][3] sizes
-      auto push = [&](unsigned long long pm, int kind, int index, int ptype, bool pfirst, const T *ppos,
-                      const T *pz, T margin) {
+      auto push = [&](unsigned long long pm, int kind, int index, int ptype, bool pfirst, const T *t6) {
         const bool mine = (pm >> lane) & 1ull;
         const int off = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
         if (mine) {
           wq.f[0 * Q_CAP + off] = cur.pos[0]; wq.f[1 * Q_CAP + off] = cur.pos[1]; wq.f[2 * Q_CAP + off] = cur.pos[2];
           wq.f[3 * Q_CAP + off] = cur.m[2]; wq.f[4 * Q_CAP + off] = cur.m[5]; wq.f[5 * Q_CAP + off] = cur.m[8];
-          wq.f[6 * Q_CAP + off] = ppos[0]; wq.f[7 * Q_CAP + off] = ppos[1]; wq.f[8 * Q_CAP + off] = ppos[2];
-          wq.f[9 * Q_CAP + off] = pz[0]; wq.f[10 * Q_CAP + off] = pz[1]; wq.f[11 * Q_CAP + off] = pz[2];
-          wq.f[12 * Q_CAP + off] = margin;
+          if (kind == EK_SLOT) {  // a static partner's pose is read from the world tables at the drain
+            wq.f[6 * Q_CAP + off] = t6[0]; wq.f[7 * Q_CAP + off] = t6[1]; wq.f[8 * Q_CAP + off] = t6[2];
+            wq.f[9 * Q_CAP + off] = t6[3]; wq.f[10 * Q_CAP + off] = t6[4]; wq.f[11 * Q_CAP + off] = t6[5];
+          }
           wq.i0[off] = lane | (gtype << 6) | (ptype << 10) | ((pfirst ? 1 : 0) << 14) | (kind << 15) | (index << 17);
           wq.i1[off] = gdoff;
-          // where the partner's sizes live relative to gd (slot partners only)
-          wq.i1[Q_CAP + off] = GD_WBOUND + 2 * nwpad + 2 * MAX_SLOTS + 3 * index;
         }
         qn += (int)__builtin_popcountll(pm);
       };
       auto drain_if_full = [&]() {
         if (qn >= 64) {
-          queue_drain<T, WBOX>(wq, qn, tp, wnarrow, tol);
+          queue_drain<T, WBOX>(wq, qn, tp, wcull, wnarrow, nwpad, tol);
           fl = wq.flags[lane];
           dead = (fl != 0 || !active) ? kInf : T(0);
         }
@@ -1223,22 +1236,40 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         T dif[3] = {cur.pos[0] - ppos[0], cur.pos[1] - ppos[1], cur.pos[2] - ppos[2]};
         const unsigned long long pm = __builtin_amdgcn_ballot_w64(!(dot3(dif, pz) + dead > wbound[wc]));
         if (pm == 0ull) continue;
-        push(pm, EK_PLANE, wc, GT_PLANE, true, ppos, pz, wbound[nwpad + wc]);
+        push(pm, EK_PLANE, wc, GT_PLANE, true, ppos);
         drain_if_full();
       }
-      // other static geoms
+      // other static geoms.  The 16 + 4 scalars of the NEXT chunk are requested before the
+      // current chunk's culls, so a wave does not sit on a scalar-load round trip per chunk
+      // (the tables are padded by one chunk).
+      T nrc[16], nbc[4];
+#pragma unroll
+      for (int k = 0; k < 16; k++) nrc[k] = wcull[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) nbc[k] = wbound[k];
       for (int base = 0; base < nwpad; base += 4) {
         const unsigned bits = (unsigned)(wmask_use >> base) & 15u;
+        T rcv[16], bcv[4];
+#pragma unroll
+        for (int k = 0; k < 16; k++) rcv[k] = nrc[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) bcv[k] = nbc[k];
+        {
+          Tab rn = wcull + (base + 4) * WC_LEN;
+          Tab bn = wbound + (base + 4);
+#pragma unroll
+          for (int k = 0; k < 16; k++) nrc[k] = rn[k];
+#pragma unroll
+          for (int k = 0; k < 4; k++) nbc[k] = bn[k];
+        }
         if (bits == 0) continue;
-        Tab rc = wcull + base * WC_LEN;
-        Tab bc = wbound + base;
         pin_geom(cur);
         unsigned long long m0, m1, m2, m3;
 #define MJPL_QCULL(k, out)                                                              \
         {                                                                               \
-          T dx = cur.pos[0] - rc[(k) * WC_LEN], dy = cur.pos[1] - rc[(k) * WC_LEN + 1],  \
-            dz = cur.pos[2] - rc[(k) * WC_LEN + 2];                                     \
-          const T bk = ((bits >> (k)) & 1u) ? bc[k] : -kInf;                            \
+          T dx = cur.pos[0] - rcv[(k) * WC_LEN], dy = cur.pos[1] - rcv[(k) * WC_LEN + 1], \
+            dz = cur.pos[2] - rcv[(k) * WC_LEN + 2];                                    \
+          const T bk = ((bits >> (k)) & 1u) ? bcv[k] : -kInf;                           \
           out = __builtin_amdgcn_ballot_w64(!(dx * dx + dy * dy + dz * dz + dead > bk)); \
         }
         MJPL_QCULL(0, m0) MJPL_QCULL(1, m1) MJPL_QCULL(2, m2) MJPL_QCULL(3, m3)
@@ -1252,15 +1283,13 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           const unsigned long long pm = k == 0 ? m0 : (k == 1 ? m1 : (k == 2 ? m2 : m3));
           if (pm == 0ull) continue;
           const int wc = base + k;
-          Tab r4 = wcull + wc * WC_LEN;
-          Tab rw = wnarrow + wc * WN_LEN;
-          const int info = ((IP)(r4 + WC_INFO))[0];
+          // the row's info word came with the chunk (first 4 bytes of its 4th scalar)
+          const T iw = k == 0 ? rcv[WC_INFO] : (k == 1 ? rcv[WC_LEN + WC_INFO] : (k == 2 ? rcv[2 * WC_LEN + WC_INFO] : rcv[3 * WC_LEN + WC_INFO]));
+          const int info = uni(info_bits(iw));
           const int ptype = info & 255, pgid = info >> 8;
-          const T ppos[3] = {r4[WC_POS], r4[WC_POS + 1], r4[WC_POS + 2]};
-          const T pz[3] = {rw[WN_ZAXIS], rw[WN_ZAXIS + 1], rw[WN_ZAXIS + 2]};
           // mj_collision order: smaller geom type first, geom id breaks ties
-          const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < uni(ip[pc - (G_SIZE + MAX_SLOTS) + G_GEOMID]));
-          push(pm, EK_STATIC, wc, ptype, pfirst, ppos, pz, wbound[nwpad + wc]);
+          const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < geom_id);
+          push(pm, EK_STATIC, wc, ptype, pfirst, cur.pos);
           drain_if_full();
         }
       }
@@ -1287,9 +1316,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           const int pw = uni(swords[slot]);
           T t6[6];
           slot_get6(sf, slot, t6);
-          const T ppos[3] = {t6[0], t6[1], t6[2]};
-          const T pz[3] = {t6[3], t6[4], t6[5]};
-          push(pm, EK_SLOT, slot, (pw >> 12) & 15, (pw & P_FIRST) != 0, ppos, pz, sbound[MAX_SLOTS + slot]);
+          push(pm, EK_SLOT, slot, (pw >> 12) & 15, (pw & P_FIRST) != 0, t6);
           drain_if_full();
         }
       }
@@ -1300,7 +1327,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       }
     }
   }
-  queue_drain<T, WBOX>(wq, qn, tp, wnarrow, tol);
+  queue_drain<T, WBOX>(wq, qn, tp, wcull, wnarrow, nwpad, tol);
   fl = wq.flags[lane];
   return !active ? V_NONE : ((fl & 1) ? V_CONTACT : ((fl & 2) ? V_UNSURE : V_NONE));
 }

@@ -76,7 +76,7 @@ __device__ __forceinline__ WaveQueue<T> wave_queue(char *qmem) {
   wq.f = reinterpret_cast<T *>(base);
   wq.i0 = reinterpret_cast<int *>(base + (size_t)Q_FIELDS * Q_CAP * sizeof(T));
   wq.i1 = wq.i0 + Q_CAP;
-  wq.flags = wq.i1 + 2 * Q_CAP;
+  wq.flags = wq.i1 + Q_CAP;
   return wq;
 }
 
@@ -574,7 +574,7 @@ int compile_program(mjpl_engine *e) {
   }
   const int nworld = (int)(wcull_tab.size() / WC_LEN);
   const int nwpad = (nworld + 3) / 4 * 4;
-  wcull_tab.resize((size_t)nwpad * WC_LEN, 0.0);
+  wcull_tab.resize((size_t)(nwpad + 4) * WC_LEN, 0.0);  // one spare chunk: the kernels prefetch ahead
   if (nworld > 64) return fail(MJPL_E_CAPACITY, "%d static geoms; this build enables at most 64 per moving geom", nworld);
   if (ng >= (1 << 23)) return fail(MJPL_E_CAPACITY, "too many geoms");
 
