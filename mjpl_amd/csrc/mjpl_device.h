@@ -968,6 +968,23 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
 }
 
 
+// ----------------------------------------------------------------------------- diagnostics
+// -DMJPL_STAMPS: per-wave s_memtime accounting of the queued interpreter's phases, summed into
+// g_stamps by lane 0 (a timing-only build; see tools/stamps.py).  Never defined in the product.
+#ifdef MJPL_STAMPS
+__device__ unsigned long long g_stamps[8];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define MJPL_T0(var) unsigned long long var = stamp()
+#define MJPL_ACC(slot, var) { unsigned long long t_ = stamp(); acc[slot] += t_ - var; var = t_; }
+#else
+#define MJPL_T0(var)
+#define MJPL_ACC(slot, var)
+#endif
+
 // ----------------------------------------------------------------------------- queued narrowphase
 // The immediate interpreter above runs a narrowphase routine as soon as ANY lane of the wave
 // passes a bounding cull: with 64 unrelated configurations per wave that is the case for ~28 %
@@ -1060,6 +1077,10 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   // Lane state lives in VGPR values, not in bools: loop-carried lane masks cost three scalar
   // instructions per mask per iteration.  `dead` is +inf for lanes that need no more tests; it is
   // added to the cull measure so that one compare yields the pass mask.  `fl` mirrors flags[lane].
+#ifdef MJPL_STAMPS
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  MJPL_T0(tt);
   const T kInf = __builtin_inff();
   T dead = active ? T(0) : kInf;
   int fl = 0;
@@ -1157,6 +1178,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       for (int k = 0; k < 4; k++) sv[(3 + k) * sstride] = qt[k];
     }
 
+    MJPL_ACC(0, tt);  // FK of the body
     for (int g = 0; g < ngeom; g++) {
       const int gtype = uni(ip[pc + G_TYPE]);
       const int gflags = uni(ip[pc + G_FLAGS]);
@@ -1190,6 +1212,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         quat2zaxis(cur.m, gq);
       }
 
+      MJPL_ACC(1, tt);  // geom record + pose
       // ---- culls: straight-line code, four static rows (then four register slots) at a time;
       // a pair costs ~9 VALU and no branch.  Pushes are a rolled loop over the few rows of a
       // chunk that some lane passed.  (A rolled per-pair loop spends most of its time in scalar
@@ -1214,9 +1237,11 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       };
       auto drain_if_full = [&]() {
         if (qn >= 64) {
+          MJPL_ACC(2, tt);
           queue_drain<T, WBOX>(wq, qn, tp, wcull, wnarrow, nwpad, tol);
           fl = wq.flags[lane];
           dead = (fl != 0 || !active) ? kInf : T(0);
+          MJPL_ACC(3, tt);  // drains
         }
       };
 #ifdef MJPL_X_Q_FKONLY
@@ -1321,14 +1346,24 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         }
       }
 
+      MJPL_ACC(2, tt);  // culls + pushes
       if (store >= 0) {
         const T t6[6] = {cur.pos[0], cur.pos[1], cur.pos[2], cur.m[2], cur.m[5], cur.m[8]};
         slot_put6(sf, store & 63, t6);
       }
+      MJPL_ACC(4, tt);  // slot store
     }
   }
+  MJPL_ACC(5, tt);
   queue_drain<T, WBOX>(wq, qn, tp, wcull, wnarrow, nwpad, tol);
   fl = wq.flags[lane];
+  MJPL_ACC(3, tt);
+#ifdef MJPL_STAMPS
+  if (lane == 0) {
+    for (int k = 0; k < 6; k++) atomicAdd(&g_stamps[k], acc[k]);
+    atomicAdd(&g_stamps[7], 1ull);
+  }
+#endif
   return !active ? V_NONE : ((fl & 1) ? V_CONTACT : ((fl & 2) ? V_UNSURE : V_NONE));
 }
 

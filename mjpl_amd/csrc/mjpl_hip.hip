@@ -1026,6 +1026,17 @@ int check_common(const mjpl_engine *e, const void *a, int64_t n, int layout) {
 extern "C" {
 
 const char *mjpl_last_error(void) { return g_err.c_str(); }
+
+#ifdef MJPL_STAMPS
+// diagnostic builds only: read and clear the phase counters of the queued interpreter
+int mjpl_debug_stamps(unsigned long long *out) {
+  unsigned long long z[8] = {0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mjpl::g_stamps), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mjpl::g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 const char *mjpl_version(void) { return "mjpl_hip 0.1 (gfx950)"; }
 
 int mjpl_device_count(void) {

@@ -124,3 +124,46 @@ def test_empty_and_tail(franka_obs):
     assert e.check_configs(Q).tolist() == [1] * 257
     info = e.info()
     assert info["arch"].startswith("gfx950")
+
+
+def test_filter_and_exact_paths_agree_at_full_size(franka_obs):
+    """BASELINE config 3 at full size (262 144 edges): the float32 filter + exact re-run and the
+    pure float64 kernels must return identical verdicts and first-bad indices, and the filter
+    must decide almost everything by itself."""
+    m = franka_obs
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    e = eng_mod.Engine(m)
+    e.set_planning(qidx, m.keyframe("home").qpos.copy())
+    qa, qb = _edges(m, qidx, 262144, seed=2)
+    e.set_filter(True, 1e-4)
+    v1, f1 = e.check_edges(qa, qb, 0.01, first_bad=True)
+    undecided = e.last_undecided()
+    e.set_filter(False)
+    v0, f0 = e.check_edges(qa, qb, 0.01, first_bad=True)
+    np.testing.assert_array_equal(v1, v0)
+    np.testing.assert_array_equal(f1, f0)
+    assert 0 < undecided < 0.02 * len(qa)
+    # size-independent property: an edge is valid iff its endpoint and every interior waypoint
+    # config is valid -> re-check a slice through the configuration kernel
+    sl = slice(0, 4096)
+    end_ok = e.check_configs(qb[sl])
+    assert np.all(v0[sl] <= end_ok)  # a valid edge has a valid endpoint
+    assert np.all((f0[sl] == 0) == (end_ok == 0))
+    # a much tighter tolerance still gives the same answers (the band only moves work)
+    e.set_filter(True, 2e-6)
+    v2 = e.check_edges(qa[:65536], qb[:65536], 0.01)
+    np.testing.assert_array_equal(v2, v0[:65536])
+
+
+def test_filter_configs_64k_and_info(oracle_mod):
+    m = scenes.franka_p()
+    e = eng_mod.Engine(m)
+    info = e.info()
+    assert info["filter_enabled"] == 1 and abs(info["filter_tol"] - 1e-4) < 1e-9
+    Q = _uniform_configs(m, 65536, seed=7)
+    want = oracle_mod.Oracle(m).valid_configs(Q, nthreads=8)
+    np.testing.assert_array_equal(e.check_configs(Q), want)
+    e.set_filter(False)
+    np.testing.assert_array_equal(e.check_configs(Q), want)
+    with pytest.raises(eng_mod.MjplError, match="tolerance"):
+        e.set_filter(True, 0.0)
