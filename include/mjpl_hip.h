@@ -182,12 +182,14 @@ void *mjpl_stream(mjpl_engine *e);
 
 /* ---- measurement ---------------------------------------------------------------- */
 
-/* Launch the edge kernel `iters` times on the engine's stream, each launch bracketed by
- * HIP events recorded on that stream; ms[k] receives launch k's duration.  Inputs and
- * outputs are device-resident.  Used by bench.py for roofline.achieved. */
+/* Run mjpl_check_edges_dev `iters` times on the engine's stream, each call bracketed by HIP
+ * events recorded on that stream; ms[k] receives call k's duration (all of its kernels) and
+ * ms_first[k] (nullable) the duration of its first, dominant kernel alone (the float32
+ * filter; the only kernel when the filter is off).  Inputs and outputs are device-resident.
+ * Used by bench.py for roofline.achieved. */
 int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E,
                         double step_dist, int32_t layout, uint8_t *dvalid, int32_t iters,
-                        float *ms);
+                        float *ms, float *ms_first);
 int mjpl_time_configs_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout,
                           uint8_t *dvalid, int32_t iters, float *ms);
 

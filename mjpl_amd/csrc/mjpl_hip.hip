@@ -444,6 +444,7 @@ struct mjpl_engine {
   int *d_ulist = nullptr;   // items (configurations / whole edges) the filter left undecided
   int *d_ucount = nullptr;  // [0] how many of those, [1] undecided waypoints of edges
   size_t ulist_cap = 0;
+  hipEvent_t mark_after_first = nullptr;  // timing runs: recorded after the first kernel of a launch
   double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
   int *d_ucedge = nullptr, *d_ucidx = nullptr;
   size_t uc_cap = 0;
@@ -981,6 +982,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
+    if (e->mark_after_first) HIP_TRY(hipEventRecord(e->mark_after_first, e->stream));
     // undecided waypoints: exact configuration kernel in patch mode (grid sized for a generous
     // share of the batch; surplus blocks return at once)
     const size_t ldsc = lds_bytes(e, 1);
@@ -1374,19 +1376,25 @@ void *mjpl_stream(mjpl_engine *e) { return e ? (void *)e->stream : nullptr; }
 // ---- measurement: per-launch HIP-event timing on the engine's own stream
 
 int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step_dist,
-                        int32_t layout, uint8_t *dvalid, int32_t iters, float *ms) {
+                        int32_t layout, uint8_t *dvalid, int32_t iters, float *ms, float *ms_first) {
   if (!e || iters < 0 || (iters > 0 && !ms)) return fail(MJPL_E_ARG, "mjpl_time_edges_dev: bad argument");
   HIP_TRY(hipSetDevice(e->device));
-  std::vector<hipEvent_t> ev(2 * (size_t)iters);
+  std::vector<hipEvent_t> ev(3 * (size_t)iters);
   for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
   int rc = MJPL_OK;
   for (int k = 0; k < iters && rc == MJPL_OK; k++) {
-    HIP_TRY(hipEventRecord(ev[2 * k], e->stream));
+    HIP_TRY(hipEventRecord(ev[3 * k], e->stream));
+    e->mark_after_first = ev[3 * k + 2];
     rc = mjpl_check_edges_dev(e, dQA, dQB, E, step_dist, layout, 0, dvalid, nullptr);
-    HIP_TRY(hipEventRecord(ev[2 * k + 1], e->stream));
+    e->mark_after_first = nullptr;
+    if (!e->filter) HIP_TRY(hipEventRecord(ev[3 * k + 2], e->stream));  // single-kernel launch
+    HIP_TRY(hipEventRecord(ev[3 * k + 1], e->stream));
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
-  for (int k = 0; k < iters && rc == MJPL_OK; k++) HIP_TRY(hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]));
+  for (int k = 0; k < iters && rc == MJPL_OK; k++) {
+    HIP_TRY(hipEventElapsedTime(&ms[k], ev[3 * k], ev[3 * k + 1]));
+    if (ms_first) HIP_TRY(hipEventElapsedTime(&ms_first[k], ev[3 * k], ev[3 * k + 2]));
+  }
   for (auto &x : ev) (void)hipEventDestroy(x);
   return rc;
 }

@@ -82,7 +82,7 @@ ABI = {
     "mjpl_sync": (C.c_int, [_VP]),
     "mjpl_stream": (_VP, [_VP]),
     "mjpl_time_edges_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int32, _VP, C.c_int32,
-                                      C.POINTER(C.c_float)]),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mjpl_time_configs_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.c_int32,
                                         C.POINTER(C.c_float)]),
     "mjpl_device_count": (C.c_int, []),
@@ -274,11 +274,15 @@ class Engine:
     def nearest_dev(self, dnodes, n, cap, dqueries, m, dout_idx, dout_d2=None):
         self._ok(self.lib.mjpl_nearest_dev(self.h, dnodes, n, cap, dqueries, m, dout_idx, dout_d2))
 
-    def time_edges_dev(self, dQA, dQB, n, step_dist, layout, dvalid, iters) -> np.ndarray:
+    def time_edges_dev(self, dQA, dQB, n, step_dist, layout, dvalid, iters, first_kernel=False):
+        """Per-call durations (ms) of `iters` edge launches; with first_kernel=True also the
+        durations of the first (dominant) kernel of each call."""
         ms = np.zeros(iters, np.float32)
+        ms1 = np.zeros(iters, np.float32)
+        fp = C.POINTER(C.c_float)
         self._ok(self.lib.mjpl_time_edges_dev(self.h, dQA, dQB, n, float(step_dist), layout, dvalid,
-                                              iters, ms.ctypes.data_as(C.POINTER(C.c_float))))
-        return ms
+                                              iters, ms.ctypes.data_as(fp), ms1.ctypes.data_as(fp)))
+        return (ms, ms1) if first_kernel else ms
 
     def time_configs_dev(self, dQ, n, layout, dvalid, iters) -> np.ndarray:
         ms = np.zeros(iters, np.float32)
