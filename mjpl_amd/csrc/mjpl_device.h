@@ -996,7 +996,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 // the narrowphase runs with full lanes, and reports contacts back to the owning lanes through
 // a per-wave flag word.  Arithmetic per pair is unchanged, only which lane executes it.
 
-enum : int { Q_CAP = 128, Q_FIELDS = 12 };  // record: cur pos/axis, (slot partner) pos/axis
+// record: cur pos/axis, (slot partner) pos/axis.  A push adds at most 64 candidates, so the queue
+// is drained as soon as fewer than 64 places are left.
+enum : int { Q_CAP = 96, Q_FIELDS = 12, Q_DRAIN_AT = Q_CAP - 64 };
 // i0: bits 0..5 owner lane, 6..9 cur type, 10..13 partner type, 14 pfirst, 15..16 kind, 17..24 index
 // i1: constant-table offset of the cur geom's block (sizes; slot sizes)
 
@@ -1236,7 +1238,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         qn += (int)__builtin_popcountll(pm);
       };
       auto drain_if_full = [&]() {
-        if (qn >= 64) {
+        if (qn >= Q_DRAIN_AT) {
           MJPL_ACC(2, tt);
           queue_drain<T, WBOX>(wq, qn, tp, wcull, wnarrow, nwpad, tol);
           fl = wq.flags[lane];

@@ -237,19 +237,26 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
   const int B = blockDim.x;
   if (rlist && (int64_t)blockIdx.x * B >= (int64_t)*rcount) return;
   const int nplan = gip[H_NPLAN];
-  Carve<T> c = carve_lds<T>(smem, gip, nip, gtp, ntp, nplan, 2, B);
+  Carve<T> c = carve_lds<T>(smem, gip, nip, gtp, ntp, nplan, 1, B);
   int64_t i;
   const bool active = pick_item(E, rlist, rcount, &i);
-  double *qe = c.col0 + threadIdx.x;  // edge end (QB)
-  double *qw = c.col1 + threadIdx.x;  // walking waypoint, starts at QA
-  load_columns(qe, B, QB, E, i, nplan, layout, active);
-  load_columns(qw, B, QA, E, i, nplan, layout, active);
+  // The walking waypoint lives in LDS (starts at QB for check 0, then QA + steps); the edge end
+  // is re-read from global memory when needed (L2-resident, coalesced in the SoA layout):
+  // halving the per-lane LDS footprint buys an extra wave per SIMD.
+  double *qw = c.col0 + threadIdx.x;
+  auto end_col = [&](int k) -> double {
+    return active ? ((layout == MJPL_SOA) ? QB[(int64_t)k * E + i] : QB[i * nplan + k]) : 0.0;
+  };
+  auto start_col = [&](int k) -> double {
+    return active ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
+  };
+  load_columns(qw, B, QB, E, i, nplan, layout, active);
   __syncthreads();
   IP perm = c.ip + c.ip[H_OFF_PERM];
 
   bool finite = true, at_end = true;
   for (int k = 0; k < nplan; k++) {
-    double a = qw[k * B], b = qe[k * B];
+    double a = start_col(k), b = qw[k * B];
     finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
     at_end = at_end && (a == b);
   }
@@ -265,25 +272,31 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
   // utils.py:144); every later iteration advances the waypoint and checks it.  One call site
   // of run_config keeps a single copy of the interpreter in the instruction stream.
   int idx = 0;
+  bool stepped = false;
   bool first = (flags & MJPL_EDGE_INTERIOR_ONLY) == 0;
   if (!first && !done && at_end) done = true;
   while (__ballot(!done) != 0ull) {
     if (!first && !done) {
+      if (idx == 0 && !stepped) {  // leaving check 0: the walk starts at QA
+        for (int k = 0; k < nplan; k++) qw[k * B] = start_col(k);
+        stepped = true;
+      }
       // _step(w, QB, step)
       double s = 0;
       for (int k = 0; k < nplan; k++) {
         const int col = perm[k];
-        double d = qe[col * B] - qw[col * B];
+        double d = end_col(col) - qw[col * B];
         s = s + d * d;
       }
       const double mag = sqrt(s);
       const double sm = step < mag ? step : mag;
       bool eq = true;
       for (int k = 0; k < nplan; k++) {
-        double d = qe[k * B] - qw[k * B];
+        const double ek = end_col(k);
+        double d = ek - qw[k * B];
         double nw = qw[k * B] + (d / mag) * sm;
         qw[k * B] = nw;
-        eq = eq && (nw == qe[k * B]);
+        eq = eq && (nw == ek);
       }
       if (eq) {
         done = true;  // reached QB: that element is dropped by waypoints[1:-1]
@@ -295,7 +308,7 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
         }
       }
     }
-    const int code = check_one<T, MAXS, WBOX, MBOX>(c, first ? qe : qw, B, !done, tol, i);
+    const int code = check_one<T, MAXS, WBOX, MBOX>(c, qw, B, !done, tol, i);
     if (!done && code == V_CONTACT) { done = true; ok = false; fb = idx; }
     if (!done && code == V_UNSURE) {
       // the filter cannot decide this configuration: hand IT (not the whole edge) to the exact
@@ -304,8 +317,7 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
       // edge go to the exact edge kernel.
       const int j = atomicAdd(uc.count, 1);
       if (j < uc.cap) {
-        const double *src = first ? qe : qw;
-        for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = src[k * B];
+        for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
         uc.edge[j] = (int)i;
         uc.idx[j] = idx;
       } else {
@@ -971,7 +983,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 2 * sizeof(int), e->stream));
     const int fblock = e->mbox ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
-    const size_t ldsf = lds_bytes(e, 2, sizeof(float), fblock, !e->mbox);
+    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
@@ -998,7 +1010,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     });
     if (rc != MJPL_OK) return rc;
   }
-  const size_t lds = lds_bytes(e, 2);
+  const size_t lds = lds_bytes(e, 1);
   int rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
     auto kern = k_check_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
     int r = allow_lds(kern, lds);
@@ -1184,7 +1196,7 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   out->nslots = e->nslots;
   out->nsaves = e->nsave;
   out->lds_bytes_configs = (int)lds_bytes(e, 1);
-  out->lds_bytes_edges = (int)lds_bytes(e, 2);
+  out->lds_bytes_edges = (int)lds_bytes(e, 1);
   out->filter_enabled = e->filter ? 1 : 0;
   out->filter_tol = e->filter_tol;
   out->block_threads = kBlock;
