@@ -1013,10 +1013,12 @@ struct WaveQueue {
 };
 
 template <class T, bool WBOX>
-__device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, typename Real<T>::Tab tp,
-                                            typename Real<T>::Tab wcull, typename Real<T>::Tab wnarrow,
-                                            int nwpad, T tol) {
-  typedef typename Real<T>::Tab Tab;
+__device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, const T *tp, const T *wcull,
+                                            const T *wnarrow, int nwpad, T tol) {
+  // tp / wcull / wnarrow point into the workgroup's LDS copy of the constant table: the drain
+  // reads them with per-lane addresses (every lane has its own candidate), which from global
+  // memory costs a ~1-2 us dependent gather per drain.
+  typedef const T *Tab;
   typedef GeomT<T> Geom;
   const int lane = threadIdx.x & 63;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1068,9 +1070,9 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, typ
 
 // Queued version of run_config for models without moving boxes (slots hold pos + z axis).
 template <class T, int MAXS, bool WBOX>
-__device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp, const double *q,
-                                                 int qstride, T *save, int sstride, bool active, T tol,
-                                                 const WaveQueue<T> &wq) {
+__device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp, const T *ltab,
+                                                 const double *q, int qstride, T *save, int sstride,
+                                                 bool active, T tol, const WaveQueue<T> &wq) {
   typedef typename Real<T>::Tab Tab;
   typedef GeomT<T> Geom;
   SlotFile<T, MAXS> sf;
@@ -1090,8 +1092,9 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   wq.flags[lane] = 0;
   const int nbodyops = uni(ip[H_NBODYOPS]);
   Tab wcull = tp + uni(ip[H_OFF_WCULL]);
-  Tab wnarrow = tp + uni(ip[H_OFF_WNARROW]);
   const int nwpad = uni(ip[H_NWPAD]);
+  const T *lwcull = ltab + uni(ip[H_OFF_WCULL]);
+  const T *lwnarrow = ltab + uni(ip[H_OFF_WNARROW]);
   int pc = uni(ip[H_OFF_BODYOPS]);
 
   for (int b = 0; b < nbodyops; b++) {
@@ -1240,7 +1243,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       auto drain_if_full = [&]() {
         if (qn >= Q_DRAIN_AT) {
           MJPL_ACC(2, tt);
-          queue_drain<T, WBOX>(wq, qn, tp, wcull, wnarrow, nwpad, tol);
+          queue_drain<T, WBOX>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol);
           fl = wq.flags[lane];
           dead = (fl != 0 || !active) ? kInf : T(0);
           MJPL_ACC(3, tt);  // drains
@@ -1257,7 +1260,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       for (unsigned long long pm_ = pmask_use; pm_; pm_ &= pm_ - 1) {
         const int wc = (int)__builtin_ctzll(pm_);
         Tab rc = wcull + wc * WC_LEN;
-        Tab rw = wnarrow + wc * WN_LEN;
+        Tab rw = tp + uni(ip[H_OFF_WNARROW]) + wc * WN_LEN;
         const T ppos[3] = {rc[WC_POS], rc[WC_POS + 1], rc[WC_POS + 2]};
         const T pz[3] = {rw[WN_ZAXIS], rw[WN_ZAXIS + 1], rw[WN_ZAXIS + 2]};
         T dif[3] = {cur.pos[0] - ppos[0], cur.pos[1] - ppos[1], cur.pos[2] - ppos[2]};
@@ -1357,7 +1360,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
     }
   }
   MJPL_ACC(5, tt);
-  queue_drain<T, WBOX>(wq, qn, tp, wcull, wnarrow, nwpad, tol);
+  queue_drain<T, WBOX>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol);
   fl = wq.flags[lane];
   MJPL_ACC(3, tt);
 #ifdef MJPL_STAMPS

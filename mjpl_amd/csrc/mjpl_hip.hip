@@ -28,7 +28,7 @@ namespace {
 using namespace mjpl;
 
 constexpr int kBlock = 256;           // threads per workgroup: 4 wavefronts
-constexpr int kFilterBlock = 64;      // queued filter kernels: one wavefront, one candidate queue
+constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts share one LDS table copy
 constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
 constexpr int kStatusNonFinite = 1;
 
@@ -61,6 +61,7 @@ struct Carve {
   double *col0, *col1;
   T *save;
   char *qmem;  // per-wave candidate queues (queued kernels), after the pose saves
+  T *ltab;     // queued kernels: the workgroup's LDS copy of the constant table (drain gathers)
   IP ip;
   typename Real<T>::Tab tp;
 };
@@ -85,7 +86,7 @@ __device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int
                                          int64_t row) {
   if constexpr (kQueued<T, MBOX>) {
     WaveQueue<T> wq = wave_queue<T>(c.qmem);
-    return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, q, B, c.save + threadIdx.x, B, active, tol, wq);
+    return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, c.ltab, q, B, c.save + threadIdx.x, B, active, tol, wq);
   } else {
     FkOut none = {};
     return run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, q, B, c.save + threadIdx.x, B, active, tol,
@@ -111,6 +112,10 @@ __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restric
   // queue memory starts 8-byte aligned after the saves
   c.qmem = reinterpret_cast<char *>(c.col0) +
            (((size_t)ncolsets * nplan * B * sizeof(double) + (size_t)nsave * 7 * B * sizeof(T) + 7) & ~(size_t)7);
+  // queued kernels: constant-table copy behind the queues (staged below, before the barrier)
+  c.ltab = reinterpret_cast<T *>(c.qmem + (size_t)(B / 64) * WaveQueue<T>::bytes());
+  if (!Real<T>::exact)
+    for (int k = threadIdx.x; k < ntp; k += blockDim.x) c.ltab[k] = gtp[k];
 #if MJPL_TABLES_LDS
   int *il = reinterpret_cast<int *>(c.save + (size_t)nsave * 7 * B);
   for (int k = threadIdx.x; k < ntp; k += blockDim.x) tl[k] = gtp[k];
@@ -798,36 +803,6 @@ int compile_program(mjpl_engine *e) {
         dp.insert(dp.end(), sm.begin(), sm.end());
         dp.insert(dp.end(), ss.begin(), ss.end());
       }
-      // unified entry list (queued kernels): planes, other statics, register slots
-      {
-        ip[nent_at + 1] = (int)dp.size();
-        int nent = 0;
-        auto entry = [&](int kind, int index, int h, bool plane_bound) {
-          const int g1 = std::min(g, h), g2 = std::max(g, h);
-          const int first = (m.geom_type[g1] > m.geom_type[g2]) ? g2 : g1;
-          const int32_t word[2] = {kind | (index << 2) | (m.geom_type[h] << 12) | (first == h ? P_FIRST : 0), 0};
-          double rec[E_LEN] = {0};
-          memcpy(&rec[E_WORD], word, sizeof(double));
-          info_at.push_back({dp.size() + E_WORD, word[0]});
-          pair_bound(h, &rec[E_BOUND], &rec[E_MARGIN]);
-          (plane_bound ? plane_bound_at : sq_bound_at).push_back(dp.size() + E_BOUND);
-          if (kind != EK_SLOT) {
-            for (int k3 = 0; k3 < 3; k3++) {
-              rec[E_POS + k3] = e->st_gxpos[3 * h + k3];
-              rec[E_ZAXIS + k3] = e->st_gxmat[9 * h + 3 * k3 + 2];
-            }
-          }
-          for (int k3 = 0; k3 < 3; k3++) rec[E_SIZE + k3] = m.geom_size[3 * h + k3];
-          dp.insert(dp.end(), rec, rec + E_LEN);
-          nent++;
-        };
-        for (int sgeom : world_partners[gk])
-          if (m.geom_type[sgeom] == GT_PLANE) entry(EK_PLANE, world_row[sgeom], sgeom, true);
-        for (int sgeom : world_partners[gk])
-          if (m.geom_type[sgeom] != GT_PLANE) entry(EK_STATIC, world_row[sgeom], sgeom, false);
-        for (int k2 : stored_partners[gk]) entry(EK_SLOT, slot_of[k2] & 63, mgeoms[k2], false);
-        ip[nent_at] = nent;
-      }
     }
     ip[base + B_NGEOM] = ngeom_here;
   }
@@ -872,7 +847,7 @@ size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(doub
   const size_t nplan = e->qidx.size();
   size_t bytes = (size_t)ncolsets * nplan * block * sizeof(double) + (size_t)e->nsave * 7 * block * scalar;
   bytes = (bytes + 7) & ~(size_t)7;
-  if (queued) bytes += (size_t)(block / 64) * WaveQueue<float>::bytes();
+  if (queued) bytes += (size_t)(block / 64) * WaveQueue<float>::bytes() + ((e->fp.size() * sizeof(float) + 7) & ~(size_t)7);
 #if MJPL_TABLES_LDS
   bytes += ((e->dp.size() * scalar + 7) / 8) * 8 + e->ip.size() * sizeof(int);
 #endif
