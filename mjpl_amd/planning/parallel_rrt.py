@@ -30,7 +30,8 @@ class EdgeValidator:
 
 
 class HipEdgeValidator(EdgeValidator):
-    """mjpl_amd.CollisionConstraint behind the EdgeValidator interface."""
+    """mjpl_amd.CollisionConstraint behind the EdgeValidator interface; also offers the
+    brute-force nearest-neighbour kernel (Tree.nearest_neighbor, planning/tree.py:57-66)."""
 
     def __init__(self, constraint, qidx, qpos_base):
         self.c = constraint
@@ -40,6 +41,23 @@ class HipEdgeValidator(EdgeValidator):
         if step is None:
             return self.c.valid_configs_planning(QB)
         return self.c.valid_edges_planning(QA, QB, step)
+
+    def nearest(self, nodes: np.ndarray, queries: np.ndarray) -> np.ndarray:
+        """Index of the node nearest to each query (squared Euclidean distance in float64,
+        ties to the lowest index), computed by ``mjpl_nearest_dev``."""
+        eng = self.c.engine
+        self.c._ensure_planning()
+        n, m = len(nodes), len(queries)
+        hn = np.ascontiguousarray(nodes.T)
+        hq = np.ascontiguousarray(queries.T)
+        dn, dq = eng.alloc(hn.nbytes).upload(hn), eng.alloc(hq.nbytes).upload(hq)
+        di = eng.alloc(4 * m)
+        try:
+            eng.nearest_dev(dn.ptr, n, n, dq.ptr, m, di.ptr)
+            return di.download(np.int32, m).astype(np.int64)
+        finally:
+            for b in (dn, dq, di):
+                b.free()
 
 
 def _row_norm(d: np.ndarray) -> np.ndarray:
@@ -70,6 +88,7 @@ class ParallelBiRRT:
         self.lo = np.asarray(model.jnt_range[self.qidx, 0], dtype=np.float64)
         self.hi = np.asarray(model.jnt_range[self.qidx, 1], dtype=np.float64)
         self.group = group
+        self.gpu_nn_min_nodes = 2048  # below this the host reduction is faster than a launch
         self.rank, self.world = 0, 1
         if group is not None:
             import torch.distributed as dist
@@ -106,6 +125,9 @@ class ParallelBiRRT:
     def _nearest(self, targets, tree):
         ids = np.flatnonzero(self.tree[: self.n] == tree)
         nodes = self.Q[ids]
+        gpu_nn = getattr(self.validator, "nearest", None)
+        if gpu_nn is not None and len(nodes) >= self.gpu_nn_min_nodes:
+            return ids[gpu_nn(nodes, targets)]
         out = np.empty(len(targets), np.int64)
         for s in range(0, len(targets), 256):  # chunked [chunk, n_tree] distance matrix
             t = targets[s:s + 256]

@@ -196,3 +196,27 @@ def test_parallel_birrt_hip_matches_oracle_backend(oracle_mod):
         assert len(paths[0]) == len(paths[1]) > 2
         for a, b in zip(*paths):
             np.testing.assert_array_equal(a, b)
+
+
+def test_gpu_nearest_neighbour_in_the_planner_matches_host(oracle_mod):
+    """f2: the frontier planner's NN through mjpl_nearest_dev gives the same plan as the host NN."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    v = mjpl.HipEdgeValidator(mjpl.CollisionConstraint(m), qidx, q_init)
+    rng = np.random.default_rng(3)
+    while True:
+        g = q_init.copy()
+        g[qidx] = rng.uniform(m.jnt_range[qidx, 0], m.jnt_range[qidx, 1])
+        if v.valid_edges(g[qidx][None], g[qidx][None], None)[0]:
+            break
+    paths = []
+    for min_nodes in (0, 1 << 30):  # always GPU NN / never
+        p = mjpl.ParallelBiRRT(m, joints, v, q_init, epsilon=0.05, interval_step=0.01, seed=5, batch=128,
+                               goal_biasing_probability=0.1, max_planning_time=120.0)
+        p.gpu_nn_min_nodes = min_nodes
+        paths.append(p.plan_to_config(q_init, g))
+    assert len(paths[0]) == len(paths[1]) > 2
+    for a, b in zip(*paths):
+        np.testing.assert_array_equal(a, b)
