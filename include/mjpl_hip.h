@@ -97,6 +97,8 @@ typedef struct mjpl_info {
   int32_t compute_units;
   int32_t filter_enabled;    /* float32 filter in front of the exact kernels              */
   float   filter_tol;        /* its tolerance band, metres                                */
+  int32_t lds_bytes_filter;  /* dynamic LDS per block, float32 filter kernels             */
+  int32_t filter_block_threads;
   char    arch[32];          /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"            */
 } mjpl_info;
 

@@ -609,6 +609,7 @@ enum : int { SLOT_NONE = 63 };
 // narrowphase prologues costs tens of VGPRs that stay live across the whole loop).
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(int &x) { asm volatile("" : "+v"(x)); }
 template <class T>
 __device__ __forceinline__ void pin_geom(GeomT<T> &g) {
   pin(g.pos[0]); pin(g.pos[1]); pin(g.pos[2]); pin(g.m[2]); pin(g.m[5]); pin(g.m[8]);
@@ -972,7 +973,7 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
 // -DMJPL_STAMPS: per-wave s_memtime accounting of the queued interpreter's phases, summed into
 // g_stamps by lane 0 (a timing-only build; see tools/stamps.py).  Never defined in the product.
 #ifdef MJPL_STAMPS
-__device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_stamps[16];
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -996,75 +997,131 @@ __device__ __forceinline__ unsigned long long stamp() {
 // the narrowphase runs with full lanes, and reports contacts back to the owning lanes through
 // a per-wave flag word.  Arithmetic per pair is unchanged, only which lane executes it.
 
-// record: cur pos/axis, (slot partner) pos/axis.  A push adds at most 64 candidates, so the queue
-// is drained as soon as fewer than 64 places are left.
-enum : int { Q_CAP = 96, Q_FIELDS = 12, Q_DRAIN_AT = Q_CAP - 64 };
+// Two queues per wave, so that a drain runs ONE family of narrowphase routines with full lanes:
+//   N: slot partners (pose travels in the record), static spheres / capsules and planes
+//   B: static boxes (sphere-box / capsule-box, the expensive routines)
+// record: cur pos/axis, (N only: slot partner pos/axis).  A push that would not fit first drains
+// one batch of up to 64 off the top, so mid-configuration drains run with (nearly) full lanes.
+enum : int { QN_CAP = 64, QN_FIELDS = 12, QB_CAP = 64, QB_FIELDS = 6 };
 // i0: bits 0..5 owner lane, 6..9 cur type, 10..13 partner type, 14 pfirst, 15..16 kind, 17..24 index
 // i1: constant-table offset of the cur geom's block (sizes; slot sizes)
 
 template <class T>
 struct WaveQueue {
-  T *f;        // [Q_FIELDS][Q_CAP]
-  int *i0, *i1;  // [Q_CAP] each: packed pair id, constant-table offset of the cur geom's block
-  int *flags;  // [64] : bit0 contact, bit1 unsure, per owning lane
+  T *nf;          // [QN_FIELDS][QN_CAP]
+  int *ni0, *ni1; // [QN_CAP] each: packed pair id, constant-table offset of the cur geom's block
+  T *bf;          // [QB_FIELDS][QB_CAP]
+  int *bi0, *bi1; // [QB_CAP]
+  int *flags;     // [64] : bit0 contact, bit1 unsure, per owning lane
   static __host__ __device__ constexpr size_t bytes() {
-    return (size_t)Q_FIELDS * Q_CAP * sizeof(T) + 2 * Q_CAP * sizeof(int) + 64 * sizeof(int);
+    return (size_t)QN_FIELDS * QN_CAP * sizeof(T) + 2 * QN_CAP * sizeof(int) +
+           (size_t)QB_FIELDS * QB_CAP * sizeof(T) + 2 * QB_CAP * sizeof(int) + 64 * sizeof(int);
+  }
+  __device__ __forceinline__ void carve(char *base) {
+    nf = reinterpret_cast<T *>(base);
+    ni0 = reinterpret_cast<int *>(nf + QN_FIELDS * QN_CAP);
+    ni1 = ni0 + QN_CAP;
+    bf = reinterpret_cast<T *>(ni1 + QN_CAP);
+    bi0 = reinterpret_cast<int *>(bf + QB_FIELDS * QB_CAP);
+    bi1 = bi0 + QB_CAP;
+    flags = bi1 + QB_CAP;
   }
 };
 
-template <class T, bool WBOX>
+// BOXQ selects the queue.  ALL: empty it (end of a configuration); otherwise one batch.
+template <class T, bool BOXQ, bool ALL>
 __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, const T *tp, const T *wcull,
-                                            const T *wnarrow, int nwpad, T tol) {
+                                            const T *wnarrow, int nwpad, T tol,
+                                            unsigned long long *dacc = nullptr) {
   // tp / wcull / wnarrow point into the workgroup's LDS copy of the constant table: the drain
   // reads them with per-lane addresses (every lane has its own candidate), which from global
   // memory costs a ~1-2 us dependent gather per drain.
   typedef const T *Tab;
   typedef GeomT<T> Geom;
+  constexpr int CAP = BOXQ ? QB_CAP : QN_CAP;
+  const T *qf = BOXQ ? wq.bf : wq.nf;
+  const int *qi0 = BOXQ ? wq.bi0 : wq.ni0, *qi1 = BOXQ ? wq.bi1 : wq.ni1;
   const int lane = threadIdx.x & 63;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  while (qn > 0) {  // wave-uniform
+  do {  // wave-uniform
     const int n = qn < 64 ? qn : 64;
+#ifdef MJPL_STAMPS
+    unsigned long long ts0 = stamp();
+#endif
     const int j = qn - n + lane;
     const bool on = lane < n;
     qn -= n;
     const int jj = on ? j : 0;
-    const int i0 = wq.i0[jj];
-    Tab gd = tp + wq.i1[jj];
+    const int i0 = qi0[jj];
+    Tab gd = tp + qi1[jj];
     const int owner = i0 & 63, gtype = (i0 >> 6) & 15, ptype = (i0 >> 10) & 15;
     const bool pfirst = (i0 >> 14) & 1;
     const int kind = (i0 >> 15) & 3, index = (i0 >> 17) & 255;
     Geom cur, par;
-    cur.pos[0] = wq.f[0 * Q_CAP + jj]; cur.pos[1] = wq.f[1 * Q_CAP + jj]; cur.pos[2] = wq.f[2 * Q_CAP + jj];
-    cur.m[2] = wq.f[3 * Q_CAP + jj]; cur.m[5] = wq.f[4 * Q_CAP + jj]; cur.m[8] = wq.f[5 * Q_CAP + jj];
+    cur.pos[0] = qf[0 * CAP + jj]; cur.pos[1] = qf[1 * CAP + jj]; cur.pos[2] = qf[2 * CAP + jj];
+    cur.m[2] = qf[3 * CAP + jj]; cur.m[5] = qf[4 * CAP + jj]; cur.m[8] = qf[5 * CAP + jj];
     cur.m[0] = cur.m[1] = cur.m[3] = cur.m[4] = cur.m[6] = cur.m[7] = 0;
     par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
     // Per-lane gathers: the cur geom's size, and for a static partner its whole pose and size
     // from the world tables (a slot partner's pose travelled in the record).
     const T gsize[3] = {gd[GD_SIZE], gd[GD_SIZE + 1], gd[GD_SIZE + 2]};
     T psize[3], margin;
-    if (kind == EK_SLOT) {
-      par.pos[0] = wq.f[6 * Q_CAP + jj]; par.pos[1] = wq.f[7 * Q_CAP + jj]; par.pos[2] = wq.f[8 * Q_CAP + jj];
-      par.m[2] = wq.f[9 * Q_CAP + jj]; par.m[5] = wq.f[10 * Q_CAP + jj]; par.m[8] = wq.f[11 * Q_CAP + jj];
-      Tab sb = gd + GD_WBOUND + 2 * nwpad;
-      margin = sb[MAX_SLOTS + index];
-      psize[0] = sb[2 * MAX_SLOTS + 3 * index]; psize[1] = sb[2 * MAX_SLOTS + 3 * index + 1];
-      psize[2] = sb[2 * MAX_SLOTS + 3 * index + 2];
-    } else {
+    int code = V_NONE;
+    if constexpr (BOXQ) {
       Tab rc = wcull + index * WC_LEN;
       Tab rw = wnarrow + index * WN_LEN;
       par.pos[0] = rc[WC_POS]; par.pos[1] = rc[WC_POS + 1]; par.pos[2] = rc[WC_POS + 2];
       par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
-      if (WBOX) {
-        par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
-        par.m[1] = rw[WN_YAXIS]; par.m[4] = rw[WN_YAXIS + 1]; par.m[7] = rw[WN_YAXIS + 2];
-      }
+      par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
+      par.m[1] = rw[WN_YAXIS]; par.m[4] = rw[WN_YAXIS + 1]; par.m[7] = rw[WN_YAXIS + 2];
       psize[0] = rw[WN_SIZE]; psize[1] = rw[WN_SIZE + 1]; psize[2] = rw[WN_SIZE + 2];
       margin = gd[GD_WBOUND + nwpad + index];
+#ifdef MJPL_STAMPS
+      pin(margin); pin(psize[0]); pin(par.m[0]);
+      unsigned long long ts1 = stamp();
+#endif
+#ifndef MJPL_X_DRAIN_NONARROW
+      if (on) code = pair_contact<T, true, false>(gtype, cur, gsize, GT_BOX, par, psize, pfirst, margin, tol);
+#endif
+#ifdef MJPL_STAMPS
+      pin(code);
+      unsigned long long ts2 = stamp();
+      dacc[4] += 1ull; dacc[5] += (unsigned long long)n; dacc[6] += ts1 - ts0; dacc[7] += ts2 - ts1;
+#endif
+    } else {
+      if (kind == EK_SLOT) {
+        par.pos[0] = qf[6 * CAP + jj]; par.pos[1] = qf[7 * CAP + jj]; par.pos[2] = qf[8 * CAP + jj];
+        par.m[2] = qf[9 * CAP + jj]; par.m[5] = qf[10 * CAP + jj]; par.m[8] = qf[11 * CAP + jj];
+        Tab sb = gd + GD_WBOUND + 2 * nwpad;
+        margin = sb[MAX_SLOTS + index];
+        psize[0] = sb[2 * MAX_SLOTS + 3 * index]; psize[1] = sb[2 * MAX_SLOTS + 3 * index + 1];
+        psize[2] = sb[2 * MAX_SLOTS + 3 * index + 2];
+      } else {
+        Tab rc = wcull + index * WC_LEN;
+        Tab rw = wnarrow + index * WN_LEN;
+        par.pos[0] = rc[WC_POS]; par.pos[1] = rc[WC_POS + 1]; par.pos[2] = rc[WC_POS + 2];
+        par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
+        psize[0] = rw[WN_SIZE]; psize[1] = rw[WN_SIZE + 1]; psize[2] = rw[WN_SIZE + 2];
+        margin = gd[GD_WBOUND + nwpad + index];
+      }
+#ifdef MJPL_STAMPS
+      pin(margin); pin(psize[0]); pin(par.m[2]);
+      unsigned long long ts1 = stamp();
+#endif
+#ifndef MJPL_X_DRAIN_NONARROW
+      if (on) code = pair_contact<T, false, false>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
+#endif
+#ifdef MJPL_STAMPS
+      pin(code);
+      unsigned long long ts2 = stamp();
+      dacc[0] += 1ull; dacc[1] += (unsigned long long)n; dacc[2] += ts1 - ts0; dacc[3] += ts2 - ts1;
+#endif
     }
-    int code = V_NONE;
-    if (on) code = pair_contact<T, WBOX, false>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
+#ifdef MJPL_X_DRAIN_NONARROW  // timing-only build: pop + gather, no narrowphase
+    code = (cur.pos[0] + par.pos[0] + psize[0] + gsize[0] + margin == T(12345.0)) ? V_CONTACT : V_NONE;
+#endif
     if (on && code != V_NONE) atomicOr(&wq.flags[owner], code == V_CONTACT ? 1 : 2);
-  }
+  } while (ALL && qn > 0);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
@@ -1082,13 +1139,13 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   // instructions per mask per iteration.  `dead` is +inf for lanes that need no more tests; it is
   // added to the cull measure so that one compare yields the pass mask.  `fl` mirrors flags[lane].
 #ifdef MJPL_STAMPS
-  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   MJPL_T0(tt);
   const T kInf = __builtin_inff();
   T dead = active ? T(0) : kInf;
   int fl = 0;
-  int qn = 0;  // wave-uniform queue fill
+  int qn = 0, qb = 0;  // wave-uniform queue fills (general / static boxes)
   wq.flags[lane] = 0;
   const int nbodyops = uni(ip[H_NBODYOPS]);
   Tab wcull = tp + uni(ip[H_OFF_WCULL]);
@@ -1098,7 +1155,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   int pc = uni(ip[H_OFF_BODYOPS]);
 
   for (int b = 0; b < nbodyops; b++) {
-    if (__builtin_amdgcn_ballot_w64(dead == T(0)) == 0ull && qn == 0) break;  // every lane decided
+    if (__builtin_amdgcn_ballot_w64(dead == T(0)) == 0ull && qn == 0 && qb == 0) break;  // every lane decided
 
     const int parent = uni(ip[pc + B_PARENT]);
     Tab bd = tp + uni(ip[pc + B_DOFF]);
@@ -1224,31 +1281,42 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       // control flow: ~5 branches and ~35 instructions per pair.)
       Tab wbound = gd + GD_WBOUND;            // [nwpad] bounds, then [nwpad] margins
       Tab sbound = wbound + 2 * nwpad;        // [16] bounds, [16] margins, [16][3] sizes
-      auto push = [&](unsigned long long pm, int kind, int index, int ptype, bool pfirst, const T *t6) {
-        const bool mine = (pm >> lane) & 1ull;
-        const int off = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
-        if (mine) {
-          wq.f[0 * Q_CAP + off] = cur.pos[0]; wq.f[1 * Q_CAP + off] = cur.pos[1]; wq.f[2 * Q_CAP + off] = cur.pos[2];
-          wq.f[3 * Q_CAP + off] = cur.m[2]; wq.f[4 * Q_CAP + off] = cur.m[5]; wq.f[5 * Q_CAP + off] = cur.m[8];
-          if (kind == EK_SLOT) {  // a static partner's pose is read from the world tables at the drain
-            wq.f[6 * Q_CAP + off] = t6[0]; wq.f[7 * Q_CAP + off] = t6[1]; wq.f[8 * Q_CAP + off] = t6[2];
-            wq.f[9 * Q_CAP + off] = t6[3]; wq.f[10 * Q_CAP + off] = t6[4]; wq.f[11 * Q_CAP + off] = t6[5];
-          }
-          wq.i0[off] = lane | (gtype << 6) | (ptype << 10) | ((pfirst ? 1 : 0) << 14) | (kind << 15) | (index << 17);
-          wq.i1[off] = gdoff;
-        }
-        qn += (int)__builtin_popcountll(pm);
-      };
-      auto drain_if_full = [&]() {
-        if (qn >= Q_DRAIN_AT) {
+      auto push = [&](auto boxq, unsigned long long pm, int kind, int index, int ptype, bool pfirst,
+                      const T *t6) {
+        constexpr bool BOXQ = decltype(boxq)::value;
+        constexpr int CAP = BOXQ ? QB_CAP : QN_CAP;
+        int &fill = BOXQ ? qb : qn;
+        const int cnt = (int)__builtin_popcountll(pm);
+        if (fill + cnt > CAP) {  // make room: one batch leaves the top of the queue
           MJPL_ACC(2, tt);
-          queue_drain<T, WBOX>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol);
+#ifdef MJPL_STAMPS
+          queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, acc + 8);
+#else
+          queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol);
+#endif
           fl = wq.flags[lane];
           dead = (fl != 0 || !active) ? kInf : T(0);
           MJPL_ACC(3, tt);  // drains
         }
+        T *qf = BOXQ ? wq.bf : wq.nf;
+        int *qi0 = BOXQ ? wq.bi0 : wq.ni0, *qi1 = BOXQ ? wq.bi1 : wq.ni1;
+        const bool mine = (pm >> lane) & 1ull;
+        const int off = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+        if (mine) {
+          qf[0 * CAP + off] = cur.pos[0]; qf[1 * CAP + off] = cur.pos[1]; qf[2 * CAP + off] = cur.pos[2];
+          qf[3 * CAP + off] = cur.m[2]; qf[4 * CAP + off] = cur.m[5]; qf[5 * CAP + off] = cur.m[8];
+          if (!BOXQ && kind == EK_SLOT) {  // a static partner's pose is read from the world tables at the drain
+            qf[6 * CAP + off] = t6[0]; qf[7 * CAP + off] = t6[1]; qf[8 * CAP + off] = t6[2];
+            qf[9 * CAP + off] = t6[3]; qf[10 * CAP + off] = t6[4]; qf[11 * CAP + off] = t6[5];
+          }
+          qi0[off] = lane | (gtype << 6) | (ptype << 10) | ((pfirst ? 1 : 0) << 14) | (kind << 15) | (index << 17);
+          qi1[off] = gdoff;
+        }
+        fill += cnt;
       };
+      const std::integral_constant<bool, false> kGeneral{};
+      const std::integral_constant<bool, true> kBoxes{};
 #ifdef MJPL_X_Q_FKONLY
       const unsigned long long pmask_use = 0, wmask_use = 0;
       const unsigned smask_use = 0;
@@ -1266,8 +1334,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         T dif[3] = {cur.pos[0] - ppos[0], cur.pos[1] - ppos[1], cur.pos[2] - ppos[2]};
         const unsigned long long pm = __builtin_amdgcn_ballot_w64(!(dot3(dif, pz) + dead > wbound[wc]));
         if (pm == 0ull) continue;
-        push(pm, EK_PLANE, wc, GT_PLANE, true, ppos);
-        drain_if_full();
+        push(kGeneral, pm, EK_PLANE, wc, GT_PLANE, true, ppos);
       }
       // other static geoms.  The 16 + 4 scalars of the NEXT chunk are requested before the
       // current chunk's culls, so a wave does not sit on a scalar-load round trip per chunk
@@ -1319,8 +1386,8 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           const int ptype = info & 255, pgid = info >> 8;
           // mj_collision order: smaller geom type first, geom id breaks ties
           const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < geom_id);
-          push(pm, EK_STATIC, wc, ptype, pfirst, cur.pos);
-          drain_if_full();
+          if (WBOX && ptype == GT_BOX) push(kBoxes, pm, EK_STATIC, wc, ptype, pfirst, cur.pos);
+          else push(kGeneral, pm, EK_STATIC, wc, ptype, pfirst, cur.pos);
         }
       }
       // earlier moving geoms in the register slots
@@ -1346,8 +1413,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           const int pw = uni(swords[slot]);
           T t6[6];
           slot_get6(sf, slot, t6);
-          push(pm, EK_SLOT, slot, (pw >> 12) & 15, (pw & P_FIRST) != 0, t6);
-          drain_if_full();
+          push(kGeneral, pm, EK_SLOT, slot, (pw >> 12) & 15, (pw & P_FIRST) != 0, t6);
         }
       }
 
@@ -1360,12 +1426,19 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
     }
   }
   MJPL_ACC(5, tt);
-  queue_drain<T, WBOX>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol);
+#ifdef MJPL_STAMPS
+  if (qn > 0) queue_drain<T, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, acc + 8);
+  if (WBOX && qb > 0) queue_drain<T, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, acc + 8);
+#else
+  if (qn > 0) queue_drain<T, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol);
+  if (WBOX && qb > 0) queue_drain<T, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol);
+#endif
   fl = wq.flags[lane];
   MJPL_ACC(3, tt);
 #ifdef MJPL_STAMPS
   if (lane == 0) {
     for (int k = 0; k < 6; k++) atomicAdd(&g_stamps[k], acc[k]);
+    for (int k = 8; k < 16; k++) atomicAdd(&g_stamps[k], acc[k]);
     atomicAdd(&g_stamps[7], 1ull);
   }
 #endif

@@ -74,10 +74,7 @@ template <class T>
 __device__ __forceinline__ WaveQueue<T> wave_queue(char *qmem) {
   char *base = qmem + (size_t)(threadIdx.x >> 6) * WaveQueue<T>::bytes();
   WaveQueue<T> wq;
-  wq.f = reinterpret_cast<T *>(base);
-  wq.i0 = reinterpret_cast<int *>(base + (size_t)Q_FIELDS * Q_CAP * sizeof(T));
-  wq.i1 = wq.i0 + Q_CAP;
-  wq.flags = wq.i1 + Q_CAP;
+  wq.carve(base);
   return wq;
 }
 
@@ -1019,7 +1016,7 @@ const char *mjpl_last_error(void) { return g_err.c_str(); }
 #ifdef MJPL_STAMPS
 // diagnostic builds only: read and clear the phase counters of the queued interpreter
 int mjpl_debug_stamps(unsigned long long *out) {
-  unsigned long long z[8] = {0};
+  unsigned long long z[16] = {0};
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mjpl::g_stamps), sizeof(z)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(mjpl::g_stamps), z, sizeof(z)) != hipSuccess) return -1;
@@ -1174,6 +1171,8 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   out->lds_bytes_edges = (int)lds_bytes(e, 1);
   out->filter_enabled = e->filter ? 1 : 0;
   out->filter_tol = e->filter_tol;
+  out->filter_block_threads = e->mbox ? kBlock : kFilterBlock;
+  out->lds_bytes_filter = (int)lds_bytes(e, 1, sizeof(float), out->filter_block_threads, !e->mbox);
   out->block_threads = kBlock;
   out->compute_units = e->prop.multiProcessorCount;
   strncpy(out->arch, e->prop.gcnArchName, sizeof(out->arch) - 1);

@@ -48,6 +48,7 @@ class Info(C.Structure):
         ("nslots", C.c_int32), ("nsaves", C.c_int32), ("lds_bytes_configs", C.c_int32),
         ("lds_bytes_edges", C.c_int32), ("block_threads", C.c_int32), ("compute_units", C.c_int32),
         ("filter_enabled", C.c_int32), ("filter_tol", C.c_float),
+        ("lds_bytes_filter", C.c_int32), ("filter_block_threads", C.c_int32),
         ("arch", C.c_char * 32),
     ]
 
