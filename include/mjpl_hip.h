@@ -201,6 +201,44 @@ int mjpl_device_count(void);
 const char *mjpl_last_error(void);
 const char *mjpl_version(void);
 
+/* ---- PoseConstraint (src/mjpl/constraint/pose_constraint.py) ---
+ * One handle per (engine, site, constraint frame).  Batches are rows of FULL qpos vectors,
+ * [N][nq] (apply() receives and returns full configurations, pose_constraint.py:78-91). */
+typedef struct mjpl_pose_desc {
+  int32_t site_body;          /* model.site_bodyid[site] (pose_constraint.py:70)              */
+  double  site_pos[3];        /* model.site_pos[site]                                          */
+  double  site_quat[4];       /* model.site_quat[site], wxyz                                   */
+  double  c_quat[4];          /* C_T_world = reference_frame.inverse() (:63): rotation, wxyz   */
+  double  c_pos[3];           /*                                        translation           */
+  double  lo[6], hi[6];       /* x y z roll pitch yaw bounds (:57-59)                          */
+  double  tolerance;          /* :29 (>= 0)                                                    */
+  double  q_step;             /* :30 (> 0; may be +inf)                                        */
+  const double *jnt_range;    /* [njnt*2] JointLimitConstraint (joint_limit_constraint.py:16-17) */
+  int32_t max_iters;          /* the reference loops without a bound (:80); <= 0 -> 1000       */
+} mjpl_pose_desc;
+
+typedef struct mjpl_pose mjpl_pose;
+
+/* PoseConstraint.__init__ (pose_constraint.py:18-70); ValueError cases -> MJPL_E_ARG */
+int mjpl_pose_create(mjpl_engine *e, const mjpl_pose_desc *desc, mjpl_pose **out);
+void mjpl_pose_destroy(mjpl_pose *p);
+/* `pose_constraint.q_step = ...` (examples/franka_constrained_move_to_pose.py:72-75) */
+int mjpl_pose_set_q_step(mjpl_pose *p, double q_step);
+
+/* Batched PoseConstraint.apply (pose_constraint.py:78-91): row i of Q is projected onto the
+ * constraint starting from itself; ok[i] = 1 and Q_out row i = the projection, or ok[i] = 0
+ * (the reference's None: joint limits violated or farther than 2*q_step from Q_old row i).
+ * iters (nullable): projection steps taken; negative = gave up after max_iters (ok = 0). */
+int mjpl_pose_apply(mjpl_pose *p, const double *Q_old, const double *Q, int64_t N, double *Q_out,
+                    uint8_t *ok, int32_t *iters);
+/* Batched PoseConstraint.valid_config (pose_constraint.py:72-76); xpos [N][3] / xmat [N][9]
+ * (nullable) receive the site's world pose (utils.site_pose, src/mjpl/utils.py:60-75). */
+int mjpl_pose_valid(mjpl_pose *p, const double *Q, int64_t N, uint8_t *valid, double *xpos, double *xmat);
+/* device-pointer variants: asynchronous on the engine's stream */
+int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQ_old, const double *dQ, int64_t N, double *dQ_out,
+                        uint8_t *dok, int32_t *diters);
+int mjpl_pose_valid_dev(mjpl_pose *p, const double *dQ, int64_t N, uint8_t *dvalid, double *dxpos, double *dxmat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <set>
 #include <string>
 #include <type_traits>
@@ -22,6 +23,7 @@
 
 #include "../../include/mjpl_hip.h"
 #include "mjpl_device.h"
+#include "mjpl_pose.h"
 
 namespace {
 
@@ -414,6 +416,145 @@ k_nearest(const double *__restrict__ nodes, int64_t n, int64_t cap, const double
   if (j < M) {
     out_idx[j] = besti;
     if (out_d2) out_d2[j] = best;
+  }
+}
+
+
+// ---- row f1: batched PoseConstraint (pose_constraint.py:72-171), one lane per configuration ----
+// LDS per lane: the working qpos [nq] and a [6][njoint] store that holds the chain joints'
+// world axis/anchor after FK and is overwritten in place by the RPY-Jacobian columns.
+constexpr int kPoseBlock = 64;
+
+__global__ void __launch_bounds__(kPoseBlock)
+k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
+             const double *__restrict__ Q, int64_t N, double *__restrict__ Qout,
+             uint8_t *__restrict__ ok, int32_t *__restrict__ iters) {
+  extern __shared__ double smem[];
+  constexpr int B = kPoseBlock;
+  const int lane = threadIdx.x;
+  const int nq = pi[PH_NQ], nj = pi[PH_NJOINT], maxit = pi[PH_MAXIT];
+  const double *tail = pd + pi[PH_OFF_TAIL];
+  const double *jrange = pd + pi[PH_OFF_JRANGE];
+  double *qw = smem + lane;                    // [nq][B]
+  double *jst = smem + (size_t)nq * B + lane;  // [6 * nj][B]
+  const int64_t i = (int64_t)blockIdx.x * B + lane;
+  const bool active = i < N;
+  for (int k = 0; k < nq; k++) qw[k * B] = active ? Q[i * nq + k] : 0.0;
+  const double tol = tail[PT_TOL], far_at = 2 * tail[PT_QSTEP];
+  // joint ids / types of the chain, in chain order, follow the per-body counts in `pi`
+  bool done = !active;
+  int result = 0, it = 0;
+  while (__ballot(!done) != 0ull) {
+    if (!done) {
+      PoseChainOut o;
+      pose_chain(pi, pd, qw, B, jst, B, o);
+      double dx[6], qs[4];
+      pose_displacement(tail, o, dx, qs);
+      if (norm6(dx) <= tol) {
+        done = true; result = 1;
+      } else if (it >= maxit) {
+        done = true; result = 2;
+      } else {
+        // _get_jacobian: E_rpy(world rpy of the site) @ [jacp; jacr]
+        double rpy[3];
+        quat2rpy(rpy, qs);
+        const double c_p = cos(rpy[1]), c_y = cos(rpy[2]), s_p = sin(rpy[1]), s_y = sin(rpy[2]);
+        const double e33 = c_y / c_p, e34 = s_y / c_p, e43 = -s_y, e44 = c_p;
+        const double e53 = c_y * (s_p / c_p), e54 = s_y * (s_p / c_p);
+        double A[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) A[r][c] = 0;
+        int ic = PH_SIZE, jk = 0;
+        for (int b = 0; b < pi[PH_NBODY]; b++) {
+          const int njnt = pi[ic++];
+          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
+            const int jtype = pi[ic];
+            const double ax[3] = {jst[(0 * nj + jk) * B], jst[(1 * nj + jk) * B], jst[(2 * nj + jk) * B]};
+            double col[6];
+            if (jtype == JT_HINGE) {
+              const double r[3] = {o.site_xpos[0] - jst[(3 * nj + jk) * B], o.site_xpos[1] - jst[(4 * nj + jk) * B],
+                                   o.site_xpos[2] - jst[(5 * nj + jk) * B]};
+              col[0] = ax[1] * r[2] - ax[2] * r[1];
+              col[1] = ax[2] * r[0] - ax[0] * r[2];
+              col[2] = ax[0] * r[1] - ax[1] * r[0];
+              col[3] = e33 * ax[0] + e34 * ax[1];
+              col[4] = e43 * ax[0] + e44 * ax[1];
+              col[5] = e53 * ax[0] + e54 * ax[1] + ax[2];
+            } else {
+              col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2];
+              col[3] = e33 * 0.0 + e34 * 0.0;
+              col[4] = e43 * 0.0 + e44 * 0.0;
+              col[5] = e53 * 0.0 + e54 * 0.0 + 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) jst[(r * nj + jk) * B] = col[r];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+              for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
+          }
+        }
+        double y[6];
+        pinv_sym6_apply(A, dx, y);
+        ic = PH_SIZE; jk = 0;
+        for (int b = 0; b < pi[PH_NBODY]; b++) {
+          const int njnt = pi[ic++];
+          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
+            const int qadr = pi[ic + 1];
+            double acc = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc = acc + jst[(r * nj + jk) * B] * y[r];
+            qw[qadr * B] -= acc;
+          }
+        }
+        bool viol = false;
+        double s = 0;
+        for (int k = 0; k < nq; k++) {
+          const double v = qw[k * B];
+          viol = viol || !(v >= jrange[2 * k] && v <= jrange[2 * k + 1]);
+          const double d = v - Qold[i * nq + k];
+          s = s + d * d;
+        }
+        it++;
+        if (viol || sqrt(s) > far_at) { done = true; result = 0; }
+      }
+    }
+  }
+  if (active) {
+    for (int k = 0; k < nq; k++) Qout[i * nq + k] = qw[k * B];
+    ok[i] = result == 1 ? 1 : 0;
+    if (iters) iters[i] = result == 2 ? -it : it;
+  }
+}
+
+__global__ void __launch_bounds__(kPoseBlock)
+k_pose_valid(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Q,
+             int64_t N, uint8_t *__restrict__ valid, double *__restrict__ xpos, double *__restrict__ xmat) {
+  extern __shared__ double smem[];
+  constexpr int B = kPoseBlock;
+  const int lane = threadIdx.x;
+  const int nq = pi[PH_NQ];
+  const double *tail = pd + pi[PH_OFF_TAIL];
+  const double *jrange = pd + pi[PH_OFF_JRANGE];
+  double *qw = smem + lane;
+  const int64_t i = (int64_t)blockIdx.x * B + lane;
+  const bool active = i < N;
+  bool inside = true;
+  for (int k = 0; k < nq; k++) {
+    const double v = active ? Q[i * nq + k] : 0.0;
+    qw[k * B] = v;
+    inside = inside && (v >= jrange[2 * k] && v <= jrange[2 * k + 1]);
+  }
+  PoseChainOut o;
+  pose_chain(pi, pd, qw, B, nullptr, 0, o);
+  double dx[6], qs[4];
+  pose_displacement(tail, o, dx, qs);
+  if (active) {
+    if (valid) valid[i] = (inside && norm6(dx) <= tail[PT_TOL]) ? 1 : 0;
+    if (xpos) for (int k = 0; k < 3; k++) xpos[i * 3 + k] = o.site_xpos[k];
+    if (xmat) for (int k = 0; k < 9; k++) xmat[i * 9 + k] = o.site_xmat[k];
   }
 }
 
@@ -1401,6 +1542,178 @@ int mjpl_time_configs_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t l
   for (int k = 0; k < iters && rc == MJPL_OK; k++) HIP_TRY(hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]));
   for (auto &x : ev) (void)hipEventDestroy(x);
   return rc;
+}
+
+// ---- row f1: PoseConstraint ---------------------------------------------------------------
+
+struct mjpl_pose {
+  mjpl_engine *e = nullptr;
+  std::vector<int> pi;
+  std::vector<double> pd;
+  int *d_pi = nullptr;
+  double *d_pd = nullptr;
+  int nq = 0, nj = 0;
+};
+
+namespace {
+size_t pose_lds(const mjpl_pose *p) { return (size_t)kPoseBlock * sizeof(double) * ((size_t)p->nq + 6 * (size_t)p->nj); }
+
+int pose_check(const mjpl_pose *p, const void *a, int64_t n) {
+  if (!p) return fail(MJPL_E_ARG, "pose handle is NULL");
+  if (n < 0) return fail(MJPL_E_ARG, "negative batch size");
+  if (n > 0 && !a) return fail(MJPL_E_ARG, "NULL batch pointer");
+  return MJPL_OK;
+}
+}  // namespace
+
+int mjpl_pose_create(mjpl_engine *e, const mjpl_pose_desc *d, mjpl_pose **out) {
+  if (!e || !d || !out) return fail(MJPL_E_ARG, "mjpl_pose_create: NULL argument");
+  const HostModel &m = e->m;
+  if (d->site_body < 0 || d->site_body >= m.nbody) return fail(MJPL_E_ARG, "site body %d out of range", d->site_body);
+  if (!d->jnt_range) return fail(MJPL_E_ARG, "jnt_range is NULL");
+  if (d->tolerance < 0.0) return fail(MJPL_E_ARG, "`tolerance` must be >= 0.");
+  if (!(d->q_step > 0.0)) return fail(MJPL_E_ARG, "`q_step` must be > 0.");
+  if (m.nq != m.njnt) return fail(MJPL_E_JOINT, "pose projection needs 1-DoF joints only (nq %d != njnt %d)", m.nq, m.njnt);
+  std::vector<int> chain;
+  for (int b = d->site_body; b > 0; b = m.body_parentid[b]) chain.push_back(b);
+  std::reverse(chain.begin(), chain.end());
+  auto p = std::make_unique<mjpl_pose>();
+  p->e = e;
+  p->nq = m.nq;
+  p->pi.assign(PH_SIZE, 0);
+  for (int b : chain) {
+    p->pi.push_back(m.body_jntnum[b]);
+    for (int k = 0; k < 3; k++) p->pd.push_back(m.body_pos[3 * b + k]);
+    for (int k = 0; k < 4; k++) p->pd.push_back(m.body_quat[4 * b + k]);
+    for (int j = 0; j < m.body_jntnum[b]; j++) {
+      const int jid = m.body_jntadr[b] + j;
+      if (m.jnt_type[jid] != JT_SLIDE && m.jnt_type[jid] != JT_HINGE)
+        return fail(MJPL_E_JOINT, "joint %d: only slide and hinge joints are supported", jid);
+      p->pi.push_back(m.jnt_type[jid]);
+      p->pi.push_back(m.jnt_qposadr[jid]);
+      p->pi.push_back(jid);
+      for (int k = 0; k < 3; k++) p->pd.push_back(m.jnt_axis[3 * jid + k]);
+      for (int k = 0; k < 3; k++) p->pd.push_back(m.jnt_pos[3 * jid + k]);
+      p->pd.push_back(m.qpos0[m.jnt_qposadr[jid]]);
+      p->nj++;
+    }
+  }
+  p->pi[PH_NBODY] = (int)chain.size();
+  p->pi[PH_NJOINT] = p->nj;
+  p->pi[PH_NQ] = m.nq;
+  p->pi[PH_MAXIT] = d->max_iters > 0 ? d->max_iters : 1000;
+  p->pi[PH_OFF_TAIL] = (int)p->pd.size();
+  p->pd.resize(p->pd.size() + PT_SIZE);
+  double *t = p->pd.data() + p->pi[PH_OFF_TAIL];
+  for (int k = 0; k < 3; k++) { t[PT_SITE_POS + k] = d->site_pos[k]; t[PT_C_POS + k] = d->c_pos[k]; }
+  for (int k = 0; k < 4; k++) { t[PT_SITE_QUAT + k] = d->site_quat[k]; t[PT_C_QUAT + k] = d->c_quat[k]; }
+  for (int k = 0; k < 6; k++) { t[PT_LO + k] = d->lo[k]; t[PT_HI + k] = d->hi[k]; }
+  t[PT_TOL] = d->tolerance;
+  t[PT_QSTEP] = d->q_step;
+  p->pi[PH_OFF_JRANGE] = (int)p->pd.size();
+  for (int k = 0; k < 2 * m.njnt; k++) p->pd.push_back(d->jnt_range[k]);
+  if (pose_lds(p.get()) > 64 * 1024)
+    return fail(MJPL_E_CAPACITY, "pose projection: %d qpos + %d chain joints exceed the LDS budget", p->nq, p->nj);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMalloc(&p->d_pi, p->pi.size() * sizeof(int)));
+  HIP_TRY(hipMalloc(&p->d_pd, p->pd.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(p->d_pi, p->pi.data(), p->pi.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_pd, p->pd.data(), p->pd.size() * sizeof(double), hipMemcpyHostToDevice));
+  *out = p.release();
+  return MJPL_OK;
+}
+
+void mjpl_pose_destroy(mjpl_pose *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->e->device);
+  if (p->d_pi) (void)hipFree(p->d_pi);
+  if (p->d_pd) (void)hipFree(p->d_pd);
+  delete p;
+}
+
+int mjpl_pose_set_q_step(mjpl_pose *p, double q_step) {
+  if (!p) return fail(MJPL_E_ARG, "pose handle is NULL");
+  if (!(q_step > 0.0)) return fail(MJPL_E_ARG, "`q_step` must be > 0.");
+  const size_t at = (size_t)p->pi[PH_OFF_TAIL] + PT_QSTEP;
+  p->pd[at] = q_step;
+  HIP_TRY(hipSetDevice(p->e->device));
+  HIP_TRY(hipStreamSynchronize(p->e->stream));
+  HIP_TRY(hipMemcpy(p->d_pd + at, &p->pd[at], sizeof(double), hipMemcpyHostToDevice));
+  return MJPL_OK;
+}
+
+int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQold, const double *dQ, int64_t N, double *dQout,
+                        uint8_t *dok, int32_t *diters) {
+  int rc = pose_check(p, dQ, N);
+  if (rc != MJPL_OK) return rc;
+  if (N == 0) return MJPL_OK;
+  if (!dQold || !dQout || !dok) return fail(MJPL_E_ARG, "NULL pointer");
+  HIP_TRY(hipSetDevice(p->e->device));
+  const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
+  hipLaunchKernelGGL(k_pose_apply, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd,
+                     dQold, dQ, N, dQout, dok, diters);
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+
+int mjpl_pose_valid_dev(mjpl_pose *p, const double *dQ, int64_t N, uint8_t *dvalid, double *dxpos, double *dxmat) {
+  int rc = pose_check(p, dQ, N);
+  if (rc != MJPL_OK) return rc;
+  if (N == 0) return MJPL_OK;
+  HIP_TRY(hipSetDevice(p->e->device));
+  const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
+  hipLaunchKernelGGL(k_pose_valid, dim3(grid), dim3(kPoseBlock), (size_t)kPoseBlock * sizeof(double) * p->nq,
+                     p->e->stream, p->d_pi, p->d_pd, dQ, N, dvalid, dxpos, dxmat);
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+
+int mjpl_pose_apply(mjpl_pose *p, const double *Q_old, const double *Q, int64_t N, double *Q_out,
+                    uint8_t *ok, int32_t *iters) {
+  int rc = pose_check(p, Q, N);
+  if (rc != MJPL_OK) return rc;
+  if (N == 0) return MJPL_OK;
+  if (!Q_old || !Q_out || !ok) return fail(MJPL_E_ARG, "NULL pointer");
+  mjpl_engine *e = p->e;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t qb = (size_t)N * p->nq * sizeof(double);
+  if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 1, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 4, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 2, (size_t)N)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 3, (size_t)N * sizeof(int32_t))) != MJPL_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(e->stage[0], Q_old, qb, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->stage[1], Q, qb, hipMemcpyHostToDevice, e->stream));
+  if ((rc = mjpl_pose_apply_dev(p, (const double *)e->stage[0], (const double *)e->stage[1], N,
+                                (double *)e->stage[4], (uint8_t *)e->stage[2], (int32_t *)e->stage[3])) != MJPL_OK)
+    return rc;
+  HIP_TRY(hipMemcpyAsync(Q_out, e->stage[4], qb, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(ok, e->stage[2], (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, e->stage[3], (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MJPL_OK;
+}
+
+int mjpl_pose_valid(mjpl_pose *p, const double *Q, int64_t N, uint8_t *valid, double *xpos, double *xmat) {
+  int rc = pose_check(p, Q, N);
+  if (rc != MJPL_OK) return rc;
+  if (N == 0) return MJPL_OK;
+  mjpl_engine *e = p->e;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t qb = (size_t)N * p->nq * sizeof(double);
+  if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 2, (size_t)N)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 4, (size_t)N * 3 * sizeof(double))) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 5, (size_t)N * 9 * sizeof(double))) != MJPL_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(e->stage[0], Q, qb, hipMemcpyHostToDevice, e->stream));
+  if ((rc = mjpl_pose_valid_dev(p, (const double *)e->stage[0], N, (uint8_t *)e->stage[2], (double *)e->stage[4],
+                                (double *)e->stage[5])) != MJPL_OK)
+    return rc;
+  if (valid) HIP_TRY(hipMemcpyAsync(valid, e->stage[2], (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  if (xpos) HIP_TRY(hipMemcpyAsync(xpos, e->stage[4], (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (xmat) HIP_TRY(hipMemcpyAsync(xmat, e->stage[5], (size_t)N * 9 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MJPL_OK;
 }
 
 }  // extern "C"

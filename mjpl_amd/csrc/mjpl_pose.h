@@ -1,0 +1,223 @@
+// mjpl_pose.h -- device code of the batched PoseConstraint:
+// PoseConstraint.valid_config / apply (src/mjpl/constraint/pose_constraint.py:72-171) for one
+// configuration per lane, float64.  FK runs along the site's ancestor chain only and keeps what
+// mj_jacSite needs (world axis + anchor of every joint on the chain); the 6x6 pseudo-inverse of
+// J J^T is a fully unrolled cyclic-Jacobi eigen-decomposition held in registers.
+//
+// Upstream arithmetic restated from published algorithms: mj_kinematics / mj_jacSite /
+// mju_mat2Quat [MJ-recalled], mink.lie SE3/SO3 [MINK-recalled], np.linalg.pinv (cutoff 1e-15 x
+// largest singular value).  Operation order follows oracle/mjpl_oracle_pose.c.
+#pragma once
+
+#include "mjpl_device.h"
+
+namespace mjpl {
+
+// pose program, int words: header, then per chain body {njnt}, per joint {type, qadr, dof}
+enum : int { PH_NBODY = 0, PH_NJOINT, PH_NQ, PH_MAXIT, PH_OFF_JRANGE, PH_OFF_TAIL, PH_SIZE };
+// doubles: per body pos[3] quat[4]; per joint axis[3] pos[3] qpos0; then at PH_OFF_TAIL:
+enum : int { PT_SITE_POS = 0, PT_SITE_QUAT = 3, PT_C_QUAT = 7, PT_C_POS = 11, PT_LO = 14, PT_HI = 20,
+             PT_TOL = 26, PT_QSTEP = 27, PT_SIZE = 28 };
+// ... and at PH_OFF_JRANGE: jnt_range[njnt][2]
+
+__device__ __forceinline__ void mat2quat(double *quat, const double *mat) {  // mju_mat2Quat
+  if (mat[0] + mat[4] + mat[8] > 0) {
+    quat[0] = 0.5 * sqrt(1 + mat[0] + mat[4] + mat[8]);
+    quat[1] = 0.25 * (mat[7] - mat[5]) / quat[0];
+    quat[2] = 0.25 * (mat[2] - mat[6]) / quat[0];
+    quat[3] = 0.25 * (mat[3] - mat[1]) / quat[0];
+  } else if (mat[0] > mat[4] && mat[0] > mat[8]) {
+    quat[1] = 0.5 * sqrt(1 + mat[0] - mat[4] - mat[8]);
+    quat[0] = 0.25 * (mat[7] - mat[5]) / quat[1];
+    quat[2] = 0.25 * (mat[1] + mat[3]) / quat[1];
+    quat[3] = 0.25 * (mat[2] + mat[6]) / quat[1];
+  } else if (mat[4] > mat[8]) {
+    quat[2] = 0.5 * sqrt(1 - mat[0] + mat[4] - mat[8]);
+    quat[0] = 0.25 * (mat[2] - mat[6]) / quat[2];
+    quat[1] = 0.25 * (mat[1] + mat[3]) / quat[2];
+    quat[3] = 0.25 * (mat[5] + mat[7]) / quat[2];
+  } else {
+    quat[3] = 0.5 * sqrt(1 - mat[0] - mat[4] + mat[8]);
+    quat[0] = 0.25 * (mat[3] - mat[1]) / quat[3];
+    quat[1] = 0.25 * (mat[2] + mat[6]) / quat[3];
+    quat[2] = 0.25 * (mat[5] + mat[7]) / quat[3];
+  }
+  normalize4(quat);
+}
+
+__device__ __forceinline__ void so3_apply(double *res, const double *quat, const double *vec) {
+  const double pv[4] = {0, vec[0], vec[1], vec[2]};
+  const double qi[4] = {quat[0], -quat[1], -quat[2], -quat[3]};
+  double t[4], r[4];
+  mul_quat(t, quat, pv);
+  mul_quat(r, t, qi);
+  res[0] = r[1]; res[1] = r[2]; res[2] = r[3];
+}
+
+__device__ __forceinline__ void quat2rpy(double *rpy, const double *q) {
+  rpy[0] = atan2(2 * (q[0] * q[1] + q[2] * q[3]), 1 - 2 * (q[1] * q[1] + q[2] * q[2]));
+  rpy[1] = asin(2 * (q[0] * q[2] - q[3] * q[1]));
+  rpy[2] = atan2(2 * (q[0] * q[3] + q[1] * q[2]), 1 - 2 * (q[2] * q[2] + q[3] * q[3]));
+}
+
+// One Jacobi rotation in the (P, Q) plane; literal indices keep A and V in registers.
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(double (&A)[6][6], double (&V)[6][6]) {
+  const double apq = A[P][Q];
+  if (apq == 0) return;
+  const double theta = (A[Q][Q] - A[P][P]) / (2 * apq);
+  const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+  const double c = 1 / sqrt(t * t + 1), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double akp = A[k][P], akq = A[k][Q];
+    A[k][P] = c * akp - s * akq;
+    A[k][Q] = s * akp + c * akq;
+    const double vkp = V[k][P], vkq = V[k][Q];
+    V[k][P] = c * vkp - s * vkq;
+    V[k][Q] = s * vkp + c * vkq;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double apk = A[P][k], aqk = A[Q][k];
+    A[P][k] = c * apk - s * aqk;
+    A[Q][k] = s * apk + c * aqk;
+  }
+  A[P][Q] = 0; A[Q][P] = 0;
+}
+
+// y = pinv(A) x for symmetric A (np.linalg.pinv semantics); A is destroyed.
+__device__ __forceinline__ void pinv_sym6_apply(double (&A)[6][6], const double *x, double *y) {
+  double V[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
+  for (int sweep = 0; sweep < 12; sweep++) {
+    jacobi_rotate<0, 1>(A, V); jacobi_rotate<0, 2>(A, V); jacobi_rotate<0, 3>(A, V);
+    jacobi_rotate<0, 4>(A, V); jacobi_rotate<0, 5>(A, V); jacobi_rotate<1, 2>(A, V);
+    jacobi_rotate<1, 3>(A, V); jacobi_rotate<1, 4>(A, V); jacobi_rotate<1, 5>(A, V);
+    jacobi_rotate<2, 3>(A, V); jacobi_rotate<2, 4>(A, V); jacobi_rotate<2, 5>(A, V);
+    jacobi_rotate<3, 4>(A, V); jacobi_rotate<3, 5>(A, V); jacobi_rotate<4, 5>(A, V);
+  }
+  double wmax = 0, inv[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) wmax = fabs(A[i][i]) > wmax ? fabs(A[i][i]) : wmax;
+#pragma unroll
+  for (int i = 0; i < 6; i++) inv[i] = (fabs(A[i][i]) > 1e-15 * wmax) ? 1 / A[i][i] : 0.0;
+  // P[i][j] = sum_k (V[i][k] inv[k]) V[j][k];  y[i] = sum_j P[i][j] x[j]   (the oracle's order)
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double yi = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double pij = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) pij = pij + (V[i][k] * inv[k]) * V[j][k];
+      yi = yi + pij * x[j];
+    }
+    y[i] = yi;
+  }
+}
+
+struct PoseChainOut {
+  double site_xpos[3], site_xmat[9];
+};
+
+// mj_kinematics along the chain.  q: this lane's qpos, q[k * qs].  jst (nullable): this lane's
+// [6][njoint] store (element (r, k) at jst[(r * nj + k) * js]) receiving xaxis (rows 0..2) and
+// xanchor (rows 3..5) of every chain joint.
+__device__ __forceinline__ void pose_chain(const int *__restrict__ pi, const double *__restrict__ pd,
+                                           const double *q, int qs, double *jst, int js,
+                                           PoseChainOut &out) {
+  const int nb = pi[PH_NBODY], nj = pi[PH_NJOINT];
+  double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  int ic = PH_SIZE, dc = 0, jk = 0;
+  for (int b = 0; b < nb; b++) {
+    const int njnt = pi[ic++];
+    double np[3], nq[4];
+    {
+      const double bpos[3] = {pd[dc], pd[dc + 1], pd[dc + 2]};
+      const double bquat[4] = {pd[dc + 3], pd[dc + 4], pd[dc + 5], pd[dc + 6]};
+      dc += 7;
+      mul_mat_vec3(np, R, bpos);
+      np[0] += p[0]; np[1] += p[1]; np[2] += p[2];
+      mul_quat(nq, qt, bquat);
+    }
+    for (int j = 0; j < njnt; j++, jk++) {
+      const int jtype = pi[ic], qadr = pi[ic + 1];
+      ic += 3;
+      const double jaxis[3] = {pd[dc], pd[dc + 1], pd[dc + 2]};
+      const double jpos[3] = {pd[dc + 3], pd[dc + 4], pd[dc + 5]};
+      const double dq = q[qadr * qs] - pd[dc + 6];
+      dc += 7;
+      double xaxis[3], xanchor[3];
+      rot_vec_quat(xaxis, jaxis, nq);
+      rot_vec_quat(xanchor, jpos, nq);
+      xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];
+      if (jst) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          jst[(r * nj + jk) * js] = xaxis[r];
+          jst[((3 + r) * nj + jk) * js] = xanchor[r];
+        }
+      }
+      if (jtype == JT_SLIDE) {
+        np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq;
+      } else {
+        double sn, cs, vec[3];
+        sincos_half(dq * 0.5, &sn, &cs);
+        const double qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};
+        mul_quat(nq, nq, qloc);
+        rot_vec_quat(vec, jpos, nq);
+        np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2];
+      }
+    }
+    normalize4(nq);
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = np[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) qt[k] = nq[k];
+    quat2mat(R, qt);
+  }
+  const double *tail = pd + pi[PH_OFF_TAIL];
+  const double spos[3] = {tail[PT_SITE_POS], tail[PT_SITE_POS + 1], tail[PT_SITE_POS + 2]};
+  const double squat[4] = {tail[PT_SITE_QUAT], tail[PT_SITE_QUAT + 1], tail[PT_SITE_QUAT + 2],
+                           tail[PT_SITE_QUAT + 3]};
+  double sp[3], sq[4];
+  mul_mat_vec3(sp, R, spos);
+  out.site_xpos[0] = sp[0] + p[0]; out.site_xpos[1] = sp[1] + p[1]; out.site_xpos[2] = sp[2] + p[2];
+  mul_quat(sq, qt, squat);
+  quat2mat(out.site_xmat, sq);
+}
+
+// _displacement_from_constraint (pose_constraint.py:93-123); also returns the site's world
+// quaternion (SO3.from_matrix) for the Jacobian's E_rpy.
+__device__ __forceinline__ void pose_displacement(const double *tail, const PoseChainOut &o, double *dx,
+                                                  double *qsite) {
+  const double cq[4] = {tail[PT_C_QUAT], tail[PT_C_QUAT + 1], tail[PT_C_QUAT + 2], tail[PT_C_QUAT + 3]};
+  double qc[4], t[3], rpy[3], d[6];
+  mat2quat(qsite, o.site_xmat);
+  mul_quat(qc, cq, qsite);
+  so3_apply(t, cq, o.site_xpos);
+  d[0] = t[0] + tail[PT_C_POS]; d[1] = t[1] + tail[PT_C_POS + 1]; d[2] = t[2] + tail[PT_C_POS + 2];
+  quat2rpy(rpy, qc);
+  d[3] = rpy[0]; d[4] = rpy[1]; d[5] = rpy[2];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double v = 0;
+    if (d[k] > tail[PT_HI + k]) v = d[k] - tail[PT_HI + k];
+    if (d[k] < tail[PT_LO + k]) v = d[k] - tail[PT_LO + k];
+    dx[k] = v;
+  }
+}
+
+__device__ __forceinline__ double norm6(const double *v) {
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) s = s + v[k] * v[k];
+  return sqrt(s);
+}
+
+}  // namespace mjpl

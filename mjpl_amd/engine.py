@@ -58,6 +58,15 @@ class Info(C.Structure):
         return d
 
 
+class PoseDesc(C.Structure):
+    _fields_ = [
+        ("site_body", C.c_int32), ("site_pos", C.c_double * 3), ("site_quat", C.c_double * 4),
+        ("c_quat", C.c_double * 4), ("c_pos", C.c_double * 3), ("lo", C.c_double * 6),
+        ("hi", C.c_double * 6), ("tolerance", C.c_double), ("q_step", C.c_double),
+        ("jnt_range", _F64P), ("max_iters", C.c_int32),
+    ]
+
+
 # every symbol include/mjpl_hip.h declares: (restype, argtypes)
 _VP = C.c_void_p
 ABI = {
@@ -86,6 +95,13 @@ ABI = {
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mjpl_time_configs_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.c_int32,
                                         C.POINTER(C.c_float)]),
+    "mjpl_pose_create": (C.c_int, [_VP, C.POINTER(PoseDesc), C.POINTER(_VP)]),
+    "mjpl_pose_destroy": (None, [_VP]),
+    "mjpl_pose_set_q_step": (C.c_int, [_VP, C.c_double]),
+    "mjpl_pose_apply": (C.c_int, [_VP, _F64P, _F64P, C.c_int64, _F64P, _U8P, _I32P]),
+    "mjpl_pose_valid": (C.c_int, [_VP, _F64P, C.c_int64, _U8P, _F64P, _F64P]),
+    "mjpl_pose_apply_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP]),
+    "mjpl_pose_valid_dev": (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, _VP]),
     "mjpl_device_count": (C.c_int, []),
     "mjpl_last_error": (C.c_char_p, []),
     "mjpl_version": (C.c_char_p, []),
@@ -290,3 +306,82 @@ class Engine:
         self._ok(self.lib.mjpl_time_configs_dev(self.h, dQ, n, layout, dvalid, iters,
                                                 ms.ctypes.data_as(C.POINTER(C.c_float))))
         return ms
+
+
+class PoseProjector:
+    """``mjpl_pose`` handle: batched PoseConstraint.valid_config / apply / site pose for one
+    (engine, site, constraint frame).  Rows are FULL qpos vectors [N, nq]."""
+
+    def __init__(self, eng: Engine, site: str, c_quat, c_pos, bounds, tolerance: float, q_step: float,
+                 max_iters: int = 1000):
+        self.eng = eng
+        model = eng.model
+        sid = model.site(site).id
+        d = PoseDesc()
+        d.site_body = int(model.site_bodyid[sid])
+        d.site_pos[:] = [float(x) for x in model.site_pos[sid]]
+        d.site_quat[:] = [float(x) for x in model.site_quat[sid]]
+        d.c_quat[:] = [float(x) for x in c_quat]
+        d.c_pos[:] = [float(x) for x in c_pos]
+        b = np.asarray(bounds, dtype=np.float64).reshape(6, 2)
+        d.lo[:] = [float(x) for x in b[:, 0]]
+        d.hi[:] = [float(x) for x in b[:, 1]]
+        d.tolerance, d.q_step, d.max_iters = float(tolerance), float(q_step), int(max_iters)
+        rng = _f64(model.jnt_range).reshape(-1)
+        d.jnt_range = rng.ctypes.data_as(_F64P)
+        self.h = None
+        h = _VP()
+        eng._ok(eng.lib.mjpl_pose_create(eng.h, C.byref(d), C.byref(h)))
+        self.h = h
+        self.nq = model.nq
+
+    def close(self):
+        if self.h and self.eng.h:
+            self.eng.lib.mjpl_pose_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_q_step(self, q_step: float):
+        self.eng._ok(self.eng.lib.mjpl_pose_set_q_step(self.h, float(q_step)))
+
+    def _rows(self, Q):
+        Q = _f64(Q)
+        if Q.ndim != 2 or Q.shape[1] != self.nq:
+            raise ValueError(f"expected rows of {self.nq} qpos values, got shape {Q.shape}")
+        return Q
+
+    def apply(self, Q_old, Q):
+        """-> (Q_projected [N, nq], ok bool[N], iters int32[N])"""
+        Q_old, Q = self._rows(Q_old), self._rows(Q)
+        if Q_old.shape != Q.shape:
+            raise ValueError("Q_old and Q must have the same shape")
+        n = len(Q)
+        out = np.empty_like(Q)
+        ok = np.zeros(n, np.uint8)
+        iters = np.zeros(n, np.int32)
+        self.eng._ok(self.eng.lib.mjpl_pose_apply(
+            self.h, Q_old.ctypes.data_as(_F64P), Q.ctypes.data_as(_F64P), n, out.ctypes.data_as(_F64P),
+            ok.ctypes.data_as(_U8P), iters.ctypes.data_as(_I32P)))
+        return out, ok.astype(bool), iters
+
+    def valid(self, Q, poses: bool = False):
+        """-> valid bool[N]  (and, with poses=True, site xpos [N, 3], xmat [N, 3, 3])"""
+        Q = self._rows(Q)
+        n = len(Q)
+        valid = np.zeros(n, np.uint8)
+        xpos = np.empty((n, 3)) if poses else None
+        xmat = np.empty((n, 9)) if poses else None
+        self.eng._ok(self.eng.lib.mjpl_pose_valid(
+            self.h, Q.ctypes.data_as(_F64P), n, valid.ctypes.data_as(_U8P),
+            xpos.ctypes.data_as(_F64P) if poses else None, xmat.ctypes.data_as(_F64P) if poses else None))
+        if poses:
+            return valid.astype(bool), xpos, xmat.reshape(n, 3, 3)
+        return valid.astype(bool)
+
+    def apply_dev(self, dQ_old, dQ, n, dQ_out, dok, diters=None):
+        self.eng._ok(self.eng.lib.mjpl_pose_apply_dev(self.h, dQ_old, dQ, n, dQ_out, dok, diters))

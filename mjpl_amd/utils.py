@@ -47,3 +47,19 @@ def random_config(model, q_init: np.ndarray, joints: list[str], seed: int | None
         out = apply_constraints(q_init, q, constraints)
         if out is not None:
             return out
+
+
+def site_pose(model, q: np.ndarray, site_name: str, engine=None):
+    """World pose of a site at configuration ``q`` as an :class:`mjpl_amd.lie.SE3` (reference
+    ``site_pose(data, site_name)``, :60-75; there is no MjData here, so the configuration is
+    passed instead of a data object).  FK runs on the GPU (``mjpl_pose_valid``)."""
+    from . import engine as _engine
+    from .lie import SE3, SO3
+    eng = engine if engine is not None else _engine.Engine(model)
+    inf = [(-np.inf, np.inf)] * 6
+    proj = _engine.PoseProjector(eng, site_name, [1.0, 0, 0, 0], [0.0, 0, 0], inf, 0.0, np.inf)
+    try:
+        _, xpos, xmat = proj.valid(np.asarray(q, dtype=np.float64)[None, :], poses=True)
+    finally:
+        proj.close()
+    return SE3.from_rotation_and_translation(SO3.from_matrix(xmat[0]), xpos[0])

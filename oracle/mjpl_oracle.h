@@ -129,6 +129,47 @@ int orc_pair_test(int32_t type1, const double *pos1, const double *mat1, const d
                   int32_t type2, const double *pos2, const double *mat2, const double *size2,
                   double margin);
 
+
+/* ------------------------------------------------------------------ row f1: PoseConstraint
+ * (src/mjpl/constraint/pose_constraint.py:11-171).  The SE3 / SO3 arithmetic of the reference
+ * lives in the un-vendored `mink >= 0.0.8` wheel (pyproject.toml:11) on top of mju_mat2Quat /
+ * mju_mulQuat, restated here from the published algorithms [MINK-recalled], [MJ-recalled];
+ * np.linalg.pinv of the 6x6 symmetric J J^T is restated as a cyclic-Jacobi eigen-decomposition
+ * with numpy's cutoff (eigenvalues <= 1e-15 * largest are dropped).  Pinned by the reference's
+ * own analytic test (test/test_pose_constraint.py:16-50) and by a numpy restatement that uses
+ * np.linalg.pinv itself (tests/test_pose_oracle.py); otherwise tolerance-level parity. */
+typedef struct orc_pose {
+  int32_t site_body;          /* model.site_bodyid[site]                         */
+  double  site_pos[3];        /* model.site_pos[site]                            */
+  double  site_quat[4];       /* model.site_quat[site]                           */
+  double  c_quat[4];          /* C_T_world = reference_frame.inverse(): rotation */
+  double  c_pos[3];           /*                                    translation  */
+  double  lo[6], hi[6];       /* x y z roll pitch yaw bounds (pose_constraint.py:57-59) */
+  double  tolerance, q_step;  /* :29-30                                          */
+  const double *jnt_range;    /* [njnt*2] JointLimitConstraint (joint_limit_constraint.py:16-17) */
+  int32_t max_iters;          /* the reference loops without a bound; the oracle gives up here   */
+} orc_pose;
+
+#define ORC_E_NOCONVERGE -6   /* orc_pose_apply ran max_iters projections */
+
+/* data.site(name).xpos / xmat after mj_kinematics (utils.site_pose, src/mjpl/utils.py:60-75) */
+int orc_site_pose(const orc_model *m, const orc_pose *p, const double *qpos, double *xpos, double *xmat);
+/* _displacement_from_constraint (pose_constraint.py:93-123) -> dx[6] */
+int orc_pose_displacement(const orc_model *m, const orc_pose *p, const double *qpos, double *dx);
+/* _get_jacobian (pose_constraint.py:125-147): E_rpy @ [jacp; jacr], row-major [6][njnt] */
+int orc_pose_jacobian(const orc_model *m, const orc_pose *p, const double *qpos, double *J);
+/* np.linalg.pinv of a symmetric 6x6 (row-major) */
+void orc_pinv_sym6(const double *A, double *out);
+/* PoseConstraint.valid_config (pose_constraint.py:72-76): 1/0, <0 error */
+int orc_pose_valid(const orc_model *m, const orc_pose *p, const double *qpos);
+/* PoseConstraint.apply (pose_constraint.py:78-91): 1 -> q_out holds the projection, 0 -> None,
+ * <0 error.  iters (nullable) receives the number of projection steps taken. */
+int orc_pose_apply(const orc_model *m, const orc_pose *p, const double *q_old, const double *q,
+                   double *q_out, int32_t *iters);
+/* batched apply over N rows of full-nq vectors [N][nq]; ok[i] = 1/0; status[i] as above */
+int orc_pose_apply_batch(const orc_model *m, const orc_pose *p, const double *Q_old, const double *Q,
+                         int64_t N, int32_t nthreads, double *Q_out, uint8_t *ok, int32_t *iters);
+
 #ifdef __cplusplus
 }
 #endif

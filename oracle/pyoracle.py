@@ -34,6 +34,15 @@ class _OrcModel(C.Structure):
     ]
 
 
+class _OrcPose(C.Structure):
+    _fields_ = [
+        ("site_body", C.c_int32), ("site_pos", C.c_double * 3), ("site_quat", C.c_double * 4),
+        ("c_quat", C.c_double * 4), ("c_pos", C.c_double * 3), ("lo", C.c_double * 6),
+        ("hi", C.c_double * 6), ("tolerance", C.c_double), ("q_step", C.c_double),
+        ("jnt_range", _F64P), ("max_iters", C.c_int32),
+    ]
+
+
 class _OrcBatch(C.Structure):
     _fields_ = [
         ("qpos_base", _F64P), ("qidx", _I32P), ("nplan", C.c_int32), ("layout", C.c_int32),
@@ -43,7 +52,8 @@ class _OrcBatch(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("mjpl_oracle.c", "mjpl_oracle.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f))
+                for f in ("mjpl_oracle.c", "mjpl_oracle_pose.c", "mjpl_oracle.h", "orc_math.h"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
         subprocess.run(["make", "-C", _HERE, "-B", "libmjpl_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
@@ -68,6 +78,10 @@ def lib():
         _lib.orc_valid_edges.restype = C.c_int
         _lib.orc_fk_batch.restype = C.c_int
         _lib.orc_pair_test.restype = C.c_int
+        for f in ("orc_site_pose", "orc_pose_displacement", "orc_pose_jacobian", "orc_pose_valid",
+                  "orc_pose_apply", "orc_pose_apply_batch"):
+            getattr(_lib, f).restype = C.c_int
+        _lib.orc_pinv_sym6.restype = None
     return _lib
 
 
@@ -238,3 +252,86 @@ def pair_test(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0) ->
     return lib().orc_pair_test(int(type1), _p(a[0], _F64P), _p(a[1], _F64P), _p(a[2], _F64P),
                                int(type2), _p(a[3], _F64P), _p(a[4], _F64P), _p(a[5], _F64P),
                                C.c_double(margin))
+
+
+def pinv_sym6(A) -> np.ndarray:
+    """The oracle's np.linalg.pinv for a symmetric 6x6."""
+    A = _f64(A).reshape(36)
+    out = np.empty(36)
+    lib().orc_pinv_sym6(_p(A, _F64P), _p(out, _F64P))
+    return out.reshape(6, 6)
+
+
+class PoseOracle:
+    """Float64 CPU restatement of PoseConstraint (pose_constraint.py:11-171) for one model,
+    site and constraint frame.  ``c_T_world`` is (wxyz[4], xyz[3]) of reference_frame.inverse()."""
+
+    def __init__(self, model, site: str, c_T_world, bounds, tolerance=0.001, q_step=0.05, max_iters=1000):
+        self.orc = Oracle(model)
+        self.model = model
+        sid = model.site(site).id
+        p = _OrcPose()
+        p.site_body = int(model.site_bodyid[sid])
+        p.site_pos[:] = list(map(float, model.site_pos[sid]))
+        p.site_quat[:] = list(map(float, model.site_quat[sid]))
+        cq, cp = c_T_world
+        p.c_quat[:] = list(map(float, cq))
+        p.c_pos[:] = list(map(float, cp))
+        b = np.asarray(bounds, dtype=np.float64).reshape(6, 2)
+        p.lo[:] = list(map(float, b[:, 0]))
+        p.hi[:] = list(map(float, b[:, 1]))
+        p.tolerance, p.q_step, p.max_iters = float(tolerance), float(q_step), int(max_iters)
+        self._rng = _f64(model.jnt_range).reshape(-1)
+        p.jnt_range = _p(self._rng, _F64P)
+        self._p = p
+
+    def set_q_step(self, q_step: float):
+        self._p.q_step = float(q_step)
+
+    def site_pose(self, q):
+        q = _f64(q)
+        pos, mat = np.empty(3), np.empty(9)
+        rc = lib().orc_site_pose(C.byref(self.orc._m), C.byref(self._p), _p(q, _F64P), _p(pos, _F64P), _p(mat, _F64P))
+        assert rc == 0, rc
+        return pos, mat.reshape(3, 3)
+
+    def displacement(self, q) -> np.ndarray:
+        q = _f64(q)
+        dx = np.empty(6)
+        rc = lib().orc_pose_displacement(C.byref(self.orc._m), C.byref(self._p), _p(q, _F64P), _p(dx, _F64P))
+        assert rc == 0, rc
+        return dx
+
+    def jacobian(self, q) -> np.ndarray:
+        q = _f64(q)
+        J = np.empty(6 * self.model.njnt)
+        rc = lib().orc_pose_jacobian(C.byref(self.orc._m), C.byref(self._p), _p(q, _F64P), _p(J, _F64P))
+        assert rc == 0, rc
+        return J.reshape(6, self.model.njnt)
+
+    def valid_config(self, q) -> bool:
+        q = _f64(q)
+        rc = lib().orc_pose_valid(C.byref(self.orc._m), C.byref(self._p), _p(q, _F64P))
+        assert rc >= 0, rc
+        return bool(rc)
+
+    def apply(self, q_old, q):
+        q_old, q = _f64(q_old), _f64(q)
+        out = np.empty_like(q)
+        it = C.c_int32(0)
+        rc = lib().orc_pose_apply(C.byref(self.orc._m), C.byref(self._p), _p(q_old, _F64P), _p(q, _F64P),
+                                  _p(out, _F64P), C.byref(it))
+        self.last_iters = it.value
+        return out if rc == 1 else None
+
+    def apply_batch(self, Q_old, Q, nthreads=1):
+        Q_old, Q = _f64(Q_old), _f64(Q)
+        n = len(Q)
+        out = np.empty_like(Q)
+        ok = np.zeros(n, np.uint8)
+        iters = np.zeros(n, np.int32)
+        rc = lib().orc_pose_apply_batch(C.byref(self.orc._m), C.byref(self._p), _p(Q_old, _F64P), _p(Q, _F64P),
+                                        C.c_int64(n), C.c_int32(nthreads), _p(out, _F64P),
+                                        ok.ctypes.data_as(C.POINTER(C.c_uint8)), _p(iters, _I32P))
+        assert rc == 0, rc
+        return out, ok.astype(bool), iters

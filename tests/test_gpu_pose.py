@@ -1,0 +1,135 @@
+"""Row f1 on the GPU: mjpl_amd.PoseConstraint (k_pose_apply / k_pose_valid through the C ABI)
+against the CPU oracle and the reference's analytic test (test/test_pose_constraint.py:16-50)."""
+import numpy as np
+import pytest
+
+import mjpl_amd as mjpl
+from mjpl_amd import scenes
+from mjpl_amd.lie import SE3, SO3
+
+pytestmark = pytest.mark.gpu
+INF = (-np.inf, np.inf)
+
+
+def test_translation_limit_kat_on_gpu():
+    m = scenes.two_dof_ball()
+    home = mjpl.site_pose(m, np.zeros(2), "ball_site")
+    pc = mjpl.PoseConstraint(m, "ball_site", home, x_translation=(-0.1, 0.1), q_step=np.inf)
+    q = np.array([0.2, 0.0])
+    assert not pc.valid_config(q)
+    qc = pc.apply(np.array([0.0, 0.0]), q)
+    assert qc is not None
+    np.testing.assert_allclose(qc, [0.1, 0.0], rtol=0, atol=1e-12)
+    assert pc.valid_config(qc)
+    pc.q_step = 1e-5
+    assert pc.apply(np.array([0.0, 0.0]), q) is None
+    with pytest.raises(ValueError, match="tolerance"):
+        mjpl.PoseConstraint(m, "ball_site", home, tolerance=-1.0, engine=pc.engine)
+    with pytest.raises(ValueError, match="q_step"):
+        mjpl.PoseConstraint(m, "ball_site", home, q_step=0.0, engine=pc.engine)
+    with pytest.raises(KeyError):
+        mjpl.PoseConstraint(m, "no_such_site", home, engine=pc.engine)
+
+
+def _setup(oracle_mod, scene):
+    if scene == "franka":
+        m, site = scenes.franka_p(obstacles=False), "ee_site"
+    else:
+        m, site = scenes.ur5e(), "attachment_site"
+    q_home = m.keyframe("home").qpos.copy()
+    kw = dict(z_translation=(-0.05, 0.05), roll=(-0.1, 0.1), pitch=(-0.1, 0.1), q_step=0.5)
+    eng = mjpl.engine.Engine(m)
+    frame = mjpl.site_pose(m, q_home, site, engine=eng)
+    pc = mjpl.PoseConstraint(m, site, frame, engine=eng, **kw)
+    inv = frame.inverse()
+    bounds = [INF, INF, kw["z_translation"], kw["roll"], kw["pitch"], INF]
+    po = oracle_mod.PoseOracle(m, site, (inv.wxyz_xyz[:4], inv.wxyz_xyz[4:]), bounds, q_step=0.5)
+    return m, q_home, pc, po
+
+
+@pytest.mark.parametrize("scene", ["franka", "ur5e"])
+def test_site_pose_and_validity_match_the_oracle(oracle_mod, scene):
+    m, q_home, pc, po = _setup(oracle_mod, scene)
+    rng = np.random.default_rng(11)
+    Q = rng.uniform(m.jnt_range[:, 0], m.jnt_range[:, 1], size=(512, m.nq))
+    Q[:128] = q_home + rng.normal(scale=0.01, size=(128, m.nq))
+    xpos, xmat = pc.site_poses(Q)
+    valid = pc.valid_configs(Q)
+    for i in range(len(Q)):
+        p, R = po.site_pose(Q[i])
+        np.testing.assert_allclose(xpos[i], p, atol=1e-13)
+        np.testing.assert_allclose(xmat[i], R, atol=1e-13)
+        assert bool(valid[i]) == po.valid_config(Q[i])
+    assert 0 < valid.sum() < len(Q)
+    home = pc.site_pose(q_home)
+    assert isinstance(home, SE3)
+    np.testing.assert_allclose(home.translation(), po.site_pose(q_home)[0], atol=1e-13)
+
+
+@pytest.mark.parametrize("scene", ["franka", "ur5e"])
+def test_batched_projection_matches_the_oracle(oracle_mod, scene):
+    m, q_home, pc, po = _setup(oracle_mod, scene)
+    rng = np.random.default_rng(12)
+    n = 4096
+    Q = np.clip(q_home + rng.normal(scale=0.06, size=(n, m.nq)), m.jnt_range[:, 0], m.jnt_range[:, 1])
+    Q_old = np.clip(q_home + rng.normal(scale=0.02, size=(n, m.nq)), m.jnt_range[:, 0], m.jnt_range[:, 1])
+    got, ok, iters = pc.apply_batch(Q_old, Q)
+    ref, rok, riters = po.apply_batch(Q_old, Q, nthreads=8)
+    # float64 on both sides with the same operation order; sin/cos/atan2/asin differ by an ulp
+    # between libm and the device library, which may flip a `<= tolerance` test in rare rows
+    same = (ok == rok) & (iters == riters)
+    assert same.mean() > 0.995, same.mean()
+    both = same & ok
+    assert both.sum() > n // 4
+    np.testing.assert_allclose(got[both], ref[both], rtol=0, atol=1e-9)
+    # rows that were rejected keep whatever iterate they stopped at on both sides
+    rej = same & ~ok
+    np.testing.assert_allclose(got[rej], ref[rej], rtol=0, atol=1e-9)
+    assert (iters[both] > 0).any()
+
+
+def test_projection_properties_at_config4_size():
+    """131 072 rows (config 4's 1 048 576 samples / 8 GPUs): every accepted row satisfies the
+    constraint, the joint limits and the 2*q_step bound; projecting a projected row is a no-op."""
+    m = scenes.franka_p(obstacles=False)
+    q_home = m.keyframe("home").qpos.copy()
+    eng = mjpl.engine.Engine(m)
+    frame = mjpl.site_pose(m, q_home, "ee_site", engine=eng)
+    pc = mjpl.PoseConstraint(m, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), engine=eng)
+    rng = np.random.default_rng(4)
+    n = 131072
+    lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+    Q_old = np.clip(q_home + rng.normal(scale=0.01, size=(n, m.nq)), lo, hi)
+    d = rng.normal(size=(n, m.nq))
+    d[:, 7:] = 0
+    Q = np.clip(Q_old + 0.05 * d / np.linalg.norm(d, axis=1, keepdims=True), lo, hi)
+    out, ok, iters = pc.apply_batch(Q_old, Q)
+    assert ok.mean() > 0.5
+    assert (iters >= 0).all()
+    assert pc.valid_configs(out[ok]).all()
+    assert np.all((out[ok] >= lo) & (out[ok] <= hi))
+    assert (np.linalg.norm(out[ok] - Q_old[ok], axis=1) <= 2 * pc.q_step + 1e-12).all()
+    again, ok2, it2 = pc.apply_batch(Q_old[ok], out[ok])
+    assert ok2.all() and (it2 == 0).all()
+    np.testing.assert_array_equal(again, out[ok])
+
+
+def test_constraint_composition_with_projection(oracle_mod):
+    """apply_constraints([pose, limits, collision]) (constraint/utils.py:22-43) with the
+    projecting constraint first, as in the reference's constrained example (:60-64)."""
+    m = scenes.franka_p(obstacles=True)
+    q_home = m.keyframe("home").qpos.copy()
+    eng = mjpl.engine.Engine(m)
+    frame = mjpl.site_pose(m, q_home, "ee_site", engine=eng)
+    pc = mjpl.PoseConstraint(m, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), engine=eng)
+    cons = [pc, mjpl.JointLimitConstraint(m), mjpl.CollisionConstraint(m)]
+    rng = np.random.default_rng(9)
+    accepted = 0
+    for _ in range(30):
+        q = q_home.copy()
+        q[:7] += rng.normal(scale=0.03, size=7)
+        out = mjpl.apply_constraints(q_home, q, cons)
+        if out is not None:
+            accepted += 1
+            assert mjpl.obeys_constraints(out, cons)
+    assert accepted >= 5
