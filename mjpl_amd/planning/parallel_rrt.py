@@ -8,9 +8,10 @@ per round with ONE all-gather of a fixed-size slab (RCCL over xGMI on GPUs, gloo
 tests).  Every rank appends the slabs in rank order, so all ranks hold bit-identical trees
 and node ids; the first connection in (rank, lane) order wins on every rank.
 
-Per-edge accept/stop rules are those of ``_constrained_extend`` for constraints that do not
-project (joint limits + collision): stop when the step is invalid, when it moves less than
-1e-8, when it does not approach the target, or when the interval check fails.
+Per-edge accept/stop rules are those of ``_constrained_extend``: the stepped configuration is
+first projected if the validator offers ``project`` (PoseConstraint, batched on the GPU), then
+the lane stops when the step is invalid, when it moves less than 1e-8, when it does not
+approach the target, or when the interval check fails.
 """
 from __future__ import annotations
 
@@ -33,14 +34,38 @@ class HipEdgeValidator(EdgeValidator):
     """mjpl_amd.CollisionConstraint behind the EdgeValidator interface; also offers the
     brute-force nearest-neighbour kernel (Tree.nearest_neighbor, planning/tree.py:57-66)."""
 
-    def __init__(self, constraint, qidx, qpos_base):
+    def __init__(self, constraint, qidx, qpos_base, pose_constraint=None):
         self.c = constraint
         self.c.set_planning(qidx, qpos_base)
+        self.qidx = np.asarray(qidx, dtype=np.int64)
+        self.qbase = np.asarray(qpos_base, dtype=np.float64).copy()
+        self.pose = pose_constraint
+        if pose_constraint is not None:
+            self.project = self._project  # the planner projects only if the attribute exists
 
     def valid_edges(self, QA, QB, step):
         if step is None:
-            return self.c.valid_configs_planning(QB)
+            ok = self.c.valid_configs_planning(QB)
+            if self.pose is not None and len(QB):
+                ok = ok & self.pose.valid_configs(self._full_rows(QB))
+            return ok
         return self.c.valid_edges_planning(QA, QB, step)
+
+    def _full_rows(self, Qp):
+        full = np.repeat(self.qbase[None, :], len(Qp), axis=0)
+        full[:, self.qidx] = Qp
+        return full
+
+    def _project(self, Q_old, Q):
+        """Batched PoseConstraint.apply over planning columns (the first constraint of
+        apply_constraints in the reference's constrained planning example,
+        franka_constrained_move_to_pose.py:60-64).  A projection that would move a joint
+        outside the planning set is rejected."""
+        out, ok, _ = self.pose.apply_batch(self._full_rows(Q_old), self._full_rows(Q))
+        fixed = np.ones(out.shape[1], bool)
+        fixed[self.qidx] = False
+        ok = ok & np.all(out[:, fixed] == self.qbase[None, fixed], axis=1)
+        return out[:, self.qidx], ok
 
     def nearest(self, nodes: np.ndarray, queries: np.ndarray) -> np.ndarray:
         """Index of the node nearest to each query (squared Euclidean distance in float64,
@@ -146,6 +171,7 @@ class ParallelBiRRT:
         cur = self.Q[near].copy()
         ref = near.copy()
         active = ~np.all(cur == targets, axis=1)
+        project = getattr(self.validator, "project", None)
         pend_index: dict[bytes, int] = {}
         while active.any():
             a = np.flatnonzero(active)
@@ -154,7 +180,11 @@ class ParallelBiRRT:
             q_new = cur[a] + d / dist[:, None] * np.minimum(self.eps, dist)[:, None]
             reach = np.all(q_new == targets[a], axis=1) | (dist <= self.eps)
             q_new[reach] = targets[a][reach]  # `_step` lands on the target within one step
-            ok = np.all((q_new >= self.lo) & (q_new <= self.hi), axis=1)
+            ok = np.ones(len(a), bool)
+            if project is not None:  # constraints that project come first (constraint/utils.py:30-31)
+                q_new, ok = project(cur[a], q_new)
+                reach = np.all(q_new == targets[a], axis=1)
+            ok &= np.all((q_new >= self.lo) & (q_new <= self.hi), axis=1)
             moved = _row_norm(q_new - cur[a])
             ok &= ~(moved < 1e-8)
             ok &= ~(_row_norm(targets[a] - q_new) > dist)

@@ -133,3 +133,31 @@ def test_constraint_composition_with_projection(oracle_mod):
             accepted += 1
             assert mjpl.obeys_constraints(out, cons)
     assert accepted >= 5
+
+
+def test_frontier_planner_with_pose_projection():
+    """Config-4 shape on one GPU: bi-RRT over [PoseConstraint(roll, pitch +-0.1), joint limits,
+    collision]; every node of the returned path satisfies all three."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    cc = mjpl.CollisionConstraint(m)
+    frame = mjpl.site_pose(m, q_init, "ee_site", engine=cc.engine)
+    pc = mjpl.PoseConstraint(m, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), engine=cc.engine)
+    cons = [pc, mjpl.JointLimitConstraint(m), cc]
+    pc.q_step = np.inf
+    q_goal = mjpl.random_config(m, q_init, joints, 7, cons)
+    pc.q_step = 0.05
+    v = mjpl.HipEdgeValidator(cc, qidx, q_init, pose_constraint=pc)
+    planner = mjpl.ParallelBiRRT(m, joints, v, q_init, epsilon=0.05, interval_step=0.01, seed=7, batch=256,
+                                 goal_biasing_probability=0.1, max_planning_time=120.0)
+    path = planner.plan_to_config(q_init, q_goal)
+    assert len(path) > 2, planner.stats
+    np.testing.assert_array_equal(path[0], q_init)
+    np.testing.assert_array_equal(path[-1], q_goal)
+    P = np.stack(path)
+    assert pc.valid_configs(P).all()
+    cc.set_planning(np.arange(m.nq), m.qpos0)
+    assert cc.valid_configs(P).all()
+    assert (np.linalg.norm(np.diff(P, axis=0), axis=1) <= 0.05 + 2 * 0.05 + 1e-9).all()

@@ -111,3 +111,60 @@ def test_world_size_two_gloo_ranks_agree():
     assert (r0, r1, w0, w1) == (0, 1, 2, 2)
     assert path0 == path1, "both ranks must return the same path"
     assert n0 == n1 and Q0 == Q1 and par0 == par1, "replicated trees must be bit-identical"
+
+
+def test_projecting_validator_on_the_cpu(oracle_mod):
+    """The planner's `project` hook (PoseConstraint first, constraint/utils.py:30-31) with the CPU
+    oracle's projection behind it: every node of the path satisfies the pose constraint."""
+    from mjpl_amd import scenes
+    from mjpl_amd.lie import SE3, SO3
+    from mjpl_amd.planning.parallel_rrt import EdgeValidator, ParallelBiRRT
+
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = np.asarray(scenes.planning_index(m, joints))
+    q_init = m.keyframe("home").qpos.copy()
+    ident = oracle_mod.PoseOracle(m, "ee_site", (np.array([1.0, 0, 0, 0]), np.zeros(3)), [(-np.inf, np.inf)] * 6)
+    pos, mat = ident.site_pose(q_init)
+    inv = SE3.from_rotation_and_translation(SO3.from_matrix(mat), pos).inverse()
+    inf = (-np.inf, np.inf)
+    po = oracle_mod.PoseOracle(m, "ee_site", (inv.wxyz_xyz[:4], inv.wxyz_xyz[4:]),
+                               [inf, inf, inf, (-0.1, 0.1), (-0.1, 0.1), inf], q_step=0.05)
+
+    class V(EdgeValidator):
+        def __init__(self):
+            self.o = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=q_init)
+
+        def full(self, Qp):
+            F = np.repeat(q_init[None], len(Qp), axis=0)
+            F[:, qidx] = Qp
+            return F
+
+        def valid_edges(self, QA, QB, step):
+            if step is None:
+                ok = self.o.valid_configs(QB, nthreads=2).astype(bool)
+                return ok & np.array([po.valid_config(r) for r in self.full(QB)], dtype=bool)
+            return self.o.valid_edges(QA, QB, step, nthreads=2).astype(bool)
+
+        def project(self, Q_old, Q):
+            out, ok, _ = po.apply_batch(self.full(Q_old), self.full(Q), nthreads=2)
+            return out[:, qidx], ok
+
+    v = V()
+    rng = np.random.default_rng(3)
+    while True:  # a goal on the constraint manifold: project a random configuration
+        g = q_init.copy()
+        g[qidx] = q_init[qidx] + rng.normal(scale=0.4, size=len(qidx))
+        po.set_q_step(np.inf)
+        gp = po.apply(q_init, g)
+        po.set_q_step(0.05)
+        if gp is not None and v.valid_edges(gp[qidx][None], gp[qidx][None], None)[0]:
+            break
+    p = ParallelBiRRT(m, joints, v, q_init, epsilon=0.05, interval_step=0.01, seed=2, batch=32,
+                      goal_biasing_probability=0.2, max_planning_time=120.0)
+    path = p.plan_to_config(q_init, gp)
+    assert len(path) > 2, p.stats
+    for q in path:
+        assert po.valid_config(q)
+    P = np.array(path)
+    assert v.o.valid_configs(P[:, qidx], nthreads=2).all()
