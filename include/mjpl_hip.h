@@ -239,6 +239,36 @@ int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQ_old, const double *dQ, in
                         uint8_t *dok, int32_t *diters);
 int mjpl_pose_valid_dev(mjpl_pose *p, const double *dQ, int64_t N, uint8_t *dvalid, double *dxpos, double *dxmat);
 
+/* ---- IK seeds (the role of MinkIKSolver.solve_ik,
+ * src/mjpl/inverse_kinematics/mink_ik_solver.py:72-116).  The reference's arithmetic is a QP in
+ * the un-vendored mink / daqp wheels; parity is tolerance-level (pose error within the
+ * tolerances, constraints obeyed -- what test/test_mink_ik_solver.py:64-70 asserts).  Every row
+ * of Q [N][nq] is one start configuration (q_init_guess or a random_config restart, :108-115)
+ * iterated with damped least squares; joints with movable[j] == 0 are held (:63-70). */
+typedef struct mjpl_ik_desc {
+  int32_t site_body;          /* model.site_bodyid[site]                                       */
+  double  site_pos[3];
+  double  site_quat[4];       /* wxyz                                                          */
+  double  target_pos[3];      /* pose: SE3 in the world frame (ik_solver_interface.py:13-19)   */
+  double  target_quat[4];     /* wxyz                                                          */
+  double  pos_tolerance;      /* mink_ik_solver.py:19 (metres)                                 */
+  double  ori_tolerance;      /* :20 (radians)                                                 */
+  int32_t iterations;         /* :23 iterations per attempt (>= 1)                             */
+  double  damping;            /* Tikhonov term (reference: damping=1e-3 of the QP, :106); <= 0 -> 1e-6 */
+  double  lm_damping;         /* error-proportional term (FrameTask lm_damping=0.1, :80); < 0 -> 0.1   */
+  double  max_step;           /* |dq|_inf limit per iteration, radians / metres; <= 0 -> 0.2   */
+  const double  *jnt_range;   /* [njnt*2] mink.ConfigurationLimit (:86)                        */
+  const uint8_t *movable;     /* [njnt] 1 for the solver's `joints`, 0 for held joints         */
+} mjpl_ik_desc;
+
+/* ok[i] = 1 iff row i reached the target within the tolerances; Q_out row i is its final
+ * iterate either way; iters (nullable) the iterations used; err (nullable) [N][2] the final
+ * position / orientation error norms. */
+int mjpl_ik_solve(mjpl_engine *e, const mjpl_ik_desc *desc, const double *Q, int64_t N, double *Q_out,
+                  uint8_t *ok, int32_t *iters, double *err);
+int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *desc, const double *dQ, int64_t N, double *dQ_out,
+                      uint8_t *dok, int32_t *diters, double *derr);
+
 #ifdef __cplusplus
 }
 #endif

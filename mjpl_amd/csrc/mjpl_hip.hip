@@ -558,6 +558,116 @@ k_pose_valid(const int *__restrict__ pi, const double *__restrict__ pd, const do
   }
 }
 
+
+// ---- row f3: batched IK seeds (the role of MinkIKSolver.solve_ik, mink_ik_solver.py:72-116) ----
+// One lane per seed: damped least squares on the 6-D world-frame pose error of the site,
+//   dq = J^T (J J^T + (damp + lm |e|^2) I)^-1 e,   |dq|_inf <= max_step,   q clamped to jnt_range,
+// joints outside the solver's joint set are held (their Jacobian columns are zero).  A seed is
+// solved when |e_pos| <= pos_tol and |e_ori| <= ori_tol (:100-102).
+__global__ void __launch_bounds__(kPoseBlock)
+k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Q,
+           int64_t N, double *__restrict__ Qout, uint8_t *__restrict__ ok, int32_t *__restrict__ iters,
+           double *__restrict__ err) {
+  extern __shared__ double smem[];
+  constexpr int B = kPoseBlock;
+  const int lane = threadIdx.x;
+  const int nq = pi[PH_NQ], nj = pi[PH_NJOINT], maxit = pi[PH_MAXIT];
+  const double *tail = pd + pi[PH_OFF_TAIL];
+  const double *jrange = pd + pi[PH_OFF_JRANGE];
+  const double *movable = jrange + 2 * nq;
+  double *qw = smem + lane;
+  double *jst = smem + (size_t)nq * B + lane;
+  const int64_t i = (int64_t)blockIdx.x * B + lane;
+  const bool active = i < N;
+  for (int k = 0; k < nq; k++) qw[k * B] = active ? Q[i * nq + k] : 0.0;
+  const double pos_tol = tail[IT_POS_TOL], ori_tol = tail[IT_ORI_TOL];
+  const double damp = tail[IT_DAMP], lm = tail[IT_LM], max_step = tail[IT_MAX_STEP];
+  bool done = !active, solved = false;
+  int it = 0;
+  double epos = 0, eori = 0;
+  while (__ballot(!done) != 0ull) {
+    if (!done) {
+      PoseChainOut o;
+      pose_chain(pi, pd, qw, B, jst, B, o);
+      double e[6];
+      ik_error(tail, o, e);
+      epos = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+      eori = sqrt(e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
+      if (epos <= pos_tol && eori <= ori_tol) {
+        done = true; solved = true;
+      } else if (it >= maxit) {
+        done = true;
+      } else {
+        const double lam = damp + lm * (epos * epos + eori * eori);
+        double A[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) A[r][c] = (r == c) ? lam : 0.0;
+        int ic = PH_SIZE, jk = 0;
+        for (int b = 0; b < pi[PH_NBODY]; b++) {
+          const int njnt = pi[ic++];
+          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
+            const int jtype = pi[ic], jid = pi[ic + 2];
+            const double mv = movable[jid];
+            const double ax[3] = {jst[(0 * nj + jk) * B], jst[(1 * nj + jk) * B], jst[(2 * nj + jk) * B]};
+            double col[6];
+            if (jtype == JT_HINGE) {
+              const double r[3] = {o.site_xpos[0] - jst[(3 * nj + jk) * B], o.site_xpos[1] - jst[(4 * nj + jk) * B],
+                                   o.site_xpos[2] - jst[(5 * nj + jk) * B]};
+              col[0] = mv * (ax[1] * r[2] - ax[2] * r[1]);
+              col[1] = mv * (ax[2] * r[0] - ax[0] * r[2]);
+              col[2] = mv * (ax[0] * r[1] - ax[1] * r[0]);
+              col[3] = mv * ax[0]; col[4] = mv * ax[1]; col[5] = mv * ax[2];
+            } else {
+              col[0] = mv * ax[0]; col[1] = mv * ax[1]; col[2] = mv * ax[2];
+              col[3] = 0; col[4] = 0; col[5] = 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) jst[(r * nj + jk) * B] = col[r];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+              for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
+          }
+        }
+        double y[6];
+        chol6_solve(A, e, y);
+        // step length limit over the whole update, then apply + clamp to the joint ranges
+        double big = 0;
+        for (int k = 0; k < nj; k++) {
+          double acc = 0;
+#pragma unroll
+          for (int r = 0; r < 6; r++) acc = acc + jst[(r * nj + k) * B] * y[r];
+          jst[k * B] = acc;  // row 0 of the store now holds dq of chain joint k
+          big = fabs(acc) > big ? fabs(acc) : big;
+        }
+        const double scale = big > max_step ? max_step / big : 1.0;
+        ic = PH_SIZE; jk = 0;
+        for (int b = 0; b < pi[PH_NBODY]; b++) {
+          const int njnt = pi[ic++];
+          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
+            const int qadr = pi[ic + 1], jid = pi[ic + 2];
+            double v = qw[qadr * B] + scale * jst[jk * B];
+            if (movable[jid] != 0.0) {
+              v = v < jrange[2 * jid] ? jrange[2 * jid] : v;
+              v = v > jrange[2 * jid + 1] ? jrange[2 * jid + 1] : v;
+              qw[qadr * B] = v;
+            }
+          }
+        }
+        it++;
+      }
+    }
+  }
+  if (active) {
+    for (int k = 0; k < nq; k++) Qout[i * nq + k] = qw[k * B];
+    ok[i] = solved ? 1 : 0;
+    if (iters) iters[i] = it;
+    if (err) { err[2 * i] = epos; err[2 * i + 1] = eori; }
+  }
+}
+
 // ------------------------------------------------------------------------------- host model
 
 struct HostModel {
@@ -1566,6 +1676,38 @@ int pose_check(const mjpl_pose *p, const void *a, int64_t n) {
 }
 }  // namespace
 
+namespace {
+// chain program shared by the pose and IK handles: per body {njnt}, per joint {type, qadr, jid}
+int build_chain(const HostModel &m, int site_body, std::vector<int> &pi, std::vector<double> &pd, int *nj) {
+  std::vector<int> chain;
+  for (int b = site_body; b > 0; b = m.body_parentid[b]) chain.push_back(b);
+  std::reverse(chain.begin(), chain.end());
+  pi.assign(PH_SIZE, 0);
+  *nj = 0;
+  for (int b : chain) {
+    pi.push_back(m.body_jntnum[b]);
+    for (int k = 0; k < 3; k++) pd.push_back(m.body_pos[3 * b + k]);
+    for (int k = 0; k < 4; k++) pd.push_back(m.body_quat[4 * b + k]);
+    for (int j = 0; j < m.body_jntnum[b]; j++) {
+      const int jid = m.body_jntadr[b] + j;
+      if (m.jnt_type[jid] != JT_SLIDE && m.jnt_type[jid] != JT_HINGE)
+        return fail(MJPL_E_JOINT, "joint %d: only slide and hinge joints are supported", jid);
+      pi.push_back(m.jnt_type[jid]);
+      pi.push_back(m.jnt_qposadr[jid]);
+      pi.push_back(jid);
+      for (int k = 0; k < 3; k++) pd.push_back(m.jnt_axis[3 * jid + k]);
+      for (int k = 0; k < 3; k++) pd.push_back(m.jnt_pos[3 * jid + k]);
+      pd.push_back(m.qpos0[m.jnt_qposadr[jid]]);
+      (*nj)++;
+    }
+  }
+  pi[PH_NBODY] = (int)chain.size();
+  pi[PH_NJOINT] = *nj;
+  pi[PH_NQ] = m.nq;
+  return MJPL_OK;
+}
+}  // namespace
+
 int mjpl_pose_create(mjpl_engine *e, const mjpl_pose_desc *d, mjpl_pose **out) {
   if (!e || !d || !out) return fail(MJPL_E_ARG, "mjpl_pose_create: NULL argument");
   const HostModel &m = e->m;
@@ -1574,33 +1716,11 @@ int mjpl_pose_create(mjpl_engine *e, const mjpl_pose_desc *d, mjpl_pose **out) {
   if (d->tolerance < 0.0) return fail(MJPL_E_ARG, "`tolerance` must be >= 0.");
   if (!(d->q_step > 0.0)) return fail(MJPL_E_ARG, "`q_step` must be > 0.");
   if (m.nq != m.njnt) return fail(MJPL_E_JOINT, "pose projection needs 1-DoF joints only (nq %d != njnt %d)", m.nq, m.njnt);
-  std::vector<int> chain;
-  for (int b = d->site_body; b > 0; b = m.body_parentid[b]) chain.push_back(b);
-  std::reverse(chain.begin(), chain.end());
   auto p = std::make_unique<mjpl_pose>();
   p->e = e;
   p->nq = m.nq;
-  p->pi.assign(PH_SIZE, 0);
-  for (int b : chain) {
-    p->pi.push_back(m.body_jntnum[b]);
-    for (int k = 0; k < 3; k++) p->pd.push_back(m.body_pos[3 * b + k]);
-    for (int k = 0; k < 4; k++) p->pd.push_back(m.body_quat[4 * b + k]);
-    for (int j = 0; j < m.body_jntnum[b]; j++) {
-      const int jid = m.body_jntadr[b] + j;
-      if (m.jnt_type[jid] != JT_SLIDE && m.jnt_type[jid] != JT_HINGE)
-        return fail(MJPL_E_JOINT, "joint %d: only slide and hinge joints are supported", jid);
-      p->pi.push_back(m.jnt_type[jid]);
-      p->pi.push_back(m.jnt_qposadr[jid]);
-      p->pi.push_back(jid);
-      for (int k = 0; k < 3; k++) p->pd.push_back(m.jnt_axis[3 * jid + k]);
-      for (int k = 0; k < 3; k++) p->pd.push_back(m.jnt_pos[3 * jid + k]);
-      p->pd.push_back(m.qpos0[m.jnt_qposadr[jid]]);
-      p->nj++;
-    }
-  }
-  p->pi[PH_NBODY] = (int)chain.size();
-  p->pi[PH_NJOINT] = p->nj;
-  p->pi[PH_NQ] = m.nq;
+  int rc = build_chain(m, d->site_body, p->pi, p->pd, &p->nj);
+  if (rc != MJPL_OK) return rc;
   p->pi[PH_MAXIT] = d->max_iters > 0 ? d->max_iters : 1000;
   p->pi[PH_OFF_TAIL] = (int)p->pd.size();
   p->pd.resize(p->pd.size() + PT_SIZE);
@@ -1712,6 +1832,83 @@ int mjpl_pose_valid(mjpl_pose *p, const double *Q, int64_t N, uint8_t *valid, do
   if (valid) HIP_TRY(hipMemcpyAsync(valid, e->stage[2], (size_t)N, hipMemcpyDeviceToHost, e->stream));
   if (xpos) HIP_TRY(hipMemcpyAsync(xpos, e->stage[4], (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   if (xmat) HIP_TRY(hipMemcpyAsync(xmat, e->stage[5], (size_t)N * 9 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MJPL_OK;
+}
+
+// ---- row f3: IK seeds ------------------------------------------------------------------------
+
+
+int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, int64_t N, double *dQout,
+                      uint8_t *dok, int32_t *diters, double *derr) {
+  if (!e || !d) return fail(MJPL_E_ARG, "mjpl_ik_solve: NULL argument");
+  if (N < 0) return fail(MJPL_E_ARG, "negative batch size");
+  if (N == 0) return MJPL_OK;
+  if (!dQ || !dQout || !dok) return fail(MJPL_E_ARG, "NULL pointer");
+  const HostModel &m = e->m;
+  if (d->site_body < 0 || d->site_body >= m.nbody) return fail(MJPL_E_ARG, "site body %d out of range", d->site_body);
+  if (!d->jnt_range || !d->movable) return fail(MJPL_E_ARG, "jnt_range / movable is NULL");
+  if (d->iterations < 1) return fail(MJPL_E_ARG, "`iterations` must be > 0.");
+  if (m.nq != m.njnt) return fail(MJPL_E_JOINT, "IK needs 1-DoF joints only (nq %d != njnt %d)", m.nq, m.njnt);
+  std::vector<int> pi;
+  std::vector<double> pd;
+  int nj = 0;
+  int rc = build_chain(m, d->site_body, pi, pd, &nj);
+  if (rc != MJPL_OK) return rc;
+  pi[PH_MAXIT] = d->iterations;
+  pi[PH_OFF_TAIL] = (int)pd.size();
+  pd.resize(pd.size() + IT_SIZE);
+  double *t = pd.data() + pi[PH_OFF_TAIL];
+  for (int k = 0; k < 3; k++) { t[IT_SITE_POS + k] = d->site_pos[k]; t[IT_TGT_POS + k] = d->target_pos[k]; }
+  for (int k = 0; k < 4; k++) { t[IT_SITE_QUAT + k] = d->site_quat[k]; t[IT_TGT_QUAT + k] = d->target_quat[k]; }
+  t[IT_POS_TOL] = d->pos_tolerance;
+  t[IT_ORI_TOL] = d->ori_tolerance;
+  t[IT_DAMP] = d->damping > 0 ? d->damping : 1e-6;
+  t[IT_LM] = d->lm_damping >= 0 ? d->lm_damping : 0.1;
+  t[IT_MAX_STEP] = d->max_step > 0 ? d->max_step : 0.2;
+  pi[PH_OFF_JRANGE] = (int)pd.size();
+  for (int k = 0; k < 2 * m.njnt; k++) pd.push_back(d->jnt_range[k]);
+  for (int k = 0; k < m.njnt; k++) pd.push_back(d->movable[k] ? 1.0 : 0.0);
+  const size_t lds = (size_t)kPoseBlock * sizeof(double) * ((size_t)m.nq + 6 * (size_t)nj);
+  if (lds > 64 * 1024) return fail(MJPL_E_CAPACITY, "IK: %d qpos + %d chain joints exceed the LDS budget", m.nq, nj);
+  HIP_TRY(hipSetDevice(e->device));
+  // the program is tiny and changes with every target: staged through the engine's scratch
+  const size_t ib = pi.size() * sizeof(int), db = pd.size() * sizeof(double);
+  if ((rc = stage_reserve(e, 5, ((ib + 7) & ~(size_t)7) + db)) != MJPL_OK) return rc;
+  int *d_pi = (int *)e->stage[5];
+  double *d_pd = (double *)((char *)e->stage[5] + ((ib + 7) & ~(size_t)7));
+  HIP_TRY(hipStreamSynchronize(e->stream));  // pageable host vectors go out of scope on return
+  HIP_TRY(hipMemcpy(d_pi, pi.data(), ib, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_pd, pd.data(), db, hipMemcpyHostToDevice));
+  const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
+  hipLaunchKernelGGL(k_ik_solve, dim3(grid), dim3(kPoseBlock), lds, e->stream, d_pi, d_pd, dQ, N, dQout, dok,
+                     diters, derr);
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+
+int mjpl_ik_solve(mjpl_engine *e, const mjpl_ik_desc *d, const double *Q, int64_t N, double *Q_out,
+                  uint8_t *ok, int32_t *iters, double *err) {
+  if (!e || !d) return fail(MJPL_E_ARG, "mjpl_ik_solve: NULL argument");
+  if (N < 0) return fail(MJPL_E_ARG, "negative batch size");
+  if (N == 0) return MJPL_OK;
+  if (!Q || !Q_out || !ok) return fail(MJPL_E_ARG, "NULL pointer");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t qb = (size_t)N * e->m.nq * sizeof(double);
+  int rc;
+  if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 1, qb)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 2, (size_t)N)) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 3, (size_t)N * sizeof(int32_t))) != MJPL_OK) return rc;
+  if ((rc = stage_reserve(e, 4, (size_t)N * 2 * sizeof(double))) != MJPL_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(e->stage[0], Q, qb, hipMemcpyHostToDevice, e->stream));
+  if ((rc = mjpl_ik_solve_dev(e, d, (const double *)e->stage[0], N, (double *)e->stage[1], (uint8_t *)e->stage[2],
+                              (int32_t *)e->stage[3], (double *)e->stage[4])) != MJPL_OK)
+    return rc;
+  HIP_TRY(hipMemcpyAsync(Q_out, e->stage[1], qb, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(ok, e->stage[2], (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, e->stage[3], (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  if (err) HIP_TRY(hipMemcpyAsync(err, e->stage[4], (size_t)N * 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MJPL_OK;
 }

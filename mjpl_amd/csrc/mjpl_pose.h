@@ -220,4 +220,64 @@ __device__ __forceinline__ double norm6(const double *v) {
   return sqrt(s);
 }
 
+// ---- row f3: batched damped-least-squares IK seeds -----------------------------------------
+// IK tail (doubles at PH_OFF_TAIL of an IK program): site pose offsets as above, then
+enum : int { IT_SITE_POS = 0, IT_SITE_QUAT = 3, IT_TGT_POS = 7, IT_TGT_QUAT = 10, IT_POS_TOL = 14,
+             IT_ORI_TOL = 15, IT_DAMP = 16, IT_LM = 17, IT_MAX_STEP = 18, IT_SIZE = 19 };
+// ... followed at PH_OFF_JRANGE by jnt_range[njnt][2] and then movable[njnt] (1.0 / 0.0)
+
+// Solve (A) y = b for a symmetric positive definite 6x6 by an unrolled Cholesky factorisation.
+__device__ __forceinline__ void chol6_solve(double (&A)[6][6], const double *b, double *y) {
+  double L[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d = d - L[j][k] * L[j][k];
+    d = sqrt(d > 1e-300 ? d : 1e-300);
+    L[j][j] = d;
+    const double inv = 1 / d;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v = v - L[i][k] * L[j][k];
+      L[i][j] = v * inv;
+    }
+  }
+  double z[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) v = v - L[i][k] * z[k];
+    z[i] = v / L[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double v = z[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) v = v - L[k][i] * y[k];
+    y[i] = v / L[i][i];
+  }
+}
+
+// world-frame pose error of the site against the target: e[0..2] = p_t - p,
+// e[3..5] = rotation vector of R_t R^T (quaternion logarithm, shortest way round)
+__device__ __forceinline__ void ik_error(const double *tail, const PoseChainOut &o, double *e) {
+  double qs[4], qe[4];
+  mat2quat(qs, o.site_xmat);
+  const double qt[4] = {tail[IT_TGT_QUAT], tail[IT_TGT_QUAT + 1], tail[IT_TGT_QUAT + 2], tail[IT_TGT_QUAT + 3]};
+  const double qc[4] = {qs[0], -qs[1], -qs[2], -qs[3]};
+  mul_quat(qe, qt, qc);
+  const double sgn = qe[0] < 0 ? -1.0 : 1.0;
+  const double w = sgn * qe[0], v[3] = {sgn * qe[1], sgn * qe[2], sgn * qe[3]};
+  const double sn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const double k = sn > 1e-12 ? 2 * atan2(sn, w) / sn : 2.0;
+  e[0] = tail[IT_TGT_POS] - o.site_xpos[0];
+  e[1] = tail[IT_TGT_POS + 1] - o.site_xpos[1];
+  e[2] = tail[IT_TGT_POS + 2] - o.site_xpos[2];
+  e[3] = k * v[0]; e[4] = k * v[1]; e[5] = k * v[2];
+}
+
 }  // namespace mjpl

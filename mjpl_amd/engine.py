@@ -67,6 +67,15 @@ class PoseDesc(C.Structure):
     ]
 
 
+class IKDesc(C.Structure):
+    _fields_ = [
+        ("site_body", C.c_int32), ("site_pos", C.c_double * 3), ("site_quat", C.c_double * 4),
+        ("target_pos", C.c_double * 3), ("target_quat", C.c_double * 4), ("pos_tolerance", C.c_double),
+        ("ori_tolerance", C.c_double), ("iterations", C.c_int32), ("damping", C.c_double),
+        ("lm_damping", C.c_double), ("max_step", C.c_double), ("jnt_range", _F64P), ("movable", _U8P),
+    ]
+
+
 # every symbol include/mjpl_hip.h declares: (restype, argtypes)
 _VP = C.c_void_p
 ABI = {
@@ -102,6 +111,8 @@ ABI = {
     "mjpl_pose_valid": (C.c_int, [_VP, _F64P, C.c_int64, _U8P, _F64P, _F64P]),
     "mjpl_pose_apply_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP]),
     "mjpl_pose_valid_dev": (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, _VP]),
+    "mjpl_ik_solve": (C.c_int, [_VP, C.POINTER(IKDesc), _F64P, C.c_int64, _F64P, _U8P, _I32P, _F64P]),
+    "mjpl_ik_solve_dev": (C.c_int, [_VP, C.POINTER(IKDesc), _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     "mjpl_device_count": (C.c_int, []),
     "mjpl_last_error": (C.c_char_p, []),
     "mjpl_version": (C.c_char_p, []),
@@ -300,6 +311,39 @@ class Engine:
         self._ok(self.lib.mjpl_time_edges_dev(self.h, dQA, dQB, n, float(step_dist), layout, dvalid,
                                               iters, ms.ctypes.data_as(fp), ms1.ctypes.data_as(fp)))
         return (ms, ms1) if first_kernel else ms
+
+    def ik_solve(self, site: str, target_pos, target_quat, Q, movable, pos_tolerance=1e-3,
+                 ori_tolerance=1e-3, iterations=500, damping=0.0, lm_damping=-1.0, max_step=0.0):
+        """Batched damped-least-squares IK: rows of Q [N, nq] are start configurations.
+        -> (Q_out [N, nq], ok bool[N], iters int32[N], err [N, 2])"""
+        model = self.model
+        sid = model.site(site).id
+        d = IKDesc()
+        d.site_body = int(model.site_bodyid[sid])
+        d.site_pos[:] = [float(x) for x in model.site_pos[sid]]
+        d.site_quat[:] = [float(x) for x in model.site_quat[sid]]
+        d.target_pos[:] = [float(x) for x in target_pos]
+        d.target_quat[:] = [float(x) for x in target_quat]
+        d.pos_tolerance, d.ori_tolerance, d.iterations = float(pos_tolerance), float(ori_tolerance), int(iterations)
+        d.damping, d.lm_damping, d.max_step = float(damping), float(lm_damping), float(max_step)
+        rng = _f64(model.jnt_range).reshape(-1)
+        mv = np.ascontiguousarray(movable, dtype=np.uint8)
+        if mv.shape != (model.njnt,):
+            raise ValueError("`movable` must have one entry per joint")
+        d.jnt_range = rng.ctypes.data_as(_F64P)
+        d.movable = mv.ctypes.data_as(_U8P)
+        Q = _f64(Q)
+        if Q.ndim != 2 or Q.shape[1] != model.nq:
+            raise ValueError(f"expected rows of {model.nq} qpos values, got shape {Q.shape}")
+        n = len(Q)
+        out = np.empty_like(Q)
+        ok = np.zeros(n, np.uint8)
+        iters = np.zeros(n, np.int32)
+        err = np.zeros((n, 2))
+        self._ok(self.lib.mjpl_ik_solve(self.h, C.byref(d), Q.ctypes.data_as(_F64P), n, out.ctypes.data_as(_F64P),
+                                        ok.ctypes.data_as(_U8P), iters.ctypes.data_as(_I32P),
+                                        err.ctypes.data_as(_F64P)))
+        return out, ok.astype(bool), iters, err
 
     def time_configs_dev(self, dQ, n, layout, dvalid, iters) -> np.ndarray:
         ms = np.zeros(iters, np.float32)

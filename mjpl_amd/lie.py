@@ -107,6 +107,24 @@ class SO3:
         padded = np.concatenate([np.zeros(1), t])
         return _mul_quat(_mul_quat(self.wxyz, padded), self.inverse().wxyz)[1:]
 
+    @staticmethod
+    def exp(tangent) -> "SO3":
+        """Rotation vector -> rotation."""
+        w = np.asarray(tangent, dtype=np.float64)
+        theta = float(np.linalg.norm(w))
+        if theta < 1e-10:
+            q = np.concatenate([[1.0], 0.5 * w])
+            return SO3(q / np.linalg.norm(q))
+        return SO3(np.concatenate([[np.cos(theta / 2)], np.sin(theta / 2) * w / theta]))
+
+    def log(self) -> np.ndarray:
+        """Rotation vector of the shortest rotation."""
+        q = self.wxyz if self.wxyz[0] >= 0 else -self.wxyz
+        s = float(np.linalg.norm(q[1:]))
+        if s < 1e-12:
+            return 2.0 * q[1:]
+        return 2.0 * np.arctan2(s, q[0]) / s * q[1:]
+
 
 class SE3:
     def __init__(self, wxyz_xyz):
@@ -145,6 +163,36 @@ class SE3:
             self.rotation().apply(other.translation()) + self.translation())
 
     __matmul__ = multiply
+
+    @staticmethod
+    def _V(w: np.ndarray):
+        """Left Jacobian of SO(3) at rotation vector w (couples translation in exp / log)."""
+        theta = float(np.linalg.norm(w))
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        if theta < 1e-6:
+            return np.eye(3) + 0.5 * K + K @ K / 6.0
+        return (np.eye(3) + (1 - np.cos(theta)) / theta ** 2 * K
+                + (theta - np.sin(theta)) / theta ** 3 * K @ K)
+
+    @staticmethod
+    def exp(tangent) -> "SE3":
+        """se(3) tangent (v[3], w[3]) -> pose."""
+        t = np.asarray(tangent, dtype=np.float64)
+        return SE3.from_rotation_and_translation(SO3.exp(t[3:]), SE3._V(t[3:]) @ t[:3])
+
+    def log(self) -> np.ndarray:
+        w = self.rotation().log()
+        return np.concatenate([np.linalg.solve(SE3._V(w), self.translation()), w])
+
+    def minus(self, other: "SE3") -> np.ndarray:
+        """Right-minus: log(other^-1 @ self), the tangent that takes ``other`` to ``self``."""
+        return other.inverse().multiply(self).log()
+
+    def interpolate(self, other: "SE3", alpha: float = 0.5) -> "SE3":
+        """``self @ exp(alpha * log(self^-1 @ other))``, alpha in [0, 1]."""
+        if alpha < 0.0 or alpha > 1.0:
+            raise ValueError(f"Expected alpha within [0.0, 1.0] but received {alpha}")
+        return self.multiply(SE3.exp(alpha * other.minus(self)))
 
     def __repr__(self) -> str:
         return f"SE3(wxyz={self.wxyz_xyz[:4]}, xyz={self.wxyz_xyz[4:]})"

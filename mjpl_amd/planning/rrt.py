@@ -43,10 +43,10 @@ class RRT:
         return self.plan_to_poses(q_init, [pose], site, solver)
 
     def plan_to_poses(self, q_init, poses, site: str, solver=None) -> list[np.ndarray]:
-        if solver is None:
-            raise NotImplementedError(
-                "plan_to_pose(s) needs an IKSolver (`solver.solve_ik(pose, site, q_init_guess)`); "
-                "the reference's default MinkIKSolver is outside this package's scope")
+        if solver is None:  # rrt.py:130-136 builds a MinkIKSolver with these arguments
+            from ..inverse_kinematics import HipIKSolver
+            solver = HipIKSolver(model=self.model, joints=self.planning_joints, constraints=self.constraints,
+                                 seed=self.seed, max_attempts=5)
         goals = [q for p in poses for q in solver.solve_ik(p, site, q_init_guess=q_init)
                  if obeys_constraints(q, self.constraints)]
         return [] if not goals else self.plan_to_configs(q_init, goals)

@@ -196,8 +196,12 @@ def test_rrt_argument_validation(two_dof):
         planner.plan_to_config(np.array([0.0, 0.0]), np.array([0.6, 0.0]))
     with pytest.raises(ValueError, match="outside of the planner's planning joints"):
         planner.plan_to_config(np.array([0.0, 0.0]), np.array([0.2, 0.3]))
-    with pytest.raises(NotImplementedError):
-        planner.plan_to_pose(np.array([0.0, 0.0]), None, "ball_site")
+
+    class NoSolution(mjpl.IKSolver):  # plan_to_poses with a caller-supplied solver (rrt.py:113-145)
+        def solve_ik(self, pose, site, q_init_guess):
+            return []
+
+    assert planner.plan_to_pose(np.array([0.0, 0.0]), None, "ball_site", solver=NoSolution()) == []
 
 
 # ---- utils (test/test_utils.py, test/test_joint_limit_constraint.py)

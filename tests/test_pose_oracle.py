@@ -171,3 +171,65 @@ def test_rotation_limit_like_the_reference(oracle_mod):
             break
     assert done >= 3
     assert np.isfinite([init_rpy.roll, init_rpy.pitch, init_rpy.yaw]).all()
+
+
+def test_se3_exp_log_minus_interpolate():
+    rng = np.random.default_rng(2)
+    for _ in range(30):
+        a = SE3.from_rotation_and_translation(
+            SO3.from_matrix(Rotation.random(random_state=rng.integers(1 << 30)).as_matrix()), rng.normal(size=3))
+        b = SE3.from_rotation_and_translation(
+            SO3.from_matrix(Rotation.random(random_state=rng.integers(1 << 30)).as_matrix()), rng.normal(size=3))
+        d = b.minus(a)
+        c = a.multiply(SE3.exp(d))
+        np.testing.assert_allclose(c.translation(), b.translation(), atol=1e-12)
+        np.testing.assert_allclose(c.rotation().as_matrix(), b.rotation().as_matrix(), atol=1e-12)
+        np.testing.assert_allclose(SE3.exp(d).log(), d, atol=1e-12)
+        mid = a.interpolate(b, 0.5)
+        np.testing.assert_allclose(mid.minus(a), 0.5 * d, atol=1e-12)
+        w = rng.normal(size=3)
+        np.testing.assert_allclose(SO3.exp(w).as_matrix(), Rotation.from_rotvec(w).as_matrix(), atol=1e-13)
+    with pytest.raises(ValueError):
+        a.interpolate(b, 1.5)
+
+
+def test_cartesian_plan_host_logic():
+    """cartesian_planner.py:11-104 with a scripted solver: interpolation counts, the
+    closest-candidate pick, the empty result, the argument checks."""
+    from mjpl_amd.constraint import Constraint
+    from mjpl_amd.inverse_kinematics import IKSolver
+    from mjpl_amd.planning.cartesian_planner import _interpolate_poses, cartesian_plan
+
+    a = SE3.from_translation([0.0, 0.0, 0.0])
+    b = SE3.from_rotation_and_translation(SO3.from_rpy_radians(0.0, 0.0, 0.25), [0.035, 0.0, 0.0])
+    poses = _interpolate_poses(a, b, 0.01, 0.1)
+    assert len(poses) == 5  # max(ceil(.035/.01)=4, ceil(.25/.1)=3) steps
+    np.testing.assert_allclose(poses[0].wxyz_xyz, a.wxyz_xyz, atol=1e-15)
+    np.testing.assert_allclose(poses[-1].wxyz_xyz, b.wxyz_xyz, atol=1e-12)
+    assert len(_interpolate_poses(a, a, 0.01, 0.1)) == 2
+    with pytest.raises(ValueError, match="lin_threshold"):
+        _interpolate_poses(a, b, 0.0, 0.1)
+    with pytest.raises(ValueError, match="ori_threshold"):
+        _interpolate_poses(a, b, 0.01, -1.0)
+
+    class Line(IKSolver):  # "IK" of a point robot: q = x, two candidates per pose
+        def solve_ik(self, pose, site, q_init_guess):
+            x = pose.translation()[0]
+            return [np.array([x + 0.5]), np.array([x])]
+
+    class Below(Constraint):
+        def __init__(self, limit):
+            self.limit = limit
+
+        def valid_config(self, q):
+            return bool(q[0] <= self.limit)
+
+        def apply(self, q_old, q):
+            return q if self.valid_config(q) else None
+
+    far = SE3.from_translation([0.03, 0.0, 0.0])
+    wps = cartesian_plan(np.array([0.0]), [a, far], "s", Line(), [Below(1.0)])
+    np.testing.assert_allclose(np.array(wps).ravel(), [0.0, 0.0, 0.01, 0.02, 0.03], atol=1e-12)
+    assert cartesian_plan(np.array([0.0]), [a, far], "s", Line(), [Below(0.015)]) == []
+    with pytest.raises(ValueError, match="site"):
+        cartesian_plan(np.array([0.0]), [a, far], "", Line(), [])
