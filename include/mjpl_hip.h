@@ -129,6 +129,11 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out);
 int mjpl_set_filter(mjpl_engine *e, int32_t enable, double tol);
 /* how many items of the most recent launch went to the float64 kernel (synchronises) */
 int64_t mjpl_filter_last_undecided(mjpl_engine *e);
+/* The filter validates edges in two passes: the endpoints of all edges, then the interior
+ * waypoints of the edges whose endpoint passed (MJPL_TWO_PASS=0 at create: one pass).  Returns how
+ * many edges the interior pass of the most recent mjpl_check_edges* took (synchronises); 0 for a
+ * one-pass launch, -1 if the filter is off. */
+int64_t mjpl_filter_last_interior_edges(mjpl_engine *e);
 
 /* ---- host-buffer entry points (stage H2D, run, copy back, synchronise) ---------- */
 

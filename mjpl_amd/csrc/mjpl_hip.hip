@@ -360,9 +360,80 @@ k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ g
                const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, double step,
                int layout, int flags, float tol, uint8_t *__restrict__ valid,
                int32_t *__restrict__ first_bad, int *__restrict__ status, int *__restrict__ ulist,
-               int *__restrict__ ucount, UndecidedConfigs uc) {
+               int *__restrict__ ucount, UndecidedConfigs uc, const int *__restrict__ rlist,
+               const int *__restrict__ rcount) {
   edge_body<float, MAXS, WBOX, MBOX>(gip, nip, gfp, nfp, QA, QB, E, step, layout, flags, tol, valid,
-                                     first_bad, status, ulist, ucount, nullptr, nullptr, uc);
+                                     first_bad, status, ulist, ucount, rlist, rcount, uc);
+}
+
+// Endpoint pass of the two-pass edge filter: check 0 (the endpoint QB, utils.py:144) for every
+// edge with full lanes; edges whose endpoint is free (or undecided) are appended to `slist` for
+// the interior pass, so that pass runs only on edges that still need it -- in an RRT batch a
+// large share of the candidate edges ends inside an obstacle, and in the one-pass kernel their
+// lanes idle through every later waypoint of the wave.
+template <int MAXS, bool WBOX, bool MBOX>
+__global__ void __launch_bounds__(kBlock)
+k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
+                   const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, int layout,
+                   float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
+                   int *__restrict__ status, int *__restrict__ ulist, int *__restrict__ ucount,
+                   UndecidedConfigs uc, int *__restrict__ slist, int *__restrict__ scount) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  const int nplan = gip[H_NPLAN];
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B);
+  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
+  const bool active = i < E;
+  double *qw = c.col0 + threadIdx.x;
+  load_columns(qw, B, QB, E, i, nplan, layout, active);
+  __syncthreads();
+  bool finite = true;
+  for (int k = 0; k < nplan; k++) {
+    const double a = active ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
+    const double b = qw[k * B];
+    finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
+  }
+  const bool run = active && finite;
+  const int code = check_one<float, MAXS, WBOX, MBOX>(c, qw, B, run, tol, i);
+  bool survive = run && code != V_CONTACT;
+  if (active) {
+    if (!finite) {
+      valid[i] = 0;
+      if (first_bad) first_bad[i] = -2;
+      atomicOr(status, kStatusNonFinite);
+    } else if (code == V_CONTACT) {
+      valid[i] = 0;
+      if (first_bad) first_bad[i] = 0;
+    } else {
+      bool whole_edge = false;
+      if (code == V_UNSURE) {  // the endpoint itself goes to the exact configuration kernel
+        const int j = atomicAdd(uc.count, 1);
+        if (j < uc.cap) {
+          for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
+          uc.edge[j] = (int)i;
+          uc.idx[j] = 0;
+        } else {
+          whole_edge = true;
+        }
+      }
+      if (whole_edge) {
+        ulist[atomicAdd(ucount, 1)] = (int)i;  // the exact edge kernel writes valid / first_bad
+        survive = false;
+      } else {
+        valid[i] = 1;  // so far; the interior pass and the patch pass may clear it
+        if (first_bad) first_bad[i] = -1;
+      }
+    }
+  }
+  const unsigned long long m = __ballot(survive);
+  if (m != 0ull) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(scount, (int)__builtin_popcountll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (survive)
+      slist[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)i;
+  }
 }
 
 template <int MAXS, bool WBOX, bool MBOX>
@@ -707,7 +778,11 @@ struct mjpl_engine {
   bool filter = true;
   float filter_tol = 1e-4f;
   int *d_ulist = nullptr;   // items (configurations / whole edges) the filter left undecided
-  int *d_ucount = nullptr;  // [0] how many of those, [1] undecided waypoints of edges
+  int *d_ucount = nullptr;  // [0] how many of those, [1] undecided waypoints of edges, [2] edges in d_slist
+  int *d_slist = nullptr;   // two-pass edge filter: edges whose endpoint passed
+  size_t slist_cap = 0;
+  bool two_pass = true;
+  hipEvent_t mark_before_main = nullptr;  // timing runs: recorded before the dominant kernel
   size_t ulist_cap = 0;
   hipEvent_t mark_after_first = nullptr;  // timing runs: recorded after the first kernel of a launch
   double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
@@ -1117,7 +1192,7 @@ int uc_reserve(mjpl_engine *e, int64_t n) {
 }
 
 int ulist_reserve(mjpl_engine *e, int64_t n) {
-  if (!e->d_ucount) HIP_TRY(hipMalloc(&e->d_ucount, 2 * sizeof(int)));
+  if (!e->d_ucount) HIP_TRY(hipMalloc(&e->d_ucount, 4 * sizeof(int)));
   if ((size_t)n > e->ulist_cap) {
     if (e->d_ulist) HIP_TRY(hipFree(e->d_ulist));
     e->d_ulist = nullptr;
@@ -1203,17 +1278,42 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
     uc.count = e->d_ucount + 1;
     uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 2 * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 4 * sizeof(int), e->stream));
     const int fblock = e->mbox ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
+    // two passes unless only the interior was asked for: endpoints of all edges, then the interior
+    // waypoints of the edges whose endpoint passed
+    const bool two_pass = e->two_pass && !(flags & MJPL_EDGE_INTERIOR_ONLY);
+    if (two_pass) {
+      if ((size_t)E > e->slist_cap) {
+        if (e->d_slist) HIP_TRY(hipFree(e->d_slist));
+        e->d_slist = nullptr; e->slist_cap = 0;
+        HIP_TRY(hipMalloc(&e->d_slist, (size_t)E * sizeof(int)));
+        e->slist_cap = (size_t)E;
+      }
+      rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+        auto kern = k_filter_endpoints<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+        int r = allow_lds(kern, ldsf);
+        if (r != MJPL_OK) return r;
+        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
+                           e->d_fp, (int)e->fp.size(), dQA, dQB, E, layout, e->filter_tol, dvalid, dfb,
+                           e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist, e->d_ucount + 2);
+        return MJPL_OK;
+      });
+      if (rc != MJPL_OK) return rc;
+    }
+    if (e->mark_before_main) HIP_TRY(hipEventRecord(e->mark_before_main, e->stream));
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
       if (r != MJPL_OK) return r;
       hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
-                         e->d_fp, (int)e->fp.size(), dQA, dQB, E, step, layout, flags, e->filter_tol, dvalid,
-                         dfb, e->d_status, e->d_ulist, e->d_ucount, uc);
+                         e->d_fp, (int)e->fp.size(), dQA, dQB, E, step, layout,
+                         two_pass ? (flags | MJPL_EDGE_INTERIOR_ONLY) : flags, e->filter_tol, dvalid,
+                         dfb, e->d_status, e->d_ulist, e->d_ucount, uc,
+                         two_pass ? (const int *)e->d_slist : nullptr,
+                         two_pass ? (const int *)(e->d_ucount + 2) : nullptr);
       return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
@@ -1341,6 +1441,7 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
   for (int k = 0; k < m.nq; k++) e->qidx[k] = k;
   e->qbase = m.qpos0;
   if (const char *f = getenv("MJPL_FILTER")) e->filter = atoi(f) != 0;
+  if (const char *f = getenv("MJPL_TWO_PASS")) e->two_pass = atoi(f) != 0;
   if (const char *t = getenv("MJPL_FILTER_TOL")) {
     const double v = atof(t);
     if (v > 0.0 && v < 1.0) e->filter_tol = (float)v;
@@ -1362,6 +1463,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_fp) (void)hipFree(e->d_fp);
   if (e->d_ulist) (void)hipFree(e->d_ulist);
   if (e->d_ucount) (void)hipFree(e->d_ucount);
+  if (e->d_slist) (void)hipFree(e->d_slist);
   if (e->d_ucq) (void)hipFree(e->d_ucq);
   if (e->d_ucedge) (void)hipFree(e->d_ucedge);
   if (e->d_ucidx) (void)hipFree(e->d_ucidx);
@@ -1405,6 +1507,15 @@ int64_t mjpl_filter_last_undecided(mjpl_engine *e) {
   if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
   if (hipMemcpy(n, e->d_ucount, 2 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int64_t)n[0] + n[1];
+}
+
+int64_t mjpl_filter_last_interior_edges(mjpl_engine *e) {
+  if (!e || !e->filter || !e->d_ucount) return -1;
+  int n[4] = {0, 0, 0, 0};
+  if (hipSetDevice(e->device) != hipSuccess) return -1;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+  if (hipMemcpy(n, e->d_ucount, 4 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)n[2];
 }
 
 int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
@@ -1616,21 +1727,26 @@ int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, in
                         int32_t layout, uint8_t *dvalid, int32_t iters, float *ms, float *ms_first) {
   if (!e || iters < 0 || (iters > 0 && !ms)) return fail(MJPL_E_ARG, "mjpl_time_edges_dev: bad argument");
   HIP_TRY(hipSetDevice(e->device));
-  std::vector<hipEvent_t> ev(3 * (size_t)iters);
+  std::vector<hipEvent_t> ev(4 * (size_t)iters);
   for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
   int rc = MJPL_OK;
   for (int k = 0; k < iters && rc == MJPL_OK; k++) {
-    HIP_TRY(hipEventRecord(ev[3 * k], e->stream));
-    e->mark_after_first = ev[3 * k + 2];
+    HIP_TRY(hipEventRecord(ev[4 * k], e->stream));
+    if (e->filter) {  // bracket the dominant kernel of the launch (the float32 edge filter)
+      e->mark_before_main = ev[4 * k + 3];
+      e->mark_after_first = ev[4 * k + 2];
+    } else {
+      HIP_TRY(hipEventRecord(ev[4 * k + 3], e->stream));
+    }
     rc = mjpl_check_edges_dev(e, dQA, dQB, E, step_dist, layout, 0, dvalid, nullptr);
-    e->mark_after_first = nullptr;
-    if (!e->filter) HIP_TRY(hipEventRecord(ev[3 * k + 2], e->stream));  // single-kernel launch
-    HIP_TRY(hipEventRecord(ev[3 * k + 1], e->stream));
+    e->mark_after_first = e->mark_before_main = nullptr;
+    if (!e->filter) HIP_TRY(hipEventRecord(ev[4 * k + 2], e->stream));  // single-kernel launch
+    HIP_TRY(hipEventRecord(ev[4 * k + 1], e->stream));
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (int k = 0; k < iters && rc == MJPL_OK; k++) {
-    HIP_TRY(hipEventElapsedTime(&ms[k], ev[3 * k], ev[3 * k + 1]));
-    if (ms_first) HIP_TRY(hipEventElapsedTime(&ms_first[k], ev[3 * k], ev[3 * k + 2]));
+    HIP_TRY(hipEventElapsedTime(&ms[k], ev[4 * k], ev[4 * k + 1]));
+    if (ms_first) HIP_TRY(hipEventElapsedTime(&ms_first[k], ev[4 * k + 3], ev[4 * k + 2]));
   }
   for (auto &x : ev) (void)hipEventDestroy(x);
   return rc;

@@ -167,3 +167,33 @@ def test_filter_configs_64k_and_info(oracle_mod):
     np.testing.assert_array_equal(e.check_configs(Q), want)
     with pytest.raises(eng_mod.MjplError, match="tolerance"):
         e.set_filter(True, 0.0)
+
+
+def test_two_pass_and_one_pass_filter_agree(monkeypatch):
+    """The endpoint-first split of the edge filter changes scheduling only: valid and first_bad are
+    those of the one-pass filter and of the pure float64 kernels, on clean edges, on edges that
+    end in an obstacle and on zero-length edges."""
+    from mjpl_amd import engine, scenes
+    import bench as _bench
+    m = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    qa, qb = _bench.make_edges(m, qidx, 20000, seed=77)
+    qb[:50] = qa[:50]  # waypoints == [start]: nothing interior
+    out = {}
+    for tag, env in (("two", {"MJPL_TWO_PASS": "1"}), ("one", {"MJPL_TWO_PASS": "0"}), ("f64", {"MJPL_FILTER": "0"})):
+        for k in ("MJPL_TWO_PASS", "MJPL_FILTER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = engine.Engine(m)
+        e.set_planning(qidx, base)
+        out[tag] = e.check_edges(qa, qb, 0.01, first_bad=True)
+        if tag == "two":
+            n_int = e.last_interior_edges()
+            assert 0 < n_int < len(qa)
+        e.close()
+    for tag in ("one", "f64"):
+        np.testing.assert_array_equal(out["two"][0], out[tag][0])
+        np.testing.assert_array_equal(out["two"][1], out[tag][1])
+    assert 0 < out["two"][0].sum() < len(qa)
