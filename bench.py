@@ -101,7 +101,9 @@ def main():
         args.gpus = world
 
     dist = torch = None
-    if world > 1:
+    # MJPL_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, barrier, max-reduce) even
+    # with one rank, to exercise it on a single-GPU box
+    if world > 1 or os.environ.get("MJPL_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist

@@ -1102,7 +1102,8 @@ int compile_program(mjpl_engine *e) {
       };
       const double inf = std::numeric_limits<double>::infinity();
       {
-        std::vector<double> wb(nwpad, inf), wm(nwpad, 0.0);
+        // rows that are no partner of this geom: -inf, so the queued culls need no enable mask
+        std::vector<double> wb(nwpad, -inf), wm(nwpad, 0.0);
         for (int sgeom : world_partners[gk]) {
           pair_bound(sgeom, &wb[world_row[sgeom]], &wm[world_row[sgeom]]);
           (m.geom_type[sgeom] == GT_PLANE ? plane_bound_at : sq_bound_at).push_back(dp.size() + world_row[sgeom]);
