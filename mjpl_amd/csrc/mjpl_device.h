@@ -92,7 +92,10 @@ enum : int { MAX_SLOTS = 16 };
 //              plane; +inf where the pair is disabled.  nwpad = rows rounded up to a multiple of 4
 //   wmargin[w] pair margin max(margin_cur, margin_w)
 //   sbound[s]  cull bound against the earlier moving geom held in register slot s (+inf if none)
-enum : int { GD_LPOS = 0, GD_LQUAT = 3, GD_SIZE = 7, GD_WBOUND = 12 };
+enum : int { GD_LPOS = 0, GD_LQUAT = 3, GD_SIZE = 7, GD_GEOMID = 10, GD_WBOUND = 12 };
+// ... | sgeom[16]: model geom id of the earlier moving geom held in slot s (as a number of the
+//                  table's scalar type; exact below 2^24); GD_GEOMID: this geom's model id
+enum : int { GS_BOUND = 0, GS_MARGIN = MAX_SLOTS, GS_SIZE = 2 * MAX_SLOTS, GS_GEOMID = 5 * MAX_SLOTS };
 
 // static partners: G_WMASK (non-plane) and G_PMASK (plane) are bit masks over the rows of the
 // world tables (<= 64 static geoms); G_SMASK is a bit mask over register slots.
@@ -1053,6 +1056,26 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define MJPL_ACC(slot, var)
 #endif
 
+// Items the float32 filter could not decide, handed to the exact float64 kernels on the device.
+// ga >= 0: one geom pair (ga = the later moving geom, gb = its partner) of the configuration;
+// ga < 0: the whole configuration.
+struct UndecidedConfigs {
+  double *q;    // [cap][nplan] configuration (waypoint), row-major
+  int *edge;    // [cap] edge it belongs to
+  int *idx;     // [cap] its check index inside that edge
+  int *ga, *gb; // [cap] model geom ids of the undecided pair, or -1
+  int *count;   // entries written (may exceed cap: the overflow went to the edge-level list)
+  int cap;
+};
+
+// Where a drain reports candidates it cannot decide (count == nullptr: flag the owning lane).
+struct PatchSink {
+  UndecidedConfigs uc;
+  const double *qcol;  // LDS columns of this wave's lanes: q[k] of lane l at qcol[k * B + l]
+  int B, nplan;
+  int idx;             // check index of the configurations under test (wave-uniform)
+};
+
 // ----------------------------------------------------------------------------- queued narrowphase
 // The immediate interpreter above runs a narrowphase routine as soon as ANY lane of the wave
 // passes a bounding cull: with 64 unrelated configurations per wave that is the case for ~28 %
@@ -1098,7 +1121,7 @@ struct WaveQueue {
 // BOXQ selects the queue.  ALL: empty it (end of a configuration); otherwise one batch.
 template <class T, bool BOXQ, bool ALL>
 __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, const T *tp, const T *wcull,
-                                            const T *wnarrow, int nwpad, T tol,
+                                            const T *wnarrow, int nwpad, T tol, const PatchSink &ps,
                                             unsigned long long *dacc = nullptr) {
   // tp / wcull / wnarrow point into the workgroup's LDS copy of the constant table: the drain
   // reads them with per-lane addresses (every lane has its own candidate), which from global
@@ -1187,7 +1210,27 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
 #ifdef MJPL_X_DRAIN_NONARROW  // timing-only build: pop + gather, no narrowphase
     code = (cur.pos[0] + par.pos[0] + psize[0] + gsize[0] + margin == T(12345.0)) ? V_CONTACT : V_NONE;
 #endif
-    if (on && code != V_NONE) atomicOr(&wq.flags[owner], code == V_CONTACT ? 1 : 2);
+    if (on && code == V_CONTACT) atomicOr(&wq.flags[owner], 1);
+    if (on && code == V_UNSURE) {
+      // hand this one pair of the owner's configuration to the exact kernel; the owner walks on
+      // as if it were free (the patch pass clears valid / lowers first_bad if it is not)
+      bool handed = false;
+      if (ps.uc.count) {
+        const int u = atomicAdd(ps.uc.count, 1);
+        if (u < ps.uc.cap) {
+          for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + owner];
+          ps.uc.edge[u] = (int)((unsigned)wq.flags[owner] >> 2);
+          ps.uc.idx[u] = ps.idx;
+          ps.uc.ga[u] = (int)gd[GD_GEOMID];
+          int gb;
+          if (!BOXQ && kind == EK_SLOT) gb = (int)gd[GD_WBOUND + 2 * nwpad + GS_GEOMID + index];
+          else gb = info_bits(wcull[index * WC_LEN + WC_INFO]) >> 8;
+          ps.uc.gb[u] = gb;
+          handed = true;
+        }
+      }
+      if (!handed) atomicOr(&wq.flags[owner], 2);
+    }
   } while (ALL && qn > 0);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -1196,7 +1239,8 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
 template <class T, int MAXS, bool WBOX>
 __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp, const T *ltab,
                                                  const double *q, int qstride, T *save, int sstride,
-                                                 bool active, T tol, const WaveQueue<T> &wq) {
+                                                 bool active, T tol, const WaveQueue<T> &wq, int item,
+                                                 const PatchSink &ps) {
   typedef typename Real<T>::Tab Tab;
   typedef GeomT<T> Geom;
   SlotFile<T, MAXS> sf;
@@ -1216,7 +1260,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
 #ifdef MJPL_X_Q_NOPUSH
   unsigned long long sink = 0;
 #endif
-  wq.flags[lane] = 0;
+  wq.flags[lane] = (int)((unsigned)item << 2);  // bits 0..1 verdict flags, the rest: whose item this is
   const int nbodyops = uni(ip[H_NBODYOPS]);
   Tab wcull = tp + uni(ip[H_OFF_WCULL]);
   const int nwpad = uni(ip[H_NWPAD]);
@@ -1360,11 +1404,11 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         if (fill + cnt > CAP) {  // make room: one batch leaves the top of the queue
           MJPL_ACC(2, tt);
 #ifdef MJPL_STAMPS
-          queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, acc + 8);
+          queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
 #else
-          queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol);
+          queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps);
 #endif
-          fl = wq.flags[lane];
+          fl = wq.flags[lane] & 3;
           dead = (fl != 0 || !active) ? kInf : T(0);
           MJPL_ACC(3, tt);  // drains
         }
@@ -1498,13 +1542,13 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   }
   MJPL_ACC(5, tt);
 #ifdef MJPL_STAMPS
-  if (qn > 0) queue_drain<T, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, acc + 8);
-  if (WBOX && qb > 0) queue_drain<T, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, acc + 8);
+  if (qn > 0) queue_drain<T, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
+  if (WBOX && qb > 0) queue_drain<T, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
 #else
-  if (qn > 0) queue_drain<T, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol);
-  if (WBOX && qb > 0) queue_drain<T, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol);
+  if (qn > 0) queue_drain<T, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);
+  if (WBOX && qb > 0) queue_drain<T, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps);
 #endif
-  fl = wq.flags[lane];
+  fl = wq.flags[lane] & 3;
   MJPL_ACC(3, tt);
 #ifdef MJPL_STAMPS
   if (lane == 0) {

@@ -82,10 +82,18 @@ __device__ __forceinline__ WaveQueue<T> wave_queue(char *qmem) {
 
 template <class T, int MAXS, bool WBOX, bool MBOX>
 __device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int B, bool active, T tol,
-                                         int64_t row) {
+                                         int64_t row, const UndecidedConfigs &uc = UndecidedConfigs{},
+                                         int idx = 0) {
   if constexpr (kQueued<T, MBOX>) {
     WaveQueue<T> wq = wave_queue<T>(c.qmem);
-    return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, c.ltab, q, B, c.save + threadIdx.x, B, active, tol, wq);
+    PatchSink ps;
+    ps.uc = uc;
+    ps.qcol = c.col0 + (threadIdx.x & ~63);
+    ps.B = B;
+    ps.nplan = c.ip[H_NPLAN];
+    ps.idx = idx;
+    return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, c.ltab, q, B, c.save + threadIdx.x, B, active, tol, wq,
+                                            (int)row, ps);
   } else {
     FkOut none = {};
     return run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, q, B, c.save + threadIdx.x, B, active, tol,
@@ -152,14 +160,6 @@ __device__ __forceinline__ bool pick_item(int64_t n, const int *__restrict__ uli
   return j < n;
 }
 
-// Configurations the filter could not decide, handed to the exact configuration kernel.
-struct UndecidedConfigs {
-  double *q;    // [cap][nplan] waypoint, row-major
-  int *edge;    // [cap] edge it belongs to
-  int *idx;     // [cap] its check index inside that edge
-  int *count;   // entries written (may exceed cap: the overflow went to the edge-level list)
-  int cap;
-};
 
 // ---- exact path (float64): final verdicts --------------------------------------------------
 
@@ -190,7 +190,7 @@ k_check_configs(const int *__restrict__ gip, int nip, const double *__restrict__
                                                                c.save + threadIdx.x, B, active, 0.0, none,
                                                                i) == V_CONTACT;
   if (uc.count) {
-    if (active && hit) {
+    if (active && hit && uc.ga[i] < 0) {  // pair-level items belong to k_patch_pairs
       const int ed = uc.edge[i];
       valid[ed] = 0;
       // first_bad holds -1 (= UINT_MAX) for "valid so far": an unsigned min keeps the lowest index
@@ -312,7 +312,10 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
         }
       }
     }
-    const int code = check_one<T, MAXS, WBOX, MBOX>(c, qw, B, !done, tol, i);
+    // idx is the same for every lane that is still walking (they all started together)
+    const unsigned long long walking = __ballot(!done);
+    const int widx = __builtin_amdgcn_readfirstlane(__shfl(idx, walking ? __ffsll((long long)walking) - 1 : 0));
+    const int code = check_one<T, MAXS, WBOX, MBOX>(c, qw, B, !done, tol, i, uc, widx);
     if (!done && code == V_CONTACT) { done = true; ok = false; fb = idx; }
     if (!done && code == V_UNSURE) {
       // the filter cannot decide this configuration: hand IT (not the whole edge) to the exact
@@ -324,6 +327,7 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
         for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
         uc.edge[j] = (int)i;
         uc.idx[j] = idx;
+        uc.ga[j] = uc.gb[j] = -1;  // the whole configuration (immediate interpreter)
       } else {
         done = true; unsure = true;
       }
@@ -394,7 +398,7 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
     finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
   }
   const bool run = active && finite;
-  const int code = check_one<float, MAXS, WBOX, MBOX>(c, qw, B, run, tol, i);
+  const int code = check_one<float, MAXS, WBOX, MBOX>(c, qw, B, run, tol, i, uc, 0);
   bool survive = run && code != V_CONTACT;
   if (active) {
     if (!finite) {
@@ -412,6 +416,7 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
           for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
           uc.edge[j] = (int)i;
           uc.idx[j] = 0;
+          uc.ga[j] = uc.gb[j] = -1;
         } else {
           whole_edge = true;
         }
@@ -739,6 +744,203 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
   }
 }
 
+
+// ---- exact re-check of single geom pairs the filter could not decide -------------------------
+// Item u = (configuration uc.q[u], moving geom uc.ga[u], partner geom uc.gb[u]).  One lane per
+// item: float64 FK of the moving bodies (same statements as run_config), capturing the world
+// pose of the one or two geoms it needs, then the bounding cull and the narrowphase routine of
+// that pair exactly as the full exact kernel would run them.  A contact clears valid[edge] and
+// lowers first_bad[edge] (unsigned min; -1 = valid so far).  Latency of a wave is one FK instead
+// of FK + all culls + every narrowphase call some lane of the wave needs.
+struct GeomTable {           // per model geom, float64 [GT_LEN]
+  const double *t;
+};
+enum : int { GTB_TYPE = 0, GTB_SIZE = 1, GTB_RBOUND = 4, GTB_MARGIN = 5, GTB_STATIC = 6, GTB_XPOS = 7,
+             GTB_XMAT = 10, GTB_LEN = 19 };
+
+__global__ void __launch_bounds__(kBlock)
+k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp, GeomTable gt,
+              UndecidedConfigs uc, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  const int64_t n = *uc.count < uc.cap ? *uc.count : uc.cap;
+  if ((int64_t)blockIdx.x * B >= n) return;
+  const int nplan = gip[H_NPLAN];
+  Carve<double> c = carve_lds<double>(smem, gip, nip, gdp, ndp, nplan, 1, B);
+  const int64_t u = (int64_t)blockIdx.x * B + threadIdx.x;
+  bool active = u < n;
+  const int ga = active ? uc.ga[u] : -1;
+  const int gb = active ? uc.gb[u] : -1;
+  active = active && ga >= 0;
+  double *q = c.col0 + threadIdx.x;
+  load_columns(q, B, uc.q, n, u, nplan, MJPL_AOS, active);
+  __syncthreads();
+  if (__ballot(active) == 0ull) return;
+
+  typedef GeomT<double> Geom;
+  IP ip = c.ip;
+  DP tp = c.tp;
+  double *save = c.save + threadIdx.x;
+  const int sstride = B;
+  Geom A, Bg;
+#pragma unroll
+  for (int k = 0; k < 3; k++) A.pos[k] = Bg.pos[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) A.m[k] = Bg.m[k] = 0;
+  double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const int nbodyops = uni(ip[H_NBODYOPS]);
+  int pc = uni(ip[H_OFF_BODYOPS]);
+  for (int b = 0; b < nbodyops; b++) {
+    const int parent = uni(ip[pc + B_PARENT]);
+    DP bd = tp + uni(ip[pc + B_DOFF]);
+    const int njnt = uni(ip[pc + B_NJNT]);
+    const int save_slot = uni(ip[pc + B_SAVE]);
+    const int ngeom = uni(ip[pc + B_NGEOM]);
+    pc += B_SIZE;
+    double pp[3], pq[4], pR[9];
+    if (parent == PARENT_CUR) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = p[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = qt[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) pR[k] = R[k];
+    } else if (parent == PARENT_STATIC) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = bd[7 + k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = bd[10 + k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) pR[k] = bd[14 + k];
+    } else {
+      const double *sv = save + (size_t)(parent - 1) * 7 * sstride;
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = sv[k * sstride];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = sv[(3 + k) * sstride];
+      quat2mat(pR, pq);
+    }
+    double np[3], nq[4];
+    {
+      double bpos[3] = {bd[0], bd[1], bd[2]};
+      double bquat[4] = {bd[3], bd[4], bd[5], bd[6]};
+      mul_mat_vec3(np, pR, bpos);
+      np[0] += pp[0]; np[1] += pp[1]; np[2] += pp[2];
+      mul_quat(nq, pq, bquat);
+    }
+    for (int j = 0; j < njnt; j++) {
+      const int jtype = uni(ip[pc + J_TYPE]);
+      const int qsrc = uni(ip[pc + J_QSRC]);
+      const int jflags = uni(ip[pc + J_FLAGS]);
+      DP jd = tp + uni(ip[pc + J_DOFF]);
+      pc += J_SIZE;
+      const double qv = (qsrc >= 0) ? q[qsrc * B] : jd[7];
+      const double dq = qv - jd[6];
+      double jaxis[3] = {jd[0], jd[1], jd[2]};
+      double jpos[3] = {jd[3], jd[4], jd[5]};
+      if (jtype == JT_SLIDE) {
+        double xaxis[3];
+        rot_vec_quat(xaxis, jaxis, nq);
+        np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq;
+      } else {
+        double xanchor[3] = {np[0], np[1], np[2]};
+        if (jflags & JF_POS_NONZERO) {
+          rot_vec_quat(xanchor, jpos, nq);
+          xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];
+        }
+        double sn, cs;
+        sincos_half(dq * 0.5, &sn, &cs);
+        double qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};
+        mul_quat(nq, nq, qloc);
+        if (jflags & JF_POS_NONZERO) {
+          double vec[3];
+          rot_vec_quat(vec, jpos, nq);
+          np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2];
+        }
+      }
+    }
+    normalize4(nq);
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = np[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) qt[k] = nq[k];
+    quat2mat(R, qt);
+    if (save_slot >= 0) {
+      double *sv = save + (size_t)save_slot * 7 * sstride;
+#pragma unroll
+      for (int k = 0; k < 3; k++) sv[k * sstride] = p[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) sv[(3 + k) * sstride] = qt[k];
+    }
+    for (int g = 0; g < ngeom; g++) {
+      const int gflags = uni(ip[pc + G_FLAGS]);
+      DP gd = tp + uni(ip[pc + G_DOFF]);
+      const int geom_id = uni(ip[pc + G_GEOMID]);
+      pc += G_SIZE + MAX_SLOTS;
+      if (__ballot(active && (geom_id == ga || geom_id == gb)) == 0ull) continue;
+      Geom cur;
+      if (gflags & GF_SAMEPOS) {
+        cur.pos[0] = p[0]; cur.pos[1] = p[1]; cur.pos[2] = p[2];
+      } else {
+        double lpos[3] = {gd[0], gd[1], gd[2]};
+        mul_mat_vec3(cur.pos, R, lpos);
+        cur.pos[0] += p[0]; cur.pos[1] += p[1]; cur.pos[2] += p[2];
+      }
+      if (gflags & GF_SAMEROT) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) cur.m[k] = R[k];
+      } else {
+        double lq[4] = {gd[3], gd[4], gd[5], gd[6]}, gq[4];
+        mul_quat(gq, qt, lq);
+        quat2mat(cur.m, gq);
+      }
+      const bool isa = geom_id == ga, isb = geom_id == gb;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { A.pos[k] = isa ? cur.pos[k] : A.pos[k]; Bg.pos[k] = isb ? cur.pos[k] : Bg.pos[k]; }
+#pragma unroll
+      for (int k = 0; k < 9; k++) { A.m[k] = isa ? cur.m[k] : A.m[k]; Bg.m[k] = isb ? cur.m[k] : Bg.m[k]; }
+    }
+  }
+  if (!active) return;
+  const double *ta = gt.t + (size_t)ga * GTB_LEN, *tb = gt.t + (size_t)gb * GTB_LEN;
+  if (tb[GTB_STATIC] != 0.0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) Bg.pos[k] = tb[GTB_XPOS + k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Bg.m[k] = tb[GTB_XMAT + k];
+  }
+  const int tya = (int)ta[GTB_TYPE], tyb = (int)tb[GTB_TYPE];
+  const double sa[3] = {ta[GTB_SIZE], ta[GTB_SIZE + 1], ta[GTB_SIZE + 2]};
+  const bool bplane = tyb == GT_PLANE;  // the interpreter passes no size for a plane
+  const double sb[3] = {bplane ? 0.0 : tb[GTB_SIZE], bplane ? 0.0 : tb[GTB_SIZE + 1], bplane ? 0.0 : tb[GTB_SIZE + 2]};
+  // pair margin and bounding cull in mj_collision's (g1 < g2) order, as compile_program folds them
+  const int g1 = ga < gb ? ga : gb, g2 = ga < gb ? gb : ga;
+  const double *t1 = gt.t + (size_t)g1 * GTB_LEN, *t2 = gt.t + (size_t)g2 * GTB_LEN;
+  const double margin = fmax(t1[GTB_MARGIN], t2[GTB_MARGIN]);
+  const double r1 = t1[GTB_RBOUND], r2 = t2[GTB_RBOUND];
+  bool pass = true;
+  if (tyb == GT_PLANE) {
+    if (ta[GTB_RBOUND] > 0) {
+      const double n[3] = {Bg.m[2], Bg.m[5], Bg.m[8]};
+      const double dif[3] = {A.pos[0] - Bg.pos[0], A.pos[1] - Bg.pos[1], A.pos[2] - Bg.pos[2]};
+      pass = !(dot3(dif, n) > margin + ta[GTB_RBOUND]);
+    }
+  } else if (r1 > 0 && r2 > 0) {
+    const double bsum = r1 + r2 + margin;
+    const double dx = A.pos[0] - Bg.pos[0], dy = A.pos[1] - Bg.pos[1], dz = A.pos[2] - Bg.pos[2];
+    pass = !(dx * dx + dy * dy + dz * dz > bsum * bsum);
+  }
+  if (!pass) return;
+  // the partner is the first geom of the pair if its type is smaller, geom id breaking ties
+  const bool pfirst = (tyb < tya) || (tyb == tya && gb < ga);
+  const int code = pair_contact<double, true, true>(tya, A, sa, tyb, Bg, sb, pfirst, margin, 0.0);
+  if (code == V_CONTACT) {
+    const int ed = uc.edge[u];
+    valid[ed] = 0;
+    if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)uc.idx[u]);
+  }
+}
+
 // ------------------------------------------------------------------------------- host model
 
 struct HostModel {
@@ -786,7 +988,8 @@ struct mjpl_engine {
   size_t ulist_cap = 0;
   hipEvent_t mark_after_first = nullptr;  // timing runs: recorded after the first kernel of a launch
   double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
-  int *d_ucedge = nullptr, *d_ucidx = nullptr;
+  int *d_ucedge = nullptr, *d_ucidx = nullptr, *d_ucga = nullptr, *d_ucgb = nullptr;
+  double *d_geomtab = nullptr;  // GTB_LEN doubles per model geom (k_patch_pairs)
   size_t uc_cap = 0;
   int nslots = 0, nsave = 0, maxs = 4;
   bool wbox = false, mbox = false;
@@ -1084,7 +1287,7 @@ int compile_program(mjpl_engine *e) {
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(gp[k3]);
       for (int k4 = 0; k4 < 4; k4++) dp.push_back(gq[k4]);
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(m.geom_size[3 * g + k3]);
-      dp.push_back(0.0);
+      dp.push_back((double)g);  // GD_GEOMID
       dp.push_back(0.0);
 
       // cull bound and margin of the pair (g, h) in mj_collision's (g1 < g2) order
@@ -1112,7 +1315,7 @@ int compile_program(mjpl_engine *e) {
         dp.insert(dp.end(), wm.begin(), wm.end());
       }
       {
-        std::vector<double> sb(MAX_SLOTS, inf), sm(MAX_SLOTS, 0.0), ss(3 * MAX_SLOTS, 0.0);
+        std::vector<double> sb(MAX_SLOTS, inf), sm(MAX_SLOTS, 0.0), ss(3 * MAX_SLOTS, 0.0), sg(MAX_SLOTS, -1.0);
         for (int k2 : stored_partners[gk]) {
           const int h = mgeoms[k2];
           const int s1 = slot_of[k2] & 63, s2 = (slot_of[k2] >> 6) & 63;
@@ -1122,10 +1325,12 @@ int compile_program(mjpl_engine *e) {
           pair_bound(h, &sb[s1], &sm[s1]);
           sq_bound_at.push_back(dp.size() + s1);
           for (int k3 = 0; k3 < 3; k3++) ss[3 * s1 + k3] = m.geom_size[3 * h + k3];
+          sg[s1] = (double)h;
         }
         dp.insert(dp.end(), sb.begin(), sb.end());
         dp.insert(dp.end(), sm.begin(), sm.end());
         dp.insert(dp.end(), ss.begin(), ss.end());
+        dp.insert(dp.end(), sg.begin(), sg.end());  // GS_GEOMID
       }
     }
     ip[base + B_NGEOM] = ngeom_here;
@@ -1184,10 +1389,30 @@ int uc_reserve(mjpl_engine *e, int64_t n) {
   if (e->d_ucq) HIP_TRY(hipFree(e->d_ucq));
   if (e->d_ucedge) HIP_TRY(hipFree(e->d_ucedge));
   if (e->d_ucidx) HIP_TRY(hipFree(e->d_ucidx));
-  e->d_ucq = nullptr; e->d_ucedge = e->d_ucidx = nullptr; e->uc_cap = 0;
+  if (e->d_ucga) HIP_TRY(hipFree(e->d_ucga));
+  if (e->d_ucgb) HIP_TRY(hipFree(e->d_ucgb));
+  e->d_ucq = nullptr; e->d_ucedge = e->d_ucidx = e->d_ucga = e->d_ucgb = nullptr; e->uc_cap = 0;
   HIP_TRY(hipMalloc(&e->d_ucq, want * std::max<size_t>(1, e->m.nq) * sizeof(double)));
   HIP_TRY(hipMalloc(&e->d_ucedge, want * sizeof(int)));
   HIP_TRY(hipMalloc(&e->d_ucidx, want * sizeof(int)));
+  HIP_TRY(hipMalloc(&e->d_ucga, want * sizeof(int)));
+  HIP_TRY(hipMalloc(&e->d_ucgb, want * sizeof(int)));
+  if (!e->d_geomtab) {
+    const HostModel &m = e->m;
+    std::vector<double> t((size_t)m.ngeom * GTB_LEN, 0.0);
+    for (int g = 0; g < m.ngeom; g++) {
+      double *r = &t[(size_t)g * GTB_LEN];
+      r[GTB_TYPE] = m.geom_type[g];
+      for (int k = 0; k < 3; k++) r[GTB_SIZE + k] = m.geom_size[3 * g + k];
+      r[GTB_RBOUND] = m.geom_rbound[g];
+      r[GTB_MARGIN] = m.geom_margin[g];
+      r[GTB_STATIC] = e->geom_static[g] ? 1.0 : 0.0;
+      for (int k = 0; k < 3; k++) r[GTB_XPOS + k] = e->st_gxpos[3 * g + k];
+      for (int k = 0; k < 9; k++) r[GTB_XMAT + k] = e->st_gxmat[9 * g + k];
+    }
+    HIP_TRY(hipMalloc(&e->d_geomtab, t.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_geomtab, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   e->uc_cap = want;
   return MJPL_OK;
 }
@@ -1277,6 +1502,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     if (rc == MJPL_OK) rc = uc_reserve(e, E);
     if (rc != MJPL_OK) return rc;
     uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
+    uc.ga = e->d_ucga; uc.gb = e->d_ucgb;
     uc.count = e->d_ucount + 1;
     uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 4 * sizeof(int), e->stream));
@@ -1323,16 +1549,24 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     // share of the batch; surplus blocks return at once)
     const size_t ldsc = lds_bytes(e, 1);
     const unsigned pgrid = (unsigned)std::min<size_t>((uc.cap + kBlock - 1) / kBlock, 1024);
-    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
-      auto kern = k_check_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
-      int r = allow_lds(kern, ldsc);
-      if (r != MJPL_OK) return r;
-      hipLaunchKernelGGL(kern, dim3(pgrid), dim3(kBlock), ldsc, e->stream, e->d_ip, (int)e->ip.size(),
-                         e->d_dp, (int)e->dp.size(), (const double *)uc.q, (int64_t)0, (int)MJPL_AOS, dvalid,
-                         (unsigned long long *)nullptr, (const int *)nullptr, (const int *)nullptr, uc, dfb);
-      return MJPL_OK;
-    });
-    if (rc != MJPL_OK) return rc;
+    if (e->mbox) {  // immediate filter: whole configurations
+      rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+        auto kern = k_check_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+        int r = allow_lds(kern, ldsc);
+        if (r != MJPL_OK) return r;
+        hipLaunchKernelGGL(kern, dim3(pgrid), dim3(kBlock), ldsc, e->stream, e->d_ip, (int)e->ip.size(),
+                           e->d_dp, (int)e->dp.size(), (const double *)uc.q, (int64_t)0, (int)MJPL_AOS, dvalid,
+                           (unsigned long long *)nullptr, (const int *)nullptr, (const int *)nullptr, uc, dfb);
+        return MJPL_OK;
+      });
+      if (rc != MJPL_OK) return rc;
+    } else {        // queued filter: single geom pairs
+      rc = allow_lds(k_patch_pairs, ldsc);
+      if (rc != MJPL_OK) return rc;
+      GeomTable gt = {e->d_geomtab};
+      hipLaunchKernelGGL(k_patch_pairs, dim3(pgrid), dim3(kBlock), ldsc, e->stream, e->d_ip, (int)e->ip.size(),
+                         e->d_dp, (int)e->dp.size(), gt, uc, dvalid, dfb);
+    }
   }
   const size_t lds = lds_bytes(e, 1);
   int rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
@@ -1465,6 +1699,9 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_ulist) (void)hipFree(e->d_ulist);
   if (e->d_ucount) (void)hipFree(e->d_ucount);
   if (e->d_slist) (void)hipFree(e->d_slist);
+  if (e->d_ucga) (void)hipFree(e->d_ucga);
+  if (e->d_ucgb) (void)hipFree(e->d_ucgb);
+  if (e->d_geomtab) (void)hipFree(e->d_geomtab);
   if (e->d_ucq) (void)hipFree(e->d_ucq);
   if (e->d_ucedge) (void)hipFree(e->d_ucedge);
   if (e->d_ucidx) (void)hipFree(e->d_ucidx);
