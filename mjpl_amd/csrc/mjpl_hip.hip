@@ -445,7 +445,8 @@ template <int MAXS, bool WBOX, bool MBOX>
 __global__ void __launch_bounds__(kBlock)
 k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
                  const double *__restrict__ Q, int64_t N, int layout, float tol,
-                 uint8_t *__restrict__ valid, int *__restrict__ ulist, int *__restrict__ ucount) {
+                 uint8_t *__restrict__ valid, int *__restrict__ ulist, int *__restrict__ ucount,
+                 UndecidedConfigs uc) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
   const int nplan = gip[H_NPLAN];
@@ -454,7 +455,9 @@ k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__
   const bool active = i < N;
   load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
   __syncthreads();
-  const int code = check_one<float, MAXS, WBOX, MBOX>(c, c.col0 + threadIdx.x, B, active, tol, i);
+  // queued interpreter: undecided pairs go to k_patch_pairs through `uc` (which clears valid[i]
+  // on a contact); V_UNSURE comes back only for what could not be handed over
+  const int code = check_one<float, MAXS, WBOX, MBOX>(c, c.col0 + threadIdx.x, B, active, tol, i, uc, 0);
   if (active) {
     if (code == V_UNSURE) ulist[atomicAdd(ucount, 1)] = (int)i;
     else valid[i] = (code == V_CONTACT) ? 0 : 1;
@@ -1459,8 +1462,16 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
   const bool filter = e->filter && dvalid && !dbits && N < (int64_t)1 << 31;
   if (filter) {
     int rc = ulist_reserve(e, N);
+    UndecidedConfigs uc = {};
+    if (rc == MJPL_OK && !e->mbox) {
+      rc = uc_reserve(e, N);
+      uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
+      uc.ga = e->d_ucga; uc.gb = e->d_ucgb;
+      uc.count = e->d_ucount + 1;
+      uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
+    }
     if (rc != MJPL_OK) return rc;
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 2 * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 4 * sizeof(int), e->stream));
     const int fblock = e->mbox ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
@@ -1470,10 +1481,19 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
       if (r != MJPL_OK) return r;
       hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                          e->d_fp, (int)e->fp.size(), dQ, N, layout, e->filter_tol, dvalid, e->d_ulist,
-                         e->d_ucount);
+                         e->d_ucount, uc);
       return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
+    if (uc.count) {  // exact re-check of the undecided pairs; rows here are planning columns, AoS
+      const size_t ldsc = lds_bytes(e, 1);
+      const unsigned pgrid = (unsigned)std::min<size_t>((uc.cap + kBlock - 1) / kBlock, 1024);
+      rc = allow_lds(k_patch_pairs, ldsc);
+      if (rc != MJPL_OK) return rc;
+      GeomTable gt = {e->d_geomtab};
+      hipLaunchKernelGGL(k_patch_pairs, dim3(pgrid), dim3(kBlock), ldsc, e->stream, e->d_ip, (int)e->ip.size(),
+                         e->d_dp, (int)e->dp.size(), gt, uc, dvalid, (int32_t *)nullptr);
+    }
   }
   const size_t lds = lds_bytes(e, 1);
   int rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
