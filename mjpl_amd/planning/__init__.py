@@ -1,8 +1,17 @@
-from .cartesian_planner import cartesian_plan
-from .parallel_rrt import EdgeValidator, HipEdgeValidator, ParallelBiRRT
-from .rrt import RRT
-from .tree import Node, Tree
-from .utils import path_length, smooth_path
+"""Planners on top of the batched constraints: the reference-shaped serial RRT, the
+frontier-sharded bi-RRT (one batched launch per extension round), Cartesian path following and
+the path utilities."""
+from . import cartesian_planner as _cart
+from . import parallel_rrt as _prrt
+from . import rrt as _rrt
+from . import tree as _tree
+from . import utils as _utils
 
-__all__ = ("RRT", "Node", "Tree", "path_length", "smooth_path", "ParallelBiRRT", "EdgeValidator",
-           "HipEdgeValidator", "cartesian_plan")
+RRT = _rrt.RRT
+ParallelBiRRT, EdgeValidator, HipEdgeValidator = _prrt.ParallelBiRRT, _prrt.EdgeValidator, _prrt.HipEdgeValidator
+Node, Tree = _tree.Node, _tree.Tree
+cartesian_plan = _cart.cartesian_plan
+smooth_path, path_length = _utils.smooth_path, _utils.path_length
+
+__all__ = ["RRT", "ParallelBiRRT", "EdgeValidator", "HipEdgeValidator", "Node", "Tree", "cartesian_plan",
+           "smooth_path", "path_length"]

@@ -1,8 +1,11 @@
 """Cartesian path following (reference src/mjpl/planning/cartesian_planner.py:11-104): the host
-loop around the batched IK solver -- interpolate the poses, solve IK seeded with the previous
-waypoint, keep the candidates that obey the constraints (and the collision interval check), take
-the one closest to the previous waypoint."""
+loop around the batched IK solver.  Poses are densified so that neighbours are at most
+``lin_threshold`` / ``ori_threshold`` apart; each pose is solved with the previous waypoint as
+the seed; of the candidates that obey the constraints (and, if asked, the collision interval
+from the previous waypoint) the one nearest to the previous waypoint is kept."""
 from __future__ import annotations
+
+import math
 
 import numpy as np
 
@@ -14,32 +17,38 @@ from .utils import _valid_collision_interval
 
 
 def _interpolate_poses(pose_from: SE3, pose_to: SE3, lin_threshold: float, ori_threshold: float) -> list[SE3]:
-    if lin_threshold <= 0.0:
-        raise ValueError("`lin_threshold` must be > 0.0")
-    if ori_threshold <= 0.0:
-        raise ValueError("`ori_threshold` must be > 0.0")
-    diff = pose_to.minus(pose_from)
-    lin_steps = int(np.ceil(np.linalg.norm(diff[:3]) / lin_threshold))
-    ori_steps = int(np.ceil(np.linalg.norm(diff[3:]) / ori_threshold))
-    num_steps = max(lin_steps, ori_steps, 1)
-    return [pose_from.interpolate(pose_to, alpha) for alpha in np.linspace(0, 1, num_steps + 1)]
+    """``pose_from`` ... ``pose_to`` inclusive, decoupled translation / rotation distances (:11-42)."""
+    for name, value in (("lin_threshold", lin_threshold), ("ori_threshold", ori_threshold)):
+        if value <= 0.0:
+            raise ValueError(f"`{name}` must be > 0.0")
+    tangent = pose_to.minus(pose_from)
+    need = (math.ceil(float(np.linalg.norm(tangent[:3])) / lin_threshold),
+            math.ceil(float(np.linalg.norm(tangent[3:])) / ori_threshold), 1)
+    alphas = np.linspace(0, 1, max(need) + 1)
+    return [pose_from.interpolate(pose_to, float(a)) for a in alphas]
 
 
 def cartesian_plan(q_init: np.ndarray, poses: list[SE3], site: str, solver: IKSolver,
                    constraints: list[Constraint], collision_interval_check=None,
                    lin_threshold: float = 0.01, ori_threshold: float = 0.1) -> list[np.ndarray]:
+    """Waypoints from ``q_init`` through IK solutions of the densified ``poses``; ``[]`` as soon as
+    one pose has no admissible solution (:44-104)."""
     if not site:
         raise ValueError("`site` must be defined.")
-    interpolated = [poses[0]]
-    for i in range(len(poses) - 1):
-        interpolated.extend(_interpolate_poses(poses[i], poses[i + 1], lin_threshold, ori_threshold)[1:])
-    waypoints = [q_init]
-    for p in interpolated:
-        configs = [q for q in solver.solve_ik(p, site, q_init_guess=waypoints[-1])
-                   if obeys_constraints(q, constraints)
-                   and (not collision_interval_check
-                        or _valid_collision_interval(waypoints[-1], q, *collision_interval_check))]
-        if not configs:
+    dense = list(poses[:1])
+    for a, b in zip(poses[:-1], poses[1:]):
+        dense += _interpolate_poses(a, b, lin_threshold, ori_threshold)[1:]
+
+    def admissible(q, prev):
+        if not obeys_constraints(q, constraints):
+            return False
+        return not collision_interval_check or _valid_collision_interval(prev, q, *collision_interval_check)
+
+    path = [q_init]
+    for pose in dense:
+        prev = path[-1]
+        good = [q for q in solver.solve_ik(pose, site, q_init_guess=prev) if admissible(q, prev)]
+        if not good:
             return []
-        waypoints.append(min(configs, key=lambda q: np.linalg.norm(q - waypoints[-1])))
-    return waypoints
+        path.append(good[int(np.argmin([np.linalg.norm(q - prev) for q in good]))])
+    return path
