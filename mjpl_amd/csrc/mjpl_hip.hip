@@ -944,6 +944,68 @@ k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ g
   }
 }
 
+
+// Partial nearest neighbour: block (x, y) scans node chunk y for 256 queries (two per thread, held
+// in registers; node tiles are staged through LDS and read as broadcasts: 14 float64 FMAs-worth
+// of work per 8-byte LDS read per pair of queries).  Distances are the same sequential-sum squared
+// norms as before; ties go to the lowest node index (strict `<`, chunks reduced in order).
+constexpr int kNNThreads = 128, kNNMaxPlan = 16;
+
+__global__ void __launch_bounds__(kNNThreads)
+k_nearest_part(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
+               int64_t M, int nplan, int64_t chunk, int32_t *__restrict__ pidx, double *__restrict__ pd2) {
+  __shared__ double tile[kNNMaxPlan * kNNThreads];
+  const int t = threadIdx.x;
+  const int64_t j0 = (int64_t)blockIdx.x * (2 * kNNThreads) + t, j1 = j0 + kNNThreads;
+  double qa[kNNMaxPlan], qb[kNNMaxPlan];
+#pragma unroll
+  for (int c = 0; c < kNNMaxPlan; c++) {
+    qa[c] = (c < nplan && j0 < M) ? queries[(int64_t)c * M + j0] : 0.0;
+    qb[c] = (c < nplan && j1 < M) ? queries[(int64_t)c * M + j1] : 0.0;
+  }
+  const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  double besta = std::numeric_limits<double>::infinity(), bestb = besta;
+  int32_t ia = -1, ib = -1;
+  for (int64_t base = lo; base < hi; base += kNNThreads) {
+    __syncthreads();
+    const int64_t src = base + t;
+    for (int c = 0; c < nplan; c++) tile[c * kNNThreads + t] = (src < hi) ? nodes[(int64_t)c * cap + src] : 0.0;
+    __syncthreads();
+    const int lim = (int)((hi - base) < kNNThreads ? (hi - base) : kNNThreads);
+    for (int k = 0; k < lim; k++) {
+      double sa = 0, sb = 0;
+#pragma unroll
+      for (int c = 0; c < kNNMaxPlan; c++) {
+        if (c < nplan) {
+          const double v = tile[c * kNNThreads + k];
+          const double da = v - qa[c], db = v - qb[c];
+          sa = sa + da * da;
+          sb = sb + db * db;
+        }
+      }
+      if (sa < besta) { besta = sa; ia = (int32_t)(base + k); }
+      if (sb < bestb) { bestb = sb; ib = (int32_t)(base + k); }
+    }
+  }
+  if (j0 < M) { pidx[(int64_t)blockIdx.y * M + j0] = ia; pd2[(int64_t)blockIdx.y * M + j0] = besta; }
+  if (j1 < M) { pidx[(int64_t)blockIdx.y * M + j1] = ib; pd2[(int64_t)blockIdx.y * M + j1] = bestb; }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_nearest_reduce(const int32_t *__restrict__ pidx, const double *__restrict__ pd2, int64_t M, int nchunks,
+                 int32_t *__restrict__ out_idx, double *__restrict__ out_d2) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  double best = std::numeric_limits<double>::infinity();
+  int32_t bi = -1;
+  for (int y = 0; y < nchunks; y++) {
+    const double d = pd2[(int64_t)y * M + j];
+    if (d < best) { best = d; bi = pidx[(int64_t)y * M + j]; }
+  }
+  out_idx[j] = bi;
+  if (out_d2) out_d2[j] = best;
+}
+
 // ------------------------------------------------------------------------------- host model
 
 struct HostModel {
@@ -993,6 +1055,8 @@ struct mjpl_engine {
   double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
   int *d_ucedge = nullptr, *d_ucidx = nullptr, *d_ucga = nullptr, *d_ucgb = nullptr;
   double *d_geomtab = nullptr;  // GTB_LEN doubles per model geom (k_patch_pairs)
+  void *d_nn = nullptr;         // nearest neighbour: per-chunk partial results
+  size_t nn_bytes = 0;
   size_t uc_cap = 0;
   int nslots = 0, nsave = 0, maxs = 4;
   bool wbox = false, mbox = false;
@@ -1722,6 +1786,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_ucga) (void)hipFree(e->d_ucga);
   if (e->d_ucgb) (void)hipFree(e->d_ucgb);
   if (e->d_geomtab) (void)hipFree(e->d_geomtab);
+  if (e->d_nn) (void)hipFree(e->d_nn);
   if (e->d_ucq) (void)hipFree(e->d_ucq);
   if (e->d_ucedge) (void)hipFree(e->d_ucedge);
   if (e->d_ucidx) (void)hipFree(e->d_ucidx);
@@ -1834,6 +1899,30 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
   if (!dnodes || !dqueries || !dout_idx) return fail(MJPL_E_ARG, "mjpl_nearest_dev: NULL pointer");
   HIP_TRY(hipSetDevice(e->device));
   const int nplan = (int)e->qidx.size();
+  if (nplan <= kNNMaxPlan && n > 0) {
+    // 2-D decomposition: 256 queries per block x node chunks, then a reduction over the chunks
+    const int64_t qtiles = (M + 2 * kNNThreads - 1) / (2 * kNNThreads);
+    int64_t nchunks = std::max<int64_t>(1, (1024 + qtiles - 1) / qtiles);
+    nchunks = std::min<int64_t>(nchunks, (n + kNNThreads - 1) / kNNThreads);
+    int64_t chunk = (n + nchunks - 1) / nchunks;
+    chunk = (chunk + kNNThreads - 1) / kNNThreads * kNNThreads;
+    nchunks = (n + chunk - 1) / chunk;
+    const size_t need = (size_t)nchunks * (size_t)M * (sizeof(double) + sizeof(int32_t));
+    if (need > e->nn_bytes) {
+      if (e->d_nn) HIP_TRY(hipFree(e->d_nn));
+      e->d_nn = nullptr; e->nn_bytes = 0;
+      HIP_TRY(hipMalloc(&e->d_nn, need));
+      e->nn_bytes = need;
+    }
+    double *pd2 = (double *)e->d_nn;
+    int32_t *pidx = (int32_t *)(pd2 + (size_t)nchunks * (size_t)M);
+    hipLaunchKernelGGL(k_nearest_part, dim3((unsigned)qtiles, (unsigned)nchunks), dim3(kNNThreads), 0, e->stream,
+                       dnodes, n, cap, dqueries, M, nplan, chunk, pidx, pd2);
+    hipLaunchKernelGGL(k_nearest_reduce, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       pidx, pd2, M, (int)nchunks, dout_idx, dout_dist2);
+    HIP_TRY(hipGetLastError());
+    return MJPL_OK;
+  }
   const size_t lds = 2 * (size_t)nplan * kBlock * sizeof(double);
   int rc = allow_lds(k_nearest, lds);
   if (rc != MJPL_OK) return rc;

@@ -93,8 +93,17 @@ __device__ __forceinline__ void pinv_sym6_apply(double (&A)[6][6], const double 
   for (int i = 0; i < 6; i++)
 #pragma unroll
     for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+  // sweeps until the off-diagonal mass is below 1e-40 of the diagonal mass (the oracle's rule)
 #pragma unroll 1
   for (int sweep = 0; sweep < 12; sweep++) {
+    double off = 0, dia = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+      dia = dia + A[p][p] * A[p][p];
+#pragma unroll
+      for (int q = p + 1; q < 6; q++) off = off + A[p][q] * A[p][q];
+    }
+    if (off <= 1e-40 * dia) break;
     jacobi_rotate<0, 1>(A, V); jacobi_rotate<0, 2>(A, V); jacobi_rotate<0, 3>(A, V);
     jacobi_rotate<0, 4>(A, V); jacobi_rotate<0, 5>(A, V); jacobi_rotate<1, 2>(A, V);
     jacobi_rotate<1, 3>(A, V); jacobi_rotate<1, 4>(A, V); jacobi_rotate<1, 5>(A, V);

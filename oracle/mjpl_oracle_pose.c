@@ -202,15 +202,22 @@ int orc_pose_jacobian(const orc_model *m, const orc_pose *p, const double *qpos,
   return ORC_OK;
 }
 
-/* np.linalg.pinv(A) for symmetric A (6x6): A = V diag(w) V^T by cyclic Jacobi rotations
- * (a fixed 12 sweeps; a 6x6 converges quadratically in ~6), then V diag(1/w_i if w_i >
- * 1e-15 * max w else 0) V^T -- numpy's default cutoff rcond = 1e-15 on the singular values. */
+/* np.linalg.pinv(A) for symmetric A (6x6): A = V diag(w) V^T by cyclic Jacobi rotations (sweeps
+ * until the off-diagonal mass is below 1e-40 of the diagonal mass, i.e. |off| <= 1e-20 |diag|;
+ * at most 12; a 6x6 converges quadratically in ~6), then V diag(1/w_i if w_i > 1e-15 * max w
+ * else 0) V^T -- numpy's default cutoff rcond = 1e-15 on the singular values. */
 #define ORC_JACOBI_SWEEPS 12
 void orc_pinv_sym6(const double *Ain, double *out) {
   double A[6][6], V[6][6];
   for (int i = 0; i < 6; i++)
     for (int j = 0; j < 6; j++) { A[i][j] = Ain[6 * i + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
   for (int sweep = 0; sweep < ORC_JACOBI_SWEEPS; sweep++) {
+    double off = 0, dia = 0;
+    for (int p = 0; p < 6; p++) {
+      dia = dia + A[p][p] * A[p][p];
+      for (int q = p + 1; q < 6; q++) off = off + A[p][q] * A[p][q];
+    }
+    if (off <= 1e-40 * dia) break;
     for (int p = 0; p < 5; p++) {
       for (int q = p + 1; q < 6; q++) {
         const double apq = A[p][q];

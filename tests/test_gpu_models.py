@@ -128,6 +128,21 @@ def test_nearest_neighbour_kernel():
     ref = np.where(np.isfinite(ref), ref, np.inf).sum(0)
     np.testing.assert_array_equal(idx, ref.argmin(1))
     assert idx[5] == 123 and d2[5] == 0.0
+    # ties go to the lowest index also across node chunks; tiny and ragged sizes
+    for n2, M2 in ((1, 3), (127, 1), (129, 300), (40000, 513)):
+        nodes2 = rng.uniform(-2, 2, size=(7, n2))
+        if n2 > 100:
+            nodes2[:, n2 - 1] = nodes2[:, 3]      # an exact duplicate far away in index
+            nodes2[:, n2 // 2] = nodes2[:, 3]
+        q2 = rng.uniform(-2, 2, size=(7, M2))
+        q2[:, 0] = nodes2[:, min(3, n2 - 1)]
+        dn2, dq2 = e.alloc(nodes2.nbytes).upload(nodes2), e.alloc(q2.nbytes).upload(q2)
+        di2 = e.alloc(4 * M2)
+        e.nearest_dev(dn2.ptr, n2, n2, dq2.ptr, M2, di2.ptr)
+        got = di2.download(np.int32, M2)
+        want = ((nodes2[:, None, :] - q2[:, :, None]) ** 2).sum(0).argmin(1)
+        np.testing.assert_array_equal(got, want)
+        assert got[0] == min(3, n2 - 1)
 
 
 def test_dropin_constraint_and_planner_equivalence(oracle_mod):
