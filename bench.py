@@ -82,6 +82,49 @@ def traffic_from_profile(workload_key):
         return None
 
 
+def bench_configs(args):
+    """BASELINE configs[1] on one GPU: N = 65 536 Franka-P configurations, self-collision + floor,
+    q ~ U[jnt_range] (default_rng(1)), verdicts checked against the oracle on a sample."""
+    from mjpl_amd import engine, scenes
+    model = scenes.franka_p(obstacles=False)
+    qidx = scenes.planning_index(model, scenes.FRANKA_ARM_JOINTS)
+    base = model.keyframe("home").qpos.copy()
+    eng = engine.Engine(model)
+    eng.set_planning(qidx, base)
+    N = 65536
+    Q = np.random.default_rng(1).uniform(model.jnt_range[qidx, 0], model.jnt_range[qidx, 1], size=(N, len(qidx)))
+    h = np.ascontiguousarray(Q.T)
+    dq, dv = eng.alloc(h.nbytes).upload(h), eng.alloc(N)
+    if args.warmup > 0:
+        eng.time_configs_dev(dq.ptr, N, engine.SOA, dv.ptr, args.warmup)
+    eng.sync()
+    t0 = time.perf_counter()
+    ms = eng.time_configs_dev(dq.ptr, N, engine.SOA, dv.ptr, args.steps)
+    elapsed = time.perf_counter() - t0
+    valid = dv.download(np.uint8, N)
+    out = {"metric": "validated configurations/sec, Franka-P self-collision (BASELINE configs[1])",
+           "value": N * args.steps / elapsed, "unit": "configs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"configs[1]: Franka-P 7-DoF, self-collision + floor, {N} configurations/launch",
+                      "valid_fraction": float(valid.mean()), "step_ms_hip_events": float(np.mean(ms))},
+           "roofline": {"bound": "hbm", "achieved": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "note": "57 algorithmic bytes per configuration; ALU/issue bound"}}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        orc = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        v = orc.valid_configs(Q, nthreads=cores)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": N / dt, "unit": "configs/s", "cores": cores, "kind": "port",
+                               "sample": f"one pass over the {N} configurations, {cores} pthreads"}
+        if not np.array_equal(v.astype(np.uint8), valid):
+            sys.exit("bench.py: GPU verdicts differ from the CPU oracle")
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +133,12 @@ def main():
     ap.add_argument("--edges", type=int, default=EDGES_PER_GPU)
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["edges", "configs"], default="edges",
+                    help="edges: the headline metric (BASELINE configs[2]); configs: BASELINE configs[1], "
+                         "65 536 Franka-P self-collision configurations per launch (an extra line, not the headline)")
     args = ap.parse_args()
+    if args.workload == "configs":
+        return bench_configs(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
