@@ -83,7 +83,7 @@ enum : int { JF_POS_NONZERO = 1 };
 
 // geom record: 10 header ints, then MAX_SLOTS stored-partner words (0 where the slot is no partner)
 enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_SMASK, G_WMASK_LO, G_WMASK_HI,
-             G_PMASK_LO, G_PMASK_HI, G_NENT, G_ENT_OFF, G_SIZE };
+             G_PMASK_LO, G_PMASK_HI, G_SIZE };
 enum : int { GF_SAMEPOS = 1, GF_SAMEROT = 2 };
 enum : int { MAX_SLOTS = 16 };
 // geom constants: lpos[3] lquat[4] size[3] pad[2] | wbound[nwpad] | wmargin[nwpad]
@@ -106,14 +106,7 @@ enum : int { P_FIRST = 1 << 17 };
 //   cull table   [nwpad][4] : pos[3], info word (type | geom id << 8)
 //   narrow table [nworld][12]: z axis[3], x axis[3], y axis[3], size[3]
 enum : int { WC_POS = 0, WC_INFO = 3, WC_LEN = 4 };
-// unified partner entries of a geom (queued kernels): one fixed-stride record per enabled pair,
-// planes first, then the other static geoms, then the register slots -- everything a bounding
-// cull and a queue push need, so the next entry is a single wide scalar load
-//   [0] word  [1] cull bound  [2..4] partner pos (static)  [5] pair margin
-//   [6..8] partner z axis (static: plane normal / capsule axis)  [9..11] partner size
-//   word: bits 0..1 kind (0 plane, 1 other static, 2 register slot) ; bits 2..9 row or slot ;
-//         bits 12..15 partner type ; bit 17 = the partner is g1 of mj_collision's (g1, g2)
-enum : int { E_WORD = 0, E_BOUND, E_POS, E_MARGIN = 5, E_ZAXIS = 6, E_SIZE = 9, E_LEN = 12 };
+// candidate kinds in the queued kernels' records
 enum : int { EK_PLANE = 0, EK_STATIC = 1, EK_SLOT = 2 };
 enum : int { WN_ZAXIS = 0, WN_XAXIS = 3, WN_YAXIS = 6, WN_SIZE = 9, WN_LEN = 12 };
 

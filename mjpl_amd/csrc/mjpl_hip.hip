@@ -1346,9 +1346,6 @@ int compile_program(mjpl_engine *e) {
       ip.push_back((int)(uint32_t)(wmask >> 32));
       ip.push_back((int)(uint32_t)(pmask & 0xffffffffull));
       ip.push_back((int)(uint32_t)(pmask >> 32));
-      const size_t nent_at = ip.size();
-      ip.push_back(0);  // G_NENT
-      ip.push_back(0);  // G_ENT_OFF
       const size_t swords_at = ip.size();
       ip.insert(ip.end(), MAX_SLOTS, 0);
       for (int k3 = 0; k3 < 3; k3++) dp.push_back(gp[k3]);
@@ -1405,7 +1402,7 @@ int compile_program(mjpl_engine *e) {
 
   // the kernels prefetch one entry past the one they test: keep that read inside the tables
   ip.insert(ip.end(), 32, 0);
-  dp.insert(dp.end(), 2 * E_LEN, 0.0);
+  dp.insert(dp.end(), 24, 0.0);
 
   // ---- the filter's float32 image: same offsets; cull bounds widened by the tolerance so that
   // a pair culled in float32 is certainly culled (or contact-free) in float64
