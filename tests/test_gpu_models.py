@@ -13,7 +13,9 @@ from helpers import OracleCollisionConstraint, random_edges, uniform_configs
 pytestmark = pytest.mark.gpu
 
 
-def random_model(seed):
+def random_model(seed, moving_boxes=True):
+    """moving_boxes=False keeps boxes on the world body only: such models run the queued float32
+    interpreter (two candidate queues, pair-level exact re-check) instead of the immediate one."""
     rng = np.random.default_rng(seed)
     mb = ModelBuilder()
     if rng.random() < 0.8:
@@ -51,7 +53,7 @@ def random_model(seed):
                 pos = rng.uniform(-0.1, 0.1, 3) if rng.random() < 0.4 else (0, 0, 0)
                 rngj = (-2.5, 2.5) if jt == "hinge" else (-0.3, 0.3)
                 mb.add_joint(name, f"j{b}_{j}", jt, axis=axis, pos=pos, range=rngj, ref=float(rng.choice([0, 0, 0.2])))
-        add_geoms(name, int(rng.integers(1, 3)), allow_box=True)
+        add_geoms(name, int(rng.integers(1, 3)), allow_box=moving_boxes)
         names.append(name)
     model = mb.compile()
     nallowed = int(rng.integers(0, 3))
@@ -60,9 +62,15 @@ def random_model(seed):
     return model, allowed
 
 
-@pytest.mark.parametrize("seed", range(24))
+def _fuzz_seeds():
+    import os
+    n = int(os.environ.get("MJPL_FUZZ_SEEDS", "12"))
+    return list(range(1000, 1000 + n))
+
+
+@pytest.mark.parametrize("seed", list(range(24)) + _fuzz_seeds())
 def test_random_models_match_oracle(oracle_mod, seed):
-    model, allowed = random_model(seed)
+    model, allowed = random_model(seed % 1000 if seed >= 1000 else seed, moving_boxes=seed < 1000)
     e = eng_mod.Engine(model, allowed)
     orc = oracle_mod.Oracle(model, allowed)
     Q = uniform_configs(model, 4096, seed=100 + seed)
@@ -235,3 +243,38 @@ def test_gpu_nearest_neighbour_in_the_planner_matches_host(oracle_mod):
     assert len(paths[0]) == len(paths[1]) > 2
     for a, b in zip(*paths):
         np.testing.assert_array_equal(a, b)
+
+
+def test_dense_clutter_stresses_the_candidate_queues(oracle_mod):
+    """A 7-link arm with two capsules per link inside 48 tightly packed static spheres, capsules
+    and boxes: most lanes pass many bounding culls, so the per-wave candidate queues fill and
+    drain several times per geom, and many pairs fall into the float32 tolerance band."""
+    rng = np.random.default_rng(77)
+    mb = ModelBuilder()
+    mb.add_geom("world", "plane", (1, 1, 0.1), pos=(0, 0, -0.35))
+    for k in range(48):
+        kind = ["sphere", "capsule", "box"][k % 3]
+        size = {"sphere": (0.07,), "capsule": (0.04, 0.1), "box": (0.06, 0.05, 0.07)}[kind]
+        q = rng.normal(size=4)
+        mb.add_geom("world", kind, size, pos=rng.uniform(-0.45, 0.45, 3), quat=q / np.linalg.norm(q))
+    parent = "world"
+    for b in range(7):
+        name = f"l{b}"
+        mb.add_body(name, parent, pos=(0, 0, 0.12) if b else (0, 0, -0.3))
+        mb.add_joint(name, f"j{b}", "hinge", axis=np.eye(3)[b % 3], range=(-2.6, 2.6))
+        mb.add_geom(name, "capsule", (0.03, 0.05), pos=(0, 0, 0.06))
+        mb.add_geom(name, "sphere" if b % 2 else "capsule", (0.035, 0.03)[: 1 if b % 2 else 2], pos=(0.03, 0, 0.02))
+        parent = name
+    model = mb.compile()
+    e = eng_mod.Engine(model)
+    orc = oracle_mod.Oracle(model)
+    Q = uniform_configs(model, 20000, seed=5)
+    want = orc.valid_configs(Q, nthreads=8)
+    np.testing.assert_array_equal(e.check_configs(Q), want)
+    assert 0 < want.sum() < len(Q)
+    qa, qb = random_edges(model, np.arange(model.nq), 6000, seed=6, eps=0.15)
+    w, wfb, _ = orc.valid_edges(qa, qb, 0.02, nthreads=8, info=True)
+    g, gfb = e.check_edges(qa, qb, 0.02, first_bad=True)
+    np.testing.assert_array_equal(g, w)
+    np.testing.assert_array_equal(gfb, wfb)
+    assert e.last_undecided() > 0
