@@ -203,12 +203,19 @@ def main():
         value = total_edges / elapsed
         launch_ms = float(np.mean(ms))          # all kernels of one step (filter + exact re-run)
         kernel_ms = float(np.mean(ms_kernel))   # the dominant kernel alone
-        kernel = "k_filter_edges" if info["filter_enabled"] else "k_check_edges"
-        # The filter runs two passes (endpoints of all edges, then the interior waypoints of the
-        # edges whose endpoint passed).  The dominant kernel is the interior pass: its units are the
-        # edges it took, each 2 x 56 B of columns + a 4 B list index read and 1 B written.
+        # The filter runs two passes: the endpoints of all edges (which also writes the interior
+        # waypoints of the edges whose endpoint passed as work items), then one lane per waypoint
+        # item.  The dominant kernel is the item pass: a unit is one configuration check, 56 B of
+        # columns + 8 B (edge, index) read and 1 B written (57 B per check, + the item).
         interior = eng.last_interior_edges() if info["filter_enabled"] else 0
-        units, unit_bytes = (interior, BYTES_PER_EDGE + 4) if interior > 0 else (E, BYTES_PER_EDGE)
+        items = eng.last_items() if info["filter_enabled"] else 0
+        if items > 0:
+            kernel, units, unit_bytes, unit_name = "k_filter_items", items, 57 + 8, "waypoint configurations"
+        elif interior > 0:
+            kernel, units, unit_bytes, unit_name = "k_filter_edges", interior, BYTES_PER_EDGE + 4, "edges"
+        else:
+            kernel = "k_filter_edges" if info["filter_enabled"] else "k_check_edges"
+            units, unit_bytes, unit_name = E, BYTES_PER_EDGE, "edges"
         achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9
         workload = (f"configs[2]: Franka-P 7-DoF + 16 box/sphere obstacles + floor, {E} edges/GPU, "
                     f"eps {EPS}, step {STEP} (endpoint + interior waypoints per edge)")
@@ -221,13 +228,14 @@ def main():
                        "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
                        "float32_filter": bool(info["filter_enabled"]), "filter_tol_m": info["filter_tol"],
                        "undecided_items_last_step": eng.last_undecided(),
-                       "edges_reaching_interior_pass": interior,
+                       "edges_reaching_interior_pass": interior, "interior_waypoint_items": items,
                        "parallelism": f"edge-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic_from_profile("%s_%d_%s" % (kernel, E, args.layout)),
                          "kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms,
-                         "algorithmic_bytes_per_edge": unit_bytes, "edges_in_this_kernel": units,
+                         "algorithmic_bytes_per_unit": unit_bytes, "units_in_this_kernel": units,
+                         "unit_of_work": unit_name,
                          "note": "ALU/issue bound, not HBM bound (SURVEY.md 8d); see roofline_valu"},
             "roofline_valu": {"bound": "vector_alu", "achieved": FLOPS_PER_EDGE * E / (launch_ms * 1e-3) / 1e12,
                               "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",

@@ -134,6 +134,11 @@ int64_t mjpl_filter_last_undecided(mjpl_engine *e);
  * many edges the interior pass of the most recent mjpl_check_edges* took (synchronises); 0 for a
  * one-pass launch, -1 if the filter is off. */
 int64_t mjpl_filter_last_interior_edges(mjpl_engine *e);
+/* The interior pass runs one lane per waypoint: a small kernel walks the waypoint recurrence of
+ * every surviving edge once and writes the waypoints out as work items (MJPL_EXPAND=0 at create:
+ * one lane per edge walks them; edges of more than ~24 waypoints always do).  Returns how many
+ * waypoint items the most recent mjpl_check_edges* checked (synchronises); -1 if never used. */
+int64_t mjpl_filter_last_items(mjpl_engine *e);
 
 /* ---- host-buffer entry points (stage H2D, run, copy back, synchronise) ---------- */
 

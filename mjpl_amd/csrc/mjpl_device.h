@@ -1066,7 +1066,8 @@ struct PatchSink {
   UndecidedConfigs uc;
   const double *qcol;  // LDS columns of this wave's lanes: q[k] of lane l at qcol[k * B + l]
   int B, nplan;
-  int idx;             // check index of the configurations under test (wave-uniform)
+  int idx;             // check index of the configurations under test (wave-uniform) ...
+  const int *item_edge, *item_idx;  // ... or, lane-per-waypoint kernels: (edge, index) of item i
 };
 
 // ----------------------------------------------------------------------------- queued narrowphase
@@ -1212,8 +1213,9 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
         const int u = atomicAdd(ps.uc.count, 1);
         if (u < ps.uc.cap) {
           for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + owner];
-          ps.uc.edge[u] = (int)((unsigned)wq.flags[owner] >> 2);
-          ps.uc.idx[u] = ps.idx;
+          const int item = (int)((unsigned)wq.flags[owner] >> 2);
+          ps.uc.edge[u] = ps.item_edge ? ps.item_edge[item] : item;
+          ps.uc.idx[u] = ps.item_idx ? ps.item_idx[item] : ps.idx;
           ps.uc.ga[u] = (int)gd[GD_GEOMID];
           int gb;
           if (!BOXQ && kind == EK_SLOT) gb = (int)gd[GD_WBOUND + 2 * nwpad + GS_GEOMID + index];

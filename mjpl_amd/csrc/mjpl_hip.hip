@@ -83,7 +83,8 @@ __device__ __forceinline__ WaveQueue<T> wave_queue(char *qmem) {
 template <class T, int MAXS, bool WBOX, bool MBOX>
 __device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int B, bool active, T tol,
                                          int64_t row, const UndecidedConfigs &uc = UndecidedConfigs{},
-                                         int idx = 0) {
+                                         int idx = 0, const int *item_edge = nullptr,
+                                         const int *item_idx = nullptr) {
   if constexpr (kQueued<T, MBOX>) {
     WaveQueue<T> wq = wave_queue<T>(c.qmem);
     PatchSink ps;
@@ -92,6 +93,8 @@ __device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int
     ps.B = B;
     ps.nplan = c.ip[H_NPLAN];
     ps.idx = idx;
+    ps.item_edge = item_edge;
+    ps.item_idx = item_idx;
     return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, c.ltab, q, B, c.save + threadIdx.x, B, active, tol, wq,
                                             (int)row, ps);
   } else {
@@ -370,6 +373,119 @@ k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ g
                                      first_bad, status, ulist, ucount, rlist, rcount, uc);
 }
 
+// ---- lane-per-waypoint interior pass --------------------------------------------------------
+// The walking kernel gives every surviving edge one lane for all of its waypoints: at config-3
+// size that is 2 300 waves for 1 024 SIMDs, each alive for the whole kernel.  Here the waypoints
+// themselves become the work items: the endpoint kernel walks the reference's recurrence for
+// every edge whose endpoint passed (float64, the statements of edge_body) and writes the interior
+// waypoints into a dense SoA buffer; k_filter_items checks one waypoint per lane.  Consecutive
+// items are consecutive waypoints of one edge, so the lanes of a wave see similar poses and pass
+// the same bounding culls.  Edges with many waypoints stay with the walking kernel: `llist`.
+struct ItemBuffers {
+  double *w;        // [nplan][cap] waypoints, SoA
+  int *edge, *idx;  // [cap] which edge, which check index (1..K)
+  int *count;       // items written
+  int cap;
+  int *llist, *lcount;  // edges left to the walking kernel
+};
+constexpr int kExpandMaxWaypoints = 24;  // longer edges take the walking kernel
+
+// qe: this lane's edge end QB (LDS, stride B); qw: scratch for the walking waypoint (LDS, stride
+// ws).  `todo` lanes own an edge i whose interior waypoints are wanted.
+__device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const double *__restrict__ QA,
+                                            int64_t E, int64_t i, double step, int layout, bool todo,
+                                            const double *qe, int B, double *qw, int ws,
+                                            const ItemBuffers &ib) {
+  const int nplan = gip[H_NPLAN];
+  const int *perm = gip + gip[H_OFF_PERM];
+  const int lane = threadIdx.x & 63;
+  auto start_col = [&](int k) -> double {
+    return todo ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
+  };
+  bool at_end = true;
+  for (int k = 0; k < nplan; k++) {
+    const double a = start_col(k);
+    qw[k * ws] = a;
+    at_end = at_end && (a == qe[k * B]);
+  }
+  double s0 = 0;
+  for (int k = 0; k < nplan; k++) {
+    const int col = perm[k];
+    const double d = qe[col * B] - qw[col * ws];
+    s0 = s0 + d * d;
+  }
+  bool done = !todo || at_end;
+  if (!done && !(sqrt(s0) <= step * (kExpandMaxWaypoints - 2))) {  // long edge
+    ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
+    done = true;
+  }
+  // one step of the recurrence: _step(w, QB, step)  (planning/utils.py:182-185; the statements of
+  // edge_body); returns true when the walk has arrived at QB
+  auto advance = [&]() -> bool {
+    double s = 0;
+    for (int k = 0; k < nplan; k++) {
+      const int col = perm[k];
+      double d = qe[col * B] - qw[col * ws];
+      s = s + d * d;
+    }
+    const double mag = sqrt(s);
+    const double sm = step < mag ? step : mag;
+    bool eq = true;
+    for (int k = 0; k < nplan; k++) {
+      const double ek = qe[k * B];
+      double d = ek - qw[k * ws];
+      double nw = qw[k * ws] + (d / mag) * sm;
+      qw[k * ws] = nw;
+      eq = eq && (nw == ek);
+    }
+    return eq;
+  };
+  // first walk: how many interior waypoints does this edge have?
+  int K = 0;
+  {
+    bool walking = !done;
+    while (__ballot(walking) != 0ull) {
+      if (walking) {
+        if (advance()) walking = false;
+        else if (++K > kExpandMaxWaypoints) walking = false;
+      }
+    }
+  }
+  if (!done && K > kExpandMaxWaypoints) {  // the estimate was off: the walking kernel takes the edge
+    ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
+    done = true;
+  }
+  if (done) K = 0;
+  // one reservation per wave: lane l owns slots [base + sum_{l' < l} K_l', +K_l)
+  int incl = K;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
+  }
+  const int total = __shfl(incl, 63);
+  if (total == 0) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(ib.count, total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const int first = base + incl - K;
+  if (!done && first + K > ib.cap) {  // out of item space: the walking kernel takes the edge
+    ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
+    for (int slot = first; slot < ib.cap; slot++) ib.edge[slot] = -1;  // reserved but void
+    done = true;
+  }
+  // second walk: write the waypoints
+  for (int k = 0; k < nplan; k++) qw[k * ws] = start_col(k);
+  for (int idx = 1; __ballot(!done && idx <= K) != 0ull; idx++) {
+    if (!done && idx <= K) {
+      advance();
+      const int slot = first + idx - 1;
+      for (int k = 0; k < nplan; k++) ib.w[(size_t)k * ib.cap + slot] = qw[k * ws];
+      ib.edge[slot] = (int)i;
+      ib.idx[slot] = idx;
+    }
+  }
+}
+
 // Endpoint pass of the two-pass edge filter: check 0 (the endpoint QB, utils.py:144) for every
 // edge with full lanes; edges whose endpoint is free (or undecided) are appended to `slist` for
 // the interior pass, so that pass runs only on edges that still need it -- in an RRT batch a
@@ -381,7 +497,8 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
                    const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, int layout,
                    float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
                    int *__restrict__ status, int *__restrict__ ulist, int *__restrict__ ucount,
-                   UndecidedConfigs uc, int *__restrict__ slist, int *__restrict__ scount) {
+                   UndecidedConfigs uc, int *__restrict__ slist, int *__restrict__ scount, ItemBuffers ib,
+                   double step) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
   const int nplan = gip[H_NPLAN];
@@ -431,14 +548,28 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
     }
   }
   const unsigned long long m = __ballot(survive);
-  if (m != 0ull) {
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(scount, (int)__builtin_popcountll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (survive)
-      slist[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)i;
+  if (m == 0ull) return;
+  if (ib.count) {
+    // lane-per-waypoint interior pass: emit this edge's interior waypoints as work items.  The
+    // walking waypoint lives in this wave's (now idle) candidate-queue memory.
+    if constexpr (kQueued<float, MBOX>) {
+      if ((size_t)nplan * 64 * sizeof(double) <= WaveQueue<float>::bytes()) {
+        double *scratch = reinterpret_cast<double *>(c.qmem + (size_t)(threadIdx.x >> 6) * WaveQueue<float>::bytes()) +
+                          (threadIdx.x & 63);
+        expand_edge(gip, QA, E, i, step, layout, survive, qw, B, scratch, 64, ib);
+        if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
+        return;
+      }
+    }
+    if (survive) ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;  // too many columns: walking kernel
+    return;
   }
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(scount, (int)__builtin_popcountll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (survive)
+    slist[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)i;
 }
 
 template <int MAXS, bool WBOX, bool MBOX>
@@ -748,6 +879,35 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
 }
 
 
+template <int MAXS, bool WBOX, bool MBOX>
+__global__ void __launch_bounds__(kBlock)
+k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp, ItemBuffers ib,
+               float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
+               int *__restrict__ ulist, int *__restrict__ ucount, UndecidedConfigs uc) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  const int64_t n = *ib.count < ib.cap ? *ib.count : ib.cap;
+  if ((int64_t)blockIdx.x * B >= n) return;
+  const int nplan = gip[H_NPLAN];
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B);
+  const int64_t it = (int64_t)blockIdx.x * B + threadIdx.x;
+  const bool active = it < n && ib.edge[it] >= 0;  // (a void slot: reserved by an edge that did not fit)
+  load_columns(c.col0 + threadIdx.x, B, ib.w, ib.cap, it, nplan, MJPL_SOA, active);
+  __syncthreads();
+  const int code = check_one<float, MAXS, WBOX, MBOX>(c, c.col0 + threadIdx.x, B, active, tol, it, uc, 0,
+                                                      ib.edge, ib.idx);
+  if (active && code != V_NONE) {
+    const int ed = ib.edge[it];
+    if (code == V_CONTACT) {
+      valid[ed] = 0;
+      if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)ib.idx[it]);
+    } else {
+      // could not hand the undecided pair over: the exact edge kernel redoes the whole edge
+      ulist[atomicAdd(ucount, 1)] = ed;
+    }
+  }
+}
+
 // ---- exact re-check of single geom pairs the filter could not decide -------------------------
 // Item u = (configuration uc.q[u], moving geom uc.ga[u], partner geom uc.gb[u]).  One lane per
 // item: float64 FK of the moving bodies (same statements as run_config), capturing the world
@@ -1055,6 +1215,11 @@ struct mjpl_engine {
   double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
   int *d_ucedge = nullptr, *d_ucidx = nullptr, *d_ucga = nullptr, *d_ucgb = nullptr;
   double *d_geomtab = nullptr;  // GTB_LEN doubles per model geom (k_patch_pairs)
+  double *d_itemw = nullptr;    // lane-per-waypoint interior pass: waypoints, (edge, idx), long-edge list
+  int *d_itemedge = nullptr, *d_itemidx = nullptr, *d_llist = nullptr, *d_icount = nullptr;
+  size_t item_cap = 0, llist_cap = 0;
+  bool expand = true;
+  size_t item_cap_limit = (size_t)1 << 26;  // MJPL_ITEM_CAP: edges beyond it take the walking kernel
   void *d_nn = nullptr;         // nearest neighbour: per-chunk partial results
   size_t nn_bytes = 0;
   size_t uc_cap = 0;
@@ -1593,6 +1758,30 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     // two passes unless only the interior was asked for: endpoints of all edges, then the interior
     // waypoints of the edges whose endpoint passed
     const bool two_pass = e->two_pass && !(flags & MJPL_EDGE_INTERIOR_ONLY);
+    // interior waypoints: one lane per waypoint for ordinary edges (the endpoint kernel emits the
+    // waypoints as items), the walking kernel for long edges and for models with moving boxes
+    const bool expand = two_pass && e->expand && !e->mbox;
+    const int *rlist = nullptr, *rcount = nullptr;  // work list of the walking kernel
+    ItemBuffers ib = {};
+    if (expand) {
+      const size_t want = std::min<size_t>((size_t)E * 8 + 4096, e->item_cap_limit);
+      if (want > e->item_cap || (size_t)E > e->llist_cap) {
+        for (void *ptr : {(void *)e->d_itemw, (void *)e->d_itemedge, (void *)e->d_itemidx, (void *)e->d_llist})
+          if (ptr) HIP_TRY(hipFree(ptr));
+        e->d_itemw = nullptr; e->d_itemedge = e->d_itemidx = e->d_llist = nullptr;
+        e->item_cap = e->llist_cap = 0;
+        const size_t nplan = e->qidx.size();
+        HIP_TRY(hipMalloc(&e->d_itemw, want * std::max<size_t>(1, nplan) * sizeof(double)));
+        HIP_TRY(hipMalloc(&e->d_itemedge, want * sizeof(int)));
+        HIP_TRY(hipMalloc(&e->d_itemidx, want * sizeof(int)));
+        HIP_TRY(hipMalloc(&e->d_llist, (size_t)E * sizeof(int)));
+        e->item_cap = want; e->llist_cap = (size_t)E;
+      }
+      if (!e->d_icount) HIP_TRY(hipMalloc(&e->d_icount, 2 * sizeof(int)));
+      HIP_TRY(hipMemsetAsync(e->d_icount, 0, 2 * sizeof(int), e->stream));
+      ib = ItemBuffers{e->d_itemw, e->d_itemedge, e->d_itemidx, e->d_icount, (int)e->item_cap, e->d_llist,
+                       e->d_icount + 1};
+    }
     if (two_pass) {
       if ((size_t)E > e->slist_cap) {
         if (e->d_slist) HIP_TRY(hipFree(e->d_slist));
@@ -1600,18 +1789,36 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         HIP_TRY(hipMalloc(&e->d_slist, (size_t)E * sizeof(int)));
         e->slist_cap = (size_t)E;
       }
+      rlist = e->d_slist;
+      rcount = e->d_ucount + 2;
       rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_endpoints<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldsf);
         if (r != MJPL_OK) return r;
         hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                            e->d_fp, (int)e->fp.size(), dQA, dQB, E, layout, e->filter_tol, dvalid, dfb,
-                           e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist, e->d_ucount + 2);
+                           e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist, e->d_ucount + 2, ib, step);
         return MJPL_OK;
       });
       if (rc != MJPL_OK) return rc;
     }
     if (e->mark_before_main) HIP_TRY(hipEventRecord(e->mark_before_main, e->stream));
+    if (expand) {
+      const unsigned igrid = (unsigned)((e->item_cap + fblock - 1) / fblock);
+      rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+        auto kern = k_filter_items<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+        int r = allow_lds(kern, ldsf);
+        if (r != MJPL_OK) return r;
+        hipLaunchKernelGGL(kern, dim3(igrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
+                           e->d_fp, (int)e->fp.size(), ib, e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount,
+                           uc);
+        return MJPL_OK;
+      });
+      if (rc != MJPL_OK) return rc;
+      if (e->mark_after_first) HIP_TRY(hipEventRecord(e->mark_after_first, e->stream));
+      rlist = e->d_llist;  // what is left for the walking kernel
+      rcount = e->d_icount + 1;
+    }
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
@@ -1619,13 +1826,11 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                          e->d_fp, (int)e->fp.size(), dQA, dQB, E, step, layout,
                          two_pass ? (flags | MJPL_EDGE_INTERIOR_ONLY) : flags, e->filter_tol, dvalid,
-                         dfb, e->d_status, e->d_ulist, e->d_ucount, uc,
-                         two_pass ? (const int *)e->d_slist : nullptr,
-                         two_pass ? (const int *)(e->d_ucount + 2) : nullptr);
+                         dfb, e->d_status, e->d_ulist, e->d_ucount, uc, rlist, rcount);
       return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
-    if (e->mark_after_first) HIP_TRY(hipEventRecord(e->mark_after_first, e->stream));
+    if (!expand && e->mark_after_first) HIP_TRY(hipEventRecord(e->mark_after_first, e->stream));
     // undecided waypoints: exact configuration kernel in patch mode (grid sized for a generous
     // share of the batch; surplus blocks return at once)
     const size_t ldsc = lds_bytes(e, 1);
@@ -1758,6 +1963,8 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
   e->qbase = m.qpos0;
   if (const char *f = getenv("MJPL_FILTER")) e->filter = atoi(f) != 0;
   if (const char *f = getenv("MJPL_TWO_PASS")) e->two_pass = atoi(f) != 0;
+  if (const char *f = getenv("MJPL_EXPAND")) e->expand = atoi(f) != 0;
+  if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
   if (const char *t = getenv("MJPL_FILTER_TOL")) {
     const double v = atof(t);
     if (v > 0.0 && v < 1.0) e->filter_tol = (float)v;
@@ -1784,6 +1991,11 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_ucgb) (void)hipFree(e->d_ucgb);
   if (e->d_geomtab) (void)hipFree(e->d_geomtab);
   if (e->d_nn) (void)hipFree(e->d_nn);
+  if (e->d_itemw) (void)hipFree(e->d_itemw);
+  if (e->d_itemedge) (void)hipFree(e->d_itemedge);
+  if (e->d_itemidx) (void)hipFree(e->d_itemidx);
+  if (e->d_llist) (void)hipFree(e->d_llist);
+  if (e->d_icount) (void)hipFree(e->d_icount);
   if (e->d_ucq) (void)hipFree(e->d_ucq);
   if (e->d_ucedge) (void)hipFree(e->d_ucedge);
   if (e->d_ucidx) (void)hipFree(e->d_ucidx);
@@ -1836,6 +2048,15 @@ int64_t mjpl_filter_last_interior_edges(mjpl_engine *e) {
   if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
   if (hipMemcpy(n, e->d_ucount, 4 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int64_t)n[2];
+}
+
+int64_t mjpl_filter_last_items(mjpl_engine *e) {
+  if (!e || !e->filter || !e->d_icount) return -1;
+  int n[2] = {0, 0};
+  if (hipSetDevice(e->device) != hipSuccess) return -1;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+  if (hipMemcpy(n, e->d_icount, 2 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)n[0];
 }
 
 int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {

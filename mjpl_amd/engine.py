@@ -86,6 +86,7 @@ ABI = {
     "mjpl_set_filter": (C.c_int, [_VP, C.c_int32, C.c_double]),
     "mjpl_filter_last_undecided": (C.c_int64, [_VP]),
     "mjpl_filter_last_interior_edges": (C.c_int64, [_VP]),
+    "mjpl_filter_last_items": (C.c_int64, [_VP]),
     "mjpl_check_configs": (C.c_int, [_VP, _F64P, C.c_int64, C.c_int32, _U8P]),
     "mjpl_check_edges": (C.c_int, [_VP, _F64P, _F64P, C.c_int64, C.c_double, C.c_int32, C.c_int32, _U8P,
                                    _I32P]),
@@ -234,6 +235,9 @@ class Engine:
     def set_filter(self, enable: bool, tol: float = 1e-4):
         """Float32 filter in front of the exact kernels (verdicts are always the exact ones)."""
         self._ok(self.lib.mjpl_set_filter(self.h, 1 if enable else 0, float(tol)))
+
+    def last_items(self) -> int:
+        return int(self.lib.mjpl_filter_last_items(self.h))
 
     def last_interior_edges(self) -> int:
         return int(self.lib.mjpl_filter_last_interior_edges(self.h))

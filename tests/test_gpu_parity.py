@@ -170,9 +170,10 @@ def test_filter_configs_64k_and_info(oracle_mod):
 
 
 def test_two_pass_and_one_pass_filter_agree(monkeypatch):
-    """The endpoint-first split of the edge filter changes scheduling only: valid and first_bad are
-    those of the one-pass filter and of the pure float64 kernels, on clean edges, on edges that
-    end in an obstacle and on zero-length edges."""
+    """The endpoint-first split of the edge filter and the lane-per-waypoint interior pass change
+    scheduling only: valid and first_bad are those of the one-pass filter, of the walking interior
+    pass, of an overflowing item buffer and of the pure float64 kernels, on clean edges, on edges
+    that end in an obstacle and on zero-length edges."""
     from mjpl_amd import engine, scenes
     import bench as _bench
     m = scenes.franka_p(obstacles=True)
@@ -181,8 +182,9 @@ def test_two_pass_and_one_pass_filter_agree(monkeypatch):
     qa, qb = _bench.make_edges(m, qidx, 20000, seed=77)
     qb[:50] = qa[:50]  # waypoints == [start]: nothing interior
     out = {}
-    for tag, env in (("two", {"MJPL_TWO_PASS": "1"}), ("one", {"MJPL_TWO_PASS": "0"}), ("f64", {"MJPL_FILTER": "0"})):
-        for k in ("MJPL_TWO_PASS", "MJPL_FILTER"):
+    for tag, env in (("two", {"MJPL_TWO_PASS": "1"}), ("one", {"MJPL_TWO_PASS": "0"}), ("f64", {"MJPL_FILTER": "0"}),
+                     ("walk", {"MJPL_EXPAND": "0"}), ("tight", {"MJPL_ITEM_CAP": "3000"})):
+        for k in ("MJPL_TWO_PASS", "MJPL_FILTER", "MJPL_EXPAND", "MJPL_ITEM_CAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -192,8 +194,11 @@ def test_two_pass_and_one_pass_filter_agree(monkeypatch):
         if tag == "two":
             n_int = e.last_interior_edges()
             assert 0 < n_int < len(qa)
+            assert e.last_items() > n_int  # one lane per interior waypoint
+        if tag == "tight":  # the item buffer overflows: the rest of the edges take the walking kernel
+            assert e.last_items() > 3000
         e.close()
-    for tag in ("one", "f64"):
+    for tag in ("one", "f64", "walk", "tight"):
         np.testing.assert_array_equal(out["two"][0], out[tag][0])
         np.testing.assert_array_equal(out["two"][1], out[tag][1])
     assert 0 < out["two"][0].sum() < len(qa)
