@@ -1445,17 +1445,18 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         if (pm == 0ull) continue;
         push(kGeneral, pm, EK_PLANE, wc, GT_PLANE, true, ppos);
       }
-      // other static geoms.  The 16 + 4 scalars of the NEXT chunk are requested before the
-      // current chunk's culls, so a wave does not sit on a scalar-load round trip per chunk
-      // (the tables are padded by one chunk).
+      // other static geoms: one wide scalar load of four rows (+ their four bounds) per chunk
+#ifdef MJPL_CHUNK_PREFETCH
       T nrc[16], nbc[4];
 #pragma unroll
       for (int k = 0; k < 16; k++) nrc[k] = wcull[k];
 #pragma unroll
       for (int k = 0; k < 4; k++) nbc[k] = wbound[k];
+#endif
       for (int base = 0; base < nwpad; base += 4) {
         const unsigned bits = (unsigned)(wmask_use >> base) & 15u;
         T rcv[16], bcv[4];
+#ifdef MJPL_CHUNK_PREFETCH
 #pragma unroll
         for (int k = 0; k < 16; k++) rcv[k] = nrc[k];
 #pragma unroll
@@ -1468,6 +1469,17 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
 #pragma unroll
           for (int k = 0; k < 4; k++) nbc[k] = bn[k];
         }
+#else
+        if (bits == 0) continue;
+        {
+          Tab rn = wcull + base * WC_LEN;
+          Tab bn = wbound + base;
+#pragma unroll
+          for (int k = 0; k < 16; k++) rcv[k] = rn[k];
+#pragma unroll
+          for (int k = 0; k < 4; k++) bcv[k] = bn[k];
+        }
+#endif
         if (bits == 0) continue;
         pin_geom(cur);
         unsigned long long m0, m1, m2, m3;
