@@ -136,7 +136,7 @@ int64_t mjpl_filter_last_undecided(mjpl_engine *e);
 int64_t mjpl_filter_last_interior_edges(mjpl_engine *e);
 /* The interior pass runs one lane per waypoint: a small kernel walks the waypoint recurrence of
  * every surviving edge once and writes the waypoints out as work items (MJPL_EXPAND=0 at create:
- * one lane per edge walks them; edges of more than ~24 waypoints always do).  Returns how many
+ * one lane per edge walks them; edges too long for the item space always do).  Returns how many
  * waypoint items the most recent mjpl_check_edges* checked (synchronises); -1 if never used. */
 int64_t mjpl_filter_last_items(mjpl_engine *e);
 

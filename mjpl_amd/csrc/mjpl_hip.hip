@@ -387,8 +387,9 @@ struct ItemBuffers {
   int *count;       // items written
   int cap;
   int *llist, *lcount;  // edges left to the walking kernel
+  int kmax;             // edges with more interior waypoints than this stay with the walking kernel
 };
-constexpr int kExpandMaxWaypoints = 24;  // longer edges take the walking kernel
+constexpr int kExpandMinWaypoints = 24;  // kmax is at least this; small batches get more (item space / E)
 
 // qe: this lane's edge end QB (LDS, stride B); qw: scratch for the walking waypoint (LDS, stride
 // ws).  `todo` lanes own an edge i whose interior waypoints are wanted.
@@ -415,7 +416,7 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
     s0 = s0 + d * d;
   }
   bool done = !todo || at_end;
-  if (!done && !(sqrt(s0) <= step * (kExpandMaxWaypoints - 2))) {  // long edge
+  if (!done && !(sqrt(s0) <= step * (double)(ib.kmax - 2))) {  // long edge
     ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
     done = true;
   }
@@ -447,11 +448,11 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
     while (__ballot(walking) != 0ull) {
       if (walking) {
         if (advance()) walking = false;
-        else if (++K > kExpandMaxWaypoints) walking = false;
+        else if (++K > ib.kmax) walking = false;
       }
     }
   }
-  if (!done && K > kExpandMaxWaypoints) {  // the estimate was off: the walking kernel takes the edge
+  if (!done && K > ib.kmax) {  // the estimate was off: the walking kernel takes the edge
     ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
     done = true;
   }
@@ -1764,7 +1765,9 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     const int *rlist = nullptr, *rcount = nullptr;  // work list of the walking kernel
     ItemBuffers ib = {};
     if (expand) {
-      const size_t want = std::min<size_t>((size_t)E * 8 + 4096, e->item_cap_limit);
+      // room for 8 waypoints per edge on average, and never less than a quarter of a million items:
+      // a handful of long edges (path shortcutting) is best served one waypoint per lane, too
+      const size_t want = std::min<size_t>(std::max<size_t>((size_t)E * 8, (size_t)1 << 18) + 4096, e->item_cap_limit);
       if (want > e->item_cap || (size_t)E > e->llist_cap) {
         for (void *ptr : {(void *)e->d_itemw, (void *)e->d_itemedge, (void *)e->d_itemidx, (void *)e->d_llist})
           if (ptr) HIP_TRY(hipFree(ptr));
@@ -1779,8 +1782,9 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       }
       if (!e->d_icount) HIP_TRY(hipMalloc(&e->d_icount, 2 * sizeof(int)));
       HIP_TRY(hipMemsetAsync(e->d_icount, 0, 2 * sizeof(int), e->stream));
+      const int kmax = (int)std::min<size_t>(std::max<size_t>(e->item_cap / (size_t)E, kExpandMinWaypoints), 1 << 16);
       ib = ItemBuffers{e->d_itemw, e->d_itemedge, e->d_itemidx, e->d_icount, (int)e->item_cap, e->d_llist,
-                       e->d_icount + 1};
+                       e->d_icount + 1, kmax};
     }
     if (two_pass) {
       if ((size_t)E > e->slist_cap) {
