@@ -699,7 +699,11 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 template <class T>
 __device__ __forceinline__ void sincos_half(T x, T *s, T *c) {
   if constexpr (Real<T>::exact) sincos_pi2(x, s, c);
+#ifdef MJPL_X_FAST_SINCOS
+  else { *s = __sinf(x); *c = __cosf(x); }
+#else
   else sincosf(x, s, c);
+#endif
 }
 
 // Walk the moving part of the body tree for this lane's configuration.
