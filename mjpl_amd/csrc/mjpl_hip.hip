@@ -33,6 +33,7 @@ constexpr int kBlock = 256;           // threads per workgroup: 4 wavefronts
 constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts share one LDS table copy
 constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
 constexpr int kStatusNonFinite = 1;
+constexpr int kCtr = 32;  // ints between device counters: one 128-byte line each
 
 thread_local std::string g_err;
 
@@ -1648,7 +1649,14 @@ int uc_reserve(mjpl_engine *e, int64_t n) {
 }
 
 int ulist_reserve(mjpl_engine *e, int64_t n) {
-  if (!e->d_ucount) HIP_TRY(hipMalloc(&e->d_ucount, 4 * sizeof(int)));
+  if (!e->d_ucount) {
+    // five device counters, each on its own 128-byte line (they are hammered by wave-level atomics
+    // of the same kernel: sharing a line costs ~7 % of a step), cleared by one memset per launch:
+    //   [0] edge-level undecided list, [kCtr] undecided pairs, [2 kCtr] edges whose endpoint passed,
+    //   [3 kCtr] waypoint items, [4 kCtr] edges left to the walking kernel
+    HIP_TRY(hipMalloc(&e->d_ucount, 5 * kCtr * sizeof(int)));
+    e->d_icount = e->d_ucount + 3 * kCtr;
+  }
   if ((size_t)n > e->ulist_cap) {
     if (e->d_ulist) HIP_TRY(hipFree(e->d_ulist));
     e->d_ulist = nullptr;
@@ -1694,11 +1702,11 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
       rc = uc_reserve(e, N);
       uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
       uc.ga = e->d_ucga; uc.gb = e->d_ucgb;
-      uc.count = e->d_ucount + 1;
+      uc.count = e->d_ucount + kCtr;
       uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
     }
     if (rc != MJPL_OK) return rc;
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 4 * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
     const int fblock = e->mbox ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
@@ -1750,9 +1758,9 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     if (rc != MJPL_OK) return rc;
     uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
     uc.ga = e->d_ucga; uc.gb = e->d_ucgb;
-    uc.count = e->d_ucount + 1;
+    uc.count = e->d_ucount + kCtr;
     uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 4 * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
     const int fblock = e->mbox ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
@@ -1780,11 +1788,9 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         HIP_TRY(hipMalloc(&e->d_llist, (size_t)E * sizeof(int)));
         e->item_cap = want; e->llist_cap = (size_t)E;
       }
-      if (!e->d_icount) HIP_TRY(hipMalloc(&e->d_icount, 2 * sizeof(int)));
-      HIP_TRY(hipMemsetAsync(e->d_icount, 0, 2 * sizeof(int), e->stream));
       const int kmax = (int)std::min<size_t>(std::max<size_t>(e->item_cap / (size_t)E, kExpandMinWaypoints), 1 << 16);
       ib = ItemBuffers{e->d_itemw, e->d_itemedge, e->d_itemidx, e->d_icount, (int)e->item_cap, e->d_llist,
-                       e->d_icount + 1, kmax};
+                       e->d_icount + kCtr, kmax};
     }
     if (two_pass) {
       if ((size_t)E > e->slist_cap) {
@@ -1794,14 +1800,14 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         e->slist_cap = (size_t)E;
       }
       rlist = e->d_slist;
-      rcount = e->d_ucount + 2;
+      rcount = e->d_ucount + 2 * kCtr;
       rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_endpoints<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldsf);
         if (r != MJPL_OK) return r;
         hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                            e->d_fp, (int)e->fp.size(), dQA, dQB, E, layout, e->filter_tol, dvalid, dfb,
-                           e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist, e->d_ucount + 2, ib, step);
+                           e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist, e->d_ucount + 2 * kCtr, ib, step);
         return MJPL_OK;
       });
       if (rc != MJPL_OK) return rc;
@@ -1821,7 +1827,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       if (rc != MJPL_OK) return rc;
       if (e->mark_after_first) HIP_TRY(hipEventRecord(e->mark_after_first, e->stream));
       rlist = e->d_llist;  // what is left for the walking kernel
-      rcount = e->d_icount + 1;
+      rcount = e->d_icount + kCtr;
     }
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
@@ -1999,7 +2005,6 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_itemedge) (void)hipFree(e->d_itemedge);
   if (e->d_itemidx) (void)hipFree(e->d_itemidx);
   if (e->d_llist) (void)hipFree(e->d_llist);
-  if (e->d_icount) (void)hipFree(e->d_icount);
   if (e->d_ucq) (void)hipFree(e->d_ucq);
   if (e->d_ucedge) (void)hipFree(e->d_ucedge);
   if (e->d_ucidx) (void)hipFree(e->d_ucidx);
@@ -2038,11 +2043,11 @@ int mjpl_set_filter(mjpl_engine *e, int32_t enable, double tol) {
 
 int64_t mjpl_filter_last_undecided(mjpl_engine *e) {
   if (!e || !e->filter || !e->d_ucount) return 0;
-  int n[2] = {0, 0};
+  int n[5 * kCtr];
   if (hipSetDevice(e->device) != hipSuccess) return -1;
   if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
-  if (hipMemcpy(n, e->d_ucount, 2 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int64_t)n[0] + n[1];
+  if (hipMemcpy(n, e->d_ucount, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)n[0] + n[kCtr];
 }
 
 int64_t mjpl_filter_last_interior_edges(mjpl_engine *e) {
@@ -2050,8 +2055,8 @@ int64_t mjpl_filter_last_interior_edges(mjpl_engine *e) {
   int n[4] = {0, 0, 0, 0};
   if (hipSetDevice(e->device) != hipSuccess) return -1;
   if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
-  if (hipMemcpy(n, e->d_ucount, 4 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int64_t)n[2];
+  if (hipMemcpy(n, e->d_ucount + 2 * kCtr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)n[0];
 }
 
 int64_t mjpl_filter_last_items(mjpl_engine *e) {
@@ -2059,7 +2064,7 @@ int64_t mjpl_filter_last_items(mjpl_engine *e) {
   int n[2] = {0, 0};
   if (hipSetDevice(e->device) != hipSuccess) return -1;
   if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
-  if (hipMemcpy(n, e->d_icount, 2 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(n, e->d_icount, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int64_t)n[0];
 }
 
