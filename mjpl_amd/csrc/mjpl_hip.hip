@@ -1694,7 +1694,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
                    unsigned long long *dbits) {
   if (N == 0) return MJPL_OK;
   const unsigned grid = (unsigned)((N + kBlock - 1) / kBlock);
-  const bool filter = e->filter && dvalid && !dbits && N < (int64_t)1 << 31;
+  const bool filter = e->filter && dvalid && !dbits && N < (int64_t)1 << 30;
   if (filter) {
     int rc = ulist_reserve(e, N);
     UndecidedConfigs uc = {};
@@ -1750,7 +1750,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
                  int layout, int flags, uint8_t *dvalid, int32_t *dfb) {
   if (E == 0) return MJPL_OK;
   const unsigned grid = (unsigned)((E + kBlock - 1) / kBlock);
-  const bool filter = e->filter && E < (int64_t)1 << 31;
+  const bool filter = e->filter && E < (int64_t)1 << 30;  // item ids travel in 30 bits of the per-lane flag words
   UndecidedConfigs uc = {};
   if (filter) {
     int rc = ulist_reserve(e, E);
