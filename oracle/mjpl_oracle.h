@@ -166,7 +166,8 @@ int orc_pose_valid(const orc_model *m, const orc_pose *p, const double *qpos);
  * <0 error.  iters (nullable) receives the number of projection steps taken. */
 int orc_pose_apply(const orc_model *m, const orc_pose *p, const double *q_old, const double *q,
                    double *q_out, int32_t *iters);
-/* batched apply over N rows of full-nq vectors [N][nq]; ok[i] = 1/0; status[i] as above */
+/* batched apply over N rows of full-nq vectors [N][nq]; ok[i] = 1/0; iters[i] = projection steps
+ * taken, negative if the row gave up after max_iters */
 int orc_pose_apply_batch(const orc_model *m, const orc_pose *p, const double *Q_old, const double *Q,
                          int64_t N, int32_t nthreads, double *Q_out, uint8_t *ok, int32_t *iters);
 

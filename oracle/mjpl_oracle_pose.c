@@ -326,7 +326,7 @@ static void *pose_job_run(void *arg) {
     int32_t it = 0;
     int rc = orc_pose_apply(j->m, j->p, j->Q_old + i * nq, j->Q + i * nq, j->Q_out + i * nq, &it);
     j->ok[i] = rc == 1;
-    if (j->iters) j->iters[i] = it;
+    if (j->iters) j->iters[i] = (rc == ORC_E_NOCONVERGE) ? -it : it;  /* negative: gave up after max_iters */
     if (rc < 0 && rc != ORC_E_NOCONVERGE) j->status = rc;
   }
   return NULL;

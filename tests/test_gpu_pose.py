@@ -161,3 +161,43 @@ def test_frontier_planner_with_pose_projection():
     cc.set_planning(np.arange(m.nq), m.qpos0)
     assert cc.valid_configs(P).all()
     assert (np.linalg.norm(np.diff(P, axis=0), axis=1) <= 0.05 + 2 * 0.05 + 1e-9).all()
+
+
+@pytest.mark.parametrize("seed", [3, 8, 1004, 1009])
+def test_projection_on_random_models(oracle_mod, seed):
+    """Chains with slide joints, off-centre hinges, two joints per body and rotated site frames:
+    site pose, validity and projection of the GPU kernels against the oracle."""
+    from test_gpu_models import random_model
+    model, _ = random_model(seed % 1000, moving_boxes=seed < 1000)
+    mb_site_body = model.body_names[-1]
+    # add a site to the last body by rebuilding the arrays the projection reads
+    import dataclasses
+    q = np.array([0.5, 0.5, -0.5, 0.5])
+    model = dataclasses.replace(model, nsite=1, site_bodyid=np.array([model.nbody - 1], np.int32),
+                                site_pos=np.array([[0.05, -0.02, 0.08]]), site_quat=q[None] / np.linalg.norm(q),
+                                site_names=["tip"])
+    assert mb_site_body == model.body_names[model.site_bodyid[0]]
+    q0 = np.asarray(model.qpos0, dtype=np.float64).copy()
+    eng = mjpl.engine.Engine(model)
+    frame = mjpl.site_pose(model, q0, "tip", engine=eng)
+    kw = dict(x_translation=(-0.02, 0.02), z_translation=(-0.03, 0.03), yaw=(-0.1, 0.1), q_step=0.4)
+    pc = mjpl.PoseConstraint(model, "tip", frame, engine=eng, **kw)
+    inv = frame.inverse()
+    bounds = [kw["x_translation"], INF, kw["z_translation"], INF, INF, kw["yaw"]]
+    po = oracle_mod.PoseOracle(model, "tip", (inv.wxyz_xyz[:4], inv.wxyz_xyz[4:]), bounds, q_step=0.4)
+    rng = np.random.default_rng(seed)
+    lo, hi = model.jnt_range[:, 0], model.jnt_range[:, 1]
+    n = 1024
+    Q = np.clip(q0 + rng.normal(scale=0.08, size=(n, model.nq)), lo, hi)
+    Q_old = np.clip(q0 + rng.normal(scale=0.02, size=(n, model.nq)), lo, hi)
+    xpos, xmat = pc.site_poses(Q[:64])
+    for i in range(64):
+        p, R = po.site_pose(Q[i])
+        np.testing.assert_allclose(xpos[i], p, atol=1e-13)
+        np.testing.assert_allclose(xmat[i], R, atol=1e-13)
+    got, ok, iters = pc.apply_batch(Q_old, Q)
+    ref, rok, riters = po.apply_batch(Q_old, Q, nthreads=8)
+    same = (ok == rok) & (iters == riters)
+    assert same.mean() > 0.99, same.mean()
+    np.testing.assert_allclose(got[same], ref[same], rtol=0, atol=1e-8)
+    assert np.array_equal(pc.valid_configs(got[same & ok]), np.ones((same & ok).sum(), bool))
