@@ -137,3 +137,37 @@ def test_rrt_plan_to_pose_uses_the_batched_solver():
     np.testing.assert_array_equal(path[0], q_init)
     got = mjpl.site_pose(m, path[-1], "attachment_site", engine=cc.engine)
     assert np.linalg.norm(got.translation() - pose.translation()) <= 1e-3
+
+
+@pytest.mark.parametrize("seed", [3, 8, 1004, 1009])
+def test_ik_on_random_chains(oracle_mod, seed):
+    """Slide joints, off-centre hinges, short chains (rank-deficient Jacobians): the seeds the
+    kernel reports as solved reach the target (oracle FK), stay inside the joint ranges and leave
+    the joints outside the chain where they were."""
+    import dataclasses
+    from test_gpu_models import random_model
+    model, _ = random_model(seed % 1000, moving_boxes=seed < 1000)
+    q = np.array([0.5, 0.5, -0.5, 0.5])
+    model = dataclasses.replace(model, nsite=1, site_bodyid=np.array([model.nbody - 1], np.int32),
+                                site_pos=np.array([[0.05, -0.02, 0.08]]), site_quat=q[None] / np.linalg.norm(q),
+                                site_names=["tip"])
+    eng = mjpl.engine.Engine(model)
+    rng = np.random.default_rng(seed)
+    lo, hi = model.jnt_range[:, 0], model.jnt_range[:, 1]
+    q_t = rng.uniform(lo, hi) * 0.6
+    target = mjpl.site_pose(model, q_t, "tip", engine=eng)
+    Q0 = np.clip(q_t + rng.normal(scale=0.3, size=(512, model.nq)), lo, hi)
+    movable = np.ones(model.njnt, np.uint8)
+    Q, ok, iters, err = eng.ik_solve("tip", target.translation(), target.rotation().wxyz, Q0, movable, iterations=300)
+    assert ok.any(), (ok.mean(), err.min(axis=0))
+    assert np.all((Q >= lo - 1e-15) & (Q <= hi + 1e-15))
+    for i in np.flatnonzero(ok)[:16]:
+        e_pos, e_ori = _pose_error(oracle_mod, model, "tip", Q[i], target)
+        assert e_pos <= 1e-3 + 1e-9 and e_ori <= 1e-3 + 1e-9
+    # joints that do not move the site are never touched
+    chain, b = set(), int(model.site_bodyid[0])
+    while b > 0:
+        chain.update(range(model.body_jntadr[b], model.body_jntadr[b] + model.body_jntnum[b]))
+        b = int(model.body_parentid[b])
+    off = [j for j in range(model.njnt) if j not in chain]
+    np.testing.assert_array_equal(Q[:, off], Q0[:, off])
