@@ -85,22 +85,26 @@ template <class T, int MAXS, bool WBOX, bool MBOX>
 __device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int B, bool active, T tol,
                                          int64_t row, const UndecidedConfigs &uc = UndecidedConfigs{},
                                          int idx = 0, const int *item_edge = nullptr,
-                                         const int *item_idx = nullptr) {
+                                         const int *item_idx = nullptr, const double *sink_q = nullptr,
+                                         int sink_stride = 0, int qstride = 0) {
+  if (qstride == 0) qstride = B;  // q[k * qstride]; the LDS pose saves always use stride B
   if constexpr (kQueued<T, MBOX>) {
     WaveQueue<T> wq = wave_queue<T>(c.qmem);
     PatchSink ps;
     ps.uc = uc;
-    ps.qcol = c.col0 + (threadIdx.x & ~63);
-    ps.B = B;
+    // where a drain lane finds the owner's configuration: the LDS columns, or (lane-per-item
+    // kernel reading its configurations straight from the item buffer) global memory
+    ps.qcol = sink_q ? sink_q : c.col0 + (threadIdx.x & ~63);
+    ps.B = sink_q ? sink_stride : B;
     ps.nplan = c.ip[H_NPLAN];
     ps.idx = idx;
     ps.item_edge = item_edge;
     ps.item_idx = item_idx;
-    return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, c.ltab, q, B, c.save + threadIdx.x, B, active, tol, wq,
-                                            (int)row, ps);
+    return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, c.ltab, q, qstride, c.save + threadIdx.x, B, active, tol,
+                                            wq, (int)row, ps);
   } else {
     FkOut none = {};
-    return run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, q, B, c.save + threadIdx.x, B, active, tol,
+    return run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, q, qstride, c.save + threadIdx.x, B, active, tol,
                                                   none, row);
   }
 }
@@ -881,8 +885,13 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
 }
 
 
+#ifdef MJPL_X_ITEMS_4WAVES
+#define MJPL_ITEMS_BOUNDS __launch_bounds__(kBlock, 4)
+#else
+#define MJPL_ITEMS_BOUNDS __launch_bounds__(kBlock)
+#endif
 template <int MAXS, bool WBOX, bool MBOX>
-__global__ void __launch_bounds__(kBlock)
+__global__ void MJPL_ITEMS_BOUNDS
 k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp, ItemBuffers ib,
                float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
                int *__restrict__ ulist, int *__restrict__ ucount, UndecidedConfigs uc) {
@@ -891,13 +900,15 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
   const int64_t n = *ib.count < ib.cap ? *ib.count : ib.cap;
   if ((int64_t)blockIdx.x * B >= n) return;
   const int nplan = gip[H_NPLAN];
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B);
+  // the configuration is read straight from the item buffer (coalesced, once per joint): no LDS
+  // columns in this kernel
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 0, B);
   const int64_t it = (int64_t)blockIdx.x * B + threadIdx.x;
   const bool active = it < n && ib.edge[it] >= 0;  // (a void slot: reserved by an edge that did not fit)
-  load_columns(c.col0 + threadIdx.x, B, ib.w, ib.cap, it, nplan, MJPL_SOA, active);
   __syncthreads();
-  const int code = check_one<float, MAXS, WBOX, MBOX>(c, c.col0 + threadIdx.x, B, active, tol, it, uc, 0,
-                                                      ib.edge, ib.idx);
+  const int64_t itc = it < (int64_t)ib.cap ? it : 0;
+  const int code = check_one<float, MAXS, WBOX, MBOX>(c, ib.w + itc, B, active, tol, it, uc, 0, ib.edge, ib.idx,
+                                                      ib.w + (itc - (threadIdx.x & 63)), ib.cap, ib.cap);
   if (active && code != V_NONE) {
     const int ed = ib.edge[it];
     if (code == V_CONTACT) {
@@ -1815,11 +1826,12 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     if (e->mark_before_main) HIP_TRY(hipEventRecord(e->mark_before_main, e->stream));
     if (expand) {
       const unsigned igrid = (unsigned)((e->item_cap + fblock - 1) / fblock);
+      const size_t ldsi = lds_bytes(e, 0, sizeof(float), fblock, true);
       rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_items<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
-        int r = allow_lds(kern, ldsf);
+        int r = allow_lds(kern, ldsi);
         if (r != MJPL_OK) return r;
-        hipLaunchKernelGGL(kern, dim3(igrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
+        hipLaunchKernelGGL(kern, dim3(igrid), dim3(fblock), ldsi, e->stream, e->d_ip, (int)e->ip.size(),
                            e->d_fp, (int)e->fp.size(), ib, e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount,
                            uc);
         return MJPL_OK;
