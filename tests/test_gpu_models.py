@@ -64,7 +64,7 @@ def random_model(seed, moving_boxes=True):
 
 def _fuzz_seeds():
     import os
-    n = int(os.environ.get("MJPL_FUZZ_SEEDS", "12"))
+    n = int(os.environ.get("MJPL_FUZZ_SEEDS", "48"))
     return list(range(1000, 1000 + n))
 
 
