@@ -47,6 +47,8 @@ class CollisionRuleset:
 
 
 class CollisionConstraint(Constraint):
+    projects = False  # apply() never moves a configuration: batched extension is allowed
+
     """Batched collision validation on one MI355X.
 
     Args:
@@ -110,6 +112,14 @@ class CollisionConstraint(Constraint):
         v = self.engine.check_edges(np.asarray(start, float)[None, :], np.asarray(end, float)[None, :],
                                     step_dist, _engine.AOS, interior_only=True)
         return bool(v[0])
+
+    def valid_intervals(self, starts: np.ndarray, ends: np.ndarray, step_dist: float) -> np.ndarray:
+        """Row-wise ``valid_interval``: full-nq edges [N, nq] -> bool [N], one launch."""
+        if step_dist <= 0.0:
+            raise ValueError("`step_dist` must be > 0")
+        self._ensure_full()
+        return self.engine.check_edges(np.asarray(starts, dtype=np.float64), np.asarray(ends, dtype=np.float64),
+                                       step_dist, _engine.AOS, interior_only=True).astype(bool)
 
     def valid_configs_planning(self, Q: np.ndarray, layout: int = _engine.AOS) -> np.ndarray:
         self._ensure_planning()

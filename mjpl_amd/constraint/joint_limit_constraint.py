@@ -11,6 +11,8 @@ from .constraint_interface import Constraint
 
 
 class JointLimitConstraint(Constraint):
+    projects = False  # apply() never moves a configuration: batched extension is allowed
+
     def __init__(self, model) -> None:
         rng = np.asarray(model.jnt_range, dtype=np.float64)
         self.lower, self.upper = rng[:, 0].copy(), rng[:, 1].copy()

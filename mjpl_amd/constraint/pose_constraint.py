@@ -17,6 +17,8 @@ from .constraint_interface import Constraint
 
 
 class PoseConstraint(Constraint):
+    projects = True  # apply() moves configurations: planners must take its steps one at a time
+
     def __init__(self, model, site: str, reference_frame: SE3,
                  x_translation: tuple[float, float] = (-np.inf, np.inf),
                  y_translation: tuple[float, float] = (-np.inf, np.inf),

@@ -49,10 +49,60 @@ def _valid_collision_interval(start: np.ndarray, end: np.ndarray, step_dist: flo
     return True
 
 
+def _batch_capable(constraints: list[Constraint], collision_interval_check) -> bool:
+    """True when a whole extension can be validated in batched launches: no constraint projects
+    (``projects`` is False) and every one offers row-wise ``valid_configs`` (and the interval
+    constraint row-wise ``valid_intervals``)."""
+    for c in constraints:
+        if getattr(c, "projects", True) or not hasattr(c, "valid_configs"):
+            return False
+    return collision_interval_check is None or hasattr(collision_interval_check[1], "valid_intervals")
+
+
+def _constrained_extend_batched(q_target: np.ndarray, tree: Tree, eps: float, constraints: list[Constraint],
+                                collision_interval_check, equality_threshold: float) -> np.ndarray:
+    """``_constrained_extend`` when no constraint projects.  The candidate configurations then do
+    not depend on the verdicts -- q_{k+1} = _step(q_k, q_target, eps) -- so the whole chain towards
+    the target is generated first and validated in one batch per constraint (plus one for the
+    intervals); the tree receives the nodes before the first failing step, exactly the nodes the
+    step-by-step loop would have added."""
+    node = tree.nearest_neighbor(q_target)
+    chain = [node.q]
+    while not np.array_equal(q_target, chain[-1]):
+        q_prev = chain[-1]
+        q = _step(q_prev, q_target, eps)
+        if np.linalg.norm(q - q_prev) < equality_threshold:
+            break
+        if np.linalg.norm(q_target - q) > np.linalg.norm(q_target - q_prev):
+            break
+        chain.append(q)
+    if len(chain) == 1:
+        return chain[0]
+    Q = np.stack(chain)
+    ok = np.ones(len(chain) - 1, dtype=bool)
+    for c in constraints:
+        idx = np.flatnonzero(ok)
+        if len(idx) == 0:
+            break
+        ok[idx] = np.asarray(c.valid_configs(Q[1:][idx]), dtype=bool)
+    if collision_interval_check is not None and ok.any():
+        step_dist, cc = collision_interval_check
+        n_ok = len(ok) if ok.all() else int(np.argmin(ok))  # only the steps before the first failure matter
+        ok[:n_ok] &= np.asarray(cc.valid_intervals(Q[:-1][:n_ok], Q[1:][:n_ok], step_dist), dtype=bool)
+    n_add = len(ok) if ok.all() else int(np.argmin(ok))
+    for k in range(1, n_add + 1):
+        node = Node(chain[k], node)
+        tree.add_node(node)
+    return chain[n_add]
+
+
 def _constrained_extend(q_target: np.ndarray, tree: Tree, eps: float, constraints: list[Constraint],
                         collision_interval_check=None, equality_threshold: float = 1e-8) -> np.ndarray:
     """CBiRRT Algorithm 2 (:105-164): grow ``tree`` from its node nearest to ``q_target`` in
     steps of at most ``eps``; returns the configuration reached."""
+    if _batch_capable(constraints, collision_interval_check):
+        return _constrained_extend_batched(q_target, tree, eps, constraints, collision_interval_check,
+                                           equality_threshold)
     node = tree.nearest_neighbor(q_target)
     q_prev = node.q
     q_cur = node.q

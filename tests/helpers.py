@@ -24,6 +24,18 @@ class OracleCollisionConstraint(Constraint):
         return self.orc.valid_collision_interval(start, end, step_dist)
 
 
+class BatchedOracleCollisionConstraint(OracleCollisionConstraint):
+    """The same verdicts with the row-wise methods the batched extension needs."""
+    projects = False
+
+    def valid_configs(self, Q):
+        self.calls += 1
+        return self.orc.valid_configs(np.asarray(Q, dtype=np.float64), nthreads=2).astype(bool)
+
+    def valid_intervals(self, starts, ends, step_dist):
+        return np.array([self.orc.valid_collision_interval(a, b, step_dist) for a, b in zip(starts, ends)], dtype=bool)
+
+
 def uniform_configs(model, n, seed, fingers=0.04):
     rng = np.random.default_rng(seed)
     Q = rng.uniform(model.jnt_range[:, 0], model.jnt_range[:, 1], size=(n, model.nq))
