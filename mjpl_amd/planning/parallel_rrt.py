@@ -173,6 +173,62 @@ class ParallelBiRRT:
         active = ~np.all(cur == targets, axis=1)
         project = getattr(self.validator, "project", None)
         pend_index: dict[bytes, int] = {}
+
+        def accept(lane, q):
+            """Lane `lane` moves to configuration q: an existing node, one already pending, or new."""
+            key = q.tobytes() + bytes([tree])
+            gid = self.index.get(key)
+            if gid is not None:
+                new_ref = gid
+            elif key in pend_index:
+                new_ref = pend_index[key]
+            else:
+                pending.append((q.copy(), int(ref[lane]), tree))
+                new_ref = -len(pending)
+                pend_index[key] = new_ref
+            cur[lane], ref[lane] = q, new_ref
+
+        if project is None:
+            # Nothing projects: a lane's candidates do not depend on the verdicts.  Generate every
+            # lane's whole chain of steps first, validate all their edges in ONE launch, then let each
+            # lane keep the steps before its first failure.
+            walk = cur.copy()
+            chains_a, chains_b, owner = [], [], []
+            alive = active.copy()
+            while alive.any():
+                a = np.flatnonzero(alive)
+                d = targets[a] - walk[a]
+                dist = _row_norm(d)
+                q_new = walk[a] + d / dist[:, None] * np.minimum(self.eps, dist)[:, None]
+                reach = np.all(q_new == targets[a], axis=1) | (dist <= self.eps)
+                q_new[reach] = targets[a][reach]
+                ok = np.all((q_new >= self.lo) & (q_new <= self.hi), axis=1)
+                ok &= ~(_row_norm(q_new - walk[a]) < 1e-8)
+                ok &= ~(_row_norm(targets[a] - q_new) > dist)
+                good = a[ok]
+                chains_a.append(walk[good].copy())
+                chains_b.append(q_new[ok])
+                owner.append(good)
+                walk[good] = q_new[ok]
+                alive[a[~ok | reach]] = False
+            if owner and sum(len(o) for o in owner):
+                QA, QB = np.concatenate(chains_a), np.concatenate(chains_b)
+                valid = self.validator.valid_edges(QA, QB, self.interval_step)
+                blocked = np.zeros(B, bool)
+                pos = 0
+                for own in owner:  # step by step, in the order the one-step-per-launch loop takes them
+                    v = valid[pos:pos + len(own)]
+                    qb = QB[pos:pos + len(own)]
+                    pos += len(own)
+                    for k, lane in enumerate(own):
+                        if blocked[lane]:
+                            continue
+                        if v[k]:
+                            accept(lane, qb[k])
+                        else:
+                            blocked[lane] = True
+            return cur, ref
+
         while active.any():
             a = np.flatnonzero(active)
             d = targets[a] - cur[a]
@@ -180,10 +236,9 @@ class ParallelBiRRT:
             q_new = cur[a] + d / dist[:, None] * np.minimum(self.eps, dist)[:, None]
             reach = np.all(q_new == targets[a], axis=1) | (dist <= self.eps)
             q_new[reach] = targets[a][reach]  # `_step` lands on the target within one step
-            ok = np.ones(len(a), bool)
-            if project is not None:  # constraints that project come first (constraint/utils.py:30-31)
-                q_new, ok = project(cur[a], q_new)
-                reach = np.all(q_new == targets[a], axis=1)
+            # constraints that project come first (constraint/utils.py:30-31)
+            q_new, ok = project(cur[a], q_new)
+            reach = np.all(q_new == targets[a], axis=1)
             ok &= np.all((q_new >= self.lo) & (q_new <= self.hi), axis=1)
             moved = _row_norm(q_new - cur[a])
             ok &= ~(moved < 1e-8)
@@ -192,18 +247,7 @@ class ParallelBiRRT:
                 sel = np.flatnonzero(ok)
                 ok[sel] = self.validator.valid_edges(cur[a][sel], q_new[sel], self.interval_step)
             for k in np.flatnonzero(ok):
-                lane = a[k]
-                key = q_new[k].tobytes() + bytes([tree])
-                gid = self.index.get(key)
-                if gid is not None:
-                    new_ref = gid
-                elif key in pend_index:
-                    new_ref = pend_index[key]
-                else:
-                    pending.append((q_new[k].copy(), int(ref[lane]), tree))
-                    new_ref = -len(pending)
-                    pend_index[key] = new_ref
-                cur[lane], ref[lane] = q_new[k], new_ref
+                accept(a[k], q_new[k])
             done = ~ok | reach
             active[a[done]] = False
         return cur, ref
