@@ -201,3 +201,18 @@ def test_projection_on_random_models(oracle_mod, seed):
     assert same.mean() > 0.99, same.mean()
     np.testing.assert_allclose(got[same], ref[same], rtol=0, atol=1e-8)
     assert np.array_equal(pc.valid_configs(got[same & ok]), np.ones((same & ok).sum(), bool))
+
+
+def test_constrained_move_to_pose_example(monkeypatch):
+    """examples/franka_constrained_move_to_pose.py end to end: PoseConstraint + joint limits +
+    collision, goal from the batched IK solver, serial RRT, shortcutting."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                        "franka_constrained_move_to_pose.py")
+    spec = importlib.util.spec_from_file_location("franka_constrained_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", [path, "-s", "5"])
+    assert mod.main()
