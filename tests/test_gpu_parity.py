@@ -202,3 +202,41 @@ def test_two_pass_and_one_pass_filter_agree(monkeypatch):
         np.testing.assert_array_equal(out["two"][0], out[tag][0])
         np.testing.assert_array_equal(out["two"][1], out[tag][1])
     assert 0 < out["two"][0].sum() < len(qa)
+
+
+def test_waypoint_recurrence_corner_cases(oracle_mod):
+    """Edges whose length is zero, tiny, below one step, an exact multiple of the step (where
+    rounding decides whether one more waypoint appears) or many steps long: the waypoint items the
+    endpoint kernel emits, the walking kernel and the oracle must agree on valid AND first_bad,
+    which is sensitive to every single waypoint (a wall in the middle of the 1-DoF scene)."""
+    m = scenes.one_dof_ball()
+    orc = oracle_mod.Oracle(m)
+    rng = np.random.default_rng(0)
+    step = 0.01
+    starts, ends = [], []
+    for a in np.concatenate([np.linspace(0.0, 0.84, 64), rng.uniform(0.0, 0.84, 192)]):
+        for length in (0.0, 1e-150, 1e-12, 0.5 * step, step, np.nextafter(step, 0), np.nextafter(step, 1),
+                       3 * step, np.nextafter(3 * step, 1), 7 * step, 0.05, 0.1, 0.17, 0.3, 0.7, 1.3):
+            starts.append([a])
+            ends.append([a + length])
+    qa, qb = np.array(starts), np.array(ends)
+    want, wfb, ncheck = orc.valid_edges(qa, qb, step, nthreads=4, info=True)
+    assert 0 < want.sum() < len(want) and ncheck.max() > 50
+    import os
+    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_ITEM_CAP": "500"}):
+        old = {k: os.environ.pop(k, None) for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_ITEM_CAP")}
+        os.environ.update(env)
+        try:
+            e = eng_mod.Engine(m)
+            got, gfb = e.check_edges(qa, qb, step, first_bad=True)
+            gi = e.check_edges(qa, qb, step, interior_only=True)
+        finally:
+            for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_ITEM_CAP"):
+                os.environ.pop(k, None)
+                if old[k] is not None:
+                    os.environ[k] = old[k]
+        np.testing.assert_array_equal(got, want, err_msg=str(env))
+        np.testing.assert_array_equal(gfb, wfb, err_msg=str(env))
+        wi = np.array([orc.valid_collision_interval(a, b, step) for a, b in zip(qa[::5], qb[::5])])
+        np.testing.assert_array_equal(gi[::5].astype(bool), wi, err_msg=str(env))
+        e.close()
