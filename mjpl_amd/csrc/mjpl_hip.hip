@@ -310,7 +310,12 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
         qw[k * B] = nw;
         eq = eq && (nw == ek);
       }
-      if (eq) {
+      if (!(mag > 0.0) || !(mag <= 1.79769313486231570815e+308)) {
+        // the squared distance under- or overflowed: the reference's recurrence yields NaN from
+        // here on and never ends -- reported like a non-finite edge
+        done = true; ok = false; fb = -2;
+        atomicOr(status, kStatusNonFinite);
+      } else if (eq) {
         done = true;  // reached QB: that element is dropped by waypoints[1:-1]
       } else {
         idx++;
@@ -427,6 +432,7 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
   }
   // one step of the recurrence: _step(w, QB, step)  (planning/utils.py:182-185; the statements of
   // edge_body); returns true when the walk has arrived at QB
+  bool degenerate = false;  // the squared distance under- or overflowed (see edge_body)
   auto advance = [&]() -> bool {
     double s = 0;
     for (int k = 0; k < nplan; k++) {
@@ -435,6 +441,7 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
       s = s + d * d;
     }
     const double mag = sqrt(s);
+    degenerate = degenerate || !(mag > 0.0) || !(mag <= 1.79769313486231570815e+308);
     const double sm = step < mag ? step : mag;
     bool eq = true;
     for (int k = 0; k < nplan; k++) {
@@ -454,6 +461,7 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
       if (walking) {
         if (advance()) walking = false;
         else if (++K > ib.kmax) walking = false;
+        if (degenerate) { walking = false; K = ib.kmax + 1; }  // the walking kernel reports it
       }
     }
   }

@@ -240,3 +240,36 @@ def test_waypoint_recurrence_corner_cases(oracle_mod):
         wi = np.array([orc.valid_collision_interval(a, b, step) for a, b in zip(qa[::5], qb[::5])])
         np.testing.assert_array_equal(gi[::5].astype(bool), wi, err_msg=str(env))
         e.close()
+
+
+def test_underflowing_edge_is_reported_not_walked(oracle_mod):
+    """An edge so short that its squared length underflows makes the reference's recurrence
+    divide by zero and never end; the oracle and the engine both report it as a non-finite edge
+    (and the engine does so at once, in every interior-pass mode)."""
+    import os
+    import time
+    m = scenes.one_dof_ball()
+    qa = np.array([[0.1], [0.2], [0.3]])
+    qb = np.array([[0.1 + 1e-3], [0.2 + 1e-170], [0.3]])
+    qb[1, 0] = np.nextafter(0.2, 1.0)  # one ulp: (2.8e-17)^2 is fine ...
+    qa2 = np.array([[0.0], [1e-170], [0.3]])  # ... but 1e-170 next to zero is not
+    qb2 = np.array([[1e-3], [2e-170], [0.3]])
+    orc = oracle_mod.Oracle(m)
+    with pytest.raises(RuntimeError):
+        orc.valid_edges(qa2, qb2, 0.01)
+    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_FILTER": "0"}):
+        old = {k: os.environ.pop(k, None) for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_FILTER")}
+        os.environ.update(env)
+        try:
+            e = eng_mod.Engine(m)
+            assert e.check_edges(qa, qb, 0.01).tolist() == [1, 1, 1]
+            t0 = time.time()
+            with pytest.raises(eng_mod.MjplError, match="NaN/inf"):
+                e.check_edges(qa2, qb2, 0.01)
+            assert time.time() - t0 < 5.0
+            e.close()
+        finally:
+            for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_FILTER"):
+                os.environ.pop(k, None)
+                if old[k] is not None:
+                    os.environ[k] = old[k]
