@@ -275,6 +275,16 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
   bool done = !active;
   bool ok = true, unsure = false;
   int fb = -1;
+  if (active && finite) {
+    // an edge that needs more than kMaxWaypoints steps would only be found out after walking
+    // them all: say so at once (same verdict: reported like a non-finite edge)
+    double s0 = 0;
+    for (int k = 0; k < nplan; k++) {
+      const double d = qw[k * B] - start_col(k);
+      s0 = s0 + d * d;
+    }
+    if (!(sqrt(s0) <= step * (kMaxWaypoints + 2.0))) finite = false;
+  }
   if (active && !finite) {
     done = true; ok = false; fb = -2;
     atomicOr(status, kStatusNonFinite);

@@ -273,3 +273,15 @@ def test_underflowing_edge_is_reported_not_walked(oracle_mod):
                 os.environ.pop(k, None)
                 if old[k] is not None:
                     os.environ[k] = old[k]
+
+
+def test_absurdly_long_edge_is_refused_at_once():
+    """More than 2^20 waypoints: an error, not a kernel that walks them all."""
+    import time
+    m = scenes.one_dof_ball()
+    e = eng_mod.Engine(m)
+    t0 = time.time()
+    with pytest.raises(eng_mod.MjplError, match="waypoints"):
+        e.check_edges(np.array([[0.0]]), np.array([[1.5]]), 1e-7)
+    assert time.time() - t0 < 5.0
+    assert e.check_edges(np.array([[0.0]]), np.array([[0.5]]), 1e-4).tolist() == [1]  # 5 000 waypoints are fine
