@@ -1068,8 +1068,8 @@ struct UndecidedConfigs {
 // Where a drain reports candidates it cannot decide (count == nullptr: flag the owning lane).
 struct PatchSink {
   UndecidedConfigs uc;
-  const double *qcol;  // LDS columns of this wave's lanes: q[k] of lane l at qcol[k * B + l]
-  int B, nplan;
+  const double *qcol;  // configurations of this wave's lanes: q[k] of lane l at qcol[k * B + l * L]
+  int B, L, nplan;     // (LDS columns: B = block size, L = 1; row-major items: B = 1, L = nplan)
   int idx;             // check index of the configurations under test (wave-uniform) ...
   const int *item_edge, *item_idx;  // ... or, lane-per-waypoint kernels: (edge, index) of item i
 };
@@ -1216,7 +1216,7 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
       if (ps.uc.count) {
         const int u = atomicAdd(ps.uc.count, 1);
         if (u < ps.uc.cap) {
-          for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + owner];
+          for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + owner * ps.L];
           const int item = (int)((unsigned)wq.flags[owner] >> 2);
           ps.uc.edge[u] = ps.item_edge ? ps.item_edge[item] : item;
           ps.uc.idx[u] = ps.item_idx ? ps.item_idx[item] : ps.idx;

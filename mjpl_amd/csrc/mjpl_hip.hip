@@ -95,7 +95,8 @@ __device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int
     // where a drain lane finds the owner's configuration: the LDS columns, or (lane-per-item
     // kernel reading its configurations straight from the item buffer) global memory
     ps.qcol = sink_q ? sink_q : c.col0 + (threadIdx.x & ~63);
-    ps.B = sink_q ? sink_stride : B;
+    ps.B = sink_q ? 1 : B;
+    ps.L = sink_q ? sink_stride : 1;
     ps.nplan = c.ip[H_NPLAN];
     ps.idx = idx;
     ps.item_edge = item_edge;
@@ -398,11 +399,12 @@ k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ g
 // size that is 2 300 waves for 1 024 SIMDs, each alive for the whole kernel.  Here the waypoints
 // themselves become the work items: the endpoint kernel walks the reference's recurrence for
 // every edge whose endpoint passed (float64, the statements of edge_body) and writes the interior
-// waypoints into a dense SoA buffer; k_filter_items checks one waypoint per lane.  Consecutive
+// waypoints into a dense item buffer; k_filter_items checks one waypoint per lane.  Consecutive
 // items are consecutive waypoints of one edge, so the lanes of a wave see similar poses and pass
 // the same bounding culls.  Edges with many waypoints stay with the walking kernel: `llist`.
 struct ItemBuffers {
-  double *w;        // [nplan][cap] waypoints, SoA
+  double *w;        // [cap][nplan] waypoints, one row per item (a lane's items are adjacent rows,
+                    // so the lines it writes during its walk fill up in cache)
   int *edge, *idx;  // [cap] which edge, which check index (1..K)
   int *count;       // items written
   int cap;
@@ -503,7 +505,7 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
     if (!done && idx <= K) {
       advance();
       const int slot = first + idx - 1;
-      for (int k = 0; k < nplan; k++) ib.w[(size_t)k * ib.cap + slot] = qw[k * ws];
+      for (int k = 0; k < nplan; k++) ib.w[(size_t)slot * nplan + k] = qw[k * ws];
       ib.edge[slot] = (int)i;
       ib.idx[slot] = idx;
     }
@@ -925,8 +927,8 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
   const bool active = it < n && ib.edge[it] >= 0;  // (a void slot: reserved by an edge that did not fit)
   __syncthreads();
   const int64_t itc = it < (int64_t)ib.cap ? it : 0;
-  const int code = check_one<float, MAXS, WBOX, MBOX>(c, ib.w + itc, B, active, tol, it, uc, 0, ib.edge, ib.idx,
-                                                      ib.w + (itc - (threadIdx.x & 63)), ib.cap, ib.cap);
+  const int code = check_one<float, MAXS, WBOX, MBOX>(c, ib.w + itc * nplan, B, active, tol, it, uc, 0, ib.edge,
+                                                      ib.idx, ib.w + (itc - (threadIdx.x & 63)) * nplan, nplan, 1);
   if (active && code != V_NONE) {
     const int ed = ib.edge[it];
     if (code == V_CONTACT) {
