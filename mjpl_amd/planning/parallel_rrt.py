@@ -89,6 +89,35 @@ def _row_norm(d: np.ndarray) -> np.ndarray:
     return np.sqrt(np.einsum("ij,ij->i", d, d))
 
 
+class _Pending:
+    """This rank's new nodes of the current round, in creation order.  Entry k is referred to
+    as ``-(k + 1)`` until the exchange has given it a global id."""
+
+    def __init__(self):
+        self.rows: list[np.ndarray] = []   # chunks [m, n]
+        self.parents: list[int] = []
+        self.trees: list[int] = []
+        self.keys: list[bytes] = []
+
+    def __len__(self) -> int:
+        return len(self.parents)
+
+    def add(self, rows: np.ndarray, parents: list, tree: int, keys: list) -> None:
+        self.rows.append(rows)
+        self.parents.extend(parents)
+        self.trees.extend([tree] * len(parents))
+        self.keys.extend(keys)
+
+    def slab(self, nrows: int, ncols: int) -> np.ndarray:
+        out = np.zeros((max(nrows, 1), ncols + 2))
+        cnt = len(self)
+        if cnt:
+            out[:cnt, :ncols] = np.concatenate(self.rows)
+            out[:cnt, ncols] = self.parents
+            out[:cnt, ncols + 1] = self.trees
+        return out
+
+
 class ParallelBiRRT:
     def __init__(self, model, planning_joints: list[str], validator: EdgeValidator, q_template: np.ndarray,
                  epsilon: float = 0.05, interval_step: float | None = None, seed: int = 0,
@@ -132,15 +161,18 @@ class ParallelBiRRT:
         self._append(q_init_p, -1, 0)
         self._append(q_goal_p, -1, 1)
 
+    def _reserve(self, extra: int) -> None:
+        while self.n + extra > len(self.Q):
+            self.Q = np.concatenate([self.Q, np.empty_like(self.Q)])
+            self.parent = np.concatenate([self.parent, np.empty_like(self.parent)])
+            self.tree = np.concatenate([self.tree, np.empty_like(self.tree)])
+
     def _append(self, q, parent, tree) -> int:
         key = q.tobytes() + bytes([tree])
         hit = self.index.get(key)
         if hit is not None:
             return hit
-        if self.n == len(self.Q):
-            self.Q = np.concatenate([self.Q, np.empty_like(self.Q)])
-            self.parent = np.concatenate([self.parent, np.empty_like(self.parent)])
-            self.tree = np.concatenate([self.tree, np.empty_like(self.tree)])
+        self._reserve(1)
         i = self.n
         self.Q[i], self.parent[i], self.tree[i] = q, parent, tree
         self.index[key] = i
@@ -163,9 +195,9 @@ class ParallelBiRRT:
 
     # ------------------------------------------------------------------ batched extend
     def _extend(self, targets, tree, pending):
-        """Reference extend loop on every lane at once.  ``pending`` collects this rank's new
-        nodes as (q, parent_ref, tree): parent_ref >= 0 is a global node id, < 0 refers to
-        pending[-1 - parent_ref].  Returns (q_reached, ref_reached) per lane."""
+        """Reference extend loop on every lane at once.  ``pending`` (:class:`_Pending`) collects
+        this rank's new nodes: a parent reference >= 0 is a global node id, < 0 refers to pending
+        entry ``-1 - ref``.  Returns (q_reached, ref_reached) per lane."""
         B = len(targets)
         near = self._nearest(targets, tree)
         cur = self.Q[near].copy()
@@ -174,19 +206,36 @@ class ParallelBiRRT:
         project = getattr(self.validator, "project", None)
         pend_index: dict[bytes, int] = {}
 
-        def accept(lane, q):
-            """Lane `lane` moves to configuration q: an existing node, one already pending, or new."""
-            key = q.tobytes() + bytes([tree])
-            gid = self.index.get(key)
-            if gid is not None:
-                new_ref = gid
-            elif key in pend_index:
-                new_ref = pend_index[key]
-            else:
-                pending.append((q.copy(), int(ref[lane]), tree))
-                new_ref = -len(pending)
-                pend_index[key] = new_ref
-            cur[lane], ref[lane] = q, new_ref
+        tb = bytes([tree])
+
+        def accept_rows(lanes, rows):
+            """Lanes move to the configurations `rows`, taken in order (a lane may appear several
+            times: its later rows hang off its earlier ones).  A row is an existing node of this
+            tree, a node already pending this round, or a new pending node."""
+            keys = [r.tobytes() + tb for r in rows]
+            new_at, new_parents, new_keys = [], [], []
+            ref_l = ref.tolist()
+            index_get, pend_get = self.index.get, pend_index.get
+            base = len(pending)
+            for k, (lane, key) in enumerate(zip(lanes.tolist(), keys)):
+                r = index_get(key)
+                if r is None:
+                    r = pend_get(key)
+                    if r is None:
+                        new_at.append(k)
+                        new_parents.append(ref_l[lane])
+                        new_keys.append(key)
+                        r = -(base + len(new_at))
+                        pend_index[key] = r
+                ref_l[lane] = r
+            if new_at:
+                pending.add(rows[new_at], new_parents, tree, new_keys)
+            ref[:] = ref_l
+            # every lane ends on its last row
+            last = np.full(B, -1)
+            last[lanes] = np.arange(len(lanes))
+            moved = np.flatnonzero(last >= 0)
+            cur[moved] = rows[last[moved]]
 
         if project is None:
             # Nothing projects: a lane's candidates do not depend on the verdicts.  Generate every
@@ -213,20 +262,14 @@ class ParallelBiRRT:
                 alive[a[~ok | reach]] = False
             if owner and sum(len(o) for o in owner):
                 QA, QB = np.concatenate(chains_a), np.concatenate(chains_b)
-                valid = self.validator.valid_edges(QA, QB, self.interval_step)
-                blocked = np.zeros(B, bool)
-                pos = 0
-                for own in owner:  # step by step, in the order the one-step-per-launch loop takes them
-                    v = valid[pos:pos + len(own)]
-                    qb = QB[pos:pos + len(own)]
-                    pos += len(own)
-                    for k, lane in enumerate(own):
-                        if blocked[lane]:
-                            continue
-                        if v[k]:
-                            accept(lane, qb[k])
-                        else:
-                            blocked[lane] = True
+                lanes_f = np.concatenate(owner)
+                level_f = np.concatenate([np.full(len(o), s) for s, o in enumerate(owner)])
+                valid = np.asarray(self.validator.valid_edges(QA, QB, self.interval_step), dtype=bool)
+                first_fail = np.full(B, len(owner))
+                np.minimum.at(first_fail, lanes_f[~valid], level_f[~valid])
+                keep = level_f < first_fail[lanes_f]  # step by step (levels), lanes ascending within a level
+                if keep.any():
+                    accept_rows(lanes_f[keep], QB[keep])
             return cur, ref
 
         while active.any():
@@ -246,8 +289,9 @@ class ParallelBiRRT:
             if ok.any():
                 sel = np.flatnonzero(ok)
                 ok[sel] = self.validator.valid_edges(cur[a][sel], q_new[sel], self.interval_step)
-            for k in np.flatnonzero(ok):
-                accept(a[k], q_new[k])
+            sel = np.flatnonzero(ok)
+            if len(sel):
+                accept_rows(a[sel], q_new[sel])
             done = ~ok | reach
             active[a[done]] = False
         return cur, ref
@@ -278,21 +322,36 @@ class ParallelBiRRT:
         if most > self.slab_rows:
             raise RuntimeError("more new nodes in one round than `max_new_per_round`")
         rows = 1 << max(most - 1, 0).bit_length() if most else 0
-        slab = np.zeros((max(rows, 1), n + 2))
-        for k, (q, pref, tree) in enumerate(pending):
-            slab[k, :n] = q
-            slab[k, n] = pref
-            slab[k, n + 1] = tree
+        slab = pending.slab(rows, n)
         slabs = self._allgather(slab) if rows else np.zeros((self.world, 1, n + 2))
         winner, stop = None, False
         for r in range(self.world):
             cnt = int(heads[r, 0])
-            local_to_global = np.empty(cnt, np.int64)
-            for k in range(cnt):
-                row = slabs[r, k]
-                pref = int(row[n])
-                par = pref if pref >= 0 else int(local_to_global[-1 - pref])
-                local_to_global[k] = self._append(row[:n].copy(), par, int(row[n + 1]))
+            block = slabs[r, :cnt]
+            qrows = np.ascontiguousarray(block[:, :n])
+            prefs = block[:, n].astype(np.int64)
+            trees = block[:, n + 1].astype(np.int64)
+            if r == self.rank and len(pending.keys) == cnt:
+                keys = pending.keys
+            else:
+                keys = [q.tobytes() + bytes([t]) for q, t in zip(qrows, trees.tolist())]
+            fresh = cnt > 0 and len(set(keys)) == cnt and not any(k in self.index for k in keys)
+            if fresh:
+                # the usual case: none of these nodes exists yet -> append them in one go
+                base = self.n
+                self._reserve(cnt)
+                local_to_global = base + np.arange(cnt, dtype=np.int64)
+                self.Q[base:base + cnt] = qrows
+                self.tree[base:base + cnt] = trees
+                self.parent[base:base + cnt] = np.where(prefs >= 0, prefs, base + (-1 - prefs))
+                self.index.update(zip(keys, range(base, base + cnt)))
+                self.n += cnt
+            else:
+                local_to_global = np.empty(cnt, np.int64)
+                for k in range(cnt):
+                    pref = int(prefs[k])
+                    par = pref if pref >= 0 else int(local_to_global[-1 - pref])
+                    local_to_global[k] = self._append(qrows[k].copy(), par, int(trees[k]))
             if winner is None and not np.isnan(heads[r, 1]):
                 refs = [int(heads[r, 1]), int(heads[r, 2])]
                 winner = tuple(x if x >= 0 else int(local_to_global[-1 - x]) for x in refs)
@@ -324,7 +383,7 @@ class ParallelBiRRT:
             targets = rng.uniform(self.lo, self.hi, size=(self.batch, len(self.qidx)))
             bias = rng.random(self.batch) <= self.p_goal
             targets[bias] = b if grow == 0 else a  # goal bias: the other tree's root
-            pending: list = []
+            pending = _Pending()
             reached_a, ref_a = self._extend(targets, grow, pending)
             reached_b, ref_b = self._extend(reached_a, other, pending)
             checks += 2 * self.batch
