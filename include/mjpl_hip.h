@@ -194,11 +194,12 @@ void *mjpl_stream(mjpl_engine *e);
 
 /* ---- measurement ---------------------------------------------------------------- */
 
-/* Run mjpl_check_edges_dev `iters` times on the engine's stream, each call bracketed by HIP
- * events recorded on that stream; ms[k] receives call k's duration (all of its kernels) and
- * ms_first[k] (nullable) the duration of its first, dominant kernel alone (the float32
- * filter; the only kernel when the filter is off).  Inputs and outputs are device-resident.
- * Used by bench.py for roofline.achieved. */
+/* Run mjpl_check_edges_dev `iters` times on the engine's stream with HIP events recorded on that
+ * stream: two around the whole run -- every ms[k] receives the mean duration of a call (all of
+ * its kernels) -- and two per call around its dominant kernel, ms_first[k] (nullable: the float32
+ * interior pass; the only kernel when the filter is off).  Calls are not bracketed one by one: the
+ * extra events cost a few percent of the throughput being measured.  Inputs and outputs are
+ * device-resident.  Used by bench.py for roofline.achieved. */
 int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E,
                         double step_dist, int32_t layout, uint8_t *dvalid, int32_t iters,
                         float *ms, float *ms_first);
