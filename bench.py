@@ -125,6 +125,97 @@ def bench_configs(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_next_rows(args):
+    """One GPU's share of BASELINE configs[3] (PoseConstraint projections of 1 M / 8 samples) or
+    configs[4] (128k / 8 IK seeds -> FK -> collision filter); device-resident inputs for the
+    projection, host buffers (PCIe included) for the IK seeds.  Results are checked against the
+    oracle on a sample."""
+    import mjpl_amd as mjpl
+    from mjpl_amd import scenes
+    from oracle import pyoracle
+    model = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    q_home = model.keyframe("home").qpos.copy()
+    cc = mjpl.CollisionConstraint(model)
+    eng = cc.engine
+    lo, hi = model.jnt_range[:, 0], model.jnt_range[:, 1]
+    rng = np.random.default_rng(4)
+    common = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    if args.workload == "pose":
+        frame = mjpl.site_pose(model, q_home, "ee_site", engine=eng)
+        pc = mjpl.PoseConstraint(model, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), q_step=0.5, engine=eng)
+        n = 131072
+        Q_old = np.clip(q_home + rng.normal(scale=0.01, size=(n, model.nq)), lo, hi)
+        d = rng.normal(size=(n, model.nq))
+        d[:, 7:] = 0
+        Q = np.clip(Q_old + 0.3 * d / np.linalg.norm(d, axis=1, keepdims=True), lo, hi)
+        dqo, dq = eng.alloc(Q_old.nbytes).upload(Q_old), eng.alloc(Q.nbytes).upload(Q)
+        dout, dok, dit = eng.alloc(Q.nbytes), eng.alloc(n), eng.alloc(4 * n)
+        for _ in range(max(args.warmup, 1)):
+            pc._proj.apply_dev(dqo.ptr, dq.ptr, n, dout.ptr, dok.ptr, dit.ptr)
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pc._proj.apply_dev(dqo.ptr, dq.ptr, n, dout.ptr, dok.ptr, dit.ptr)
+        eng.sync()
+        elapsed = time.perf_counter() - t0
+        out_q, ok, iters = dout.download(np.float64, n * model.nq).reshape(n, -1), dok.download(np.uint8, n), dit.download(np.int32, n)
+        inv = frame.inverse()
+        po = pyoracle.PoseOracle(model, "ee_site", (inv.wxyz_xyz[:4], inv.wxyz_xyz[4:]),
+                                 [(-np.inf, np.inf)] * 3 + [(-0.1, 0.1)] * 2 + [(-np.inf, np.inf)], q_step=0.5)
+        k = 8192
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        ref, rok, rit = po.apply_batch(Q_old[:k], Q[:k], nthreads=cores)
+        dtc = time.perf_counter() - t0
+        same = (rok == ok[:k].astype(bool)) & (rit == iters[:k])
+        if same.mean() < 0.99 or np.abs(ref[same] - out_q[:k][same]).max() > 1e-8:
+            sys.exit("bench.py: GPU projections differ from the CPU oracle")
+        out = dict(common, metric="PoseConstraint projections/sec, Franka-P ee roll/pitch +-0.1 (one GPU of configs[3])",
+                   value=n * args.steps / elapsed, unit="rows/s", ms_per_step=elapsed / args.steps * 1e3,
+                   config={"workload": f"{n} rows per launch, {np.abs(iters).mean():.1f} projection steps per row on average",
+                           "accepted_fraction": float(ok.mean())},
+                   roofline={"bound": "hbm", "achieved": n * (2 * 8 * model.nq + 8 * model.nq + 1) * args.steps / elapsed / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": n * (3 * 8 * model.nq + 1) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "note": "FP64 issue bound (6x6 Jacobi eigen-decomposition per projection step)"},
+                   cpu_baseline={"value": k / dtc, "unit": "rows/s", "cores": cores, "kind": "port",
+                                 "sample": f"first {k} rows, {cores} pthreads"})
+    else:
+        solver = mjpl.HipIKSolver(model, joints, [], seed=3, num_seeds=16384, iterations=200, engine=eng)
+        q_t = mjpl.random_config(model, q_home, joints, 5, [mjpl.JointLimitConstraint(model), cc])
+        target = mjpl.site_pose(model, q_t, "ee_site", engine=eng)
+        Q0 = solver._seeds(q_home, np.random.default_rng(3))
+
+        def once():
+            Qs, ok, its, err = eng.ik_solve("ee_site", target.translation(), target.rotation().wxyz, Q0, solver.movable,
+                                            iterations=200)
+            return Qs, ok, its, cc.valid_configs(Qs[ok])
+
+        for _ in range(max(args.warmup, 1)):
+            once()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            Qs, ok, its, free = once()
+        elapsed = time.perf_counter() - t0
+        orc = pyoracle.Oracle(model)
+        sample = np.flatnonzero(ok)[:2048]
+        if not np.array_equal(orc.valid_configs(Qs[sample], nthreads=8).astype(bool), free[:len(sample)]):
+            sys.exit("bench.py: collision filter differs from the CPU oracle")
+        out = dict(common, metric="IK seeds/sec: damped-least-squares seeds -> FK -> collision filter (one GPU of configs[4])",
+                   value=len(Q0) * args.steps / elapsed, unit="seeds/s", ms_per_step=elapsed / args.steps * 1e3,
+                   config={"workload": f"{len(Q0)} seeds per launch, <= 200 iterations, host buffers (PCIe included)",
+                           "converged_fraction": float(ok.mean()), "collision_free_of_converged": float(free.mean()),
+                           "mean_iterations": float(its.mean())},
+                   roofline={"bound": "hbm", "achieved": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "note": "latency of the iteration chain (256 waves on 1 024 SIMDs)"},
+                   cpu_baseline=None)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,12 +224,16 @@ def main():
     ap.add_argument("--edges", type=int, default=EDGES_PER_GPU)
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["edges", "configs"], default="edges",
-                    help="edges: the headline metric (BASELINE configs[2]); configs: BASELINE configs[1], "
-                         "65 536 Franka-P self-collision configurations per launch (an extra line, not the headline)")
+    ap.add_argument("--workload", choices=["edges", "configs", "pose", "ik"], default="edges",
+                    help="edges: the headline metric (BASELINE configs[2]).  Extra lines, not the headline: "
+                         "configs = configs[1], 65 536 Franka-P self-collision configurations per launch; "
+                         "pose = one GPU's share of configs[3], 131 072 PoseConstraint projections; "
+                         "ik = one GPU's share of configs[4], 16 384 IK seeds -> FK -> collision filter")
     args = ap.parse_args()
     if args.workload == "configs":
         return bench_configs(args)
+    if args.workload in ("pose", "ik"):
+        return bench_next_rows(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
