@@ -53,6 +53,10 @@ template <> struct Real<float> { static constexpr bool exact = false; typedef FP
 
 // verdict codes of the narrowphase (the exact path only produces 0 and 1)
 enum : int { V_NONE = 0, V_CONTACT = 1, V_UNSURE = 2 };
+// the float32 filter decides only configurations whose body origins stay within this many metres
+// of the world origin (rounding error ~ 1e-7 x coordinate x chain length must stay far below the
+// tolerance band)
+constexpr float kFilterMaxCoord = 64.0f;
 
 // ----------------------------------------------------------------------------- program layout
 // The model is compiled on the host (mjpl_hip.hip: compile_program) into two flat tables that
@@ -815,6 +819,8 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
 #pragma unroll
     for (int k = 0; k < 4; k++) qt[k] = nq[k];
     quat2mat(R, qt);
+    if constexpr (!Real<T>::exact)  // see run_config_queued: too far out for the float32 tolerance
+      unsure = unsure || (active && !(fmax(fabs(p[0]), fmax(fabs(p[1]), fabs(p[2]))) <= T(kFilterMaxCoord)));
 
     if (save_slot >= 0) {
       T *sv = save + (size_t)save_slot * 7 * sstride;
@@ -1254,6 +1260,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   MJPL_T0(tt);
   const T kInf = __builtin_inff();
   T dead = active ? T(0) : kInf;
+  bool far = false;
   int fl = 0;
   int qn = 0, qb = 0;  // wave-uniform queue fills (general / static boxes)
 #ifdef MJPL_X_Q_NOPUSH
@@ -1345,6 +1352,11 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
 #pragma unroll
     for (int k = 0; k < 4; k++) qt[k] = nq[k];
     quat2mat(R, qt);
+    // float32 positions lose absolute accuracy with distance from the origin: beyond
+    // kFilterMaxCoord the tolerance band no longer covers the rounding error, so the whole
+    // configuration goes to the exact path (this also catches NaN)
+    far = far || !(fmax(fabs(p[0]), fmax(fabs(p[1]), fabs(p[2]))) <= T(kFilterMaxCoord));
+    if (far) dead = kInf;
     if (save_slot >= 0) {
       T *sv = save + (size_t)save_slot * 7 * sstride;
 #pragma unroll
@@ -1408,7 +1420,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps);
 #endif
           fl = wq.flags[lane] & 3;
-          dead = (fl != 0 || !active) ? kInf : T(0);
+          dead = (fl != 0 || !active || far) ? kInf : T(0);
           MJPL_ACC(3, tt);  // drains
         }
         T *qf = BOXQ ? wq.bf : wq.nf;
@@ -1571,6 +1583,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
 #ifdef MJPL_X_Q_NOPUSH
   if (sink == 0x123456789ull) fl |= 1;
 #endif
+  if (active && far) return V_UNSURE;  // nothing this lane's candidates said can be trusted
   return !active ? V_NONE : ((fl & 1) ? V_CONTACT : ((fl & 2) ? V_UNSURE : V_NONE));
 }
 

@@ -346,8 +346,9 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
       // the filter cannot decide this configuration: hand IT (not the whole edge) to the exact
       // configuration kernel and walk on as if it were valid; that kernel lowers first_bad and
       // clears valid if it finds a contact.  Only if the hand-off buffer is full does the whole
-      // edge go to the exact edge kernel.
-      const int j = atomicAdd(uc.count, 1);
+      // edge go to the exact edge kernel.  (The queued interpreter hands over single pairs by
+      // itself; when IT reports a configuration undecidable, the whole edge goes.)
+      const int j = kQueued<T, MBOX> ? uc.cap : atomicAdd(uc.count, 1);
       if (j < uc.cap) {
         for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
         uc.edge[j] = (int)i;
@@ -555,7 +556,7 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
     } else {
       bool whole_edge = false;
       if (code == V_UNSURE) {  // the endpoint itself goes to the exact configuration kernel
-        const int j = atomicAdd(uc.count, 1);
+        const int j = kQueued<float, MBOX> ? uc.cap : atomicAdd(uc.count, 1);  // (queued: the whole edge)
         if (j < uc.cap) {
           for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
           uc.edge[j] = (int)i;

@@ -278,3 +278,33 @@ def test_dense_clutter_stresses_the_candidate_queues(oracle_mod):
     np.testing.assert_array_equal(g, w)
     np.testing.assert_array_equal(gfb, wfb)
     assert e.last_undecided() > 0
+
+
+@pytest.mark.parametrize("moving_boxes", [False, True])
+def test_far_from_the_origin_the_filter_steps_aside(oracle_mod, moving_boxes):
+    """A scene 1 km away from the world origin: float32 positions are only good to ~1e-4 m there,
+    so the filter must hand every configuration to the exact kernels -- verdicts stay bit-exact."""
+    import dataclasses
+    model, allowed = random_model(5, moving_boxes=moving_boxes)
+    shift = np.array([1000.0, -800.0, 300.0])
+    body_pos = model.body_pos.copy()
+    body_pos[model.body_parentid == 0] += shift  # every body hanging off the world
+    body_pos[0] = 0
+    geom_pos = model.geom_pos.copy()
+    geom_pos[model.geom_bodyid == 0] += shift    # and the world's own geoms
+    far = dataclasses.replace(model, body_pos=body_pos, geom_pos=geom_pos)
+    e = eng_mod.Engine(far, allowed)
+    orc = oracle_mod.Oracle(far, allowed)
+    Q = uniform_configs(far, 2048, seed=3)
+    want = orc.valid_configs(Q, nthreads=8)
+    np.testing.assert_array_equal(e.check_configs(Q), want)
+    assert e.last_undecided() == len(Q)  # nothing was decided in float32
+    qa, qb = random_edges(far, np.arange(far.nq), 1024, seed=4, eps=0.2)
+    w, wfb, _ = orc.valid_edges(qa, qb, 0.03, nthreads=8, info=True)
+    g, gfb = e.check_edges(qa, qb, 0.03, first_bad=True)
+    np.testing.assert_array_equal(g, w)
+    np.testing.assert_array_equal(gfb, wfb)
+    # the same scene at the origin is decided by the filter
+    e0 = eng_mod.Engine(model, allowed)
+    e0.check_configs(Q)
+    assert e0.last_undecided() < len(Q) // 4

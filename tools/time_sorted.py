@@ -24,6 +24,7 @@ for name, order in (("unsorted", np.arange(E)),
     a, b = qa[order], qb[order]
     ha,hb = np.ascontiguousarray(a.T), np.ascontiguousarray(b.T)
     dqa,dqb = e.alloc(ha.nbytes).upload(ha), e.alloc(hb.nbytes).upload(hb); dv = e.alloc(E)
+    e.time_edges_dev(dqa.ptr, dqb.ptr, E, 0.01, engine.SOA, dv.ptr, 3)  # warm-up (buffers are allocated on first use)
     ms, msk = e.time_edges_dev(dqa.ptr,dqb.ptr,E,0.01,engine.SOA,dv.ptr,12, first_kernel=True)
     print(f"{name:22s} step {ms[2:].mean():.4f} ms  items kernel {msk[2:].mean():.4f} ms  valid {dv.download(np.uint8,E).mean():.4f}")
     for x in (dqa,dqb,dv): x.free()

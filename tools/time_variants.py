@@ -14,5 +14,6 @@ if len(sys.argv) > 1:
 for lib in libs:
     e = engine.Engine(m, lib_path=os.path.abspath(lib) if lib else None); e.set_planning(qidx, base)
     dqa, dqb = e.alloc(ha.nbytes).upload(ha), e.alloc(hb.nbytes).upload(hb); dv = e.alloc(E)
+    e.time_edges_dev(dqa.ptr, dqb.ptr, E, 0.01, engine.SOA, dv.ptr, 3)  # warm-up (buffers are allocated on first use)
     ms, msk = e.time_edges_dev(dqa.ptr, dqb.ptr, E, 0.01, engine.SOA, dv.ptr, 12, first_kernel=True)
     print(f"{lib or 'product':32s} step {ms[2:].mean():.4f} ms  first kernel {msk[2:].mean():.4f} ms  undecided {e.last_undecided()}")
