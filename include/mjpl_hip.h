@@ -171,6 +171,13 @@ int mjpl_check_configs_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t 
 int mjpl_check_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E,
                          double step_dist, int32_t layout, int32_t flags, uint8_t *dvalid,
                          int32_t *dfirst_bad);
+/* The device-pointer edge entry point cannot return MJPL_E_NONFINITE (it does not synchronise):
+ * a NaN/inf or absurdly long edge gets valid = 0 and first_bad = -2, and a sticky status bit is
+ * set on the device.  mjpl_take_status synchronises the engine's stream, stores MJPL_OK or
+ * MJPL_E_NONFINITE (the status every mjpl_check_edges_dev call since the last take would have
+ * returned) in *status and clears the bit.  The host-buffer mjpl_check_edges clears the bit
+ * before it launches and reports it itself. */
+int mjpl_take_status(mjpl_engine *e, int32_t *status);
 /* as mjpl_check_configs_dev but one bit per configuration, packed by wavefront ballot:
  * bit (i & 63) of dbits[i >> 6]. */
 int mjpl_check_configs_bits_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout,

@@ -15,7 +15,6 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmjpl_hip.so")
 LIB_LDS_PATH = os.path.join(CSRC, "libmjpl_hip_ldstables.so")
 
-_SOURCES = ["mjpl_hip.hip", "mjpl_device.h", "mjpl_trig.h"]
 # -ffp-contract=off: one IEEE rounding per operation, the contract the CPU path is compared under.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17",
                "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
@@ -25,7 +24,8 @@ def _stale(target: str) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    deps = [os.path.join(CSRC, f) for f in _SOURCES] + [os.path.join(_ROOT, "include", "mjpl_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(_ROOT, "include", "mjpl_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

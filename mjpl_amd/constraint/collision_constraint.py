@@ -47,8 +47,6 @@ class CollisionRuleset:
 
 
 class CollisionConstraint(Constraint):
-    projects = False  # apply() never moves a configuration: batched extension is allowed
-
     """Batched collision validation on one MI355X.
 
     Args:
@@ -57,6 +55,8 @@ class CollisionConstraint(Constraint):
             configuration; empty means any contact invalidates (collision_constraint.py:86-88).
         device: HIP device ordinal.
     """
+
+    projects = False  # apply() never moves a configuration: batched extension is allowed
 
     def __init__(self, model, allowed_collision_bodies: list[tuple[str, str]] = [],
                  device: int = 0) -> None:

@@ -412,6 +412,8 @@ struct ItemBuffers {
   int cap;
   int *llist, *lcount;  // edges left to the walking kernel
   int kmax;             // edges with more interior waypoints than this stay with the walking kernel
+  int *claim;           // [E] per-edge claim word (see k_filter_items)
+  int gen;              // this launch's generation: claim[edge] == gen <=> the edge is in ulist already
 };
 constexpr int kExpandMinWaypoints = 24;  // kmax is at least this; small batches get more (item space / E)
 
@@ -937,8 +939,11 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
       valid[ed] = 0;
       if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)ib.idx[it]);
     } else {
-      // could not hand the undecided pair over: the exact edge kernel redoes the whole edge
-      ulist[atomicAdd(ucount, 1)] = ed;
+      // could not hand the undecided pair over: the exact edge kernel redoes the whole edge.  An
+      // edge has up to K items here, but `ulist` holds E entries and the re-run has one lane per
+      // entry: the first item to claim the edge (generation-stamped word, never cleared between
+      // launches) lists it, the others find it listed.
+      if (atomicExch(&ib.claim[ed], ib.gen) != ib.gen) ulist[atomicAdd(ucount, 1)] = ed;
     }
   }
 }
@@ -1252,12 +1257,14 @@ struct mjpl_engine {
   double *d_geomtab = nullptr;  // GTB_LEN doubles per model geom (k_patch_pairs)
   double *d_itemw = nullptr;    // lane-per-waypoint interior pass: waypoints, (edge, idx), long-edge list
   int *d_itemedge = nullptr, *d_itemidx = nullptr, *d_llist = nullptr, *d_icount = nullptr;
+  int *d_eclaim = nullptr;  // [llist_cap] per-edge claim word: the launch generation that listed the edge in d_ulist
+  int claim_gen = 0;
   size_t item_cap = 0, llist_cap = 0;
   bool expand = true;
   size_t item_cap_limit = (size_t)1 << 26;  // MJPL_ITEM_CAP: edges beyond it take the walking kernel
   void *d_nn = nullptr;         // nearest neighbour: per-chunk partial results
   size_t nn_bytes = 0;
-  size_t uc_cap = 0;
+  size_t uc_cap = 0, uc_cap_limit = 0;
   int nslots = 0, nsave = 0, maxs = 4;
   bool wbox = false, mbox = false;
   int npairs = 0, npairs_world = 0, nmoving = 0, nstatic = 0;
@@ -1648,7 +1655,8 @@ size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(doub
 }
 
 int uc_reserve(mjpl_engine *e, int64_t n) {
-  const size_t want = (size_t)std::max<int64_t>(4096, n);
+  // MJPL_UC_CAP (create-time, tests): a small hand-over buffer, to exercise its overflow paths
+  const size_t want = e->uc_cap_limit ? e->uc_cap_limit : (size_t)std::max<int64_t>(4096, n);
   if (want <= e->uc_cap) return MJPL_OK;
   if (e->d_ucq) HIP_TRY(hipFree(e->d_ucq));
   if (e->d_ucedge) HIP_TRY(hipFree(e->d_ucedge));
@@ -1819,20 +1827,29 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       // a handful of long edges (path shortcutting) is best served one waypoint per lane, too
       const size_t want = std::min<size_t>(std::max<size_t>((size_t)E * 8, (size_t)1 << 18) + 4096, e->item_cap_limit);
       if (want > e->item_cap || (size_t)E > e->llist_cap) {
-        for (void *ptr : {(void *)e->d_itemw, (void *)e->d_itemedge, (void *)e->d_itemidx, (void *)e->d_llist})
+        for (void *ptr : {(void *)e->d_itemw, (void *)e->d_itemedge, (void *)e->d_itemidx, (void *)e->d_llist,
+                          (void *)e->d_eclaim})
           if (ptr) HIP_TRY(hipFree(ptr));
-        e->d_itemw = nullptr; e->d_itemedge = e->d_itemidx = e->d_llist = nullptr;
+        e->d_itemw = nullptr; e->d_itemedge = e->d_itemidx = e->d_llist = e->d_eclaim = nullptr;
         e->item_cap = e->llist_cap = 0;
-        const size_t nplan = e->qidx.size();
-        HIP_TRY(hipMalloc(&e->d_itemw, want * std::max<size_t>(1, nplan) * sizeof(double)));
+        // rows are sized by nq, the upper bound of nplan: mjpl_set_planning may widen the planning
+        // set later without this buffer being reallocated
+        HIP_TRY(hipMalloc(&e->d_itemw, want * std::max<size_t>(1, e->m.nq) * sizeof(double)));
         HIP_TRY(hipMalloc(&e->d_itemedge, want * sizeof(int)));
         HIP_TRY(hipMalloc(&e->d_itemidx, want * sizeof(int)));
         HIP_TRY(hipMalloc(&e->d_llist, (size_t)E * sizeof(int)));
+        HIP_TRY(hipMalloc(&e->d_eclaim, (size_t)E * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(e->d_eclaim, 0, (size_t)E * sizeof(int), e->stream));
+        e->claim_gen = 0;
         e->item_cap = want; e->llist_cap = (size_t)E;
       }
       const int kmax = (int)std::min<size_t>(std::max<size_t>(e->item_cap / (size_t)E, kExpandMinWaypoints), 1 << 16);
+      if (++e->claim_gen == std::numeric_limits<int>::max()) {  // generations never repeat between clears
+        HIP_TRY(hipMemsetAsync(e->d_eclaim, 0, e->llist_cap * sizeof(int), e->stream));
+        e->claim_gen = 1;
+      }
       ib = ItemBuffers{e->d_itemw, e->d_itemedge, e->d_itemidx, e->d_icount, (int)e->item_cap, e->d_llist,
-                       e->d_icount + kCtr, kmax};
+                       e->d_icount + kCtr, kmax, e->d_eclaim, e->claim_gen};
     }
     if (two_pass) {
       if ((size_t)E > e->slist_cap) {
@@ -2018,6 +2035,7 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
   if (const char *f = getenv("MJPL_TWO_PASS")) e->two_pass = atoi(f) != 0;
   if (const char *f = getenv("MJPL_EXPAND")) e->expand = atoi(f) != 0;
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
+  if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));
   if (const char *t = getenv("MJPL_FILTER_TOL")) {
     const double v = atof(t);
     if (v > 0.0 && v < 1.0) e->filter_tol = (float)v;
@@ -2048,6 +2066,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_itemedge) (void)hipFree(e->d_itemedge);
   if (e->d_itemidx) (void)hipFree(e->d_itemidx);
   if (e->d_llist) (void)hipFree(e->d_llist);
+  if (e->d_eclaim) (void)hipFree(e->d_eclaim);
   if (e->d_ucq) (void)hipFree(e->d_ucq);
   if (e->d_ucedge) (void)hipFree(e->d_ucedge);
   if (e->d_ucidx) (void)hipFree(e->d_ucidx);
@@ -2160,6 +2179,17 @@ int mjpl_check_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, i
   if (!(step_dist > 0.0)) return fail(MJPL_E_ARG, "`step_dist` must be > 0");
   HIP_TRY(hipSetDevice(e->device));
   return launch_edges(e, dQA, dQB, E, step_dist, layout, flags, dvalid, dfirst_bad);
+}
+
+int mjpl_take_status(mjpl_engine *e, int32_t *status) {
+  if (!e || !status) return fail(MJPL_E_ARG, "mjpl_take_status: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int s = 0;
+  HIP_TRY(hipMemcpyAsync(&s, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *status = (s & kStatusNonFinite) ? MJPL_E_NONFINITE : MJPL_OK;
+  return MJPL_OK;
 }
 
 int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap, const double *dqueries,

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -94,6 +95,7 @@ ABI = {
     "mjpl_check_configs_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP]),
     "mjpl_check_edges_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int32, C.c_int32, _VP,
                                        _VP]),
+    "mjpl_take_status": (C.c_int, [_VP, _I32P]),
     "mjpl_check_configs_bits_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP]),
     "mjpl_nearest_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, _VP, _VP]),
     "mjpl_dev_alloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
@@ -207,6 +209,7 @@ class Engine:
         self._ok(rc)
         self.h = h
         self.nplan = model.nq
+        self._projectors: "weakref.WeakSet[PoseProjector]" = weakref.WeakSet()
 
     # -- plumbing
     def _ok(self, rc: int):
@@ -215,6 +218,10 @@ class Engine:
 
     def close(self):
         if self.h:
+            # mjpl_pose handles hold device memory of their own and a pointer to this engine:
+            # destroy them first so that closing the engine before its projectors leaks nothing
+            for p in list(getattr(self, "_projectors", ())):
+                p.close()
             self.lib.mjpl_destroy(self.h)
             self.h = None
 
@@ -223,6 +230,12 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def sync(self):
         self._ok(self.lib.mjpl_sync(self.h))
@@ -307,6 +320,13 @@ class Engine:
         self._ok(self.lib.mjpl_check_edges_dev(self.h, dQA, dQB, n, float(step_dist), layout, flags,
                                                dvalid, dfirst_bad))
 
+    def take_status(self) -> int:
+        """Sticky status of the device-pointer edge launches since the last take (0 or
+        MJPL_E_NONFINITE = -7); synchronises."""
+        st = C.c_int32(0)
+        self._ok(self.lib.mjpl_take_status(self.h, C.byref(st)))
+        return int(st.value)
+
     def nearest_dev(self, dnodes, n, cap, dqueries, m, dout_idx, dout_d2=None):
         self._ok(self.lib.mjpl_nearest_dev(self.h, dnodes, n, cap, dqueries, m, dout_idx, dout_d2))
 
@@ -386,6 +406,7 @@ class PoseProjector:
         eng._ok(eng.lib.mjpl_pose_create(eng.h, C.byref(d), C.byref(h)))
         self.h = h
         self.nq = model.nq
+        eng._projectors.add(self)
 
     def close(self):
         if self.h and self.eng.h:

@@ -42,11 +42,18 @@ class HipIKSolver(IKSolver):
         self.pos_tolerance, self.ori_tolerance = pos_tolerance, ori_tolerance
         self.seed, self.max_attempts, self.iterations = seed, max_attempts, iterations
         self.num_seeds = num_seeds
+        self._owns_engine = engine is None
         self.engine = engine if engine is not None else _engine.Engine(model, device=device)
         self.q_idx = np.asarray(_utils.qpos_idx(model, joints), dtype=np.int64)
         self.movable = np.zeros(model.njnt, np.uint8)
         self.movable[[model.joint(j).id for j in joints]] = 1
         self.stats: dict = {}
+
+    def close(self) -> None:
+        """Release the engine this solver created for itself (a shared one is left alone)."""
+        if self._owns_engine and self.engine is not None:
+            self.engine.close()
+        self.engine = None
 
     def _seeds(self, q_start: np.ndarray, rng) -> np.ndarray:
         """Row 0 = the guess; the others re-draw the solver's joints uniformly in their ranges

@@ -57,9 +57,13 @@ def site_pose(model, q: np.ndarray, site_name: str, engine=None):
     from .lie import SE3, SO3
     eng = engine if engine is not None else _engine.Engine(model)
     inf = [(-np.inf, np.inf)] * 6
-    proj = _engine.PoseProjector(eng, site_name, [1.0, 0, 0, 0], [0.0, 0, 0], inf, 0.0, np.inf)
+    proj = None
     try:
+        proj = _engine.PoseProjector(eng, site_name, [1.0, 0, 0, 0], [0.0, 0, 0], inf, 0.0, np.inf)
         _, xpos, xmat = proj.valid(np.asarray(q, dtype=np.float64)[None, :], poses=True)
     finally:
-        proj.close()
+        if proj is not None:
+            proj.close()
+        if engine is None:
+            eng.close()  # a temporary engine of this call: do not leave its device memory to __del__
     return SE3.from_rotation_and_translation(SO3.from_matrix(xmat[0]), xpos[0])

@@ -15,14 +15,15 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 #define ORC_MAXCON 4096
 
 /* per-thread scratch, grown on demand (a malloc per configuration serialises 256 threads) */
-static __thread double *tls_buf[3];
-static __thread size_t tls_cap[3];
+static __thread double *tls_buf[5];
+static __thread size_t tls_cap[5];
 
 static double *scratch(int slot, size_t ndoubles) {
   if (tls_cap[slot] < ndoubles) {
@@ -560,11 +561,12 @@ int orc_valid_collision_interval(const orc_model *m, const int32_t *allowed, int
                                  const double *start, const double *end, double step_dist,
                                  int32_t *nwaypoints, int32_t *first_bad) {
   const int n = m->nq;
-  double *w = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+  double *w = scratch(3, 2 * (size_t)n);  /* per-thread, grown once: no malloc per edge */
+  if (!w) return ORC_E_OVERFLOW;
   double *nx = w + n;
   int res = 1, idx = 0, bad = 0;
   for (int k = 0; k < n; k++) {
-    if (!isfinite(start[k]) || !isfinite(end[k])) { free(w); return ORC_E_NONFINITE; }
+    if (!isfinite(start[k]) || !isfinite(end[k])) return ORC_E_NONFINITE;
     w[k] = start[k];
   }
   /* w walks start -> end; every w that is neither start nor end is an interior waypoint. */
@@ -583,7 +585,6 @@ int orc_valid_collision_interval(const orc_model *m, const int32_t *allowed, int
   }
   if (nwaypoints) *nwaypoints = idx;
   if (first_bad) *first_bad = bad;
-  free(w);
   return res;
 }
 
@@ -598,34 +599,36 @@ static void gather_q(const orc_model *m, const orc_batch *b, const double *Q, in
 
 typedef struct {
   const orc_model *m; const orc_batch *b;
-  const double *QA, *QB; int64_t N, lo, hi; double step;
-  uint8_t *valid; int32_t *first_bad, *ncheck; int mode; int status;
+  const double *QA, *QB; int64_t N; double step;
+  uint8_t *valid; int32_t *first_bad, *ncheck; int mode;
 } job_t;
 
-static void *job_run(void *arg) {
-  job_t *j = (job_t *)arg;
+/* items [lo, hi) of a batch job; returns the last negative status seen (or ORC_OK) */
+static int job_range(const job_t *j, int64_t lo, int64_t hi) {
   const orc_model *m = j->m;
-  double *qa = (double *)malloc(sizeof(double) * 2 * (size_t)m->nq);
+  int status = ORC_OK;
+  double *qa = scratch(4, 2 * (size_t)m->nq);
+  if (!qa) return ORC_E_OVERFLOW;
   double *qb = qa + m->nq;
-  for (int64_t i = j->lo; i < j->hi; i++) {
+  for (int64_t i = lo; i < hi; i++) {
     if (j->mode == 0) {
       gather_q(m, j->b, j->QA, j->N, i, qa);
       int v = orc_valid_config(m, j->b->allowed, j->b->nallowed, qa);
-      if (v < 0) { j->status = v; v = 0; }
+      if (v < 0) { status = v; v = 0; }
       j->valid[i] = (uint8_t)v;
     } else {
       gather_q(m, j->b, j->QA, j->N, i, qa);
       gather_q(m, j->b, j->QB, j->N, i, qb);
       int32_t nchk = 1, fb = -1;
       int v = orc_valid_config(m, j->b->allowed, j->b->nallowed, qb);
-      if (v < 0) { j->status = v; v = 0; }
+      if (v < 0) { status = v; v = 0; }
       if (!v) {
         fb = 0;
       } else {
         int32_t nwp = 0, bad = 0;
         v = orc_valid_collision_interval(m, j->b->allowed, j->b->nallowed, qa, qb, j->step,
                                          &nwp, &bad);
-        if (v < 0) { j->status = v; v = 0; bad = 0; }
+        if (v < 0) { status = v; v = 0; bad = 0; }
         if (!v) { fb = bad; nchk += bad; } else { nchk += nwp; }
       }
       j->valid[i] = (uint8_t)v;
@@ -633,31 +636,101 @@ static void *job_run(void *arg) {
       if (j->ncheck) j->ncheck[i] = nchk;
     }
   }
-  free(qa);
+  return status;
+}
+
+/* Persistent worker pool.  Threads are created once (grown on demand up to ORC_MAX_THREADS) and
+ * sleep on a condition variable between batches; a batch is cut into chunks that the workers --
+ * and the calling thread -- take from a shared atomic cursor, so a pass over a few hundred
+ * thousand edges (milliseconds of work per core) pays neither 256 pthread_create calls nor the
+ * imbalance of a static partition (edges that end in an obstacle cost a fifth of a free one). */
+#define ORC_MAX_THREADS 512
+#define ORC_CHUNK 64
+
+static struct {
+  pthread_mutex_t mu;
+  pthread_cond_t wake, done;
+  pthread_t th[ORC_MAX_THREADS];
+  int nthreads;           /* workers created so far */
+  unsigned long long gen; /* batch generation: a worker runs each generation at most once */
+  int want;               /* workers that should take part in the current generation */
+  int running;            /* workers still inside the current generation */
+  const job_t *job;
+  int64_t cursor, N;      /* next unclaimed item (atomic) */
+  int status;
+} pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+          {0}, 0, 0, 0, 0, NULL, 0, 0, ORC_OK};
+
+static int pool_drain(const job_t *j) {
+  int status = ORC_OK;
+  for (;;) {
+    const int64_t lo = __atomic_fetch_add(&pool.cursor, (int64_t)ORC_CHUNK, __ATOMIC_RELAXED);
+    if (lo >= pool.N) break;
+    const int64_t hi = lo + ORC_CHUNK < pool.N ? lo + ORC_CHUNK : pool.N;
+    const int st = job_range(j, lo, hi);
+    if (st != ORC_OK) status = st;
+  }
+  return status;
+}
+
+static void *pool_worker(void *arg) {
+  const int id = (int)(intptr_t)arg;
+  unsigned long long seen = 0;
+  pthread_mutex_lock(&pool.mu);
+  for (;;) {
+    while (pool.gen == seen || id >= pool.want) {
+      if (pool.gen != seen && id >= pool.want) seen = pool.gen;  /* not invited to this batch */
+      pthread_cond_wait(&pool.wake, &pool.mu);
+    }
+    seen = pool.gen;
+    const job_t *j = pool.job;
+    pthread_mutex_unlock(&pool.mu);
+    const int st = pool_drain(j);
+    pthread_mutex_lock(&pool.mu);
+    if (st != ORC_OK) pool.status = st;
+    if (--pool.running == 0) pthread_cond_signal(&pool.done);
+  }
   return NULL;
 }
 
+/* one batch at a time (callers are the tests and bench.py: single-threaded hosts) */
+static pthread_mutex_t pool_batch_mu = PTHREAD_MUTEX_INITIALIZER;
+
 static int run_jobs(job_t proto, int64_t N, int nthreads) {
   if (nthreads < 1) nthreads = 1;
-  if (nthreads > 256) nthreads = 256;
-  if ((int64_t)nthreads > N) nthreads = N > 0 ? (int)N : 1;
-  job_t jobs[256];
-  pthread_t th[256];
-  int status = ORC_OK;
-  for (int t = 0; t < nthreads; t++) {
-    jobs[t] = proto;
-    jobs[t].lo = N * t / nthreads;
-    jobs[t].hi = N * (t + 1) / nthreads;
-    jobs[t].status = ORC_OK;
+  if (nthreads > ORC_MAX_THREADS) nthreads = ORC_MAX_THREADS;
+  const int64_t nchunks = (N + ORC_CHUNK - 1) / ORC_CHUNK;
+  if ((int64_t)nthreads > nchunks) nthreads = nchunks > 0 ? (int)nchunks : 1;
+  if (nthreads == 1) return N > 0 ? job_range(&proto, 0, N) : ORC_OK;
+
+  pthread_mutex_lock(&pool_batch_mu);
+  pthread_mutex_lock(&pool.mu);
+  const int helpers = nthreads - 1;  /* the caller works too */
+  while (pool.nthreads < helpers) {
+    if (pthread_create(&pool.th[pool.nthreads], NULL, pool_worker, (void *)(intptr_t)pool.nthreads) != 0) break;
+    pthread_detach(pool.th[pool.nthreads]);
+    pool.nthreads++;
   }
-  if (nthreads == 1) {
-    job_run(&jobs[0]);
-  } else {
-    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, job_run, &jobs[t]);
-    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-  }
-  for (int t = 0; t < nthreads; t++)
-    if (jobs[t].status != ORC_OK) status = jobs[t].status;
+  const int use = helpers < pool.nthreads ? helpers : pool.nthreads;
+  pool.job = &proto;
+  pool.N = N;
+  __atomic_store_n(&pool.cursor, (int64_t)0, __ATOMIC_RELAXED);
+  pool.status = ORC_OK;
+  pool.want = use;
+  pool.running = use;
+  pool.gen++;
+  pthread_cond_broadcast(&pool.wake);
+  pthread_mutex_unlock(&pool.mu);
+
+  const int mine = pool_drain(&proto);
+
+  pthread_mutex_lock(&pool.mu);
+  while (pool.running > 0) pthread_cond_wait(&pool.done, &pool.mu);
+  int status = pool.status;
+  pool.want = 0;
+  pthread_mutex_unlock(&pool.mu);
+  pthread_mutex_unlock(&pool_batch_mu);
+  if (mine != ORC_OK) status = mine;
   return status;
 }
 

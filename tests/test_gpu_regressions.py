@@ -1,0 +1,143 @@
+"""GPU regression tests for defects found by review: buffers sized for an
+earlier planning set, the edge-level undecided list overflowing when one edge contributes several
+undecided waypoint items, the sticky status of the device-pointer edge entry point, handle
+lifetimes.  Every verdict is compared with the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from mjpl_amd import engine as eng_mod
+from mjpl_amd import scenes
+from mjpl_amd.model import ModelBuilder
+
+from helpers import random_edges
+
+pytestmark = pytest.mark.gpu
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_replanning_with_more_columns_keeps_item_rows_apart(oracle_mod):
+    """set_planning(5 columns) -> check_edges -> set_planning(7 columns) -> check_edges with the
+    same E: the waypoint item buffer allocated for the first call must hold the wider rows."""
+    m = scenes.franka_p(obstacles=True)
+    base = m.keyframe("home").qpos.copy()
+    e = eng_mod.Engine(m)
+    E = 20000
+    for joints in (scenes.FRANKA_ARM_JOINTS[:5], scenes.FRANKA_ARM_JOINTS, scenes.FRANKA_ARM_JOINTS[:3],
+                   scenes.FRANKA_ARM_JOINTS + ["finger_joint1", "finger_joint2"]):
+        qidx = scenes.planning_index(m, joints)
+        e.set_planning(qidx, base)
+        orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+        qa, qb = random_edges(m, qidx, E, seed=len(joints))
+        want, wfb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
+        got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+        np.testing.assert_array_equal(got, want, err_msg=str(joints))
+        np.testing.assert_array_equal(gfb, wfb, err_msg=str(joints))
+        assert e.last_items() > E  # the lane-per-waypoint pass ran
+    e.close()
+
+
+def test_undecided_overflow_lists_every_edge_once(oracle_mod):
+    """A tolerance band of half a metre makes nearly every culled-in pair undecided; with a
+    64-entry hand-over buffer the items fall back to the edge-level list, several per edge.  The
+    list holds E entries and the exact re-run has one lane per entry: duplicates would overflow
+    it and leave edges at the provisional `valid` of the endpoint pass."""
+    m = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    qa, qb = random_edges(m, qidx, 6000, seed=11)
+    want, wfb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
+    with _Env(MJPL_UC_CAP="64"):
+        e = eng_mod.Engine(m)
+    e.set_planning(qidx, base)
+    e.set_filter(True, 0.5)
+    got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+    assert e.last_undecided() > 1000  # the overflow path really ran
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(gfb, wfb)
+    # configurations through the same tiny buffer
+    Q = np.concatenate([qa, qb])
+    np.testing.assert_array_equal(e.check_configs(Q), orc.valid_configs(Q, nthreads=8))
+    e.close()
+
+
+def _long_slide() -> "scenes.Model":
+    """A ball on a 200 m rail with walls inside and outside the float32 filter's range."""
+    mb = ModelBuilder()
+    mb.add_geom("world", "plane", (0, 0, 0.1))
+    mb.add_body("ball", pos=(0, 0, 1))
+    mb.add_joint("ball", "rail", "slide", axis=(1, 0, 0), range=(-100, 100))
+    mb.add_geom("ball", "sphere", (0.01,))
+    for k, x in enumerate((0.9, 63.5, 64.5, 70.0)):
+        mb.add_geom("world", "box", (0.05, 0.5, 0.5), pos=(x, 0, 1), name=f"wall{k}")
+    return mb.compile()
+
+
+def test_edges_straddling_the_filter_range(oracle_mod):
+    """Edges that start beyond the range the float32 filter decides and end inside it: the
+    endpoint is decided by the filter, every far interior waypoint is an undecided item of the
+    same edge.  Verdict and first_bad must be the oracle's, in every interior-pass mode."""
+    m = _long_slide()
+    orc = oracle_mod.Oracle(m)
+    rng = np.random.default_rng(3)
+    n = 3000
+    far = rng.uniform(62.0, 72.0, size=(n, 1))
+    near = rng.uniform(61.0, 66.0, size=(n, 1))
+    qa, qb = np.concatenate([far, near]), np.concatenate([near, far])
+    want, wfb, _ = orc.valid_edges(qa, qb, 0.05, nthreads=8, info=True)
+    assert 0.05 < want.mean() < 0.95
+    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_UC_CAP": "16"}):
+        with _Env(**env):
+            e = eng_mod.Engine(m)
+        got, gfb = e.check_edges(qa, qb, 0.05, first_bad=True)
+        np.testing.assert_array_equal(got, want, err_msg=str(env))
+        np.testing.assert_array_equal(gfb, wfb, err_msg=str(env))
+        e.close()
+
+
+def test_device_path_status_is_sticky_until_taken():
+    m = scenes.one_dof_ball()
+    e = eng_mod.Engine(m)
+    qa = np.array([[0.0], [np.nan], [0.1]])
+    qb = np.array([[0.2], [0.3], [0.3]])
+    da, db = e.alloc(qa.nbytes).upload(qa), e.alloc(qb.nbytes).upload(qb)
+    dv, dfb = e.alloc(3), e.alloc(12)
+    assert e.take_status() == 0
+    e.check_edges_dev(da.ptr, db.ptr, 3, 0.01, eng_mod.AOS, dv.ptr, dfb.ptr)
+    assert dv.download(np.uint8, 3).tolist() == [1, 0, 1]
+    assert dfb.download(np.int32, 3).tolist() == [-1, -2, -1]
+    assert e.take_status() == -7  # MJPL_E_NONFINITE
+    assert e.take_status() == 0   # taken
+    e.close()
+
+
+def test_engine_close_destroys_its_pose_handles():
+    import mjpl_amd as mjpl
+    m = scenes.franka_p()
+    q = m.keyframe("home").qpos.copy()
+    e = eng_mod.Engine(m)
+    frame = mjpl.site_pose(m, q, "ee_site", engine=e)
+    pc = mjpl.PoseConstraint(m, "ee_site", frame, roll=(-0.1, 0.1), engine=e)
+    assert pc.valid_config(q)
+    e.close()          # engine first ...
+    assert pc._proj.h is None
+    pc._proj.close()   # ... then the projector: nothing left to free, no crash
+    # site_pose without an engine builds and closes its own
+    assert np.allclose(mjpl.site_pose(m, q, "ee_site").translation(), frame.translation())
+    assert mjpl.CollisionConstraint.__doc__.startswith("Batched collision validation")
