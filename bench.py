@@ -9,9 +9,10 @@ every edge, FK + narrowphase per waypoint) over one batch of E synthetic edges t
 already resident in HBM.  Weak scaling: every rank owns its own E edges (independent units,
 no data-path collective).  Rank 0 prints ONE JSON line.
 
-The timed K steps are launched through mjpl_time_edges_dev, which brackets every launch
-with HIP events on the stream the kernel runs on; roofline.achieved comes from those.
-torch is imported only for N > 1 (rendezvous, barrier, max-reduce over RCCL).
+The timed K steps are launched through mjpl_time_edges_stages_dev: K back-to-back launches on the
+engine's own stream between two HIP events, every fourth launch also carrying one event after each
+of its kernels; roofline.achieved is the longest kernel's algorithmic bytes over its mean duration
+from those events.  torch is imported only for N > 1 (rendezvous, barrier, max-reduce over RCCL).
 """
 import argparse
 import json
@@ -29,9 +30,10 @@ METRIC = "validated RRT edges/sec, Franka 7-DoF 16-geom scene, at 1/2/4/8 MI355X
 EDGES_PER_GPU = 262144       # BASELINE.json configs[2]
 EPS, STEP = 0.05, 0.01       # rrt.py:30 epsilon; 4 interior waypoints + endpoint per edge
 BYTES_PER_EDGE = 113         # 2 x 7 x 8 B read + 1 B verdict written
-FLOPS_PER_EDGE = 80e3        # SURVEY.md 8(d) estimate, FP64
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64 (half of the 157.3 TF FP32 vector peak)
+# MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles on a SIMD-32,
+# 4 SIMDs per CU, 256 CUs, 2.4 GHz max clock -> wave-instructions per second the chip can issue
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 
 
 def make_edges(model, qidx, n, seed):
@@ -46,40 +48,88 @@ def make_edges(model, qidx, n, seed):
     return qa, qb
 
 
+def host_cpu():
+    """CPU model string and the affinity of this process (SURVEY.md 8d 'CPU baseline timing')."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = list(range(os.cpu_count() or 1))
+    runs, lo = [], None
+    for c in aff + [None]:  # compress to ranges
+        if lo is None:
+            lo = prev = c
+        elif c is not None and c == prev + 1:
+            prev = c
+        else:
+            runs.append(f"{lo}-{prev}" if prev != lo else f"{lo}")
+            lo = prev = c
+    # a container may own fewer CPUs than it can see: the cgroup quota bounds what threads can use
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", ):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+        except (OSError, ValueError):
+            pass
+    if quota is None:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = len(aff) if quota is None else max(1, min(len(aff), int(quota + 0.5)))
+    return model, usable, ",".join(runs), (None if quota is None else f"cgroup cpu quota {quota:g} CPUs of {len(aff)} visible")
+
+
 def cpu_baseline(model, qidx, base, qa, qb):
     """The oracle (a port, not the reference) timed on this box's host cores on a bounded
     sample of the same edges; reported, never the target."""
     from oracle import pyoracle
     orc = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
-    cores = os.cpu_count() or 1
-    pilot = min(2048, len(qa))
+    cpu, cores, aff, quota = host_cpu()
+    pilot = min(4096, len(qa))
+    orc.valid_edges(qa[:64], qb[:64], STEP, nthreads=1)
     t0 = time.perf_counter()
     orc.valid_edges(qa[:pilot], qb[:pilot], STEP, nthreads=1)
     per_edge = (time.perf_counter() - t0) / pilot
-    # bounded sample: about 15 core-seconds of oracle work in total, i.e. `reps` passes over
-    # the first n edges of this rank's batch with every host core busy
     n = len(qa)
-    reps = max(1, int(round(15.0 / (per_edge * n))))
+    orc.valid_edges(qa[:n], qb[:n], STEP, nthreads=cores)  # starts the worker pool, warms the caches
+    # bounded sample: `reps` passes over this rank's batch with every core this process may use
+    # busy (one thread per CPU of the cgroup quota: more threads only get throttled), about
+    # 20 core-seconds of oracle work and never less than ~1.5 s of wall time
+    reps = max(1, int(round(max(20.0 / (per_edge * n), 1.5 * cores / (per_edge * n)))))
     t0 = time.perf_counter()
     for _ in range(reps):
         v = orc.valid_edges(qa[:n], qb[:n], STEP, nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": reps * n / dt, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} passes over the {n} edges of rank 0 (~{reps * n * per_edge:.0f} core-seconds), "
-                      f"oracle/libmjpl_oracle.so (gcc -O2 -ffp-contract=off), {cores} pthreads; "
-                      f"1-thread pilot {1.0 / per_edge:.0f} edges/s"}, v, n
+            "cpu_model": cpu, "affinity": aff, "cpu_quota": quota, "single_thread_edges_per_s": 1.0 / per_edge,
+            "sample": f"{reps} passes over the {n} edges of rank 0 ({reps * n * per_edge:.0f} core-seconds of "
+                      f"single-thread work, {dt:.2f} s wall), oracle/libmjpl_oracle.so (gcc -O2 "
+                      f"-ffp-contract=off), persistent pool of {cores} threads, 64-edge chunks"}, v, n
 
 
-def traffic_from_profile(workload_key):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass of this same command
-    (profiles/*_traffic.json, written by tools/pmc_summary.py); None if absent."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def profile_record(kernel, E, layout):
+    """Counters of the committed rocprofv3 PMC passes of this same command (profiles/pmc.json,
+    written by tools/pmc_summary.py): HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950
+    correction of MI355X_MICROARCH.md "HBM") and wave-level instruction counts; {} if absent."""
     try:
-        with open(path) as f:
-            t = json.load(f)
-        return t.get(workload_key, {}).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
+            return json.load(f).get("%s_%d_%s" % (kernel, E, layout), {})
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 def bench_configs(args):
@@ -105,7 +155,8 @@ def bench_configs(args):
     out = {"metric": "validated configurations/sec, Franka-P self-collision (BASELINE configs[1])",
            "value": N * args.steps / elapsed, "unit": "configs/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32-filter+f64-exact" if eng.info()["filter_enabled"] else "f64", "data": "synthetic",
            "config": {"workload": f"configs[1]: Franka-P 7-DoF, self-collision + floor, {N} configurations/launch",
                       "valid_fraction": float(valid.mean()), "step_ms_hip_events": float(np.mean(ms))},
            "roofline": {"bound": "hbm", "achieved": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -219,8 +270,9 @@ def bench_next_rows(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000,
+                    help="timed steps; the default keeps the timed region near one second")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--edges", type=int, default=EDGES_PER_GPU)
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -279,11 +331,13 @@ def main():
 
     # warmup (untimed)
     if args.warmup > 0:
-        eng.time_edges_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, args.warmup)
+        eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, args.warmup, 1 << 30)
     barrier()
     t0 = time.perf_counter()
-    ms, ms_kernel = eng.time_edges_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, args.steps,
-                                       first_kernel=True)  # syncs
+    # EXACTLY args.steps launches, back to back on the engine's stream; every 4th one also carries
+    # one HIP event after each of its kernels (the per-kernel durations roofline.achieved uses)
+    launch_ms, stage_ms, nsamp = eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr,
+                                                           args.steps, 4)  # syncs
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -296,49 +350,65 @@ def main():
     if rank == 0:
         total_edges = E * world * args.steps
         value = total_edges / elapsed
-        launch_ms = float(np.mean(ms))          # all kernels of one step (filter + exact re-run)
-        kernel_ms = float(np.mean(ms_kernel))   # the dominant kernel alone
-        # The filter runs two passes: the endpoints of all edges (which also writes the interior
-        # waypoints of the edges whose endpoint passed as work items), then one lane per waypoint
-        # item.  The dominant kernel is the item pass: a unit is one configuration check, 56 B of
-        # columns + 8 B (edge, index) read and 1 B written (57 B per check, + the item).
-        interior = eng.last_interior_edges() if info["filter_enabled"] else 0
-        items = eng.last_items() if info["filter_enabled"] else 0
-        if items > 0:
-            kernel, units, unit_bytes, unit_name = "k_filter_items", items, 57 + 8, "waypoint configurations"
-        elif interior > 0:
-            kernel, units, unit_bytes, unit_name = "k_filter_edges", interior, BYTES_PER_EDGE + 4, "edges"
-        else:
-            kernel = "k_filter_edges" if info["filter_enabled"] else "k_check_edges"
-            units, unit_bytes, unit_name = E, BYTES_PER_EDGE, "edges"
+        filt = bool(info["filter_enabled"])
+        interior = eng.last_interior_edges() if filt else 0
+        items = eng.last_items() if filt else 0
+        # units and SURVEY.md 8(d) algorithmic bytes of every kernel of a step:
+        #   endpoint pass: one edge = 2 x 56 B of columns read + 1 B verdict (113 B)
+        #   item pass:     one waypoint configuration = 56 B + 1 B (57 B per check) + its 8 B (edge, index)
+        #   walking pass:  one edge, 113 B + the 4 B list entry
+        per_stage = {"k_filter_endpoints": (E, BYTES_PER_EDGE, "edges"),
+                     "k_filter_items": (items, 57 + 8, "waypoint configurations"),
+                     "k_filter_edges": (max(interior - 0, 0) if items == 0 else 0, BYTES_PER_EDGE + 4, "edges"),
+                     "k_patch_pairs": (eng.last_undecided(), 56 + 16, "undecided geom pairs"),
+                     "k_check_edges": (E if not filt else 0, BYTES_PER_EDGE, "edges")}
+        # the dominant kernel of THIS run = the longest stage
+        kernel = max(stage_ms, key=lambda k: stage_ms[k])
+        kernel_ms = stage_ms[kernel]
+        units, unit_bytes, unit_name = per_stage[kernel]
         achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9
+        prof = profile_record(kernel, E, args.layout)
         workload = (f"configs[2]: Franka-P 7-DoF + 16 box/sphere obstacles + floor, {E} edges/GPU, "
                     f"eps {EPS}, step {STEP} (endpoint + interior waypoints per edge)")
         out = {
             "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # what ran: a binary32 filter decides what it can within its tolerance band, binary64
+            # kernels decide the rest; every verdict equals the pure binary64 path's
+            "dtype": "f32-filter+f64-exact" if filt else "f64",
             "data": "synthetic",
             "config": {"workload": workload, "edges_per_gpu": E, "layout": args.layout,
                        "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
-                       "float32_filter": bool(info["filter_enabled"]), "filter_tol_m": info["filter_tol"],
+                       "float32_filter": filt, "filter_tol_m": info["filter_tol"],
                        "undecided_items_last_step": eng.last_undecided(),
                        "edges_reaching_interior_pass": interior, "interior_waypoint_items": items,
                        "parallelism": f"edge-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic_from_profile("%s_%d_%s" % (kernel, E, args.layout)),
+                         "traffic": prof.get("hbm_bytes_per_launch"),
                          "kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms,
+                         "kernels_ms": stage_ms, "kernel_samples": nsamp,
                          "algorithmic_bytes_per_unit": unit_bytes, "units_in_this_kernel": units,
                          "unit_of_work": unit_name,
-                         "note": "ALU/issue bound, not HBM bound (SURVEY.md 8d); see roofline_valu"},
-            "roofline_valu": {"bound": "vector_alu", "achieved": FLOPS_PER_EDGE * E / (launch_ms * 1e-3) / 1e12,
-                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": FLOPS_PER_EDGE * E / (launch_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                              "flops_per_edge_estimate": FLOPS_PER_EDGE,
-                              "note": "algorithmic FP64 flop estimate of SURVEY.md 8d against the FP64 vector "
-                                      "peak; the filter executes most of them in float32"},
+                         "whole_step": {"algorithmic_bytes": BYTES_PER_EDGE * E,
+                                        "achieved_GBs": BYTES_PER_EDGE * E / (launch_ms * 1e-3) / 1e9,
+                                        "frac": BYTES_PER_EDGE * E / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "note": "vector-issue / latency bound, not HBM bound (SURVEY.md 8d); see valu_issue"},
         }
+        # vector-ALU issue occupancy of the dominant kernel, from the committed counter pass:
+        # SQ_INSTS_VALU wave-instructions per launch / (kernel time x issue slots per second)
+        if prof.get("SQ_INSTS_VALU"):
+            iv = float(prof["SQ_INSTS_VALU"])
+            out["valu_issue"] = {"kernel": kernel, "wave_insts_valu_per_launch": iv,
+                                 "wave_insts_salu_per_launch": prof.get("SQ_INSTS_SALU"),
+                                 "achieved_per_s": iv / (kernel_ms * 1e-3), "peak_per_s": VALU_ISSUE_PEAK,
+                                 "frac": iv / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK,
+                                 "source": prof.get("source"),
+                                 "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU "
+                                         "instruction (MI355X_MICROARCH.md, Wave scheduling)"}
+        else:
+            out["valu_issue"] = None
         if world == 1 and not args.no_cpu_baseline:
             cb, v_cpu, n = cpu_baseline(model, qidx, base, qa, qb)
             out["cpu_baseline"] = cb

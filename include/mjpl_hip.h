@@ -201,12 +201,30 @@ void *mjpl_stream(mjpl_engine *e);
 
 /* ---- measurement ---------------------------------------------------------------- */
 
-/* Run mjpl_check_edges_dev `iters` times on the engine's stream with HIP events recorded on that
- * stream: two around the whole run -- every ms[k] receives the mean duration of a call (all of
- * its kernels) -- and two per call around its dominant kernel, ms_first[k] (nullable: the float32
- * interior pass; the only kernel when the filter is off).  Calls are not bracketed one by one: the
- * extra events cost a few percent of the throughput being measured.  Inputs and outputs are
- * device-resident.  Used by bench.py for roofline.achieved. */
+/* Stages of one mjpl_check_edges* launch, in stream order.  With the float32 filter on:
+ * endpoints of all edges (+ emission of the survivors' interior waypoints as work items), one lane
+ * per waypoint item, the walking kernel for what was not expanded, the float64 re-check of the
+ * undecided pairs / configurations, the float64 edge kernel for undecided whole edges.  With the
+ * filter off the float64 edge kernel is the whole launch. */
+#define MJPL_STAGE_ENDPOINTS 0  /* k_filter_endpoints (incl. the counter memset)          */
+#define MJPL_STAGE_ITEMS     1  /* k_filter_items                                          */
+#define MJPL_STAGE_WALK      2  /* k_filter_edges                                          */
+#define MJPL_STAGE_PATCH     3  /* k_patch_pairs (moving boxes: k_check_configs, patch mode) */
+#define MJPL_STAGE_EXACT     4  /* k_check_edges                                           */
+#define MJPL_NSTAGES         5
+
+/* Run mjpl_check_edges_dev `iters` times back to back on the engine's stream, timed with HIP
+ * events recorded on that stream: two around the whole run (*ms_mean = mean duration of a call,
+ * all kernels) and, on every `sample_every`-th call, one after each stage, so that
+ * stage_ms[MJPL_NSTAGES] (nullable) receives each stage's mean duration over *nsamples (nullable)
+ * sampled calls.  Sampling keeps the instrumentation below one percent of the run it measures.
+ * Inputs and outputs are device-resident.  Used by bench.py for roofline.achieved. */
+int mjpl_time_edges_stages_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E,
+                               double step_dist, int32_t layout, uint8_t *dvalid, int32_t iters,
+                               int32_t sample_every, float *ms_mean, float *stage_ms,
+                               int32_t *nsamples);
+/* The same with every call sampled: ms[k] = the mean call, ms_first[k] (nullable) = the mean
+ * duration of the filter's item pass (filter off: of the float64 edge kernel). */
 int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E,
                         double step_dist, int32_t layout, uint8_t *dvalid, int32_t iters,
                         float *ms, float *ms_first);

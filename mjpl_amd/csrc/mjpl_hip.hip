@@ -1249,9 +1249,10 @@ struct mjpl_engine {
   int *d_slist = nullptr;   // two-pass edge filter: edges whose endpoint passed
   size_t slist_cap = 0;
   bool two_pass = true;
-  hipEvent_t mark_before_main = nullptr;  // timing runs: recorded before the dominant kernel
   size_t ulist_cap = 0;
-  hipEvent_t mark_after_first = nullptr;  // timing runs: recorded after the first kernel of a launch
+  // timing runs (mjpl_time_edges_stages_dev): marks[k] is recorded after stage k - 1 of the launch
+  // (marks[0] at its start); nullptr in ordinary launches
+  hipEvent_t *marks = nullptr;
   double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
   int *d_ucedge = nullptr, *d_ucidx = nullptr, *d_ucga = nullptr, *d_ucgb = nullptr;
   double *d_geomtab = nullptr;  // GTB_LEN doubles per model geom (k_patch_pairs)
@@ -1796,6 +1797,12 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
   return MJPL_OK;
 }
 
+// stages of one edge launch, in stream order (include/mjpl_hip.h: MJPL_STAGE_*)
+#define MJPL_MARK(k)                                                          \
+  do {                                                                        \
+    if (e->marks) HIP_TRY(hipEventRecord(e->marks[k], e->stream));            \
+  } while (0)
+
 int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step,
                  int layout, int flags, uint8_t *dvalid, int32_t *dfb) {
   if (E == 0) return MJPL_OK;
@@ -1810,6 +1817,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     uc.ga = e->d_ucga; uc.gb = e->d_ucgb;
     uc.count = e->d_ucount + kCtr;
     uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
+    MJPL_MARK(0);
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
     const int fblock = e->mbox ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
@@ -1871,7 +1879,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       });
       if (rc != MJPL_OK) return rc;
     }
-    if (e->mark_before_main) HIP_TRY(hipEventRecord(e->mark_before_main, e->stream));
+    MJPL_MARK(1);  // after k_filter_endpoints (nothing ran yet in a one-pass launch)
     if (expand) {
       const unsigned igrid = (unsigned)((e->item_cap + fblock - 1) / fblock);
       const size_t ldsi = lds_bytes(e, 0, sizeof(float), fblock, true);
@@ -1885,10 +1893,10 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         return MJPL_OK;
       });
       if (rc != MJPL_OK) return rc;
-      if (e->mark_after_first) HIP_TRY(hipEventRecord(e->mark_after_first, e->stream));
       rlist = e->d_llist;  // what is left for the walking kernel
       rcount = e->d_icount + kCtr;
     }
+    MJPL_MARK(2);  // after k_filter_items
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
@@ -1900,7 +1908,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
-    if (!expand && e->mark_after_first) HIP_TRY(hipEventRecord(e->mark_after_first, e->stream));
+    MJPL_MARK(3);  // after k_filter_edges (the walking kernel)
     // undecided waypoints: exact configuration kernel in patch mode (grid sized for a generous
     // share of the batch; surplus blocks return at once)
     const size_t ldsc = lds_bytes(e, 1);
@@ -1923,6 +1931,9 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       hipLaunchKernelGGL(k_patch_pairs, dim3(pgrid), dim3(kBlock), ldsc, e->stream, e->d_ip, (int)e->ip.size(),
                          e->d_dp, (int)e->dp.size(), gt, uc, dvalid, dfb);
     }
+    MJPL_MARK(4);  // after the exact re-check of undecided pairs / configurations
+  } else {
+    for (int k = 0; k <= 4; k++) MJPL_MARK(k);  // filter off: the exact kernel is the whole launch
   }
   const size_t lds = lds_bytes(e, 1);
   int rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
@@ -1935,6 +1946,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     return MJPL_OK;
   });
   if (rc != MJPL_OK) return rc;
+  MJPL_MARK(5);  // after k_check_edges
   HIP_TRY(hipGetLastError());
   return MJPL_OK;
 }
@@ -2370,40 +2382,63 @@ void *mjpl_stream(mjpl_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 // ---- measurement: per-launch HIP-event timing on the engine's own stream
 
-int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step_dist,
-                        int32_t layout, uint8_t *dvalid, int32_t iters, float *ms, float *ms_first) {
-  if (!e || iters < 0 || (iters > 0 && !ms)) return fail(MJPL_E_ARG, "mjpl_time_edges_dev: bad argument");
+int mjpl_time_edges_stages_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step_dist,
+                               int32_t layout, uint8_t *dvalid, int32_t iters, int32_t sample_every,
+                               float *ms_mean, float *stage_ms, int32_t *nsamples) {
+  if (!e || iters < 0 || (iters > 0 && !ms_mean)) return fail(MJPL_E_ARG, "mjpl_time_edges_stages_dev: bad argument");
   HIP_TRY(hipSetDevice(e->device));
-  // two events per step (around the dominant kernel) and two around the whole region: per-step
-  // start / end events would cost ~3 % of the throughput they are there to measure
-  std::vector<hipEvent_t> ev(2 * (size_t)iters + 2);
+  if (sample_every < 1) sample_every = 1;
+  // Two events around the whole run (the mean step) and, on every `sample_every`-th step, one
+  // event after each stage of the launch: bracketing every kernel of every step would cost a few
+  // percent of the throughput the run is there to measure.
+  const int nsamp = iters > 0 ? (iters + sample_every - 1) / sample_every : 0;
+  constexpr int NM = MJPL_NSTAGES + 1;
+  std::vector<hipEvent_t> ev((size_t)nsamp * NM + 2);
   for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
-  hipEvent_t region_start = ev[2 * (size_t)iters], region_end = ev[2 * (size_t)iters + 1];
+  hipEvent_t region_start = ev[(size_t)nsamp * NM], region_end = ev[(size_t)nsamp * NM + 1];
   int rc = MJPL_OK;
   HIP_TRY(hipEventRecord(region_start, e->stream));
   for (int k = 0; k < iters && rc == MJPL_OK; k++) {
-    if (e->filter) {  // bracket the dominant kernel of the launch (the float32 interior pass)
-      e->mark_before_main = ev[2 * k];
-      e->mark_after_first = ev[2 * k + 1];
-    } else {
-      HIP_TRY(hipEventRecord(ev[2 * k], e->stream));
-    }
+    e->marks = (k % sample_every == 0) ? &ev[(size_t)(k / sample_every) * NM] : nullptr;
     rc = mjpl_check_edges_dev(e, dQA, dQB, E, step_dist, layout, 0, dvalid, nullptr);
-    e->mark_after_first = e->mark_before_main = nullptr;
-    if (!e->filter) HIP_TRY(hipEventRecord(ev[2 * k + 1], e->stream));  // single-kernel launch
+    e->marks = nullptr;
   }
   HIP_TRY(hipEventRecord(region_end, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (rc == MJPL_OK && iters > 0) {
     float total = 0;
     HIP_TRY(hipEventElapsedTime(&total, region_start, region_end));
-    for (int k = 0; k < iters; k++) {
-      ms[k] = total / (float)iters;  // the mean step: steps are not bracketed one by one
-      if (ms_first) HIP_TRY(hipEventElapsedTime(&ms_first[k], ev[2 * k], ev[2 * k + 1]));
+    *ms_mean = total / (float)iters;
+    if (stage_ms) {
+      for (int st = 0; st < MJPL_NSTAGES; st++) {
+        double acc = 0;
+        for (int sidx = 0; sidx < nsamp; sidx++) {
+          float t = 0;
+          HIP_TRY(hipEventElapsedTime(&t, ev[(size_t)sidx * NM + st], ev[(size_t)sidx * NM + st + 1]));
+          acc += t;
+        }
+        stage_ms[st] = (float)(acc / nsamp);
+      }
     }
+    if (nsamples) *nsamples = nsamp;
   }
   for (auto &x : ev) (void)hipEventDestroy(x);
   return rc;
+}
+
+int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E, double step_dist,
+                        int32_t layout, uint8_t *dvalid, int32_t iters, float *ms, float *ms_first) {
+  if (!e || iters < 0 || (iters > 0 && !ms)) return fail(MJPL_E_ARG, "mjpl_time_edges_dev: bad argument");
+  float mean = 0, stage[MJPL_NSTAGES] = {0};
+  const int rc = mjpl_time_edges_stages_dev(e, dQA, dQB, E, step_dist, layout, dvalid, iters, 1, &mean,
+                                            ms_first ? stage : nullptr, nullptr);
+  if (rc != MJPL_OK) return rc;
+  const int main_stage = e->filter ? MJPL_STAGE_ITEMS : MJPL_STAGE_EXACT;
+  for (int k = 0; k < iters; k++) {
+    ms[k] = mean;
+    if (ms_first) ms_first[k] = stage[main_stage];
+  }
+  return MJPL_OK;
 }
 
 int mjpl_time_configs_dev(mjpl_engine *e, const double *dQ, int64_t N, int32_t layout, uint8_t *dvalid,

@@ -106,6 +106,8 @@ ABI = {
     "mjpl_stream": (_VP, [_VP]),
     "mjpl_time_edges_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int32, _VP, C.c_int32,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mjpl_time_edges_stages_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int32, _VP, C.c_int32,
+                                             C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), _I32P]),
     "mjpl_time_configs_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.c_int32,
                                         C.POINTER(C.c_float)]),
     "mjpl_pose_create": (C.c_int, [_VP, C.POINTER(PoseDesc), C.POINTER(_VP)]),
@@ -339,6 +341,18 @@ class Engine:
         self._ok(self.lib.mjpl_time_edges_dev(self.h, dQA, dQB, n, float(step_dist), layout, dvalid,
                                               iters, ms.ctypes.data_as(fp), ms1.ctypes.data_as(fp)))
         return (ms, ms1) if first_kernel else ms
+
+    STAGES = ("k_filter_endpoints", "k_filter_items", "k_filter_edges", "k_patch_pairs", "k_check_edges")
+
+    def time_edges_stages_dev(self, dQA, dQB, n, step_dist, layout, dvalid, iters, sample_every=4):
+        """`iters` back-to-back edge launches -> (mean ms per launch, {stage kernel: mean ms},
+        sampled launches); the stages are bracketed on every `sample_every`-th launch only."""
+        mean = C.c_float(0)
+        st = (C.c_float * len(self.STAGES))()
+        ns = C.c_int32(0)
+        self._ok(self.lib.mjpl_time_edges_stages_dev(self.h, dQA, dQB, n, float(step_dist), layout, dvalid, iters,
+                                                     sample_every, C.byref(mean), st, C.byref(ns)))
+        return float(mean.value), {k: float(st[i]) for i, k in enumerate(self.STAGES)}, int(ns.value)
 
     def ik_solve(self, site: str, target_pos, target_quat, Q, movable, pos_tolerance=1e-3,
                  ori_tolerance=1e-3, iterations=500, damping=0.0, lm_damping=-1.0, max_step=0.0):

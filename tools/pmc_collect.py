@@ -1,0 +1,44 @@
+"""Fold the per-kernel PMC summaries of one profiling round (profiles/<tag>_pmc_<kernel>.json,
+written by tools/pmc_summary.py from separate rocprofv3 --pmc passes) into profiles/pmc.json, the
+file bench.py reads `roofline.traffic` and `valu_issue` from.
+usage: python tools/pmc_collect.py <tag> [E] [layout]"""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    E = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
+    layout = sys.argv[3] if len(sys.argv) > 3 else "soa"
+    path = os.path.join(ROOT, "profiles", "pmc.json")
+    try:
+        with open(path) as f:
+            out = json.load(f)
+    except (OSError, ValueError):
+        out = {}
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_pmc_*.json"))):
+        kernel = os.path.basename(p)[len(tag) + 5:-5]
+        with open(p) as f:
+            r = json.load(f)
+        rec = {k: r[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES",
+                                 "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU",
+                                 "GRBM_GUI_ACTIVE", "avg_ns") if k in r}
+        if "FETCH_SIZE" in r or "WRITE_SIZE" in r:
+            rec["FETCH_SIZE_KiB"] = r.get("FETCH_SIZE")
+            rec["WRITE_SIZE_KiB"] = r.get("WRITE_SIZE")
+            rec["hbm_bytes_per_launch"] = (2 * r.get("FETCH_SIZE", 0.0) + r.get("WRITE_SIZE", 0.0)) * 1024
+            rec["correction"] = ("gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); "
+                                 "FETCH_SIZE and WRITE_SIZE from separate --pmc passes")
+        rec["source"] = f"profiles/{os.path.basename(p)} (tools/profile_gpu.sh {tag})"
+        out[f"{kernel}_{E}_{layout}"] = rec
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v.get("source") for k, v in out.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
