@@ -100,6 +100,13 @@ typedef struct mjpl_info {
   int32_t lds_bytes_filter;  /* dynamic LDS per block, float32 filter kernels             */
   int32_t filter_block_threads;
   char    arch[32];          /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"            */
+  /* the filter's binary32 error bound for this model: a float32 signed distance is
+   * within filter_err_a + filter_err_b * C of the float64 one while every moving coordinate
+   * magnitude is <= C; configurations beyond filter_max_coord go to the float64 kernels */
+  float   filter_max_coord;
+  float   filter_err_a;
+  float   filter_err_b;
+  int32_t filter_poisoned_geoms; /* static geoms too large / far for binary32: always re-checked */
 } mjpl_info;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -125,7 +132,12 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out);
  * classified with a tolerance `tol` (metres) as certain / uncertain; only the items it cannot
  * decide are re-run by the float64 kernel (same stream, no host round trip).  enable = 0
  * sends everything through the float64 kernels.  Environment overrides at create:
- * MJPL_FILTER=0|1, MJPL_FILTER_TOL=<metres>. */
+ * MJPL_FILTER=0|1, MJPL_FILTER_TOL=<metres>.
+ * Half of `tol` is the budget for the binary32 rounding error of this model's poses, which
+ * mjpl_create bounds from the kinematic chain (mjpl_info.filter_err_a / _b).  The default tolerance
+ * is max(1e-4, 2.5 * filter_err_a); a tolerance set here is kept as given, and if the model's
+ * error floor does not fit under it the filter is switched off for this engine
+ * (mjpl_info.filter_enabled = 0: everything runs on the float64 kernels). */
 int mjpl_set_filter(mjpl_engine *e, int32_t enable, double tol);
 /* how many items of the most recent launch went to the float64 kernel (synchronises) */
 int64_t mjpl_filter_last_undecided(mjpl_engine *e);

@@ -53,10 +53,13 @@ template <> struct Real<float> { static constexpr bool exact = false; typedef FP
 
 // verdict codes of the narrowphase (the exact path only produces 0 and 1)
 enum : int { V_NONE = 0, V_CONTACT = 1, V_UNSURE = 2 };
-// the float32 filter decides only configurations whose body origins stay within this many metres
-// of the world origin (rounding error ~ 1e-7 x coordinate x chain length must stay far below the
-// tolerance band)
-constexpr float kFilterMaxCoord = 64.0f;
+// The float32 filter decides a configuration only while its float32 world poses are provably
+// within tol/2 of the float64 ones (DESIGN.md section 5.1b derives the bound E = A + B * C per
+// model): every moving body origin within FC_MAXCOORD metres of the world origin (C), every
+// hinge angle within FC_MAXANGLE radians of its reference.  Anything else goes to the exact path.
+// The limits are per model: mjpl_create derives them from the kinematic chain and the tolerance.
+enum : int { FC_MAXCOORD = 0, FC_MAXANGLE = 1, FC_SIZE = 4 };
+constexpr float kFilterMaxAngle = 6.5f;
 
 // ----------------------------------------------------------------------------- program layout
 // The model is compiled on the host (mjpl_hip.hip: compile_program) into two flat tables that
@@ -73,6 +76,7 @@ enum : int {
   H_OFF_WNARROW,   // constant-table offset of the world narrowphase table
   H_NWORLD,        // static geoms
   H_NWPAD,         // ... rounded up to a multiple of 4
+  H_OFF_FCONST,    // constant-table offset of the filter's limits (FC_*)
   H_SIZE
 };
 
@@ -395,9 +399,11 @@ __device__ __forceinline__ int capsule_capsule(T margin, const GeomT<T> &c1, con
   int res = V_NONE;
 
   if constexpr (!Real<T>::exact) {
-    // The closest-point parameters are ill-conditioned for nearly parallel axes (and the exact
-    // path has its own branch there): leave those pairs, and degenerate capsules, to it.
-    if (!(det > T(1e-3) * ma * mc)) return V_UNSURE;
+    // Leave to the exact path: nearly parallel axes (sin^2 < 1e-4: binary32 cannot form det, and
+    // the float64 routine switches to its parallel branch at the ABSOLUTE threshold |det| < 1e-15,
+    // which tiny capsules reach at any angle -- ma * mc itself is below it for half-lengths under
+    // ~2e-4 m), and degenerate capsules.  NaN fails both tests.
+    if (!(det > T(1e-4) * ma * mc) || !(det > T(4e-15))) return V_UNSURE;
   }
   const bool general = Real<T>::exact ? (fabs(det) >= T(MJPL_MINVAL)) : true;
   if (general) {
@@ -417,7 +423,30 @@ __device__ __forceinline__ int capsule_capsule(T margin, const GeomT<T> &c1, con
       vec1[k] = c1.pos[k] + axis1[k] * x1;
       vec2[k] = c2.pos[k] + axis2[k] * x2;
     }
-    res = sphere_sphere(margin, vec1, size1[0], vec2, size2[0], tol);
+    if constexpr (Real<T>::exact) {
+      res = sphere_sphere(margin, vec1, size1[0], vec2, size2[0], tol);
+    } else {
+      // The parameters above carry binary32 rounding amplified by 1 / sin^2, so the verdict does
+      // not rest on them being the minimiser:
+      //  * CONTACT needs only two points ON the segments (x1, x2 in [-1, 1] by construction) that
+      //    are closer than the threshold;
+      //  * NO CONTACT needs a lower bound of the minimum.  f = |vec1 - vec2|^2 / 2 is convex in
+      //    (x1, x2), so f(x*) >= f(x) + grad f . (x* - x) >= f(x) - 2 (|g1|' + |g2|'), where a
+      //    component whose parameter sits on its bound and whose gradient points outward
+      //    contributes nothing.  g_k is itself evaluated in binary32: |a_k| * tol / 8 covers that
+      //    (its inputs are accurate to tol / 2 * 4 eps / B).
+      // Whatever is neither goes to the exact path.
+      const T dd[3] = {vec1[0] - vec2[0], vec1[1] - vec2[1], vec1[2] - vec2[2]};
+      const T D2 = dot3(dd, dd);
+      const T D = rsqrt_val(D2);
+      const T rs = margin + size1[0] + size2[0];
+      const T g1 = dot3(axis1, dd), g2 = -dot3(axis2, dd);
+      const T e1 = x1 >= 1 ? fmax(g1, T(0)) : (x1 <= -1 ? fmax(-g1, T(0)) : fabs(g1));
+      const T e2 = x2 >= 1 ? fmax(g2, T(0)) : (x2 <= -1 ? fmax(-g2, T(0)) : fabs(g2));
+      const T alen = T(1.001) * (size1[1] + size2[1]);  // |a1| + |a2| (the axes are unit vectors)
+      const T lo2 = D2 - T(4) * (e1 + e2) - alen * (T(0.5) * tol + T(2e-6) * D) - T(1e-6) * D2;
+      res = (D - rs < -tol) ? V_CONTACT : ((lo2 > (rs + tol) * (rs + tol)) ? V_NONE : V_UNSURE);
+    }
   } else {
     // parallel axes (rare, exact path only): any of the four end tests
     T x1, x2;
@@ -510,7 +539,28 @@ __device__ __forceinline__ int capsule_box(T margin, const GeomT<T> &cap, const 
   T t = (den > 0) ? lo + (hi - lo) * rdiv(0 - glo, den) : lo;
   t = (g_m1 >= 0) ? T(-1) : ((g_p1 <= 0) ? T(1) : t);
   T c[3] = {p[0] + t * h[0], p[1] + t * h[1], p[2] + t * h[2]};
-  return sphere_box_local(margin, c, size1[0], size2, tol);
+  if constexpr (Real<T>::exact) {
+    return sphere_box_local(margin, c, size1[0], size2, tol);
+  } else {
+    // As in capsule_capsule the verdict does not rest on t being the minimiser (the breakpoints
+    // divide by components of h that may be tiny): CONTACT needs one point of the segment within
+    // the threshold of the box; NO CONTACT needs a lower bound of the minimum, and dist^2 / 2 is
+    // convex in t with derivative g(t): dist^2(t*) >= dist^2(t) - 4 |g(t)|', the one-sided part
+    // only when t sits on an end of [-1, 1].
+    t = clipd(t, T(-1), T(1));
+    c[0] = p[0] + t * h[0]; c[1] = p[1] + t * h[1]; c[2] = p[2] + t * h[2];
+    T d[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) d[k] = clipd(c[k], -size2[k], size2[k]) - c[k];
+    const T D2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const T D = rsqrt_val(D2);
+    const T rs = margin + size1[0];
+    const T gt = -(h[0] * d[0] + h[1] * d[1] + h[2] * d[2]);  // g(t) = sum h_k e_k, e = -d
+    const T ge = t >= 1 ? fmax(gt, T(0)) : (t <= -1 ? fmax(-gt, T(0)) : fabs(gt));
+    const T hl = T(1.001) * size1[1];
+    const T lo2 = D2 - T(4) * ge - hl * (T(0.5) * tol + T(2e-6) * D) - T(1e-6) * D2;
+    return (D - rs < -tol) ? V_CONTACT : ((lo2 > (rs + tol) * (rs + tol)) ? V_NONE : V_UNSURE);
+  }
 }
 
 // 15-axis separating-axis verdict; see oracle/mjpl_oracle.c box_box
@@ -733,6 +783,9 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
   Tab wnarrow = tp + uni(ip[H_OFF_WNARROW]);
   const int nwpad = uni(ip[H_NWPAD]);
   int pc = uni(ip[H_OFF_BODYOPS]);
+  // filter path: the per-model limits inside which binary32 poses are within tol / 2
+  const T maxcoord = Real<T>::exact ? T(0) : tp[uni(ip[H_OFF_FCONST]) + FC_MAXCOORD];
+  const T maxangle = Real<T>::exact ? T(0) : tp[uni(ip[H_OFF_FCONST]) + FC_MAXANGLE];
 
   for (int b = 0; b < nbodyops; b++) {
     // a wave whose every lane is already decided skips the rest of the tree
@@ -801,6 +854,8 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
           rot_vec_quat(xanchor, jpos, nq);
           xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];
         }
+        if constexpr (!Real<T>::exact)  // binary32(q) is off by eps |q|: only modest angles are decided here
+          unsure = unsure || (active && !(fabs(dq) <= maxangle));
         T sn, cs;
         sincos_half(dq * T(0.5), &sn, &cs);
         T qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};
@@ -820,7 +875,7 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
     for (int k = 0; k < 4; k++) qt[k] = nq[k];
     quat2mat(R, qt);
     if constexpr (!Real<T>::exact)  // see run_config_queued: too far out for the float32 tolerance
-      unsure = unsure || (active && !(fmax(fabs(p[0]), fmax(fabs(p[1]), fabs(p[2]))) <= T(kFilterMaxCoord)));
+      unsure = unsure || (active && !(fmax(fabs(p[0]), fmax(fabs(p[1]), fabs(p[2]))) <= maxcoord));
 
     if (save_slot >= 0) {
       T *sv = save + (size_t)save_slot * 7 * sstride;
@@ -1273,6 +1328,9 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   const T *lwcull = ltab + uni(ip[H_OFF_WCULL]);
   const T *lwnarrow = ltab + uni(ip[H_OFF_WNARROW]);
   int pc = uni(ip[H_OFF_BODYOPS]);
+  // the per-model limits inside which binary32 poses are within tol / 2 of the binary64 ones
+  const T maxcoord = tp[uni(ip[H_OFF_FCONST]) + FC_MAXCOORD];
+  const T maxangle = tp[uni(ip[H_OFF_FCONST]) + FC_MAXANGLE];
 
   for (int b = 0; b < nbodyops; b++) {
     if (__builtin_amdgcn_ballot_w64(dead == T(0)) == 0ull && qn == 0 && qb == 0) break;  // every lane decided
@@ -1335,6 +1393,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           rot_vec_quat(xanchor, jpos, nq);
           xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];
         }
+        far = far || !(fabs(dq) <= maxangle);  // binary32(q) is off by eps |q|
         T sn, cs;
         sincos_half(dq * T(0.5), &sn, &cs);
         T qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};
@@ -1352,10 +1411,10 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
 #pragma unroll
     for (int k = 0; k < 4; k++) qt[k] = nq[k];
     quat2mat(R, qt);
-    // float32 positions lose absolute accuracy with distance from the origin: beyond
-    // kFilterMaxCoord the tolerance band no longer covers the rounding error, so the whole
+    // float32 positions lose absolute accuracy with distance from the origin: beyond the model's
+    // limit (FC_MAXCOORD) the tolerance band no longer covers the rounding error, so the whole
     // configuration goes to the exact path (this also catches NaN)
-    far = far || !(fmax(fabs(p[0]), fmax(fabs(p[1]), fabs(p[2]))) <= T(kFilterMaxCoord));
+    far = far || !(fmax(fabs(p[0]), fmax(fabs(p[1]), fabs(p[2]))) <= maxcoord);
     if (far) dead = kInf;
     if (save_slot >= 0) {
       T *sv = save + (size_t)save_slot * 7 * sstride;

@@ -1243,7 +1243,13 @@ struct mjpl_engine {
   int *d_status = nullptr;
   // float32 filter + exact re-run of what it cannot decide
   bool filter = true;
-  float filter_tol = 1e-4f;
+  float filter_tol = 1e-4f;       // tolerance band in force (>= filter_tol_req)
+  float filter_tol_req = 1e-4f;   // what the caller (or the default) asked for
+  bool filter_tol_user = false;   // asked for through mjpl_set_filter / MJPL_FILTER_TOL
+  bool filter_usable = true;      // false: this model's binary32 error floor is too high, exact path only
+  double ferr_a = 0, ferr_b = 0;  // |pose error| <= ferr_a + ferr_b * max coordinate
+  double fmax_coord = 0;
+  int npoisoned = 0;              // static geoms too large / far for binary32: their pairs are always undecided
   int *d_ulist = nullptr;   // items (configurations / whole edges) the filter left undecided
   int *d_ucount = nullptr;  // [0] how many of those, [1] undecided waypoints of edges, [2] edges in d_slist
   int *d_slist = nullptr;   // two-pass edge filter: edges whose endpoint passed
@@ -1355,6 +1361,7 @@ int compile_program(mjpl_engine *e) {
   std::vector<int> winfo;
   std::vector<std::pair<size_t, int>> info_at;  // dp index -> int stored there (first 4 bytes)
   std::vector<size_t> sq_bound_at, plane_bound_at;  // dp indices of cull bounds
+  std::vector<int> poison_rows;                     // world rows whose binary32 narrowphase data is NaN
   e->nstatic = e->nmoving = 0;
   for (int g = 0; g < ng; g++) {
     const int b = m.geom_bodyid[g];
@@ -1612,20 +1619,134 @@ int compile_program(mjpl_engine *e) {
   ip.insert(ip.end(), 32, 0);
   dp.insert(dp.end(), 24, 0.0);
 
+  // ---- binary32 error bound of the filter.  eps = 2^-24.  For every
+  // moving body b, by induction along the chain (every operation of run_config_queued counted with
+  // its worst-case rounding; fused multiply-adds only lower these):
+  //   rot(b) <= rot(parent) + (20 + 42 * hinges(b)) eps          orientation error, radians
+  //   pos(b) <= posA(b) + posB(b) * C                            position error, metres, where C
+  //             bounds every moving coordinate magnitude (enforced per lane: FC_MAXCOORD), and
+  //   posA(b) = posA(parent) + L_b (rot(parent) + 8 eps) + 3 eps L_b + sum_hinges 2 |jnt_pos| (rot(b) + 8 eps)
+  //   posB(b) = posB(parent) + sqrt(3) eps (1 + slides(b) + 2 offcentre_hinges(b))
+  // A geom adds |lpos| (rot + 8 eps) + extent (rot + 24 eps) + 2 eps |size| and sqrt(3) eps C; a static
+  // geom is off by the rounding of its constants; evaluating a narrowphase formula on binary32
+  // poses adds 16 eps (pair scale) + 4 eps C.  Signed distances are 1-Lipschitz in every point of
+  // either geom, so |distance32 - distance64| <= E = A + B C over all enabled pairs.
+  {
+    const double eps = std::ldexp(1.0, -24);
+    const double r3 = std::sqrt(3.0);
+    auto norm3 = [](const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    std::vector<double> rot(nb, 0.0), posA(nb, 0.0), posB(nb, 0.0);
+    for (int b = 0; b < nb; b++)
+      if (e->body_static[b]) { rot[b] = 2 * eps; posA[b] = r3 * eps * norm3(&e->st_xpos[3 * b]); }
+    for (int b : order) {
+      const int p = m.body_parentid[b];
+      int hinges = 0, slides = 0, off = 0;
+      double jp = 0;
+      for (int j = 0; j < m.body_jntnum[b]; j++) {
+        const int jid = m.body_jntadr[b] + j;
+        if (m.jnt_type[jid] == JT_HINGE) {
+          hinges++;
+          const double l = norm3(&m.jnt_pos[3 * jid]);
+          if (l > 0) { off++; jp += l; }
+        } else {
+          slides++;
+        }
+      }
+      const double L = norm3(&m.body_pos[3 * b]);
+      rot[b] = rot[p] + (20.0 + 42.0 * hinges) * eps;
+      posA[b] = posA[p] + L * (rot[p] + 8 * eps) + 3 * eps * L + 2 * jp * (rot[b] + 8 * eps);
+      posB[b] = posB[p] + r3 * eps * (1 + slides + 2 * off);
+    }
+    auto extent = [&](int g) {  // farthest point of the geom from its frame origin along rotating directions
+      const double *sz = &m.geom_size[3 * g];
+      if (m.geom_type[g] == GT_CAPSULE) return sz[1];
+      if (m.geom_type[g] == GT_BOX) return norm3(sz);
+      return 0.0;
+    };
+    std::vector<double> gA(ng, 0.0), gB(ng, 0.0);
+    e->npoisoned = 0;
+    std::vector<char> poisoned(ng, 0);
+    const double tolh_req = 0.5 * e->filter_tol_req;
+    for (int g = 0; g < ng; g++) {
+      const int b = m.geom_bodyid[g];
+      const double lp = norm3(&m.geom_pos[3 * g]), sz = norm3(&m.geom_size[3 * g]);
+      if (e->geom_static[g]) {
+        gA[g] = r3 * eps * (norm3(&e->st_gxpos[3 * g]) + extent(g)) + 2 * eps * sz;
+        // a static geom whose own constants do not fit binary32 within an eighth of the band: its
+        // narrowphase rows are NaN in the float tables, so every pair that passes its (widened)
+        // cull comes out undecided and is settled by the float64 pair kernel
+        if (gA[g] > 0.25 * tolh_req) { poisoned[g] = 1; e->npoisoned++; }
+      } else {
+        gA[g] = posA[b] + lp * (rot[b] + 8 * eps) + extent(g) * (rot[b] + 24 * eps) + 2 * eps * sz;
+        gB[g] = posB[b] + r3 * eps;
+      }
+    }
+    double A = 0, B = 0;
+    for (int k = 0; k < nm; k++) {
+      const int g = mgeoms[k];
+      auto pair = [&](int h) {
+        if (poisoned[h]) return;
+        const double scale = m.geom_rbound[g] + m.geom_rbound[h] + std::fmax(m.geom_margin[g], m.geom_margin[h]) +
+                             (m.geom_type[h] == GT_PLANE ? norm3(&e->st_gxpos[3 * h]) : 0.0);
+        A = std::fmax(A, gA[g] + gA[h] + 16 * eps * scale);
+        B = std::fmax(B, gB[g] + gB[h] + 4 * eps);
+      };
+      for (int sgeom : world_partners[k]) pair(sgeom);
+      for (int k2 : stored_partners[k]) pair(mgeoms[k2]);
+    }
+    e->ferr_a = A;
+    e->ferr_b = B;
+    // half the band is the error budget: E(C) = A + B C <= tol / 2.  A default tolerance grows with
+    // the model's floor; one the caller asked for is kept, and if the floor does not fit under it
+    // the filter steps aside for this model (exact path only).
+    double tol = e->filter_tol_req;
+    e->filter_usable = true;
+    if (A > 0.4 * tol) {
+      if (e->filter_tol_user) e->filter_usable = false;
+      else tol = A / 0.4;
+      if (!(tol < 1e-2)) e->filter_usable = false;  // a band of centimetres decides nothing useful
+    }
+    e->filter_tol = (float)tol;
+    double maxc = (B > 0) ? (0.5 * tol - A) / B : 1e6;
+    maxc = std::fmin(std::fmax(maxc, 0.0), 1e6);
+    e->fmax_coord = e->filter_usable ? maxc : 0.0;
+    ip[H_OFF_FCONST] = (int)dp.size();
+    double fc[FC_SIZE] = {0};
+    fc[FC_MAXCOORD] = e->fmax_coord;
+    fc[FC_MAXANGLE] = kFilterMaxAngle;
+    dp.insert(dp.end(), fc, fc + FC_SIZE);
+    // NaN rows: written into the float image below
+    for (int g = 0; g < ng; g++)
+      if (poisoned[g]) poison_rows.push_back(world_row[g]);
+  }
+
   // ---- the filter's float32 image: same offsets; cull bounds widened by the tolerance so that
   // a pair culled in float32 is certainly culled (or contact-free) in float64
   std::vector<float> &fp = e->fp;
   fp.resize(dp.size());
   for (size_t k = 0; k < dp.size(); k++) fp[k] = (float)dp[k];
+  // (a poisoned static geom's own rounding may exceed the band: its bounds are widened by that, too)
   const double tol = e->filter_tol;
+  double poison_slack = 0;
+  for (int w : poison_rows) {
+    const double *rc = &dp[(size_t)ip[H_OFF_WCULL] + (size_t)w * WC_LEN];
+    const double *rn = &dp[(size_t)ip[H_OFF_WNARROW] + (size_t)w * WN_LEN];
+    const double mag = std::fabs(rc[0]) + std::fabs(rc[1]) + std::fabs(rc[2]) + std::fabs(rn[WN_SIZE]) +
+                       std::fabs(rn[WN_SIZE + 1]) + std::fabs(rn[WN_SIZE + 2]);
+    poison_slack = std::fmax(poison_slack, 4 * std::ldexp(1.0, -24) * mag);
+  }
   for (size_t k : sq_bound_at)
     if (std::isfinite(dp[k])) {
-      const double r = std::sqrt(dp[k]) + tol;
+      const double r = std::sqrt(dp[k]) + tol + poison_slack;
       fp[k] = (float)(r * r * (1.0 + 1e-6));
     }
   for (size_t k : plane_bound_at)
-    if (std::isfinite(dp[k])) fp[k] = (float)(dp[k] + tol + 1e-6 * std::fabs(dp[k]));
+    if (std::isfinite(dp[k])) fp[k] = (float)(dp[k] + tol + poison_slack + 1e-6 * std::fabs(dp[k]));
   for (auto &kv : info_at) memcpy(&fp[kv.first], &kv.second, sizeof(float));
+  // the whole narrowphase row (axes and sizes; the position belongs to the cull table): every
+  // routine then computes NaN and classifies the pair as undecided
+  for (int w : poison_rows)
+    for (int k = 0; k < WN_LEN; k++) fp[(size_t)ip[H_OFF_WNARROW] + (size_t)w * WN_LEN + k] = std::numeric_limits<float>::quiet_NaN();
 
   // ---- upload
   if (e->d_ip) (void)hipFree(e->d_ip);
@@ -1745,7 +1866,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
                    unsigned long long *dbits) {
   if (N == 0) return MJPL_OK;
   const unsigned grid = (unsigned)((N + kBlock - 1) / kBlock);
-  const bool filter = e->filter && dvalid && !dbits && N < (int64_t)1 << 30;
+  const bool filter = e->filter && e->filter_usable && dvalid && !dbits && N < (int64_t)1 << 30;
   if (filter) {
     int rc = ulist_reserve(e, N);
     UndecidedConfigs uc = {};
@@ -1807,7 +1928,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
                  int layout, int flags, uint8_t *dvalid, int32_t *dfb) {
   if (E == 0) return MJPL_OK;
   const unsigned grid = (unsigned)((E + kBlock - 1) / kBlock);
-  const bool filter = e->filter && E < (int64_t)1 << 30;  // item ids travel in 30 bits of the per-lane flag words
+  const bool filter = e->filter && e->filter_usable && E < (int64_t)1 << 30;  // item ids travel in 30 bits of the per-lane flag words
   UndecidedConfigs uc = {};
   if (filter) {
     int rc = ulist_reserve(e, E);
@@ -2050,7 +2171,7 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
   if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));
   if (const char *t = getenv("MJPL_FILTER_TOL")) {
     const double v = atof(t);
-    if (v > 0.0 && v < 1.0) e->filter_tol = (float)v;
+    if (v > 0.0 && v < 1.0) { e->filter_tol_req = (float)v; e->filter_tol_user = true; }
   }
   int rc = compile_program(e);
   if (rc != MJPL_OK) return bail(rc);
@@ -2108,15 +2229,16 @@ int mjpl_set_filter(mjpl_engine *e, int32_t enable, double tol) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->filter = enable != 0;
-  if (enable && (float)tol != e->filter_tol) {
-    e->filter_tol = (float)tol;
+  if (enable && (!e->filter_tol_user || (float)tol != e->filter_tol_req)) {
+    e->filter_tol_req = (float)tol;
+    e->filter_tol_user = true;
     return compile_program(e);
   }
   return MJPL_OK;
 }
 
 int64_t mjpl_filter_last_undecided(mjpl_engine *e) {
-  if (!e || !e->filter || !e->d_ucount) return 0;
+  if (!e || !e->filter || !e->filter_usable || !e->d_ucount) return 0;
   int n[5 * kCtr];
   if (hipSetDevice(e->device) != hipSuccess) return -1;
   if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
@@ -2155,8 +2277,12 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   out->nsaves = e->nsave;
   out->lds_bytes_configs = (int)lds_bytes(e, 1);
   out->lds_bytes_edges = (int)lds_bytes(e, 1);
-  out->filter_enabled = e->filter ? 1 : 0;
+  out->filter_enabled = (e->filter && e->filter_usable) ? 1 : 0;
   out->filter_tol = e->filter_tol;
+  out->filter_max_coord = (float)e->fmax_coord;
+  out->filter_err_a = (float)e->ferr_a;
+  out->filter_err_b = (float)e->ferr_b;
+  out->filter_poisoned_geoms = e->npoisoned;
   out->filter_block_threads = e->mbox ? kBlock : kFilterBlock;
   out->lds_bytes_filter = (int)lds_bytes(e, 1, sizeof(float), out->filter_block_threads, !e->mbox);
   out->block_threads = kBlock;
@@ -2433,7 +2559,7 @@ int mjpl_time_edges_dev(mjpl_engine *e, const double *dQA, const double *dQB, in
   const int rc = mjpl_time_edges_stages_dev(e, dQA, dQB, E, step_dist, layout, dvalid, iters, 1, &mean,
                                             ms_first ? stage : nullptr, nullptr);
   if (rc != MJPL_OK) return rc;
-  const int main_stage = e->filter ? MJPL_STAGE_ITEMS : MJPL_STAGE_EXACT;
+  const int main_stage = (e->filter && e->filter_usable) ? MJPL_STAGE_ITEMS : MJPL_STAGE_EXACT;
   for (int k = 0; k < iters; k++) {
     ms[k] = mean;
     if (ms_first) ms_first[k] = stage[main_stage];

@@ -36,6 +36,10 @@ static double *scratch(int slot, size_t ndoubles) {
 
 #include "orc_math.h"
 
+int orc_trig_mode = 0;
+void orc_set_trig(int mode) { orc_trig_mode = mode ? 1 : 0; }
+int orc_get_trig(void) { return orc_trig_mode; }
+
 /* ------------------------------------------------------------------ a3: mj_kinematics
  * [MJ-recalled: engine_core_smooth.c mj_kinematics + mj_local2Global].
  * Reference call site: collision_constraint.py:28. */

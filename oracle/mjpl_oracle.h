@@ -171,6 +171,11 @@ int orc_pose_apply(const orc_model *m, const orc_pose *p, const double *q_old, c
 int orc_pose_apply_batch(const orc_model *m, const orc_pose *p, const double *Q_old, const double *Q,
                          int64_t N, int32_t nthreads, double *Q_out, uint8_t *ok, int32_t *iters);
 
+/* sin/cos used by mju_axisAngle2Quat: 0 = libm (default, as MuJoCo), 1 = the fdlibm algorithm in
+ * fixed-order IEEE double operations (bit-reproducible; see orc_math.h).  Process-wide. */
+void orc_set_trig(int mode);
+int orc_get_trig(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,13 +55,67 @@ ORC_UNUSED static void rot_vec_quat(double *res, const double *vec, const double
   }
 }
 
+/* Which sin/cos mju_axisAngle2Quat uses.  0 (default): the C library's, as MuJoCo does -- libm
+ * implementations differ from one another in the last bit, and so does the GPU's, so a verdict
+ * whose signed distance lies within ~1e-15 of zero may differ between ANY two of them.
+ * 1: the fdlibm algorithm restated below (Sun Microsystems' published k_sin.c / k_cos.c /
+ * e_rem_pio2.c, medium-argument path), evaluated in plain IEEE double operations in a fixed order
+ * without FMA, hence bit-reproducible on any IEEE machine.  The at-threshold parity tests run in
+ * mode 1 so that "bit-exact" can be asserted down to the last ulp of the joint value; every other
+ * test runs in mode 0.  (orc_set_trig in mjpl_oracle.c.) */
+extern int orc_trig_mode;
+
+ORC_UNUSED static double orc_ksin(double x, double y) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = x * x, w = z * z;
+  double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+  double v = z * x;
+  return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+
+ORC_UNUSED static double orc_kcos(double x, double y) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = x * x, w = z * z;
+  double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+  double hz = 0.5 * z;
+  w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+
+ORC_UNUSED static void orc_sincos(double x, double *s, double *c) {
+  if (orc_trig_mode == 0 || !(fabs(x) < 8.2e5)) { *s = sin(x); *c = cos(x); return; }
+  /* x = n * pi/2 + (y0 + y1), pi/2 in three 33-bit pieces (Cody-Waite) */
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+               pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
+  double fn = rint(x * invpio2);
+  int n = (int)fn;
+  double t = x - fn * pio2_1;
+  double w = fn * pio2_2;
+  double r = t - w;
+  w = fn * pio2_2t - ((t - r) - w);
+  double y0 = r - w;
+  double y1 = (r - y0) - w;
+  double sn = orc_ksin(y0, y1), cs = orc_kcos(y0, y1);
+  switch (n & 3) {
+    case 0: *s = sn; *c = cs; break;
+    case 1: *s = cs; *c = -sn; break;
+    case 2: *s = -sn; *c = -cs; break;
+    default: *s = -cs; *c = sn; break;
+  }
+}
+
 /* mju_axisAngle2Quat */
 ORC_UNUSED static void axis_angle2quat(double *res, const double *axis, double angle) {
   if (angle == 0) {
     res[0] = 1; res[1] = 0; res[2] = 0; res[3] = 0;
   } else {
-    double s = sin(angle * 0.5);
-    res[0] = cos(angle * 0.5);
+    double s, c;
+    orc_sincos(angle * 0.5, &s, &c);
+    res[0] = c;
     res[1] = axis[0] * s;
     res[2] = axis[1] * s;
     res[3] = axis[2] * s;

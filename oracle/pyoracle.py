@@ -97,6 +97,21 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
+class portable_trig:
+    """Context manager: the oracle's sin/cos become the bit-reproducible fdlibm restatement
+    (oracle/orc_math.h) instead of libm's.  Used by the at-threshold parity tests only: any two
+    libm's (and the GPU's routine) differ in the last bit of some sin/cos, which can flip a verdict
+    whose signed distance lies within ~1e-15 of zero."""
+
+    def __enter__(self):
+        self.old = lib().orc_get_trig()
+        lib().orc_set_trig(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_trig(self.old)
+
+
 def sorted_allowed(model, allowed_collision_bodies) -> np.ndarray:
     """np.sort(body_ids, axis=1) of collision_constraint.py:60-64."""
     if not allowed_collision_bodies:
