@@ -317,6 +317,69 @@ int mjpl_ik_solve(mjpl_engine *e, const mjpl_ik_desc *desc, const double *Q, int
 int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *desc, const double *dQ, int64_t N, double *dQ_out,
                       uint8_t *dok, int32_t *diters, double *derr);
 
+/* ---- frontier bi-RRT, device-resident (BASELINE configs[3]) -------------
+ * RRT.plan_to_configs' sample / extend / connect loop (src/mjpl/planning/rrt.py:190-235) for `lanes`
+ * samples per round, with _constrained_extend's per-step rules (src/mjpl/planning/utils.py:139-164):
+ * step <= epsilon towards the target, PoseConstraint projection first if a pose handle is given
+ * (constraint order of examples/franka_constrained_move_to_pose.py:60-64), joint limits [lo, hi],
+ * stop when a step moves less than 1e-8, leads away from the target, or fails the collision check
+ * (endpoint + interval waypoints at interval_step; <= 0: endpoint only).  Both trees stay in HBM
+ * as SoA slabs [nplan][capacity]; batches are over the engine's planning columns
+ * (mjpl_set_planning).  The goal tree's roots are the goal configurations (the reference's sink
+ * node, rrt.py:179-188, is implicit).  Rank k of W draws its own targets (counter-based generator
+ * keyed by seed, k and the round); after every round all ranks' new nodes are all-gathered and
+ * appended in rank order, so all ranks hold identical trees. */
+typedef struct mjpl_rrt mjpl_rrt;
+
+typedef struct mjpl_rrt_desc {
+  int32_t lanes;               /* samples per rank per round                                   */
+  int64_t capacity;            /* node capacity of each tree                                    */
+  double  epsilon;             /* rrt.py:30                                                     */
+  double  interval_step;       /* collision_interval_check step (rrt.py:28); <= 0: none         */
+  double  goal_bias;           /* rrt.py:32                                                     */
+  uint64_t seed;
+  const double *lo, *hi;       /* [nplan] sampling box = JointLimitConstraint ranges            */
+  mjpl_pose *pose;             /* nullable: PoseConstraint applied first                        */
+  int64_t max_new_per_round;   /* slab rows per tree per rank per round; <= 0: max(128 lanes, 65536) */
+} mjpl_rrt_desc;
+
+typedef struct mjpl_rrt_round_info {
+  int32_t round;
+  int32_t new_nodes[2];        /* appended this round, all ranks: start tree, goal tree         */
+  int32_t nodes[2];            /* tree sizes after the round                                    */
+  int32_t connected;           /* 1: a lane's two extensions met                                */
+  int32_t conn_start, conn_goal; /* node ids of the junction in the start / goal tree           */
+  int32_t conn_rank;           /* the rank whose lane connected (lowest rank, lowest lane wins) */
+  int32_t stop_requested;      /* some rank passed request_stop != 0 this round                 */
+} mjpl_rrt_round_info;
+
+int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *desc, mjpl_rrt **out);
+void mjpl_rrt_destroy(mjpl_rrt *r);
+/* new query: start tree = {q_init}, goal tree = the ngoal rows of q_goals [ngoal][nplan] */
+int mjpl_rrt_reset(mjpl_rrt *r, const double *q_init, const double *q_goals, int32_t ngoal, uint64_t seed);
+/* one round: sample, extend the growing tree, extend the other towards what was reached, exchange.
+ * Synchronises (the host needs the connection flag and the node counts).  request_stop != 0 (a
+ * rank's time limit has passed) travels with the exchange, so that all ranks stop after the same
+ * round: info->stop_requested. */
+int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info);
+/* after a round with connected = 1: the path q_init ... goal, rows [len][nplan] */
+int mjpl_rrt_path(mjpl_rrt *r, double *path, int32_t maxlen, int32_t *len);
+/* download a tree (0 = start, 1 = goal): rows Q [n][nplan] and parent ids (-1 = root); either may
+ * be NULL; *n always receives the node count */
+int mjpl_rrt_get_tree(mjpl_rrt *r, int32_t tree, double *Q, int32_t *parent, int64_t maxn, int64_t *n);
+/* the targets [lanes][nplan] and participation flags of the most recent round (tests) */
+int mjpl_rrt_get_lanes(mjpl_rrt *r, double *targets, uint8_t *on);
+
+/* The exchange step runs on RCCL, called from this library on the engine's stream; a launcher only
+ * ferries the 128-byte ncclUniqueId from rank 0 to the others (any transport).  Without a
+ * communicator an engine is a world of one. */
+int mjpl_comm_unique_id(void *id128);
+int mjpl_comm_init(mjpl_engine *e, const void *id128, int32_t rank, int32_t world);
+int mjpl_comm_destroy(mjpl_engine *e);
+/* ncclAllGather of bytes_per_rank bytes per rank on the engine's stream (in place allowed:
+ * dsend == drecv + rank * bytes_per_rank) */
+int mjpl_allgather_dev(mjpl_engine *e, const void *dsend, void *drecv, size_t bytes_per_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,14 +7,14 @@ from .constraint import (CollisionConstraint, CollisionRuleset, Constraint, Join
 from .inverse_kinematics import HipIKSolver, IKSolver
 from .lie import SE3, SO3
 from .model import Model, ModelBuilder, load_mjcf, parse_mjcf
-from .planning import (RRT, EdgeValidator, HipEdgeValidator, Node, ParallelBiRRT, Tree, cartesian_plan,
-                       path_length, smooth_path)
+from .planning import (RRT, DeviceBiRRT, EdgeValidator, HipEdgeValidator, Node, ParallelBiRRT, Tree,
+                       cartesian_plan, path_length, smooth_path)
 from .utils import all_joints, qpos_idx, qvel_idx, random_config, site_pose
 
 __all__ = (
     "CollisionConstraint", "CollisionRuleset", "Constraint", "JointLimitConstraint", "PoseConstraint",
     "SE3", "SO3", "site_pose", "HipIKSolver", "IKSolver", "cartesian_plan",
     "apply_constraints", "obeys_constraints", "Model", "ModelBuilder", "load_mjcf", "parse_mjcf",
-    "RRT", "Node", "Tree", "path_length", "smooth_path", "ParallelBiRRT", "EdgeValidator", "HipEdgeValidator",
+    "RRT", "Node", "Tree", "path_length", "smooth_path", "ParallelBiRRT", "DeviceBiRRT", "EdgeValidator", "HipEdgeValidator",
     "all_joints", "qpos_idx", "qvel_idx", "random_config",
 )

@@ -1278,6 +1278,9 @@ struct mjpl_engine {
   // static poses for FK output
   std::vector<double> st_xpos, st_xquat, st_gxpos, st_gxmat;
   std::vector<char> body_static, geom_static;
+  // RCCL communicator of the frontier planner's exchange (mjpl_comm_init); none = a world of one
+  void *comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
   // grow-only staging buffers for the host-pointer entry points
   void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
@@ -2183,6 +2186,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->comm) (void)mjpl_comm_destroy(e);
   for (int k = 0; k < 6; k++)
     if (e->stage[k]) (void)hipFree(e->stage[k]);
   if (e->d_ip) (void)hipFree(e->d_ip);
@@ -2845,3 +2849,5 @@ int mjpl_ik_solve(mjpl_engine *e, const mjpl_ik_desc *d, const double *Q, int64_
 }
 
 }  // extern "C"
+
+#include "mjpl_rrt.h"

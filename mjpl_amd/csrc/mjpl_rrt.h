@@ -1,0 +1,896 @@
+// mjpl_rrt.h -- device-resident frontier bi-RRT and the RCCL exchange (SURVEY.md section 8e,
+// BASELINE configs[3]).  Included at the end of mjpl_hip.hip: same translation unit, so it uses the
+// engine's launch helpers directly.
+//
+// What it replaces, for L lanes at a time: RRT.plan_to_configs' sample / extend / connect loop
+// (reference src/mjpl/planning/rrt.py:190-235) with _constrained_extend's per-step accept / stop
+// rules (src/mjpl/planning/utils.py:139-164).  Both trees live in HBM as SoA slabs [nplan][cap]
+// (the layout mjpl_nearest_dev reads); a round never moves tree data through the host: the host
+// reads back one 64-byte counter block per extension chunk and per exchange, nothing else.
+//
+// The algorithm (one round r = 1, 2, ... on rank k of W, L lanes per rank) is stated in DESIGN.md
+// section 7 and mirrored in NumPy by mjpl_amd/planning/parallel_rrt.py (the CPU / gloo flavour and
+// the reference the GPU tests compare whole trees against):
+//   1. targets: counter-based splitmix64 draws keyed by (seed, rank, round); goal bias; of the
+//      biased lanes that share a target only the lowest takes part;
+//   2. nearest node of the growing tree per lane (snapshot at round start);
+//   3. extend: repeated _step(cur, target, eps) [-> PoseConstraint projection] -> joint limits ->
+//      moved >= 1e-8 -> not farther from the target -> collision edge (endpoint + interval);
+//      the accepted prefix of every lane becomes new nodes, ordered (lane, level);
+//   4. the other tree extends towards what each lane reached; equal ends = a connection;
+//   5. exchange: all ranks' new nodes are all-gathered (RCCL on the engine's stream) and appended
+//      in rank order, so every rank holds bit-identical trees and node ids.
+#pragma once
+
+#include <dlfcn.h>
+
+namespace {
+
+using namespace mjpl;
+
+// ----------------------------------------------------------------------------- RNG
+__host__ __device__ inline uint64_t sm64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline uint64_t rrt_key(uint64_t seed, uint64_t rank, uint64_t round) {
+  return sm64(sm64(seed) ^ sm64((rank << 40) ^ round));
+}
+__host__ __device__ inline double rrt_u01(uint64_t key, uint64_t ctr) {
+  return (double)(sm64(key + ctr * 0x9E3779B97F4A7C15ull) >> 11) * 0x1.0p-53;
+}
+
+// counters shared with the host (one 64-byte block, read back per chunk / per exchange)
+enum : int { RC_EDGES = 0, RC_ACC, RC_ACTIVE, RC_CONN, RC_CONN_REFA, RC_CONN_REFB, RC_NEWA, RC_NEWB,
+             RC_OVERFLOW, RC_SIZE = 16 };
+
+struct RrtLanes {
+  double *T, *C, *RA;          // [nplan][L] SoA: target, current end of the lane's chain, reach of extend A
+  int32_t *near, *refA, *refB; // nearest node; final reference of the lane in tree A / B
+  uint8_t *on, *act;           // takes part this round; still extending
+  int32_t *cnt, *off;          // accepted nodes of the lane in this extension; exclusive scan
+  int32_t *gfirst, *gcount;    // candidates of the lane in this chunk: first slot, how many
+  uint8_t *gend;               // the lane ends after this chunk's candidates whatever their verdicts
+  int32_t *goal;               // biased lanes: goal index (-1: not biased)
+};
+
+struct RrtCand {               // candidates of one chunk, AoS rows of nplan
+  double *A, *B;
+  int32_t *lane, *level;
+  uint8_t *valid, *rule, *reach;
+  int cap;
+};
+
+struct RrtAcc {                // nodes accepted during the current extension, any order
+  double *Q;                   // [cap][nplan]
+  int32_t *lane, *level;
+  int cap;
+};
+
+// ----------------------------------------------------------------------------- kernels
+__device__ __forceinline__ double seqnorm(const double *d, int n) {  // the sum order of the whole path
+  double s = 0;
+  for (int k = 0; k < n; k++) s = s + d[k] * d[k];
+  return sqrt(s);
+}
+
+constexpr int kRrtMaxPlan = 16;
+
+__global__ void __launch_bounds__(256)
+k_rrt_sample(int L, int nplan, uint64_t key, double pgoal, int grow, int ngoal, const double *__restrict__ lo,
+             const double *__restrict__ hi, const double *__restrict__ qinit, const double *__restrict__ goalQ,
+             int64_t goalcap, RrtLanes ln, int32_t *__restrict__ first) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const uint64_t base = (uint64_t)l * (uint64_t)(nplan + 2);
+  const bool biased = rrt_u01(key, base + nplan) <= pgoal;  // rng.random() <= p  (rrt.py:197)
+  int g = -1;
+  if (biased) {
+    if (grow == 0) {  // the start tree grows: a random goal (rrt.py:201-203)
+      g = (int)(rrt_u01(key, base + nplan + 1) * (double)ngoal);
+      g = g < ngoal ? g : ngoal - 1;
+      for (int c = 0; c < nplan; c++) ln.T[(int64_t)c * L + l] = goalQ[(int64_t)c * goalcap + g];
+    } else {          // the goal tree grows: q_init (rrt.py:198-199)
+      g = 0;
+      for (int c = 0; c < nplan; c++) ln.T[(int64_t)c * L + l] = qinit[c];
+    }
+    atomicMin(&first[g], l);
+  } else {
+    for (int c = 0; c < nplan; c++) {
+      const double u = rrt_u01(key, base + c);
+      ln.T[(int64_t)c * L + l] = lo[c] + u * (hi[c] - lo[c]);
+    }
+  }
+  ln.goal[l] = g;
+}
+
+// extension start: C = node nearest to the target, lane on unless it duplicates a lower biased lane
+__global__ void __launch_bounds__(256)
+k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLanes ln, const int32_t *__restrict__ first,
+            const double *__restrict__ Tgt, int second) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  bool on;
+  if (!second) {
+    const int g = ln.goal[l];
+    on = g < 0 || first[g] == l;
+    ln.on[l] = on ? 1 : 0;
+  } else {
+    on = ln.on[l] != 0;
+  }
+  const int nn = ln.near[l];
+  bool same = true;
+  for (int c = 0; c < nplan; c++) {
+    const double v = Q[(int64_t)c * cap + nn];
+    ln.C[(int64_t)c * L + l] = v;
+    same = same && (v == Tgt[(int64_t)c * L + l]);
+  }
+  ln.act[l] = (on && !same) ? 1 : 0;
+  ln.cnt[l] = 0;
+}
+
+// One chunk of an extension: every active lane walks up to S steps from C towards its target and
+// emits the candidate edges (w -> q) it would like validated.  Without a projecting constraint the
+// candidates do not depend on the verdicts, so S may exceed 1 and the rule checks (joint limits,
+// moved, not farther) are made here; with one, S = 1 and the rules are checked after projection.
+__global__ void __launch_bounds__(256)
+k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__restrict__ lo,
+          const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln, RrtCand cd, int *__restrict__ ctr) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool act = l < L && ln.act[l] != 0;
+  double T[kRrtMaxPlan], w[kRrtMaxPlan], q[kRrtMaxPlan], d[kRrtMaxPlan];
+  if (act)
+    for (int c = 0; c < nplan; c++) { T[c] = Tgt[(int64_t)c * L + l]; w[c] = ln.C[(int64_t)c * L + l]; }
+  // one step of the walk; returns 0 = rule failure (nothing emitted), 1 = emit and continue,
+  // 2 = emit, then the lane has arrived
+  auto step = [&]() -> int {
+    for (int c = 0; c < nplan; c++) d[c] = T[c] - w[c];
+    const double mag = seqnorm(d, nplan);
+    const double sm = eps < mag ? eps : mag;
+    bool reach = true;
+    for (int c = 0; c < nplan; c++) {
+      q[c] = w[c] + (d[c] / mag) * sm;
+      reach = reach && (q[c] == T[c]);
+    }
+    reach = reach || (mag <= eps);
+    if (reach)
+      for (int c = 0; c < nplan; c++) q[c] = T[c];  // a step of at most eps lands on the target
+    if (projecting) return reach ? 2 : 1;
+    bool ok = true;
+    for (int c = 0; c < nplan; c++) ok = ok && (q[c] >= lo[c] && q[c] <= hi[c]);
+    for (int c = 0; c < nplan; c++) d[c] = q[c] - w[c];
+    ok = ok && !(seqnorm(d, nplan) < 1e-8);
+    for (int c = 0; c < nplan; c++) d[c] = T[c] - q[c];
+    ok = ok && !(seqnorm(d, nplan) > mag);
+    return ok ? (reach ? 2 : 1) : 0;
+  };
+  // pass 1: count
+  int count = 0, end = 0;
+  if (act) {
+    for (int s = 0; s < S; s++) {
+      const int r = step();
+      if (r == 0) { end = 1; break; }
+      count++;
+      for (int c = 0; c < nplan; c++) w[c] = q[c];
+      if (r == 2 && !projecting) { end = 1; break; }  // (projecting: arrival is judged after the projection)
+    }
+  }
+  // one reservation per wave
+  int incl = count;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  const int total = __shfl(incl, 63);
+  int base = 0;
+  if (lane == 0 && total > 0) base = atomicAdd(&ctr[RC_EDGES], total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (!act) return;
+  int first = base + incl - count;
+  if (first + count > cd.cap) {  // out of candidate space: the lane waits for the next chunk
+    atomicOr(&ctr[RC_OVERFLOW], 1);
+    // the slots it reserved below the end of the buffer are validated with everything else: give
+    // them a harmless zero-length edge at the lane's current configuration
+    for (int slot = first; slot < cd.cap; slot++) {
+      for (int c = 0; c < nplan; c++) {
+        const double v = ln.C[(int64_t)c * L + l];
+        cd.A[(int64_t)slot * nplan + c] = v;
+        cd.B[(int64_t)slot * nplan + c] = v;
+      }
+      cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
+    }
+    count = 0; end = 0; first = 0;
+  }
+  ln.gfirst[l] = first;
+  ln.gcount[l] = count;
+  ln.gend[l] = (uint8_t)end;
+  if (count == 0) {
+    if (end) ln.act[l] = 0;  // stopped by a rule before emitting anything
+    return;
+  }
+  atomicAdd(&ctr[RC_ACTIVE], 1);
+  // pass 2: write
+  for (int c = 0; c < nplan; c++) w[c] = ln.C[(int64_t)c * L + l];
+  const int lvl0 = ln.cnt[l];
+  for (int s = 0; s < count; s++) {
+    const int r = step();
+    const int slot = first + s;
+    for (int c = 0; c < nplan; c++) {
+      cd.A[(int64_t)slot * nplan + c] = w[c];
+      cd.B[(int64_t)slot * nplan + c] = q[c];
+    }
+    cd.lane[slot] = l;
+    cd.level[slot] = lvl0 + s;
+    cd.rule[slot] = 1;
+    cd.reach[slot] = (r == 2) ? 1 : 0;
+    for (int c = 0; c < nplan; c++) w[c] = q[c];
+  }
+}
+
+// projecting constraint: planning columns -> full qpos rows for k_pose_apply
+__global__ void __launch_bounds__(256)
+k_rrt_fullrows(int E, int nplan, int nq, const int *__restrict__ qidx, const double *__restrict__ qbase, RrtCand cd,
+               double *__restrict__ Fold, double *__restrict__ Fnew) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  for (int k = 0; k < nq; k++) { Fold[(int64_t)i * nq + k] = qbase[k]; Fnew[(int64_t)i * nq + k] = qbase[k]; }
+  for (int c = 0; c < nplan; c++) {
+    Fold[(int64_t)i * nq + qidx[c]] = cd.A[(int64_t)i * nplan + c];
+    Fnew[(int64_t)i * nq + qidx[c]] = cd.B[(int64_t)i * nplan + c];
+  }
+}
+
+// after the projection: B <- projected planning columns; rules of _constrained_extend
+__global__ void __launch_bounds__(256)
+k_rrt_after_pose(int E, int L, int nplan, int nq, const int *__restrict__ qidx, const double *__restrict__ qbase,
+                 const uint8_t *__restrict__ isplan, const double *__restrict__ lo, const double *__restrict__ hi,
+                 const double *__restrict__ Tgt, RrtCand cd, const double *__restrict__ Fout,
+                 const uint8_t *__restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  const int l = cd.lane[i];
+  bool good = ok[i] != 0;
+  for (int k = 0; k < nq; k++)  // a projection that moves a joint outside the planning set is rejected
+    if (!isplan[k]) good = good && (Fout[(int64_t)i * nq + k] == qbase[k]);
+  double q[kRrtMaxPlan], d[kRrtMaxPlan];
+  bool reach = true;
+  for (int c = 0; c < nplan; c++) {
+    q[c] = Fout[(int64_t)i * nq + qidx[c]];
+    reach = reach && (q[c] == Tgt[(int64_t)c * L + l]);
+    good = good && (q[c] >= lo[c] && q[c] <= hi[c]);
+  }
+  for (int c = 0; c < nplan; c++) d[c] = q[c] - cd.A[(int64_t)i * nplan + c];
+  good = good && !(seqnorm(d, nplan) < 1e-8);
+  for (int c = 0; c < nplan; c++) d[c] = Tgt[(int64_t)c * L + l] - q[c];
+  const double after = seqnorm(d, nplan);
+  for (int c = 0; c < nplan; c++) d[c] = Tgt[(int64_t)c * L + l] - cd.A[(int64_t)i * nplan + c];
+  good = good && !(after > seqnorm(d, nplan));
+  if (good)
+    for (int c = 0; c < nplan; c++) cd.B[(int64_t)i * nplan + c] = q[c];
+  else  // keep a harmless edge for the validation launch
+    for (int c = 0; c < nplan; c++) cd.B[(int64_t)i * nplan + c] = cd.A[(int64_t)i * nplan + c];
+  cd.rule[i] = good ? 1 : 0;
+  cd.reach[i] = (good && reach) ? 1 : 0;
+}
+
+// accept the leading valid candidates of every lane
+__global__ void __launch_bounds__(256)
+k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restrict__ ctr) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L || !ln.act[l]) return;
+  const int n = ln.gcount[l];
+  if (n == 0) return;  // waiting for candidate space
+  const int f = ln.gfirst[l];
+  int a = 0;
+  bool arrived = false;
+  while (a < n && cd.valid[f + a] && cd.rule[f + a]) {
+    arrived = cd.reach[f + a] != 0;
+    a++;
+  }
+  if (a > 0) {
+    const int at = atomicAdd(&ctr[RC_ACC], a);
+    if (at + a > acc.cap) {
+      atomicOr(&ctr[RC_OVERFLOW], 2);
+      ln.act[l] = 0;
+      return;
+    }
+    const int lvl0 = ln.cnt[l];
+    for (int s = 0; s < a; s++) {
+      for (int c = 0; c < nplan; c++) acc.Q[(int64_t)(at + s) * nplan + c] = cd.B[(int64_t)(f + s) * nplan + c];
+      acc.lane[at + s] = l;
+      acc.level[at + s] = lvl0 + s;
+    }
+    for (int c = 0; c < nplan; c++) ln.C[(int64_t)c * L + l] = cd.B[(int64_t)(f + a - 1) * nplan + c];
+    ln.cnt[l] = lvl0 + a;
+  }
+  if (a < n || ln.gend[l] || arrived) ln.act[l] = 0;
+}
+
+// exclusive scan of cnt[L] by one workgroup (deterministic node order: lanes ascending)
+__global__ void __launch_bounds__(1024)
+k_rrt_scan(int L, const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int *__restrict__ total) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int t = threadIdx.x;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < L; base += 1024) {
+    const int i = base + t;
+    const int v = i < L ? cnt[i] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int add = t >= o ? part[t - o] : 0;
+      __syncthreads();
+      part[t] += add;
+      __syncthreads();
+    }
+    if (i < L) off[i] = carry + part[t] - v;
+    __syncthreads();
+    if (t == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (t == 0) *total = carry;
+}
+
+// place the accepted nodes in (lane, level) order into this rank's pending slab of the tree
+__global__ void __launch_bounds__(256)
+k_rrt_place(int nacc, int nplan, RrtAcc acc, const int32_t *__restrict__ off, const int32_t *__restrict__ near,
+            double *__restrict__ pendQ, int32_t *__restrict__ pendpar) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nacc) return;
+  const int l = acc.lane[i], lv = acc.level[i];
+  const int pos = off[l] + lv;
+  for (int c = 0; c < nplan; c++) pendQ[(int64_t)pos * nplan + c] = acc.Q[(int64_t)i * nplan + c];
+  pendpar[pos] = lv == 0 ? near[l] : -pos;  // >= 0: node id in the tree; < 0: -1 - (pending index pos - 1)
+}
+
+__global__ void __launch_bounds__(256)
+k_rrt_finish(int L, int nplan, RrtLanes ln, int32_t *__restrict__ ref, double *__restrict__ reached) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const int n = ln.cnt[l];
+  ref[l] = n > 0 ? -1 - (ln.off[l] + n - 1) : ln.near[l];
+  if (reached)
+    for (int c = 0; c < nplan; c++) reached[(int64_t)c * L + l] = ln.C[(int64_t)c * L + l];
+}
+
+__global__ void __launch_bounds__(256)
+k_rrt_connect(int L, int nplan, RrtLanes ln, int *__restrict__ ctr) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L || !ln.on[l]) return;
+  bool eq = true;
+  for (int c = 0; c < nplan; c++) eq = eq && (ln.RA[(int64_t)c * L + l] == ln.C[(int64_t)c * L + l]);
+  if (eq) atomicMin(&ctr[RC_CONN], l);
+}
+
+// this rank's exchange header: [new nodes of the tree that grew, of the other tree, connecting lane
+// (INT_MAX: none), its reference in the start tree, in the goal tree, 0, 0, 0]
+__global__ void k_rrt_header(RrtLanes ln, const int *__restrict__ ctr, int grow, int stop, int *__restrict__ head) {
+  const int l = ctr[RC_CONN];
+  head[0] = ctr[RC_NEWA];
+  head[1] = ctr[RC_NEWB];
+  head[2] = l;
+  head[3] = head[4] = 0;
+  if (l != 0x7fffffff) {  // [3]: the lane's node in the start tree, [4]: in the goal tree
+    head[3] = grow == 0 ? ln.refA[l] : ln.refB[l];
+    head[4] = grow == 0 ? ln.refB[l] : ln.refA[l];
+  }
+  head[5] = stop;  // this rank asks for the search to end (time limit): honoured by all ranks together
+  head[6] = head[7] = 0;
+}
+
+__global__ void k_rrt_round_init(int *__restrict__ ctr, int32_t *__restrict__ first, int nfirst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < RC_SIZE) ctr[i] = i == RC_CONN ? 0x7fffffff : 0;
+  if (i < nfirst) first[i] = 0x7fffffff;
+}
+
+// append one rank's slab to a tree: rows [cnt][nplan] AoS -> SoA [nplan][cap] at base
+__global__ void __launch_bounds__(256)
+k_rrt_merge(int cnt, int nplan, const double *__restrict__ rows, const int32_t *__restrict__ par, double *__restrict__ Q,
+            int32_t *__restrict__ parent, int64_t cap, int base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  for (int c = 0; c < nplan; c++) Q[(int64_t)c * cap + base + i] = rows[(int64_t)i * nplan + c];
+  const int p = par[i];
+  parent[base + i] = p >= 0 ? p : base + (-1 - p);
+}
+
+// root-ward walk from `node`, rows written leaf first
+__global__ void k_rrt_walk(const double *__restrict__ Q, const int32_t *__restrict__ parent, int64_t cap, int nplan, int node,
+                           int maxlen, double *__restrict__ out, int *__restrict__ len) {
+  int n = 0;
+  while (node >= 0 && n < maxlen) {
+    for (int c = 0; c < nplan; c++) out[(int64_t)n * nplan + c] = Q[(int64_t)c * cap + node];
+    node = parent[node];
+    n++;
+  }
+  *len = node >= 0 ? -1 : n;
+}
+
+// ----------------------------------------------------------------------------- RCCL, loaded on demand
+struct Id128 { char b[128]; };  // ncclUniqueId
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, Id128, int) = nullptr;  // the id travels by value
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+
+Rccl *rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (r.lib) {
+      r.GetUniqueId = (int (*)(void *))dlsym(r.lib, "ncclGetUniqueId");
+      r.CommInitRank = (int (*)(void **, int, Id128, int))dlsym(r.lib, "ncclCommInitRank");
+      r.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(r.lib, "ncclAllGather");
+      r.CommDestroy = (int (*)(void *))dlsym(r.lib, "ncclCommDestroy");
+      r.GetErrorString = (const char *(*)(int))dlsym(r.lib, "ncclGetErrorString");
+      if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { dlclose(r.lib); r.lib = nullptr; }
+    }
+  }
+  return r.lib ? &r : nullptr;
+}
+
+constexpr int kNcclInt8 = 0;  // ncclInt8 / ncclChar
+
+}  // namespace
+
+struct mjpl_rrt {
+  mjpl_engine *e = nullptr;
+  mjpl_pose *pose = nullptr;
+  int nplan = 0, nq = 0, L = 0;
+  int64_t cap = 0;
+  double eps = 0.05, istep = 0, pgoal = 0.05;
+  uint64_t seed = 0;
+  int ngoal = 0, round = 0;
+  int n[2] = {0, 0};
+  double *d_Q[2] = {nullptr, nullptr};
+  int32_t *d_parent[2] = {nullptr, nullptr};
+  double *d_lo = nullptr, *d_hi = nullptr, *d_qinit = nullptr, *d_qbase = nullptr;
+  int *d_qidx = nullptr;
+  uint8_t *d_isplan = nullptr;
+  RrtLanes ln{};
+  RrtCand cd{};
+  RrtAcc acc{};
+  int32_t *d_first = nullptr;
+  int first_cap = 1;
+  double *d_pendQ[2] = {nullptr, nullptr};
+  int32_t *d_pendpar[2] = {nullptr, nullptr};
+  int pendcap = 0;
+  double *d_F[3] = {nullptr, nullptr, nullptr};  // full-row buffers of the projection
+  uint8_t *d_pok = nullptr;
+  int *d_ctr = nullptr, *h_ctr = nullptr;
+  // exchange
+  int *d_heads = nullptr, *h_heads = nullptr;
+  char *d_gather = nullptr;
+  size_t gather_bytes = 0;
+  double *d_path = nullptr;
+  std::vector<void *> owned;
+  // result of the last successful round
+  int conn_start = -1, conn_goal = -1;
+};
+
+namespace {
+
+template <class T>
+int rrt_alloc(mjpl_rrt *r, T **p, size_t count) {
+  void *v = nullptr;
+  HIP_TRY(hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T)));
+  r->owned.push_back(v);
+  *p = (T *)v;
+  return MJPL_OK;
+}
+
+inline unsigned rgrid(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+int rrt_read_ctr(mjpl_rrt *r) {
+  HIP_TRY(hipMemcpyAsync(r->h_ctr, r->d_ctr, RC_SIZE * sizeof(int), hipMemcpyDeviceToHost, r->e->stream));
+  HIP_TRY(hipStreamSynchronize(r->e->stream));
+  return MJPL_OK;
+}
+
+// one extension of tree `t` towards the targets Tgt ([nplan][L]); `second`: the connect phase
+int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
+  mjpl_engine *e = r->e;
+  hipStream_t st = e->stream;
+  const int L = r->L, nplan = r->nplan;
+  int rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, Tgt, L, r->ln.near, nullptr);
+  if (rc != MJPL_OK) return rc;
+  hipLaunchKernelGGL(k_rrt_begin, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->d_Q[t], r->cap, r->ln, r->d_first, Tgt,
+                     second);
+  HIP_TRY(hipMemsetAsync(r->d_ctr + RC_ACC, 0, sizeof(int), st));
+  const bool projecting = r->pose != nullptr;
+  int S = projecting ? 1 : 4;
+  for (;;) {
+    HIP_TRY(hipMemsetAsync(r->d_ctr + RC_EDGES, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(r->d_ctr + RC_ACTIVE, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_rrt_gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, projecting ? 1 : 0, r->d_lo, r->d_hi,
+                       Tgt, r->ln, r->cd, r->d_ctr);
+    if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
+    const int E = r->h_ctr[RC_EDGES];
+    if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
+    if (E == 0) {
+      if (r->h_ctr[RC_OVERFLOW] & 1) {  // every waiting lane was refused: S is too large for the space left
+        HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
+        if (S == 1) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer too small for one step per lane");
+        S = 1;
+        continue;
+      }
+      break;
+    }
+    if (r->h_ctr[RC_OVERFLOW] & 1) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
+    if (projecting) {
+      hipLaunchKernelGGL(k_rrt_fullrows, dim3(rgrid(E)), dim3(256), 0, st, E, nplan, r->nq, r->d_qidx, r->d_qbase, r->cd, r->d_F[0],
+                         r->d_F[1]);
+      rc = mjpl_pose_apply_dev(r->pose, r->d_F[0], r->d_F[1], E, r->d_F[2], r->d_pok, nullptr);
+      if (rc != MJPL_OK) return rc;
+      hipLaunchKernelGGL(k_rrt_after_pose, dim3(rgrid(E)), dim3(256), 0, st, E, L, nplan, r->nq, r->d_qidx, r->d_qbase, r->d_isplan,
+                         r->d_lo, r->d_hi, Tgt, r->cd, r->d_F[2], r->d_pok);
+    }
+    if (r->istep > 0)
+      rc = launch_edges(e, r->cd.A, r->cd.B, E, r->istep, MJPL_AOS, 0, r->cd.valid, nullptr);
+    else
+      rc = launch_configs(e, r->cd.B, E, MJPL_AOS, r->cd.valid, nullptr);
+    if (rc != MJPL_OK) return rc;
+    hipLaunchKernelGGL(k_rrt_accept, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->cd, r->acc, r->d_ctr);
+    // chunk sizes double: a chain of n steps costs O(log n) chunks and at most 2x its own checks
+    if (!projecting && S < 64) {
+      const int64_t room = (int64_t)r->cd.cap / std::max(1, r->h_ctr[RC_ACTIVE]);
+      S = (int)std::max<int64_t>(1, std::min<int64_t>(2 * S, room));
+    }
+  }
+  // node order of the extension: lanes ascending, levels ascending within a lane
+  hipLaunchKernelGGL(k_rrt_scan, dim3(1), dim3(1024), 0, st, L, r->ln.cnt, r->ln.off, r->d_ctr + (t == (r->round - 1) % 2 ? RC_NEWA : RC_NEWB));
+  if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
+  const int nacc = r->h_ctr[RC_ACC];
+  *nnew = nacc;
+  if (nacc > r->pendcap) return fail(MJPL_E_CAPACITY, "rrt: %d new nodes in one extension, pending slab holds %d", nacc, r->pendcap);
+  if (nacc > 0)
+    hipLaunchKernelGGL(k_rrt_place, dim3(rgrid(nacc)), dim3(256), 0, st, nacc, nplan, r->acc, r->ln.off, r->ln.near, r->d_pendQ[t],
+                       r->d_pendpar[t]);
+  hipLaunchKernelGGL(k_rrt_finish, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, second ? r->ln.refB : r->ln.refA,
+                     second ? (double *)nullptr : r->ln.RA);
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mjpl_comm_unique_id(void *id128) {
+  if (!id128) return fail(MJPL_E_ARG, "mjpl_comm_unique_id: NULL");
+  Rccl *nc = rccl();
+  if (!nc) return fail(MJPL_E_HIP, "librccl.so could not be loaded");
+  const int rc = nc->GetUniqueId(id128);
+  if (rc != 0) return fail(MJPL_E_HIP, "ncclGetUniqueId failed: %s", nc->GetErrorString ? nc->GetErrorString(rc) : "?");
+  return MJPL_OK;
+}
+
+int mjpl_comm_init(mjpl_engine *e, const void *id128, int32_t rank, int32_t world) {
+  if (!e || !id128 || world < 1 || rank < 0 || rank >= world) return fail(MJPL_E_ARG, "mjpl_comm_init: bad argument");
+  if (e->comm) return fail(MJPL_E_ARG, "mjpl_comm_init: the engine already has a communicator");
+  Rccl *nc = rccl();
+  if (!nc) return fail(MJPL_E_HIP, "librccl.so could not be loaded");
+  HIP_TRY(hipSetDevice(e->device));
+  Id128 id;
+  memcpy(id.b, id128, sizeof(id.b));
+  void *comm = nullptr;
+  const int rc = nc->CommInitRank(&comm, world, id, rank);
+  if (rc != 0) return fail(MJPL_E_HIP, "ncclCommInitRank failed: %s", nc->GetErrorString ? nc->GetErrorString(rc) : "?");
+  e->comm = comm;
+  e->comm_rank = rank;
+  e->comm_world = world;
+  return MJPL_OK;
+}
+
+int mjpl_comm_destroy(mjpl_engine *e) {
+  if (!e) return fail(MJPL_E_ARG, "mjpl_comm_destroy: NULL engine");
+  if (e->comm) {
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    Rccl *nc = rccl();
+    if (nc) nc->CommDestroy(e->comm);
+    e->comm = nullptr;
+    e->comm_rank = 0;
+    e->comm_world = 1;
+  }
+  return MJPL_OK;
+}
+
+int mjpl_allgather_dev(mjpl_engine *e, const void *dsend, void *drecv, size_t bytes_per_rank) {
+  if (!e || (bytes_per_rank && (!dsend || !drecv))) return fail(MJPL_E_ARG, "mjpl_allgather_dev: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->comm) {  // no communicator: a world of one
+    if (dsend != drecv && bytes_per_rank)
+      HIP_TRY(hipMemcpyAsync(drecv, dsend, bytes_per_rank, hipMemcpyDeviceToDevice, e->stream));
+    return MJPL_OK;
+  }
+  Rccl *nc = rccl();
+  const int rc = nc->AllGather(dsend, drecv, bytes_per_rank, kNcclInt8, e->comm, e->stream);
+  if (rc != 0) return fail(MJPL_E_HIP, "ncclAllGather failed: %s", nc->GetErrorString ? nc->GetErrorString(rc) : "?");
+  return MJPL_OK;
+}
+
+void mjpl_rrt_destroy(mjpl_rrt *r) {
+  if (!r) return;
+  (void)hipSetDevice(r->e->device);
+  (void)hipStreamSynchronize(r->e->stream);
+  for (void *p : r->owned) (void)hipFree(p);
+  if (r->h_ctr) (void)hipHostFree(r->h_ctr);
+  if (r->h_heads) (void)hipHostFree(r->h_heads);
+  if (r->d_gather) (void)hipFree(r->d_gather);
+  delete r;
+}
+
+int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
+  if (!e || !d || !out) return fail(MJPL_E_ARG, "mjpl_rrt_create: NULL argument");
+  *out = nullptr;
+  const int nplan = (int)e->qidx.size();
+  if (nplan < 1 || nplan > kRrtMaxPlan) return fail(MJPL_E_CAPACITY, "rrt: %d planning columns (1..%d supported)", nplan, kRrtMaxPlan);
+  if (d->lanes < 1 || d->capacity < 2 || !d->lo || !d->hi) return fail(MJPL_E_ARG, "mjpl_rrt_create: bad sizes");
+  if (!(d->epsilon > 0.0)) return fail(MJPL_E_ARG, "`epsilon` must be > 0.0");
+  if (!(d->goal_bias >= 0.0 && d->goal_bias <= 1.0)) return fail(MJPL_E_ARG, "`goal_biasing_probability` must be within [0.0, 1.0].");
+  if (d->pose && d->pose->e != e) return fail(MJPL_E_ARG, "the pose handle belongs to another engine");
+  HIP_TRY(hipSetDevice(e->device));
+  std::unique_ptr<mjpl_rrt, void (*)(mjpl_rrt *)> r(new mjpl_rrt(), mjpl_rrt_destroy);
+  r->e = e;
+  r->pose = d->pose;
+  r->nplan = nplan;
+  r->nq = e->m.nq;
+  r->L = d->lanes;
+  r->cap = d->capacity;
+  r->eps = d->epsilon;
+  r->istep = d->interval_step;
+  r->pgoal = d->goal_bias;
+  r->seed = d->seed;
+  const int L = r->L;
+  int rc = MJPL_OK;
+#define RA(ptr, count) if ((rc = rrt_alloc(r.get(), &(ptr), (size_t)(count))) != MJPL_OK) return rc
+  for (int t = 0; t < 2; t++) { RA(r->d_Q[t], (size_t)nplan * r->cap); RA(r->d_parent[t], r->cap); }
+  RA(r->d_lo, nplan); RA(r->d_hi, nplan); RA(r->d_qinit, nplan); RA(r->d_qbase, r->nq); RA(r->d_qidx, nplan); RA(r->d_isplan, r->nq);
+  RA(r->ln.T, (size_t)nplan * L); RA(r->ln.C, (size_t)nplan * L); RA(r->ln.RA, (size_t)nplan * L);
+  RA(r->ln.near, L); RA(r->ln.refA, L); RA(r->ln.refB, L); RA(r->ln.on, L); RA(r->ln.act, L); RA(r->ln.cnt, L); RA(r->ln.off, L);
+  RA(r->ln.gfirst, L); RA(r->ln.gcount, L); RA(r->ln.gend, L); RA(r->ln.goal, L);
+  r->cd.cap = (int)std::min<int64_t>(std::max<int64_t>(4 * (int64_t)L, 1 << 16), (int64_t)1 << 27);
+  RA(r->cd.A, (size_t)r->cd.cap * nplan); RA(r->cd.B, (size_t)r->cd.cap * nplan); RA(r->cd.lane, r->cd.cap); RA(r->cd.level, r->cd.cap);
+  RA(r->cd.valid, r->cd.cap); RA(r->cd.rule, r->cd.cap); RA(r->cd.reach, r->cd.cap);
+  r->pendcap = (int)std::min<int64_t>(r->cap, d->max_new_per_round > 0 ? d->max_new_per_round : std::max<int64_t>(128 * (int64_t)L, 1 << 16));
+  r->acc.cap = r->pendcap;
+  RA(r->acc.Q, (size_t)r->acc.cap * nplan); RA(r->acc.lane, r->acc.cap); RA(r->acc.level, r->acc.cap);
+  for (int t = 0; t < 2; t++) { RA(r->d_pendQ[t], (size_t)r->pendcap * nplan); RA(r->d_pendpar[t], r->pendcap); }
+  if (r->pose) {
+    for (int k = 0; k < 3; k++) RA(r->d_F[k], (size_t)r->cd.cap * r->nq);
+    RA(r->d_pok, r->cd.cap);
+  }
+  RA(r->d_ctr, RC_SIZE); RA(r->d_heads, 8 * 1024); RA(r->d_path, (size_t)nplan * 65536);
+  RA(r->d_first, 1);  // re-allocated by reset for the number of goals
+#undef RA
+  HIP_TRY(hipHostMalloc((void **)&r->h_ctr, RC_SIZE * sizeof(int)));
+  HIP_TRY(hipHostMalloc((void **)&r->h_heads, 8 * 1024 * sizeof(int)));
+  std::vector<uint8_t> isplan(r->nq, 0);
+  for (int c : e->qidx) isplan[c] = 1;
+  HIP_TRY(hipMemcpy(r->d_lo, d->lo, nplan * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(r->d_hi, d->hi, nplan * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(r->d_qbase, e->qbase.data(), r->nq * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(r->d_qidx, e->qidx.data(), nplan * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(r->d_isplan, isplan.data(), r->nq, hipMemcpyHostToDevice));
+  *out = r.release();
+  return MJPL_OK;
+}
+
+int mjpl_rrt_reset(mjpl_rrt *r, const double *q_init, const double *q_goals, int32_t ngoal, uint64_t seed) {
+  if (!r || !q_init || !q_goals || ngoal < 1) return fail(MJPL_E_ARG, "mjpl_rrt_reset: bad argument");
+  if (ngoal >= r->cap) return fail(MJPL_E_CAPACITY, "rrt: more goals than node capacity");
+  mjpl_engine *e = r->e;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int nplan = r->nplan;
+  // start tree: node 0 = q_init.  goal tree: nodes 0..ngoal-1 = the goals (their common parent, the
+  // reference's sink node at +inf, is implicit: parent -1; rrt.py:179-188)
+  std::vector<double> col0((size_t)nplan), colg((size_t)nplan * ngoal);
+  for (int c = 0; c < nplan; c++) {
+    HIP_TRY(hipMemcpy(r->d_Q[0] + (int64_t)c * r->cap, q_init + c, sizeof(double), hipMemcpyHostToDevice));
+    for (int g = 0; g < ngoal; g++) colg[(size_t)c * ngoal + g] = q_goals[(size_t)g * nplan + c];
+    HIP_TRY(hipMemcpy(r->d_Q[1] + (int64_t)c * r->cap, &colg[(size_t)c * ngoal], ngoal * sizeof(double), hipMemcpyHostToDevice));
+  }
+  std::vector<int32_t> minus(ngoal, -1);
+  HIP_TRY(hipMemcpy(r->d_parent[0], minus.data(), sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(r->d_parent[1], minus.data(), ngoal * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(r->d_qinit, q_init, nplan * sizeof(double), hipMemcpyHostToDevice));
+  if (ngoal > r->first_cap) {
+    int rc = rrt_alloc(r, &r->d_first, (size_t)ngoal);
+    if (rc != MJPL_OK) return rc;
+    r->first_cap = ngoal;
+  }
+  r->n[0] = 1;
+  r->n[1] = ngoal;
+  r->ngoal = ngoal;
+  r->round = 0;
+  r->seed = seed;
+  r->conn_start = r->conn_goal = -1;
+  return MJPL_OK;
+}
+
+int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info) {
+  if (!r || !info) return fail(MJPL_E_ARG, "mjpl_rrt_round: NULL argument");
+  if (r->n[0] < 1 || r->n[1] < 1) return fail(MJPL_E_ARG, "mjpl_rrt_round: call mjpl_rrt_reset first");
+  mjpl_engine *e = r->e;
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = e->stream;
+  const int L = r->L, nplan = r->nplan;
+  const int world = e->comm ? e->comm_world : 1, rank = e->comm ? e->comm_rank : 0;
+  r->round++;
+  const int grow = (r->round - 1) % 2, other = 1 - grow;  // tree swap every round (rrt.py:234-235)
+  memset(info, 0, sizeof(*info));
+  info->round = r->round;
+
+  {
+    const int nf = std::max(r->ngoal, 1);
+    hipLaunchKernelGGL(k_rrt_round_init, dim3(rgrid(std::max(nf, (int)RC_SIZE))), dim3(256), 0, st, r->d_ctr, r->d_first, nf);
+  }
+  hipLaunchKernelGGL(k_rrt_sample, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, rrt_key(r->seed, (uint64_t)rank, (uint64_t)r->round), r->pgoal,
+                     grow, r->ngoal, r->d_lo, r->d_hi, r->d_qinit, r->d_Q[1], r->cap, r->ln, r->d_first);
+  int newA = 0, newB = 0;
+  int rc = rrt_extend(r, grow, r->ln.T, 0, &newA);
+  if (rc != MJPL_OK) return rc;
+  rc = rrt_extend(r, other, r->ln.RA, 1, &newB);
+  if (rc != MJPL_OK) return rc;
+  hipLaunchKernelGGL(k_rrt_connect, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->d_ctr);
+  if (world > 1024) return fail(MJPL_E_CAPACITY, "rrt: world size %d not supported", world);
+  // ---- exchange: headers of all ranks, then the new-node slabs padded to the round's largest count
+  hipLaunchKernelGGL(k_rrt_header, dim3(1), dim3(1), 0, st, r->ln, r->d_ctr, grow, request_stop ? 1 : 0,
+                     r->d_heads + 8 * rank);
+  rc = mjpl_allgather_dev(e, r->d_heads + 8 * rank, r->d_heads, 8 * sizeof(int));
+  if (rc != MJPL_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(r->h_heads, r->d_heads, (size_t)world * 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  int maxA = 0, maxB = 0;
+  int64_t totA = 0, totB = 0;
+  for (int k = 0; k < world; k++) {
+    if (r->h_heads[8 * k + 5]) info->stop_requested = 1;
+    maxA = std::max(maxA, r->h_heads[8 * k]);
+    maxB = std::max(maxB, r->h_heads[8 * k + 1]);
+    totA += r->h_heads[8 * k];
+    totB += r->h_heads[8 * k + 1];
+  }
+  if (r->n[grow] + totA > r->cap || r->n[other] + totB > r->cap) return fail(MJPL_E_CAPACITY, "rrt: node capacity %lld exhausted", (long long)r->cap);
+  int win_rank = -1;
+  for (int k = 0; k < world && win_rank < 0; k++)
+    if (r->h_heads[8 * k + 2] != 0x7fffffff) win_rank = k;
+  int baseA_of_winner = 0, baseB_of_winner = 0;
+  for (int pass = 0; pass < 2; pass++) {  // pass 0: the tree that grew; 1: the other
+    const int t = pass == 0 ? grow : other;
+    const int mx = pass == 0 ? maxA : maxB;
+    int base = r->n[t];
+    if (mx > 0) {
+      const size_t rowb = (size_t)mx * nplan * sizeof(double), parb = (size_t)mx * sizeof(int32_t);
+      const char *srcQ = (const char *)r->d_pendQ[t];
+      const char *srcP = (const char *)r->d_pendpar[t];
+      const char *allQ = srcQ, *allP = srcP;
+      if (world > 1 || e->comm) {
+        const size_t need = (size_t)world * (rowb + parb);
+        if (need > r->gather_bytes) {
+          if (r->d_gather) HIP_TRY(hipFree(r->d_gather));
+          r->d_gather = nullptr; r->gather_bytes = 0;
+          HIP_TRY(hipMalloc((void **)&r->d_gather, need));
+          r->gather_bytes = need;
+        }
+        char *gQ = r->d_gather, *gP = r->d_gather + (size_t)world * rowb;
+        if ((rc = mjpl_allgather_dev(e, srcQ, gQ, rowb)) != MJPL_OK) return rc;
+        if ((rc = mjpl_allgather_dev(e, srcP, gP, parb)) != MJPL_OK) return rc;
+        allQ = gQ; allP = gP;
+      }
+      for (int k = 0; k < world; k++) {
+        const int cnt = r->h_heads[8 * k + pass];
+        if (k == win_rank) (pass == 0 ? baseA_of_winner : baseB_of_winner) = base;
+        if (cnt > 0)
+          hipLaunchKernelGGL(k_rrt_merge, dim3(rgrid(cnt)), dim3(256), 0, st, cnt, nplan, (const double *)(allQ + (size_t)k * rowb),
+                             (const int32_t *)(allP + (size_t)k * parb), r->d_Q[t], r->d_parent[t], r->cap, base);
+        base += cnt;
+      }
+    } else if (win_rank >= 0) {
+      (pass == 0 ? baseA_of_winner : baseB_of_winner) = base;
+    }
+    r->n[t] = base;
+  }
+  HIP_TRY(hipGetLastError());
+  info->new_nodes[grow] = (int32_t)totA;
+  info->new_nodes[other] = (int32_t)totB;
+  info->nodes[0] = r->n[0];
+  info->nodes[1] = r->n[1];
+  info->connected = win_rank >= 0 ? 1 : 0;
+  if (win_rank >= 0) {
+    // header refs: [3] in the start tree, [4] in the goal tree; pending indices are relative to
+    // the winner's block of that tree (pass 0 = the tree that grew)
+    const int ra = r->h_heads[8 * win_rank + 3], rb = r->h_heads[8 * win_rank + 4];
+    const int base_start = grow == 0 ? baseA_of_winner : baseB_of_winner;
+    const int base_goal = grow == 0 ? baseB_of_winner : baseA_of_winner;
+    r->conn_start = ra >= 0 ? ra : base_start + (-1 - ra);
+    r->conn_goal = rb >= 0 ? rb : base_goal + (-1 - rb);
+    info->conn_start = r->conn_start;
+    info->conn_goal = r->conn_goal;
+    info->conn_rank = win_rank;
+  }
+  return MJPL_OK;
+}
+
+int mjpl_rrt_path(mjpl_rrt *r, double *path, int32_t maxlen, int32_t *len) {
+  if (!r || !path || !len || maxlen < 2) return fail(MJPL_E_ARG, "mjpl_rrt_path: bad argument");
+  if (r->conn_start < 0) return fail(MJPL_E_ARG, "mjpl_rrt_path: no connection has been found");
+  mjpl_engine *e = r->e;
+  HIP_TRY(hipSetDevice(e->device));
+  const int nplan = r->nplan, room = 65536;
+  std::vector<double> a, b;
+  for (int t = 0; t < 2; t++) {
+    // the junction configuration is in both trees: the goal-tree half starts at its parent
+    hipLaunchKernelGGL(k_rrt_walk, dim3(1), dim3(1), 0, e->stream, r->d_Q[t], r->d_parent[t], r->cap, nplan,
+                       t == 0 ? r->conn_start : r->conn_goal, room, r->d_path, r->d_ctr);
+    int n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, r->d_ctr, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (n < 0) return fail(MJPL_E_CAPACITY, "rrt: path longer than %d nodes", room);
+    std::vector<double> &v = t == 0 ? a : b;
+    v.resize((size_t)n * nplan);
+    HIP_TRY(hipMemcpy(v.data(), r->d_path, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  const int na = (int)(a.size() / nplan), nb = (int)(b.size() / nplan);
+  const int total = na + nb - 1;
+  *len = total;
+  if (total > maxlen) return fail(MJPL_E_CAPACITY, "mjpl_rrt_path: the path has %d waypoints, the buffer holds %d", total, maxlen);
+  for (int i = 0; i < na; i++) memcpy(path + (size_t)i * nplan, &a[(size_t)(na - 1 - i) * nplan], nplan * sizeof(double));
+  for (int i = 1; i < nb; i++) memcpy(path + (size_t)(na + i - 1) * nplan, &b[(size_t)i * nplan], nplan * sizeof(double));
+  return MJPL_OK;
+}
+
+int mjpl_rrt_get_tree(mjpl_rrt *r, int32_t tree, double *Q, int32_t *parent, int64_t maxn, int64_t *n) {
+  if (!r || tree < 0 || tree > 1 || !n) return fail(MJPL_E_ARG, "mjpl_rrt_get_tree: bad argument");
+  mjpl_engine *e = r->e;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *n = r->n[tree];
+  if (!Q && !parent) return MJPL_OK;
+  if (maxn < r->n[tree]) return fail(MJPL_E_CAPACITY, "mjpl_rrt_get_tree: %d nodes, the buffers hold %lld", r->n[tree], (long long)maxn);
+  const int cnt = r->n[tree];
+  if (Q) {  // rows [n][nplan]
+    std::vector<double> col(cnt);
+    for (int c = 0; c < r->nplan; c++) {
+      HIP_TRY(hipMemcpy(col.data(), r->d_Q[tree] + (int64_t)c * r->cap, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < cnt; i++) Q[(size_t)i * r->nplan + c] = col[i];
+    }
+  }
+  if (parent) HIP_TRY(hipMemcpy(parent, r->d_parent[tree], (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return MJPL_OK;
+}
+
+// the lanes of the most recent round (tests): targets [L][nplan], on flags
+int mjpl_rrt_get_lanes(mjpl_rrt *r, double *targets, uint8_t *on) {
+  if (!r) return fail(MJPL_E_ARG, "mjpl_rrt_get_lanes: NULL");
+  mjpl_engine *e = r->e;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (targets) {
+    std::vector<double> col(r->L);
+    for (int c = 0; c < r->nplan; c++) {
+      HIP_TRY(hipMemcpy(col.data(), r->ln.T + (int64_t)c * r->L, (size_t)r->L * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < r->L; i++) targets[(size_t)i * r->nplan + c] = col[i];
+    }
+  }
+  if (on) HIP_TRY(hipMemcpy(on, r->ln.on, (size_t)r->L, hipMemcpyDeviceToHost));
+  return MJPL_OK;
+}
+
+}  // extern "C"

@@ -79,6 +79,21 @@ class IKDesc(C.Structure):
     ]
 
 
+class RrtDesc(C.Structure):
+    _fields_ = [
+        ("lanes", C.c_int32), ("capacity", C.c_int64), ("epsilon", C.c_double), ("interval_step", C.c_double),
+        ("goal_bias", C.c_double), ("seed", C.c_uint64), ("lo", _F64P), ("hi", _F64P), ("pose", C.c_void_p),
+        ("max_new_per_round", C.c_int64),
+    ]
+
+
+class RrtRoundInfo(C.Structure):
+    _fields_ = [
+        ("round", C.c_int32), ("new_nodes", C.c_int32 * 2), ("nodes", C.c_int32 * 2), ("connected", C.c_int32),
+        ("conn_start", C.c_int32), ("conn_goal", C.c_int32), ("conn_rank", C.c_int32), ("stop_requested", C.c_int32),
+    ]
+
+
 # every symbol include/mjpl_hip.h declares: (restype, argtypes)
 _VP = C.c_void_p
 ABI = {
@@ -121,6 +136,17 @@ ABI = {
     "mjpl_pose_valid_dev": (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, _VP]),
     "mjpl_ik_solve": (C.c_int, [_VP, C.POINTER(IKDesc), _F64P, C.c_int64, _F64P, _U8P, _I32P, _F64P]),
     "mjpl_ik_solve_dev": (C.c_int, [_VP, C.POINTER(IKDesc), _VP, C.c_int64, _VP, _VP, _VP, _VP]),
+    "mjpl_rrt_create": (C.c_int, [_VP, C.POINTER(RrtDesc), C.POINTER(_VP)]),
+    "mjpl_rrt_destroy": (None, [_VP]),
+    "mjpl_rrt_reset": (C.c_int, [_VP, _F64P, _F64P, C.c_int32, C.c_uint64]),
+    "mjpl_rrt_round": (C.c_int, [_VP, C.c_int32, C.POINTER(RrtRoundInfo)]),
+    "mjpl_rrt_path": (C.c_int, [_VP, _F64P, C.c_int32, _I32P]),
+    "mjpl_rrt_get_tree": (C.c_int, [_VP, C.c_int32, _F64P, _I32P, C.c_int64, C.POINTER(C.c_int64)]),
+    "mjpl_rrt_get_lanes": (C.c_int, [_VP, _F64P, _U8P]),
+    "mjpl_comm_unique_id": (C.c_int, [_VP]),
+    "mjpl_comm_init": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
+    "mjpl_comm_destroy": (C.c_int, [_VP]),
+    "mjpl_allgather_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     "mjpl_device_count": (C.c_int, []),
     "mjpl_last_error": (C.c_char_p, []),
     "mjpl_version": (C.c_char_p, []),
@@ -324,6 +350,18 @@ class Engine:
         self._ok(self.lib.mjpl_check_edges_dev(self.h, dQA, dQB, n, float(step_dist), layout, flags,
                                                dvalid, dfirst_bad))
 
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """RCCL communicator for the frontier planner's exchange (one per engine)."""
+        if len(unique_id) != 128:
+            raise ValueError("a ncclUniqueId is 128 bytes")
+        self._ok(self.lib.mjpl_comm_init(self.h, C.create_string_buffer(unique_id, 128), rank, world))
+
+    def comm_destroy(self):
+        self._ok(self.lib.mjpl_comm_destroy(self.h))
+
+    def allgather_dev(self, dsend, drecv, nbytes_per_rank: int):
+        self._ok(self.lib.mjpl_allgather_dev(self.h, dsend, drecv, nbytes_per_rank))
+
     def take_status(self) -> int:
         """Sticky status of the device-pointer edge launches since the last take (0 or
         MJPL_E_NONFINITE = -7); synchronises."""
@@ -474,3 +512,83 @@ class PoseProjector:
 
     def apply_dev(self, dQ_old, dQ, n, dQ_out, dok, diters=None):
         self.eng._ok(self.eng.lib.mjpl_pose_apply_dev(self.h, dQ_old, dQ, n, dQ_out, dok, diters))
+
+
+class DeviceRRT:
+    """``mjpl_rrt`` handle: both trees of a frontier bi-RRT resident in HBM (include/mjpl_hip.h).
+    Batches are over the engine's planning columns, so call ``Engine.set_planning`` first."""
+
+    def __init__(self, eng: Engine, lanes: int, capacity: int, lo, hi, epsilon=0.05, interval_step=None,
+                 goal_bias=0.05, seed=0, pose: PoseProjector | None = None, max_new_per_round=0):
+        self.eng, self.nplan, self.lanes = eng, eng.nplan, int(lanes)
+        lo, hi = _f64(lo), _f64(hi)
+        if lo.shape != (self.nplan,) or hi.shape != (self.nplan,):
+            raise ValueError("lo / hi must have one entry per planning column")
+        d = RrtDesc()
+        d.lanes, d.capacity, d.epsilon = int(lanes), int(capacity), float(epsilon)
+        d.interval_step = float(interval_step) if interval_step else 0.0
+        d.goal_bias, d.seed = float(goal_bias), int(seed) & (2**64 - 1)
+        d.lo, d.hi = lo.ctypes.data_as(_F64P), hi.ctypes.data_as(_F64P)
+        d.pose = pose.h if pose is not None else None
+        d.max_new_per_round = int(max_new_per_round)
+        self._pose = pose  # keep the handle alive
+        self.h = None
+        h = _VP()
+        eng._ok(eng.lib.mjpl_rrt_create(eng.h, C.byref(d), C.byref(h)))
+        self.h = h
+        eng._projectors.add(self)  # closed with (before) its engine
+
+    def close(self):
+        if self.h and self.eng.h:
+            self.eng.lib.mjpl_rrt_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, q_init, q_goals, seed: int):
+        q_init, q_goals = _f64(q_init), _f64(np.atleast_2d(q_goals))
+        if q_init.shape != (self.nplan,) or q_goals.shape[1] != self.nplan:
+            raise ValueError("configurations must hold the planning columns")
+        self.eng._ok(self.eng.lib.mjpl_rrt_reset(self.h, q_init.ctypes.data_as(_F64P), q_goals.ctypes.data_as(_F64P),
+                                                 len(q_goals), int(seed) & (2**64 - 1)))
+
+    def round(self, request_stop: bool = False) -> RrtRoundInfo:
+        info = RrtRoundInfo()
+        self.eng._ok(self.eng.lib.mjpl_rrt_round(self.h, 1 if request_stop else 0, C.byref(info)))
+        return info
+
+    def path(self, maxlen: int = 65536) -> np.ndarray:
+        out = np.empty((maxlen, self.nplan))
+        n = C.c_int32(0)
+        self.eng._ok(self.eng.lib.mjpl_rrt_path(self.h, out.ctypes.data_as(_F64P), maxlen, C.byref(n)))
+        return out[: n.value].copy()
+
+    def tree(self, t: int):
+        """-> (Q [n, nplan], parent int32[n]) of tree t (0 = start, 1 = goal)"""
+        n = C.c_int64(0)
+        self.eng._ok(self.eng.lib.mjpl_rrt_get_tree(self.h, t, None, None, 0, C.byref(n)))
+        Q = np.empty((n.value, self.nplan))
+        par = np.empty(n.value, np.int32)
+        self.eng._ok(self.eng.lib.mjpl_rrt_get_tree(self.h, t, Q.ctypes.data_as(_F64P), par.ctypes.data_as(_I32P), n.value,
+                                                    C.byref(n)))
+        return Q, par
+
+    def lanes_state(self):
+        T = np.empty((self.lanes, self.nplan))
+        on = np.empty(self.lanes, np.uint8)
+        self.eng._ok(self.eng.lib.mjpl_rrt_get_lanes(self.h, T.ctypes.data_as(_F64P), on.ctypes.data_as(_U8P)))
+        return T, on.astype(bool)
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: 128 bytes for rank 0 to hand to the other ranks."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.mjpl_comm_unique_id(buf)
+    if rc != 0:
+        raise MjplError(rc, lib.mjpl_last_error().decode())
+    return buf.raw

@@ -9,9 +9,10 @@ from . import utils as _utils
 
 RRT = _rrt.RRT
 ParallelBiRRT, EdgeValidator, HipEdgeValidator = _prrt.ParallelBiRRT, _prrt.EdgeValidator, _prrt.HipEdgeValidator
+DeviceBiRRT = _prrt.DeviceBiRRT
 Node, Tree = _tree.Node, _tree.Tree
 cartesian_plan = _cart.cartesian_plan
 smooth_path, path_length = _utils.smooth_path, _utils.path_length
 
-__all__ = ["RRT", "ParallelBiRRT", "EdgeValidator", "HipEdgeValidator", "Node", "Tree", "cartesian_plan",
+__all__ = ["RRT", "DeviceBiRRT", "ParallelBiRRT", "EdgeValidator", "HipEdgeValidator", "Node", "Tree", "cartesian_plan",
            "smooth_path", "path_length"]

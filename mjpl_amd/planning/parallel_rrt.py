@@ -1,17 +1,28 @@
-"""Frontier-sharded bi-directional RRT (BASELINE config 4).
+"""Frontier-sharded bi-directional RRT (BASELINE configs[3]).
 
-The reference grows its two trees one candidate edge at a time (rrt.py:195-235,
-planning/utils.py:139-164).  Here every rank draws its own batch of samples per round, runs
-the reference's extend loop on all of its lanes at once -- each step of every lane is one
-row of a single batched edge validation -- and the new nodes of all ranks are exchanged once
-per round with ONE all-gather of a fixed-size slab (RCCL over xGMI on GPUs, gloo in the CPU
-tests).  Every rank appends the slabs in rank order, so all ranks hold bit-identical trees
-and node ids; the first connection in (rank, lane) order wins on every rank.
+The reference grows its two trees one candidate edge at a time (rrt.py:190-235,
+planning/utils.py:139-164).  Here every rank draws a batch of samples per round, runs the
+reference's extend loop on all of its lanes at once, and the new nodes of all ranks are exchanged
+once per round with one all-gather of a padded slab; every rank appends the slabs in rank order,
+so all ranks hold bit-identical trees and node ids and the first connection in (rank, lane) order
+wins everywhere.
 
-Per-edge accept/stop rules are those of ``_constrained_extend``: the stepped configuration is
-first projected if the validator offers ``project`` (PoseConstraint, batched on the GPU), then
-the lane stops when the step is invalid, when it moves less than 1e-8, when it does not
-approach the target, or when the interval check fails.
+Two flavours of the SAME algorithm (DESIGN.md section 7 states it):
+
+* :class:`DeviceBiRRT` -- the product: trees, lanes and candidates live in HBM
+  (``mjpl_rrt_*`` in include/mjpl_hip.h), the exchange is ``ncclAllGather`` called from the library
+  on the engine's stream (RCCL over xGMI); the host only ferries the 128-byte ncclUniqueId.
+* :class:`ParallelBiRRT` -- a NumPy restatement with any :class:`EdgeValidator` behind it (the CPU
+  oracle in the tests) and ``torch.distributed`` (gloo) for the exchange: what the GPU tests compare
+  whole trees against, and what the world-size-2 CPU test runs.
+
+Per-step rules are those of ``_constrained_extend``: a step of at most ``epsilon`` towards the
+target (a step that gets within ``epsilon`` lands on the target), projected first if a
+PoseConstraint is present (constraint order of examples/franka_constrained_move_to_pose.py:60-64),
+then joint limits; the lane stops when the step is invalid, moves less than 1e-8, does not
+approach the target, or fails the collision check (endpoint + interval waypoints).  Goals are the
+roots of the goal tree (the reference's sink node, rrt.py:179-188, is implicit), so
+``plan_to_configs`` / ``plan_to_poses`` work as in the reference.
 """
 from __future__ import annotations
 
@@ -21,18 +32,89 @@ import numpy as np
 
 from .. import utils as _utils
 
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+INT_MAX = 0x7FFFFFFF
+
+
+def _sm64(z):
+    """splitmix64 finaliser on uint64 arrays (wraps modulo 2^64), as mjpl_rrt.h:sm64."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(z, dtype=np.uint64) + _GOLD)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def rrt_key(seed: int, rank: int, rnd: int) -> np.uint64:
+    s = _sm64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF))
+    return _sm64(s ^ _sm64(np.uint64(((rank << 40) ^ rnd) & 0xFFFFFFFFFFFFFFFF)))
+
+
+def rrt_u01(key, ctr) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = _sm64(np.uint64(key) + np.asarray(ctr, dtype=np.uint64) * _GOLD)
+    return (x >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+
+
+def sample_targets(key, lanes: int, lo, hi, p_goal: float, grow: int, q_init, goals):
+    """Targets of one round: (T [L, n], on bool[L]).  Lane l uses counters l * (n + 2) + {0..n-1}
+    for its columns, + n for the goal-bias draw (biased iff u <= p, rrt.py:197) and + n + 1 for the
+    goal pick (rrt.py:201-203).  Of the biased lanes that share a target only the lowest is on."""
+    n = len(lo)
+    base = np.arange(lanes, dtype=np.uint64) * np.uint64(n + 2)
+    cols = rrt_u01(key, base[:, None] + np.arange(n, dtype=np.uint64)[None, :])
+    T = lo[None, :] + cols * (hi - lo)[None, :]
+    biased = rrt_u01(key, base + np.uint64(n)) <= p_goal
+    on = np.ones(lanes, bool)
+    if biased.any():
+        if grow == 0:
+            g = np.minimum((rrt_u01(key, base + np.uint64(n + 1)) * len(goals)).astype(np.int64), len(goals) - 1)
+            T[biased] = goals[g[biased]]
+        else:
+            g = np.zeros(lanes, np.int64)
+            T[biased] = q_init
+        idx = np.flatnonzero(biased)
+        _, first = np.unique(g[idx], return_index=True)
+        on[idx] = False
+        on[idx[first]] = True
+    return T, on
+
+
+def row_norm(d: np.ndarray) -> np.ndarray:
+    """Row 2-norms with the sequential left-to-right sum the kernels use (mjpl_rrt.h:seqnorm)."""
+    s = np.zeros(len(d))
+    for c in range(d.shape[1]):
+        s = s + d[:, c] * d[:, c]
+    return np.sqrt(s)
+
+
+def nearest(nodes: np.ndarray, targets: np.ndarray) -> np.ndarray:
+    """Index of the node nearest to each target: squared distance summed column by column, ties to
+    the lowest index (k_nearest_part)."""
+    out = np.empty(len(targets), np.int64)
+    for s in range(0, len(targets), 512):
+        t = targets[s:s + 512]
+        d2 = np.zeros((len(t), len(nodes)))
+        for c in range(nodes.shape[1]):
+            diff = nodes[None, :, c] - t[:, None, c]
+            d2 = d2 + diff * diff
+        out[s:s + 512] = np.argmin(d2, axis=1)
+    return out
+
 
 class EdgeValidator:
-    """What the planner needs from a collision backend: ``valid_edges(QA, QB, step)`` over
-    planning columns -> bool[N] (endpoint QB + interior waypoints; ``step=None`` = endpoint only)."""
+    """What the host planner needs from a collision backend: ``valid_edges(QA, QB, step)`` over
+    planning columns -> bool[N] (endpoint QB + interior waypoints; ``step=None`` = endpoint only).
+    An optional ``project(Q_old, Q) -> (Q_projected, ok)`` makes the planner project every step."""
 
     def valid_edges(self, QA: np.ndarray, QB: np.ndarray, step: float | None) -> np.ndarray:
         raise NotImplementedError
 
 
 class HipEdgeValidator(EdgeValidator):
-    """mjpl_amd.CollisionConstraint behind the EdgeValidator interface; also offers the
-    brute-force nearest-neighbour kernel (Tree.nearest_neighbor, planning/tree.py:57-66)."""
+    """mjpl_amd.CollisionConstraint (and optionally a PoseConstraint) behind the EdgeValidator
+    interface, for running the host flavour against the GPU kernels."""
 
     def __init__(self, constraint, qidx, qpos_base, pose_constraint=None):
         self.c = constraint
@@ -57,72 +139,42 @@ class HipEdgeValidator(EdgeValidator):
         return full
 
     def _project(self, Q_old, Q):
-        """Batched PoseConstraint.apply over planning columns (the first constraint of
-        apply_constraints in the reference's constrained planning example,
-        franka_constrained_move_to_pose.py:60-64).  A projection that would move a joint
-        outside the planning set is rejected."""
+        """Batched PoseConstraint.apply over planning columns.  A projection that would move a
+        joint outside the planning set is rejected."""
         out, ok, _ = self.pose.apply_batch(self._full_rows(Q_old), self._full_rows(Q))
         fixed = np.ones(out.shape[1], bool)
         fixed[self.qidx] = False
         ok = ok & np.all(out[:, fixed] == self.qbase[None, fixed], axis=1)
         return out[:, self.qidx], ok
 
-    def nearest(self, nodes: np.ndarray, queries: np.ndarray) -> np.ndarray:
-        """Index of the node nearest to each query (squared Euclidean distance in float64,
-        ties to the lowest index), computed by ``mjpl_nearest_dev``."""
-        eng = self.c.engine
-        self.c._ensure_planning()
-        n, m = len(nodes), len(queries)
-        hn = np.ascontiguousarray(nodes.T)
-        hq = np.ascontiguousarray(queries.T)
-        dn, dq = eng.alloc(hn.nbytes).upload(hn), eng.alloc(hq.nbytes).upload(hq)
-        di = eng.alloc(4 * m)
-        try:
-            eng.nearest_dev(dn.ptr, n, n, dq.ptr, m, di.ptr)
-            return di.download(np.int32, m).astype(np.int64)
-        finally:
-            for b in (dn, dq, di):
-                b.free()
+
+class _Trees:
+    """Start tree (0) and goal tree (1): rows of planning columns + parent ids (-1 = root)."""
+
+    def __init__(self, n):
+        self.Q = [np.empty((1024, n)), np.empty((1024, n))]
+        self.parent = [np.empty(1024, np.int64), np.empty(1024, np.int64)]
+        self.n = [0, 0]
+
+    def append(self, t, rows, parents):
+        k = len(rows)
+        while self.n[t] + k > len(self.Q[t]):
+            self.Q[t] = np.concatenate([self.Q[t], np.empty_like(self.Q[t])])
+            self.parent[t] = np.concatenate([self.parent[t], np.empty_like(self.parent[t])])
+        a = self.n[t]
+        self.Q[t][a:a + k] = rows
+        self.parent[t][a:a + k] = parents
+        self.n[t] += k
+
+    def nodes(self, t):
+        return self.Q[t][: self.n[t]]
 
 
-def _row_norm(d: np.ndarray) -> np.ndarray:
-    return np.sqrt(np.einsum("ij,ij->i", d, d))
+class _PlannerBase:
+    """Argument checks, goal handling and path assembly shared by both flavours."""
 
-
-class _Pending:
-    """This rank's new nodes of the current round, in creation order.  Entry k is referred to
-    as ``-(k + 1)`` until the exchange has given it a global id."""
-
-    def __init__(self):
-        self.rows: list[np.ndarray] = []   # chunks [m, n]
-        self.parents: list[int] = []
-        self.trees: list[int] = []
-        self.keys: list[bytes] = []
-
-    def __len__(self) -> int:
-        return len(self.parents)
-
-    def add(self, rows: np.ndarray, parents: list, tree: int, keys: list) -> None:
-        self.rows.append(rows)
-        self.parents.extend(parents)
-        self.trees.extend([tree] * len(parents))
-        self.keys.extend(keys)
-
-    def slab(self, nrows: int, ncols: int) -> np.ndarray:
-        out = np.zeros((max(nrows, 1), ncols + 2))
-        cnt = len(self)
-        if cnt:
-            out[:cnt, :ncols] = np.concatenate(self.rows)
-            out[:cnt, ncols] = self.parents
-            out[:cnt, ncols + 1] = self.trees
-        return out
-
-
-class ParallelBiRRT:
-    def __init__(self, model, planning_joints: list[str], validator: EdgeValidator, q_template: np.ndarray,
-                 epsilon: float = 0.05, interval_step: float | None = None, seed: int = 0,
-                 goal_biasing_probability: float = 0.05, batch: int = 256, max_rounds: int = 1000,
-                 max_planning_time: float = 10.0, max_new_per_round: int = 1 << 20, group=None):
+    def __init__(self, model, planning_joints, q_template, epsilon, seed, goal_biasing_probability, batch,
+                 max_rounds, max_planning_time):
         if not planning_joints:
             raise ValueError("`planning_joints` cannot be empty.")
         if epsilon <= 0.0:
@@ -132,287 +184,328 @@ class ParallelBiRRT:
         if batch <= 0 or max_rounds <= 0 or max_planning_time <= 0.0:
             raise ValueError("`batch`, `max_rounds` and `max_planning_time` must be > 0")
         self.model = model
+        self.planning_joints = planning_joints
         self.qidx = np.asarray(_utils.qpos_idx(model, planning_joints), dtype=np.int64)
-        self.validator = validator
         self.q_template = np.asarray(q_template, dtype=np.float64).copy()
-        self.eps, self.interval_step = float(epsilon), interval_step
+        self.eps = float(epsilon)
         self.seed, self.p_goal = int(seed), float(goal_biasing_probability)
         self.batch, self.max_rounds, self.max_time = int(batch), int(max_rounds), float(max_planning_time)
-        self.slab_rows = int(max_new_per_round)
         self.lo = np.asarray(model.jnt_range[self.qidx, 0], dtype=np.float64)
         self.hi = np.asarray(model.jnt_range[self.qidx, 1], dtype=np.float64)
-        self.group = group
-        self.gpu_nn_min_nodes = 2048  # below this the host reduction is faster than a launch
         self.rank, self.world = 0, 1
+        self.stats: dict = {}
+
+    # -- to be provided
+    def _valid_ends(self, ends: np.ndarray) -> np.ndarray:
+        raise NotImplementedError
+
+    def _search(self, a: np.ndarray, goals: np.ndarray) -> np.ndarray | None:
+        """-> path rows over planning columns (start ... goal) or None"""
+        raise NotImplementedError
+
+    # -- the reference's entry points (rrt.py:69-139)
+    def plan_to_config(self, q_init: np.ndarray, q_goal: np.ndarray) -> list[np.ndarray]:
+        return self.plan_to_configs(q_init, [q_goal])
+
+    def plan_to_pose(self, q_init, pose, site: str, solver=None) -> list[np.ndarray]:
+        return self.plan_to_poses(q_init, [pose], site, solver)
+
+    def plan_to_poses(self, q_init, poses, site: str, solver=None) -> list[np.ndarray]:
+        """IK for every pose, then plan to whatever configurations came back (rrt.py:106-139)."""
+        if solver is None:
+            solver = self._default_solver()
+        configs = [q for p in poses for q in solver.solve_ik(p, site, q_init_guess=q_init)]
+        configs = [q for q in configs if self._valid_ends(np.asarray(q, float)[None, self.qidx]).all()]
+        return [] if not configs else self.plan_to_configs(q_init, configs)
+
+    def _default_solver(self):
+        raise ValueError("plan_to_poses needs an IK `solver` (e.g. mjpl_amd.HipIKSolver)")
+
+    def plan_to_configs(self, q_init: np.ndarray, q_goals) -> list[np.ndarray]:
+        q_init = np.asarray(q_init, float)
+        q_goals = [np.asarray(q, float) for q in q_goals]
+        if not q_goals:
+            raise ValueError("`q_goals` cannot be empty")
+        fixed = np.setdiff1d(np.arange(self.model.nq), self.qidx)
+        for q in q_goals:
+            if not np.allclose(q_init[fixed], q[fixed], rtol=0, atol=1e-12):
+                raise ValueError("goal config differs from q_init outside of the planning joints")
+        a = q_init[self.qidx]
+        goals = np.stack([q[self.qidx] for q in q_goals])
+        ends = np.concatenate([a[None], goals])
+        in_lim = np.all((ends >= self.lo) & (ends <= self.hi), axis=1)
+        if not (in_lim.all() and self._valid_ends(ends).all()):
+            raise ValueError("q_init or a goal config is not a valid configuration")
+        for q in q_goals:  # a direct connection (rrt.py:174-176)
+            if np.linalg.norm(q - q_init) <= self.eps:
+                return [q_init, q]
+        rows = self._search(a, goals)
+        if rows is None:
+            return []
+        out = []
+        for r in rows:
+            q = self.q_template.copy()
+            q[self.qidx] = r
+            out.append(q)
+        out[0] = q_init
+        hit = np.flatnonzero(np.all(goals == rows[-1][None, :], axis=1))
+        out[-1] = q_goals[int(hit[0])]
+        return out
+
+
+class ParallelBiRRT(_PlannerBase):
+    """Host (NumPy) flavour: any :class:`EdgeValidator`, torch.distributed for the exchange."""
+
+    def __init__(self, model, planning_joints: list[str], validator: EdgeValidator, q_template: np.ndarray,
+                 epsilon: float = 0.05, interval_step: float | None = None, seed: int = 0,
+                 goal_biasing_probability: float = 0.05, batch: int = 256, max_rounds: int = 1000,
+                 max_planning_time: float = 10.0, max_new_per_round: int = 1 << 20, group=None):
+        super().__init__(model, planning_joints, q_template, epsilon, seed, goal_biasing_probability, batch,
+                         max_rounds, max_planning_time)
+        self.validator = validator
+        self.interval_step = interval_step
+        self.slab_rows = int(max_new_per_round)
+        self.group = group
         if group is not None:
             import torch.distributed as dist
             self._dist = dist
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.stats = {}
+        self.trees: _Trees | None = None
 
-    # ------------------------------------------------------------------ replicated tree store
-    def _reset(self, q_init_p, q_goal_p):
-        n = len(self.qidx)
-        self.Q = np.empty((1024, n))
-        self.parent = np.empty(1024, np.int64)
-        self.tree = np.empty(1024, np.int8)
-        self.n = 0
-        self.index: dict[bytes, int] = {}
-        self._append(q_init_p, -1, 0)
-        self._append(q_goal_p, -1, 1)
+    def _valid_ends(self, ends):
+        return np.asarray(self.validator.valid_edges(ends, ends, None), dtype=bool)
 
-    def _reserve(self, extra: int) -> None:
-        while self.n + extra > len(self.Q):
-            self.Q = np.concatenate([self.Q, np.empty_like(self.Q)])
-            self.parent = np.concatenate([self.parent, np.empty_like(self.parent)])
-            self.tree = np.concatenate([self.tree, np.empty_like(self.tree)])
-
-    def _append(self, q, parent, tree) -> int:
-        key = q.tobytes() + bytes([tree])
-        hit = self.index.get(key)
-        if hit is not None:
-            return hit
-        self._reserve(1)
-        i = self.n
-        self.Q[i], self.parent[i], self.tree[i] = q, parent, tree
-        self.index[key] = i
-        self.n += 1
-        return i
-
-    def _nearest(self, targets, tree):
-        ids = np.flatnonzero(self.tree[: self.n] == tree)
-        nodes = self.Q[ids]
-        gpu_nn = getattr(self.validator, "nearest", None)
-        if gpu_nn is not None and len(nodes) >= self.gpu_nn_min_nodes:
-            return ids[gpu_nn(nodes, targets)]
-        out = np.empty(len(targets), np.int64)
-        for s in range(0, len(targets), 256):  # chunked [chunk, n_tree] distance matrix
-            t = targets[s:s + 256]
-            d2 = (np.einsum("ij,ij->i", t, t)[:, None] - 2.0 * t @ nodes.T
-                  + np.einsum("ij,ij->i", nodes, nodes)[None, :])
-            out[s:s + 256] = ids[np.argmin(d2, axis=1)]
-        return out
-
-    # ------------------------------------------------------------------ batched extend
-    def _extend(self, targets, tree, pending):
-        """Reference extend loop on every lane at once.  ``pending`` (:class:`_Pending`) collects
-        this rank's new nodes: a parent reference >= 0 is a global node id, < 0 refers to pending
-        entry ``-1 - ref``.  Returns (q_reached, ref_reached) per lane."""
-        B = len(targets)
-        near = self._nearest(targets, tree)
-        cur = self.Q[near].copy()
-        ref = near.copy()
-        active = ~np.all(cur == targets, axis=1)
+    # ------------------------------------------------------------------ one extension
+    def _extend(self, t: int, targets: np.ndarray, on: np.ndarray):
+        """Extend tree t towards `targets` on the lanes that are `on`.
+        -> (reached [L, n], ref [L], new rows, new parents): a reference >= 0 is a node id of tree t,
+        < 0 means pending entry -1 - ref of this extension; new nodes are ordered (lane, level)."""
+        nodes = self.trees.nodes(t)
+        L = len(targets)
+        near = nearest(nodes, targets)
+        cur = nodes[near].copy()
+        active = on & ~np.all(cur == targets, axis=1)
         project = getattr(self.validator, "project", None)
-        pend_index: dict[bytes, int] = {}
+        acc_rows, acc_lane, acc_level = [], [], []
+        cnt = np.zeros(L, np.int64)
 
-        tb = bytes([tree])
+        def gen(a, walk):
+            d = targets[a] - walk
+            dist = row_norm(d)
+            q_new = walk + d / dist[:, None] * np.minimum(self.eps, dist)[:, None]
+            reach = np.all(q_new == targets[a], axis=1) | (dist <= self.eps)
+            q_new[reach] = targets[a][reach]  # a step of at most eps lands on the target
+            return q_new, dist, reach
 
-        def accept_rows(lanes, rows):
-            """Lanes move to the configurations `rows`, taken in order (a lane may appear several
-            times: its later rows hang off its earlier ones).  A row is an existing node of this
-            tree, a node already pending this round, or a new pending node."""
-            keys = [r.tobytes() + tb for r in rows]
-            new_at, new_parents, new_keys = [], [], []
-            ref_l = ref.tolist()
-            index_get, pend_get = self.index.get, pend_index.get
-            base = len(pending)
-            for k, (lane, key) in enumerate(zip(lanes.tolist(), keys)):
-                r = index_get(key)
-                if r is None:
-                    r = pend_get(key)
-                    if r is None:
-                        new_at.append(k)
-                        new_parents.append(ref_l[lane])
-                        new_keys.append(key)
-                        r = -(base + len(new_at))
-                        pend_index[key] = r
-                ref_l[lane] = r
-            if new_at:
-                pending.add(rows[new_at], new_parents, tree, new_keys)
-            ref[:] = ref_l
-            # every lane ends on its last row
-            last = np.full(B, -1)
-            last[lanes] = np.arange(len(lanes))
-            moved = np.flatnonzero(last >= 0)
-            cur[moved] = rows[last[moved]]
+        def rules(a, walk, q_new, dist):
+            ok = np.all((q_new >= self.lo) & (q_new <= self.hi), axis=1)
+            ok &= ~(row_norm(q_new - walk) < 1e-8)
+            ok &= ~(row_norm(targets[a] - q_new) > dist)
+            return ok
 
         if project is None:
-            # Nothing projects: a lane's candidates do not depend on the verdicts.  Generate every
-            # lane's whole chain of steps first, validate all their edges in ONE launch, then let each
-            # lane keep the steps before its first failure.
+            # nothing projects: a lane's candidates do not depend on the verdicts.  Generate every
+            # lane's whole chain, validate all edges in one launch, keep each lane's valid prefix.
             walk = cur.copy()
-            chains_a, chains_b, owner = [], [], []
             alive = active.copy()
+            QA, QB, owner, level = [], [], [], []
+            lv = 0
             while alive.any():
                 a = np.flatnonzero(alive)
-                d = targets[a] - walk[a]
-                dist = _row_norm(d)
-                q_new = walk[a] + d / dist[:, None] * np.minimum(self.eps, dist)[:, None]
-                reach = np.all(q_new == targets[a], axis=1) | (dist <= self.eps)
-                q_new[reach] = targets[a][reach]
-                ok = np.all((q_new >= self.lo) & (q_new <= self.hi), axis=1)
-                ok &= ~(_row_norm(q_new - walk[a]) < 1e-8)
-                ok &= ~(_row_norm(targets[a] - q_new) > dist)
+                q_new, dist, reach = gen(a, walk[a])
+                ok = rules(a, walk[a], q_new, dist)
                 good = a[ok]
-                chains_a.append(walk[good].copy())
-                chains_b.append(q_new[ok])
+                QA.append(walk[good].copy())
+                QB.append(q_new[ok])
                 owner.append(good)
+                level.append(np.full(len(good), lv))
                 walk[good] = q_new[ok]
                 alive[a[~ok | reach]] = False
+                lv += 1
             if owner and sum(len(o) for o in owner):
-                QA, QB = np.concatenate(chains_a), np.concatenate(chains_b)
-                lanes_f = np.concatenate(owner)
-                level_f = np.concatenate([np.full(len(o), s) for s, o in enumerate(owner)])
+                QA, QB = np.concatenate(QA), np.concatenate(QB)
+                owner, level = np.concatenate(owner), np.concatenate(level)
                 valid = np.asarray(self.validator.valid_edges(QA, QB, self.interval_step), dtype=bool)
-                first_fail = np.full(B, len(owner))
-                np.minimum.at(first_fail, lanes_f[~valid], level_f[~valid])
-                keep = level_f < first_fail[lanes_f]  # step by step (levels), lanes ascending within a level
-                if keep.any():
-                    accept_rows(lanes_f[keep], QB[keep])
-            return cur, ref
-
-        while active.any():
-            a = np.flatnonzero(active)
-            d = targets[a] - cur[a]
-            dist = _row_norm(d)
-            q_new = cur[a] + d / dist[:, None] * np.minimum(self.eps, dist)[:, None]
-            reach = np.all(q_new == targets[a], axis=1) | (dist <= self.eps)
-            q_new[reach] = targets[a][reach]  # `_step` lands on the target within one step
-            # constraints that project come first (constraint/utils.py:30-31)
-            q_new, ok = project(cur[a], q_new)
-            reach = np.all(q_new == targets[a], axis=1)
-            ok &= np.all((q_new >= self.lo) & (q_new <= self.hi), axis=1)
-            moved = _row_norm(q_new - cur[a])
-            ok &= ~(moved < 1e-8)
-            ok &= ~(_row_norm(targets[a] - q_new) > dist)
-            if ok.any():
+                first_fail = np.full(L, lv)
+                np.minimum.at(first_fail, owner[~valid], level[~valid])
+                keep = level < first_fail[owner]
+                acc_rows, acc_lane, acc_level = [QB[keep]], [owner[keep]], [level[keep]]
+        else:
+            while active.any():
+                a = np.flatnonzero(active)
+                q_new, dist, _ = gen(a, cur[a])
+                q_new, ok = project(cur[a], q_new)  # constraints that project come first
+                reach = np.all(q_new == targets[a], axis=1)
+                ok = np.asarray(ok, bool) & rules(a, cur[a], q_new, dist)
+                # the device validates every candidate (a rejected one as a zero-length edge)
                 sel = np.flatnonzero(ok)
-                ok[sel] = self.validator.valid_edges(cur[a][sel], q_new[sel], self.interval_step)
-            sel = np.flatnonzero(ok)
-            if len(sel):
-                accept_rows(a[sel], q_new[sel])
-            done = ~ok | reach
-            active[a[done]] = False
-        return cur, ref
+                if len(sel):
+                    ok[sel] = self.validator.valid_edges(cur[a][sel], q_new[sel], self.interval_step)
+                sel = np.flatnonzero(ok)
+                acc_rows.append(q_new[sel])
+                acc_lane.append(a[sel])
+                acc_level.append(cnt[a[sel]].copy())
+                cur[a[sel]] = q_new[sel]
+                cnt[a[sel]] += 1
+                active[a[~ok | reach]] = False
+
+        if acc_rows and sum(len(r) for r in acc_rows):
+            rows, lane, level = np.concatenate(acc_rows), np.concatenate(acc_lane), np.concatenate(acc_level)
+            order = np.lexsort((level, lane))  # lanes ascending, levels ascending within a lane
+            rows, lane, level = rows[order], lane[order], level[order]
+            pos = np.arange(len(rows))
+            parents = np.where(level == 0, near[lane], -pos)  # -1 - (pos - 1)
+            reached = cur.copy()
+            ref = near.copy()
+            last = np.flatnonzero(np.r_[lane[1:] != lane[:-1], True])
+            reached[lane[last]] = rows[last]
+            ref[lane[last]] = -1 - pos[last]
+            return reached, ref, rows, parents
+        return cur, near.copy(), np.empty((0, targets.shape[1])), np.empty(0, np.int64)
 
     # ------------------------------------------------------------------ exchange
     def _allgather(self, arr: np.ndarray) -> np.ndarray:
-        """[rows, cols] float64 per rank -> [world, rows, cols] (rank order)."""
         if self.world == 1:
             return arr[None]
         import torch
-        dev = "cuda" if self._dist.get_backend(self.group) == "nccl" else "cpu"
-        mine = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
-        out = torch.empty((self.world * arr.shape[0], arr.shape[1]), dtype=mine.dtype, device=dev)
-        self._dist.all_gather_into_tensor(out, mine, group=self.group)
-        return out.cpu().numpy().reshape((self.world,) + arr.shape)
+        mine = torch.from_numpy(np.ascontiguousarray(arr))
+        out = torch.empty((self.world,) + arr.shape, dtype=mine.dtype)
+        self._dist.all_gather_into_tensor(out.view(-1, *arr.shape[1:]) if arr.ndim > 1 else out.view(-1), mine,
+                                          group=self.group)
+        return out.numpy()
 
-    def _exchange(self, pending, connection):
-        """One exchange step per round: a 4-double header per rank (count, connection refs, stop
-        flag), then ONE all-gather of the new-node slabs, padded to the round's largest count
-        rounded up to a power of two (few distinct message sizes).  Slabs are merged in rank
-        order on every rank, so node ids are global and identical everywhere."""
+    def _search(self, a, goals):
         n = len(self.qidx)
-        head = np.array([[len(pending), np.nan, np.nan, float(time.time() - self._t0 >= self.max_time)]])
-        if connection is not None:
-            head[0, 1:3] = connection
-        heads = self._allgather(head)[:, 0, :]
-        most = int(heads[:, 0].max())
-        if most > self.slab_rows:
-            raise RuntimeError("more new nodes in one round than `max_new_per_round`")
-        rows = 1 << max(most - 1, 0).bit_length() if most else 0
-        slab = pending.slab(rows, n)
-        slabs = self._allgather(slab) if rows else np.zeros((self.world, 1, n + 2))
-        winner, stop = None, False
-        for r in range(self.world):
-            cnt = int(heads[r, 0])
-            block = slabs[r, :cnt]
-            qrows = np.ascontiguousarray(block[:, :n])
-            prefs = block[:, n].astype(np.int64)
-            trees = block[:, n + 1].astype(np.int64)
-            if r == self.rank and len(pending.keys) == cnt:
-                keys = pending.keys
-            else:
-                keys = [q.tobytes() + bytes([t]) for q, t in zip(qrows, trees.tolist())]
-            fresh = cnt > 0 and len(set(keys)) == cnt and not any(k in self.index for k in keys)
-            if fresh:
-                # the usual case: none of these nodes exists yet -> append them in one go
-                base = self.n
-                self._reserve(cnt)
-                local_to_global = base + np.arange(cnt, dtype=np.int64)
-                self.Q[base:base + cnt] = qrows
-                self.tree[base:base + cnt] = trees
-                self.parent[base:base + cnt] = np.where(prefs >= 0, prefs, base + (-1 - prefs))
-                self.index.update(zip(keys, range(base, base + cnt)))
-                self.n += cnt
-            else:
-                local_to_global = np.empty(cnt, np.int64)
-                for k in range(cnt):
-                    pref = int(prefs[k])
-                    par = pref if pref >= 0 else int(local_to_global[-1 - pref])
-                    local_to_global[k] = self._append(qrows[k].copy(), par, int(trees[k]))
-            if winner is None and not np.isnan(heads[r, 1]):
-                refs = [int(heads[r, 1]), int(heads[r, 2])]
-                winner = tuple(x if x >= 0 else int(local_to_global[-1 - x]) for x in refs)
-            stop = stop or bool(heads[r, 3])
-        return winner, stop
-
-    # ------------------------------------------------------------------ driver
-    def plan_to_config(self, q_init: np.ndarray, q_goal: np.ndarray) -> list[np.ndarray]:
-        q_init, q_goal = np.asarray(q_init, float), np.asarray(q_goal, float)
-        fixed = np.setdiff1d(np.arange(self.model.nq), self.qidx)
-        if not np.allclose(q_init[fixed], q_goal[fixed], rtol=0, atol=1e-12):
-            raise ValueError("goal config differs from q_init outside of the planning joints")
-        a, b = q_init[self.qidx], q_goal[self.qidx]
-        ends = np.stack([a, b])
-        in_lim = np.all((ends >= self.lo) & (ends <= self.hi), axis=1)
-        if not (in_lim.all() and self.validator.valid_edges(ends, ends, None).all()):
-            raise ValueError("q_init or q_goal is not a valid configuration")
-        if np.linalg.norm(b - a) <= self.eps:
-            return [q_init, q_goal]
-
-        self._reset(a, b)
-        rng = np.random.default_rng(self.seed + 1000003 * self.rank)
-        self._t0 = time.time()
+        self.trees = _Trees(n)
+        self.trees.append(0, a[None], [-1])
+        self.trees.append(1, goals, [-1] * len(goals))
+        t0 = time.time()
         winner = None
-        rounds = checks = 0
+        rounds = 0
         for rounds in range(1, self.max_rounds + 1):
-            grow = (rounds - 1) % 2          # tree swap every round (rrt.py:234-235)
+            grow = (rounds - 1) % 2  # tree swap every round (rrt.py:234-235)
             other = 1 - grow
-            targets = rng.uniform(self.lo, self.hi, size=(self.batch, len(self.qidx)))
-            bias = rng.random(self.batch) <= self.p_goal
-            targets[bias] = b if grow == 0 else a  # goal bias: the other tree's root
-            pending = _Pending()
-            reached_a, ref_a = self._extend(targets, grow, pending)
-            reached_b, ref_b = self._extend(reached_a, other, pending)
-            checks += 2 * self.batch
-            hit = np.flatnonzero(np.all(reached_a == reached_b, axis=1))
-            conn = None
+            key = rrt_key(self.seed, self.rank, rounds)
+            T, on = sample_targets(key, self.batch, self.lo, self.hi, self.p_goal, grow, a, goals)
+            RA, refA, rowsA, parA = self._extend(grow, T, on)
+            RB, refB, rowsB, parB = self._extend(other, RA, on)
+            hit = np.flatnonzero(on & np.all(RA == RB, axis=1))
+            head = np.zeros(8, np.int64)
+            head[:3] = len(rowsA), len(rowsB), INT_MAX
             if len(hit):
-                k = hit[0]
-                conn = (ref_a[k], ref_b[k]) if grow == 0 else (ref_b[k], ref_a[k])
-            winner, stop = self._exchange(pending, conn)
-            if winner is not None or stop:
+                k = int(hit[0])  # [3]: node in the start tree, [4]: in the goal tree
+                head[2:5] = k, (refA[k] if grow == 0 else refB[k]), (refB[k] if grow == 0 else refA[k])
+            head[5] = int(time.time() - t0 >= self.max_time)
+            heads = self._allgather(head)
+            if max(int(heads[:, 0].max()), int(heads[:, 1].max())) > self.slab_rows:
+                raise RuntimeError("more new nodes in one round than `max_new_per_round`")
+            win_rank = next((k for k in range(self.world) if heads[k, 2] != INT_MAX), -1)
+            bases = {}
+            for which, t, rows, par in ((0, grow, rowsA, parA), (1, other, rowsB, parB)):
+                mx = int(heads[:, which].max())
+                if mx == 0:
+                    bases[t] = self.trees.n[t]
+                    continue
+                slab = np.zeros((mx, n + 1))
+                slab[: len(rows), :n] = rows
+                slab[: len(rows), n] = par
+                slabs = self._allgather(slab)
+                for k in range(self.world):
+                    cnt = int(heads[k, which])
+                    base = self.trees.n[t]
+                    if k == win_rank:
+                        bases[t] = base
+                    p = slabs[k, :cnt, n].astype(np.int64)
+                    self.trees.append(t, slabs[k, :cnt, :n], np.where(p >= 0, p, base + (-1 - p)))
+                bases.setdefault(t, self.trees.n[t])
+            if win_rank >= 0:
+                ra, rb = int(heads[win_rank, 3]), int(heads[win_rank, 4])
+                winner = (ra if ra >= 0 else bases[0] + (-1 - ra), rb if rb >= 0 else bases[1] + (-1 - rb))
                 break
-        self.stats = dict(rounds=rounds, nodes=self.n, world=self.world,
-                          seconds=time.time() - self._t0)
+            if heads[:, 5].any():
+                break
+        self.stats = dict(rounds=rounds, nodes=tuple(self.trees.n), world=self.world, seconds=time.time() - t0)
         if winner is None:
-            return []
-        ia, ib = winner  # node in the start tree, node in the goal tree (same configuration)
-        head = []
+            return None
+        ia, ib = winner
+        head_ids, tail_ids = [], []
         while ia >= 0:
-            head.append(ia)
-            ia = self.parent[ia]
-        tail = []
-        ib = self.parent[ib]  # the junction configuration appears once
+            head_ids.append(ia)
+            ia = int(self.trees.parent[0][ia])
+        ib = int(self.trees.parent[1][ib])  # the junction configuration appears once
         while ib >= 0:
-            tail.append(ib)
-            ib = self.parent[ib]
-        out = []
-        for i in list(reversed(head)) + tail:
-            q = self.q_template.copy()
-            q[self.qidx] = self.Q[i]
-            out.append(q)
-        out[0], out[-1] = q_init, q_goal
-        return out
+            tail_ids.append(ib)
+            ib = int(self.trees.parent[1][ib])
+        if not tail_ids:  # the junction IS a goal root
+            return np.array([self.trees.Q[0][i] for i in reversed(head_ids)])
+        return np.array([self.trees.Q[0][i] for i in reversed(head_ids)] + [self.trees.Q[1][i] for i in tail_ids])
+
+
+class DeviceBiRRT(_PlannerBase):
+    """The product flavour: everything of a round stays on the GPU (``mjpl_rrt_*``).
+
+    ``collision`` is an :class:`mjpl_amd.CollisionConstraint`; ``pose`` an optional
+    :class:`mjpl_amd.PoseConstraint` built on the same engine.  ``comm`` = (unique_id bytes, rank,
+    world) attaches an RCCL communicator to the engine (or pass ``group``, a torch.distributed
+    group used ONLY to broadcast the 128-byte id from rank 0)."""
+
+    def __init__(self, model, planning_joints: list[str], collision, q_template: np.ndarray, epsilon: float = 0.05,
+                 interval_step: float | None = None, seed: int = 0, goal_biasing_probability: float = 0.05,
+                 batch: int = 4096, max_rounds: int = 1000, max_planning_time: float = 10.0, capacity: int = 1 << 20,
+                 pose=None, comm=None, group=None, max_new_per_round: int = 0):
+        super().__init__(model, planning_joints, q_template, epsilon, seed, goal_biasing_probability, batch,
+                         max_rounds, max_planning_time)
+        from .. import engine as _engine
+        self.collision, self.pose = collision, pose
+        self.interval_step = interval_step
+        collision.set_planning(self.qidx.astype(np.int32), self.q_template)
+        collision._ensure_planning()
+        eng = collision.engine
+        if pose is not None and pose.engine is not eng:
+            raise ValueError("the PoseConstraint must be built on the collision constraint's engine")
+        if group is not None and comm is None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [_engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            comm = (box[0], rank, world)
+        if comm is not None:
+            uid, self.rank, self.world = comm
+            eng.comm_init(uid, self.rank, self.world)
+        self.rrt = _engine.DeviceRRT(eng, self.batch, capacity, self.lo, self.hi, epsilon=self.eps,
+                                     interval_step=interval_step, goal_bias=self.p_goal, seed=self.seed,
+                                     pose=None if pose is None else pose._proj, max_new_per_round=max_new_per_round)
+
+    def _valid_ends(self, ends):
+        self.collision._ensure_planning()
+        ok = self.collision.valid_configs_planning(ends)
+        if self.pose is not None and len(ends):
+            full = np.repeat(self.q_template[None, :], len(ends), axis=0)
+            full[:, self.qidx] = ends
+            ok = ok & self.pose.valid_configs(full)
+        return ok
+
+    def _default_solver(self):
+        from ..constraint.joint_limit_constraint import JointLimitConstraint
+        from ..inverse_kinematics.hip_ik_solver import HipIKSolver
+        cons = [JointLimitConstraint(self.model), self.collision]
+        return HipIKSolver(self.model, self.planning_joints, cons, seed=self.seed, max_attempts=5,
+                           engine=self.collision.engine)
+
+    def _search(self, a, goals):
+        self.collision._ensure_planning()
+        self.rrt.reset(a, goals, self.seed)
+        t0 = time.time()
+        info = None
+        found = False
+        rounds = 0
+        for rounds in range(1, self.max_rounds + 1):
+            info = self.rrt.round(request_stop=time.time() - t0 >= self.max_time)
+            if info.connected:
+                found = True
+                break
+            if info.stop_requested:
+                break
+        self.stats = dict(rounds=rounds, nodes=(info.nodes[0], info.nodes[1]) if info else (1, len(goals)),
+                          world=self.world, seconds=time.time() - t0)
+        return self.rrt.path() if found else None

@@ -1,0 +1,197 @@
+"""The device-resident frontier bi-RRT (mjpl_rrt_* through the C ABI) against its NumPy
+restatement running on the CPU oracle: same seed -> the same targets, the same trees node for node,
+the same path; multi-goal / pose goals; the RCCL exchange with a one-rank communicator; and one
+GPU's share of BASELINE configs[3] (131 072 lanes per round under [PoseConstraint, JointLimit,
+Collision]) checked through properties every accepted node and edge must have."""
+import numpy as np
+import pytest
+
+import mjpl_amd as mjpl
+from mjpl_amd import engine as eng_mod
+from mjpl_amd import scenes
+from mjpl_amd.planning import parallel_rrt as pr
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleValidator(pr.EdgeValidator):
+    def __init__(self, oracle_mod, model, qidx, base):
+        self.o = oracle_mod.Oracle(model, planning_qidx=qidx, qpos_base=base)
+
+    def valid_edges(self, QA, QB, step):
+        if step is None:
+            return self.o.valid_configs(QB, nthreads=8).astype(bool)
+        return self.o.valid_edges(QA, QB, step, nthreads=8).astype(bool)
+
+
+def _scene(oracle_mod, seed=5):
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    v = OracleValidator(oracle_mod, m, qidx, q_init)
+    rng = np.random.default_rng(seed)
+    goals = []
+    while len(goals) < 3:
+        g = q_init.copy()
+        g[qidx] = rng.uniform(m.jnt_range[qidx, 0], m.jnt_range[qidx, 1])
+        if v.valid_edges(g[qidx][None], g[qidx][None], None)[0]:
+            goals.append(g)
+    return m, joints, qidx, q_init, v, goals
+
+
+def test_device_sampler_is_the_host_sampler(oracle_mod):
+    m, joints, qidx, q_init, v, goals = _scene(oracle_mod)
+    cc = mjpl.CollisionConstraint(m)
+    cc.set_planning(qidx, q_init)
+    lo, hi = m.jnt_range[qidx, 0], m.jnt_range[qidx, 1]
+    G = np.stack([g[qidx] for g in goals])
+    r = eng_mod.DeviceRRT(cc.engine, 4096, 1 << 20, lo, hi, epsilon=0.05, interval_step=0.01, goal_bias=0.2, seed=9)
+    r.reset(q_init[qidx], G, 9)
+    for rnd in (1, 2, 3):
+        r.round()
+        T, on = r.lanes_state()
+        Th, onh = pr.sample_targets(pr.rrt_key(9, 0, rnd), 4096, lo, hi, 0.2, (rnd - 1) % 2, q_init[qidx], G)
+        np.testing.assert_array_equal(T, Th)
+        np.testing.assert_array_equal(on, onh)
+    r.close()
+
+
+@pytest.mark.parametrize("seed,batch,ngoal", [(1, 48, 1), (2, 256, 3), (3, 64, 2)])
+def test_device_trees_equal_the_oracle_validated_planner(oracle_mod, seed, batch, ngoal):
+    """Same algorithm, same seed: the GPU planner (float32 filter + float64 kernels, device RNG,
+    device nearest neighbour, chunked extension) and the NumPy planner on the CPU oracle must build
+    the same two trees node for node and return the same path."""
+    m, joints, qidx, q_init, v, goals = _scene(oracle_mod, seed=seed + 10)
+    goals = goals[:ngoal]
+    kw = dict(epsilon=0.05, interval_step=0.01, seed=seed, goal_biasing_probability=0.1, batch=batch,
+              max_planning_time=300.0)
+    host = pr.ParallelBiRRT(m, joints, v, q_init, **kw)
+    want = host.plan_to_configs(q_init, goals)
+    assert len(want) > 2
+    cc = mjpl.CollisionConstraint(m)
+    dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, capacity=1 << 20, **kw)
+    got = dev.plan_to_configs(q_init, goals)
+    assert dev.stats["rounds"] == host.stats["rounds"] and dev.stats["nodes"] == host.stats["nodes"]
+    for t in (0, 1):
+        Q, par = dev.rrt.tree(t)
+        np.testing.assert_array_equal(Q, host.trees.nodes(t))
+        np.testing.assert_array_equal(par, host.trees.parent[t][: host.trees.n[t]])
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    assert any(np.array_equal(got[-1], g) for g in goals)
+
+
+def test_endpoint_only_validation_and_argument_errors(oracle_mod):
+    m, joints, qidx, q_init, v, goals = _scene(oracle_mod, seed=21)
+    kw = dict(epsilon=0.07, interval_step=None, seed=4, goal_biasing_probability=0.05, batch=96, max_planning_time=300.0)
+    host = pr.ParallelBiRRT(m, joints, v, q_init, **kw)
+    want = host.plan_to_config(q_init, goals[0])
+    cc = mjpl.CollisionConstraint(m)
+    dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, capacity=1 << 20, **kw)
+    got = dev.plan_to_config(q_init, goals[0])
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    near = q_init.copy()
+    near[qidx[0]] += 0.01
+    assert len(dev.plan_to_configs(q_init, [goals[0], near])) == 2
+    bad = q_init.copy()
+    bad[qidx[3]] = 0.5
+    with pytest.raises(ValueError, match="not a valid configuration"):
+        dev.plan_to_config(q_init, bad)
+    other = goals[0].copy()
+    other[8] += 0.01
+    with pytest.raises(ValueError, match="outside of the planning joints"):
+        dev.plan_to_config(q_init, other)
+    with pytest.raises(eng_mod.MjplError, match="status -4"):
+        tiny = mjpl.DeviceBiRRT(m, joints, mjpl.CollisionConstraint(m), q_init, capacity=64, **kw)
+        tiny.plan_to_config(q_init, goals[0])
+
+
+def test_allgather_through_a_one_rank_rccl_communicator():
+    m = scenes.one_dof_ball()
+    e = eng_mod.Engine(m)
+    e.comm_init(eng_mod.comm_unique_id(), 0, 1)
+    src = np.arange(1000, dtype=np.float64)
+    a, b = e.alloc(src.nbytes).upload(src), e.alloc(src.nbytes)
+    e.allgather_dev(a.ptr, b.ptr, src.nbytes)
+    np.testing.assert_array_equal(b.download(np.float64, 1000), src)
+    e.allgather_dev(a.ptr, a.ptr, src.nbytes)  # in place
+    np.testing.assert_array_equal(a.download(np.float64, 1000), src)
+    with pytest.raises(eng_mod.MjplError, match="already has a communicator"):
+        e.comm_init(eng_mod.comm_unique_id(), 0, 1)
+    e.comm_destroy()
+    e.close()
+
+
+def _constrained(m, q_init, seed):
+    cc = mjpl.CollisionConstraint(m)
+    frame = mjpl.site_pose(m, q_init, "ee_site", engine=cc.engine)
+    pc = mjpl.PoseConstraint(m, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), engine=cc.engine)
+    cons = [pc, mjpl.JointLimitConstraint(m), cc]
+    pc.q_step = np.inf
+    q_goal = mjpl.random_config(m, q_init, scenes.FRANKA_ARM_JOINTS, seed, cons)
+    pc.q_step = 0.05
+    return cc, pc, q_goal
+
+
+def test_one_gpu_share_of_configs3_through_rccl(oracle_mod):
+    """BASELINE configs[3] on one GPU: 131 072 samples per round, constraints [PoseConstraint(roll,
+    pitch +-0.1), JointLimit, Collision] (examples/franka_constrained_move_to_pose.py:51-64), the
+    exchange running through a one-rank RCCL communicator.  Size-independent properties of every
+    node the rounds added: on the constraint manifold, inside the joint limits, collision-free, a
+    valid edge away from its parent (oracle on a sample), parents preceding children."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    cc, pc, q_goal = _constrained(m, q_init, 7)
+    L = 131072
+    dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=3, goal_biasing_probability=0.05,
+                           batch=L, capacity=1 << 22, pose=pc, comm=(eng_mod.comm_unique_id(), 0, 1))
+    dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 3)
+    infos = [dev.rrt.round(), dev.rrt.round()]
+    assert infos[0].new_nodes[0] > 1000 and infos[1].new_nodes[1] > 1000, [(i.new_nodes[0], i.new_nodes[1]) for i in infos]
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=q_init)
+    rng = np.random.default_rng(0)
+    for t in (0, 1):
+        Q, par = dev.rrt.tree(t)
+        n = len(Q)
+        assert n == infos[1].nodes[t]
+        assert par[0] == -1 and np.all(par[1:] < np.arange(1, n)) and np.all(par[1:] >= 0)
+        assert np.all((Q >= m.jnt_range[qidx, 0]) & (Q <= m.jnt_range[qidx, 1]))
+        full = np.repeat(q_init[None], n, axis=0)
+        full[:, qidx] = Q
+        assert pc.valid_configs(full).all()
+        cc._ensure_planning()
+        assert cc.valid_configs_planning(Q).all()
+        step = np.linalg.norm(Q[1:] - Q[par[1:]], axis=1)
+        assert step.max() <= 0.05 + 2 * 0.05 + 1e-9 and step.min() >= 1e-8
+        pick = rng.choice(np.arange(1, n), size=min(3000, n - 1), replace=False)
+        assert orc.valid_edges(Q[par[pick]], Q[pick], 0.01, nthreads=8).all()
+    # and the search itself, at a size that finishes quickly: a path on the manifold
+    small = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=7, goal_biasing_probability=0.1,
+                             batch=2048, capacity=1 << 20, pose=pc, max_planning_time=120.0)
+    path = small.plan_to_config(q_init, q_goal)
+    assert len(path) > 2, small.stats
+    P = np.stack(path)
+    np.testing.assert_array_equal(P[0], q_init)
+    np.testing.assert_array_equal(P[-1], q_goal)
+    assert pc.valid_configs(P).all()
+    assert orc.valid_edges(P[:-1, qidx], P[1:, qidx], 0.01, nthreads=8).all()
+
+
+def test_plan_to_poses_through_batched_ik(oracle_mod):
+    """plan_to_poses (rrt.py:106-139): IK seeds for each pose, the valid ones become goals."""
+    m, joints, qidx, q_init, v, goals = _scene(oracle_mod, seed=31)
+    cc = mjpl.CollisionConstraint(m)
+    poses = [mjpl.site_pose(m, g, "ee_site", engine=cc.engine) for g in goals[:2]]
+    dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=5, goal_biasing_probability=0.1,
+                           batch=1024, capacity=1 << 18, max_planning_time=120.0)
+    path = dev.plan_to_poses(q_init, poses, "ee_site")
+    assert len(path) > 2
+    end = mjpl.site_pose(m, path[-1], "ee_site", engine=cc.engine)
+    err = min(np.linalg.norm(end.translation() - p.translation()) for p in poses)
+    assert err < 2e-3
+    P = np.stack(path)
+    assert v.valid_edges(P[:-1, qidx], P[1:, qidx], 0.01).all()

@@ -58,9 +58,64 @@ def test_single_process_plan_is_valid_and_deterministic():
     _, _, _, p2, _, _ = _make()
     again = p2.plan_to_config(q_init, g)
     assert len(again) == len(path) and all(np.array_equal(a, b) for a, b in zip(path, again))
-    # every node's parent precedes it and the two trees never mix
-    assert np.all(p.parent[2:p.n] < np.arange(2, p.n))
-    assert np.all(p.tree[p.parent[2:p.n]] == p.tree[2:p.n])
+    # every node's parent precedes it (roots: -1); edges are no longer than epsilon
+    for t in (0, 1):
+        n, par, Q = p.trees.n[t], p.trees.parent[t], p.trees.Q[t]
+        assert par[0] == -1 and np.all(par[1:n] < np.arange(1, n)) and np.all(par[1:n] >= 0)
+        assert np.all(np.linalg.norm(Q[1:n] - Q[par[1:n]], axis=1) <= 0.05 + 1e-12)
+
+
+def test_multiple_goals_and_the_sink_semantics():
+    """plan_to_configs (rrt.py:141-237): the goal tree's roots are the goals; the path ends on one
+    of them; a goal within epsilon of q_init short-circuits; an invalid goal raises."""
+    m, qidx, v, p, q_init, g = _make(seed=4)
+    rng = np.random.default_rng(11)
+    goals = [g]
+    while len(goals) < 3:
+        c = q_init.copy()
+        c[qidx] = rng.uniform(m.jnt_range[qidx, 0], m.jnt_range[qidx, 1])
+        if v.valid_edges(c[qidx][None], c[qidx][None], None)[0]:
+            goals.append(c)
+    path = p.plan_to_configs(q_init, goals)
+    assert len(path) > 2
+    assert any(np.array_equal(path[-1], q) for q in goals)
+    k = [np.array_equal(path[-1], q) for q in goals].index(True)
+    _check_path(m, qidx, v, path, q_init, goals[k])
+    assert p.trees.n[1] >= 3 and np.all(p.trees.parent[1][:3] == -1)
+    near = q_init.copy()
+    near[qidx[0]] += 0.01
+    assert len(p.plan_to_configs(q_init, [g, near])) == 2
+    bad = q_init.copy()
+    bad[qidx[3]] = 0.5  # joint4's range is [-3.07, -0.07]
+    with pytest.raises(ValueError, match="not a valid configuration"):
+        p.plan_to_configs(q_init, [g, bad])
+
+
+def test_counter_based_sampler_known_answers():
+    """The sampler both flavours share (mjpl_rrt.h: sm64 / rrt_key / rrt_u01): splitmix64 outputs
+    for seed 0 are the published test vector; lanes, goal bias and duplicate suppression."""
+    from mjpl_amd.planning import parallel_rrt as pr
+    z = np.uint64(0)
+    outs = []
+    for _ in range(3):  # splitmix64 stream with state += GOLD: sm64(state) is the published generator
+        outs.append(int(pr._sm64(z)))
+        z = np.uint64((int(z) + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+    assert outs == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+    key = pr.rrt_key(7, 1, 3)
+    u = pr.rrt_u01(key, np.arange(1000))
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.05
+    lo, hi = np.full(7, -1.0), np.full(7, 2.0)
+    goals = np.arange(21.0).reshape(3, 7)
+    T, on = pr.sample_targets(key, 4096, lo, hi, 0.25, 0, np.zeros(7), goals)
+    biased = np.any(T[:, None, :] == goals[None, :, :], axis=2).all(axis=1) if False else np.array(
+        [any(np.array_equal(t, g) for g in goals) for t in T])
+    assert 0.2 < biased.mean() < 0.3
+    assert on[~biased].all() and on[biased].sum() == 3  # one lane per goal
+    assert np.all((T[~biased] >= lo) & (T[~biased] < hi))
+    T1, on1 = pr.sample_targets(key, 4096, lo, hi, 0.25, 1, np.zeros(7), goals)
+    assert on1[biased].sum() == 1 and np.array_equal(T1[~biased], T[~biased])
+    T2, _ = pr.sample_targets(pr.rrt_key(7, 0, 3), 4096, lo, hi, 0.25, 0, np.zeros(7), goals)
+    assert not np.array_equal(T2, T)  # another rank draws other targets
 
 
 def test_argument_validation_and_trivial_goal():
@@ -88,7 +143,9 @@ def _worker(rank, world, port, q):
         m, qidx, v, p, q_init, g = _make(world_group=dist.group.WORLD, batch=24)
         path = p.plan_to_config(q_init, g)
         _check_path(m, qidx, v, path, q_init, g)
-        q.put((rank, np.array(path).tobytes(), p.n, p.Q[: p.n].tobytes(), p.parent[: p.n].tobytes(), p.stats["world"]))
+        q.put((rank, np.array(path).tobytes(), tuple(p.trees.n),
+               p.trees.nodes(0).tobytes() + p.trees.nodes(1).tobytes(),
+               p.trees.parent[0][: p.trees.n[0]].tobytes() + p.trees.parent[1][: p.trees.n[1]].tobytes(), p.stats["world"]))
     finally:
         dist.destroy_process_group()
 
