@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
 """Planning-time harness in the shape of the reference's examples/benchmark.py (:26-91):
-N seeded plan-to-config attempts on the Franka scene, success rate and median planning time.
-Constraints = joint limits + collision, validated by the MI355X engine.
+`number_of_attempts` = 15 plans from the "home" keyframe to the end-effector pose of
+random_config(seed), ONE seed for every attempt, `plan_to_pose` (IK inside the timed region),
+constraints = joint limits + collision, no interval check, epsilon 0.05, goal bias 0.1, 10 s limit;
+prints the success rate and the median planning time of the successful attempts.
 
-    python examples/benchmark.py [--attempts 15] [--obstacles] [--planner parallel|rrt]
+    python examples/benchmark.py [--planner device|host|rrt] [--obstacles] [--interval 0.01]
+                                 [--goal config] [--vary-seed] [--attempts 15] [--batch 512]
+
+--planner device : frontier bi-RRT resident on the GPU (mjpl_amd.DeviceBiRRT)
+          host   : the same algorithm in NumPy over the GPU kernels (mjpl_amd.ParallelBiRRT)
+          rrt    : the reference-shaped serial CBiRRT with batched extensions (mjpl_amd.RRT)
 """
 import argparse
 import os
@@ -21,8 +28,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--attempts", type=int, default=15)
     ap.add_argument("--obstacles", action="store_true")
-    ap.add_argument("--planner", choices=["parallel", "rrt"], default="parallel")
+    ap.add_argument("--planner", choices=["device", "host", "rrt"], default="device")
+    ap.add_argument("--goal", choices=["pose", "config"], default="pose")
+    ap.add_argument("--interval", type=float, default=0.0, help="collision_interval_check step; 0 = none (reference)")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--vary-seed", action="store_true", help="seed + k for attempt k instead of one seed")
+    ap.add_argument("--batch", type=int, default=512)
     args = ap.parse_args()
 
     model = scenes.franka_p(obstacles=args.obstacles)
@@ -31,29 +42,44 @@ def main():
     q_init = model.keyframe("home").qpos.copy()
     cc = mjpl.CollisionConstraint(model)
     constraints = [mjpl.JointLimitConstraint(model), cc]
-    validator = mjpl.HipEdgeValidator(cc, qidx, q_init)
+    step = args.interval if args.interval > 0 else None
+
+    planners = {}
+
+    def planner_for(seed):
+        # planners are built once per seed (device buffers, compiled model); planning is what is timed
+        if seed in planners:
+            return planners[seed]
+        kw = dict(epsilon=0.05, seed=seed, goal_biasing_probability=0.1, max_planning_time=10.0)
+        if args.planner == "device":
+            p = mjpl.DeviceBiRRT(model, joints, cc, q_init, interval_step=step, batch=args.batch, capacity=1 << 21, **kw)
+        elif args.planner == "host":
+            p = mjpl.ParallelBiRRT(model, joints, mjpl.HipEdgeValidator(cc, qidx, q_init), q_init,
+                                   interval_step=step, batch=args.batch, **kw)
+        else:
+            p = mjpl.RRT(model, joints, constraints, collision_interval_check=(step, cc) if step else None, **kw)
+        planners[seed] = p
+        return p
 
     times, ok = [], 0
     for k in range(args.attempts):
-        seed = args.seed + k
+        seed = args.seed + k if args.vary_seed else args.seed
         q_goal = mjpl.random_config(model, q_init, joints, seed, constraints)
+        goal_pose = mjpl.site_pose(model, q_goal, "ee_site", engine=cc.engine)
+        planner = planner_for(seed)
+        solver = mjpl.HipIKSolver(model, joints, constraints, seed=seed, max_attempts=5, engine=cc.engine)
         t0 = time.time()
-        if args.planner == "parallel":
-            planner = mjpl.ParallelBiRRT(model, joints, validator, q_init, epsilon=0.05, interval_step=0.01,
-                                         seed=seed, goal_biasing_probability=0.1, batch=512,
-                                         max_planning_time=10.0)
-            path = planner.plan_to_config(q_init, q_goal)
+        if args.goal == "pose":
+            path = planner.plan_to_pose(q_init, goal_pose, "ee_site", solver=solver)
         else:
-            planner = mjpl.RRT(model, joints, constraints, collision_interval_check=(0.01, cc), seed=seed,
-                               goal_biasing_probability=0.1, max_planning_time=10.0, epsilon=0.05)
             path = planner.plan_to_config(q_init, q_goal)
         dt = time.time() - t0
         if path:
             ok += 1
             times.append(dt)
-        print(f"attempt {k}: {'ok' if path else 'FAILED'} in {dt:.3f}s, {len(path)} waypoints")
-    print(f"success rate {ok}/{args.attempts}; median planning time "
-          f"{np.median(times) if times else float('nan'):.4f}s")
+        print(f"attempt {k}: {'ok' if path else 'FAILED'} in {dt:.4f}s, {len(path)} waypoints")
+    print(f"planner {args.planner}, goal {args.goal}, interval {step}: success rate {ok}/{args.attempts}; "
+          f"median planning time {np.median(times) if times else float('nan'):.4f}s")
     return 0 if ok else 1
 
 
