@@ -111,9 +111,13 @@ enum : int { GS_BOUND = 0, GS_MARGIN = MAX_SLOTS, GS_SIZE = 2 * MAX_SLOTS, GS_GE
 //   bit 17 = the partner is the FIRST geom of the pair in mj_collision's (g1,g2) order
 enum : int { P_FIRST = 1 << 17 };
 // world tables (fixed strides so that a chunk of four rows is one wide scalar load):
-//   cull table   [nwpad][4] : pos[3], info word (type | geom id << 8)
+//   cull table   [nwpad / 4][4 fields][4 rows]: x, y, z, info word (type | geom id << 8) of four
+//                rows side by side, so that the packed binary32 culls of two rows take their
+//                operands from adjacent scalar registers (row-major cost 12 s_mov per chunk)
 //   narrow table [nworld][12]: z axis[3], x axis[3], y axis[3], size[3]
 enum : int { WC_POS = 0, WC_INFO = 3, WC_LEN = 4 };
+// table index of field f of world row w
+MJPL_HD int wc_at(int w, int f) { return ((w >> 2) << 4) + (f << 2) + (w & 3); }
 // candidate kinds in the queued kernels' records
 enum : int { EK_PLANE = 0, EK_STATIC = 1, EK_SLOT = 2 };
 enum : int { WN_ZAXIS = 0, WN_XAXIS = 3, WN_YAXIS = 6, WN_SIZE = 9, WN_LEN = 12 };
@@ -946,10 +950,9 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
         // ---- static planes (few): signed-distance cull, then the plane routines
         for (unsigned long long pm = pmask_all; pm; pm &= pm - 1) {
           const int wc = (int)__builtin_ctzll(pm);
-          Tab rc = wcull + wc * WC_LEN;
           Tab rw = wnarrow + wc * WN_LEN;
           Geom par;
-          par.pos[0] = rc[WC_POS]; par.pos[1] = rc[WC_POS + 1]; par.pos[2] = rc[WC_POS + 2];
+          par.pos[0] = wcull[wc_at(wc, 0)]; par.pos[1] = wcull[wc_at(wc, 1)]; par.pos[2] = wcull[wc_at(wc, 2)];
           par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
           par.m[0] = par.m[1] = par.m[3] = par.m[4] = par.m[6] = par.m[7] = 0;
           T dif[3] = {cur.pos[0] - par.pos[0], cur.pos[1] - par.pos[1], cur.pos[2] - par.pos[2]};
@@ -983,8 +986,8 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
           bool ps0, ps1, ps2, ps3;
 #define MJPL_WCULL(k, out)                                                              \
           {                                                                             \
-            T dx = cur.pos[0] - rc[(k) * WC_LEN], dy = cur.pos[1] - rc[(k) * WC_LEN + 1],  \
-              dz = cur.pos[2] - rc[(k) * WC_LEN + 2];                                   \
+            T dx = cur.pos[0] - rc[k], dy = cur.pos[1] - rc[4 + (k)],                   \
+              dz = cur.pos[2] - rc[8 + (k)];                                            \
             out = !(dx * dx + dy * dy + dz * dz > bc[k]) && live && ((bits >> (k)) & 1u); \
           }
           MJPL_WCULL(0, ps0) MJPL_WCULL(1, ps1) MJPL_WCULL(2, ps2) MJPL_WCULL(3, ps3)
@@ -999,13 +1002,12 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
             const bool pk = (k == 0 ? ps0 : (k == 1 ? ps1 : (k == 2 ? ps2 : ps3))) && live;
             if (__builtin_amdgcn_ballot_w64(pk) == 0ull) continue;
             const int wc = base + k;
-            Tab r4 = wcull + wc * WC_LEN;
             Tab rw = wnarrow + wc * WN_LEN;
-            const int info = ((IP)(r4 + WC_INFO))[0];
+            const int info = info_bits(wcull[wc_at(wc, WC_INFO)]);
             const int ptype = info & 255;
             __builtin_assume(ptype != GT_PLANE);
             Geom par;
-            par.pos[0] = r4[WC_POS]; par.pos[1] = r4[WC_POS + 1]; par.pos[2] = r4[WC_POS + 2];
+            par.pos[0] = wcull[wc_at(wc, 0)]; par.pos[1] = wcull[wc_at(wc, 1)]; par.pos[2] = wcull[wc_at(wc, 2)];
             par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
             if (WBOX) {
               par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
@@ -1217,9 +1219,8 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
     T psize[3], margin;
     int code = V_NONE;
     if constexpr (BOXQ) {
-      Tab rc = wcull + index * WC_LEN;
       Tab rw = wnarrow + index * WN_LEN;
-      par.pos[0] = rc[WC_POS]; par.pos[1] = rc[WC_POS + 1]; par.pos[2] = rc[WC_POS + 2];
+      par.pos[0] = wcull[wc_at(index, 0)]; par.pos[1] = wcull[wc_at(index, 1)]; par.pos[2] = wcull[wc_at(index, 2)];
       par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
       par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
       par.m[1] = rw[WN_YAXIS]; par.m[4] = rw[WN_YAXIS + 1]; par.m[7] = rw[WN_YAXIS + 2];
@@ -1246,9 +1247,8 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
         psize[0] = sb[2 * MAX_SLOTS + 3 * index]; psize[1] = sb[2 * MAX_SLOTS + 3 * index + 1];
         psize[2] = sb[2 * MAX_SLOTS + 3 * index + 2];
       } else {
-        Tab rc = wcull + index * WC_LEN;
         Tab rw = wnarrow + index * WN_LEN;
-        par.pos[0] = rc[WC_POS]; par.pos[1] = rc[WC_POS + 1]; par.pos[2] = rc[WC_POS + 2];
+        par.pos[0] = wcull[wc_at(index, 0)]; par.pos[1] = wcull[wc_at(index, 1)]; par.pos[2] = wcull[wc_at(index, 2)];
         par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
         psize[0] = rw[WN_SIZE]; psize[1] = rw[WN_SIZE + 1]; psize[2] = rw[WN_SIZE + 2];
         margin = gd[GD_WBOUND + nwpad + index];
@@ -1284,7 +1284,7 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
           ps.uc.ga[u] = (int)gd[GD_GEOMID];
           int gb;
           if (!BOXQ && kind == EK_SLOT) gb = (int)gd[GD_WBOUND + 2 * nwpad + GS_GEOMID + index];
-          else gb = info_bits(wcull[index * WC_LEN + WC_INFO]) >> 8;
+          else gb = info_bits(wcull[wc_at(index, WC_INFO)]) >> 8;
           ps.uc.gb[u] = gb;
           handed = true;
         }
@@ -1511,9 +1511,8 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       // static planes (few)
       for (unsigned long long pm_ = pmask_use; pm_; pm_ &= pm_ - 1) {
         const int wc = (int)__builtin_ctzll(pm_);
-        Tab rc = wcull + wc * WC_LEN;
         Tab rw = tp + uni(ip[H_OFF_WNARROW]) + wc * WN_LEN;
-        const T ppos[3] = {rc[WC_POS], rc[WC_POS + 1], rc[WC_POS + 2]};
+        const T ppos[3] = {wcull[wc_at(wc, 0)], wcull[wc_at(wc, 1)], wcull[wc_at(wc, 2)]};
         const T pz[3] = {rw[WN_ZAXIS], rw[WN_ZAXIS + 1], rw[WN_ZAXIS + 2]};
         T dif[3] = {cur.pos[0] - ppos[0], cur.pos[1] - ppos[1], cur.pos[2] - ppos[2]};
         const unsigned long long pm = __builtin_amdgcn_ballot_w64(!(dot3(dif, pz) + dead > wbound[wc]));
@@ -1560,8 +1559,8 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         unsigned long long m0, m1, m2, m3;
 #define MJPL_QCULL(k, out)                                                              \
         {                                                                               \
-          T dx = cur.pos[0] - rcv[(k) * WC_LEN], dy = cur.pos[1] - rcv[(k) * WC_LEN + 1], \
-            dz = cur.pos[2] - rcv[(k) * WC_LEN + 2];                                    \
+          T dx = cur.pos[0] - rcv[k], dy = cur.pos[1] - rcv[4 + (k)],                     \
+            dz = cur.pos[2] - rcv[8 + (k)];                                              \
           out = __builtin_amdgcn_ballot_w64(!(sqnorm3(dx, dy, dz) + dead > bcv[k]));     \
         }
         MJPL_QCULL(0, m0) MJPL_QCULL(1, m1) MJPL_QCULL(2, m2) MJPL_QCULL(3, m3)
@@ -1577,7 +1576,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           if (pm == 0ull) continue;
           const int wc = base + k;
           // the row's info word came with the chunk (first 4 bytes of its 4th scalar)
-          const T iw = k == 0 ? rcv[WC_INFO] : (k == 1 ? rcv[WC_LEN + WC_INFO] : (k == 2 ? rcv[2 * WC_LEN + WC_INFO] : rcv[3 * WC_LEN + WC_INFO]));
+          const T iw = k == 0 ? rcv[12] : (k == 1 ? rcv[13] : (k == 2 ? rcv[14] : rcv[15]));
           const int info = uni(info_bits(iw));
           const int ptype = info & 255, pgid = info >> 8;
           // mj_collision order: smaller geom type first, geom id breaks ties

@@ -1383,7 +1383,7 @@ int compile_program(mjpl_engine *e) {
     for (int k = 0; k < 3; k++) e->st_gxpos[3 * g + k] = gp[k] + e->st_xpos[3 * b + k];
     mul_quat(gq, &e->st_xquat[4 * b], &m.geom_quat[4 * g]);
     quat2mat(&e->st_gxmat[9 * g], gq);
-    world_row[g] = (int)(wcull_tab.size() / WC_LEN);
+    world_row[g] = (int)winfo.size();
     {
       const double *gmx = &e->st_gxmat[9 * g];
       double rc[WC_LEN] = {0}, rn[WN_LEN] = {0};
@@ -1396,14 +1396,17 @@ int compile_program(mjpl_engine *e) {
       }
       const int32_t info[2] = {m.geom_type[g] | (g << 8), 0};
       memcpy(&rc[WC_INFO], info, sizeof(double));
+      const int w = (int)winfo.size();
       winfo.push_back(info[0]);
-      wcull_tab.insert(wcull_tab.end(), rc, rc + WC_LEN);
+      // four rows side by side per chunk (wc_at); one spare chunk: the kernels may prefetch ahead
+      wcull_tab.resize((size_t)((w >> 2) + 2) * 16, 0.0);
+      for (int f = 0; f < WC_LEN; f++) wcull_tab[wc_at(w, f)] = rc[f];
       wnarrow_tab.insert(wnarrow_tab.end(), rn, rn + WN_LEN);
     }
   }
-  const int nworld = (int)(wcull_tab.size() / WC_LEN);
+  const int nworld = (int)winfo.size();
   const int nwpad = (nworld + 3) / 4 * 4;
-  wcull_tab.resize((size_t)(nwpad + 4) * WC_LEN, 0.0);  // one spare chunk: the kernels prefetch ahead
+  wcull_tab.resize((size_t)(nwpad + 4) * WC_LEN, 0.0);
   if (nworld > 64) return fail(MJPL_E_CAPACITY, "%d static geoms; this build enables at most 64 per moving geom", nworld);
   if (ng >= (1 << 23)) return fail(MJPL_E_CAPACITY, "too many geoms");
 
@@ -1494,7 +1497,7 @@ int compile_program(mjpl_engine *e) {
   ip[H_NWORLD] = nworld;
   ip[H_NWPAD] = nwpad;
   dp = wcull_tab;
-  for (int w = 0; w < nworld; w++) info_at.push_back({(size_t)w * WC_LEN + WC_INFO, winfo[w]});
+  for (int w = 0; w < nworld; w++) info_at.push_back({(size_t)wc_at(w, WC_INFO), winfo[w]});
   ip[H_OFF_WNARROW] = (int)dp.size();
   dp.insert(dp.end(), wnarrow_tab.begin(), wnarrow_tab.end());
 
@@ -1732,7 +1735,8 @@ int compile_program(mjpl_engine *e) {
   const double tol = e->filter_tol;
   double poison_slack = 0;
   for (int w : poison_rows) {
-    const double *rc = &dp[(size_t)ip[H_OFF_WCULL] + (size_t)w * WC_LEN];
+    const double *wt = &dp[(size_t)ip[H_OFF_WCULL]];
+    const double rc[3] = {wt[wc_at(w, 0)], wt[wc_at(w, 1)], wt[wc_at(w, 2)]};
     const double *rn = &dp[(size_t)ip[H_OFF_WNARROW] + (size_t)w * WN_LEN];
     const double mag = std::fabs(rc[0]) + std::fabs(rc[1]) + std::fabs(rc[2]) + std::fabs(rn[WN_SIZE]) +
                        std::fabs(rn[WN_SIZE + 1]) + std::fabs(rn[WN_SIZE + 2]);
