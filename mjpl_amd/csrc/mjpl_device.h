@@ -93,9 +93,9 @@ enum : int { JF_POS_NONZERO = 1 };
 enum : int { G_TYPE = 0, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_SMASK, G_WMASK_LO, G_WMASK_HI,
              G_PMASK_LO, G_PMASK_HI, G_SIZE };
 enum : int { GF_SAMEPOS = 1, GF_SAMEROT = 2 };
-enum : int { MAX_SLOTS = 16 };
+enum : int { MAX_SLOTS = 32 };
 // geom constants: lpos[3] lquat[4] size[3] pad[2] | wbound[nwpad] | wmargin[nwpad]
-//                 | sbound[16] | smargin[16] | ssize[16][3]
+//                 | sbound[MAX_SLOTS] | smargin[MAX_SLOTS] | ssize[MAX_SLOTS][3]
 //   wbound[w]  cull bound against static geom w: (r1+r2+margin)^2, or margin + rbound for a
 //              plane; +inf where the pair is disabled.  nwpad = rows rounded up to a multiple of 4
 //   wmargin[w] pair margin max(margin_cur, margin_w)

@@ -182,32 +182,36 @@ k_check_configs(const int *__restrict__ gip, int nip, const double *__restrict__
   extern __shared__ double smem[];
   const int B = blockDim.x;
   if (ulist && (int64_t)blockIdx.x * B >= (int64_t)*ucount) return;  // nothing left to re-run
-  if (uc.count) {
-    // patch mode: the rows of uc.q are undecided waypoints of edges; N is read on the device
-    const int64_t n = *uc.count < uc.cap ? *uc.count : uc.cap;
-    if ((int64_t)blockIdx.x * B >= n) return;
-    N = n;
-  }
   const int nplan = gip[H_NPLAN];
   Carve<double> c = carve_lds<double>(smem, gip, nip, gdp, ndp, nplan, 1, B);
+  FkOut none = {};
+  if (uc.count) {
+    // patch mode: the rows of uc.q are undecided waypoints of edges; their number is read on the
+    // device and may exceed what the grid covers in one pass: blocks stride over it
+    const int64_t n = *uc.count < uc.cap ? *uc.count : uc.cap;
+    for (int64_t base = (int64_t)blockIdx.x * B; base < n; base += (int64_t)gridDim.x * B) {
+      const int64_t i = base + threadIdx.x;
+      const bool active = i < n && uc.ga[i] < 0;  // pair-level items belong to k_patch_pairs
+      load_columns(c.col0 + threadIdx.x, B, Q, n, i < n ? i : 0, nplan, layout, active);
+      const bool hit = run_config<double, MAXS, false, WBOX, MBOX>(c.ip, c.tp, c.col0 + threadIdx.x, B,
+                                                                   c.save + threadIdx.x, B, active, 0.0, none,
+                                                                   i) == V_CONTACT;
+      if (active && hit) {
+        const int ed = uc.edge[i];
+        valid[ed] = 0;
+        // first_bad holds -1 (= UINT_MAX) for "valid so far": an unsigned min keeps the lowest index
+        if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)uc.idx[i]);
+      }
+    }
+    return;
+  }
   int64_t i;
   const bool active = pick_item(N, ulist, ucount, &i);
   load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
   __syncthreads();
-
-  FkOut none = {};
   const bool hit = run_config<double, MAXS, false, WBOX, MBOX>(c.ip, c.tp, c.col0 + threadIdx.x, B,
                                                                c.save + threadIdx.x, B, active, 0.0, none,
                                                                i) == V_CONTACT;
-  if (uc.count) {
-    if (active && hit && uc.ga[i] < 0) {  // pair-level items belong to k_patch_pairs
-      const int ed = uc.edge[i];
-      valid[ed] = 0;
-      // first_bad holds -1 (= UINT_MAX) for "valid so far": an unsigned min keeps the lowest index
-      if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)uc.idx[i]);
-    }
-    return;
-  }
   if (valid && active) valid[i] = hit ? 0 : 1;
   if (bits) {
     unsigned long long m = __ballot(active && !hit);
@@ -532,7 +536,8 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
   extern __shared__ double smem[];
   const int B = blockDim.x;
   const int nplan = gip[H_NPLAN];
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B);
+  // (immediate interpreter + item expansion: a second column set holds the walking waypoint)
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, (!kQueued<float, MBOX> && ib.count) ? 2 : 1, B);
   const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
   const bool active = i < E;
   double *qw = c.col0 + threadIdx.x;
@@ -590,6 +595,10 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
         if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
         return;
       }
+    } else {
+      expand_edge(gip, QA, E, i, step, layout, survive, qw, B, c.col1 + threadIdx.x, B, ib);
+      if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
+      return;
     }
     if (survive) ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;  // too many columns: walking kernel
     return;
@@ -939,11 +948,25 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
       valid[ed] = 0;
       if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)ib.idx[it]);
     } else {
-      // could not hand the undecided pair over: the exact edge kernel redoes the whole edge.  An
+      bool handed = false;
+      if constexpr (!kQueued<float, MBOX>) {
+        // immediate interpreter: the whole configuration goes to the exact configuration kernel
+        if (uc.count) {
+          const int j = atomicAdd(uc.count, 1);
+          if (j < uc.cap) {
+            for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = ib.w[itc * nplan + k];
+            uc.edge[j] = ed;
+            uc.idx[j] = ib.idx[it];
+            uc.ga[j] = uc.gb[j] = -1;
+            handed = true;
+          }
+        }
+      }
+      // could not hand the undecided item over: the exact edge kernel redoes the whole edge.  An
       // edge has up to K items here, but `ulist` holds E entries and the re-run has one lane per
       // entry: the first item to claim the edge (generation-stamped word, never cleared between
       // launches) lists it, the others find it listed.
-      if (atomicExch(&ib.claim[ed], ib.gen) != ib.gen) ulist[atomicAdd(ucount, 1)] = ed;
+      if (!handed && atomicExch(&ib.claim[ed], ib.gen) != ib.gen) ulist[atomicAdd(ucount, 1)] = ed;
     }
   }
 }
@@ -970,15 +993,16 @@ k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ g
   if ((int64_t)blockIdx.x * B >= n) return;
   const int nplan = gip[H_NPLAN];
   Carve<double> c = carve_lds<double>(smem, gip, nip, gdp, ndp, nplan, 1, B);
-  const int64_t u = (int64_t)blockIdx.x * B + threadIdx.x;
+  // the number of items is read on the device and may exceed the grid: blocks stride over it
+  for (int64_t base = (int64_t)blockIdx.x * B; base < n; base += (int64_t)gridDim.x * B) {
+  const int64_t u = base + threadIdx.x;
   bool active = u < n;
   const int ga = active ? uc.ga[u] : -1;
   const int gb = active ? uc.gb[u] : -1;
   active = active && ga >= 0;
   double *q = c.col0 + threadIdx.x;
-  load_columns(q, B, uc.q, n, u, nplan, MJPL_AOS, active);
-  __syncthreads();
-  if (__ballot(active) == 0ull) return;
+  load_columns(q, B, uc.q, n, u < n ? u : 0, nplan, MJPL_AOS, active);
+  if (__ballot(active) == 0ull) continue;
 
   typedef GeomT<double> Geom;
   IP ip = c.ip;
@@ -1104,7 +1128,7 @@ k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ g
       for (int k = 0; k < 9; k++) { A.m[k] = isa ? cur.m[k] : A.m[k]; Bg.m[k] = isb ? cur.m[k] : Bg.m[k]; }
     }
   }
-  if (!active) return;
+  if (!active) continue;
   const double *ta = gt.t + (size_t)ga * GTB_LEN, *tb = gt.t + (size_t)gb * GTB_LEN;
   if (tb[GTB_STATIC] != 0.0) {
 #pragma unroll
@@ -1133,7 +1157,7 @@ k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ g
     const double dx = A.pos[0] - Bg.pos[0], dy = A.pos[1] - Bg.pos[1], dz = A.pos[2] - Bg.pos[2];
     pass = !(dx * dx + dy * dy + dz * dz > bsum * bsum);
   }
-  if (!pass) return;
+  if (!pass) continue;
   // the partner is the first geom of the pair if its type is smaller, geom id breaking ties
   const bool pfirst = (tyb < tya) || (tyb == tya && gb < ga);
   const int code = pair_contact<double, true, true>(tya, A, sa, tyb, Bg, sb, pfirst, margin, 0.0);
@@ -1141,6 +1165,7 @@ k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ g
     const int ed = uc.edge[u];
     valid[ed] = 0;
     if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)uc.idx[u]);
+  }
   }
 }
 
@@ -1274,6 +1299,9 @@ struct mjpl_engine {
   size_t uc_cap = 0, uc_cap_limit = 0;
   int nslots = 0, nsave = 0, maxs = 4;
   bool wbox = false, mbox = false;
+  // the immediate (non-queued) interpreter serves models with moving boxes and models that keep
+  // more than 16 geoms in the slot file (one general <32, true, true> build)
+  bool immediate() const { return mbox || maxs > 16; }
   int npairs = 0, npairs_world = 0, nmoving = 0, nstatic = 0;
   // static poses for FK output
   std::vector<double> st_xpos, st_xquat, st_gxpos, st_gxmat;
@@ -1477,7 +1505,7 @@ int compile_program(mjpl_engine *e) {
   if (e->nslots > MAX_SLOTS)
     return fail(MJPL_E_CAPACITY, "%d moving geoms must be held at once; this build has %d register slots",
                 e->nslots, (int)MAX_SLOTS);
-  e->maxs = e->nslots <= 4 ? 4 : (e->nslots <= 8 ? 8 : 16);  // vector widths with indirect addressing
+  e->maxs = e->nslots <= 4 ? 4 : (e->nslots <= 8 ? 8 : (e->nslots <= 16 ? 16 : 32));  // vector widths with indirect addressing
   e->nsave = nsave;
 
   // ---- emit
@@ -1858,14 +1886,16 @@ int allow_lds(K kernel, size_t bytes) {
 template <class F>
 int dispatch_variant(const mjpl_engine *e, F &&f) {
   auto with_box = [&](auto S) -> int {
-    if (e->mbox) return f(S, std::true_type{}, std::true_type{});  // moving boxes: general build
+    if (e->immediate()) return f(S, std::true_type{}, std::true_type{});  // moving boxes: general build
     if (e->wbox) return f(S, std::true_type{}, std::false_type{});
     return f(S, std::false_type{}, std::false_type{});
   };
   switch (e->maxs) {
     case 4: return with_box(std::integral_constant<int, 4>{});
     case 8: return with_box(std::integral_constant<int, 8>{});
-    default: return with_box(std::integral_constant<int, 16>{});
+    case 16: return with_box(std::integral_constant<int, 16>{});
+    // more than 16 stored geoms at once (e.g. a gripper with many pad boxes): one general build
+    default: return f(std::integral_constant<int, 32>{}, std::true_type{}, std::true_type{});
   }
 }
 
@@ -1877,7 +1907,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
   if (filter) {
     int rc = ulist_reserve(e, N);
     UndecidedConfigs uc = {};
-    if (rc == MJPL_OK && !e->mbox) {
+    if (rc == MJPL_OK && !e->immediate()) {
       rc = uc_reserve(e, N);
       uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
       uc.ga = e->d_ucga; uc.gb = e->d_ucgb;
@@ -1886,9 +1916,9 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
     }
     if (rc != MJPL_OK) return rc;
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
-    const int fblock = e->mbox ? kBlock : kFilterBlock;
+    const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
-    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
+    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate());
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
@@ -1947,15 +1977,18 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
     MJPL_MARK(0);
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
-    const int fblock = e->mbox ? kBlock : kFilterBlock;
+    const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
-    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->mbox);
+    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate());
+    // the endpoint kernel of the immediate interpreter walks the waypoint recurrence in a second
+    // column set (the queued one uses its idle queue memory)
+    const size_t ldse = e->immediate() ? lds_bytes(e, 2, sizeof(float), fblock, false) : ldsf;
     // two passes unless only the interior was asked for: endpoints of all edges, then the interior
     // waypoints of the edges whose endpoint passed
     const bool two_pass = e->two_pass && !(flags & MJPL_EDGE_INTERIOR_ONLY);
     // interior waypoints: one lane per waypoint for ordinary edges (the endpoint kernel emits the
     // waypoints as items), the walking kernel for long edges and for models with moving boxes
-    const bool expand = two_pass && e->expand && !e->mbox;
+    const bool expand = two_pass && e->expand;
     const int *rlist = nullptr, *rcount = nullptr;  // work list of the walking kernel
     ItemBuffers ib = {};
     if (expand) {
@@ -1998,9 +2031,9 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       rcount = e->d_ucount + 2 * kCtr;
       rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_endpoints<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
-        int r = allow_lds(kern, ldsf);
+        int r = allow_lds(kern, ldse);
         if (r != MJPL_OK) return r;
-        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
+        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldse, e->stream, e->d_ip, (int)e->ip.size(),
                            e->d_fp, (int)e->fp.size(), dQA, dQB, E, layout, e->filter_tol, dvalid, dfb,
                            e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist, e->d_ucount + 2 * kCtr, ib, step);
         return MJPL_OK;
@@ -2010,7 +2043,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     MJPL_MARK(1);  // after k_filter_endpoints (nothing ran yet in a one-pass launch)
     if (expand) {
       const unsigned igrid = (unsigned)((e->item_cap + fblock - 1) / fblock);
-      const size_t ldsi = lds_bytes(e, 0, sizeof(float), fblock, true);
+      const size_t ldsi = lds_bytes(e, 0, sizeof(float), fblock, !e->immediate());
       rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_items<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldsi);
@@ -2041,7 +2074,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     // share of the batch; surplus blocks return at once)
     const size_t ldsc = lds_bytes(e, 1);
     const unsigned pgrid = (unsigned)std::min<size_t>((uc.cap + kBlock - 1) / kBlock, 1024);
-    if (e->mbox) {  // immediate filter: whole configurations
+    if (e->immediate()) {  // immediate filter: whole configurations
       rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_check_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldsc);
@@ -2291,8 +2324,8 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   out->filter_err_a = (float)e->ferr_a;
   out->filter_err_b = (float)e->ferr_b;
   out->filter_poisoned_geoms = e->npoisoned;
-  out->filter_block_threads = e->mbox ? kBlock : kFilterBlock;
-  out->lds_bytes_filter = (int)lds_bytes(e, 1, sizeof(float), out->filter_block_threads, !e->mbox);
+  out->filter_block_threads = e->immediate() ? kBlock : kFilterBlock;
+  out->lds_bytes_filter = (int)lds_bytes(e, 1, sizeof(float), out->filter_block_threads, !e->immediate());
   out->block_threads = kBlock;
   out->compute_units = e->prop.multiProcessorCount;
   strncpy(out->arch, e->prop.gcnArchName, sizeof(out->arch) - 1);

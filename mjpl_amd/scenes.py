@@ -51,8 +51,21 @@ def load_obstacles(name: str = "obstacles16.json") -> list[dict]:
         return json.load(f)["obstacles"]
 
 
-def franka_p_builder(obstacles=False) -> ModelBuilder:
+# the ten fingertip pad boxes of the reference Panda, five per finger body:
+# (half-sizes, position in the finger frame), examples/models/franka_emika_panda/panda.xml:20-33,225-241
+FINGER_PADS = (((0.0085, 0.004, 0.0085), (0.0, 0.0055, 0.0445)),
+               ((0.003, 0.002, 0.003), (0.0055, 0.002, 0.05)),
+               ((0.003, 0.002, 0.003), (-0.0055, 0.002, 0.05)),
+               ((0.003, 0.002, 0.0035), (0.0055, 0.002, 0.0395)),
+               ((0.003, 0.002, 0.0035), (-0.0055, 0.002, 0.0395)))
+
+
+def franka_p_builder(obstacles=False, pads=False) -> ModelBuilder:
     mb = parse_mjcf(os.path.join(_MODELS, "franka_p.xml"))
+    if pads:
+        for finger in ("left_finger", "right_finger"):
+            for k, (size, pos) in enumerate(FINGER_PADS):
+                mb.add_geom(finger, "box", size, pos=pos, name=f"{finger}_pad{k + 1}")
     if obstacles:
         obs = load_obstacles() if obstacles is True else obstacles
         for k, o in enumerate(obs):
@@ -61,9 +74,10 @@ def franka_p_builder(obstacles=False) -> ModelBuilder:
     return mb
 
 
-def franka_p(obstacles=False) -> Model:
-    """Franka-P; ``obstacles=True`` adds the 16 committed box/sphere obstacles."""
-    return franka_p_builder(obstacles).compile()
+def franka_p(obstacles=False, pads=False) -> Model:
+    """Franka-P; ``obstacles=True`` adds the 16 committed box/sphere obstacles, ``pads=True`` the
+    ten fingertip pad boxes the reference Panda carries on its two finger bodies (moving boxes)."""
+    return franka_p_builder(obstacles, pads).compile()
 
 
 def ur5e() -> Model:

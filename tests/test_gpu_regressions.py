@@ -141,3 +141,45 @@ def test_engine_close_destroys_its_pose_handles():
     # site_pose without an engine builds and closes its own
     assert np.allclose(mjpl.site_pose(m, q, "ee_site").translation(), frame.translation())
     assert mjpl.CollisionConstraint.__doc__.startswith("Batched collision validation")
+
+
+@pytest.mark.parametrize("allowed", [(), (("left_finger", "right_finger"),)])
+def test_franka_with_the_ten_finger_pad_boxes(oracle_mod, allowed):
+    """The reference Panda carries ten pad boxes on its finger bodies (panda.xml:20-33,225-241):
+    moving boxes, 17 geoms held in the slot file at once.  Such models run the immediate
+    interpreter (general <32, true, true> build) with the lane-per-waypoint interior pass; verdicts
+    and first-bad indices must be the oracle's, filter on and off, fingers moving or not.
+    Clipping the random edges to the joint ranges puts both fingers at exactly 0 in some rows, where
+    opposite pads touch with a gap of +-1e-17: there the verdict hangs on the last bit of sin/cos, so
+    the oracle runs with its bit-reproducible trig (see test_gpu_filter_adversarial.py)."""
+    with oracle_mod.portable_trig():
+        _finger_pads(oracle_mod, allowed)
+
+
+def _finger_pads(oracle_mod, allowed):
+    m = scenes.franka_p(obstacles=True, pads=True)
+    base = m.keyframe("home").qpos.copy()
+    e = eng_mod.Engine(m, allowed)
+    info = e.info()
+    assert info["nmoving_geoms"] == 20 and info["filter_enabled"] == 1
+    assert (info["nslots"] > 16) == (not allowed)  # pad-against-pad pairs keep the left pads in the slot file
+    rng = np.random.default_rng(3)
+    for joints in (scenes.FRANKA_ARM_JOINTS, scenes.FRANKA_ARM_JOINTS + ["finger_joint1", "finger_joint2"]):
+        qidx = scenes.planning_index(m, joints)
+        b = base.copy()
+        b[7:] = rng.uniform(0.0, 0.04, size=2)
+        e.set_planning(qidx, b)
+        orc = oracle_mod.Oracle(m, allowed, planning_qidx=qidx, qpos_base=b)
+        qa, qb = random_edges(m, qidx, 30000, seed=len(joints))
+        want, wfb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
+        assert 0.05 < want.mean() < 0.95
+        for filt in (True, False):
+            e.set_filter(filt, 1e-4) if filt else e.set_filter(False)
+            got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+            np.testing.assert_array_equal(got, want, err_msg=f"{joints[-1]} filter={filt}")
+            np.testing.assert_array_equal(gfb, wfb, err_msg=f"{joints[-1]} filter={filt}")
+            if filt:
+                assert e.last_items() > len(qa)  # one lane per interior waypoint, also for this model
+        Q = np.concatenate([qa, qb])
+        np.testing.assert_array_equal(e.check_configs(Q), orc.valid_configs(Q, nthreads=8))
+    e.close()
