@@ -353,6 +353,72 @@ class ModelBuilder:
         )
 
 
+# ----------------------------------------------------------------------------- MJCF writer
+
+
+def to_mjcf(model: Model, name: str = "mjpl_amd_model") -> str:
+    """Primitive-only MJCF of a :class:`Model`: what ``mujoco.MjModel.from_xml_string`` needs to
+    rebuild the same kinematic tree and collision geoms, so that real MuJoCo (where it is
+    installed) can be asked for the verdicts this package computes (tools/crosscheck_mujoco.py).
+    Numbers are written with ``repr`` (round-trip exact); ``autolimits`` is off and every joint
+    carries its range explicitly; planes get a finite rendering size, which MuJoCo ignores for
+    collisions."""
+    inv_j = {v: k for k, v in _JNT_NAMES.items()}
+    inv_g = {v: k for k, v in _GEOM_NAMES.items()}
+
+    def v(a):
+        return " ".join(repr(float(x)) for x in np.asarray(a).ravel())
+
+    children: dict[int, list[int]] = {}
+    for b in range(1, model.nbody):
+        children.setdefault(int(model.body_parentid[b]), []).append(b)
+    out = [f'<mujoco model="{name}">', '  <compiler angle="radian" autolimits="false"/>',
+           '  <option gravity="0 0 0"/>']
+
+    def emit_body(b: int, ind: str):
+        if b == 0:
+            out.append(ind + "<worldbody>")
+        else:
+            out.append(f'{ind}<body name="{model.body_names[b]}" pos="{v(model.body_pos[b])}" '
+                       f'quat="{v(model.body_quat[b])}">')
+        for j in range(int(model.body_jntadr[b]), int(model.body_jntadr[b]) + int(model.body_jntnum[b])) \
+                if model.body_jntnum[b] else []:
+            lo, hi = model.jnt_range[j]
+            limited = "true" if (lo != 0.0 or hi != 0.0) else "false"
+            nm = f'name="{model.joint_names[j]}" ' if model.joint_names[j] else ""
+            out.append(f'{ind}  <joint {nm}type="{inv_j[int(model.jnt_type[j])]}" axis="{v(model.jnt_axis[j])}" '
+                       f'pos="{v(model.jnt_pos[j])}" limited="{limited}" range="{v(model.jnt_range[j])}" '
+                       f'ref="{repr(float(model.qpos0[model.jnt_qposadr[j]]))}"/>')
+        for g in range(model.ngeom):
+            if int(model.geom_bodyid[g]) != b:
+                continue
+            t = int(model.geom_type[g])
+            size = model.geom_size[g].copy()
+            nsz = {GEOM_PLANE: 3, GEOM_SPHERE: 1, GEOM_CAPSULE: 2, GEOM_CYLINDER: 2}.get(t, 3)
+            if t == GEOM_PLANE and size[0] == 0 and size[1] == 0:
+                size[2] = size[2] if size[2] > 0 else 0.1  # infinite plane: only the grid spacing must be > 0
+            nm = f'name="{model.geom_names[g]}" ' if model.geom_names[g] else ""
+            out.append(f'{ind}  <geom {nm}type="{inv_g[t]}" size="{v(size[:nsz])}" pos="{v(model.geom_pos[g])}" '
+                       f'quat="{v(model.geom_quat[g])}" contype="{int(model.geom_contype[g])}" '
+                       f'conaffinity="{int(model.geom_conaffinity[g])}" margin="{repr(float(model.geom_margin[g]))}"/>')
+        for k in range(model.nsite):
+            if int(model.site_bodyid[k]) == b:
+                out.append(f'{ind}  <site name="{model.site_names[k]}" pos="{v(model.site_pos[k])}" '
+                           f'quat="{v(model.site_quat[k])}"/>')
+        for c in children.get(b, []):
+            emit_body(c, ind + "  ")
+        out.append(ind + ("</worldbody>" if b == 0 else "</body>"))
+
+    emit_body(0, "  ")
+    if len(model.keyframe_names):
+        out.append("  <keyframe>")
+        for k, kn in enumerate(model.keyframe_names):
+            out.append(f'    <key name="{kn}" qpos="{v(model.key_qpos[k])}"/>')
+        out.append("  </keyframe>")
+    out.append("</mujoco>")
+    return "\n".join(out) + "\n"
+
+
 # ----------------------------------------------------------------------------- MJCF reader
 
 
