@@ -241,7 +241,7 @@ def bench_next_rows(args):
 
         def once():
             Qs, ok, its, err = eng.ik_solve("ee_site", target.translation(), target.rotation().wxyz, Q0, solver.movable,
-                                            iterations=200)
+                                            iterations=200, restarts=8, restart_seed=11)
             return Qs, ok, its, cc.valid_configs(Qs[ok])
 
         for _ in range(max(args.warmup, 1)):
@@ -254,6 +254,19 @@ def bench_next_rows(args):
         sample = np.flatnonzero(ok)[:2048]
         if not np.array_equal(orc.valid_configs(Qs[sample], nthreads=8).astype(bool), free[:len(sample)]):
             sys.exit("bench.py: collision filter differs from the CPU oracle")
+        # CPU baseline: the oracle's statement of the same iteration on a bounded sample of the seeds
+        cpu, cores, aff, quota = host_cpu()
+        k = 2048
+        t0 = time.perf_counter()
+        Qc, okc, itc, _ = pyoracle.ik_solve_batch(model, "ee_site", target.translation(), target.rotation().wxyz, Q0[:k],
+                                                  solver.movable, iterations=200, restarts=8, restart_seed=11, nthreads=cores)
+        freec = orc.valid_configs(Qc[okc], nthreads=cores)
+        dtc = time.perf_counter() - t0
+        if abs(float(okc.mean()) - float(ok[:k].mean())) > 0.05:
+            sys.exit("bench.py: GPU and CPU IK converge on different fractions of the same seeds")
+        cpu_ik = {"value": k / dtc, "unit": "seeds/s", "cores": cores, "kind": "port", "cpu_model": cpu, "affinity": aff,
+                  "cpu_quota": quota, "sample": f"first {k} seeds, {cores} threads, converged {okc.mean():.3f} "
+                                                f"(GPU on the same rows {ok[:k].mean():.3f}), {len(freec)} collision checks"}
         out = dict(common, metric="IK seeds/sec: damped-least-squares seeds -> FK -> collision filter (one GPU of configs[4])",
                    value=len(Q0) * args.steps / elapsed, unit="seeds/s", ms_per_step=elapsed / args.steps * 1e3,
                    config={"workload": f"{len(Q0)} seeds per launch, <= 200 iterations, host buffers (PCIe included)",
@@ -263,7 +276,7 @@ def bench_next_rows(args):
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "note": "latency of the iteration chain (256 waves on 1 024 SIMDs)"},
-                   cpu_baseline=None)
+                   cpu_baseline=cpu_ik)
     print(json.dumps(out), flush=True)
 
 

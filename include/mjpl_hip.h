@@ -307,6 +307,10 @@ typedef struct mjpl_ik_desc {
   double  max_step;           /* |dq|_inf limit per iteration, radians / metres; <= 0 -> 0.2   */
   const double  *jnt_range;   /* [njnt*2] mink.ConfigurationLimit (:86)                        */
   const uint8_t *movable;     /* [njnt] 1 for the solver's `joints`, 0 for held joints         */
+  int32_t restarts;           /* a stalled row re-draws its joints uniformly in their ranges, up to this
+                               * many times within `iterations` (the reference restarts a failed attempt
+                               * from random_config, :108-115); 0: none                           */
+  uint64_t restart_seed;      /* seed of those draws                                           */
 } mjpl_ik_desc;
 
 /* ok[i] = 1 iff row i reached the target within the tolerances; Q_out row i is its final

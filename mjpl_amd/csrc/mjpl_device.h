@@ -61,6 +61,22 @@ enum : int { V_NONE = 0, V_CONTACT = 1, V_UNSURE = 2 };
 enum : int { FC_MAXCOORD = 0, FC_MAXANGLE = 1, FC_SIZE = 4 };
 constexpr float kFilterMaxAngle = 6.5f;
 
+// ----------------------------------------------------------------------------- counter-based RNG
+// splitmix64 finaliser as a stateless generator: u01(key, counter).  The frontier planner's sampler
+// (mjpl_rrt.h; mirrored in NumPy by mjpl_amd/planning/parallel_rrt.py) and the IK restarts use it.
+MJPL_HD uint64_t sm64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+MJPL_HD uint64_t rrt_key(uint64_t seed, uint64_t rank, uint64_t round) {
+  return sm64(sm64(seed) ^ sm64((rank << 40) ^ round));
+}
+MJPL_HD double rrt_u01(uint64_t key, uint64_t ctr) {
+  return (double)(sm64(key + ctr * 0x9E3779B97F4A7C15ull) >> 11) * 0x1.0p-53;
+}
+
 // ----------------------------------------------------------------------------- program layout
 // The model is compiled on the host (mjpl_hip.hip: compile_program) into two flat tables that
 // every workgroup stages into LDS: `ip` (int32 control words) and `dp` (float64 constants).

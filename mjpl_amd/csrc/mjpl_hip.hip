@@ -117,8 +117,11 @@ __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restric
                                               int B) {
   Carve<T> c;
 #if MJPL_TABLES_LDS
-  T *tl = reinterpret_cast<T *>(smem);
-  const int tdoubles = (int)((ntp * sizeof(T) + 7) / 8);
+  // A/B build: [control words | constants | columns | saves | queues | ...], tables first so that
+  // their place does not depend on what the kernel carves behind the saves
+  int *il = reinterpret_cast<int *>(smem);
+  T *tl = reinterpret_cast<T *>(smem + (nip * sizeof(int) + 7) / 8);
+  const int tdoubles = (int)((nip * sizeof(int) + 7) / 8 + (ntp * sizeof(T) + 7) / 8);
   c.col0 = smem + tdoubles;
 #else
   c.col0 = smem;
@@ -134,7 +137,6 @@ __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restric
   if (!Real<T>::exact)
     for (int k = threadIdx.x; k < ntp; k += blockDim.x) c.ltab[k] = gtp[k];
 #if MJPL_TABLES_LDS
-  int *il = reinterpret_cast<int *>(c.save + (size_t)nsave * 7 * B);
   for (int k = threadIdx.x; k < ntp; k += blockDim.x) tl[k] = gtp[k];
   for (int k = threadIdx.x; k < nip; k += blockDim.x) il[k] = gip[k];
   c.ip = il;
@@ -816,7 +818,7 @@ k_pose_valid(const int *__restrict__ pi, const double *__restrict__ pd, const do
 __global__ void __launch_bounds__(kPoseBlock)
 k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Q,
            int64_t N, double *__restrict__ Qout, uint8_t *__restrict__ ok, int32_t *__restrict__ iters,
-           double *__restrict__ err) {
+           double *__restrict__ err, int max_restarts, uint64_t restart_seed) {
   extern __shared__ double smem[];
   constexpr int B = kPoseBlock;
   const int lane = threadIdx.x;
@@ -834,6 +836,19 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
   bool done = !active, solved = false;
   int it = 0;
   double epos = 0, eori = 0;
+  // Levenberg-Marquardt flavour of the damping: the error-proportional term is scaled up when an
+  // iteration made the error grow and relaxed when it shrank; joints that sit on a limit and are
+  // pushed further out are taken out of the step (one re-solve), otherwise a clamped joint keeps
+  // absorbing the step every iteration and the seed stalls on the boundary.
+  double lam_scale = 1.0, prev_err2 = 1.0e300;
+  // A seed that has not improved its best error by 1 % for 12 iterations sits in a local minimum
+  // (in practice: on joint limits) and more iterations do not move it.  Like the reference, which
+  // re-draws the start with random_config when an attempt fails (mink_ik_solver.py:108-115), the
+  // row then restarts from a fresh uniform draw of the solver's joints -- inside its iteration
+  // budget, up to max_restarts times.
+  double best_err2 = 1.0e300;
+  int best_it = 0, restarts = 0;
+  const uint64_t rkey = rrt_key(restart_seed, (uint64_t)i, 0x494bull);
   while (__ballot(!done) != 0ull) {
     if (!done) {
       PoseChainOut o;
@@ -847,12 +862,29 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
       } else if (it >= maxit) {
         done = true;
       } else {
-        const double lam = damp + lm * (epos * epos + eori * eori);
-        double A[6][6];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-          for (int c = 0; c < 6; c++) A[r][c] = (r == c) ? lam : 0.0;
+        const double err2 = epos * epos + eori * eori;
+        if (err2 < 0.98 * best_err2) { best_err2 = err2; best_it = it; }
+        if (it - best_it >= 12 && restarts < max_restarts) {
+          restarts++;
+          int ic2 = PH_SIZE;
+          for (int b = 0; b < pi[PH_NBODY]; b++) {
+            const int njnt = pi[ic2++];
+            for (int j = 0; j < njnt; j++, ic2 += 3) {
+              const int qadr = pi[ic2 + 1], jid = pi[ic2 + 2];
+              if (movable[jid] != 0.0) {
+                const double u = rrt_u01(rkey, (uint64_t)restarts * 64u + (uint64_t)(jid & 63));
+                qw[qadr * B] = jrange[2 * jid] + u * (jrange[2 * jid + 1] - jrange[2 * jid]);
+              }
+            }
+          }
+          lam_scale = 1.0; prev_err2 = 1.0e300; best_err2 = 1.0e300; best_it = it;
+          it++;
+          continue;
+        }
+        lam_scale = err2 > prev_err2 ? fmin(lam_scale * 4.0, 1.0e4) : fmax(lam_scale * 0.5, 1.0 / 64.0);
+        prev_err2 = err2;
+        const double lam = (damp + lm * err2) * lam_scale;
+        // Jacobian columns of the chain joints -> rows 0..5 of the store (held joints: zero)
         int ic = PH_SIZE, jk = 0;
         for (int b = 0; b < pi[PH_NBODY]; b++) {
           const int njnt = pi[ic++];
@@ -874,30 +906,62 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
             }
 #pragma unroll
             for (int r = 0; r < 6; r++) jst[(r * nj + jk) * B] = col[r];
+          }
+        }
+        unsigned locked = 0;
+        double scale = 1.0;
+        for (int pass = 0; pass < 2; pass++) {
+          double A[6][6];
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) A[r][c] = (r == c) ? lam : 0.0;
+          for (int k = 0; k < nj; k++) {
+            if ((locked >> (k & 31)) & 1u) continue;
+            double col[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) col[r] = jst[(r * nj + k) * B];
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
               for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
           }
-        }
-        double y[6];
-        chol6_solve(A, e, y);
-        // step length limit over the whole update, then apply + clamp to the joint ranges
-        double big = 0;
-        for (int k = 0; k < nj; k++) {
-          double acc = 0;
+          double y[6];
+          chol6_solve(A, e, y);
+          // dq of chain joint k -> row 6 of the store; step length limit over the whole update
+          double big = 0;
+          for (int k = 0; k < nj; k++) {
+            double acc = 0;
+            if (!((locked >> (k & 31)) & 1u)) {
 #pragma unroll
-          for (int r = 0; r < 6; r++) acc = acc + jst[(r * nj + k) * B] * y[r];
-          jst[k * B] = acc;  // row 0 of the store now holds dq of chain joint k
-          big = fabs(acc) > big ? fabs(acc) : big;
+              for (int r = 0; r < 6; r++) acc = acc + jst[(r * nj + k) * B] * y[r];
+            }
+            jst[(6 * nj + k) * B] = acc;
+            big = fabs(acc) > big ? fabs(acc) : big;
+          }
+          scale = big > max_step ? max_step / big : 1.0;
+          if (pass == 1 || nj > 32) break;
+          unsigned out = 0;
+          ic = PH_SIZE; jk = 0;
+          for (int b = 0; b < pi[PH_NBODY]; b++) {
+            const int njnt = pi[ic++];
+            for (int j = 0; j < njnt; j++, jk++, ic += 3) {
+              const int qadr = pi[ic + 1], jid = pi[ic + 2];
+              const double dq = jst[(6 * nj + jk) * B], v = qw[qadr * B];
+              const double span = jrange[2 * jid + 1] - jrange[2 * jid];
+              const bool at_lo = v <= jrange[2 * jid] + 1e-9 * span, at_hi = v >= jrange[2 * jid + 1] - 1e-9 * span;
+              if (movable[jid] != 0.0 && ((at_lo && dq < 0) || (at_hi && dq > 0))) out |= 1u << (jk & 31);
+            }
+          }
+          if (out == 0) break;
+          locked = out;
         }
-        const double scale = big > max_step ? max_step / big : 1.0;
         ic = PH_SIZE; jk = 0;
         for (int b = 0; b < pi[PH_NBODY]; b++) {
           const int njnt = pi[ic++];
           for (int j = 0; j < njnt; j++, jk++, ic += 3) {
             const int qadr = pi[ic + 1], jid = pi[ic + 2];
-            double v = qw[qadr * B] + scale * jst[jk * B];
+            double v = qw[qadr * B] + scale * jst[(6 * nj + jk) * B];
             if (movable[jid] != 0.0) {
               v = v < jrange[2 * jid] ? jrange[2 * jid] : v;
               v = v > jrange[2 * jid + 1] ? jrange[2 * jid + 1] : v;
@@ -1312,6 +1376,10 @@ struct mjpl_engine {
   // grow-only staging buffers for the host-pointer entry points
   void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+  // pinned, grow-only host block of the fused small-batch path of the host-pointer entry points
+  // (one H2D and one D2H per call instead of five copies from / to pageable memory)
+  void *h_pin = nullptr;
+  size_t h_pin_bytes = 0;
 };
 
 namespace {
@@ -1326,6 +1394,18 @@ int stage_reserve(mjpl_engine *e, int k, size_t bytes) {
   e->stage_bytes[k] = want;
   return MJPL_OK;
 }
+
+int pin_reserve(mjpl_engine *e, size_t bytes) {
+  if (bytes <= e->h_pin_bytes) return MJPL_OK;
+  if (e->h_pin) HIP_TRY(hipHostFree(e->h_pin));
+  e->h_pin = nullptr;
+  e->h_pin_bytes = 0;
+  const size_t want = std::max<size_t>(bytes, 1 << 16);
+  HIP_TRY(hipHostMalloc(&e->h_pin, want));
+  e->h_pin_bytes = want;
+  return MJPL_OK;
+}
+constexpr size_t kFusedHostBytes = (size_t)256 << 10;  // batches up to this size take the fused path
 
 // mj_collision pair filters [MJ-recalled: engine_collision_driver.c filterBitmask /
 // filterBodyPair] + the a6 ruleset folded in.  returns true if the pair is tested.
@@ -1806,7 +1886,7 @@ size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(doub
   bytes = (bytes + 7) & ~(size_t)7;
   if (queued) bytes += (size_t)(block / 64) * WaveQueue<float>::bytes() + ((e->fp.size() * sizeof(float) + 7) & ~(size_t)7);
 #if MJPL_TABLES_LDS
-  bytes += ((e->dp.size() * scalar + 7) / 8) * 8 + e->ip.size() * sizeof(int);
+  bytes += ((e->dp.size() * scalar + 7) / 8) * 8 + ((e->ip.size() * sizeof(int) + 7) / 8) * 8;
 #endif
   return bytes ? bytes : 8;
 }
@@ -2226,6 +2306,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->comm) (void)mjpl_comm_destroy(e);
   for (int k = 0; k < 6; k++)
     if (e->stage[k]) (void)hipFree(e->stage[k]);
+  if (e->h_pin) (void)hipHostFree(e->h_pin);
   if (e->d_ip) (void)hipFree(e->d_ip);
   if (e->d_dp) (void)hipFree(e->d_dp);
   if (e->d_fp) (void)hipFree(e->d_fp);
@@ -2423,6 +2504,18 @@ int mjpl_check_configs(mjpl_engine *e, const double *Q, int64_t N, int32_t layou
   const size_t qb = (size_t)N * e->qidx.size() * sizeof(double);
   if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
   if ((rc = stage_reserve(e, 2, (size_t)N)) != MJPL_OK) return rc;
+  if (qb + (size_t)N <= kFusedHostBytes) {
+    // planner-sized batch: through the pinned block, one copy each way
+    if ((rc = pin_reserve(e, qb + (size_t)N)) != MJPL_OK) return rc;
+    char *pin = (char *)e->h_pin;
+    memcpy(pin, Q, qb);
+    HIP_TRY(hipMemcpyAsync(e->stage[0], pin, qb, hipMemcpyHostToDevice, e->stream));
+    if ((rc = launch_configs(e, (const double *)e->stage[0], N, layout, (uint8_t *)e->stage[2], nullptr)) != MJPL_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(pin + qb, e->stage[2], (size_t)N, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(valid, pin + qb, (size_t)N);
+    return MJPL_OK;
+  }
   HIP_TRY(hipMemcpyAsync(e->stage[0], Q, qb, hipMemcpyHostToDevice, e->stream));
   if ((rc = launch_configs(e, (const double *)e->stage[0], N, layout, (uint8_t *)e->stage[2], nullptr)) != MJPL_OK) return rc;
   HIP_TRY(hipMemcpyAsync(valid, e->stage[2], (size_t)N, hipMemcpyDeviceToHost, e->stream));
@@ -2439,6 +2532,34 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
   if (!QB || !valid) return fail(MJPL_E_ARG, "NULL pointer");
   HIP_TRY(hipSetDevice(e->device));
   const size_t qb = (size_t)E * e->qidx.size() * sizeof(double);
+  if (2 * qb + 5 * (size_t)E + 16 <= kFusedHostBytes) {
+    // planner-sized batch: QA | QB go up in one copy from the pinned block, valid | first_bad |
+    // status come back in one
+    const size_t vb = ((size_t)E + 7) & ~(size_t)7, fbb = (size_t)E * sizeof(int32_t);
+    if ((rc = stage_reserve(e, 0, 2 * qb)) != MJPL_OK) return rc;
+    if ((rc = stage_reserve(e, 2, vb + fbb + 8)) != MJPL_OK) return rc;
+    if ((rc = pin_reserve(e, 2 * qb + vb + fbb + 8)) != MJPL_OK) return rc;
+    char *pin = (char *)e->h_pin;
+    memcpy(pin, QA, qb);
+    memcpy(pin + qb, QB, qb);
+    char *dq = (char *)e->stage[0], *dout = (char *)e->stage[2];
+    HIP_TRY(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
+    HIP_TRY(hipMemcpyAsync(dq, pin, 2 * qb, hipMemcpyHostToDevice, e->stream));
+    if ((rc = launch_edges(e, (const double *)dq, (const double *)(dq + qb), E, step_dist, layout, flags, (uint8_t *)dout,
+                           first_bad ? (int32_t *)(dout + vb) : nullptr)) != MJPL_OK)
+      return rc;
+    HIP_TRY(hipMemcpyAsync(dout + vb + fbb, e->d_status, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+    char *hout = pin + 2 * qb;
+    HIP_TRY(hipMemcpyAsync(hout, dout, vb + fbb + 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(valid, hout, (size_t)E);
+    if (first_bad) memcpy(first_bad, hout + vb, fbb);
+    int status = 0;
+    memcpy(&status, hout + vb + fbb, sizeof(int));
+    if (status & kStatusNonFinite)
+      return fail(MJPL_E_NONFINITE, "an edge holds NaN/inf or needs more than %d waypoints", kMaxWaypoints);
+    return MJPL_OK;
+  }
   if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
   if ((rc = stage_reserve(e, 1, qb)) != MJPL_OK) return rc;
   if ((rc = stage_reserve(e, 2, (size_t)E)) != MJPL_OK) return rc;
@@ -2841,7 +2962,7 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, i
   pi[PH_OFF_JRANGE] = (int)pd.size();
   for (int k = 0; k < 2 * m.njnt; k++) pd.push_back(d->jnt_range[k]);
   for (int k = 0; k < m.njnt; k++) pd.push_back(d->movable[k] ? 1.0 : 0.0);
-  const size_t lds = (size_t)kPoseBlock * sizeof(double) * ((size_t)m.nq + 6 * (size_t)nj);
+  const size_t lds = (size_t)kPoseBlock * sizeof(double) * ((size_t)m.nq + 7 * (size_t)nj);  // + the step row
   if (lds > 64 * 1024) return fail(MJPL_E_CAPACITY, "IK: %d qpos + %d chain joints exceed the LDS budget", m.nq, nj);
   HIP_TRY(hipSetDevice(e->device));
   // the program is tiny and changes with every target: staged through the engine's scratch
@@ -2854,7 +2975,7 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, i
   HIP_TRY(hipMemcpy(d_pd, pd.data(), db, hipMemcpyHostToDevice));
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
   hipLaunchKernelGGL(k_ik_solve, dim3(grid), dim3(kPoseBlock), lds, e->stream, d_pi, d_pd, dQ, N, dQout, dok,
-                     diters, derr);
+                     diters, derr, d->restarts > 0 ? d->restarts : 0, (uint64_t)d->restart_seed);
   HIP_TRY(hipGetLastError());
   return MJPL_OK;
 }

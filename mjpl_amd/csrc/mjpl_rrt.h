@@ -28,19 +28,7 @@ namespace {
 
 using namespace mjpl;
 
-// ----------------------------------------------------------------------------- RNG
-__host__ __device__ inline uint64_t sm64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__host__ __device__ inline uint64_t rrt_key(uint64_t seed, uint64_t rank, uint64_t round) {
-  return sm64(sm64(seed) ^ sm64((rank << 40) ^ round));
-}
-__host__ __device__ inline double rrt_u01(uint64_t key, uint64_t ctr) {
-  return (double)(sm64(key + ctr * 0x9E3779B97F4A7C15ull) >> 11) * 0x1.0p-53;
-}
+// (the counter-based generator -- sm64 / rrt_key / rrt_u01 -- lives in mjpl_device.h)
 
 // counters shared with the host (one 64-byte block, read back per chunk / per exchange)
 enum : int { RC_EDGES = 0, RC_ACC, RC_ACTIVE, RC_CONN, RC_CONN_REFA, RC_CONN_REFB, RC_NEWA, RC_NEWB,

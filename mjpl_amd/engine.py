@@ -76,6 +76,7 @@ class IKDesc(C.Structure):
         ("target_pos", C.c_double * 3), ("target_quat", C.c_double * 4), ("pos_tolerance", C.c_double),
         ("ori_tolerance", C.c_double), ("iterations", C.c_int32), ("damping", C.c_double),
         ("lm_damping", C.c_double), ("max_step", C.c_double), ("jnt_range", _F64P), ("movable", _U8P),
+        ("restarts", C.c_int32), ("restart_seed", C.c_uint64),
     ]
 
 
@@ -395,7 +396,8 @@ class Engine:
         return float(mean.value), {k: float(st[i]) for i, k in enumerate(self.STAGES)}, int(ns.value)
 
     def ik_solve(self, site: str, target_pos, target_quat, Q, movable, pos_tolerance=1e-3,
-                 ori_tolerance=1e-3, iterations=500, damping=0.0, lm_damping=-1.0, max_step=0.0):
+                 ori_tolerance=1e-3, iterations=500, damping=0.0, lm_damping=-1.0, max_step=0.0,
+                 restarts=0, restart_seed=0):
         """Batched damped-least-squares IK: rows of Q [N, nq] are start configurations.
         -> (Q_out [N, nq], ok bool[N], iters int32[N], err [N, 2])"""
         model = self.model
@@ -408,6 +410,7 @@ class Engine:
         d.target_quat[:] = [float(x) for x in target_quat]
         d.pos_tolerance, d.ori_tolerance, d.iterations = float(pos_tolerance), float(ori_tolerance), int(iterations)
         d.damping, d.lm_damping, d.max_step = float(damping), float(lm_damping), float(max_step)
+        d.restarts, d.restart_seed = int(restarts), int(restart_seed) & (2**64 - 1)
         rng = _f64(model.jnt_range).reshape(-1)
         mv = np.ascontiguousarray(movable, dtype=np.uint8)
         if mv.shape != (model.njnt,):

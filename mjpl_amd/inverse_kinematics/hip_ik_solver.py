@@ -27,7 +27,7 @@ class HipIKSolver(IKSolver):
     def __init__(self, model, joints: list[str], constraints: list[Constraint] = [],
                  pos_tolerance: float = 1e-3, ori_tolerance: float = 1e-3, seed: int | None = None,
                  max_attempts: int = 1, iterations: int = 500, num_seeds: int = 256,
-                 engine: _engine.Engine | None = None, device: int = 0):
+                 engine: _engine.Engine | None = None, device: int = 0, restarts: int = 8):
         if not joints:
             raise ValueError("`joints` cannot be empty.")
         if max_attempts < 1:
@@ -42,6 +42,7 @@ class HipIKSolver(IKSolver):
         self.pos_tolerance, self.ori_tolerance = pos_tolerance, ori_tolerance
         self.seed, self.max_attempts, self.iterations = seed, max_attempts, iterations
         self.num_seeds = num_seeds
+        self.restarts = restarts  # in-kernel re-draws of a stalled seed (the reference's restart, :108-115)
         self._owns_engine = engine is None
         self.engine = engine if engine is not None else _engine.Engine(model, device=device)
         self.q_idx = np.asarray(_utils.qpos_idx(model, joints), dtype=np.int64)
@@ -82,7 +83,8 @@ class HipIKSolver(IKSolver):
         """All rows of Q_start as seeds of one launch -> (Q, converged & obeys constraints, err)."""
         Q, ok, iters, err = self.engine.ik_solve(
             site, pose.translation(), pose.rotation().wxyz, Q_start, self.movable,
-            pos_tolerance=self.pos_tolerance, ori_tolerance=self.ori_tolerance, iterations=self.iterations)
+            pos_tolerance=self.pos_tolerance, ori_tolerance=self.ori_tolerance, iterations=self.iterations,
+            restarts=self.restarts, restart_seed=0 if self.seed is None else self.seed + 1)
         good = ok.copy()
         if good.any():
             idx = np.flatnonzero(good)

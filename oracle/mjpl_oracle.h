@@ -171,6 +171,25 @@ int orc_pose_apply(const orc_model *m, const orc_pose *p, const double *q_old, c
 int orc_pose_apply_batch(const orc_model *m, const orc_pose *p, const double *Q_old, const double *Q,
                          int64_t N, int32_t nthreads, double *Q_out, uint8_t *ok, int32_t *iters);
 
+/* IK seeds: the CPU statement of the product's damped-least-squares iteration (mjpl_oracle_pose.c);
+ * fields as mjpl_ik_desc in include/mjpl_hip.h */
+typedef struct orc_ik {
+  int32_t site_body;
+  double  site_pos[3], site_quat[4], target_pos[3], target_quat[4];
+  double  pos_tolerance, ori_tolerance;
+  int32_t iterations;
+  double  damping, lm_damping, max_step;
+  const double  *jnt_range;
+  const uint8_t *movable;
+  int32_t restarts;
+  uint64_t restart_seed;
+} orc_ik;
+/* one row: 1 solved / 0 not / < 0 error; `row` keys the restart draws */
+int orc_ik_solve(const orc_model *m, const orc_ik *d, const double *q0, int64_t row, double *q_out,
+                 int32_t *iters, double *err2);
+int orc_ik_solve_batch(const orc_model *m, const orc_ik *d, const double *Q, int64_t N, int32_t nthreads,
+                       double *Q_out, uint8_t *ok, int32_t *iters, double *err);
+
 /* sin/cos used by mju_axisAngle2Quat: 0 = libm (default, as MuJoCo), 1 = the fdlibm algorithm in
  * fixed-order IEEE double operations (bit-reproducible; see orc_math.h).  Process-wide. */
 void orc_set_trig(int mode);

@@ -353,3 +353,204 @@ int orc_pose_apply_batch(const orc_model *m, const orc_pose *p, const double *Q_
   }
   return status;
 }
+
+/* ------------------------------------------------------------------ IK seeds
+ * CPU statement of the damped-least-squares iteration of the product's k_ik_solve (the role of
+ * MinkIKSolver.solve_ik, src/mjpl/inverse_kinematics/mink_ik_solver.py:72-116, whose own arithmetic
+ * is a QP in the un-vendored mink / daqp wheels): world-frame 6-D pose error, J^T (J J^T + lam I)^-1 e
+ * with error-proportional, adaptively scaled damping, step-length limit, joint-range clamp with an
+ * active set, restarts from a uniform draw when a row stalls.  Test infrastructure and CPU baseline
+ * only; parity with the GPU is tolerance-level (both must reach the pose within the tolerances). */
+static uint64_t ik_sm64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static double ik_u01(uint64_t key, uint64_t ctr) {
+  return (double)(ik_sm64(key + ctr * 0x9E3779B97F4A7C15ull) >> 11) * 0x1.0p-53;
+}
+
+static void ik_pose_error(const orc_ik *d, const chain_kin *ck, double *e) {
+  double qs[4], qe[4];
+  mat2quat(qs, ck->site_xmat);
+  const double qc[4] = {qs[0], -qs[1], -qs[2], -qs[3]};
+  mul_quat(qe, d->target_quat, qc);
+  const double sgn = qe[0] < 0 ? -1.0 : 1.0;
+  const double w = sgn * qe[0], v[3] = {sgn * qe[1], sgn * qe[2], sgn * qe[3]};
+  const double sn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const double k = sn > 1e-12 ? 2 * atan2(sn, w) / sn : 2.0;
+  for (int c = 0; c < 3; c++) { e[c] = d->target_pos[c] - ck->site_xpos[c]; e[3 + c] = k * v[c]; }
+}
+
+static void chol6(double A[6][6], const double *b, double *x) {
+  double L[6][6] = {{0}};
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i][j];
+      for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+      L[i][j] = i == j ? sqrt(s > 1e-300 ? s : 1e-300) : s / L[j][j];
+    }
+  double y[6];
+  for (int i = 0; i < 6; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
+    y[i] = s / L[i][i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+}
+
+int orc_ik_solve(const orc_model *m, const orc_ik *d, const double *q0, int64_t row, double *q_out,
+                 int32_t *iters, double *err2) {
+  orc_pose ps;
+  memset(&ps, 0, sizeof(ps));
+  ps.site_body = d->site_body;
+  memcpy(ps.site_pos, d->site_pos, sizeof(ps.site_pos));
+  memcpy(ps.site_quat, d->site_quat, sizeof(ps.site_quat));
+  const int nq = m->nq;
+  double q[ORC_MAXCHAIN * 4];
+  if (nq > ORC_MAXCHAIN * 4) return ORC_E_OVERFLOW;
+  memcpy(q, q0, sizeof(double) * (size_t)nq);
+  const double damp = d->damping > 0 ? d->damping : 1e-6, lm = d->lm_damping >= 0 ? d->lm_damping : 0.1;
+  const double max_step = d->max_step > 0 ? d->max_step : 0.2;
+  double lam_scale = 1.0, prev = 1e300, best = 1e300, epos = 0, eori = 0;
+  int best_it = 0, restarts = 0, it = 0, solved = 0;
+  const uint64_t key = ik_sm64(ik_sm64(d->restart_seed) ^ ik_sm64(((uint64_t)row << 40) ^ 0x494bull));
+  for (;;) {
+    chain_kin ck;
+    int rc = chain_kinematics(m, &ps, q, &ck);
+    if (rc != ORC_OK) return rc;
+    double e[6];
+    ik_pose_error(d, &ck, e);
+    epos = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    eori = sqrt(e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
+    if (epos <= d->pos_tolerance && eori <= d->ori_tolerance) { solved = 1; break; }
+    if (it >= d->iterations) break;
+    const double e2 = epos * epos + eori * eori;
+    if (e2 < 0.98 * best) { best = e2; best_it = it; }
+    if (it - best_it >= 12 && restarts < d->restarts) {
+      restarts++;
+      for (int k = 0; k < ck.njoint; k++) {
+        const int jid = ck.jid[k];
+        if (d->movable[jid]) {
+          const double u = ik_u01(key, (uint64_t)restarts * 64u + (uint64_t)(jid & 63));
+          q[m->jnt_qposadr[jid]] = d->jnt_range[2 * jid] + u * (d->jnt_range[2 * jid + 1] - d->jnt_range[2 * jid]);
+        }
+      }
+      lam_scale = 1.0; prev = 1e300; best = 1e300; best_it = it;
+      it++;
+      continue;
+    }
+    lam_scale = e2 > prev ? fmin(lam_scale * 4.0, 1e4) : fmax(lam_scale * 0.5, 1.0 / 64.0);
+    prev = e2;
+    const double lam = (damp + lm * e2) * lam_scale;
+    double col[ORC_MAXCHAIN][6], dq[ORC_MAXCHAIN];
+    for (int k = 0; k < ck.njoint; k++) {
+      const int jid = ck.jid[k];
+      const double mv = d->movable[jid] ? 1.0 : 0.0, *ax = ck.xaxis[k];
+      if (m->jnt_type[jid] == ORC_JNT_HINGE) {
+        const double r[3] = {ck.site_xpos[0] - ck.xanchor[k][0], ck.site_xpos[1] - ck.xanchor[k][1],
+                             ck.site_xpos[2] - ck.xanchor[k][2]};
+        col[k][0] = mv * (ax[1] * r[2] - ax[2] * r[1]);
+        col[k][1] = mv * (ax[2] * r[0] - ax[0] * r[2]);
+        col[k][2] = mv * (ax[0] * r[1] - ax[1] * r[0]);
+        col[k][3] = mv * ax[0]; col[k][4] = mv * ax[1]; col[k][5] = mv * ax[2];
+      } else {
+        col[k][0] = mv * ax[0]; col[k][1] = mv * ax[1]; col[k][2] = mv * ax[2];
+        col[k][3] = col[k][4] = col[k][5] = 0;
+      }
+    }
+    unsigned locked = 0;
+    double scale = 1.0;
+    for (int pass = 0; pass < 2; pass++) {
+      double A[6][6], y[6];
+      for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) A[r][c] = r == c ? lam : 0.0;
+      for (int k = 0; k < ck.njoint; k++) {
+        if ((locked >> (k & 31)) & 1u) continue;
+        for (int r = 0; r < 6; r++)
+          for (int c = 0; c < 6; c++) A[r][c] += col[k][r] * col[k][c];
+      }
+      chol6(A, e, y);
+      double big = 0;
+      for (int k = 0; k < ck.njoint; k++) {
+        double acc = 0;
+        if (!((locked >> (k & 31)) & 1u))
+          for (int r = 0; r < 6; r++) acc += col[k][r] * y[r];
+        dq[k] = acc;
+        if (fabs(acc) > big) big = fabs(acc);
+      }
+      scale = big > max_step ? max_step / big : 1.0;
+      if (pass == 1 || ck.njoint > 32) break;
+      unsigned out = 0;
+      for (int k = 0; k < ck.njoint; k++) {
+        const int jid = ck.jid[k];
+        const double v = q[m->jnt_qposadr[jid]], lo = d->jnt_range[2 * jid], hi = d->jnt_range[2 * jid + 1];
+        const double span = hi - lo;
+        if (d->movable[jid] && ((v <= lo + 1e-9 * span && dq[k] < 0) || (v >= hi - 1e-9 * span && dq[k] > 0)))
+          out |= 1u << (k & 31);
+      }
+      if (!out) break;
+      locked = out;
+    }
+    for (int k = 0; k < ck.njoint; k++) {
+      const int jid = ck.jid[k];
+      if (!d->movable[jid]) continue;
+      double v = q[m->jnt_qposadr[jid]] + scale * dq[k];
+      v = v < d->jnt_range[2 * jid] ? d->jnt_range[2 * jid] : v;
+      v = v > d->jnt_range[2 * jid + 1] ? d->jnt_range[2 * jid + 1] : v;
+      q[m->jnt_qposadr[jid]] = v;
+    }
+    it++;
+  }
+  memcpy(q_out, q, sizeof(double) * (size_t)nq);
+  if (iters) *iters = it;
+  if (err2) { err2[0] = epos; err2[1] = eori; }
+  return solved;
+}
+
+typedef struct ik_job {
+  const orc_model *m; const orc_ik *d; const double *Q; double *Q_out; uint8_t *ok; int32_t *iters; double *err;
+  int64_t lo, hi; int status;
+} ik_job;
+
+static void *ik_job_run(void *arg) {
+  ik_job *j = (ik_job *)arg;
+  const int nq = j->m->nq;
+  for (int64_t i = j->lo; i < j->hi; i++) {
+    int32_t it = 0;
+    double e2[2] = {0, 0};
+    int rc = orc_ik_solve(j->m, j->d, j->Q + i * nq, i, j->Q_out + i * nq, &it, e2);
+    j->ok[i] = rc == 1;
+    if (j->iters) j->iters[i] = it;
+    if (j->err) { j->err[2 * i] = e2[0]; j->err[2 * i + 1] = e2[1]; }
+    if (rc < 0) j->status = rc;
+  }
+  return NULL;
+}
+
+int orc_ik_solve_batch(const orc_model *m, const orc_ik *d, const double *Q, int64_t N, int32_t nthreads,
+                       double *Q_out, uint8_t *ok, int32_t *iters, double *err) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 512) nthreads = 512;
+  ik_job jobs[512];
+  pthread_t th[512];
+  const int64_t chunk = (N + nthreads - 1) / nthreads;
+  int status = ORC_OK;
+  for (int t = 0; t < nthreads; t++) {
+    ik_job jb = {m, d, Q, Q_out, ok, iters, err, t * chunk, (t + 1) * chunk < N ? (t + 1) * chunk : N, ORC_OK};
+    if (jb.lo > N) jb.lo = N;
+    jobs[t] = jb;
+    if (nthreads == 1) ik_job_run(&jobs[t]);
+    else pthread_create(&th[t], NULL, ik_job_run, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; t++) {
+    if (nthreads > 1) pthread_join(th[t], NULL);
+    if (jobs[t].status != ORC_OK) status = jobs[t].status;
+  }
+  return status;
+}

@@ -350,3 +350,41 @@ class PoseOracle:
                                         ok.ctypes.data_as(C.POINTER(C.c_uint8)), _p(iters, _I32P))
         assert rc == 0, rc
         return out, ok.astype(bool), iters
+
+
+class _OrcIK(C.Structure):
+    _fields_ = [("site_body", C.c_int32), ("site_pos", C.c_double * 3), ("site_quat", C.c_double * 4),
+                ("target_pos", C.c_double * 3), ("target_quat", C.c_double * 4), ("pos_tolerance", C.c_double),
+                ("ori_tolerance", C.c_double), ("iterations", C.c_int32), ("damping", C.c_double),
+                ("lm_damping", C.c_double), ("max_step", C.c_double), ("jnt_range", _F64P),
+                ("movable", C.POINTER(C.c_uint8)), ("restarts", C.c_int32), ("restart_seed", C.c_uint64)]
+
+
+def ik_solve_batch(model, site: str, target_pos, target_quat, Q, movable, pos_tolerance=1e-3, ori_tolerance=1e-3,
+                   iterations=200, restarts=0, restart_seed=0, nthreads=1):
+    """CPU statement of the product's IK-seed iteration (oracle/mjpl_oracle_pose.c: orc_ik_solve).
+    -> (Q_out [N, nq], ok bool[N], iters int32[N], err [N, 2])"""
+    orc = Oracle(model)
+    sid = model.site(site).id
+    d = _OrcIK()
+    d.site_body = int(model.site_bodyid[sid])
+    d.site_pos[:] = list(map(float, model.site_pos[sid]))
+    d.site_quat[:] = list(map(float, model.site_quat[sid]))
+    d.target_pos[:] = list(map(float, target_pos))
+    d.target_quat[:] = list(map(float, target_quat))
+    d.pos_tolerance, d.ori_tolerance, d.iterations = float(pos_tolerance), float(ori_tolerance), int(iterations)
+    d.damping, d.lm_damping, d.max_step = 0.0, -1.0, 0.0
+    rng = _f64(model.jnt_range).reshape(-1)
+    mv = np.ascontiguousarray(movable, dtype=np.uint8)
+    d.jnt_range, d.movable = _p(rng, _F64P), mv.ctypes.data_as(C.POINTER(C.c_uint8))
+    d.restarts, d.restart_seed = int(restarts), int(restart_seed) & (2**64 - 1)
+    Q = _f64(Q)
+    n = len(Q)
+    out, ok, its, err = np.empty_like(Q), np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 2))
+    f = lib().orc_ik_solve_batch
+    f.restype = C.c_int
+    rc = f(C.byref(orc._m), C.byref(d), _p(Q, _F64P), C.c_int64(n), C.c_int32(nthreads), _p(out, _F64P),
+           ok.ctypes.data_as(C.POINTER(C.c_uint8)), its.ctypes.data_as(_I32P), _p(err, _F64P))
+    if rc < 0:
+        raise RuntimeError(f"orc_ik_solve_batch status {rc}")
+    return out, ok.astype(bool), its, err

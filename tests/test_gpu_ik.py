@@ -171,3 +171,31 @@ def test_ik_on_random_chains(oracle_mod, seed):
         b = int(model.body_parentid[b])
     off = [j for j in range(model.njnt) if j not in chain]
     np.testing.assert_array_equal(Q[:, off], Q0[:, off])
+
+
+def test_restarts_lift_convergence_and_match_the_cpu_statement(oracle_mod):
+    """One GPU's share of configs[4] in miniature: uniform seeds stall on joint limits (local minima
+    of the clamped problem) in about half the rows; re-drawing a stalled row inside its iteration
+    budget -- the reference restarts failed attempts from random_config, mink_ik_solver.py:108-115 --
+    must lift convergence well above that, and the CPU statement of the same iteration
+    (oracle/mjpl_oracle_pose.c) must converge on the same fraction of the same seeds."""
+    import mjpl_amd as mjpl
+    from mjpl_amd import scenes
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    q_home = m.keyframe("home").qpos.copy()
+    cc = mjpl.CollisionConstraint(m)
+    solver = mjpl.HipIKSolver(m, joints, [], seed=3, num_seeds=4096, iterations=200, engine=cc.engine)
+    q_t = mjpl.random_config(m, q_home, joints, 5, [mjpl.JointLimitConstraint(m), cc])
+    target = mjpl.site_pose(m, q_t, "ee_site", engine=cc.engine)
+    Q0 = solver._seeds(q_home, np.random.default_rng(3))
+    args = ("ee_site", target.translation(), target.rotation().wxyz, Q0, solver.movable)
+    _, ok0, _, _ = cc.engine.ik_solve(*args, iterations=200)
+    Qs, ok8, its, err = cc.engine.ik_solve(*args, iterations=200, restarts=8, restart_seed=11)
+    assert ok8.mean() > 0.9 > ok0.mean()
+    assert (err[ok8] <= 1e-3).all() and its.max() <= 200
+    lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+    assert np.all((Qs >= lo) & (Qs <= hi)) and np.all(Qs[:, 7:] == q_home[7:])
+    _, okc, _, errc = oracle_mod.ik_solve_batch(m, *args, iterations=200, restarts=8, restart_seed=11, nthreads=8)
+    assert abs(okc.mean() - ok8.mean()) < 0.03
+    assert (okc == ok8).mean() > 0.9  # row by row they mostly agree (not bit for bit: another sin/cos)
