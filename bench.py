@@ -394,6 +394,7 @@ def main():
             "config": {"workload": workload, "edges_per_gpu": E, "layout": args.layout,
                        "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
                        "float32_filter": filt, "filter_tol_m": info["filter_tol"],
+                       "specialised_kernels": eng.spec_loaded(),
                        "undecided_items_last_step": eng.last_undecided(),
                        "edges_reaching_interior_pass": interior, "interior_waypoint_items": items,
                        "parallelism": f"edge-sharded x{world}, no data-path collective"},

@@ -321,6 +321,30 @@ int mjpl_ik_solve(mjpl_engine *e, const mjpl_ik_desc *desc, const double *Q, int
 int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *desc, const double *dQ, int64_t N, double *dQ_out,
                       uint8_t *dok, int32_t *diters, double *derr);
 
+/* ---- per-model specialised filter kernels ------------------------------
+ * mjpl_create compiles a model into a program (control words + constant tables) that generic kernels
+ * interpret.  mjpl_amd/specialise.py turns one such program into straight-line code, builds the
+ * float32 filter kernels around it as libmjpl_spec_<hash>.so, and an engine whose program has that
+ * hash launches them instead of the interpreting ones (same verdicts; MJPL_SPEC=0 disables,
+ * MJPL_SPEC_DIR overrides the directory `spec` next to the library).  mjpl_program_dump compiles a
+ * model on the host only -- no device needed -- and returns the program and its hash: call it with
+ * ip = fp = dp = NULL for the sizes, then with buffers. */
+typedef struct mjpl_program_info {
+  uint64_t hash;            /* FNV-1a of (ip, fp, kernel variant, MJPL_SPEC_ABI) */
+  int32_t maxs, wbox, mbox; /* kernel variant: slot-file width, static / moving boxes present */
+  int32_t immediate;        /* 1: the model runs the immediate interpreter (not specialisable yet) */
+  int32_t filter_usable;
+  float   filter_tol;
+  int32_t nslots, nsave;
+  int32_t spec_abi;
+} mjpl_program_info;
+int mjpl_program_dump(const mjpl_model_desc *model, const int32_t *allowed_bodies, int32_t nallowed,
+                      const int32_t *qidx, int32_t nplan, const double *qpos_base, double filter_tol,
+                      int32_t *ip, int32_t *nip, float *fp, double *dp, int32_t *ntab,
+                      mjpl_program_info *info);
+/* 1 if the engine's current program runs on a specialised library */
+int mjpl_spec_loaded(const mjpl_engine *e);
+
 /* ---- frontier bi-RRT, device-resident (BASELINE configs[3]) -------------
  * RRT.plan_to_configs' sample / extend / connect loop (src/mjpl/planning/rrt.py:190-235) for `lanes`
  * samples per round, with _constrained_extend's per-step rules (src/mjpl/planning/utils.py:139-164):

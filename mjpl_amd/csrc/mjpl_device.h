@@ -767,6 +767,18 @@ __device__ __forceinline__ double bcast(double v, int l) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// Park a 64-bit wave mask in lane LANE (a literal) of the register pair (lo, hi): two
+// v_writelane_b32.  This clang has the readlane builtin but not the writelane one, and the hazard
+// recogniser does not look inside inline asm: a VALU-written SGPR / VCC (the v_cmp that produced the
+// mask) needs two wait states before another VALU instruction reads it as data on gfx94x/gfx950 --
+// without them the low half of the mask is sometimes stale -- hence the s_nop.
+template <int LANE>
+__device__ __forceinline__ void park_mask(int &lo, int &hi, unsigned long long m) {
+  asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+      : "+v"(lo), "+v"(hi)
+      : "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "n"(LANE));
+}
+
 // control words are wave-uniform: pin them to SGPRs so the interpreter's branches are scalar
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -1309,6 +1321,39 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
     }
   } while (ALL && qn > 0);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Append the lanes of `pm` (each with its own cur pose cur6 = pos + z axis; a slot partner's pose in
+// t6) to a wave's candidate queue, first draining one batch if they would not fit.  The interpreter
+// below carries this as a lambda; generated per-model code (mjpl_amd/specialise.py) calls it.
+template <class T, bool BOXQ>
+__device__ __forceinline__ void queue_push(const WaveQueue<T> &wq, int &fill, T &dead, int &fl, bool active, bool far,
+                                           const T *ltab, const T *lwcull, const T *lwnarrow, int nwpad, T tol,
+                                           const PatchSink &ps, unsigned long long pm, int kind, int index, int gtype,
+                                           int ptype, bool pfirst, int gdoff, const T *cur6, const T *t6) {
+  constexpr int CAP = BOXQ ? QB_CAP : QN_CAP;
+  const int lane = threadIdx.x & 63;
+  const int cnt = (int)__builtin_popcountll(pm);
+  if (fill + cnt > CAP) {  // make room: one batch leaves the top of the queue
+    queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps);
+    fl = wq.flags[lane] & 3;
+    dead = (fl != 0 || !active || far) ? T(__builtin_inff()) : T(0);
+  }
+  T *qf = BOXQ ? wq.bf : wq.nf;
+  int *qi0 = BOXQ ? wq.bi0 : wq.ni0, *qi1 = BOXQ ? wq.bi1 : wq.ni1;
+  const bool mine = (pm >> lane) & 1ull;
+  const int off = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) qf[k * CAP + off] = cur6[k];
+    if (!BOXQ && kind == EK_SLOT) {  // a static partner's pose is read from the world tables at the drain
+#pragma unroll
+      for (int k = 0; k < 6; k++) qf[(6 + k) * CAP + off] = t6[k];
+    }
+    qi0[off] = lane | (gtype << 6) | (ptype << 10) | ((pfirst ? 1 : 0) << 14) | (kind << 15) | (index << 17);
+    qi1[off] = gdoff;
+  }
+  fill += cnt;
 }
 
 // Queued version of run_config for models without moving boxes (slots hold pos + z axis).

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <dlfcn.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -24,16 +25,14 @@
 
 #include "../../include/mjpl_hip.h"
 #include "mjpl_device.h"
+#include "mjpl_filter.h"
 #include "mjpl_pose.h"
 
 namespace {
 
 using namespace mjpl;
 
-constexpr int kBlock = 256;           // threads per workgroup: 4 wavefronts
-constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts share one LDS table copy
 constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
-constexpr int kStatusNonFinite = 1;
 constexpr int kCtr = 32;  // ints between device counters: one 128-byte line each
 
 thread_local std::string g_err;
@@ -57,106 +56,6 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 // ------------------------------------------------------------------------------- kernels
-
-// LDS carve shared by all kernels: [tables (A/B build only) | float64 columns | pose saves].
-// With the default build the tables stay in global memory (scalar loads).
-template <class T>
-struct Carve {
-  double *col0, *col1;
-  T *save;
-  char *qmem;  // per-wave candidate queues (queued kernels), after the pose saves
-  T *ltab;     // queued kernels: the workgroup's LDS copy of the constant table (drain gathers)
-  IP ip;
-  typename Real<T>::Tab tp;
-};
-
-// queued narrowphase: the float32 filter of models without moving boxes
-template <class T, bool MBOX>
-constexpr bool kQueued = !Real<T>::exact && !MBOX;
-
-template <class T>
-__device__ __forceinline__ WaveQueue<T> wave_queue(char *qmem) {
-  char *base = qmem + (size_t)(threadIdx.x >> 6) * WaveQueue<T>::bytes();
-  WaveQueue<T> wq;
-  wq.carve(base);
-  return wq;
-}
-
-template <class T, int MAXS, bool WBOX, bool MBOX>
-__device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int B, bool active, T tol,
-                                         int64_t row, const UndecidedConfigs &uc = UndecidedConfigs{},
-                                         int idx = 0, const int *item_edge = nullptr,
-                                         const int *item_idx = nullptr, const double *sink_q = nullptr,
-                                         int sink_stride = 0, int qstride = 0) {
-  if (qstride == 0) qstride = B;  // q[k * qstride]; the LDS pose saves always use stride B
-  if constexpr (kQueued<T, MBOX>) {
-    WaveQueue<T> wq = wave_queue<T>(c.qmem);
-    PatchSink ps;
-    ps.uc = uc;
-    // where a drain lane finds the owner's configuration: the LDS columns, or (lane-per-item
-    // kernel reading its configurations straight from the item buffer) global memory
-    ps.qcol = sink_q ? sink_q : c.col0 + (threadIdx.x & ~63);
-    ps.B = sink_q ? 1 : B;
-    ps.L = sink_q ? sink_stride : 1;
-    ps.nplan = c.ip[H_NPLAN];
-    ps.idx = idx;
-    ps.item_edge = item_edge;
-    ps.item_idx = item_idx;
-    return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, c.ltab, q, qstride, c.save + threadIdx.x, B, active, tol,
-                                            wq, (int)row, ps);
-  } else {
-    FkOut none = {};
-    return run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, q, qstride, c.save + threadIdx.x, B, active, tol,
-                                                  none, row);
-  }
-}
-
-template <class T>
-__device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restrict__ gip, int nip,
-                                              const T *__restrict__ gtp, int ntp, int nplan, int ncolsets,
-                                              int B) {
-  Carve<T> c;
-#if MJPL_TABLES_LDS
-  // A/B build: [control words | constants | columns | saves | queues | ...], tables first so that
-  // their place does not depend on what the kernel carves behind the saves
-  int *il = reinterpret_cast<int *>(smem);
-  T *tl = reinterpret_cast<T *>(smem + (nip * sizeof(int) + 7) / 8);
-  const int tdoubles = (int)((nip * sizeof(int) + 7) / 8 + (ntp * sizeof(T) + 7) / 8);
-  c.col0 = smem + tdoubles;
-#else
-  c.col0 = smem;
-#endif
-  c.col1 = c.col0 + (size_t)nplan * B;
-  c.save = reinterpret_cast<T *>(c.col0 + (size_t)ncolsets * nplan * B);
-  const int nsave = gip[H_NSAVE];
-  // queue memory starts 8-byte aligned after the saves
-  c.qmem = reinterpret_cast<char *>(c.col0) +
-           (((size_t)ncolsets * nplan * B * sizeof(double) + (size_t)nsave * 7 * B * sizeof(T) + 7) & ~(size_t)7);
-  // queued kernels: constant-table copy behind the queues (staged below, before the barrier)
-  c.ltab = reinterpret_cast<T *>(c.qmem + (size_t)(B / 64) * WaveQueue<T>::bytes());
-  if (!Real<T>::exact)
-    for (int k = threadIdx.x; k < ntp; k += blockDim.x) c.ltab[k] = gtp[k];
-#if MJPL_TABLES_LDS
-  for (int k = threadIdx.x; k < ntp; k += blockDim.x) tl[k] = gtp[k];
-  for (int k = threadIdx.x; k < nip; k += blockDim.x) il[k] = gip[k];
-  c.ip = il;
-  c.tp = tl;
-#else
-  c.ip = (IP)gip;
-  c.tp = (typename Real<T>::Tab)gtp;
-#endif
-  return c;
-}
-
-// planning columns of configuration i -> this lane's LDS column slice
-__device__ __forceinline__ void load_columns(double *col, int B, const double *__restrict__ Q,
-                                             int64_t N, int64_t i, int nplan, int layout, bool active) {
-  for (int c = 0; c < nplan; c++) {
-    double v = 0.0;
-    if (active) v = (layout == MJPL_SOA) ? Q[(int64_t)c * N + i] : Q[i * nplan + c];
-    col[c * B] = v;
-  }
-}
 
 // Work assignment shared by the exact kernels: lane j takes item j, or -- when re-running the
 // filter's uncertain items -- item ulist[j] for j < *ucount.
@@ -400,240 +299,6 @@ k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ g
                const int *__restrict__ rcount) {
   edge_body<float, MAXS, WBOX, MBOX>(gip, nip, gfp, nfp, QA, QB, E, step, layout, flags, tol, valid,
                                      first_bad, status, ulist, ucount, rlist, rcount, uc);
-}
-
-// ---- lane-per-waypoint interior pass --------------------------------------------------------
-// The walking kernel gives every surviving edge one lane for all of its waypoints: at config-3
-// size that is 2 300 waves for 1 024 SIMDs, each alive for the whole kernel.  Here the waypoints
-// themselves become the work items: the endpoint kernel walks the reference's recurrence for
-// every edge whose endpoint passed (float64, the statements of edge_body) and writes the interior
-// waypoints into a dense item buffer; k_filter_items checks one waypoint per lane.  Consecutive
-// items are consecutive waypoints of one edge, so the lanes of a wave see similar poses and pass
-// the same bounding culls.  Edges with many waypoints stay with the walking kernel: `llist`.
-struct ItemBuffers {
-  double *w;        // [cap][nplan] waypoints, one row per item (a lane's items are adjacent rows,
-                    // so the lines it writes during its walk fill up in cache)
-  int *edge, *idx;  // [cap] which edge, which check index (1..K)
-  int *count;       // items written
-  int cap;
-  int *llist, *lcount;  // edges left to the walking kernel
-  int kmax;             // edges with more interior waypoints than this stay with the walking kernel
-  int *claim;           // [E] per-edge claim word (see k_filter_items)
-  int gen;              // this launch's generation: claim[edge] == gen <=> the edge is in ulist already
-};
-constexpr int kExpandMinWaypoints = 24;  // kmax is at least this; small batches get more (item space / E)
-
-// qe: this lane's edge end QB (LDS, stride B); qw: scratch for the walking waypoint (LDS, stride
-// ws).  `todo` lanes own an edge i whose interior waypoints are wanted.
-__device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const double *__restrict__ QA,
-                                            int64_t E, int64_t i, double step, int layout, bool todo,
-                                            const double *qe, int B, double *qw, int ws,
-                                            const ItemBuffers &ib) {
-  const int nplan = gip[H_NPLAN];
-  const int *perm = gip + gip[H_OFF_PERM];
-  const int lane = threadIdx.x & 63;
-  auto start_col = [&](int k) -> double {
-    return todo ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
-  };
-  bool at_end = true;
-  for (int k = 0; k < nplan; k++) {
-    const double a = start_col(k);
-    qw[k * ws] = a;
-    at_end = at_end && (a == qe[k * B]);
-  }
-  double s0 = 0;
-  for (int k = 0; k < nplan; k++) {
-    const int col = perm[k];
-    const double d = qe[col * B] - qw[col * ws];
-    s0 = s0 + d * d;
-  }
-  bool done = !todo || at_end;
-  if (!done && !(sqrt(s0) <= step * (double)(ib.kmax - 2))) {  // long edge
-    ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
-    done = true;
-  }
-  // one step of the recurrence: _step(w, QB, step)  (planning/utils.py:182-185; the statements of
-  // edge_body); returns true when the walk has arrived at QB
-  bool degenerate = false;  // the squared distance under- or overflowed (see edge_body)
-  auto advance = [&]() -> bool {
-    double s = 0;
-    for (int k = 0; k < nplan; k++) {
-      const int col = perm[k];
-      double d = qe[col * B] - qw[col * ws];
-      s = s + d * d;
-    }
-    const double mag = sqrt(s);
-    degenerate = degenerate || !(mag > 0.0) || !(mag <= 1.79769313486231570815e+308);
-    const double sm = step < mag ? step : mag;
-    bool eq = true;
-    for (int k = 0; k < nplan; k++) {
-      const double ek = qe[k * B];
-      double d = ek - qw[k * ws];
-      double nw = qw[k * ws] + (d / mag) * sm;
-      qw[k * ws] = nw;
-      eq = eq && (nw == ek);
-    }
-    return eq;
-  };
-  // first walk: how many interior waypoints does this edge have?
-  int K = 0;
-  {
-    bool walking = !done;
-    while (__ballot(walking) != 0ull) {
-      if (walking) {
-        if (advance()) walking = false;
-        else if (++K > ib.kmax) walking = false;
-        if (degenerate) { walking = false; K = ib.kmax + 1; }  // the walking kernel reports it
-      }
-    }
-  }
-  if (!done && K > ib.kmax) {  // the estimate was off: the walking kernel takes the edge
-    ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
-    done = true;
-  }
-  if (done) K = 0;
-  // one reservation per wave: lane l owns slots [base + sum_{l' < l} K_l', +K_l)
-  int incl = K;
-  for (int off = 1; off < 64; off <<= 1) {
-    const int up = __shfl_up(incl, off);
-    if (lane >= off) incl += up;
-  }
-  const int total = __shfl(incl, 63);
-  if (total == 0) return;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(ib.count, total);
-  base = __builtin_amdgcn_readfirstlane(base);
-  const int first = base + incl - K;
-  if (!done && first + K > ib.cap) {  // out of item space: the walking kernel takes the edge
-    ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
-    for (int slot = first; slot < ib.cap; slot++) ib.edge[slot] = -1;  // reserved but void
-    done = true;
-  }
-  // second walk: write the waypoints
-  for (int k = 0; k < nplan; k++) qw[k * ws] = start_col(k);
-  for (int idx = 1; __ballot(!done && idx <= K) != 0ull; idx++) {
-    if (!done && idx <= K) {
-      advance();
-      const int slot = first + idx - 1;
-      for (int k = 0; k < nplan; k++) ib.w[(size_t)slot * nplan + k] = qw[k * ws];
-      ib.edge[slot] = (int)i;
-      ib.idx[slot] = idx;
-    }
-  }
-}
-
-// Endpoint pass of the two-pass edge filter: check 0 (the endpoint QB, utils.py:144) for every
-// edge with full lanes; edges whose endpoint is free (or undecided) are appended to `slist` for
-// the interior pass, so that pass runs only on edges that still need it -- in an RRT batch a
-// large share of the candidate edges ends inside an obstacle, and in the one-pass kernel their
-// lanes idle through every later waypoint of the wave.
-template <int MAXS, bool WBOX, bool MBOX>
-__global__ void __launch_bounds__(kBlock)
-k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
-                   const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, int layout,
-                   float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
-                   int *__restrict__ status, int *__restrict__ ulist, int *__restrict__ ucount,
-                   UndecidedConfigs uc, int *__restrict__ slist, int *__restrict__ scount, ItemBuffers ib,
-                   double step) {
-  extern __shared__ double smem[];
-  const int B = blockDim.x;
-  const int nplan = gip[H_NPLAN];
-  // (immediate interpreter + item expansion: a second column set holds the walking waypoint)
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, (!kQueued<float, MBOX> && ib.count) ? 2 : 1, B);
-  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
-  const bool active = i < E;
-  double *qw = c.col0 + threadIdx.x;
-  load_columns(qw, B, QB, E, i, nplan, layout, active);
-  __syncthreads();
-  bool finite = true;
-  for (int k = 0; k < nplan; k++) {
-    const double a = active ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
-    const double b = qw[k * B];
-    finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
-  }
-  const bool run = active && finite;
-  const int code = check_one<float, MAXS, WBOX, MBOX>(c, qw, B, run, tol, i, uc, 0);
-  bool survive = run && code != V_CONTACT;
-  if (active) {
-    if (!finite) {
-      valid[i] = 0;
-      if (first_bad) first_bad[i] = -2;
-      atomicOr(status, kStatusNonFinite);
-    } else if (code == V_CONTACT) {
-      valid[i] = 0;
-      if (first_bad) first_bad[i] = 0;
-    } else {
-      bool whole_edge = false;
-      if (code == V_UNSURE) {  // the endpoint itself goes to the exact configuration kernel
-        const int j = kQueued<float, MBOX> ? uc.cap : atomicAdd(uc.count, 1);  // (queued: the whole edge)
-        if (j < uc.cap) {
-          for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
-          uc.edge[j] = (int)i;
-          uc.idx[j] = 0;
-          uc.ga[j] = uc.gb[j] = -1;
-        } else {
-          whole_edge = true;
-        }
-      }
-      if (whole_edge) {
-        ulist[atomicAdd(ucount, 1)] = (int)i;  // the exact edge kernel writes valid / first_bad
-        survive = false;
-      } else {
-        valid[i] = 1;  // so far; the interior pass and the patch pass may clear it
-        if (first_bad) first_bad[i] = -1;
-      }
-    }
-  }
-  const unsigned long long m = __ballot(survive);
-  if (m == 0ull) return;
-  if (ib.count) {
-    // lane-per-waypoint interior pass: emit this edge's interior waypoints as work items.  The
-    // walking waypoint lives in this wave's (now idle) candidate-queue memory.
-    if constexpr (kQueued<float, MBOX>) {
-      if ((size_t)nplan * 64 * sizeof(double) <= WaveQueue<float>::bytes()) {
-        double *scratch = reinterpret_cast<double *>(c.qmem + (size_t)(threadIdx.x >> 6) * WaveQueue<float>::bytes()) +
-                          (threadIdx.x & 63);
-        expand_edge(gip, QA, E, i, step, layout, survive, qw, B, scratch, 64, ib);
-        if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
-        return;
-      }
-    } else {
-      expand_edge(gip, QA, E, i, step, layout, survive, qw, B, c.col1 + threadIdx.x, B, ib);
-      if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
-      return;
-    }
-    if (survive) ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;  // too many columns: walking kernel
-    return;
-  }
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(scount, (int)__builtin_popcountll(m));
-  base = __builtin_amdgcn_readfirstlane(base);
-  if (survive)
-    slist[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)i;
-}
-
-template <int MAXS, bool WBOX, bool MBOX>
-__global__ void __launch_bounds__(kBlock)
-k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
-                 const double *__restrict__ Q, int64_t N, int layout, float tol,
-                 uint8_t *__restrict__ valid, int *__restrict__ ulist, int *__restrict__ ucount,
-                 UndecidedConfigs uc) {
-  extern __shared__ double smem[];
-  const int B = blockDim.x;
-  const int nplan = gip[H_NPLAN];
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B);
-  const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
-  const bool active = i < N;
-  load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
-  __syncthreads();
-  // queued interpreter: undecided pairs go to k_patch_pairs through `uc` (which clears valid[i]
-  // on a contact); V_UNSURE comes back only for what could not be handed over
-  const int code = check_one<float, MAXS, WBOX, MBOX>(c, c.col0 + threadIdx.x, B, active, tol, i, uc, 0);
-  if (active) {
-    if (code == V_UNSURE) ulist[atomicAdd(ucount, 1)] = (int)i;
-    else valid[i] = (code == V_CONTACT) ? 0 : 1;
-  }
 }
 
 // Tree.nearest_neighbor (planning/tree.py:57-66) for a batch of queries: squared Euclidean
@@ -982,59 +647,6 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
 }
 
 
-#ifdef MJPL_X_ITEMS_4WAVES
-#define MJPL_ITEMS_BOUNDS __launch_bounds__(kBlock, 4)
-#else
-#define MJPL_ITEMS_BOUNDS __launch_bounds__(kBlock)
-#endif
-template <int MAXS, bool WBOX, bool MBOX>
-__global__ void MJPL_ITEMS_BOUNDS
-k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp, ItemBuffers ib,
-               float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
-               int *__restrict__ ulist, int *__restrict__ ucount, UndecidedConfigs uc) {
-  extern __shared__ double smem[];
-  const int B = blockDim.x;
-  const int64_t n = *ib.count < ib.cap ? *ib.count : ib.cap;
-  if ((int64_t)blockIdx.x * B >= n) return;
-  const int nplan = gip[H_NPLAN];
-  // the configuration is read straight from the item buffer (coalesced, once per joint): no LDS
-  // columns in this kernel
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 0, B);
-  const int64_t it = (int64_t)blockIdx.x * B + threadIdx.x;
-  const bool active = it < n && ib.edge[it] >= 0;  // (a void slot: reserved by an edge that did not fit)
-  __syncthreads();
-  const int64_t itc = it < (int64_t)ib.cap ? it : 0;
-  const int code = check_one<float, MAXS, WBOX, MBOX>(c, ib.w + itc * nplan, B, active, tol, it, uc, 0, ib.edge,
-                                                      ib.idx, ib.w + (itc - (threadIdx.x & 63)) * nplan, nplan, 1);
-  if (active && code != V_NONE) {
-    const int ed = ib.edge[it];
-    if (code == V_CONTACT) {
-      valid[ed] = 0;
-      if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)ib.idx[it]);
-    } else {
-      bool handed = false;
-      if constexpr (!kQueued<float, MBOX>) {
-        // immediate interpreter: the whole configuration goes to the exact configuration kernel
-        if (uc.count) {
-          const int j = atomicAdd(uc.count, 1);
-          if (j < uc.cap) {
-            for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = ib.w[itc * nplan + k];
-            uc.edge[j] = ed;
-            uc.idx[j] = ib.idx[it];
-            uc.ga[j] = uc.gb[j] = -1;
-            handed = true;
-          }
-        }
-      }
-      // could not hand the undecided item over: the exact edge kernel redoes the whole edge.  An
-      // edge has up to K items here, but `ulist` holds E entries and the re-run has one lane per
-      // entry: the first item to claim the edge (generation-stamped word, never cleared between
-      // launches) lists it, the others find it listed.
-      if (!handed && atomicExch(&ib.claim[ed], ib.gen) != ib.gen) ulist[atomicAdd(ucount, 1)] = ed;
-    }
-  }
-}
-
 // ---- exact re-check of single geom pairs the filter could not decide -------------------------
 // Item u = (configuration uc.q[u], moving geom uc.ga[u], partner geom uc.gb[u]).  One lane per
 // item: float64 FK of the moving bodies (same statements as run_config), capturing the world
@@ -1312,6 +924,21 @@ std::vector<T> copy_n(const T *p, size_t n) {
   return std::vector<T>(p, p + n);
 }
 
+// entry points of a per-model specialised library (see load_spec)
+struct SpecLib {
+  typedef int (*ConfigsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, const double *,
+                           int64_t, int, float, uint8_t *, int *, int *, UndecidedConfigs);
+  typedef int (*EndpointsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, const double *,
+                             const double *, int64_t, int, float, uint8_t *, int32_t *, int *, int *, int *, UndecidedConfigs,
+                             int *, int *, ItemBuffers, double);
+  typedef int (*ItemsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, ItemBuffers, float,
+                         uint8_t *, int32_t *, int *, int *, UndecidedConfigs);
+  void *lib = nullptr;
+  ConfigsFn configs = nullptr;
+  EndpointsFn endpoints = nullptr;
+  ItemsFn items = nullptr;
+};
+
 }  // namespace
 
 struct mjpl_engine {
@@ -1339,6 +966,8 @@ struct mjpl_engine {
   double ferr_a = 0, ferr_b = 0;  // |pose error| <= ferr_a + ferr_b * max coordinate
   double fmax_coord = 0;
   int npoisoned = 0;              // static geoms too large / far for binary32: their pairs are always undecided
+  uint64_t program_hash = 0;      // FNV-1a of the compiled tables (ip, fp) and the kernel variant
+  const SpecLib *spec = nullptr;  // this model's own filter kernels, if a library for program_hash was found
   int *d_ulist = nullptr;   // items (configurations / whole edges) the filter left undecided
   int *d_ucount = nullptr;  // [0] how many of those, [1] undecided waypoints of edges, [2] edges in d_slist
   int *d_slist = nullptr;   // two-pass edge filter: edges whose endpoint passed
@@ -1384,6 +1013,8 @@ struct mjpl_engine {
 
 namespace {
 
+void load_spec(mjpl_engine *e);
+
 int stage_reserve(mjpl_engine *e, int k, size_t bytes) {
   if (bytes <= e->stage_bytes[k]) return MJPL_OK;
   if (e->stage[k]) HIP_TRY(hipFree(e->stage[k]));
@@ -1393,6 +1024,56 @@ int stage_reserve(mjpl_engine *e, int k, size_t bytes) {
   HIP_TRY(hipMalloc(&e->stage[k], want));
   e->stage_bytes[k] = want;
   return MJPL_OK;
+}
+
+// ---- per-model specialised filter kernels (mjpl_amd/specialise.py builds them) ----
+// A library libmjpl_spec_<hash>.so holds the three float32 filter kernels of mjpl_filter.h instantiated
+// with generated straight-line code for ONE compiled program.  It is looked up by the program's hash
+// in $MJPL_SPEC_DIR (default: the directory `spec` next to this library); MJPL_SPEC=0 disables it.
+std::map<uint64_t, SpecLib> &spec_cache() {
+  static std::map<uint64_t, SpecLib> c;
+  return c;
+}
+
+void load_spec(mjpl_engine *e) {
+  e->spec = nullptr;
+  if (const char *s = getenv("MJPL_SPEC"))
+    if (atoi(s) == 0) return;
+  if (e->immediate() || !e->filter_usable) return;
+  auto &cache = spec_cache();
+  auto it = cache.find(e->program_hash);
+  if (it != cache.end()) {
+    e->spec = it->second.lib ? &it->second : nullptr;
+    return;
+  }
+  SpecLib sl;
+  std::string dir;
+  if (const char *d = getenv("MJPL_SPEC_DIR")) {
+    dir = d;
+  } else {
+    Dl_info info;
+    if (dladdr((const void *)&mjpl_version, &info) && info.dli_fname) {
+      dir = info.dli_fname;
+      const size_t slash = dir.rfind('/');
+      dir = (slash == std::string::npos ? std::string(".") : dir.substr(0, slash)) + "/spec";
+    }
+  }
+  char name[64];
+  snprintf(name, sizeof(name), "/libmjpl_spec_%016llx.so", (unsigned long long)e->program_hash);
+  void *lib = dir.empty() ? nullptr : dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (lib) {
+    auto abi = (int (*)())dlsym(lib, "mjpl_spec_abi");
+    auto hash = (unsigned long long (*)())dlsym(lib, "mjpl_spec_hash");
+    sl.configs = (SpecLib::ConfigsFn)dlsym(lib, "mjpl_spec_launch_configs");
+    sl.endpoints = (SpecLib::EndpointsFn)dlsym(lib, "mjpl_spec_launch_endpoints");
+    sl.items = (SpecLib::ItemsFn)dlsym(lib, "mjpl_spec_launch_items");
+    if (abi && hash && abi() == MJPL_SPEC_ABI && hash() == e->program_hash && sl.configs && sl.endpoints && sl.items)
+      sl.lib = lib;
+    else
+      dlclose(lib);
+  }
+  cache[e->program_hash] = sl;
+  e->spec = cache[e->program_hash].lib ? &cache[e->program_hash] : nullptr;
 }
 
 int pin_reserve(mjpl_engine *e, size_t bytes) {
@@ -1863,6 +1544,22 @@ int compile_program(mjpl_engine *e) {
   for (int w : poison_rows)
     for (int k = 0; k < WN_LEN; k++) fp[(size_t)ip[H_OFF_WNARROW] + (size_t)w * WN_LEN + k] = std::numeric_limits<float>::quiet_NaN();
 
+  // ---- identity of the compiled program: what a per-model specialised library is keyed by
+  {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](const void *ptr, size_t n) {
+      const unsigned char *b = (const unsigned char *)ptr;
+      for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 0x100000001b3ull; }
+    };
+    mix(ip.data(), ip.size() * sizeof(int));
+    mix(fp.data(), fp.size() * sizeof(float));
+    const int shape[4] = {e->maxs, e->wbox ? 1 : 0, e->mbox ? 1 : 0, MJPL_SPEC_ABI};
+    mix(shape, sizeof(shape));
+    e->program_hash = h;
+  }
+  if (e->device < 0) return MJPL_OK;  // mjpl_program_dump: host tables only
+  load_spec(e);
+
   // ---- upload
   if (e->d_ip) (void)hipFree(e->d_ip);
   if (e->d_dp) (void)hipFree(e->d_dp);
@@ -1999,8 +1696,12 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
     const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate());
-    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
-      auto kern = k_filter_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+    if (e->spec)
+      rc = e->spec->configs(e->stream, fgrid, (unsigned)fblock, ldsf, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQ, N,
+                            layout, e->filter_tol, dvalid, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
+           : fail(MJPL_E_HIP, "specialised configuration kernel failed to launch");
+    else rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+      auto kern = k_filter_configs<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
       if (r != MJPL_OK) return r;
       hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
@@ -2109,8 +1810,13 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       }
       rlist = e->d_slist;
       rcount = e->d_ucount + 2 * kCtr;
-      rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
-        auto kern = k_filter_endpoints<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+      if (e->spec)
+        rc = e->spec->endpoints(e->stream, fgrid, (unsigned)fblock, ldse, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQA,
+                                dQB, E, layout, e->filter_tol, dvalid, dfb, e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist,
+                                e->d_ucount + 2 * kCtr, ib, step) == 0 ? MJPL_OK
+             : fail(MJPL_E_HIP, "specialised endpoint kernel failed to launch");
+      else rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+        auto kern = k_filter_endpoints<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldse);
         if (r != MJPL_OK) return r;
         hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldse, e->stream, e->d_ip, (int)e->ip.size(),
@@ -2124,8 +1830,12 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     if (expand) {
       const unsigned igrid = (unsigned)((e->item_cap + fblock - 1) / fblock);
       const size_t ldsi = lds_bytes(e, 0, sizeof(float), fblock, !e->immediate());
-      rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
-        auto kern = k_filter_items<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+      if (e->spec)
+        rc = e->spec->items(e->stream, igrid, (unsigned)fblock, ldsi, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib,
+                            e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
+             : fail(MJPL_E_HIP, "specialised item kernel failed to launch");
+      else rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+        auto kern = k_filter_items<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldsi);
         if (r != MJPL_OK) return r;
         hipLaunchKernelGGL(kern, dim3(igrid), dim3(fblock), ldsi, e->stream, e->d_ip, (int)e->ip.size(),
@@ -2226,27 +1936,9 @@ int mjpl_device_count(void) {
   return n;
 }
 
-int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t nallowed,
-                int32_t device, mjpl_engine **out) {
-  if (!d || !out) return fail(MJPL_E_ARG, "mjpl_create: NULL argument");
-  *out = nullptr;
-  if (d->nq < 0 || d->njnt < 0 || d->nbody < 1 || d->ngeom < 0 || nallowed < 0)
-    return fail(MJPL_E_ARG, "mjpl_create: negative size");
-  if (d->nq != d->njnt) return fail(MJPL_E_JOINT, "nq != njnt: only 1-DoF joints are supported");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(MJPL_E_NODEVICE, "no HIP device available (this library has no CPU fallback)");
-  if (device < 0 || device >= ndev) return fail(MJPL_E_NODEVICE, "device %d out of range [0,%d)", device, ndev);
-
-  mjpl_engine *e = new mjpl_engine();
-  e->device = device;
-  auto bail = [&](int rc) { mjpl_destroy(e); return rc; };
-  if (hipSetDevice(device) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipSetDevice(%d) failed", device));
-  if (hipGetDeviceProperties(&e->prop, device) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipGetDeviceProperties failed"));
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipStreamCreate failed"));
-  if (hipMalloc(&e->d_status, sizeof(int)) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipMalloc failed"));
-  (void)hipMemset(e->d_status, 0, sizeof(int));
-
+namespace {
+// copy the model tables, the allowed body pairs and the environment overrides into a fresh engine
+int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t nallowed) {
   HostModel &m = e->m;
   m.nq = d->nq; m.njnt = d->njnt; m.nbody = d->nbody; m.ngeom = d->ngeom;
   m.body_parentid = copy_n(d->body_parentid, m.nbody);
@@ -2271,14 +1963,14 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
   m.geom_margin = copy_n(d->geom_margin, m.ngeom);
   for (int b = 0; b < m.nbody; b++)
     if (m.body_parentid[b] < 0 || m.body_parentid[b] > b || m.body_weldid[b] < 0 || m.body_weldid[b] > b)
-      return bail(fail(MJPL_E_ARG, "body %d: parent/weld ids must precede the body", b));
+      return (fail(MJPL_E_ARG, "body %d: parent/weld ids must precede the body", b));
   for (int g = 0; g < m.ngeom; g++)
     if (m.geom_bodyid[g] < 0 || m.geom_bodyid[g] >= m.nbody)
-      return bail(fail(MJPL_E_ARG, "geom %d: body id out of range", g));
+      return (fail(MJPL_E_ARG, "geom %d: body id out of range", g));
   for (int a = 0; a < nallowed; a++) {
     int b1 = allowed_bodies[2 * a], b2 = allowed_bodies[2 * a + 1];
     if (b1 < 0 || b2 < 0 || b1 >= m.nbody || b2 >= m.nbody)
-      return bail(fail(MJPL_E_ARG, "allowed body pair %d out of range", a));
+      return (fail(MJPL_E_ARG, "allowed body pair %d out of range", a));
     e->allowed.insert({std::min(b1, b2), std::max(b1, b2)});
   }
   e->qidx.resize(m.nq);
@@ -2293,7 +1985,34 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
     const double v = atof(t);
     if (v > 0.0 && v < 1.0) { e->filter_tol_req = (float)v; e->filter_tol_user = true; }
   }
-  int rc = compile_program(e);
+  return MJPL_OK;
+}
+}  // namespace
+
+int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t nallowed,
+                int32_t device, mjpl_engine **out) {
+  if (!d || !out) return fail(MJPL_E_ARG, "mjpl_create: NULL argument");
+  *out = nullptr;
+  if (d->nq < 0 || d->njnt < 0 || d->nbody < 1 || d->ngeom < 0 || nallowed < 0)
+    return fail(MJPL_E_ARG, "mjpl_create: negative size");
+  if (d->nq != d->njnt) return fail(MJPL_E_JOINT, "nq != njnt: only 1-DoF joints are supported");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MJPL_E_NODEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(MJPL_E_NODEVICE, "device %d out of range [0,%d)", device, ndev);
+
+  mjpl_engine *e = new mjpl_engine();
+  e->device = device;
+  auto bail = [&](int rc) { mjpl_destroy(e); return rc; };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipSetDevice(%d) failed", device));
+  if (hipGetDeviceProperties(&e->prop, device) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipGetDeviceProperties failed"));
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipStreamCreate failed"));
+  if (hipMalloc(&e->d_status, sizeof(int)) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipMalloc failed"));
+  (void)hipMemset(e->d_status, 0, sizeof(int));
+
+  int rc = engine_from_desc(e, d, allowed_bodies, nallowed);
+  if (rc != MJPL_OK) return bail(rc);
+  rc = compile_program(e);
   if (rc != MJPL_OK) return bail(rc);
   *out = e;
   return MJPL_OK;
@@ -2329,6 +2048,43 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
+
+int mjpl_program_dump(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t nallowed, const int32_t *qidx,
+                      int32_t nplan, const double *qpos_base, double filter_tol, int32_t *ip, int32_t *nip, float *fp,
+                      double *dp, int32_t *ntab, mjpl_program_info *info) {
+  if (!d || !nip || !ntab || !info) return fail(MJPL_E_ARG, "mjpl_program_dump: NULL argument");
+  if (d->nq < 0 || d->njnt < 0 || d->nbody < 1 || d->ngeom < 0 || nallowed < 0) return fail(MJPL_E_ARG, "negative size");
+  if (d->nq != d->njnt) return fail(MJPL_E_JOINT, "nq != njnt: only 1-DoF joints are supported");
+  std::unique_ptr<mjpl_engine> e(new mjpl_engine());
+  e->device = -1;  // host tables only: nothing is allocated or uploaded
+  int rc = engine_from_desc(e.get(), d, allowed_bodies, nallowed);
+  if (rc != MJPL_OK) return rc;
+  if (qidx) {
+    e->qidx.assign(qidx, qidx + nplan);
+    for (int c : e->qidx)
+      if (c < 0 || c >= d->nq) return fail(MJPL_E_ARG, "planning index %d out of range", c);
+  }
+  if (qpos_base) e->qbase.assign(qpos_base, qpos_base + d->nq);
+  if (filter_tol > 0.0) { e->filter_tol_req = (float)filter_tol; e->filter_tol_user = true; }
+  if ((rc = compile_program(e.get())) != MJPL_OK) return rc;
+  memset(info, 0, sizeof(*info));
+  info->hash = e->program_hash;
+  info->maxs = e->maxs; info->wbox = e->wbox; info->mbox = e->mbox; info->immediate = e->immediate();
+  info->filter_usable = e->filter_usable; info->filter_tol = e->filter_tol; info->nslots = e->nslots; info->nsave = e->nsave;
+  info->spec_abi = MJPL_SPEC_ABI;
+  const int32_t want_ip = (int32_t)e->ip.size(), want_tab = (int32_t)e->fp.size();
+  const bool fits = ip && fp && *nip >= want_ip && *ntab >= want_tab;
+  *nip = want_ip;
+  *ntab = want_tab;
+  if (!ip && !fp && !dp) return MJPL_OK;  // size query
+  if (!fits) return fail(MJPL_E_CAPACITY, "mjpl_program_dump: buffers too small (%d control words, %d constants)", want_ip, want_tab);
+  memcpy(ip, e->ip.data(), e->ip.size() * sizeof(int));
+  memcpy(fp, e->fp.data(), e->fp.size() * sizeof(float));
+  if (dp) memcpy(dp, e->dp.data(), e->dp.size() * sizeof(double));
+  return MJPL_OK;
+}
+
+int mjpl_spec_loaded(const mjpl_engine *e) { return (e && e->spec) ? 1 : 0; }
 
 int mjpl_set_planning(mjpl_engine *e, const int32_t *qidx, int32_t nplan, const double *qpos_base) {
   if (!e || nplan < 0 || (nplan > 0 && !qidx)) return fail(MJPL_E_ARG, "mjpl_set_planning: bad argument");

@@ -148,6 +148,8 @@ ABI = {
     "mjpl_comm_init": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
     "mjpl_comm_destroy": (C.c_int, [_VP]),
     "mjpl_allgather_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "mjpl_program_dump": (C.c_int, None),   # bound in mjpl_amd/specialise.py
+    "mjpl_spec_loaded": (C.c_int, [_VP]),
     "mjpl_device_count": (C.c_int, []),
     "mjpl_last_error": (C.c_char_p, []),
     "mjpl_version": (C.c_char_p, []),
@@ -169,7 +171,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     for name, (res, args) in ABI.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
-        fn.argtypes = args
+        if args is not None:
+            fn.argtypes = args
     _libs[path] = lib
     return lib
 
@@ -275,6 +278,11 @@ class Engine:
         i = Info()
         self._ok(self.lib.mjpl_get_info(self.h, C.byref(i)))
         return i.as_dict()
+
+    def spec_loaded(self) -> bool:
+        """True if this engine's filter kernels are the model's own specialised ones
+        (mjpl_amd/specialise.py), not the interpreter."""
+        return bool(self.lib.mjpl_spec_loaded(self.h))
 
     def set_filter(self, enable: bool, tol: float = 1e-4):
         """Float32 filter in front of the exact kernels (verdicts are always the exact ones)."""

@@ -1,0 +1,511 @@
+"""Per-model specialised filter kernels.
+
+``mjpl_create`` compiles a model into a *program* -- control words ``ip`` and constant tables
+``fp`` / ``dp`` -- which the generic kernels of ``mjpl_device.h`` interpret: every body, joint, geom
+and four-row chunk of partners costs scalar loads of control words, address arithmetic, loop
+branches and mask bookkeeping (0.78 scalar instructions per vector instruction in the item pass,
+round-1 counters).  This module turns ONE program into straight-line HIP source instead:
+
+* forward kinematics with the model's constants as literals, terms that multiply an exact 0
+  dropped and exact +-1 folded at generation time (a hinge about z contributes two products per
+  quaternion component instead of four);
+* one bounding cull per ENABLED partner, operands as literals, each hit mask parked in lane k of a
+  register pair (``v_writelane``) so that one rolled loop per geom -- the only copy of the push and
+  drain code -- picks the partners some lane passed (``ballot`` of the non-zero lanes);
+* the candidate queues, the drains (full-lane narrowphase), the exact re-check of undecided pairs
+  and every table they read are the generic ones: verdicts are the same.
+
+The generated code is compiled with the kernels of ``mjpl_filter.h`` into
+``mjpl_amd/csrc/spec/libmjpl_spec_<hash>.so``; an engine whose program has that hash loads it
+(``mjpl_hip.hip: load_spec``).  Building needs ``hipcc`` and no GPU (``mjpl_program_dump`` compiles
+the model on the host), so it runs in the build container, or on a GPU box BEFORE the process
+touches the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+from . import build as _build
+from . import engine as _engine
+
+SPEC_DIR = os.path.join(_build.CSRC, "spec")
+
+# program layout (mjpl_device.h)
+H_NBODYOPS, H_NPLAN, H_NSAVE, H_NSLOTS, H_OFF_BODYOPS, H_OFF_PERM, H_OFF_WCULL, H_OFF_WNARROW, H_NWORLD, H_NWPAD, \
+    H_OFF_FCONST, H_SIZE = range(12)
+B_PARENT, B_DOFF, B_BODYID, B_NJNT, B_SAVE, B_NGEOM, B_SIZE = range(7)
+J_TYPE, J_QSRC, J_FLAGS, J_DOFF, J_SIZE = range(5)
+G_TYPE, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_SMASK, G_WMASK_LO, G_WMASK_HI, G_PMASK_LO, G_PMASK_HI, G_SIZE = range(11)
+MAX_SLOTS = 32
+GD_SIZE, GD_WBOUND = 7, 12
+GF_SAMEPOS, GF_SAMEROT = 1, 2
+JF_POS_NONZERO = 1
+PARENT_CUR, PARENT_STATIC = 0, -1
+JT_SLIDE, JT_HINGE = 2, 3
+GT_PLANE, GT_SPHERE, GT_CAPSULE, GT_BOX = 0, 2, 3, 6
+EK_PLANE, EK_STATIC, EK_SLOT = 0, 1, 2
+WN_ZAXIS, WN_LEN = 0, 12
+P_FIRST = 1 << 17
+SLOT_NONE = 63
+FC_MAXCOORD, FC_MAXANGLE = 0, 1
+
+
+class ProgramInfo(C.Structure):
+    _fields_ = [("hash", C.c_uint64), ("maxs", C.c_int32), ("wbox", C.c_int32), ("mbox", C.c_int32),
+                ("immediate", C.c_int32), ("filter_usable", C.c_int32), ("filter_tol", C.c_float),
+                ("nslots", C.c_int32), ("nsave", C.c_int32), ("spec_abi", C.c_int32)]
+
+
+def dump_program(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_tol: float = 0.0):
+    """Compile `model` on the host (no GPU) -> (ip int32[], fp float32[], dp float64[], ProgramInfo)."""
+    lib = _engine.load_library()
+    f = lib.mjpl_program_dump
+    f.restype = C.c_int
+    d = _engine._ModelDesc()
+    d.nq, d.njnt, d.nbody, d.ngeom = model.nq, model.njnt, model.nbody, model.ngeom
+    keep = []
+    for name, typ in _engine._ModelDesc._fields_[4:]:
+        arr = getattr(model, name)
+        arr = _engine._i32(arr) if typ is _engine._I32P else _engine._f64(arr)
+        keep.append(arr)
+        setattr(d, name, arr.ctypes.data_as(typ))
+    pairs = _engine._i32([(model.body(a).id, model.body(b).id) for a, b in allowed_collision_bodies]).reshape(-1, 2)
+    q = None if qidx is None else _engine._i32(qidx)
+    base = None if qpos_base is None else _engine._f64(qpos_base)
+    info = ProgramInfo()
+    nip, ntab = C.c_int32(0), C.c_int32(0)
+
+    def call(ip, fp, dp):
+        rc = f(C.byref(d), pairs.ctypes.data_as(_engine._I32P), len(pairs),
+               None if q is None else q.ctypes.data_as(_engine._I32P), 0 if q is None else len(q),
+               None if base is None else base.ctypes.data_as(_engine._F64P), C.c_double(filter_tol),
+               None if ip is None else ip.ctypes.data_as(_engine._I32P), C.byref(nip),
+               None if fp is None else fp.ctypes.data_as(C.POINTER(C.c_float)),
+               None if dp is None else dp.ctypes.data_as(_engine._F64P), C.byref(ntab), C.byref(info))
+        if rc != 0:
+            raise _engine.MjplError(rc, lib.mjpl_last_error().decode())
+
+    call(None, None, None)
+    ip, fp, dp = np.zeros(nip.value, np.int32), np.zeros(ntab.value, np.float32), np.zeros(ntab.value, np.float64)
+    call(ip, fp, dp)
+    return ip, fp, dp, info
+
+
+# ----------------------------------------------------------------------------- expression helpers
+def lit(x: float) -> str:
+    """Exact C literal of a binary32 value."""
+    x = float(np.float32(x))
+    if math.isnan(x):
+        return "__builtin_nanf(\"\")"
+    if math.isinf(x):
+        return "__builtin_inff()" if x > 0 else "(-__builtin_inff())"
+    return f"{x.hex()}f"
+
+
+def lin(terms, const: float = 0.0) -> str:
+    """sum of coef * expr with exact-zero terms dropped and exact +-1 coefficients folded;
+    `terms` = [(coef, expr)].  Returns a C expression (float)."""
+    parts = []
+    for c, e in terms:
+        c = float(np.float32(c))
+        if c == 0.0:
+            continue
+        if c == 1.0:
+            parts.append(("+", e))
+        elif c == -1.0:
+            parts.append(("-", e))
+        elif c < 0:
+            parts.append(("-", f"{lit(-c)} * {e}"))
+        else:
+            parts.append(("+", f"{lit(c)} * {e}"))
+    const = float(np.float32(const))
+    if const != 0.0:
+        parts.append(("+" if const > 0 else "-", lit(abs(const))))
+    if not parts:
+        return "0.0f"
+    out = ("-" if parts[0][0] == "-" else "") + parts[0][1]
+    for sgn, e in parts[1:]:
+        out += f" {sgn} {e}"
+    return f"({out})"
+
+
+def quat_mul_const_right(a, b) -> list[str]:
+    """a (expressions) x b (constants) -> 4 expressions (mju_mulQuat)."""
+    return [lin([(b[0], a[0]), (-b[1], a[1]), (-b[2], a[2]), (-b[3], a[3])]),
+            lin([(b[1], a[0]), (b[0], a[1]), (b[3], a[2]), (-b[2], a[3])]),
+            lin([(b[2], a[0]), (-b[3], a[1]), (b[0], a[2]), (b[1], a[3])]),
+            lin([(b[3], a[0]), (b[2], a[1]), (-b[1], a[2]), (b[0], a[3])])]
+
+
+def quat_mul_np(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                     a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+                     a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def quat_mat_np(q):
+    w, x, y, z = q
+    return np.array([w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z])
+
+
+class _Gen:
+    def __init__(self, ip, fp, dp, info):
+        self.ip, self.fp, self.dp, self.info = ip, fp, dp, info
+        self.lines: list[str] = []
+        self.ind = 3
+
+    def w(self, s=""):
+        self.lines.append("  " * self.ind + s)
+
+    # rot_vec_quat(res, const vec, quat expr): v + 2 * cross(q_xyz, q_w v + cross(q_xyz, v))
+    def rot_vec_quat(self, dst, vec, qn):
+        v = [float(x) for x in vec]
+        self.w(f"{{ const float t0_ = {lin([(v[0], qn[0]), (v[2], qn[2]), (-v[1], qn[3])])};")
+        self.w(f"  const float t1_ = {lin([(v[1], qn[0]), (v[0], qn[3]), (-v[2], qn[1])])};")
+        self.w(f"  const float t2_ = {lin([(v[2], qn[0]), (v[1], qn[1]), (-v[0], qn[2])])};")
+        self.w(f"  {dst}0 = {lit(v[0])} + 2.0f * ({qn[2]} * t2_ - {qn[3]} * t1_);")
+        self.w(f"  {dst}1 = {lit(v[1])} + 2.0f * ({qn[3]} * t0_ - {qn[1]} * t2_);")
+        self.w(f"  {dst}2 = {lit(v[2])} + 2.0f * ({qn[1]} * t1_ - {qn[2]} * t0_); }}")
+
+
+def generate(ip, fp, dp, info) -> str:
+    """HIP source of `struct Spec` for one compiled program."""
+    if info.immediate or not info.filter_usable:
+        raise ValueError("this model runs the immediate interpreter / has no usable filter: nothing to specialise")
+    g = _Gen(ip, fp, dp, info)
+    w = g.w
+    nbody = int(ip[H_NBODYOPS])
+    nwpad = int(ip[H_NWPAD])
+    off_wcull, off_wnarrow = int(ip[H_OFF_WCULL]), int(ip[H_OFF_WNARROW])
+    fconst = int(ip[H_OFF_FCONST])
+    maxs = int(info.maxs)
+
+    def wc_at(wrow, f):
+        return off_wcull + ((wrow >> 2) << 4) + (f << 2) + (wrow & 3)
+
+    stages = []       # (case body lines, gtype, gdoff, store)
+    desc = []         # per stage: list of packed partner descriptors
+    pending_fk: list[str] = []   # FK of bodies since the last stage (bodies without geoms)
+    pc = int(ip[H_OFF_BODYOPS])
+    state_known = None  # (p, q) as numpy constants while the chain so far is constant (static parent, fixed joints)
+
+    for b in range(nbody):
+        parent, bdoff, njnt, save_slot, ngeom = (int(ip[pc + k]) for k in (B_PARENT, B_DOFF, B_NJNT, B_SAVE, B_NGEOM))
+        pc += B_SIZE
+        bd = dp[bdoff:]
+        g.lines, body_lines = [], None
+        # ---- parent pose
+        if parent == PARENT_STATIC:
+            pp, pq, pR = bd[7:10].copy(), bd[10:14].copy(), bd[14:23].copy()
+            npc = pp + pR.reshape(3, 3) @ bd[0:3]
+            nqc = quat_mul_np(pq, bd[3:7])
+            w(f"float np0 = {lit(npc[0])}, np1 = {lit(npc[1])}, np2 = {lit(npc[2])};")
+            w(f"float nq0 = {lit(nqc[0])}, nq1 = {lit(nqc[1])}, nq2 = {lit(nqc[2])}, nq3 = {lit(nqc[3])};")
+        else:
+            if parent != PARENT_CUR:  # restore a saved pose
+                k = parent - 1
+                w(f"{{ const float *sv = save + (size_t){k} * 7 * sstride;")
+                w("  p0 = sv[0]; p1 = sv[sstride]; p2 = sv[2 * sstride];")
+                w("  q0 = sv[3 * sstride]; q1 = sv[4 * sstride]; q2 = sv[5 * sstride]; q3 = sv[6 * sstride];")
+                w("  MJPL_SPEC_QUAT2MAT(); }")
+            bp, bq = bd[0:3], bd[3:7]
+            for r in range(3):
+                w(f"float np{r} = p{r} + {lin([(bp[0], f'R{3 * r}'), (bp[1], f'R{3 * r + 1}'), (bp[2], f'R{3 * r + 2}')])};")
+            e = quat_mul_const_right(["q0", "q1", "q2", "q3"], bq)
+            w(f"float nq0 = {e[0]}, nq1 = {e[1]}, nq2 = {e[2]}, nq3 = {e[3]};")
+        # ---- joints
+        for j in range(njnt):
+            jtype, qsrc, jflags, jdoff = (int(ip[pc + k]) for k in (J_TYPE, J_QSRC, J_FLAGS, J_DOFF))
+            pc += J_SIZE
+            jd = dp[jdoff:]
+            axis, jpos, qpos0, qconst = jd[0:3], jd[3:6], float(jd[6]), float(jd[7])
+            if qsrc >= 0:
+                w(f"{{ const float dq = (float)q[{qsrc} * qstride] - {lit(qpos0)};")
+            else:
+                w(f"{{ const float dq = {lit(np.float32(qconst) - np.float32(qpos0))};")
+            nqn = ["nq0", "nq1", "nq2", "nq3"]
+            if jtype == JT_SLIDE:
+                w("  float xa0, xa1, xa2;")
+                g.rot_vec_quat("xa", axis, nqn)
+                w("  np0 += xa0 * dq; np1 += xa1 * dq; np2 += xa2 * dq; }")
+            else:
+                if jflags & JF_POS_NONZERO:
+                    w("  float an0, an1, an2;")
+                    g.rot_vec_quat("an", jpos, nqn)
+                    w("  an0 += np0; an1 += np1; an2 += np2;")
+                w("  far = far || !(fabsf(dq) <= maxangle);  // binary32(q) is off by eps |q|")
+                w("  float sn, cs; sincosf(dq * 0.5f, &sn, &cs);")
+                # nq = nq (x) (cs, ax sn, ay sn, az sn)
+                a = [float(np.float32(x)) for x in axis]
+                sx = [f"{lit(a[k])} * sn" if a[k] not in (0.0, 1.0, -1.0) else ("sn" if a[k] == 1.0 else ("(-sn)" if a[k] == -1.0 else None))
+                      for k in range(3)]
+
+                def term(sign, left, right):
+                    return None if right is None else (sign, f"{left} * {right}")
+
+                comps = [
+                    [("+", "nq0 * cs"), term("-", "nq1", sx[0]), term("-", "nq2", sx[1]), term("-", "nq3", sx[2])],
+                    [term("+", "nq0", sx[0]), ("+", "nq1 * cs"), term("+", "nq2", sx[2]), term("-", "nq3", sx[1])],
+                    [term("+", "nq0", sx[1]), term("-", "nq1", sx[2]), ("+", "nq2 * cs"), term("+", "nq3", sx[0])],
+                    [term("+", "nq0", sx[2]), term("+", "nq1", sx[1]), term("-", "nq2", sx[0]), ("+", "nq3 * cs")],
+                ]
+                exprs = []
+                for comp in comps:
+                    ts = [t for t in comp if t is not None]
+                    out = ("-" if ts[0][0] == "-" else "") + ts[0][1]
+                    for sgn, ex in ts[1:]:
+                        out += f" {sgn} {ex}"
+                    exprs.append(out)
+                w(f"  const float t0 = {exprs[0]}, t1 = {exprs[1]}, t2 = {exprs[2]}, t3 = {exprs[3]};")
+                w("  nq0 = t0; nq1 = t1; nq2 = t2; nq3 = t3;")
+                if jflags & JF_POS_NONZERO:
+                    w("  float vv0, vv1, vv2;")
+                    g.rot_vec_quat("vv", jpos, nqn)
+                    w("  np0 = an0 - vv0; np1 = an1 - vv1; np2 = an2 - vv2;")
+                w("}")
+        # ---- normalise, rotation matrix, range check, save
+        w("{ const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(nq0 * nq0 + nq1 * nq1 + nq2 * nq2 + nq3 * nq3));")
+        w("  q0 = nq0 * inv; q1 = nq1 * inv; q2 = nq2 * inv; q3 = nq3 * inv; }")
+        w("p0 = np0; p1 = np1; p2 = np2;")
+        w("MJPL_SPEC_QUAT2MAT();")
+        w("far = far || !(fmaxf(fabsf(p0), fmaxf(fabsf(p1), fabsf(p2))) <= maxcoord);")
+        w("if (far) dead = kInf;")
+        if save_slot >= 0:
+            w(f"{{ float *sv = save + (size_t){save_slot} * 7 * sstride;")
+            w("  sv[0] = p0; sv[sstride] = p1; sv[2 * sstride] = p2;")
+            w("  sv[3 * sstride] = q0; sv[4 * sstride] = q1; sv[5 * sstride] = q2; sv[6 * sstride] = q3; }")
+        body_lines = g.lines
+        pending_fk.extend(["{"] + body_lines + ["}"])
+        # ---- geoms
+        for gi in range(ngeom):
+            gtype, gflags, gdoff, store, geom_id, smask = (int(ip[pc + k]) for k in (G_TYPE, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_SMASK))
+            wmask = (int(ip[pc + G_WMASK_LO]) & 0xFFFFFFFF) | ((int(ip[pc + G_WMASK_HI]) & 0xFFFFFFFF) << 32)
+            pmask = (int(ip[pc + G_PMASK_LO]) & 0xFFFFFFFF) | ((int(ip[pc + G_PMASK_HI]) & 0xFFFFFFFF) << 32)
+            swords = [int(x) for x in ip[pc + G_SIZE: pc + G_SIZE + MAX_SLOTS]]
+            pc += G_SIZE + MAX_SLOTS
+            gd = dp[gdoff:]
+            fgd = fp[gdoff:]
+            g.lines = []
+            lpos, lquat = gd[0:3], gd[3:7]
+            if gflags & GF_SAMEPOS:
+                w("cx = p0; cy = p1; cz = p2;")
+            else:
+                for r, nm in enumerate(("cx", "cy", "cz")):
+                    w(f"{nm} = p{r} + {lin([(lpos[0], f'R{3 * r}'), (lpos[1], f'R{3 * r + 1}'), (lpos[2], f'R{3 * r + 2}')])};")
+            if gflags & GF_SAMEROT:
+                w("zx = R2; zy = R5; zz = R8;")
+            else:
+                e = quat_mul_const_right(["q0", "q1", "q2", "q3"], lquat)
+                w(f"{{ const float g0 = {e[0]}, g1 = {e[1]}, g2 = {e[2]}, g3 = {e[3]};")
+                w("  zx = 2.0f * (g1 * g3 + g0 * g2); zy = 2.0f * (g2 * g3 - g0 * g1); zz = g0 * g0 - g1 * g1 - g2 * g2 + g3 * g3; }")
+            partners = []
+            wbound = fgd[GD_WBOUND: GD_WBOUND + nwpad]
+            sbound = fgd[GD_WBOUND + 2 * nwpad: GD_WBOUND + 2 * nwpad + MAX_SLOTS]
+            # static planes
+            for wrow in range(64):
+                if not (pmask >> wrow) & 1:
+                    continue
+                ppos = [float(fp[wc_at(wrow, f)]) for f in range(3)]
+                pz = [float(x) for x in fp[off_wnarrow + wrow * WN_LEN + WN_ZAXIS: off_wnarrow + wrow * WN_LEN + WN_ZAXIS + 3]]
+                k = len(partners)
+                dot = lin([(pz[0], "cx"), (pz[1], "cy"), (pz[2], "cz")], -(np.float32(pz[0]) * np.float32(ppos[0]) + np.float32(pz[1]) * np.float32(ppos[1]) + np.float32(pz[2]) * np.float32(ppos[2])))
+                w(f"MJPL_SPEC_HIT({k}, !({dot} + dead > {lit(wbound[wrow])}));")
+                partners.append((EK_PLANE, wrow, GT_PLANE, 1, 0))
+            # other static geoms
+            for wrow in range(64):
+                if not (wmask >> wrow) & 1:
+                    continue
+                info_word = int(np.frombuffer(np.float32(fp[wc_at(wrow, 3)]).tobytes(), dtype=np.int32)[0])
+                ptype, pgid = info_word & 255, info_word >> 8
+                pfirst = 1 if (ptype < gtype or (ptype == gtype and pgid < geom_id)) else 0
+                X, Y, Z = (float(fp[wc_at(wrow, f)]) for f in range(3))
+                k = len(partners)
+                w(f"MJPL_SPEC_CULL({k}, {lit(X)}, {lit(Y)}, {lit(Z)}, {lit(wbound[wrow])});")
+                partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if ptype == GT_BOX else 0))
+            # earlier moving geoms in the slot file
+            for n in range(maxs):
+                if not (smask >> n) & 1:
+                    continue
+                pw = swords[n]
+                k = len(partners)
+                w(f"MJPL_SPEC_SLOTCULL({k}, {n}, {lit(sbound[n])});")
+                partners.append((EK_SLOT, n, (pw >> 12) & 15, 1 if (pw & P_FIRST) else 0, 0))
+            if len(partners) > 64:
+                raise ValueError("a geom with more than 64 enabled partners cannot be specialised")
+            stages.append((pending_fk + g.lines, gtype, gdoff, store & 63 if store >= 0 else -1))
+            pending_fk = []
+            desc.append([(kind << 0) | (index << 2) | (ptype << 10) | (pfirst << 14) | (boxq << 15)
+                         for kind, index, ptype, pfirst, boxq in partners])
+    if pending_fk:  # trailing bodies without geoms influence nothing: drop them
+        pending_fk = []
+    nstage = len(stages)
+    out = []
+    o = out.append
+    o("// GENERATED by mjpl_amd/specialise.py -- straight-line per-configuration check of ONE compiled program.")
+    o(f"// program hash {info.hash:016x}, {nbody} moving bodies, {nstage} moving geoms, "
+      f"{sum(len(d) for d in desc)} enabled pairs, slot file width {maxs}")
+    o("#define MJPL_SPEC_QUAT2MAT() \\")
+    o("  do { R0 = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3; R4 = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3; \\")
+    o("       R8 = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3; R1 = 2.0f * (q1 * q2 - q0 * q3); R2 = 2.0f * (q1 * q3 + q0 * q2); \\")
+    o("       R3 = 2.0f * (q1 * q2 + q0 * q3); R5 = 2.0f * (q2 * q3 - q0 * q1); R6 = 2.0f * (q1 * q3 - q0 * q2); \\")
+    o("       R7 = 2.0f * (q2 * q3 + q0 * q1); } while (0)")
+    o("#define MJPL_SPEC_HIT(k, pass) \\")
+    o("  do { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(pass); \\")
+    o("       mjpl::park_mask<k>(mlo, mhi, m_); } while (0)")
+    o("#define MJPL_SPEC_CULL(k, X, Y, Z, BOUND) \\")
+    o("  do { const float dx_ = cx - (X), dy_ = cy - (Y), dz_ = cz - (Z); \\")
+    o("       MJPL_SPEC_HIT(k, !(mjpl::sqnorm3(dx_, dy_, dz_) + dead > (BOUND))); } while (0)")
+    o("#define MJPL_SPEC_SLOTCULL(k, n, BOUND) \\")
+    o("  do { const float dx_ = cx - sf.f[0][n], dy_ = cy - sf.f[1][n], dz_ = cz - sf.f[2][n]; \\")
+    o("       MJPL_SPEC_HIT(k, !(mjpl::sqnorm3(dx_, dy_, dz_) + dead > (BOUND))); } while (0)")
+    o("")
+    o(f"__constant__ int kSpecDesc[{nstage} * 64] = {{")
+    for d in desc:
+        o("  " + ", ".join(str(x) for x in (d + [0] * (64 - len(d)))) + ",")
+    o("};")
+    o(f"__constant__ int kSpecStage[{nstage} * 4] = {{  // gtype, gdoff, store, partners")
+    for (_, gtype, gdoff, store), d in zip(stages, desc):
+        o(f"  {gtype}, {gdoff}, {store}, {len(d)},")
+    o("};")
+    o("")
+    o("struct Spec {")
+    o("  static __device__ __forceinline__ int run(mjpl::FP tp, const float *ltab, const double *q, int qstride, float *save,")
+    o("                                            int sstride, bool active, float tol, const mjpl::WaveQueue<float> &wq,")
+    o("                                            int item, const mjpl::PatchSink &ps) {")
+    o("    using namespace mjpl;")
+    o(f"    SlotFile<float, {maxs}> sf;")
+    o("    float p0 = 0, p1 = 0, p2 = 0, q0 = 1, q1 = 0, q2 = 0, q3 = 0;")
+    o("    float R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1;")
+    o("    const int lane = threadIdx.x & 63;")
+    o("    const float kInf = __builtin_inff();")
+    o("    float dead = active ? 0.0f : kInf;")
+    o("    bool far = false;")
+    o("    int fl = 0, qn = 0, qb = 0;")
+    o("    wq.flags[lane] = (int)((unsigned)item << 2);")
+    o(f"    const float maxcoord = {lit(fp[fconst + FC_MAXCOORD])}, maxangle = {lit(fp[fconst + FC_MAXANGLE])};")
+    o(f"    const int nwpad = {nwpad};")
+    o(f"    const float *lwcull = ltab + {off_wcull}, *lwnarrow = ltab + {off_wnarrow};")
+    o("#pragma nounroll")
+    o(f"    for (int g = 0; g < {nstage}; g++) {{")
+    o("      if (__builtin_amdgcn_ballot_w64(dead == 0.0f) == 0ull && qn == 0 && qb == 0) break;  // every lane decided")
+    o("      float cx = 0, cy = 0, cz = 0, zx = 0, zy = 0, zz = 0;")
+    o("      int mlo = 0, mhi = 0;  // lane k holds the hit mask of this geom's partner k")
+    o("      switch (g) {")
+    for si, (lines, _, _, _) in enumerate(stages):
+        o(f"        case {si}: {{")
+        for ln in lines:
+            o("      " + ln)
+        o("        } break;")
+    o("        default: break;")
+    o("      }")
+    o("      const int gtype = kSpecStage[4 * g], gdoff = kSpecStage[4 * g + 1], store = kSpecStage[4 * g + 2];")
+    o("      const float cur6[6] = {cx, cy, cz, zx, zy, zz};")
+    o("      // partners some lane passed: bit k of the ballot <=> lane k's stored mask is non-zero")
+    o("      for (unsigned long long ab = __builtin_amdgcn_ballot_w64((mlo | mhi) != 0); ab; ab &= ab - 1) {")
+    o("        const int k = (int)__builtin_ctzll(ab);")
+    o("        const unsigned long long pm = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(mlo, k) |")
+    o("                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, k) << 32);")
+    o("        const int d = kSpecDesc[64 * g + k];")
+    o("        const int kind = d & 3, index = (d >> 2) & 255, ptype = (d >> 10) & 15;")
+    o("        const bool pfirst = (d >> 14) & 1;")
+    o("        float t6[6] = {0, 0, 0, 0, 0, 0};")
+    o("        if (kind == EK_SLOT) slot_get6(sf, index, t6);")
+    o("        if ((d >> 15) & 1)")
+    o("          queue_push<float, true>(wq, qb, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
+    o("                                  gtype, ptype, pfirst, gdoff, cur6, t6);")
+    o("        else")
+    o("          queue_push<float, false>(wq, qn, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
+    o("                                   gtype, ptype, pfirst, gdoff, cur6, t6);")
+    o("      }")
+    o("      if (store >= 0) slot_put6(sf, store, cur6);")
+    o("    }")
+    o("    if (qn > 0) queue_drain<float, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
+    if info.wbox:
+        o("    if (qb > 0) queue_drain<float, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
+    o("    fl = wq.flags[lane] & 3;")
+    o("    if (active && far) return V_UNSURE;  // nothing this lane's candidates said can be trusted")
+    o("    return !active ? V_NONE : ((fl & 1) ? V_CONTACT : ((fl & 2) ? V_UNSURE : V_NONE));")
+    o("  }")
+    o("};")
+    return "\n".join(out) + "\n"
+
+
+_TU = """// GENERATED translation unit: the float32 filter kernels of mjpl_filter.h around one model's Spec.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mjpl_filter.h"
+
+namespace {
+%(spec)s
+}  // namespace
+
+using namespace mjpl;
+#define SPEC_LAUNCH(kern, ...)                                                                      \\
+  do {                                                                                              \\
+    static size_t granted = 0;                                                                      \\
+    if (lds > granted) {                                                                            \\
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1; \\
+      granted = lds;                                                                                \\
+    }                                                                                               \\
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, __VA_ARGS__);                        \\
+    return hipGetLastError() == hipSuccess ? 0 : -1;                                                \\
+  } while (0)
+
+extern "C" {
+int mjpl_spec_abi(void) { return MJPL_SPEC_ABI; }
+unsigned long long mjpl_spec_hash(void) { return 0x%(hash)016xull; }
+int mjpl_spec_launch_configs(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
+                             int nfp, const double *Q, int64_t N, int layout, float tol, uint8_t *valid, int *ulist, int *ucount,
+                             UndecidedConfigs uc) {
+  SPEC_LAUNCH((k_filter_configs<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, Q, N, layout, tol, valid, ulist, ucount, uc);
+}
+int mjpl_spec_launch_endpoints(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
+                               int nfp, const double *QA, const double *QB, int64_t E, int layout, float tol, uint8_t *valid,
+                               int32_t *first_bad, int *status, int *ulist, int *ucount, UndecidedConfigs uc, int *slist,
+                               int *scount, ItemBuffers ib, double step) {
+  SPEC_LAUNCH((k_filter_endpoints<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, QA, QB, E, layout, tol, valid, first_bad, status,
+              ulist, ucount, uc, slist, scount, ib, step);
+}
+int mjpl_spec_launch_items(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
+                           int nfp, ItemBuffers ib, float tol, uint8_t *valid, int32_t *first_bad, int *ulist, int *ucount,
+                           UndecidedConfigs uc) {
+  SPEC_LAUNCH((k_filter_items<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, ib, tol, valid, first_bad, ulist, ucount, uc);
+}
+}
+"""
+
+
+def spec_path(hash_: int) -> str:
+    return os.path.join(SPEC_DIR, f"libmjpl_spec_{hash_:016x}.so")
+
+
+def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_tol: float = 0.0, force: bool = False,
+          keep_source: bool = True) -> str | None:
+    """Generate and compile the specialised library of (model, planning set, tolerance).  Returns the
+    path of the library, or None if the model cannot be specialised (immediate interpreter)."""
+    ip, fp, dp, info = dump_program(model, allowed_collision_bodies, qidx, qpos_base, filter_tol)
+    if info.immediate or not info.filter_usable:
+        return None
+    os.makedirs(SPEC_DIR, exist_ok=True)
+    target = spec_path(info.hash)
+    deps = [os.path.join(_build.CSRC, f) for f in ("mjpl_filter.h", "mjpl_device.h", "mjpl_trig.h")] + [__file__]
+    if not force and os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
+        return target
+    src = _TU % dict(spec=generate(ip, fp, dp, info), hash=info.hash, maxs=info.maxs, wbox="true" if info.wbox else "false")
+    src_path = os.path.join(SPEC_DIR, f"spec_{info.hash:016x}.hip")
+    with open(src_path, "w") as f:
+        f.write(src)
+    cmd = [_build.hipcc(), *_build.HIPCC_FLAGS, "-Wno-unused-variable", "-Wno-unused-but-set-variable", f"-I{_build.CSRC}",
+           "-o", target, src_path]
+    subprocess.run(cmd, check=True)
+    if not keep_source:
+        os.remove(src_path)
+    return target

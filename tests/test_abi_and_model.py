@@ -3,6 +3,7 @@ without a GPU), the product fails loudly without a device, and the model compile
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -141,3 +142,30 @@ def test_mjcf_emitter_round_trips_through_the_parser(tmp_path):
     except ImportError:
         r = subprocess.run([sys.executable, tool, "--n", "10", "--models", "ur5e"], capture_output=True, text=True)
         assert r.returncode == 0 and "NOTHING WAS CHECKED" in r.stdout
+
+
+def test_program_dump_and_code_generation_need_no_gpu():
+    """mjpl_program_dump compiles a model on the host; mjpl_amd/specialise.py turns the program into
+    HIP source.  Hashes are stable, depend on the planning set, and the generated source has one
+    stage per moving geom and one bounding cull per enabled pair."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mjpl_amd import scenes, specialise
+    from spec_models import spec_models
+    seen = set()
+    for name, m, allowed, qidx, base in spec_models():
+        ip, fp, dp, info = specialise.dump_program(m, allowed, qidx, base)
+        ip2, fp2, _, info2 = specialise.dump_program(m, allowed, qidx, base)
+        assert info.hash == info2.hash and np.array_equal(ip, ip2) and np.array_equal(fp.view(np.uint32), fp2.view(np.uint32))
+        assert info.hash not in seen, name
+        seen.add(info.hash)
+        assert not info.immediate and info.filter_usable and info.spec_abi == 1
+        np.testing.assert_allclose(fp[np.isfinite(fp)], dp[np.isfinite(fp)].astype(np.float32), rtol=2e-5, atol=2e-4)
+        src = specialise.generate(ip, fp, dp, info)
+        assert src.count("MJPL_SPEC_CULL(") + src.count("MJPL_SPEC_SLOTCULL(") + src.count("MJPL_SPEC_HIT(") >= 10
+        assert "struct Spec" in src and f"{info.hash:016x}" in src
+    m = scenes.franka_p(True, True)  # moving boxes: immediate interpreter, nothing to specialise
+    _, _, _, info = specialise.dump_program(m)
+    assert info.immediate
+    with pytest.raises(ValueError, match="immediate"):
+        specialise.generate(*specialise.dump_program(m))
+    assert specialise.build(m) is None
