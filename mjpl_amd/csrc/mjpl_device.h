@@ -794,15 +794,16 @@ __device__ __forceinline__ void sincos_half(T x, T *s, T *c) {
 
 // Walk the moving part of the body tree for this lane's configuration.
 //   ip, tp : program tables (control words; constants in the instantiation's scalar type)
-//   q      : this lane's planning columns (always float64), q[c*qstride]
+//   q      : this lane's planning columns, q[c*qstride] (float64; the float32 filter also takes
+//            them already rounded to binary32)
 //   save   : this lane's LDS pose-save area, save[(slot*7+k)*sstride]
 // Returns V_CONTACT iff the configuration has a contact outside the allowed body pairs,
 // V_NONE if it has none, and -- filter path only -- V_UNSURE if that cannot be told within
 // `tol` (the caller then re-runs the configuration on the exact path).
 // `active` = false lanes run along (wave-uniform control flow) but never report anything.
 // EMIT: also write body/geom world poses to `out` row `row` (FK parity kernel, exact path).
-template <class T, int MAXS, bool EMIT, bool WBOX, bool MBOX>
-__device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const double *q, int qstride,
+template <class T, int MAXS, bool EMIT, bool WBOX, bool MBOX, class QT>
+__device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const QT *q, int qstride,
                                           T *save, int sstride, bool active, T tol, const FkOut &out,
                                           int64_t row) {
   typedef typename Real<T>::Tab Tab;
@@ -1157,12 +1158,51 @@ struct UndecidedConfigs {
 };
 
 // Where a drain reports candidates it cannot decide (count == nullptr: flag the owning lane).
+// Where the edges of a launch live, for kernels that rebuild a waypoint instead of reading it.
+struct EdgeSource {
+  const double *QA, *QB;  // null: not an edge launch
+  long long E;
+  int layout;
+  double step;
+};
+
+// Waypoint `idx` (1-based) of edge i, EXACTLY as the reference's recurrence produces it
+// (planning/utils.py:182-185, the statements of edge_body): idx steps from QA, each recomputing
+// direction and distance from the previous waypoint.  `out[0..nplan)` doubles as the working row.
+// Meant for the few waypoints that go to the exact re-check -- one lane walks alone here.
+template <class Perm>
+__device__ inline void exact_waypoint(const EdgeSource &src, Perm perm, int nplan, long long i, int idx,
+                                      double *out) {
+  auto at = [&](const double *Q, int k) -> double {
+    return (src.layout == MJPL_SOA) ? Q[(long long)k * src.E + i] : Q[i * nplan + k];
+  };
+  for (int k = 0; k < nplan; k++) out[k] = at(src.QA, k);
+  for (int n = 0; n < idx; n++) {
+    double s = 0;
+    for (int k = 0; k < nplan; k++) {
+      const int col = perm[k];
+      const double d = at(src.QB, col) - out[col];
+      s = s + d * d;
+    }
+    const double mag = sqrt(s);
+    const double sm = src.step < mag ? src.step : mag;
+    for (int k = 0; k < nplan; k++) {
+      const double d = at(src.QB, k) - out[k];
+      out[k] = out[k] + (d / mag) * sm;
+    }
+  }
+}
+
 struct PatchSink {
   UndecidedConfigs uc;
   const double *qcol;  // configurations of this wave's lanes: q[k] of lane l at qcol[k * B + l * L]
-  int B, L, nplan;     // (LDS columns: B = block size, L = 1; row-major items: B = 1, L = nplan)
+  int B, L, nplan;     // (LDS columns: B = block size, L = 1)
   int idx;             // check index of the configurations under test (wave-uniform) ...
   const int *item_edge, *item_idx;  // ... or, lane-per-waypoint kernels: (edge, index) of item i
+  // lane-per-waypoint kernels test waypoints in closed form (see k_filter_items): what goes to the
+  // exact re-check is rebuilt by the recurrence, not copied from qcol
+  EdgeSource src;
+  IP perm;
 };
 
 // ----------------------------------------------------------------------------- queued narrowphase
@@ -1218,6 +1258,12 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
   typedef const T *Tab;
   typedef GeomT<T> Geom;
   constexpr int CAP = BOXQ ? QB_CAP : QN_CAP;
+#ifdef MJPL_X_NODRAIN  // timing-only build: the item kernel's candidates are queued and thrown away
+  if (ps.item_idx) {
+    qn = 0;
+    return;
+  }
+#endif
   const T *qf = BOXQ ? wq.bf : wq.nf;
   const int *qi0 = BOXQ ? wq.bi0 : wq.ni0, *qi1 = BOXQ ? wq.bi1 : wq.ni1;
   const int lane = threadIdx.x & 63;
@@ -1305,10 +1351,17 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
       if (ps.uc.count) {
         const int u = atomicAdd(ps.uc.count, 1);
         if (u < ps.uc.cap) {
-          for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + owner * ps.L];
           const int item = (int)((unsigned)wq.flags[owner] >> 2);
-          ps.uc.edge[u] = ps.item_edge ? ps.item_edge[item] : item;
-          ps.uc.idx[u] = ps.item_idx ? ps.item_idx[item] : ps.idx;
+          const int ed = ps.item_edge ? ps.item_edge[item] : item;
+          const int ix = ps.item_idx ? ps.item_idx[item] : ps.idx;
+          if (ps.src.QA) {  // row `ed` of the caller's configurations (ix = 0), or waypoint ix of edge `ed`
+#ifndef MJPL_X_NOREGEN
+            exact_waypoint(ps.src, ps.perm, ps.nplan, ed, ix, ps.uc.q + (size_t)u * ps.nplan);
+#endif
+          } else
+            for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + owner * ps.L];
+          ps.uc.edge[u] = ed;
+          ps.uc.idx[u] = ix;
           ps.uc.ga[u] = (int)gd[GD_GEOMID];
           int gb;
           if (!BOXQ && kind == EK_SLOT) gb = (int)gd[GD_WBOUND + 2 * nwpad + GS_GEOMID + index];
@@ -1333,6 +1386,12 @@ __device__ __forceinline__ void queue_push(const WaveQueue<T> &wq, int &fill, T 
                                            int ptype, bool pfirst, int gdoff, const T *cur6, const T *t6) {
   constexpr int CAP = BOXQ ? QB_CAP : QN_CAP;
   const int lane = threadIdx.x & 63;
+#ifdef MJPL_X_NOPUSH  // timing-only build: the item kernel culls, but queues nothing (the masks stay live through fl)
+  if (ps.item_idx) {
+    fl ^= (int)(pm >> (lane & 31)) & 4;
+    return;
+  }
+#endif
   const int cnt = (int)__builtin_popcountll(pm);
   if (fill + cnt > CAP) {  // make room: one batch leaves the top of the queue
     queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps);
@@ -1357,9 +1416,9 @@ __device__ __forceinline__ void queue_push(const WaveQueue<T> &wq, int &fill, T 
 }
 
 // Queued version of run_config for models without moving boxes (slots hold pos + z axis).
-template <class T, int MAXS, bool WBOX>
+template <class T, int MAXS, bool WBOX, class QT>
 __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp, const T *ltab,
-                                                 const double *q, int qstride, T *save, int sstride,
+                                                 const QT *q, int qstride, T *save, int sstride,
                                                  bool active, T tol, const WaveQueue<T> &wq, int item,
                                                  const PatchSink &ps) {
   typedef typename Real<T>::Tab Tab;

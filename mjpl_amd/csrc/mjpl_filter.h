@@ -18,7 +18,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 1
+#define MJPL_SPEC_ABI 2
 // A model's own straight-line code is asked to fit three waves per SIMD (168 VGPRs): its register
 // pressure is a few registers above that without the bound, and the third wave is worth more
 template <class Spec> constexpr int kMinWaves = std::is_void<Spec>::value ? 1 : 3;
@@ -47,26 +47,30 @@ __device__ __forceinline__ WaveQueue<T> wave_queue(char *qmem) {
   return wq;
 }
 
-template <class T, int MAXS, bool WBOX, bool MBOX, class Spec = void>
-__device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int B, bool active, T tol,
+template <class T, int MAXS, bool WBOX, bool MBOX, class Spec = void, class QT = double>
+__device__ __forceinline__ int check_one(const Carve<T> &c, const QT *q, int B, bool active, T tol,
                                          int64_t row, const UndecidedConfigs &uc = UndecidedConfigs{},
                                          int idx = 0, const int *item_edge = nullptr,
-                                         const int *item_idx = nullptr, const double *sink_q = nullptr,
-                                         int sink_stride = 0, int qstride = 0) {
-  if (qstride == 0) qstride = B;  // q[k * qstride]; the LDS pose saves always use stride B
+                                         const int *item_idx = nullptr, const EdgeSource &src = EdgeSource{}) {
+  const int qstride = B;  // q[k * qstride]: an LDS column slice, like the pose saves
+#ifdef MJPL_X_NOCHECK  // timing-only build: what the item kernel costs around the check
+  if (item_idx) return V_NONE;
+#endif
   if constexpr (kQueued<T, MBOX>) {
     WaveQueue<T> wq = wave_queue<T>(c.qmem);
     PatchSink ps;
     ps.uc = uc;
-    // where a drain lane finds the owner's configuration: the LDS columns, or (lane-per-item
-    // kernel reading its configurations straight from the item buffer) global memory
-    ps.qcol = sink_q ? sink_q : c.col0 + (threadIdx.x & ~63);
-    ps.B = sink_q ? 1 : B;
-    ps.L = sink_q ? sink_stride : 1;
+    // where a drain lane finds the owner's configuration: the float64 LDS columns -- or, with
+    // `src` (float32 columns hold a rounded copy), the caller's rows / the recurrence from them
+    ps.qcol = c.col0 + (threadIdx.x & ~63);
+    ps.B = B;
+    ps.L = 1;
     ps.nplan = c.ip[H_NPLAN];
     ps.idx = idx;
     ps.item_edge = item_edge;
     ps.item_idx = item_idx;
+    ps.src = src;
+    ps.perm = c.ip + c.ip[H_OFF_PERM];
     if constexpr (!std::is_void<Spec>::value)  // this model's own straight-line check (same contract)
       return Spec::run(c.tp, c.ltab, q, qstride, c.save + threadIdx.x, B, active, tol, wq, (int)row, ps);
     else
@@ -82,7 +86,7 @@ __device__ __forceinline__ int check_one(const Carve<T> &c, const double *q, int
 template <class T>
 __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restrict__ gip, int nip,
                                               const T *__restrict__ gtp, int ntp, int nplan, int ncolsets,
-                                              int B) {
+                                              int B, size_t colscalar = sizeof(double)) {
   Carve<T> c;
 #if MJPL_TABLES_LDS
   // A/B build: [control words | constants | columns | saves | queues | ...], tables first so that
@@ -95,11 +99,13 @@ __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restric
   c.col0 = smem;
 #endif
   c.col1 = c.col0 + (size_t)nplan * B;
-  c.save = reinterpret_cast<T *>(c.col0 + (size_t)ncolsets * nplan * B);
+  // (float32 filter kernels keep binary32 columns: a third workgroup fits a CU's LDS with them)
+  const size_t colbytes = ((size_t)ncolsets * nplan * B * colscalar + 7) & ~(size_t)7;
+  c.save = reinterpret_cast<T *>(reinterpret_cast<char *>(c.col0) + colbytes);
   const int nsave = gip[H_NSAVE];
   // queue memory starts 8-byte aligned after the saves
   c.qmem = reinterpret_cast<char *>(c.col0) +
-           (((size_t)ncolsets * nplan * B * sizeof(double) + (size_t)nsave * 7 * B * sizeof(T) + 7) & ~(size_t)7);
+           ((colbytes + (size_t)nsave * 7 * B * sizeof(T) + 7) & ~(size_t)7);
   // queued kernels: constant-table copy behind the queues (staged below, before the barrier)
   c.ltab = reinterpret_cast<T *>(c.qmem + (size_t)(B / 64) * WaveQueue<T>::bytes());
   if (!Real<T>::exact)
@@ -116,14 +122,50 @@ __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restric
   return c;
 }
 
-// planning columns of configuration i -> this lane's LDS column slice
-__device__ __forceinline__ void load_columns(double *col, int B, const double *__restrict__ Q,
-                                             int64_t N, int64_t i, int nplan, int layout, bool active) {
-  for (int c = 0; c < nplan; c++) {
-    double v = 0.0;
-    if (active) v = (layout == MJPL_SOA) ? Q[(int64_t)c * N + i] : Q[i * nplan + c];
-    col[c * B] = v;
+// Number of planning columns when the kernel is built for one model (0: read from the program).
+// With it the per-column loops below unroll and their loads go out together.
+template <class Spec> struct StaticNplan { static constexpr int value = Spec::kNplan; };
+template <> struct StaticNplan<void> { static constexpr int value = 0; };
+
+// f(k, Q[row i][k]) for all planning columns, eight independent loads at a time (a plain loop
+// over a run-time nplan waits out one memory round trip per column)
+template <class F>
+__device__ __forceinline__ void for_row(const double *__restrict__ Q, int64_t N, int64_t i, int nplan,
+                                        int layout, bool on, F &&f) {
+  for (int k0 = 0; k0 < nplan; k0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      v[j] = (on && k0 + j < nplan) ? ((layout == MJPL_SOA) ? Q[(int64_t)(k0 + j) * N + i] : Q[i * nplan + k0 + j]) : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (k0 + j < nplan) f(k0 + j, v[j]);
   }
+}
+// the same over two arrays of one shape: f(k, A[i][k], B[i][k])
+template <class F>
+__device__ __forceinline__ void for_rows(const double *__restrict__ A, const double *__restrict__ Bq, int64_t N,
+                                         int64_t i, int nplan, int layout, bool on, F &&f) {
+  for (int k0 = 0; k0 < nplan; k0 += 8) {
+    double a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const bool in = on && k0 + j < nplan;
+      const int64_t at = (layout == MJPL_SOA) ? (int64_t)(k0 + j) * N + i : i * nplan + k0 + j;
+      a[j] = in ? A[at] : 0.0;
+      b[j] = in ? Bq[at] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (k0 + j < nplan) f(k0 + j, a[j], b[j]);
+  }
+}
+
+// planning columns of configuration i -> this lane's LDS column slice
+template <class QT>
+__device__ __forceinline__ void load_columns(QT *col, int B, const double *__restrict__ Q,
+                                             int64_t N, int64_t i, int nplan, int layout, bool active) {
+  for_row(Q, N, i, nplan, layout, active, [&](int c, double v) { col[c * B] = (QT)v; });
 }
 
 
@@ -136,13 +178,12 @@ __device__ __forceinline__ void load_columns(double *col, int B, const double *_
 // items are consecutive waypoints of one edge, so the lanes of a wave see similar poses and pass
 // the same bounding culls.  Edges with many waypoints stay with the walking kernel: `llist`.
 struct ItemBuffers {
-  double *w;        // [cap][nplan] waypoints, one row per item (a lane's items are adjacent rows,
-                    // so the lines it writes during its walk fill up in cache)
   int *edge, *idx;  // [cap] which edge, which check index (1..K)
   int *count;       // items written
   int cap;
   int *llist, *lcount;  // edges left to the walking kernel
   int kmax;             // edges with more interior waypoints than this stay with the walking kernel
+  double *tstep;        // [E] step / |QB - QA| of the edges that have items
   int *claim;           // [E] per-edge claim word (see k_filter_items)
   int gen;              // this launch's generation: claim[edge] == gen <=> the edge is in ulist already
 };
@@ -153,19 +194,14 @@ constexpr int kExpandMinWaypoints = 24;  // kmax is at least this; small batches
 __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const double *__restrict__ QA,
                                             int64_t E, int64_t i, double step, int layout, bool todo,
                                             const double *qe, int B, double *qw, int ws,
-                                            const ItemBuffers &ib) {
-  const int nplan = gip[H_NPLAN];
+                                            const ItemBuffers &ib, int nplan) {
   const int *perm = gip + gip[H_OFF_PERM];
   const int lane = threadIdx.x & 63;
-  auto start_col = [&](int k) -> double {
-    return todo ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
-  };
   bool at_end = true;
-  for (int k = 0; k < nplan; k++) {
-    const double a = start_col(k);
+  for_row(QA, E, i, nplan, layout, todo, [&](int k, double a) {
     qw[k * ws] = a;
     at_end = at_end && (a == qe[k * B]);
-  }
+  });
   double s0 = 0;
   for (int k = 0; k < nplan; k++) {
     const int col = perm[k];
@@ -190,13 +226,42 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
     const double mag = sqrt(s);
     degenerate = degenerate || !(mag > 0.0) || !(mag <= 1.79769313486231570815e+308);
     const double sm = step < mag ? step : mag;
-    bool eq = true;
+    // The nplan quotients d / mag share their divisor.  The compiler expands each division into
+    // div_scale x2, rcp, two Newton steps on the reciprocal, a product, a remainder, div_fmas,
+    // div_fixup; with every operand well inside the normal range (no scaling, no special case)
+    // that is  r = refined rcp(mag);  q0 = d r;  q = fma(fma(-mag, q0, d), r, q0)  -- the same
+    // operations on the same values, with r computed once.  Anything else divides as usual.
+    bool plain = !(mag >= 0x1p-400 && mag <= 0x1p400);
     for (int k = 0; k < nplan; k++) {
-      const double ek = qe[k * B];
-      double d = ek - qw[k * ws];
-      double nw = qw[k * ws] + (d / mag) * sm;
-      qw[k * ws] = nw;
-      eq = eq && (nw == ek);
+      const double ad = fabs(qe[k * B] - qw[k * ws]);
+      plain = plain || !(ad == 0.0 || ad >= 0x1p-400);
+    }
+#ifdef MJPL_X_PLAINDIV  // timing-only build: every quotient by the compiler's division
+    plain = true;
+#endif
+    bool eq = true;
+    if (__ballot(plain) != 0ull) {  // (wave-uniform: a per-lane select would compute both)
+      for (int k = 0; k < nplan; k++) {
+        const double ek = qe[k * B];
+        const double d = ek - qw[k * ws];
+        const double nw = qw[k * ws] + (d / mag) * sm;
+        qw[k * ws] = nw;
+        eq = eq && (nw == ek);
+      }
+    } else {
+      double r = __builtin_amdgcn_rcp(mag);
+      r = fma(r, fma(-mag, r, 1.0), r);
+      r = fma(r, fma(-mag, r, 1.0), r);
+      for (int k = 0; k < nplan; k++) {
+        const double ek = qe[k * B];
+        const double d = ek - qw[k * ws];
+        const double q0 = d * r;
+        double quo = fma(fma(-mag, q0, d), r, q0);
+        quo = (d == 0.0) ? d : quo;  // (+-0 / mag keeps its sign)
+        const double nw = qw[k * ws] + quo * sm;
+        qw[k * ws] = nw;
+        eq = eq && (nw == ek);
+      }
     }
     return eq;
   };
@@ -208,6 +273,9 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
       if (walking) {
         if (advance()) walking = false;
         else if (++K > ib.kmax) walking = false;
+#ifdef MJPL_X_SHORTWALK  // timing-only build: one step of the walk
+        walking = false;
+#endif
         if (degenerate) { walking = false; K = ib.kmax + 1; }  // the walking kernel reports it
       }
     }
@@ -234,17 +302,21 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
     for (int slot = first; slot < ib.cap; slot++) ib.edge[slot] = -1;  // reserved but void
     done = true;
   }
-  // second walk: write the waypoints
-  for (int k = 0; k < nplan; k++) qw[k * ws] = start_col(k);
-  for (int idx = 1; __ballot(!done && idx <= K) != 0ull; idx++) {
-    if (!done && idx <= K) {
-      advance();
-      const int slot = first + idx - 1;
-      for (int k = 0; k < nplan; k++) ib.w[(size_t)slot * nplan + k] = qw[k * ws];
-      ib.edge[slot] = (int)i;
-      ib.idx[slot] = idx;
+  // The items carry (edge, index) only.  The reference's waypoint idx is idx steps of length
+  // `step` from QA towards QB, each with a freshly computed direction: it lies within a few
+  // idx * 2^-53 |q| of QA + idx * step * (QB - QA) / |QB - QA|, which is what k_filter_items tests
+  // (its float32 bounds absorb 1e-5; the exact re-check rebuilds the waypoint by the recurrence).
+  // So the walk above is needed for the COUNT only -- where `step` divides the edge length the
+  // count hangs on the last bit of the running distance -- and no waypoint is stored.
+  if (!done && K > 0) ib.tstep[i] = step / sqrt(s0);
+#ifdef MJPL_X_NOSTORE  // timing-only build: items reserved, not written
+  if (K < 1000) return;
+#endif
+  if (!done)
+    for (int idx = 1; idx <= K; idx++) {
+      ib.edge[first + idx - 1] = (int)i;
+      ib.idx[first + idx - 1] = idx;
     }
-  }
 }
 
 // Endpoint pass of the two-pass edge filter: check 0 (the endpoint QB, utils.py:144) for every
@@ -262,22 +334,25 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
                    double step) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
-  const int nplan = gip[H_NPLAN];
+  const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
   // (immediate interpreter + item expansion: a second column set holds the walking waypoint)
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, (!kQueued<float, MBOX> && ib.count) ? 2 : 1, B);
+  // queued interpreter: binary32 columns for the check (what goes to the exact re-check is read
+  // from QB again), and the walk below reuses the workgroup's columns, saves and queues
+  constexpr bool kQ = kQueued<float, MBOX>;
+  typedef typename std::conditional<kQ, float, double>::type QT;
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, (!kQ && ib.count) ? 2 : 1, B, sizeof(QT));
   const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
   const bool active = i < E;
-  double *qw = c.col0 + threadIdx.x;
+  QT *qw = reinterpret_cast<QT *>(c.col0) + threadIdx.x;
   load_columns(qw, B, QB, E, i, nplan, layout, active);
   __syncthreads();
   bool finite = true;
-  for (int k = 0; k < nplan; k++) {
-    const double a = active ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
-    const double b = qw[k * B];
+  for_rows(QA, QB, E, i, nplan, layout, active, [&](int, double a, double b) {
     finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
-  }
+  });
   const bool run = active && finite;
-  const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, qw, B, run, tol, i, uc, 0);
+  const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, qw, B, run, tol, i, uc, 0, nullptr, nullptr,
+                                                            kQ ? EdgeSource{QB, QB, E, layout, 0.0} : EdgeSource{});
   bool survive = run && code != V_CONTACT;
   if (active) {
     if (!finite) {
@@ -292,7 +367,7 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
       if (code == V_UNSURE) {  // the endpoint itself goes to the exact configuration kernel
         const int j = kQueued<float, MBOX> ? uc.cap : atomicAdd(uc.count, 1);  // (queued: the whole edge)
         if (j < uc.cap) {
-          for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
+          for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = (double)qw[k * B];  // (float64 columns here)
           uc.edge[j] = (int)i;
           uc.idx[j] = 0;
           uc.ga[j] = uc.gb[j] = -1;
@@ -309,27 +384,36 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
       }
     }
   }
+#ifdef MJPL_X_NOEXPAND  // timing-only build: the endpoint kernel without the waypoint count / the items
+  return;
+#endif
   const unsigned long long m = __ballot(survive);
-  if (m == 0ull) return;
   if (ib.count) {
-    // lane-per-waypoint interior pass: emit this edge's interior waypoints as work items.  The
-    // walking waypoint lives in this wave's (now idle) candidate-queue memory.
-    if constexpr (kQueued<float, MBOX>) {
-      if ((size_t)nplan * 64 * sizeof(double) <= WaveQueue<float>::bytes()) {
-        double *scratch = reinterpret_cast<double *>(c.qmem + (size_t)(threadIdx.x >> 6) * WaveQueue<float>::bytes()) +
-                          (threadIdx.x & 63);
-        expand_edge(gip, QA, E, i, step, layout, survive, qw, B, scratch, 64, ib);
+    // lane-per-waypoint interior pass: emit this edge's interior waypoints as work items
+    if constexpr (kQ) {
+      // the walk's two float64 rows per lane (QB, the walking waypoint) take over the workgroup's
+      // columns, saves and queues once every wave is through with its check
+      const size_t idle = (size_t)(reinterpret_cast<char *>(c.ltab) - reinterpret_cast<char *>(c.col0));
+      const bool fits = (size_t)2 * nplan * B * sizeof(double) <= idle;
+      __syncthreads();
+      if (m == 0ull) return;
+      if (fits) {
+        double *qe = c.col0 + threadIdx.x;
+        load_columns(qe, B, QB, E, i, nplan, layout, active);
+        expand_edge(gip, QA, E, i, step, layout, survive, qe, B, qe + (size_t)nplan * B, B, ib, nplan);
         if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
         return;
       }
     } else {
-      expand_edge(gip, QA, E, i, step, layout, survive, qw, B, c.col1 + threadIdx.x, B, ib);
+      if (m == 0ull) return;
+      expand_edge(gip, QA, E, i, step, layout, survive, qw, B, c.col1 + threadIdx.x, B, ib, nplan);
       if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
       return;
     }
     if (survive) ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;  // too many columns: walking kernel
     return;
   }
+  if (m == 0ull) return;
   const int lane = threadIdx.x & 63;
   int base = 0;
   if (lane == 0) base = atomicAdd(scount, (int)__builtin_popcountll(m));
@@ -346,15 +430,19 @@ k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__
                  UndecidedConfigs uc) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
-  const int nplan = gip[H_NPLAN];
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B);
+  const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
+  constexpr bool kQ = kQueued<float, MBOX>;
+  typedef typename std::conditional<kQ, float, double>::type QT;  // (see k_filter_endpoints)
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B, sizeof(QT));
   const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
   const bool active = i < N;
-  load_columns(c.col0 + threadIdx.x, B, Q, N, i, nplan, layout, active);
+  QT *qc = reinterpret_cast<QT *>(c.col0) + threadIdx.x;
+  load_columns(qc, B, Q, N, i, nplan, layout, active);
   __syncthreads();
   // queued interpreter: undecided pairs go to k_patch_pairs through `uc` (which clears valid[i]
   // on a contact); V_UNSURE comes back only for what could not be handed over
-  const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, c.col0 + threadIdx.x, B, active, tol, i, uc, 0);
+  const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, qc, B, active, tol, i, uc, 0, nullptr, nullptr,
+                                                            kQ ? EdgeSource{Q, Q, N, layout, 0.0} : EdgeSource{});
   if (active) {
     if (code == V_UNSURE) ulist[atomicAdd(ucount, 1)] = (int)i;
     else valid[i] = (code == V_CONTACT) ? 0 : 1;
@@ -370,24 +458,33 @@ k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__
 template <class Spec, int MAXS, bool WBOX, bool MBOX>
 __global__ void MJPL_ITEMS_BOUNDS
 k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp, ItemBuffers ib,
-               float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
+               EdgeSource src, float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
                int *__restrict__ ulist, int *__restrict__ ucount, UndecidedConfigs uc) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
   const int64_t n = *ib.count < ib.cap ? *ib.count : ib.cap;
   if ((int64_t)blockIdx.x * B >= n) return;
-  const int nplan = gip[H_NPLAN];
-  // the configuration is read straight from the item buffer (coalesced, once per joint): no LDS
-  // columns in this kernel
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 0, B);
+  const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B, sizeof(float));
   const int64_t it = (int64_t)blockIdx.x * B + threadIdx.x;
-  const bool active = it < n && ib.edge[it] >= 0;  // (a void slot: reserved by an edge that did not fit)
-  __syncthreads();
   const int64_t itc = it < (int64_t)ib.cap ? it : 0;
-  const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, ib.w + itc * nplan, B, active, tol, it, uc, 0, ib.edge,
-                                                      ib.idx, ib.w + (itc - (threadIdx.x & 63)) * nplan, nplan, 1);
+  const int ed = it < n ? ib.edge[itc] : -1;
+  const bool active = ed >= 0;  // (a void slot: reserved by an edge that did not fit)
+  // the waypoint in closed form (see expand_edge): QA + min(idx * step / |QB - QA|, 1) (QB - QA),
+  // rounded to binary32 as the check would round it anyway
+  float *qw = reinterpret_cast<float *>(c.col0) + threadIdx.x;
+  {
+    const int64_t e0 = active ? ed : 0;
+    double t = active ? (double)ib.idx[itc] * ib.tstep[e0] : 0.0;
+    t = t < 1.0 ? t : 1.0;
+    for_rows(src.QA, src.QB, src.E, e0, nplan, src.layout, true, [&](int k, double a, double b) {
+      qw[k * B] = active ? (float)fma(t, b - a, a) : 0.0f;
+    });
+  }
+  __syncthreads();
+  const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, qw, B, active, tol, it, uc, 0, ib.edge,
+                                                            ib.idx, src);
   if (active && code != V_NONE) {
-    const int ed = ib.edge[it];
     if (code == V_CONTACT) {
       valid[ed] = 0;
       if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)ib.idx[it]);
@@ -398,7 +495,7 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
         if (uc.count) {
           const int j = atomicAdd(uc.count, 1);
           if (j < uc.cap) {
-            for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = ib.w[itc * nplan + k];
+            exact_waypoint(src, gip + gip[H_OFF_PERM], nplan, ed, ib.idx[it], uc.q + (size_t)j * nplan);
             uc.edge[j] = ed;
             uc.idx[j] = ib.idx[it];
             uc.ga[j] = uc.gb[j] = -1;

@@ -931,7 +931,7 @@ struct SpecLib {
   typedef int (*EndpointsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, const double *,
                              const double *, int64_t, int, float, uint8_t *, int32_t *, int *, int *, int *, UndecidedConfigs,
                              int *, int *, ItemBuffers, double);
-  typedef int (*ItemsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, ItemBuffers, float,
+  typedef int (*ItemsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, ItemBuffers, EdgeSource, float,
                          uint8_t *, int32_t *, int *, int *, UndecidedConfigs);
   void *lib = nullptr;
   ConfigsFn configs = nullptr;
@@ -980,7 +980,8 @@ struct mjpl_engine {
   double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
   int *d_ucedge = nullptr, *d_ucidx = nullptr, *d_ucga = nullptr, *d_ucgb = nullptr;
   double *d_geomtab = nullptr;  // GTB_LEN doubles per model geom (k_patch_pairs)
-  double *d_itemw = nullptr;    // lane-per-waypoint interior pass: waypoints, (edge, idx), long-edge list
+  // lane-per-waypoint interior pass: (edge, idx) items, long-edge list
+  double *d_tstep = nullptr;
   int *d_itemedge = nullptr, *d_itemidx = nullptr, *d_llist = nullptr, *d_icount = nullptr;
   int *d_eclaim = nullptr;  // [llist_cap] per-edge claim word: the launch generation that listed the edge in d_ulist
   int claim_gen = 0;
@@ -1577,9 +1578,9 @@ int compile_program(mjpl_engine *e) {
 }
 
 size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(double), int block = kBlock,
-                 bool queued = false) {
+                 bool queued = false, size_t colscalar = sizeof(double)) {
   const size_t nplan = e->qidx.size();
-  size_t bytes = (size_t)ncolsets * nplan * block * sizeof(double) + (size_t)e->nsave * 7 * block * scalar;
+  size_t bytes = (((size_t)ncolsets * nplan * block * colscalar + 7) & ~(size_t)7) + (size_t)e->nsave * 7 * block * scalar;
   bytes = (bytes + 7) & ~(size_t)7;
   if (queued) bytes += (size_t)(block / 64) * WaveQueue<float>::bytes() + ((e->fp.size() * sizeof(float) + 7) & ~(size_t)7);
 #if MJPL_TABLES_LDS
@@ -1695,7 +1696,8 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
     const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
-    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate());
+    // (queued interpreter: binary32 columns)
+    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate(), e->immediate() ? sizeof(double) : sizeof(float));
     if (e->spec)
       rc = e->spec->configs(e->stream, fgrid, (unsigned)fblock, ldsf, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQ, N,
                             layout, e->filter_tol, dvalid, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
@@ -1760,10 +1762,12 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
     const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
-    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate());
+    const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate());  // walking kernel: float64 columns
+    // endpoint and item kernels of the queued interpreter keep binary32 columns
+    const size_t ldsq = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate(), e->immediate() ? sizeof(double) : sizeof(float));
     // the endpoint kernel of the immediate interpreter walks the waypoint recurrence in a second
-    // column set (the queued one uses its idle queue memory)
-    const size_t ldse = e->immediate() ? lds_bytes(e, 2, sizeof(float), fblock, false) : ldsf;
+    // column set (the queued one reuses the workgroup's columns, saves and queues)
+    const size_t ldse = e->immediate() ? lds_bytes(e, 2, sizeof(float), fblock, false) : ldsq;
     // two passes unless only the interior was asked for: endpoints of all edges, then the interior
     // waypoints of the edges whose endpoint passed
     const bool two_pass = e->two_pass && !(flags & MJPL_EDGE_INTERIOR_ONLY);
@@ -1777,17 +1781,16 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       // a handful of long edges (path shortcutting) is best served one waypoint per lane, too
       const size_t want = std::min<size_t>(std::max<size_t>((size_t)E * 8, (size_t)1 << 18) + 4096, e->item_cap_limit);
       if (want > e->item_cap || (size_t)E > e->llist_cap) {
-        for (void *ptr : {(void *)e->d_itemw, (void *)e->d_itemedge, (void *)e->d_itemidx, (void *)e->d_llist,
+        for (void *ptr : {(void *)e->d_tstep, (void *)e->d_itemedge, (void *)e->d_itemidx, (void *)e->d_llist,
                           (void *)e->d_eclaim})
           if (ptr) HIP_TRY(hipFree(ptr));
-        e->d_itemw = nullptr; e->d_itemedge = e->d_itemidx = e->d_llist = e->d_eclaim = nullptr;
+        e->d_tstep = nullptr;
+        e->d_itemedge = e->d_itemidx = e->d_llist = e->d_eclaim = nullptr;
         e->item_cap = e->llist_cap = 0;
-        // rows are sized by nq, the upper bound of nplan: mjpl_set_planning may widen the planning
-        // set later without this buffer being reallocated
-        HIP_TRY(hipMalloc(&e->d_itemw, want * std::max<size_t>(1, e->m.nq) * sizeof(double)));
         HIP_TRY(hipMalloc(&e->d_itemedge, want * sizeof(int)));
         HIP_TRY(hipMalloc(&e->d_itemidx, want * sizeof(int)));
         HIP_TRY(hipMalloc(&e->d_llist, (size_t)E * sizeof(int)));
+        HIP_TRY(hipMalloc(&e->d_tstep, (size_t)E * sizeof(double)));
         HIP_TRY(hipMalloc(&e->d_eclaim, (size_t)E * sizeof(int)));
         HIP_TRY(hipMemsetAsync(e->d_eclaim, 0, (size_t)E * sizeof(int), e->stream));
         e->claim_gen = 0;
@@ -1798,8 +1801,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         HIP_TRY(hipMemsetAsync(e->d_eclaim, 0, e->llist_cap * sizeof(int), e->stream));
         e->claim_gen = 1;
       }
-      ib = ItemBuffers{e->d_itemw, e->d_itemedge, e->d_itemidx, e->d_icount, (int)e->item_cap, e->d_llist,
-                       e->d_icount + kCtr, kmax, e->d_eclaim, e->claim_gen};
+      ib = ItemBuffers{e->d_itemedge, e->d_itemidx, e->d_icount, (int)e->item_cap, e->d_llist,
+                       e->d_icount + kCtr, kmax, e->d_tstep, e->d_eclaim, e->claim_gen};
     }
     if (two_pass) {
       if ((size_t)E > e->slist_cap) {
@@ -1829,17 +1832,17 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     MJPL_MARK(1);  // after k_filter_endpoints (nothing ran yet in a one-pass launch)
     if (expand) {
       const unsigned igrid = (unsigned)((e->item_cap + fblock - 1) / fblock);
-      const size_t ldsi = lds_bytes(e, 0, sizeof(float), fblock, !e->immediate());
+      const EdgeSource src = {dQA, dQB, (long long)E, layout, step};
       if (e->spec)
-        rc = e->spec->items(e->stream, igrid, (unsigned)fblock, ldsi, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib,
-                            e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
+        rc = e->spec->items(e->stream, igrid, (unsigned)fblock, ldsq, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib,
+                            src, e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
              : fail(MJPL_E_HIP, "specialised item kernel failed to launch");
       else rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_items<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
-        int r = allow_lds(kern, ldsi);
+        int r = allow_lds(kern, ldsq);
         if (r != MJPL_OK) return r;
-        hipLaunchKernelGGL(kern, dim3(igrid), dim3(fblock), ldsi, e->stream, e->d_ip, (int)e->ip.size(),
-                           e->d_fp, (int)e->fp.size(), ib, e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount,
+        hipLaunchKernelGGL(kern, dim3(igrid), dim3(fblock), ldsq, e->stream, e->d_ip, (int)e->ip.size(),
+                           e->d_fp, (int)e->fp.size(), ib, src, e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount,
                            uc);
         return MJPL_OK;
       });
@@ -2036,7 +2039,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_ucgb) (void)hipFree(e->d_ucgb);
   if (e->d_geomtab) (void)hipFree(e->d_geomtab);
   if (e->d_nn) (void)hipFree(e->d_nn);
-  if (e->d_itemw) (void)hipFree(e->d_itemw);
+  if (e->d_tstep) (void)hipFree(e->d_tstep);
   if (e->d_itemedge) (void)hipFree(e->d_itemedge);
   if (e->d_itemidx) (void)hipFree(e->d_itemidx);
   if (e->d_llist) (void)hipFree(e->d_llist);
@@ -2162,7 +2165,8 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   out->filter_err_b = (float)e->ferr_b;
   out->filter_poisoned_geoms = e->npoisoned;
   out->filter_block_threads = e->immediate() ? kBlock : kFilterBlock;
-  out->lds_bytes_filter = (int)lds_bytes(e, 1, sizeof(float), out->filter_block_threads, !e->immediate());
+  out->lds_bytes_filter = (int)lds_bytes(e, 1, sizeof(float), out->filter_block_threads, !e->immediate(),
+                                         e->immediate() ? sizeof(double) : sizeof(float));
   out->block_threads = kBlock;
   out->compute_units = e->prop.multiProcessorCount;
   strncpy(out->arch, e->prop.gcnArchName, sizeof(out->arch) - 1);

@@ -319,7 +319,9 @@ def generate(ip, fp, dp, info) -> str:
                 dot = lin([(pz[0], "cx"), (pz[1], "cy"), (pz[2], "cz")], -(np.float32(pz[0]) * np.float32(ppos[0]) + np.float32(pz[1]) * np.float32(ppos[1]) + np.float32(pz[2]) * np.float32(ppos[2])))
                 w(f"MJPL_SPEC_HIT({k}, !({dot} + dead > {lit(wbound[wrow])}));")
                 partners.append((EK_PLANE, wrow, GT_PLANE, 1, 0))
-            # other static geoms
+            # other static geoms, two per packed cull
+            w("const float ux = cx + dead;")
+            statics = []
             for wrow in range(64):
                 if not (wmask >> wrow) & 1:
                     continue
@@ -327,9 +329,14 @@ def generate(ip, fp, dp, info) -> str:
                 ptype, pgid = info_word & 255, info_word >> 8
                 pfirst = 1 if (ptype < gtype or (ptype == gtype and pgid < geom_id)) else 0
                 X, Y, Z = (float(fp[wc_at(wrow, f)]) for f in range(3))
-                k = len(partners)
-                w(f"MJPL_SPEC_CULL({k}, {lit(X)}, {lit(Y)}, {lit(Z)}, {lit(wbound[wrow])});")
+                statics.append((len(partners), X, Y, Z, wbound[wrow]))
                 partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if ptype == GT_BOX else 0))
+            for a, b in zip(statics[0::2], statics[1::2]):
+                w(f"MJPL_SPEC_CULL2({a[0]}, {b[0]}, {lit(a[1])}, {lit(b[1])}, {lit(a[2])}, {lit(b[2])}, {lit(a[3])}, {lit(b[3])}, "
+                  f"{lit(a[4])}, {lit(b[4])});")
+            if len(statics) % 2:
+                k, X, Y, Z, bound = statics[-1]
+                w(f"MJPL_SPEC_CULL({k}, {lit(X)}, {lit(Y)}, {lit(Z)}, {lit(bound)});")
             # earlier moving geoms in the slot file
             for n in range(maxs):
                 if not (smask >> n) & 1:
@@ -357,27 +364,34 @@ def generate(ip, fp, dp, info) -> str:
     o("       R8 = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3; R1 = 2.0f * (q1 * q2 - q0 * q3); R2 = 2.0f * (q1 * q3 + q0 * q2); \\")
     o("       R3 = 2.0f * (q1 * q2 + q0 * q3); R5 = 2.0f * (q2 * q3 - q0 * q1); R6 = 2.0f * (q1 * q3 - q0 * q2); \\")
     o("       R7 = 2.0f * (q2 * q3 + q0 * q1); } while (0)")
+    o("typedef float spec_v2f __attribute__((ext_vector_type(2)));")
+    o("// (most culls pass for no lane of the wave: a scalar branch around the two v_writelane)")
     o("#define MJPL_SPEC_HIT(k, pass) \\")
     o("  do { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(pass); \\")
-    o("       mjpl::park_mask<k>(mlo, mhi, m_); } while (0)")
+    o("       if (m_) mjpl::park_mask<k>(mlo, mhi, m_); } while (0)")
+    o("// ux = cx, or +inf on a lane that is not to report anything (inactive / decided / out of range)")
     o("#define MJPL_SPEC_CULL(k, X, Y, Z, BOUND) \\")
-    o("  do { const float dx_ = cx - (X), dy_ = cy - (Y), dz_ = cz - (Z); \\")
-    o("       MJPL_SPEC_HIT(k, !(mjpl::sqnorm3(dx_, dy_, dz_) + dead > (BOUND))); } while (0)")
+    o("  do { const float dx_ = ux - (X), dy_ = cy - (Y), dz_ = cz - (Z); \\")
+    o("       MJPL_SPEC_HIT(k, !(mjpl::sqnorm3(dx_, dy_, dz_) > (BOUND))); } while (0)")
+    o("// two static partners at once: packed float32 arithmetic")
+    o("#define MJPL_SPEC_CULL2(ka, kb, XA, XB, YA, YB, ZA, ZB, BOUNDA, BOUNDB) \\")
+    o("  do { const spec_v2f dx_ = (spec_v2f){ux, ux} - (spec_v2f){XA, XB}, dy_ = (spec_v2f){cy, cy} - (spec_v2f){YA, YB}, \\")
+    o("                      dz_ = (spec_v2f){cz, cz} - (spec_v2f){ZA, ZB}; \\")
+    o("       const spec_v2f s_ = __builtin_elementwise_fma(dx_, dx_, __builtin_elementwise_fma(dy_, dy_, dz_ * dz_)); \\")
+    o("       MJPL_SPEC_HIT(ka, !(s_.x > (BOUNDA))); MJPL_SPEC_HIT(kb, !(s_.y > (BOUNDB))); } while (0)")
     o("#define MJPL_SPEC_SLOTCULL(k, n, BOUND) \\")
-    o("  do { const float dx_ = cx - sf.f[0][n], dy_ = cy - sf.f[1][n], dz_ = cz - sf.f[2][n]; \\")
-    o("       MJPL_SPEC_HIT(k, !(mjpl::sqnorm3(dx_, dy_, dz_) + dead > (BOUND))); } while (0)")
+    o("  do { const float dx_ = ux - sf.f[0][n], dy_ = cy - sf.f[1][n], dz_ = cz - sf.f[2][n]; \\")
+    o("       MJPL_SPEC_HIT(k, !(mjpl::sqnorm3(dx_, dy_, dz_) > (BOUND))); } while (0)")
     o("")
     o(f"__constant__ int kSpecDesc[{nstage} * 64] = {{")
     for d in desc:
         o("  " + ", ".join(str(x) for x in (d + [0] * (64 - len(d)))) + ",")
     o("};")
-    o(f"__constant__ int kSpecStage[{nstage} * 4] = {{  // gtype, gdoff, store, partners")
-    for (_, gtype, gdoff, store), d in zip(stages, desc):
-        o(f"  {gtype}, {gdoff}, {store}, {len(d)},")
-    o("};")
     o("")
     o("struct Spec {")
-    o("  static __device__ __forceinline__ int run(mjpl::FP tp, const float *ltab, const double *q, int qstride, float *save,")
+    o(f"  static constexpr int kNplan = {int(ip[H_NPLAN])};")
+    o("  template <class QT>")
+    o("  static __device__ __forceinline__ int run(mjpl::FP tp, const float *ltab, const QT *q, int qstride, float *save,")
     o("                                            int sstride, bool active, float tol, const mjpl::WaveQueue<float> &wq,")
     o("                                            int item, const mjpl::PatchSink &ps) {")
     o("    using namespace mjpl;")
@@ -398,22 +412,26 @@ def generate(ip, fp, dp, info) -> str:
     o("      if (__builtin_amdgcn_ballot_w64(dead == 0.0f) == 0ull && qn == 0 && qb == 0) break;  // every lane decided")
     o("      float cx = 0, cy = 0, cz = 0, zx = 0, zy = 0, zz = 0;")
     o("      int mlo = 0, mhi = 0;  // lane k holds the hit mask of this geom's partner k")
+    o("      // ... and the descriptor of partner k: one vector load per stage, issued ahead of the stage's")
+    o("      // arithmetic (a scalar load per hit stalls the wave for its whole latency)")
+    o("      const int dv = kSpecDesc[64 * g + lane];")
+    o("      int gtype = 0, gdoff = 0;")
     o("      switch (g) {")
-    for si, (lines, _, _, _) in enumerate(stages):
+    for si, (lines, gtype, gdoff, store) in enumerate(stages):
         o(f"        case {si}: {{")
         for ln in lines:
             o("      " + ln)
+        o(f"          gtype = {gtype}; gdoff = {gdoff};")
         o("        } break;")
     o("        default: break;")
     o("      }")
-    o("      const int gtype = kSpecStage[4 * g], gdoff = kSpecStage[4 * g + 1], store = kSpecStage[4 * g + 2];")
     o("      const float cur6[6] = {cx, cy, cz, zx, zy, zz};")
     o("      // partners some lane passed: bit k of the ballot <=> lane k's stored mask is non-zero")
     o("      for (unsigned long long ab = __builtin_amdgcn_ballot_w64((mlo | mhi) != 0); ab; ab &= ab - 1) {")
     o("        const int k = (int)__builtin_ctzll(ab);")
     o("        const unsigned long long pm = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(mlo, k) |")
     o("                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, k) << 32);")
-    o("        const int d = kSpecDesc[64 * g + k];")
+    o("        const int d = __builtin_amdgcn_readlane(dv, k);")
     o("        const int kind = d & 3, index = (d >> 2) & 255, ptype = (d >> 10) & 15;")
     o("        const bool pfirst = (d >> 14) & 1;")
     o("        float t6[6] = {0, 0, 0, 0, 0, 0};")
@@ -425,7 +443,12 @@ def generate(ip, fp, dp, info) -> str:
     o("          queue_push<float, false>(wq, qn, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
     o("                                   gtype, ptype, pfirst, gdoff, cur6, t6);")
     o("      }")
-    o("      if (store >= 0) slot_put6(sf, store, cur6);")
+    o("      switch (g) {  // (a literal slot index keeps the slot file in registers)")
+    for si, (_, _, _, store) in enumerate(stages):
+        if store >= 0:
+            o(f"        case {si}: slot_put6(sf, {store}, cur6); break;")
+    o("        default: break;")
+    o("      }")
     o("    }")
     o("    if (qn > 0) queue_drain<float, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
     if info.wbox:
@@ -475,9 +498,9 @@ int mjpl_spec_launch_endpoints(hipStream_t st, unsigned grid, unsigned block, si
               ulist, ucount, uc, slist, scount, ib, step);
 }
 int mjpl_spec_launch_items(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
-                           int nfp, ItemBuffers ib, float tol, uint8_t *valid, int32_t *first_bad, int *ulist, int *ucount,
+                           int nfp, ItemBuffers ib, EdgeSource src, float tol, uint8_t *valid, int32_t *first_bad, int *ulist, int *ucount,
                            UndecidedConfigs uc) {
-  SPEC_LAUNCH((k_filter_items<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, ib, tol, valid, first_bad, ulist, ucount, uc);
+  SPEC_LAUNCH((k_filter_items<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, ib, src, tol, valid, first_bad, ulist, ucount, uc);
 }
 }
 """
@@ -488,14 +511,14 @@ def spec_path(hash_: int) -> str:
 
 
 def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_tol: float = 0.0, force: bool = False,
-          keep_source: bool = True) -> str | None:
+          keep_source: bool = True, extra_flags=(), output: str | None = None) -> str | None:
     """Generate and compile the specialised library of (model, planning set, tolerance).  Returns the
     path of the library, or None if the model cannot be specialised (immediate interpreter)."""
     ip, fp, dp, info = dump_program(model, allowed_collision_bodies, qidx, qpos_base, filter_tol)
     if info.immediate or not info.filter_usable:
         return None
     os.makedirs(SPEC_DIR, exist_ok=True)
-    target = spec_path(info.hash)
+    target = output or spec_path(info.hash)  # (output, extra_flags: timing-only variants, tools/time_variants.sh)
     deps = [os.path.join(_build.CSRC, f) for f in ("mjpl_filter.h", "mjpl_device.h", "mjpl_trig.h")] + [__file__]
     if not force and os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
         return target
@@ -504,7 +527,7 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
     with open(src_path, "w") as f:
         f.write(src)
     cmd = [_build.hipcc(), *_build.HIPCC_FLAGS, "-Wno-unused-variable", "-Wno-unused-but-set-variable", f"-I{_build.CSRC}",
-           "-o", target, src_path]
+           *extra_flags, "-o", target, src_path]
     subprocess.run(cmd, check=True)
     if not keep_source:
         os.remove(src_path)

@@ -183,3 +183,46 @@ def _finger_pads(oracle_mod, allowed):
         Q = np.concatenate([qa, qb])
         np.testing.assert_array_equal(e.check_configs(Q), orc.valid_configs(Q, nthreads=8))
     e.close()
+
+
+def test_item_count_is_the_reference_walk(oracle_mod):
+    """The endpoint kernel counts the interior waypoints of an edge by walking the reference's
+    recurrence (planning/utils.py:182-185) -- with its divisions sharing one refined reciprocal.
+    Where the step divides the edge length the count hangs on the last bit of every intermediate
+    value: the number of items of a batch must equal the oracle's step-by-step count."""
+    m = scenes.franka_p(obstacles=False)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    e = eng_mod.Engine(m)
+    e.set_planning(qidx, base)
+    rng = np.random.default_rng(77)
+    E, step = 6000, 0.01
+    # around the home pose nothing is near contact: every endpoint survives, nothing is undecided,
+    # and the number of items is the sum of the counts
+    qa = base[qidx] + rng.uniform(-0.25, 0.25, size=(E, len(qidx)))
+    u = rng.normal(size=(E, len(qidx)))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    # lengths: exact multiples of the step (as an RRT extension makes them), near-multiples, anything
+    length = np.where(rng.random(E) < 0.6, step * rng.integers(1, 12, E), rng.uniform(0.001, 0.12, E))
+    length = np.where(rng.random(E) < 0.1, length * (1 + rng.uniform(-4, 4, E) * 2.0 ** -52), length)
+    qb = qa + length[:, None] * u
+    if rng.random() < 2:  # a few edges along one axis only (zero components in the direction)
+        qb[:200] = qa[:200]
+        qb[:200, 3] += step * rng.integers(1, 9, 200)
+    assert orc.valid_configs(qb).all()
+    want = 0
+    for i in range(E):
+        w, k = qa[i].copy(), 0
+        while True:
+            w = oracle_mod.step(w, qb[i], step)
+            if np.array_equal(w, qb[i]):
+                break
+            k += 1
+            assert k < 64
+        want += k
+    got_valid = e.check_edges(qa, qb, step)
+    np.testing.assert_array_equal(got_valid, orc.valid_edges(qa, qb, step, nthreads=8))
+    assert e.last_undecided() == 0
+    assert e.last_items() == want
+    e.close()
