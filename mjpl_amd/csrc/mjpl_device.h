@@ -1164,20 +1164,31 @@ struct EdgeSource {
   long long E;
   int layout;
   double step;
+  const double *ckpt;     // [item slot][nplan] exact waypoints of the items with idx % kCkptEvery == 0, or null
 };
+constexpr int kCkptEvery = 32;
 
 // Waypoint `idx` (1-based) of edge i, EXACTLY as the reference's recurrence produces it
-// (planning/utils.py:182-185, the statements of edge_body): idx steps from QA, each recomputing
+// (planning/utils.py:182-185, the statements of edge_body): steps from QA, each recomputing
 // direction and distance from the previous waypoint.  `out[0..nplan)` doubles as the working row.
-// Meant for the few waypoints that go to the exact re-check -- one lane walks alone here.
+// Meant for the few waypoints that go to the exact re-check -- one lane walks alone here, at most
+// kCkptEvery - 1 steps when the launch keeps checkpoints (`slot` = the waypoint's item slot; an
+// edge's items are consecutive slots).
 template <class Perm>
 __device__ inline void exact_waypoint(const EdgeSource &src, Perm perm, int nplan, long long i, int idx,
-                                      double *out) {
+                                      double *out, long long slot = -1) {
   auto at = [&](const double *Q, int k) -> double {
     return (src.layout == MJPL_SOA) ? Q[(long long)k * src.E + i] : Q[i * nplan + k];
   };
-  for (int k = 0; k < nplan; k++) out[k] = at(src.QA, k);
-  for (int n = 0; n < idx; n++) {
+  int from = 0;
+  if (src.ckpt && slot >= 0 && idx >= kCkptEvery) {
+    from = idx - idx % kCkptEvery;
+    const double *row = src.ckpt + (size_t)(slot - (idx - from)) * nplan;
+    for (int k = 0; k < nplan; k++) out[k] = row[k];
+  } else {
+    for (int k = 0; k < nplan; k++) out[k] = at(src.QA, k);
+  }
+  for (int n = from; n < idx; n++) {
     double s = 0;
     for (int k = 0; k < nplan; k++) {
       const int col = perm[k];
@@ -1356,7 +1367,7 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
           const int ix = ps.item_idx ? ps.item_idx[item] : ps.idx;
           if (ps.src.QA) {  // row `ed` of the caller's configurations (ix = 0), or waypoint ix of edge `ed`
 #ifndef MJPL_X_NOREGEN
-            exact_waypoint(ps.src, ps.perm, ps.nplan, ed, ix, ps.uc.q + (size_t)u * ps.nplan);
+            exact_waypoint(ps.src, ps.perm, ps.nplan, ed, ix, ps.uc.q + (size_t)u * ps.nplan, ps.item_idx ? item : -1);
 #endif
           } else
             for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + owner * ps.L];

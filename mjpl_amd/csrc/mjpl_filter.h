@@ -184,6 +184,8 @@ struct ItemBuffers {
   int *llist, *lcount;  // edges left to the walking kernel
   int kmax;             // edges with more interior waypoints than this stay with the walking kernel
   double *tstep;        // [E] step / |QB - QA| of the edges that have items
+  double *ckpt;         // [cap][nplan] exact waypoints of the items with idx % kCkptEvery == 0 (launches
+                        // with kmax >= kCkptEvery; else null): where exact_waypoint starts from
   int *claim;           // [E] per-edge claim word (see k_filter_items)
   int gen;              // this launch's generation: claim[edge] == gen <=> the edge is in ulist already
 };
@@ -317,6 +319,21 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
       ib.edge[first + idx - 1] = (int)i;
       ib.idx[first + idx - 1] = idx;
     }
+  // long edges (few-edge launches: path shortcutting) walk once more and leave every
+  // kCkptEvery-th waypoint behind, so that rebuilding one never takes more than that many steps
+  if (ib.ckpt) {
+    const bool longe = !done && K >= kCkptEvery;
+    if (__ballot(longe) != 0ull) {
+      for_row(QA, E, i, nplan, layout, longe, [&](int k, double a) { qw[k * ws] = a; });
+      for (int idx = 1; __ballot(longe && idx <= K) != 0ull; idx++) {
+        if (longe && idx <= K) {
+          advance();
+          if (idx % kCkptEvery == 0)
+            for (int k = 0; k < nplan; k++) ib.ckpt[(size_t)(first + idx - 1) * nplan + k] = qw[k * ws];
+        }
+      }
+    }
+  }
 }
 
 // Endpoint pass of the two-pass edge filter: check 0 (the endpoint QB, utils.py:144) for every
@@ -352,7 +369,7 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
   });
   const bool run = active && finite;
   const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, qw, B, run, tol, i, uc, 0, nullptr, nullptr,
-                                                            kQ ? EdgeSource{QB, QB, E, layout, 0.0} : EdgeSource{});
+                                                            kQ ? EdgeSource{QB, QB, E, layout, 0.0, nullptr} : EdgeSource{});
   bool survive = run && code != V_CONTACT;
   if (active) {
     if (!finite) {
@@ -442,7 +459,7 @@ k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__
   // queued interpreter: undecided pairs go to k_patch_pairs through `uc` (which clears valid[i]
   // on a contact); V_UNSURE comes back only for what could not be handed over
   const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, qc, B, active, tol, i, uc, 0, nullptr, nullptr,
-                                                            kQ ? EdgeSource{Q, Q, N, layout, 0.0} : EdgeSource{});
+                                                            kQ ? EdgeSource{Q, Q, N, layout, 0.0, nullptr} : EdgeSource{});
   if (active) {
     if (code == V_UNSURE) ulist[atomicAdd(ucount, 1)] = (int)i;
     else valid[i] = (code == V_CONTACT) ? 0 : 1;
@@ -495,7 +512,7 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
         if (uc.count) {
           const int j = atomicAdd(uc.count, 1);
           if (j < uc.cap) {
-            exact_waypoint(src, gip + gip[H_OFF_PERM], nplan, ed, ib.idx[it], uc.q + (size_t)j * nplan);
+            exact_waypoint(src, gip + gip[H_OFF_PERM], nplan, ed, ib.idx[it], uc.q + (size_t)j * nplan, it);
             uc.edge[j] = ed;
             uc.idx[j] = ib.idx[it];
             uc.ga[j] = uc.gb[j] = -1;

@@ -981,7 +981,8 @@ struct mjpl_engine {
   int *d_ucedge = nullptr, *d_ucidx = nullptr, *d_ucga = nullptr, *d_ucgb = nullptr;
   double *d_geomtab = nullptr;  // GTB_LEN doubles per model geom (k_patch_pairs)
   // lane-per-waypoint interior pass: (edge, idx) items, long-edge list
-  double *d_tstep = nullptr;
+  double *d_tstep = nullptr, *d_itemck = nullptr;  // (checkpoint rows: allocated by the first launch with long items)
+  size_t itemck_cap = 0;
   int *d_itemedge = nullptr, *d_itemidx = nullptr, *d_llist = nullptr, *d_icount = nullptr;
   int *d_eclaim = nullptr;  // [llist_cap] per-edge claim word: the launch generation that listed the edge in d_ulist
   int claim_gen = 0;
@@ -1801,8 +1802,19 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         HIP_TRY(hipMemsetAsync(e->d_eclaim, 0, e->llist_cap * sizeof(int), e->stream));
         e->claim_gen = 1;
       }
+      double *ckpt = nullptr;
+      if (kmax >= kCkptEvery) {
+        // rows are sized by nq, the upper bound of nplan (mjpl_set_planning may widen the planning set)
+        if (e->itemck_cap < e->item_cap) {
+          if (e->d_itemck) HIP_TRY(hipFree(e->d_itemck));
+          e->d_itemck = nullptr; e->itemck_cap = 0;
+          HIP_TRY(hipMalloc(&e->d_itemck, e->item_cap * std::max<size_t>(1, e->m.nq) * sizeof(double)));
+          e->itemck_cap = e->item_cap;
+        }
+        ckpt = e->d_itemck;
+      }
       ib = ItemBuffers{e->d_itemedge, e->d_itemidx, e->d_icount, (int)e->item_cap, e->d_llist,
-                       e->d_icount + kCtr, kmax, e->d_tstep, e->d_eclaim, e->claim_gen};
+                       e->d_icount + kCtr, kmax, e->d_tstep, ckpt, e->d_eclaim, e->claim_gen};
     }
     if (two_pass) {
       if ((size_t)E > e->slist_cap) {
@@ -1832,7 +1844,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     MJPL_MARK(1);  // after k_filter_endpoints (nothing ran yet in a one-pass launch)
     if (expand) {
       const unsigned igrid = (unsigned)((e->item_cap + fblock - 1) / fblock);
-      const EdgeSource src = {dQA, dQB, (long long)E, layout, step};
+      const EdgeSource src = {dQA, dQB, (long long)E, layout, step, ib.ckpt};
       if (e->spec)
         rc = e->spec->items(e->stream, igrid, (unsigned)fblock, ldsq, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib,
                             src, e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
@@ -2040,6 +2052,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_geomtab) (void)hipFree(e->d_geomtab);
   if (e->d_nn) (void)hipFree(e->d_nn);
   if (e->d_tstep) (void)hipFree(e->d_tstep);
+  if (e->d_itemck) (void)hipFree(e->d_itemck);
   if (e->d_itemedge) (void)hipFree(e->d_itemedge);
   if (e->d_itemidx) (void)hipFree(e->d_itemidx);
   if (e->d_llist) (void)hipFree(e->d_llist);

@@ -226,3 +226,27 @@ def test_item_count_is_the_reference_walk(oracle_mod):
     assert e.last_undecided() == 0
     assert e.last_items() == want
     e.close()
+
+
+def test_long_edges_rebuild_undecided_waypoints_from_checkpoints(oracle_mod):
+    """A few long edges (path shortcutting) become hundreds of lane-per-waypoint items each; the
+    items the filter cannot decide are rebuilt for the exact re-check by the reference's
+    recurrence from the nearest stored checkpoint (every 32nd waypoint), not from the start."""
+    m = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    e = eng_mod.Engine(m)
+    e.set_planning(qidx, base)
+    e.set_filter(True, 2e-2)  # a wide tolerance band: many undecided pairs, at every index
+    rng = np.random.default_rng(9)
+    lo, hi = m.jnt_range[qidx, 0], m.jnt_range[qidx, 1]
+    for E in (48, 700):
+        qa = rng.uniform(lo, hi, size=(E, len(qidx)))
+        qb = np.clip(qa + rng.uniform(-1.2, 1.2, size=qa.shape), lo, hi)
+        want, wfb, _ = orc.valid_edges(qa, qb, 0.005, nthreads=8, info=True)
+        got, gfb = e.check_edges(qa, qb, 0.005, first_bad=True)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(gfb, wfb)
+        assert e.last_items() > 40 * E and e.last_undecided() > 0
+    e.close()
