@@ -18,7 +18,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 2
+#define MJPL_SPEC_ABI 3
 // A model's own straight-line code is asked to fit three waves per SIMD (168 VGPRs): its register
 // pressure is a few registers above that without the bound, and the third wave is worth more
 template <class Spec> constexpr int kMinWaves = std::is_void<Spec>::value ? 1 : 3;
@@ -179,8 +179,14 @@ __device__ __forceinline__ void load_columns(QT *col, int B, const double *__res
 // the same bounding culls.  Edges with many waypoints stay with the walking kernel: `llist`.
 struct ItemBuffers {
   int *edge, *idx;  // [cap] which edge, which check index (1..K)
-  int *count;       // items written
-  int cap;
+  // The item space is split into `regions` equal parts of `regcap` slots (a multiple of the block
+  // size), each with its own fill counter count[r * kCounterStride]: a workgroup reserves in region
+  // blockIdx % regions.  One shared counter would take a returning atomic from every wave of the
+  // endpoint kernel on one address -- at 4 096 waves that serialisation was a fifth of the kernel.
+  int *count;       // items reserved, per region (may exceed regcap: the surplus went to llist)
+  int cap;          // regions * regcap
+  int regions, regcap;
+  int *scount;      // survivors per region (statistic: edges reaching the interior pass)
   int *llist, *lcount;  // edges left to the walking kernel
   int kmax;             // edges with more interior waypoints than this stay with the walking kernel
   double *tstep;        // [E] step / |QB - QA| of the edges that have items
@@ -189,16 +195,80 @@ struct ItemBuffers {
   int *claim;           // [E] per-edge claim word (see k_filter_items)
   int gen;              // this launch's generation: claim[edge] == gen <=> the edge is in ulist already
 };
+constexpr int kCounterStride = 32;    // ints between device counters: one 128-byte line each
+constexpr int kItemRegions = 32;
 constexpr int kExpandMinWaypoints = 24;  // kmax is at least this; small batches get more (item space / E)
 
-// qe: this lane's edge end QB (LDS, stride B); qw: scratch for the walking waypoint (LDS, stride
-// ws).  `todo` lanes own an edge i whose interior waypoints are wanted.
-__device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const double *__restrict__ QA,
-                                            int64_t E, int64_t i, double step, int layout, bool todo,
-                                            const double *qe, int B, double *qw, int ws,
-                                            const ItemBuffers &ib, int nplan) {
+// One step of the recurrence: _step(w, QB, step)  (planning/utils.py:182-185; the statements of
+// edge_body) on this lane's LDS rows qw (waypoint, stride ws) and qe (QB, stride B); returns true
+// when the walk has arrived at QB.  `degenerate`: the squared distance under- or overflowed.
+template <class Perm>
+__device__ __forceinline__ bool walk_step(Perm perm, int nplan, const double *qe, int B, double *qw, int ws,
+                                          double step, bool &degenerate) {
+  double s = 0;
+  for (int k = 0; k < nplan; k++) {
+    const int col = perm[k];
+    double d = qe[col * B] - qw[col * ws];
+    s = s + d * d;
+  }
+  const double mag = sqrt(s);
+  degenerate = degenerate || !(mag > 0.0) || !(mag <= 1.79769313486231570815e+308);
+  const double sm = step < mag ? step : mag;
+  // The nplan quotients d / mag share their divisor.  The compiler expands each division into
+  // div_scale x2, rcp, two Newton steps on the reciprocal, a product, a remainder, div_fmas,
+  // div_fixup; with every operand well inside the normal range (no scaling, no special case)
+  // that is  r = refined rcp(mag);  q0 = d r;  q = fma(fma(-mag, q0, d), r, q0)  -- the same
+  // operations on the same values, with r computed once.  Anything else divides as usual.
+  bool plain = !(mag >= 0x1p-400 && mag <= 0x1p400);
+  for (int k = 0; k < nplan; k++) {
+    const double ad = fabs(qe[k * B] - qw[k * ws]);
+    plain = plain || !(ad == 0.0 || ad >= 0x1p-400);
+  }
+#ifdef MJPL_X_PLAINDIV  // timing-only build: every quotient by the compiler's division
+  plain = true;
+#endif
+  bool eq = true;
+  if (__ballot(plain) != 0ull) {  // (wave-uniform: a per-lane select would compute both)
+    for (int k = 0; k < nplan; k++) {
+      const double ek = qe[k * B];
+      const double d = ek - qw[k * ws];
+      const double nw = qw[k * ws] + (d / mag) * sm;
+      qw[k * ws] = nw;
+      eq = eq && (nw == ek);
+    }
+  } else {
+    double r = __builtin_amdgcn_rcp(mag);
+    r = fma(r, fma(-mag, r, 1.0), r);
+    r = fma(r, fma(-mag, r, 1.0), r);
+    for (int k = 0; k < nplan; k++) {
+      const double ek = qe[k * B];
+      const double d = ek - qw[k * ws];
+      const double q0 = d * r;
+      double quo = fma(fma(-mag, q0, d), r, q0);
+      quo = (d == 0.0) ? d : quo;  // (+-0 / mag keeps its sign)
+      const double nw = qw[k * ws] + quo * sm;
+      qw[k * ws] = nw;
+      eq = eq && (nw == ek);
+    }
+  }
+  return eq;
+}
+
+// How many interior waypoints does edge i have?  Walks the recurrence (`todo` lanes; qe: the
+// lane's QB row in LDS, qw: scratch for the walking waypoint).  Returns the count, or -1 for an
+// edge that stays with the walking kernel (longer than kmax waypoints, or degenerate: that kernel
+// reports it).  Leaves step / |QB - QA| in ib.tstep[i] for k_filter_items.
+// The items carry (edge, index) only.  The reference's waypoint idx is idx steps of length
+// `step` from QA towards QB, each with a freshly computed direction: it lies within a few
+// idx * 2^-53 |q| of QA + idx * (step / |QB - QA|) * (QB - QA), which is what k_filter_items tests
+// (its float32 bounds absorb 1e-5; the exact re-check rebuilds the waypoint by the recurrence).
+// So the walk is needed for the COUNT only -- where `step` divides the edge length the count
+// hangs on the last bit of the running distance -- and no waypoint is stored.
+__device__ __forceinline__ int count_waypoints(const int *__restrict__ gip, const double *__restrict__ QA,
+                                               int64_t E, int64_t i, double step, int layout, bool todo,
+                                               const double *qe, int B, double *qw, int ws,
+                                               const ItemBuffers &ib, int nplan) {
   const int *perm = gip + gip[H_OFF_PERM];
-  const int lane = threadIdx.x & 63;
   bool at_end = true;
   for_row(QA, E, i, nplan, layout, todo, [&](int k, double a) {
     qw[k * ws] = a;
@@ -210,84 +280,41 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
     const double d = qe[col * B] - qw[col * ws];
     s0 = s0 + d * d;
   }
-  bool done = !todo || at_end;
-  if (!done && !(sqrt(s0) <= step * (double)(ib.kmax - 2))) {  // long edge
-    ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
-    done = true;
-  }
-  // one step of the recurrence: _step(w, QB, step)  (planning/utils.py:182-185; the statements of
-  // edge_body); returns true when the walk has arrived at QB
-  bool degenerate = false;  // the squared distance under- or overflowed (see edge_body)
-  auto advance = [&]() -> bool {
-    double s = 0;
-    for (int k = 0; k < nplan; k++) {
-      const int col = perm[k];
-      double d = qe[col * B] - qw[col * ws];
-      s = s + d * d;
-    }
-    const double mag = sqrt(s);
-    degenerate = degenerate || !(mag > 0.0) || !(mag <= 1.79769313486231570815e+308);
-    const double sm = step < mag ? step : mag;
-    // The nplan quotients d / mag share their divisor.  The compiler expands each division into
-    // div_scale x2, rcp, two Newton steps on the reciprocal, a product, a remainder, div_fmas,
-    // div_fixup; with every operand well inside the normal range (no scaling, no special case)
-    // that is  r = refined rcp(mag);  q0 = d r;  q = fma(fma(-mag, q0, d), r, q0)  -- the same
-    // operations on the same values, with r computed once.  Anything else divides as usual.
-    bool plain = !(mag >= 0x1p-400 && mag <= 0x1p400);
-    for (int k = 0; k < nplan; k++) {
-      const double ad = fabs(qe[k * B] - qw[k * ws]);
-      plain = plain || !(ad == 0.0 || ad >= 0x1p-400);
-    }
-#ifdef MJPL_X_PLAINDIV  // timing-only build: every quotient by the compiler's division
-    plain = true;
-#endif
-    bool eq = true;
-    if (__ballot(plain) != 0ull) {  // (wave-uniform: a per-lane select would compute both)
-      for (int k = 0; k < nplan; k++) {
-        const double ek = qe[k * B];
-        const double d = ek - qw[k * ws];
-        const double nw = qw[k * ws] + (d / mag) * sm;
-        qw[k * ws] = nw;
-        eq = eq && (nw == ek);
-      }
-    } else {
-      double r = __builtin_amdgcn_rcp(mag);
-      r = fma(r, fma(-mag, r, 1.0), r);
-      r = fma(r, fma(-mag, r, 1.0), r);
-      for (int k = 0; k < nplan; k++) {
-        const double ek = qe[k * B];
-        const double d = ek - qw[k * ws];
-        const double q0 = d * r;
-        double quo = fma(fma(-mag, q0, d), r, q0);
-        quo = (d == 0.0) ? d : quo;  // (+-0 / mag keeps its sign)
-        const double nw = qw[k * ws] + quo * sm;
-        qw[k * ws] = nw;
-        eq = eq && (nw == ek);
-      }
-    }
-    return eq;
-  };
-  // first walk: how many interior waypoints does this edge have?
+  if (!todo || at_end) return 0;
+  const bool long_edge = !(sqrt(s0) <= step * (double)(ib.kmax - 2));
   int K = 0;
-  {
-    bool walking = !done;
-    while (__ballot(walking) != 0ull) {
-      if (walking) {
-        if (advance()) walking = false;
-        else if (++K > ib.kmax) walking = false;
+  bool degenerate = false;
+  bool walking = !long_edge;
+  while (__ballot(walking) != 0ull) {
+    if (walking) {
+      if (walk_step(perm, nplan, qe, B, qw, ws, step, degenerate)) walking = false;
+      else if (++K > ib.kmax) walking = false;
 #ifdef MJPL_X_SHORTWALK  // timing-only build: one step of the walk
-        walking = false;
+      walking = false;
 #endif
-        if (degenerate) { walking = false; K = ib.kmax + 1; }  // the walking kernel reports it
-      }
+      if (degenerate) { walking = false; K = ib.kmax + 1; }
     }
   }
-  if (!done && K > ib.kmax) {  // the estimate was off: the walking kernel takes the edge
+  if (long_edge || K > ib.kmax) return -1;  // (the estimate can be off by a step)
+  if (K > 0) ib.tstep[i] = step / sqrt(s0);
+  return K;
+}
+
+// Turn the counts of a wave's surviving edges into items: one reservation per wave, lane l owns
+// slots [base + sum_{l' < l} K_l', +K_l).  With checkpoints (ib.ckpt: few-edge launches with long
+// items, path shortcutting) long edges walk once more through qe / qw and leave every
+// kCkptEvery-th waypoint behind, so that rebuilding one never takes more than that many steps.
+__device__ __forceinline__ void emit_items(const int *__restrict__ gip, const double *__restrict__ QA, int64_t E,
+                                           int64_t i, double step, int layout, bool survive, int K,
+                                           const double *qe, int B, double *qw, int ws, const ItemBuffers &ib,
+                                           int nplan) {
+  const int lane = threadIdx.x & 63;
+  bool done = !survive;
+  if (!done && K < 0) {  // the walking kernel takes the edge
     ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
     done = true;
   }
   if (done) K = 0;
-  // one reservation per wave: lane l owns slots [base + sum_{l' < l} K_l', +K_l)
   int incl = K;
   for (int off = 1; off < 64; off <<= 1) {
     const int up = __shfl_up(incl, off);
@@ -296,21 +323,20 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
   const int total = __shfl(incl, 63);
   if (total == 0) return;
   int base = 0;
-  if (lane == 0) base = atomicAdd(ib.count, total);
+#ifdef MJPL_X_NOATOMIC  // timing-only build: no reservation (slots collide, the count stays 0)
+  const int region = 0;
+  base = (int)(((blockIdx.x * 4u + (threadIdx.x >> 6)) * 320u) % (unsigned)(ib.regcap - 2000));
+#else
+  const int region = (int)(blockIdx.x % (unsigned)ib.regions);
+  if (lane == 0) base = atomicAdd(ib.count + region * kCounterStride, total);
+#endif
   base = __builtin_amdgcn_readfirstlane(base);
-  const int first = base + incl - K;
-  if (!done && first + K > ib.cap) {  // out of item space: the walking kernel takes the edge
+  const int rel = base + incl - K, first = region * ib.regcap + rel;
+  if (!done && rel + K > ib.regcap) {  // out of item space: the walking kernel takes the edge
     ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;
-    for (int slot = first; slot < ib.cap; slot++) ib.edge[slot] = -1;  // reserved but void
+    for (int r = rel > 0 ? rel : 0; r < ib.regcap; r++) ib.edge[region * ib.regcap + r] = -1;  // reserved but void
     done = true;
   }
-  // The items carry (edge, index) only.  The reference's waypoint idx is idx steps of length
-  // `step` from QA towards QB, each with a freshly computed direction: it lies within a few
-  // idx * 2^-53 |q| of QA + idx * step * (QB - QA) / |QB - QA|, which is what k_filter_items tests
-  // (its float32 bounds absorb 1e-5; the exact re-check rebuilds the waypoint by the recurrence).
-  // So the walk above is needed for the COUNT only -- where `step` divides the edge length the
-  // count hangs on the last bit of the running distance -- and no waypoint is stored.
-  if (!done && K > 0) ib.tstep[i] = step / sqrt(s0);
 #ifdef MJPL_X_NOSTORE  // timing-only build: items reserved, not written
   if (K < 1000) return;
 #endif
@@ -319,15 +345,15 @@ __device__ __forceinline__ void expand_edge(const int *__restrict__ gip, const d
       ib.edge[first + idx - 1] = (int)i;
       ib.idx[first + idx - 1] = idx;
     }
-  // long edges (few-edge launches: path shortcutting) walk once more and leave every
-  // kCkptEvery-th waypoint behind, so that rebuilding one never takes more than that many steps
   if (ib.ckpt) {
     const bool longe = !done && K >= kCkptEvery;
     if (__ballot(longe) != 0ull) {
+      const int *perm = gip + gip[H_OFF_PERM];
       for_row(QA, E, i, nplan, layout, longe, [&](int k, double a) { qw[k * ws] = a; });
+      bool degenerate = false;
       for (int idx = 1; __ballot(longe && idx <= K) != 0ull; idx++) {
         if (longe && idx <= K) {
-          advance();
+          walk_step(perm, nplan, qe, B, qw, ws, step, degenerate);
           if (idx % kCkptEvery == 0)
             for (int k = 0; k < nplan; k++) ib.ckpt[(size_t)(first + idx - 1) * nplan + k] = qw[k * ws];
         }
@@ -360,13 +386,34 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
   Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, (!kQ && ib.count) ? 2 : 1, B, sizeof(QT));
   const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
   const bool active = i < E;
-  QT *qw = reinterpret_cast<QT *>(c.col0) + threadIdx.x;
-  load_columns(qw, B, QB, E, i, nplan, layout, active);
-  __syncthreads();
   bool finite = true;
   for_rows(QA, QB, E, i, nplan, layout, active, [&](int, double a, double b) {
     finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
   });
+  // Lane-per-waypoint interior pass, queued interpreter: the waypoint COUNT of every edge is
+  // taken first (float64 rows QB / walking waypoint laid over the columns, saves and queues the
+  // check is about to use).  Counting after the check instead would spare the edges whose
+  // endpoint is in contact, but a wave walks as long as its longest edge either way, and it
+  // would have to wait for the slowest check of the workgroup before it may reuse the memory;
+  // here the waves arrive at the barrier together.  (With checkpoints -- few long edges -- the
+  // count follows the check: the survivors walk twice.)
+  const size_t idle = (size_t)(reinterpret_cast<char *>(c.ltab) - reinterpret_cast<char *>(c.col0));
+  const bool fits = kQ && (size_t)2 * nplan * B * sizeof(double) <= idle;
+#ifdef MJPL_X_LATECOUNT  // timing-only build: count after the check, as with checkpoints
+  const bool early = false;
+#else
+  const bool early = kQ && ib.count && fits && !ib.ckpt;
+#endif
+  int K = 0;
+  if (early) {
+    double *qe = c.col0 + threadIdx.x;
+    load_columns(qe, B, QB, E, i, nplan, layout, active);
+    K = count_waypoints(gip, QA, E, i, step, layout, active && finite, qe, B, qe + (size_t)nplan * B, B, ib, nplan);
+    __syncthreads();
+  }
+  QT *qw = reinterpret_cast<QT *>(c.col0) + threadIdx.x;
+  load_columns(qw, B, QB, E, i, nplan, layout, active);
+  __syncthreads();
   const bool run = active && finite;
   const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, qw, B, run, tol, i, uc, 0, nullptr, nullptr,
                                                             kQ ? EdgeSource{QB, QB, E, layout, 0.0, nullptr} : EdgeSource{});
@@ -408,22 +455,30 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
   if (ib.count) {
     // lane-per-waypoint interior pass: emit this edge's interior waypoints as work items
     if constexpr (kQ) {
-      // the walk's two float64 rows per lane (QB, the walking waypoint) take over the workgroup's
-      // columns, saves and queues once every wave is through with its check
-      const size_t idle = (size_t)(reinterpret_cast<char *>(c.ltab) - reinterpret_cast<char *>(c.col0));
-      const bool fits = (size_t)2 * nplan * B * sizeof(double) <= idle;
+      if (early) {
+        if (m == 0ull) return;
+        emit_items(gip, QA, E, i, step, layout, survive, K, nullptr, B, nullptr, B, ib, nplan);
+        if ((threadIdx.x & 63) == 0)
+          atomicAdd(ib.scount + (blockIdx.x % (unsigned)ib.regions) * kCounterStride, (int)__builtin_popcountll(m));
+        return;
+      }
+      // count after the check: the two float64 rows per lane take over the workgroup's columns,
+      // saves and queues once every wave is through with its check
       __syncthreads();
       if (m == 0ull) return;
       if (fits) {
         double *qe = c.col0 + threadIdx.x;
         load_columns(qe, B, QB, E, i, nplan, layout, active);
-        expand_edge(gip, QA, E, i, step, layout, survive, qe, B, qe + (size_t)nplan * B, B, ib, nplan);
-        if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
+        K = count_waypoints(gip, QA, E, i, step, layout, survive, qe, B, qe + (size_t)nplan * B, B, ib, nplan);
+        emit_items(gip, QA, E, i, step, layout, survive, K, qe, B, qe + (size_t)nplan * B, B, ib, nplan);
+        if ((threadIdx.x & 63) == 0)
+          atomicAdd(ib.scount + (blockIdx.x % (unsigned)ib.regions) * kCounterStride, (int)__builtin_popcountll(m));
         return;
       }
     } else {
       if (m == 0ull) return;
-      expand_edge(gip, QA, E, i, step, layout, survive, qw, B, c.col1 + threadIdx.x, B, ib, nplan);
+      K = count_waypoints(gip, QA, E, i, step, layout, survive, qw, B, c.col1 + threadIdx.x, B, ib, nplan);
+      emit_items(gip, QA, E, i, step, layout, survive, K, qw, B, c.col1 + threadIdx.x, B, ib, nplan);
       if ((threadIdx.x & 63) == 0) atomicAdd(scount, (int)__builtin_popcountll(m));
       return;
     }
@@ -479,15 +534,20 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
                int *__restrict__ ulist, int *__restrict__ ucount, UndecidedConfigs uc) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
-  const int64_t n = *ib.count < ib.cap ? *ib.count : ib.cap;
-  if ((int64_t)blockIdx.x * B >= n) return;
+  // this block's region of the item space (round robin: the blocks with work come first in the
+  // grid, the surplus ones after them), and how far that region is filled
+  const int region = (int)(blockIdx.x % (unsigned)ib.regions);
+  const int64_t start = (int64_t)region * ib.regcap + (int64_t)(blockIdx.x / (unsigned)ib.regions) * B;
+  const int fill = ib.count[region * kCounterStride];
+  const int64_t n = (int64_t)region * ib.regcap + (fill < ib.regcap ? fill : ib.regcap);
+  if (start >= n) return;
   const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
   Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B, sizeof(float));
-  const int64_t it = (int64_t)blockIdx.x * B + threadIdx.x;
+  const int64_t it = start + threadIdx.x;
   const int64_t itc = it < (int64_t)ib.cap ? it : 0;
   const int ed = it < n ? ib.edge[itc] : -1;
   const bool active = ed >= 0;  // (a void slot: reserved by an edge that did not fit)
-  // the waypoint in closed form (see expand_edge): QA + min(idx * step / |QB - QA|, 1) (QB - QA),
+  // the waypoint in closed form (see count_waypoints): QA + min(idx * step / |QB - QA|, 1) (QB - QA),
   // rounded to binary32 as the check would round it anyway
   float *qw = reinterpret_cast<float *>(c.col0) + threadIdx.x;
   {

@@ -33,7 +33,8 @@ namespace {
 using namespace mjpl;
 
 constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
-constexpr int kCtr = 32;  // ints between device counters: one 128-byte line each
+constexpr int kCtr = kCounterStride;  // ints between device counters: one 128-byte line each
+constexpr int kNumCtr = 5 + 2 * kItemRegions;  // (see engine_alloc: five scalars, per-region item fills and survivor counts)
 
 thread_local std::string g_err;
 
@@ -1630,8 +1631,9 @@ int ulist_reserve(mjpl_engine *e, int64_t n) {
     // five device counters, each on its own 128-byte line (they are hammered by wave-level atomics
     // of the same kernel: sharing a line costs ~7 % of a step), cleared by one memset per launch:
     //   [0] edge-level undecided list, [kCtr] undecided pairs, [2 kCtr] edges whose endpoint passed,
-    //   [3 kCtr] waypoint items, [4 kCtr] edges left to the walking kernel
-    HIP_TRY(hipMalloc(&e->d_ucount, 5 * kCtr * sizeof(int)));
+    //   [3 kCtr] (unused), [4 kCtr] edges left to the walking kernel,
+    //   [5 kCtr ..] waypoint items per region, then edges whose endpoint passed per region
+    HIP_TRY(hipMalloc(&e->d_ucount, kNumCtr * kCtr * sizeof(int)));
     e->d_icount = e->d_ucount + 3 * kCtr;
   }
   if ((size_t)n > e->ulist_cap) {
@@ -1694,7 +1696,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
       uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
     }
     if (rc != MJPL_OK) return rc;
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, kNumCtr * kCtr * sizeof(int), e->stream));
     const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
     // (queued interpreter: binary32 columns)
@@ -1760,7 +1762,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     uc.count = e->d_ucount + kCtr;
     uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
     MJPL_MARK(0);
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, 5 * kCtr * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, kNumCtr * kCtr * sizeof(int), e->stream));
     const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate());  // walking kernel: float64 columns
@@ -1780,7 +1782,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     if (expand) {
       // room for 8 waypoints per edge on average, and never less than a quarter of a million items:
       // a handful of long edges (path shortcutting) is best served one waypoint per lane, too
-      const size_t want = std::min<size_t>(std::max<size_t>((size_t)E * 8, (size_t)1 << 18) + 4096, e->item_cap_limit);
+      size_t want = std::min<size_t>(std::max<size_t>((size_t)E * 8, (size_t)1 << 18) + 4096, e->item_cap_limit);
+      want = (want + fblock - 1) / fblock * fblock;  // whole blocks (the item space is split into regions of them)
       if (want > e->item_cap || (size_t)E > e->llist_cap) {
         for (void *ptr : {(void *)e->d_tstep, (void *)e->d_itemedge, (void *)e->d_itemidx, (void *)e->d_llist,
                           (void *)e->d_eclaim})
@@ -1813,7 +1816,11 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         }
         ckpt = e->d_itemck;
       }
-      ib = ItemBuffers{e->d_itemedge, e->d_itemidx, e->d_icount, (int)e->item_cap, e->d_llist,
+      // regions: enough workgroups behind each counter to fill it evenly, few enough waves to not queue up
+      const int regions = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(kItemRegions, fgrid / 8), e->item_cap / fblock));
+      const int regcap = (int)(e->item_cap / regions / fblock * fblock);
+      ib = ItemBuffers{e->d_itemedge, e->d_itemidx, e->d_ucount + 5 * kCtr, regions * regcap, regions, regcap,
+                       e->d_ucount + (5 + kItemRegions) * kCtr, e->d_llist,
                        e->d_icount + kCtr, kmax, e->d_tstep, ckpt, e->d_eclaim, e->claim_gen};
     }
     if (two_pass) {
@@ -1843,7 +1850,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     }
     MJPL_MARK(1);  // after k_filter_endpoints (nothing ran yet in a one-pass launch)
     if (expand) {
-      const unsigned igrid = (unsigned)((e->item_cap + fblock - 1) / fblock);
+      const unsigned igrid = (unsigned)(ib.cap / fblock);  // (regions of whole blocks)
       const EdgeSource src = {dQA, dQB, (long long)E, layout, step, ib.ckpt};
       if (e->spec)
         rc = e->spec->items(e->stream, igrid, (unsigned)fblock, ldsq, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib,
@@ -2140,22 +2147,32 @@ int64_t mjpl_filter_last_undecided(mjpl_engine *e) {
   return (int64_t)n[0] + n[kCtr];
 }
 
+namespace {
+// the launch's counters on the host (synchronises the stream)
+bool read_counters(mjpl_engine *e, std::vector<int> &n) {
+  n.assign((size_t)kNumCtr * kCtr, 0);
+  if (hipSetDevice(e->device) != hipSuccess) return false;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+  return hipMemcpy(n.data(), e->d_ucount, n.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+}
+}  // namespace
+
 int64_t mjpl_filter_last_interior_edges(mjpl_engine *e) {
   if (!e || !e->filter || !e->d_ucount) return -1;
-  int n[4] = {0, 0, 0, 0};
-  if (hipSetDevice(e->device) != hipSuccess) return -1;
-  if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
-  if (hipMemcpy(n, e->d_ucount + 2 * kCtr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int64_t)n[0];
+  std::vector<int> n;
+  if (!read_counters(e, n)) return -1;
+  int64_t total = n[2 * kCtr];  // (one counter without the lane-per-waypoint pass, one per region with it)
+  for (int r = 0; r < kItemRegions; r++) total += n[(size_t)(5 + kItemRegions + r) * kCtr];
+  return total;
 }
 
 int64_t mjpl_filter_last_items(mjpl_engine *e) {
-  if (!e || !e->filter || !e->d_icount) return -1;
-  int n[2] = {0, 0};
-  if (hipSetDevice(e->device) != hipSuccess) return -1;
-  if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
-  if (hipMemcpy(n, e->d_icount, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int64_t)n[0];
+  if (!e || !e->filter || !e->d_ucount) return -1;
+  std::vector<int> n;
+  if (!read_counters(e, n)) return -1;
+  int64_t total = 0;  // (reserved slots, as before: a region's surplus went to the walking kernel)
+  for (int r = 0; r < kItemRegions; r++) total += n[(size_t)(5 + r) * kCtr];
+  return total;
 }
 
 int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
