@@ -792,6 +792,98 @@ __device__ __forceinline__ void sincos_half(T x, T *s, T *c) {
 #endif
 }
 
+// Items the float32 filter could not decide, handed to the exact float64 kernels on the device.
+// ga >= 0: one geom pair (ga = the later moving geom, gb = its partner) of the configuration;
+// ga < 0: the whole configuration.
+struct UndecidedConfigs {
+  double *q;    // [cap][nplan] configuration (waypoint), row-major
+  int *edge;    // [cap] edge it belongs to
+  int *idx;     // [cap] its check index inside that edge
+  int *ga, *gb; // [cap] model geom ids of the undecided pair, or -1
+  int *count;   // entries written (may exceed cap: the overflow went to the edge-level list)
+  int cap;
+};
+
+// Where a drain reports candidates it cannot decide (count == nullptr: flag the owning lane).
+// Where the edges of a launch live, for kernels that rebuild a waypoint instead of reading it.
+struct EdgeSource {
+  const double *QA, *QB;  // null: not an edge launch
+  long long E;
+  int layout;
+  double step;
+  const double *ckpt;     // [item slot][nplan] exact waypoints of the items with idx % kCkptEvery == 0, or null
+};
+constexpr int kCkptEvery = 32;
+
+// Waypoint `idx` (1-based) of edge i, EXACTLY as the reference's recurrence produces it
+// (planning/utils.py:182-185, the statements of edge_body): steps from QA, each recomputing
+// direction and distance from the previous waypoint.  `out[0..nplan)` doubles as the working row.
+// Meant for the few waypoints that go to the exact re-check -- one lane walks alone here, at most
+// kCkptEvery - 1 steps when the launch keeps checkpoints (`slot` = the waypoint's item slot; an
+// edge's items are consecutive slots).
+template <class Perm>
+__device__ inline void exact_waypoint(const EdgeSource &src, Perm perm, int nplan, long long i, int idx,
+                                      double *out, long long slot = -1) {
+  auto at = [&](const double *Q, int k) -> double {
+    return (src.layout == MJPL_SOA) ? Q[(long long)k * src.E + i] : Q[i * nplan + k];
+  };
+  int from = 0;
+  if (src.ckpt && slot >= 0 && idx >= kCkptEvery) {
+    from = idx - idx % kCkptEvery;
+    const double *row = src.ckpt + (size_t)(slot - (idx - from)) * nplan;
+    for (int k = 0; k < nplan; k++) out[k] = row[k];
+  } else {
+    for (int k = 0; k < nplan; k++) out[k] = at(src.QA, k);
+  }
+  for (int n = from; n < idx; n++) {
+    double s = 0;
+    for (int k = 0; k < nplan; k++) {
+      const int col = perm[k];
+      const double d = at(src.QB, col) - out[col];
+      s = s + d * d;
+    }
+    const double mag = sqrt(s);
+    const double sm = src.step < mag ? src.step : mag;
+    for (int k = 0; k < nplan; k++) {
+      const double d = at(src.QB, k) - out[k];
+      out[k] = out[k] + (d / mag) * sm;
+    }
+  }
+}
+
+struct PatchSink {
+  UndecidedConfigs uc;
+  const double *qcol;  // configurations of this wave's lanes: q[k] of lane l at qcol[k * B + l * L]
+  int B, L, nplan;     // (LDS columns: B = block size, L = 1)
+  int idx;             // check index of the configurations under test (wave-uniform) ...
+  const int *item_edge, *item_idx;  // ... or, lane-per-waypoint kernels: (edge, index) of item i
+  // lane-per-waypoint kernels test waypoints in closed form (see k_filter_items): what goes to the
+  // exact re-check is rebuilt by the recurrence, not copied from qcol
+  EdgeSource src;
+  IP perm;
+};
+
+// A lane hands ONE undecided geom pair of its own configuration to the exact pair kernel
+// (immediate interpreter; the queued one does the same from its drains, for the candidate's
+// owner).  `item`: the lane's row / item index.  Returns false if there is nowhere to hand it.
+__device__ __forceinline__ bool hand_over_own(const PatchSink &ps, int item, int ga, int gb) {
+  if (!ps.uc.count) return false;
+  const int u = atomicAdd(ps.uc.count, 1);
+  if (u >= ps.uc.cap) return false;
+  const int lane = threadIdx.x & 63;
+  const int ed = ps.item_edge ? ps.item_edge[item] : item;
+  const int ix = ps.item_idx ? ps.item_idx[item] : ps.idx;
+  if (ps.src.QA)
+    exact_waypoint(ps.src, ps.perm, ps.nplan, ed, ix, ps.uc.q + (size_t)u * ps.nplan, ps.item_idx ? item : -1);
+  else
+    for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + lane * ps.L];
+  ps.uc.edge[u] = ed;
+  ps.uc.idx[u] = ix;
+  ps.uc.ga[u] = ga;
+  ps.uc.gb[u] = gb;
+  return true;
+}
+
 // Walk the moving part of the body tree for this lane's configuration.
 //   ip, tp : program tables (control words; constants in the instantiation's scalar type)
 //   q      : this lane's planning columns, q[c*qstride] (float64; the float32 filter also takes
@@ -805,7 +897,14 @@ __device__ __forceinline__ void sincos_half(T x, T *s, T *c) {
 template <class T, int MAXS, bool EMIT, bool WBOX, bool MBOX, class QT>
 __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const QT *q, int qstride,
                                           T *save, int sstride, bool active, T tol, const FkOut &out,
-                                          int64_t row) {
+                                          int64_t row, const PatchSink &ps = PatchSink{}) {
+  // float32 filter: a pair the narrowphase cannot decide goes to the exact pair kernel by itself
+  // (`ps`), and the lane carries on with its other pairs; only what cannot be handed over makes
+  // the whole configuration undecided
+  auto undecided = [&](bool un, int ga, int gb) -> bool {
+    if constexpr (Real<T>::exact) return un;
+    else return un && !hand_over_own(ps, (int)row, ga, gb);
+  };
   typedef typename Real<T>::Tab Tab;
   typedef GeomT<T> Geom;
   SlotFile<T, MAXS> sf;
@@ -992,8 +1091,9 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
           const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, GT_PLANE, par, psize, true,
                                                        wbound[nwpad + wc], tol);
           hit = hit || (pass && code == V_CONTACT);
-          unsure = unsure || (pass && code == V_UNSURE);
-          live = live && !(pass && code != V_NONE);
+          const bool un = undecided(pass && code == V_UNSURE, geom_id, info_bits(wcull[wc_at(wc, WC_INFO)]) >> 8);
+          unsure = unsure || un;
+          live = live && !(pass && code == V_CONTACT) && !un;
         }
 
         // ---- other static partners, four rows of the world cull table at a time.  The four
@@ -1051,8 +1151,9 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
             const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst,
                                                          wbound[nwpad + wc], tol);
             hit = hit || (pk && code == V_CONTACT);
-            unsure = unsure || (pk && code == V_UNSURE);
-            live = live && !(pk && code != V_NONE);
+            const bool un = undecided(pk && code == V_UNSURE, geom_id, pgid);
+            unsure = unsure || un;
+            live = live && !(pk && code == V_CONTACT) && !un;
           }
         }
 
@@ -1107,8 +1208,9 @@ __device__ __forceinline__ int run_config(IP ip, typename Real<T>::Tab tp, const
           const int code = pair_contact<T, WBOX, MBOX>(gtype, cur, gsize, ptype, par, psize, pfirst,
                                                        sbound[MAX_SLOTS + slot], tol);
           hit = hit || (pk && code == V_CONTACT);
-          unsure = unsure || (pk && code == V_UNSURE);
-          live = live && !(pk && code != V_NONE);
+          const bool un = undecided(pk && code == V_UNSURE, geom_id, (int)sbound[GS_GEOMID + slot]);
+          unsure = unsure || un;
+          live = live && !(pk && code == V_CONTACT) && !un;
         }
       }
 
@@ -1144,77 +1246,6 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define MJPL_T0(var)
 #define MJPL_ACC(slot, var)
 #endif
-
-// Items the float32 filter could not decide, handed to the exact float64 kernels on the device.
-// ga >= 0: one geom pair (ga = the later moving geom, gb = its partner) of the configuration;
-// ga < 0: the whole configuration.
-struct UndecidedConfigs {
-  double *q;    // [cap][nplan] configuration (waypoint), row-major
-  int *edge;    // [cap] edge it belongs to
-  int *idx;     // [cap] its check index inside that edge
-  int *ga, *gb; // [cap] model geom ids of the undecided pair, or -1
-  int *count;   // entries written (may exceed cap: the overflow went to the edge-level list)
-  int cap;
-};
-
-// Where a drain reports candidates it cannot decide (count == nullptr: flag the owning lane).
-// Where the edges of a launch live, for kernels that rebuild a waypoint instead of reading it.
-struct EdgeSource {
-  const double *QA, *QB;  // null: not an edge launch
-  long long E;
-  int layout;
-  double step;
-  const double *ckpt;     // [item slot][nplan] exact waypoints of the items with idx % kCkptEvery == 0, or null
-};
-constexpr int kCkptEvery = 32;
-
-// Waypoint `idx` (1-based) of edge i, EXACTLY as the reference's recurrence produces it
-// (planning/utils.py:182-185, the statements of edge_body): steps from QA, each recomputing
-// direction and distance from the previous waypoint.  `out[0..nplan)` doubles as the working row.
-// Meant for the few waypoints that go to the exact re-check -- one lane walks alone here, at most
-// kCkptEvery - 1 steps when the launch keeps checkpoints (`slot` = the waypoint's item slot; an
-// edge's items are consecutive slots).
-template <class Perm>
-__device__ inline void exact_waypoint(const EdgeSource &src, Perm perm, int nplan, long long i, int idx,
-                                      double *out, long long slot = -1) {
-  auto at = [&](const double *Q, int k) -> double {
-    return (src.layout == MJPL_SOA) ? Q[(long long)k * src.E + i] : Q[i * nplan + k];
-  };
-  int from = 0;
-  if (src.ckpt && slot >= 0 && idx >= kCkptEvery) {
-    from = idx - idx % kCkptEvery;
-    const double *row = src.ckpt + (size_t)(slot - (idx - from)) * nplan;
-    for (int k = 0; k < nplan; k++) out[k] = row[k];
-  } else {
-    for (int k = 0; k < nplan; k++) out[k] = at(src.QA, k);
-  }
-  for (int n = from; n < idx; n++) {
-    double s = 0;
-    for (int k = 0; k < nplan; k++) {
-      const int col = perm[k];
-      const double d = at(src.QB, col) - out[col];
-      s = s + d * d;
-    }
-    const double mag = sqrt(s);
-    const double sm = src.step < mag ? src.step : mag;
-    for (int k = 0; k < nplan; k++) {
-      const double d = at(src.QB, k) - out[k];
-      out[k] = out[k] + (d / mag) * sm;
-    }
-  }
-}
-
-struct PatchSink {
-  UndecidedConfigs uc;
-  const double *qcol;  // configurations of this wave's lanes: q[k] of lane l at qcol[k * B + l * L]
-  int B, L, nplan;     // (LDS columns: B = block size, L = 1)
-  int idx;             // check index of the configurations under test (wave-uniform) ...
-  const int *item_edge, *item_idx;  // ... or, lane-per-waypoint kernels: (edge, index) of item i
-  // lane-per-waypoint kernels test waypoints in closed form (see k_filter_items): what goes to the
-  // exact re-check is rebuilt by the recurrence, not copied from qcol
-  EdgeSource src;
-  IP perm;
-};
 
 // ----------------------------------------------------------------------------- queued narrowphase
 // The immediate interpreter above runs a narrowphase routine as soon as ANY lane of the wave

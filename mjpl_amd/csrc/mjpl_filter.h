@@ -56,21 +56,22 @@ __device__ __forceinline__ int check_one(const Carve<T> &c, const QT *q, int B, 
 #ifdef MJPL_X_NOCHECK  // timing-only build: what the item kernel costs around the check
   if (item_idx) return V_NONE;
 #endif
+  PatchSink ps;
+  ps.uc = uc;
+  // where the owner's configuration is found when a pair is handed to the exact re-check: the
+  // float64 LDS columns -- or, with `src` (float32 columns hold a rounded copy), the caller's
+  // rows / the recurrence from them
+  ps.qcol = c.col0 + (threadIdx.x & ~63);
+  ps.B = B;
+  ps.L = 1;
+  ps.nplan = c.ip[H_NPLAN];
+  ps.idx = idx;
+  ps.item_edge = item_edge;
+  ps.item_idx = item_idx;
+  ps.src = src;
+  ps.perm = c.ip + c.ip[H_OFF_PERM];
   if constexpr (kQueued<T, MBOX>) {
     WaveQueue<T> wq = wave_queue<T>(c.qmem);
-    PatchSink ps;
-    ps.uc = uc;
-    // where a drain lane finds the owner's configuration: the float64 LDS columns -- or, with
-    // `src` (float32 columns hold a rounded copy), the caller's rows / the recurrence from them
-    ps.qcol = c.col0 + (threadIdx.x & ~63);
-    ps.B = B;
-    ps.L = 1;
-    ps.nplan = c.ip[H_NPLAN];
-    ps.idx = idx;
-    ps.item_edge = item_edge;
-    ps.item_idx = item_idx;
-    ps.src = src;
-    ps.perm = c.ip + c.ip[H_OFF_PERM];
     if constexpr (!std::is_void<Spec>::value)  // this model's own straight-line check (same contract)
       return Spec::run(c.tp, c.ltab, q, qstride, c.save + threadIdx.x, B, active, tol, wq, (int)row, ps);
     else
@@ -78,8 +79,9 @@ __device__ __forceinline__ int check_one(const Carve<T> &c, const QT *q, int B, 
                                               wq, (int)row, ps);
   } else {
     FkOut none = {};
+    if constexpr (Real<T>::exact) ps.uc.count = nullptr;  // (the exact path decides everything itself)
     return run_config<T, MAXS, false, WBOX, MBOX>(c.ip, c.tp, q, qstride, c.save + threadIdx.x, B, active, tol,
-                                                  none, row);
+                                                  none, row, ps);
   }
 }
 

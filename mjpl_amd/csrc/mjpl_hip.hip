@@ -1688,7 +1688,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
   if (filter) {
     int rc = ulist_reserve(e, N);
     UndecidedConfigs uc = {};
-    if (rc == MJPL_OK && !e->immediate()) {
+    if (rc == MJPL_OK) {  // (both interpreters hand single undecided pairs over)
       rc = uc_reserve(e, N);
       uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
       uc.ga = e->d_ucga; uc.gb = e->d_ucgb;
@@ -1886,7 +1886,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     // share of the batch; surplus blocks return at once)
     const size_t ldsc = lds_bytes(e, 1);
     const unsigned pgrid = (unsigned)std::min<size_t>((uc.cap + kBlock - 1) / kBlock, 1024);
-    if (e->immediate()) {  // immediate filter: whole configurations
+    if (e->immediate()) {  // immediate filter: also whole configurations (entries with ga < 0)
       rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_check_configs<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldsc);
@@ -1897,7 +1897,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         return MJPL_OK;
       });
       if (rc != MJPL_OK) return rc;
-    } else {        // queued filter: single geom pairs
+    }
+    {  // single geom pairs (entries with ga >= 0)
       rc = allow_lds(k_patch_pairs, ldsc);
       if (rc != MJPL_OK) return rc;
       GeomTable gt = {e->d_geomtab};
