@@ -107,6 +107,11 @@ typedef struct mjpl_info {
   float   filter_err_a;
   float   filter_err_b;
   int32_t filter_poisoned_geoms; /* static geoms too large / far for binary32: always re-checked */
+  /* which float32 interpreter this model runs: 0 = queued narrowphase, small builds (no moving
+   * boxes, <= 16 stored geoms; the only one a specialised library can replace); 1 = queued, the
+   * general 24-slot build with moving boxes in the box queue; 2 = immediate narrowphase (more
+   * than 24 stored geoms, or MJPL_FORCE_IMMEDIATE=1 at creation: tests) */
+  int32_t filter_interpreter;
 } mjpl_info;
 
 /* ---- lifetime ------------------------------------------------------------------ */

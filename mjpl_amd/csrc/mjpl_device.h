@@ -1264,34 +1264,40 @@ __device__ __forceinline__ unsigned long long stamp() {
 // record: cur pos/axis, (N only: slot partner pos/axis).  A push that would not fit first drains
 // one batch of up to 64 off the top, so mid-configuration drains run with (nearly) full lanes.
 enum : int { QN_CAP = 64, QN_FIELDS = 12, QB_CAP = 64, QB_FIELDS = 6 };
+// Models with MOVING boxes (MBOX builds): every candidate with a box on either side goes to the
+// B queue, whose records then carry full frames -- [0..5] cur pos, z axis; [6..11] cur x, y axes;
+// [12..17] slot partner pos, z axis; [18..23] slot partner x, y axes -- so the N drains keep to the
+// cheap sphere / capsule / plane routines.
+enum : int { QB_FIELDS_MBOX = 24 };
 // i0: bits 0..5 owner lane, 6..9 cur type, 10..13 partner type, 14 pfirst, 15..16 kind, 17..24 index
 // i1: constant-table offset of the cur geom's block (sizes; slot sizes)
 
-template <class T>
+template <class T, bool MBOX = false>
 struct WaveQueue {
+  static constexpr int kBFields = MBOX ? QB_FIELDS_MBOX : QB_FIELDS;
   T *nf;          // [QN_FIELDS][QN_CAP]
   int *ni0, *ni1; // [QN_CAP] each: packed pair id, constant-table offset of the cur geom's block
-  T *bf;          // [QB_FIELDS][QB_CAP]
+  T *bf;          // [kBFields][QB_CAP]
   int *bi0, *bi1; // [QB_CAP]
   int *flags;     // [64] : bit0 contact, bit1 unsure, per owning lane
   static __host__ __device__ constexpr size_t bytes() {
     return (size_t)QN_FIELDS * QN_CAP * sizeof(T) + 2 * QN_CAP * sizeof(int) +
-           (size_t)QB_FIELDS * QB_CAP * sizeof(T) + 2 * QB_CAP * sizeof(int) + 64 * sizeof(int);
+           (size_t)kBFields * QB_CAP * sizeof(T) + 2 * QB_CAP * sizeof(int) + 64 * sizeof(int);
   }
   __device__ __forceinline__ void carve(char *base) {
     nf = reinterpret_cast<T *>(base);
     ni0 = reinterpret_cast<int *>(nf + QN_FIELDS * QN_CAP);
     ni1 = ni0 + QN_CAP;
     bf = reinterpret_cast<T *>(ni1 + QN_CAP);
-    bi0 = reinterpret_cast<int *>(bf + QB_FIELDS * QB_CAP);
+    bi0 = reinterpret_cast<int *>(bf + kBFields * QB_CAP);
     bi1 = bi0 + QB_CAP;
     flags = bi1 + QB_CAP;
   }
 };
 
 // BOXQ selects the queue.  ALL: empty it (end of a configuration); otherwise one batch.
-template <class T, bool BOXQ, bool ALL>
-__device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, const T *tp, const T *wcull,
+template <class T, bool BOXQ, bool ALL, bool MBOX = false>
+__device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &qn, const T *tp, const T *wcull,
                                             const T *wnarrow, int nwpad, T tol, const PatchSink &ps,
                                             unsigned long long *dacc = nullptr) {
   // tp / wcull / wnarrow point into the workgroup's LDS copy of the constant table: the drain
@@ -1334,7 +1340,32 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
     const T gsize[3] = {gd[GD_SIZE], gd[GD_SIZE + 1], gd[GD_SIZE + 2]};
     T psize[3], margin;
     int code = V_NONE;
-    if constexpr (BOXQ) {
+    if constexpr (BOXQ && MBOX) {
+      // a box on either side: full frames (see QB_FIELDS_MBOX); static partners from the tables
+      cur.m[0] = qf[6 * CAP + jj]; cur.m[3] = qf[7 * CAP + jj]; cur.m[6] = qf[8 * CAP + jj];
+      cur.m[1] = qf[9 * CAP + jj]; cur.m[4] = qf[10 * CAP + jj]; cur.m[7] = qf[11 * CAP + jj];
+      if (kind == EK_SLOT) {
+        par.pos[0] = qf[12 * CAP + jj]; par.pos[1] = qf[13 * CAP + jj]; par.pos[2] = qf[14 * CAP + jj];
+        par.m[2] = qf[15 * CAP + jj]; par.m[5] = qf[16 * CAP + jj]; par.m[8] = qf[17 * CAP + jj];
+        par.m[0] = qf[18 * CAP + jj]; par.m[3] = qf[19 * CAP + jj]; par.m[6] = qf[20 * CAP + jj];
+        par.m[1] = qf[21 * CAP + jj]; par.m[4] = qf[22 * CAP + jj]; par.m[7] = qf[23 * CAP + jj];
+        Tab sb = gd + GD_WBOUND + 2 * nwpad;
+        margin = sb[MAX_SLOTS + index];
+        psize[0] = sb[2 * MAX_SLOTS + 3 * index]; psize[1] = sb[2 * MAX_SLOTS + 3 * index + 1];
+        psize[2] = sb[2 * MAX_SLOTS + 3 * index + 2];
+      } else {  // EK_STATIC (any type), EK_PLANE
+        Tab rw = wnarrow + index * WN_LEN;
+        par.pos[0] = wcull[wc_at(index, 0)]; par.pos[1] = wcull[wc_at(index, 1)]; par.pos[2] = wcull[wc_at(index, 2)];
+        par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
+        par.m[0] = rw[WN_XAXIS]; par.m[3] = rw[WN_XAXIS + 1]; par.m[6] = rw[WN_XAXIS + 2];
+        par.m[1] = rw[WN_YAXIS]; par.m[4] = rw[WN_YAXIS + 1]; par.m[7] = rw[WN_YAXIS + 2];
+        const bool plane = kind == EK_PLANE;  // (the interpreter passes no size for a plane)
+        psize[0] = plane ? T(0) : rw[WN_SIZE]; psize[1] = plane ? T(0) : rw[WN_SIZE + 1];
+        psize[2] = plane ? T(0) : rw[WN_SIZE + 2];
+        margin = gd[GD_WBOUND + nwpad + index];
+      }
+      if (on) code = pair_contact<T, true, true>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
+    } else if constexpr (BOXQ) {
       Tab rw = wnarrow + index * WN_LEN;
       par.pos[0] = wcull[wc_at(index, 0)]; par.pos[1] = wcull[wc_at(index, 1)]; par.pos[2] = wcull[wc_at(index, 2)];
       par.m[2] = rw[WN_ZAXIS]; par.m[5] = rw[WN_ZAXIS + 1]; par.m[8] = rw[WN_ZAXIS + 2];
@@ -1406,7 +1437,7 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T> &wq, int &qn, con
           ps.uc.idx[u] = ix;
           ps.uc.ga[u] = (int)gd[GD_GEOMID];
           int gb;
-          if (!BOXQ && kind == EK_SLOT) gb = (int)gd[GD_WBOUND + 2 * nwpad + GS_GEOMID + index];
+          if ((!BOXQ || MBOX) && kind == EK_SLOT) gb = (int)gd[GD_WBOUND + 2 * nwpad + GS_GEOMID + index];
           else gb = info_bits(wcull[wc_at(index, WC_INFO)]) >> 8;
           ps.uc.gb[u] = gb;
           handed = true;
@@ -1458,10 +1489,10 @@ __device__ __forceinline__ void queue_push(const WaveQueue<T> &wq, int &fill, T 
 }
 
 // Queued version of run_config for models without moving boxes (slots hold pos + z axis).
-template <class T, int MAXS, bool WBOX, class QT>
+template <class T, int MAXS, bool WBOX, bool MBOX, class QT>
 __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp, const T *ltab,
                                                  const QT *q, int qstride, T *save, int sstride,
-                                                 bool active, T tol, const WaveQueue<T> &wq, int item,
+                                                 bool active, T tol, const WaveQueue<T, MBOX> &wq, int item,
                                                  const PatchSink &ps) {
   typedef typename Real<T>::Tab Tab;
   typedef GeomT<T> Geom;
@@ -1612,13 +1643,21 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         mul_mat_vec3(cur.pos, R, lpos);
         cur.pos[0] += p[0]; cur.pos[1] += p[1]; cur.pos[2] += p[2];
       }
+      const bool curbox = MBOX && gtype == GT_BOX;  // (wave-uniform) a moving box: the whole frame
       if (gflags & GF_SAMEROT) {
-        cur.m[2] = R[2]; cur.m[5] = R[5]; cur.m[8] = R[8];
+        if (curbox) {
+#pragma unroll
+          for (int k = 0; k < 9; k++) cur.m[k] = R[k];
+        } else {
+          cur.m[2] = R[2]; cur.m[5] = R[5]; cur.m[8] = R[8];
+        }
       } else {
         T lq[4] = {gd[3], gd[4], gd[5], gd[6]}, gq[4];
         mul_quat(gq, qt, lq);
-        quat2zaxis(cur.m, gq);
+        if (curbox) quat2mat(cur.m, gq);
+        else quat2zaxis(cur.m, gq);
       }
+      if (!curbox) cur.m[0] = cur.m[1] = cur.m[3] = cur.m[4] = cur.m[6] = cur.m[7] = T(0);
 
       MJPL_ACC(1, tt);  // geom record + pose
       // ---- culls: straight-line code, four static rows (then four register slots) at a time;
@@ -1627,8 +1666,9 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       // control flow: ~5 branches and ~35 instructions per pair.)
       Tab wbound = gd + GD_WBOUND;            // [nwpad] bounds, then [nwpad] margins
       Tab sbound = wbound + 2 * nwpad;        // [16] bounds, [16] margins, [16][3] sizes
+      // t6: a slot partner's pos + z axis; t6b: its x, y axes (MBOX builds, partner a box)
       auto push = [&](auto boxq, unsigned long long pm, int kind, int index, int ptype, bool pfirst,
-                      const T *t6) {
+                      const T *t6, const T *t6b = nullptr) {
         constexpr bool BOXQ = decltype(boxq)::value;
         constexpr int CAP = BOXQ ? QB_CAP : QN_CAP;
         int &fill = BOXQ ? qb : qn;
@@ -1636,9 +1676,9 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         if (fill + cnt > CAP) {  // make room: one batch leaves the top of the queue
           MJPL_ACC(2, tt);
 #ifdef MJPL_STAMPS
-          queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
+          queue_drain<T, BOXQ, false, MBOX>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
 #else
-          queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps);
+          queue_drain<T, BOXQ, false, MBOX>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps);
 #endif
           fl = wq.flags[lane] & 3;
           dead = (fl != 0 || !active || far) ? kInf : T(0);
@@ -1655,6 +1695,16 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           if (!BOXQ && kind == EK_SLOT) {  // a static partner's pose is read from the world tables at the drain
             qf[6 * CAP + off] = t6[0]; qf[7 * CAP + off] = t6[1]; qf[8 * CAP + off] = t6[2];
             qf[9 * CAP + off] = t6[3]; qf[10 * CAP + off] = t6[4]; qf[11 * CAP + off] = t6[5];
+          }
+          if constexpr (BOXQ && MBOX) {
+            qf[6 * CAP + off] = cur.m[0]; qf[7 * CAP + off] = cur.m[3]; qf[8 * CAP + off] = cur.m[6];
+            qf[9 * CAP + off] = cur.m[1]; qf[10 * CAP + off] = cur.m[4]; qf[11 * CAP + off] = cur.m[7];
+            if (kind == EK_SLOT) {
+#pragma unroll
+              for (int k = 0; k < 6; k++) qf[(12 + k) * CAP + off] = t6[k];
+#pragma unroll
+              for (int k = 0; k < 6; k++) qf[(18 + k) * CAP + off] = t6b ? t6b[k] : T(0);
+            }
           }
           qi0[off] = lane | (gtype << 6) | (ptype << 10) | ((pfirst ? 1 : 0) << 14) | (kind << 15) | (index << 17);
           qi1[off] = gdoff;
@@ -1679,7 +1729,8 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
         T dif[3] = {cur.pos[0] - ppos[0], cur.pos[1] - ppos[1], cur.pos[2] - ppos[2]};
         const unsigned long long pm = __builtin_amdgcn_ballot_w64(!(dot3(dif, pz) + dead > wbound[wc]));
         if (pm == 0ull) continue;
-        push(kGeneral, pm, EK_PLANE, wc, GT_PLANE, true, ppos);
+        if (curbox) push(kBoxes, pm, EK_PLANE, wc, GT_PLANE, true, ppos);
+        else push(kGeneral, pm, EK_PLANE, wc, GT_PLANE, true, ppos);
       }
       // other static geoms: one wide scalar load of four rows (+ their four bounds) per chunk
 #ifdef MJPL_CHUNK_PREFETCH
@@ -1743,7 +1794,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           const int ptype = info & 255, pgid = info >> 8;
           // mj_collision order: smaller geom type first, geom id breaks ties
           const bool pfirst = (ptype < gtype) || (ptype == gtype && pgid < geom_id);
-          if (WBOX && ptype == GT_BOX) push(kBoxes, pm, EK_STATIC, wc, ptype, pfirst, cur.pos);
+          if ((WBOX && ptype == GT_BOX) || curbox) push(kBoxes, pm, EK_STATIC, wc, ptype, pfirst, cur.pos);
           else push(kGeneral, pm, EK_STATIC, wc, ptype, pfirst, cur.pos);
         }
       }
@@ -1769,9 +1820,16 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           const int slot = (int)__builtin_ctz(ab);
           const unsigned long long pm = __builtin_amdgcn_ballot_w64((lanebits >> slot) & 1u);
           const int pw = uni(swords[slot]);
+          const int ptype = (pw >> 12) & 15;
           T t6[6];
           slot_get6(sf, slot, t6);
-          push(kGeneral, pm, EK_SLOT, slot, (pw >> 12) & 15, (pw & P_FIRST) != 0, t6);
+          if (MBOX && (curbox || ptype == GT_BOX)) {
+            T t6b[6] = {0, 0, 0, 0, 0, 0};
+            if ((pw & 63) != SLOT_NONE) slot_get6(sf, pw & 63, t6b);  // stored box: x and y axes
+            push(kBoxes, pm, EK_SLOT, slot, ptype, (pw & P_FIRST) != 0, t6, t6b);
+          } else {
+            push(kGeneral, pm, EK_SLOT, slot, ptype, (pw & P_FIRST) != 0, t6);
+          }
         }
       }
 
@@ -1779,17 +1837,21 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
       if (store >= 0) {
         const T t6[6] = {cur.pos[0], cur.pos[1], cur.pos[2], cur.m[2], cur.m[5], cur.m[8]};
         slot_put6(sf, store & 63, t6);
+        if (MBOX && ((store >> 6) & 63) != SLOT_NONE) {
+          const T t6b[6] = {cur.m[0], cur.m[3], cur.m[6], cur.m[1], cur.m[4], cur.m[7]};
+          slot_put6(sf, (store >> 6) & 63, t6b);
+        }
       }
       MJPL_ACC(4, tt);  // slot store
     }
   }
   MJPL_ACC(5, tt);
 #ifdef MJPL_STAMPS
-  if (qn > 0) queue_drain<T, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
-  if (WBOX && qb > 0) queue_drain<T, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
+  if (qn > 0) queue_drain<T, false, true, MBOX>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
+  if ((WBOX || MBOX) && qb > 0) queue_drain<T, true, true, MBOX>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps, acc + 8);
 #else
-  if (qn > 0) queue_drain<T, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);
-  if (WBOX && qb > 0) queue_drain<T, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps);
+  if (qn > 0) queue_drain<T, false, true, MBOX>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);
+  if ((WBOX || MBOX) && qb > 0) queue_drain<T, true, true, MBOX>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps);
 #endif
   fl = wq.flags[lane] & 3;
   MJPL_ACC(3, tt);

@@ -19,9 +19,12 @@ constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
 #define MJPL_SPEC_ABI 3
+#ifndef MJPL_MBOX_WAVES
+#define MJPL_MBOX_WAVES 1  // the 24-slot moving-box build: ~360 VGPRs; bound to two waves per SIMD it spills 200 dwords and is 4x slower
+#endif
 // A model's own straight-line code is asked to fit three waves per SIMD (168 VGPRs): its register
 // pressure is a few registers above that without the bound, and the third wave is worth more
-template <class Spec> constexpr int kMinWaves = std::is_void<Spec>::value ? 1 : 3;
+template <class Spec, int MAXS = 0> constexpr int kMinWaves = std::is_void<Spec>::value ? (MAXS == 24 ? MJPL_MBOX_WAVES : 1) : 3;
 
 // LDS carve shared by all kernels: [tables (A/B build only) | float64 columns | pose saves].
 // With the default build the tables stay in global memory (scalar loads).
@@ -35,14 +38,16 @@ struct Carve {
   typename Real<T>::Tab tp;
 };
 
-// queued narrowphase: the float32 filter of models without moving boxes
-template <class T, bool MBOX>
-constexpr bool kQueued = !Real<T>::exact && !MBOX;
+// queued narrowphase: the float32 filter, except in the one general build for models that keep
+// more than kQueuedMaxSlots geoms in the slot file (immediate interpreter)
+constexpr int kQueuedMaxSlots = 24;
+template <class T, int MAXS>
+constexpr bool kQueued = !Real<T>::exact && MAXS <= kQueuedMaxSlots;
 
-template <class T>
-__device__ __forceinline__ WaveQueue<T> wave_queue(char *qmem) {
-  char *base = qmem + (size_t)(threadIdx.x >> 6) * WaveQueue<T>::bytes();
-  WaveQueue<T> wq;
+template <class T, bool MBOX>
+__device__ __forceinline__ WaveQueue<T, MBOX> wave_queue(char *qmem) {
+  char *base = qmem + (size_t)(threadIdx.x >> 6) * WaveQueue<T, MBOX>::bytes();
+  WaveQueue<T, MBOX> wq;
   wq.carve(base);
   return wq;
 }
@@ -70,13 +75,13 @@ __device__ __forceinline__ int check_one(const Carve<T> &c, const QT *q, int B, 
   ps.item_idx = item_idx;
   ps.src = src;
   ps.perm = c.ip + c.ip[H_OFF_PERM];
-  if constexpr (kQueued<T, MBOX>) {
-    WaveQueue<T> wq = wave_queue<T>(c.qmem);
+  if constexpr (kQueued<T, MAXS>) {
+    WaveQueue<T, MBOX> wq = wave_queue<T, MBOX>(c.qmem);
     if constexpr (!std::is_void<Spec>::value)  // this model's own straight-line check (same contract)
       return Spec::run(c.tp, c.ltab, q, qstride, c.save + threadIdx.x, B, active, tol, wq, (int)row, ps);
     else
-      return run_config_queued<T, MAXS, WBOX>(c.ip, c.tp, c.ltab, q, qstride, c.save + threadIdx.x, B, active, tol,
-                                              wq, (int)row, ps);
+      return run_config_queued<T, MAXS, WBOX, MBOX>(c.ip, c.tp, c.ltab, q, qstride, c.save + threadIdx.x, B, active,
+                                                    tol, wq, (int)row, ps);
   } else {
     FkOut none = {};
     if constexpr (Real<T>::exact) ps.uc.count = nullptr;  // (the exact path decides everything itself)
@@ -88,7 +93,8 @@ __device__ __forceinline__ int check_one(const Carve<T> &c, const QT *q, int B, 
 template <class T>
 __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restrict__ gip, int nip,
                                               const T *__restrict__ gtp, int ntp, int nplan, int ncolsets,
-                                              int B, size_t colscalar = sizeof(double)) {
+                                              int B, size_t colscalar = sizeof(double),
+                                              size_t qbytes = WaveQueue<T>::bytes()) {
   Carve<T> c;
 #if MJPL_TABLES_LDS
   // A/B build: [control words | constants | columns | saves | queues | ...], tables first so that
@@ -109,7 +115,7 @@ __device__ __forceinline__ Carve<T> carve_lds(double *smem, const int *__restric
   c.qmem = reinterpret_cast<char *>(c.col0) +
            ((colbytes + (size_t)nsave * 7 * B * sizeof(T) + 7) & ~(size_t)7);
   // queued kernels: constant-table copy behind the queues (staged below, before the barrier)
-  c.ltab = reinterpret_cast<T *>(c.qmem + (size_t)(B / 64) * WaveQueue<T>::bytes());
+  c.ltab = reinterpret_cast<T *>(c.qmem + (size_t)(B / 64) * qbytes);  // (qbytes: one wave's queues)
   if (!Real<T>::exact)
     for (int k = threadIdx.x; k < ntp; k += blockDim.x) c.ltab[k] = gtp[k];
 #if MJPL_TABLES_LDS
@@ -370,7 +376,7 @@ __device__ __forceinline__ void emit_items(const int *__restrict__ gip, const do
 // large share of the candidate edges ends inside an obstacle, and in the one-pass kernel their
 // lanes idle through every later waypoint of the wave.
 template <class Spec, int MAXS, bool WBOX, bool MBOX>
-__global__ void __launch_bounds__(kBlock, kMinWaves<Spec>)
+__global__ void __launch_bounds__(kBlock, (kMinWaves<Spec, MAXS>))
 k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
                    const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, int layout,
                    float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
@@ -383,9 +389,10 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
   // (immediate interpreter + item expansion: a second column set holds the walking waypoint)
   // queued interpreter: binary32 columns for the check (what goes to the exact re-check is read
   // from QB again), and the walk below reuses the workgroup's columns, saves and queues
-  constexpr bool kQ = kQueued<float, MBOX>;
+  constexpr bool kQ = kQueued<float, MAXS>;
   typedef typename std::conditional<kQ, float, double>::type QT;
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, (!kQ && ib.count) ? 2 : 1, B, sizeof(QT));
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, (!kQ && ib.count) ? 2 : 1, B, sizeof(QT),
+                                    WaveQueue<float, MBOX>::bytes());
   const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
   const bool active = i < E;
   bool finite = true;
@@ -431,7 +438,7 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
     } else {
       bool whole_edge = false;
       if (code == V_UNSURE) {  // the endpoint itself goes to the exact configuration kernel
-        const int j = kQueued<float, MBOX> ? uc.cap : atomicAdd(uc.count, 1);  // (queued: the whole edge)
+        const int j = kQueued<float, MAXS> ? uc.cap : atomicAdd(uc.count, 1);  // (queued: the whole edge)
         if (j < uc.cap) {
           for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = (double)qw[k * B];  // (float64 columns here)
           uc.edge[j] = (int)i;
@@ -497,7 +504,7 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
 }
 
 template <class Spec, int MAXS, bool WBOX, bool MBOX>
-__global__ void __launch_bounds__(kBlock, kMinWaves<Spec>)
+__global__ void __launch_bounds__(kBlock, (kMinWaves<Spec, MAXS>))
 k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
                  const double *__restrict__ Q, int64_t N, int layout, float tol,
                  uint8_t *__restrict__ valid, int *__restrict__ ulist, int *__restrict__ ucount,
@@ -505,9 +512,9 @@ k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__
   extern __shared__ double smem[];
   const int B = blockDim.x;
   const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
-  constexpr bool kQ = kQueued<float, MBOX>;
+  constexpr bool kQ = kQueued<float, MAXS>;
   typedef typename std::conditional<kQ, float, double>::type QT;  // (see k_filter_endpoints)
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B, sizeof(QT));
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B, sizeof(QT), WaveQueue<float, MBOX>::bytes());
   const int64_t i = (int64_t)blockIdx.x * B + threadIdx.x;
   const bool active = i < N;
   QT *qc = reinterpret_cast<QT *>(c.col0) + threadIdx.x;
@@ -527,7 +534,7 @@ k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__
 #ifdef MJPL_X_ITEMS_4WAVES
 #define MJPL_ITEMS_BOUNDS __launch_bounds__(kBlock, 4)
 #else
-#define MJPL_ITEMS_BOUNDS __launch_bounds__(kBlock, kMinWaves<Spec>)
+#define MJPL_ITEMS_BOUNDS __launch_bounds__(kBlock, (kMinWaves<Spec, MAXS>))
 #endif
 template <class Spec, int MAXS, bool WBOX, bool MBOX>
 __global__ void MJPL_ITEMS_BOUNDS
@@ -544,7 +551,7 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
   const int64_t n = (int64_t)region * ib.regcap + (fill < ib.regcap ? fill : ib.regcap);
   if (start >= n) return;
   const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
-  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B, sizeof(float));
+  Carve<float> c = carve_lds<float>(smem, gip, nip, gfp, nfp, nplan, 1, B, sizeof(float), WaveQueue<float, MBOX>::bytes());
   const int64_t it = start + threadIdx.x;
   const int64_t itc = it < (int64_t)ib.cap ? it : 0;
   const int ed = it < n ? ib.edge[itc] : -1;
@@ -569,7 +576,7 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
       if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)ib.idx[it]);
     } else {
       bool handed = false;
-      if constexpr (!kQueued<float, MBOX>) {
+      if constexpr (!kQueued<float, MAXS>) {
         // immediate interpreter: the whole configuration goes to the exact configuration kernel
         if (uc.count) {
           const int j = atomicAdd(uc.count, 1);

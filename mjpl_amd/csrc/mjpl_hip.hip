@@ -157,7 +157,7 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
   const int B = blockDim.x;
   if (rlist && (int64_t)blockIdx.x * B >= (int64_t)*rcount) return;
   const int nplan = gip[H_NPLAN];
-  Carve<T> c = carve_lds<T>(smem, gip, nip, gtp, ntp, nplan, 1, B);
+  Carve<T> c = carve_lds<T>(smem, gip, nip, gtp, ntp, nplan, 1, B, sizeof(double), WaveQueue<T, MBOX>::bytes());
   int64_t i;
   const bool active = pick_item(E, rlist, rcount, &i);
   // The walking waypoint lives in LDS (starts at QB for check 0, then QA + steps); the edge end
@@ -254,7 +254,7 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
       // clears valid if it finds a contact.  Only if the hand-off buffer is full does the whole
       // edge go to the exact edge kernel.  (The queued interpreter hands over single pairs by
       // itself; when IT reports a configuration undecidable, the whole edge goes.)
-      const int j = kQueued<T, MBOX> ? uc.cap : atomicAdd(uc.count, 1);
+      const int j = kQueued<T, MAXS> ? uc.cap : atomicAdd(uc.count, 1);
       if (j < uc.cap) {
         for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
         uc.edge[j] = (int)i;
@@ -997,7 +997,14 @@ struct mjpl_engine {
   bool wbox = false, mbox = false;
   // the immediate (non-queued) interpreter serves models with moving boxes and models that keep
   // more than 16 geoms in the slot file (one general <32, true, true> build)
-  bool immediate() const { return mbox || maxs > 16; }
+  // Which builds a model runs.  Exact kernels: <4|8|16, wbox, false>, or the general <32, true, true>
+  // for moving boxes / more than 16 stored geoms.  Filter kernels: the same small builds, then
+  // <24, true, true> -- still the queued interpreter, moving boxes through its box queue -- and
+  // only beyond 24 stored geoms the immediate interpreter <32, true, true>.
+  bool exact_general() const { return mbox || maxs > 16; }
+  bool force_immediate = false;  // MJPL_FORCE_IMMEDIATE (create-time, tests)
+  bool immediate() const { return nslots > kQueuedMaxSlots || (force_immediate && exact_general()); }
+  bool filter_mbox() const { return exact_general() && !immediate(); }
   int npairs = 0, npairs_world = 0, nmoving = 0, nstatic = 0;
   // static poses for FK output
   std::vector<double> st_xpos, st_xquat, st_gxpos, st_gxmat;
@@ -1042,7 +1049,7 @@ void load_spec(mjpl_engine *e) {
   e->spec = nullptr;
   if (const char *s = getenv("MJPL_SPEC"))
     if (atoi(s) == 0) return;
-  if (e->immediate() || !e->filter_usable) return;
+  if (e->exact_general() || !e->filter_usable) return;  // (the generator covers the small queued builds)
   auto &cache = spec_cache();
   auto it = cache.find(e->program_hash);
   if (it != cache.end()) {
@@ -1584,7 +1591,9 @@ size_t lds_bytes(const mjpl_engine *e, int ncolsets, size_t scalar = sizeof(doub
   const size_t nplan = e->qidx.size();
   size_t bytes = (((size_t)ncolsets * nplan * block * colscalar + 7) & ~(size_t)7) + (size_t)e->nsave * 7 * block * scalar;
   bytes = (bytes + 7) & ~(size_t)7;
-  if (queued) bytes += (size_t)(block / 64) * WaveQueue<float>::bytes() + ((e->fp.size() * sizeof(float) + 7) & ~(size_t)7);
+  if (queued)
+    bytes += (size_t)(block / 64) * (e->filter_mbox() ? WaveQueue<float, true>::bytes() : WaveQueue<float, false>::bytes()) +
+             ((e->fp.size() * sizeof(float) + 7) & ~(size_t)7);
 #if MJPL_TABLES_LDS
   bytes += ((e->dp.size() * scalar + 7) / 8) * 8 + ((e->ip.size() * sizeof(int) + 7) / 8) * 8;
 #endif
@@ -1663,11 +1672,11 @@ int allow_lds(K kernel, size_t bytes) {
   return MJPL_OK;
 }
 
-// pick the <MAXS, WBOX, MBOX> instantiation for this model
+// pick the <MAXS, WBOX, MBOX> instantiation of the EXACT kernels for this model
 template <class F>
 int dispatch_variant(const mjpl_engine *e, F &&f) {
+  if (e->exact_general()) return f(std::integral_constant<int, 32>{}, std::true_type{}, std::true_type{});
   auto with_box = [&](auto S) -> int {
-    if (e->immediate()) return f(S, std::true_type{}, std::true_type{});  // moving boxes: general build
     if (e->wbox) return f(S, std::true_type{}, std::false_type{});
     return f(S, std::false_type{}, std::false_type{});
   };
@@ -1675,9 +1684,16 @@ int dispatch_variant(const mjpl_engine *e, F &&f) {
     case 4: return with_box(std::integral_constant<int, 4>{});
     case 8: return with_box(std::integral_constant<int, 8>{});
     case 16: return with_box(std::integral_constant<int, 16>{});
-    // more than 16 stored geoms at once (e.g. a gripper with many pad boxes): one general build
     default: return f(std::integral_constant<int, 32>{}, std::true_type{}, std::true_type{});
   }
+}
+
+// ... and of the FILTER kernels
+template <class F>
+int dispatch_filter(const mjpl_engine *e, F &&f) {
+  if (e->immediate()) return f(std::integral_constant<int, 32>{}, std::true_type{}, std::true_type{});
+  if (e->filter_mbox()) return f(std::integral_constant<int, kQueuedMaxSlots>{}, std::true_type{}, std::true_type{});
+  return dispatch_variant(e, f);
 }
 
 int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint8_t *dvalid,
@@ -1705,7 +1721,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
       rc = e->spec->configs(e->stream, fgrid, (unsigned)fblock, ldsf, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQ, N,
                             layout, e->filter_tol, dvalid, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
            : fail(MJPL_E_HIP, "specialised configuration kernel failed to launch");
-    else rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+    else rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_configs<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
       if (r != MJPL_OK) return r;
@@ -1837,7 +1853,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
                                 dQB, E, layout, e->filter_tol, dvalid, dfb, e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist,
                                 e->d_ucount + 2 * kCtr, ib, step) == 0 ? MJPL_OK
              : fail(MJPL_E_HIP, "specialised endpoint kernel failed to launch");
-      else rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+      else rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_endpoints<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldse);
         if (r != MJPL_OK) return r;
@@ -1856,7 +1872,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         rc = e->spec->items(e->stream, igrid, (unsigned)fblock, ldsq, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib,
                             src, e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
              : fail(MJPL_E_HIP, "specialised item kernel failed to launch");
-      else rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+      else rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_items<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
         int r = allow_lds(kern, ldsq);
         if (r != MJPL_OK) return r;
@@ -1870,7 +1886,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       rcount = e->d_icount + kCtr;
     }
     MJPL_MARK(2);  // after k_filter_items
-    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+    rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
       if (r != MJPL_OK) return r;
@@ -2001,6 +2017,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   e->qbase = m.qpos0;
   if (const char *f = getenv("MJPL_FILTER")) e->filter = atoi(f) != 0;
   if (const char *f = getenv("MJPL_TWO_PASS")) e->two_pass = atoi(f) != 0;
+  if (const char *f = getenv("MJPL_FORCE_IMMEDIATE")) e->force_immediate = atoi(f) != 0;
   if (const char *f = getenv("MJPL_EXPAND")) e->expand = atoi(f) != 0;
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
   if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));
@@ -2093,7 +2110,7 @@ int mjpl_program_dump(const mjpl_model_desc *d, const int32_t *allowed_bodies, i
   if ((rc = compile_program(e.get())) != MJPL_OK) return rc;
   memset(info, 0, sizeof(*info));
   info->hash = e->program_hash;
-  info->maxs = e->maxs; info->wbox = e->wbox; info->mbox = e->mbox; info->immediate = e->immediate();
+  info->maxs = e->maxs; info->wbox = e->wbox; info->mbox = e->mbox; info->immediate = e->exact_general();  // ("general builds only": nothing to specialise)
   info->filter_usable = e->filter_usable; info->filter_tol = e->filter_tol; info->nslots = e->nslots; info->nsave = e->nsave;
   info->spec_abi = MJPL_SPEC_ABI;
   const int32_t want_ip = (int32_t)e->ip.size(), want_tab = (int32_t)e->fp.size();
@@ -2195,6 +2212,7 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   out->filter_err_a = (float)e->ferr_a;
   out->filter_err_b = (float)e->ferr_b;
   out->filter_poisoned_geoms = e->npoisoned;
+  out->filter_interpreter = e->immediate() ? 2 : (e->filter_mbox() ? 1 : 0);
   out->filter_block_threads = e->immediate() ? kBlock : kFilterBlock;
   out->lds_bytes_filter = (int)lds_bytes(e, 1, sizeof(float), out->filter_block_threads, !e->immediate(),
                                          e->immediate() ? sizeof(double) : sizeof(float));

@@ -52,7 +52,7 @@ class Info(C.Structure):
         ("lds_bytes_filter", C.c_int32), ("filter_block_threads", C.c_int32),
         ("arch", C.c_char * 32),
         ("filter_max_coord", C.c_float), ("filter_err_a", C.c_float), ("filter_err_b", C.c_float),
-        ("filter_poisoned_geoms", C.c_int32),
+        ("filter_poisoned_geoms", C.c_int32), ("filter_interpreter", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

@@ -1,6 +1,8 @@
 """GPU parity over randomly generated models: every joint/geom/pair type the engine accepts,
 branching trees, off-centre hinges, margins, contype/conaffinity masks and allowed body pairs,
 each checked bit-exact (verdicts) / 1e-6 (FK) against the CPU oracle through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -71,7 +73,13 @@ def _fuzz_seeds():
 @pytest.mark.parametrize("seed", list(range(24)) + _fuzz_seeds())
 def test_random_models_match_oracle(oracle_mod, seed):
     model, allowed = random_model(seed % 1000 if seed >= 1000 else seed, moving_boxes=seed < 1000)
-    e = eng_mod.Engine(model, allowed)
+    # (every third model with moving boxes through the immediate interpreter, which only models
+    # with more than 24 stored geoms would get by themselves)
+    os.environ["MJPL_FORCE_IMMEDIATE"] = "1" if seed % 3 == 2 else "0"
+    try:
+        e = eng_mod.Engine(model, allowed)
+    finally:
+        os.environ.pop("MJPL_FORCE_IMMEDIATE", None)
     orc = oracle_mod.Oracle(model, allowed)
     Q = uniform_configs(model, 4096, seed=100 + seed)
     Q[::97] = model.qpos0  # exact reference pose: the angle == 0 shortcut of mju_axisAngle2Quat

@@ -143,25 +143,29 @@ def test_engine_close_destroys_its_pose_handles():
     assert mjpl.CollisionConstraint.__doc__.startswith("Batched collision validation")
 
 
+@pytest.mark.parametrize("immediate", [False, True])
 @pytest.mark.parametrize("allowed", [(), (("left_finger", "right_finger"),)])
-def test_franka_with_the_ten_finger_pad_boxes(oracle_mod, allowed):
+def test_franka_with_the_ten_finger_pad_boxes(oracle_mod, allowed, immediate):
     """The reference Panda carries ten pad boxes on its finger bodies (panda.xml:20-33,225-241):
-    moving boxes, 17 geoms held in the slot file at once.  Such models run the immediate
-    interpreter (general <32, true, true> build) with the lane-per-waypoint interior pass; verdicts
+    moving boxes, 17 geoms held in the slot file at once.  Such models run the queued interpreter's
+    24-slot build, box pairs through its box queue with full frames (and, forced here, the
+    immediate interpreter that models with more than 24 stored geoms get), with the
+    lane-per-waypoint interior pass; verdicts
     and first-bad indices must be the oracle's, filter on and off, fingers moving or not.
     Clipping the random edges to the joint ranges puts both fingers at exactly 0 in some rows, where
     opposite pads touch with a gap of +-1e-17: there the verdict hangs on the last bit of sin/cos, so
     the oracle runs with its bit-reproducible trig (see test_gpu_filter_adversarial.py)."""
-    with oracle_mod.portable_trig():
-        _finger_pads(oracle_mod, allowed)
+    with oracle_mod.portable_trig(), _Env(MJPL_FORCE_IMMEDIATE="1" if immediate else "0"):
+        _finger_pads(oracle_mod, allowed, immediate)
 
 
-def _finger_pads(oracle_mod, allowed):
+def _finger_pads(oracle_mod, allowed, immediate):
     m = scenes.franka_p(obstacles=True, pads=True)
     base = m.keyframe("home").qpos.copy()
     e = eng_mod.Engine(m, allowed)
     info = e.info()
     assert info["nmoving_geoms"] == 20 and info["filter_enabled"] == 1
+    assert info["filter_interpreter"] == (2 if immediate else 1)
     assert (info["nslots"] > 16) == (not allowed)  # pad-against-pad pairs keep the left pads in the slot file
     rng = np.random.default_rng(3)
     for joints in (scenes.FRANKA_ARM_JOINTS, scenes.FRANKA_ARM_JOINTS + ["finger_joint1", "finger_joint2"]):
