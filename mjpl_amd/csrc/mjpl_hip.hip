@@ -847,27 +847,36 @@ k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ g
 }
 
 
-// Partial nearest neighbour: block (x, y) scans node chunk y for 256 queries (two per thread, held
-// in registers; node tiles are staged through LDS and read as broadcasts: 14 float64 FMAs-worth
-// of work per 8-byte LDS read per pair of queries).  Distances are the same sequential-sum squared
-// norms as before; ties go to the lowest node index (strict `<`, chunks reduced in order).
-constexpr int kNNThreads = 128, kNNMaxPlan = 16;
+// Partial nearest neighbour: block (x, y) scans node chunk y for 512 queries (four per thread, held
+// in registers; node tiles are staged through LDS and read as broadcasts: 84 float64 operations
+// per 7 LDS reads for a 7-joint arm).  Distances are the same sequential-sum squared norms as on
+// the host (s = s + d * d, the product rounded on its own: numpy's norm of a row); ties go to the
+// lowest node index (strict `<`, chunks reduced in order).  NP: the number of planning columns
+// when it is one of the instantiated ones (registers and loops sized for it), 0 = any up to 16.
+constexpr int kNNThreads = 128, kNNMaxPlan = 16, kNNQueries = 4;
 
+template <int NP>
 __global__ void __launch_bounds__(kNNThreads)
 k_nearest_part(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
-               int64_t M, int nplan, int64_t chunk, int32_t *__restrict__ pidx, double *__restrict__ pd2) {
-  __shared__ double tile[kNNMaxPlan * kNNThreads];
+               int64_t M, int nplan_rt, int64_t chunk, int32_t *__restrict__ pidx, double *__restrict__ pd2) {
+  constexpr int W = NP ? NP : kNNMaxPlan;
+  const int nplan = NP ? NP : nplan_rt;
+  __shared__ double tile[W * kNNThreads];
   const int t = threadIdx.x;
-  const int64_t j0 = (int64_t)blockIdx.x * (2 * kNNThreads) + t, j1 = j0 + kNNThreads;
-  double qa[kNNMaxPlan], qb[kNNMaxPlan];
+  const int64_t j0 = (int64_t)blockIdx.x * (kNNQueries * kNNThreads) + t;
+  double q[kNNQueries][W];
 #pragma unroll
-  for (int c = 0; c < kNNMaxPlan; c++) {
-    qa[c] = (c < nplan && j0 < M) ? queries[(int64_t)c * M + j0] : 0.0;
-    qb[c] = (c < nplan && j1 < M) ? queries[(int64_t)c * M + j1] : 0.0;
-  }
+  for (int a = 0; a < kNNQueries; a++)
+#pragma unroll
+    for (int c = 0; c < W; c++) {
+      const int64_t j = j0 + (int64_t)a * kNNThreads;
+      q[a][c] = (c < nplan && j < M) ? queries[(int64_t)c * M + j] : 0.0;
+    }
   const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-  double besta = std::numeric_limits<double>::infinity(), bestb = besta;
-  int32_t ia = -1, ib = -1;
+  double best[kNNQueries];
+  int32_t bi[kNNQueries];
+#pragma unroll
+  for (int a = 0; a < kNNQueries; a++) { best[a] = std::numeric_limits<double>::infinity(); bi[a] = -1; }
   for (int64_t base = lo; base < hi; base += kNNThreads) {
     __syncthreads();
     const int64_t src = base + t;
@@ -875,22 +884,30 @@ k_nearest_part(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     __syncthreads();
     const int lim = (int)((hi - base) < kNNThreads ? (hi - base) : kNNThreads);
     for (int k = 0; k < lim; k++) {
-      double sa = 0, sb = 0;
+      double s[kNNQueries];
 #pragma unroll
-      for (int c = 0; c < kNNMaxPlan; c++) {
-        if (c < nplan) {
+      for (int a = 0; a < kNNQueries; a++) s[a] = 0;
+#pragma unroll
+      for (int c = 0; c < W; c++) {
+        if (NP || c < nplan) {
           const double v = tile[c * kNNThreads + k];
-          const double da = v - qa[c], db = v - qb[c];
-          sa = sa + da * da;
-          sb = sb + db * db;
+#pragma unroll
+          for (int a = 0; a < kNNQueries; a++) {
+            const double d = v - q[a][c];
+            s[a] = s[a] + d * d;
+          }
         }
       }
-      if (sa < besta) { besta = sa; ia = (int32_t)(base + k); }
-      if (sb < bestb) { bestb = sb; ib = (int32_t)(base + k); }
+#pragma unroll
+      for (int a = 0; a < kNNQueries; a++)
+        if (s[a] < best[a]) { best[a] = s[a]; bi[a] = (int32_t)(base + k); }
     }
   }
-  if (j0 < M) { pidx[(int64_t)blockIdx.y * M + j0] = ia; pd2[(int64_t)blockIdx.y * M + j0] = besta; }
-  if (j1 < M) { pidx[(int64_t)blockIdx.y * M + j1] = ib; pd2[(int64_t)blockIdx.y * M + j1] = bestb; }
+#pragma unroll
+  for (int a = 0; a < kNNQueries; a++) {
+    const int64_t j = j0 + (int64_t)a * kNNThreads;
+    if (j < M) { pidx[(int64_t)blockIdx.y * M + j] = bi[a]; pd2[(int64_t)blockIdx.y * M + j] = best[a]; }
+  }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -2269,10 +2286,14 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
   HIP_TRY(hipSetDevice(e->device));
   const int nplan = (int)e->qidx.size();
   if (nplan <= kNNMaxPlan && n > 0) {
-    // 2-D decomposition: 256 queries per block x node chunks, then a reduction over the chunks
-    const int64_t qtiles = (M + 2 * kNNThreads - 1) / (2 * kNNThreads);
-    int64_t nchunks = std::max<int64_t>(1, (1024 + qtiles - 1) / qtiles);
+    // 2-D decomposition: 512 queries per block x node chunks, then a reduction over the chunks;
+    // chunks sized for about eight two-wave blocks per SIMD quartet (the scan is one dependent
+    // chain per query: waves, not instructions, hide its latencies)
+    const int qblock = kNNQueries * kNNThreads;
+    const int64_t qtiles = (M + qblock - 1) / qblock;
+    int64_t nchunks = std::max<int64_t>(1, (8192 + qtiles - 1) / qtiles);
     nchunks = std::min<int64_t>(nchunks, (n + kNNThreads - 1) / kNNThreads);
+    nchunks = std::max<int64_t>(nchunks, 1);
     int64_t chunk = (n + nchunks - 1) / nchunks;
     chunk = (chunk + kNNThreads - 1) / kNNThreads * kNNThreads;
     nchunks = (n + chunk - 1) / chunk;
@@ -2285,8 +2306,20 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
     }
     double *pd2 = (double *)e->d_nn;
     int32_t *pidx = (int32_t *)(pd2 + (size_t)nchunks * (size_t)M);
-    hipLaunchKernelGGL(k_nearest_part, dim3((unsigned)qtiles, (unsigned)nchunks), dim3(kNNThreads), 0, e->stream,
-                       dnodes, n, cap, dqueries, M, nplan, chunk, pidx, pd2);
+    const dim3 grid((unsigned)qtiles, (unsigned)nchunks);
+#define MJPL_NN_CASE(NPV)                                                                                   \
+    case NPV:                                                                                               \
+      hipLaunchKernelGGL(k_nearest_part<NPV>, grid, dim3(kNNThreads), 0, e->stream, dnodes, n, cap, dqueries, \
+                         M, nplan, chunk, pidx, pd2);                                                       \
+      break;
+    switch (nplan) {
+      MJPL_NN_CASE(2) MJPL_NN_CASE(3) MJPL_NN_CASE(4) MJPL_NN_CASE(5) MJPL_NN_CASE(6) MJPL_NN_CASE(7)
+      MJPL_NN_CASE(8) MJPL_NN_CASE(9)
+      default:
+        hipLaunchKernelGGL(k_nearest_part<0>, grid, dim3(kNNThreads), 0, e->stream, dnodes, n, cap, dqueries, M,
+                           nplan, chunk, pidx, pd2);
+    }
+#undef MJPL_NN_CASE
     hipLaunchKernelGGL(k_nearest_reduce, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
                        pidx, pd2, M, (int)nchunks, dout_idx, dout_dist2);
     HIP_TRY(hipGetLastError());

@@ -102,11 +102,14 @@ class HipIKSolver(IKSolver):
                 sols = Q[good]
                 # distinct solutions, closest to the guess first (cartesian_planner.py:101-102 picks that one)
                 order = np.argsort(np.linalg.norm(sols - q0, axis=1), kind="stable")
-                out: list[np.ndarray] = []
-                for k in order:
-                    if not any(np.linalg.norm(sols[k] - s) < 1e-6 for s in out):
-                        out.append(sols[k].copy())
-                return out
+                sols = sols[order]
+                # greedy in that order: keep a solution unless an earlier KEPT one is within 1e-6
+                # (row-wise distances to the kept set, not one Python call per pair)
+                kept = np.zeros(len(sols), dtype=bool)
+                for k in range(len(sols)):
+                    if not kept[:k].any() or np.linalg.norm(sols[:k][kept[:k]] - sols[k], axis=1).min() >= 1e-6:
+                        kept[k] = True
+                return [q.copy() for q in sols[kept]]
         return []
 
 

@@ -215,7 +215,9 @@ class _PlannerBase:
         if solver is None:
             solver = self._default_solver()
         configs = [q for p in poses for q in solver.solve_ik(p, site, q_init_guess=q_init)]
-        configs = [q for q in configs if self._valid_ends(np.asarray(q, float)[None, self.qidx]).all()]
+        if configs:  # one batched validity check of all the ends
+            ok = self._valid_ends(np.asarray(configs, float)[:, self.qidx])
+            configs = [q for q, v in zip(configs, ok) if v]
         return [] if not configs else self.plan_to_configs(q_init, configs)
 
     def _default_solver(self):
