@@ -18,7 +18,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 3
+#define MJPL_SPEC_ABI 4
 #ifndef MJPL_MBOX_WAVES
 #define MJPL_MBOX_WAVES 1  // the 24-slot moving-box build: ~360 VGPRs; bound to two waves per SIMD it spills 200 dwords and is 4x slower
 #endif
@@ -205,6 +205,15 @@ struct ItemBuffers {
 };
 constexpr int kCounterStride = 32;    // ints between device counters: one 128-byte line each
 constexpr int kItemRegions = 32;
+// device counters of one launch: five scalars (edge-level undecided list, undecided pairs, edges whose
+// endpoint passed, unused, edges left to the walking kernel), the per-region item fills, the per-region
+// survivor counts.  The engine keeps two such sets and alternates: the first kernel of a launch clears
+// the set the NEXT launch will use (nobody touches it meanwhile), which saves a fill kernel per launch.
+constexpr int kNumCounters = 5 + 2 * kItemRegions;
+__device__ __forceinline__ void zero_counters(int *next) {
+  if (next && blockIdx.x == 0)
+    for (int k = threadIdx.x; k < kNumCounters * kCounterStride; k += blockDim.x) next[k] = 0;
+}
 constexpr int kExpandMinWaypoints = 24;  // kmax is at least this; small batches get more (item space / E)
 
 // One step of the recurrence: _step(w, QB, step)  (planning/utils.py:182-185; the statements of
@@ -382,9 +391,10 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
                    float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
                    int *__restrict__ status, int *__restrict__ ulist, int *__restrict__ ucount,
                    UndecidedConfigs uc, int *__restrict__ slist, int *__restrict__ scount, ItemBuffers ib,
-                   double step) {
+                   double step, int *__restrict__ zero_next) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
+  zero_counters(zero_next);
   const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
   // (immediate interpreter + item expansion: a second column set holds the walking waypoint)
   // queued interpreter: binary32 columns for the check (what goes to the exact re-check is read
@@ -508,9 +518,10 @@ __global__ void __launch_bounds__(kBlock, (kMinWaves<Spec, MAXS>))
 k_filter_configs(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
                  const double *__restrict__ Q, int64_t N, int layout, float tol,
                  uint8_t *__restrict__ valid, int *__restrict__ ulist, int *__restrict__ ucount,
-                 UndecidedConfigs uc) {
+                 UndecidedConfigs uc, int *__restrict__ zero_next) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
+  zero_counters(zero_next);
   const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
   constexpr bool kQ = kQueued<float, MAXS>;
   typedef typename std::conditional<kQ, float, double>::type QT;  // (see k_filter_endpoints)

@@ -34,7 +34,7 @@ using namespace mjpl;
 
 constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
 constexpr int kCtr = kCounterStride;  // ints between device counters: one 128-byte line each
-constexpr int kNumCtr = 5 + 2 * kItemRegions;  // (see engine_alloc: five scalars, per-region item fills and survivor counts)
+constexpr int kNumCtr = kNumCounters;
 
 thread_local std::string g_err;
 
@@ -297,7 +297,8 @@ k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ g
                int layout, int flags, float tol, uint8_t *__restrict__ valid,
                int32_t *__restrict__ first_bad, int *__restrict__ status, int *__restrict__ ulist,
                int *__restrict__ ucount, UndecidedConfigs uc, const int *__restrict__ rlist,
-               const int *__restrict__ rcount) {
+               const int *__restrict__ rcount, int *__restrict__ zero_next) {
+  zero_counters(zero_next);  // (only when this is the first kernel of the launch: one-pass mode)
   edge_body<float, MAXS, WBOX, MBOX>(gip, nip, gfp, nfp, QA, QB, E, step, layout, flags, tol, valid,
                                      first_bad, status, ulist, ucount, rlist, rcount, uc);
 }
@@ -945,10 +946,10 @@ std::vector<T> copy_n(const T *p, size_t n) {
 // entry points of a per-model specialised library (see load_spec)
 struct SpecLib {
   typedef int (*ConfigsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, const double *,
-                           int64_t, int, float, uint8_t *, int *, int *, UndecidedConfigs);
+                           int64_t, int, float, uint8_t *, int *, int *, UndecidedConfigs, int *);
   typedef int (*EndpointsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, const double *,
                              const double *, int64_t, int, float, uint8_t *, int32_t *, int *, int *, int *, UndecidedConfigs,
-                             int *, int *, ItemBuffers, double);
+                             int *, int *, ItemBuffers, double, int *);
   typedef int (*ItemsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, ItemBuffers, EdgeSource, float,
                          uint8_t *, int32_t *, int *, int *, UndecidedConfigs);
   void *lib = nullptr;
@@ -987,6 +988,8 @@ struct mjpl_engine {
   uint64_t program_hash = 0;      // FNV-1a of the compiled tables (ip, fp) and the kernel variant
   const SpecLib *spec = nullptr;  // this model's own filter kernels, if a library for program_hash was found
   int *d_ulist = nullptr;   // items (configurations / whole edges) the filter left undecided
+  int *d_ucount_base = nullptr;  // both counter sets; d_ucount = the one the last launch used
+  bool counters_stale = false;
   int *d_ucount = nullptr;  // [0] how many of those, [1] undecided waypoints of edges, [2] edges in d_slist
   int *d_slist = nullptr;   // two-pass edge filter: edges whose endpoint passed
   size_t slist_cap = 0;
@@ -1659,7 +1662,10 @@ int ulist_reserve(mjpl_engine *e, int64_t n) {
     //   [0] edge-level undecided list, [kCtr] undecided pairs, [2 kCtr] edges whose endpoint passed,
     //   [3 kCtr] (unused), [4 kCtr] edges left to the walking kernel,
     //   [5 kCtr ..] waypoint items per region, then edges whose endpoint passed per region
-    HIP_TRY(hipMalloc(&e->d_ucount, kNumCtr * kCtr * sizeof(int)));
+    // two sets, used alternately (next_counters): the first kernel of a launch clears the other one
+    HIP_TRY(hipMalloc(&e->d_ucount_base, 2 * kNumCtr * kCtr * sizeof(int)));
+    HIP_TRY(hipMemset(e->d_ucount_base, 0, 2 * kNumCtr * kCtr * sizeof(int)));
+    e->d_ucount = e->d_ucount_base;
     e->d_icount = e->d_ucount + 3 * kCtr;
   }
   if ((size_t)n > e->ulist_cap) {
@@ -1689,6 +1695,19 @@ int allow_lds(K kernel, size_t bytes) {
   return MJPL_OK;
 }
 
+// A filter launch takes the cleared counter set and returns the other one, which its first kernel is
+// to clear for the launch after it.
+int *next_counters(mjpl_engine *e) {
+  if (e->counters_stale) {  // a launch failed between taking its set and its first kernel
+    (void)hipMemsetAsync(e->d_ucount_base, 0, 2 * (size_t)kNumCtr * kCtr * sizeof(int), e->stream);
+    e->counters_stale = false;
+  }
+  int *other = e->d_ucount;
+  e->d_ucount = (e->d_ucount == e->d_ucount_base) ? e->d_ucount_base + (size_t)kNumCtr * kCtr : e->d_ucount_base;
+  e->d_icount = e->d_ucount + 3 * kCtr;
+  return other;
+}
+
 // pick the <MAXS, WBOX, MBOX> instantiation of the EXACT kernels for this model
 template <class F>
 int dispatch_variant(const mjpl_engine *e, F &&f) {
@@ -1713,6 +1732,12 @@ int dispatch_filter(const mjpl_engine *e, F &&f) {
   return dispatch_variant(e, f);
 }
 
+struct CounterGuard {  // marks the counter sets for a full clear unless the launch got through
+  mjpl_engine *e;
+  bool armed;
+  ~CounterGuard() { if (armed) e->counters_stale = true; }
+};
+
 int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint8_t *dvalid,
                    unsigned long long *dbits) {
   if (N == 0) return MJPL_OK;
@@ -1720,6 +1745,9 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
   const bool filter = e->filter && e->filter_usable && dvalid && !dbits && N < (int64_t)1 << 30;
   if (filter) {
     int rc = ulist_reserve(e, N);
+    if (rc != MJPL_OK) return rc;
+    int *zero_next = next_counters(e);
+    CounterGuard guard{e, true};
     UndecidedConfigs uc = {};
     if (rc == MJPL_OK) {  // (both interpreters hand single undecided pairs over)
       rc = uc_reserve(e, N);
@@ -1729,14 +1757,13 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
       uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
     }
     if (rc != MJPL_OK) return rc;
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, kNumCtr * kCtr * sizeof(int), e->stream));
     const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
     // (queued interpreter: binary32 columns)
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate(), e->immediate() ? sizeof(double) : sizeof(float));
     if (e->spec)
       rc = e->spec->configs(e->stream, fgrid, (unsigned)fblock, ldsf, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQ, N,
-                            layout, e->filter_tol, dvalid, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
+                            layout, e->filter_tol, dvalid, e->d_ulist, e->d_ucount, uc, zero_next) == 0 ? MJPL_OK
            : fail(MJPL_E_HIP, "specialised configuration kernel failed to launch");
     else rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_configs<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
@@ -1744,10 +1771,11 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
       if (r != MJPL_OK) return r;
       hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                          e->d_fp, (int)e->fp.size(), dQ, N, layout, e->filter_tol, dvalid, e->d_ulist,
-                         e->d_ucount, uc);
+                         e->d_ucount, uc, zero_next);
       return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
+    guard.armed = false;
     if (uc.count) {  // exact re-check of the undecided pairs; rows here are planning columns, AoS
       const size_t ldsc = lds_bytes(e, 1);
       const unsigned pgrid = (unsigned)std::min<size_t>((uc.cap + kBlock - 1) / kBlock, 1024);
@@ -1790,12 +1818,13 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     int rc = ulist_reserve(e, E);
     if (rc == MJPL_OK) rc = uc_reserve(e, E);
     if (rc != MJPL_OK) return rc;
+    int *zero_next = next_counters(e);  // (this launch's own set was cleared by the launch before it)
+    CounterGuard guard{e, true};
     uc.q = e->d_ucq; uc.edge = e->d_ucedge; uc.idx = e->d_ucidx;
     uc.ga = e->d_ucga; uc.gb = e->d_ucgb;
     uc.count = e->d_ucount + kCtr;
     uc.cap = (int)std::min<size_t>(e->uc_cap, (size_t)1 << 30);
     MJPL_MARK(0);
-    HIP_TRY(hipMemsetAsync(e->d_ucount, 0, kNumCtr * kCtr * sizeof(int), e->stream));
     const int fblock = e->immediate() ? kBlock : kFilterBlock;
     const unsigned fgrid = (unsigned)((E + fblock - 1) / fblock);
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate());  // walking kernel: float64 columns
@@ -1868,7 +1897,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       if (e->spec)
         rc = e->spec->endpoints(e->stream, fgrid, (unsigned)fblock, ldse, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQA,
                                 dQB, E, layout, e->filter_tol, dvalid, dfb, e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist,
-                                e->d_ucount + 2 * kCtr, ib, step) == 0 ? MJPL_OK
+                                e->d_ucount + 2 * kCtr, ib, step, zero_next) == 0 ? MJPL_OK
              : fail(MJPL_E_HIP, "specialised endpoint kernel failed to launch");
       else rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
         auto kern = k_filter_endpoints<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
@@ -1876,10 +1905,12 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         if (r != MJPL_OK) return r;
         hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldse, e->stream, e->d_ip, (int)e->ip.size(),
                            e->d_fp, (int)e->fp.size(), dQA, dQB, E, layout, e->filter_tol, dvalid, dfb,
-                           e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist, e->d_ucount + 2 * kCtr, ib, step);
+                           e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist, e->d_ucount + 2 * kCtr, ib, step,
+                           zero_next);
         return MJPL_OK;
       });
       if (rc != MJPL_OK) return rc;
+      guard.armed = false;
     }
     MJPL_MARK(1);  // after k_filter_endpoints (nothing ran yet in a one-pass launch)
     if (expand) {
@@ -1910,10 +1941,12 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       hipLaunchKernelGGL(kern, dim3(fgrid), dim3(fblock), ldsf, e->stream, e->d_ip, (int)e->ip.size(),
                          e->d_fp, (int)e->fp.size(), dQA, dQB, E, step, layout,
                          two_pass ? (flags | MJPL_EDGE_INTERIOR_ONLY) : flags, e->filter_tol, dvalid,
-                         dfb, e->d_status, e->d_ulist, e->d_ucount, uc, rlist, rcount);
+                         dfb, e->d_status, e->d_ulist, e->d_ucount, uc, rlist, rcount,
+                         two_pass ? (int *)nullptr : zero_next);
       return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
+    guard.armed = false;
     MJPL_MARK(3);  // after k_filter_edges (the walking kernel)
     // undecided waypoints: exact configuration kernel in patch mode (grid sized for a generous
     // share of the batch; surplus blocks return at once)
@@ -2087,7 +2120,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_dp) (void)hipFree(e->d_dp);
   if (e->d_fp) (void)hipFree(e->d_fp);
   if (e->d_ulist) (void)hipFree(e->d_ulist);
-  if (e->d_ucount) (void)hipFree(e->d_ucount);
+  if (e->d_ucount_base) (void)hipFree(e->d_ucount_base);
   if (e->d_slist) (void)hipFree(e->d_slist);
   if (e->d_ucga) (void)hipFree(e->d_ucga);
   if (e->d_ucgb) (void)hipFree(e->d_ucgb);

@@ -487,15 +487,16 @@ int mjpl_spec_abi(void) { return MJPL_SPEC_ABI; }
 unsigned long long mjpl_spec_hash(void) { return 0x%(hash)016xull; }
 int mjpl_spec_launch_configs(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
                              int nfp, const double *Q, int64_t N, int layout, float tol, uint8_t *valid, int *ulist, int *ucount,
-                             UndecidedConfigs uc) {
-  SPEC_LAUNCH((k_filter_configs<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, Q, N, layout, tol, valid, ulist, ucount, uc);
+                             UndecidedConfigs uc, int *zero_next) {
+  SPEC_LAUNCH((k_filter_configs<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, Q, N, layout, tol, valid, ulist, ucount, uc,
+              zero_next);
 }
 int mjpl_spec_launch_endpoints(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
                                int nfp, const double *QA, const double *QB, int64_t E, int layout, float tol, uint8_t *valid,
                                int32_t *first_bad, int *status, int *ulist, int *ucount, UndecidedConfigs uc, int *slist,
-                               int *scount, ItemBuffers ib, double step) {
+                               int *scount, ItemBuffers ib, double step, int *zero_next) {
   SPEC_LAUNCH((k_filter_endpoints<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, QA, QB, E, layout, tol, valid, first_bad, status,
-              ulist, ucount, uc, slist, scount, ib, step);
+              ulist, ucount, uc, slist, scount, ib, step, zero_next);
 }
 int mjpl_spec_launch_items(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
                            int nfp, ItemBuffers ib, EdgeSource src, float tol, uint8_t *valid, int32_t *first_bad, int *ulist, int *ucount,
