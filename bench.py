@@ -280,6 +280,64 @@ def bench_next_rows(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_rrt(args):
+    """One GPU's share of BASELINE configs[3] as the planner runs it (not the headline): rounds of
+    `mjpl_rrt_round` -- sample, nearest, extend with projection, validate, connect, exchange over a
+    one-rank RCCL communicator -- with 131 072 lanes.  A step is one round; round 1 (empty trees)
+    is the warm-up.  The path any round reports is checked against the oracle."""
+    import mjpl_amd as mjpl
+    from mjpl_amd import engine as eng_mod
+    from mjpl_amd import scenes
+    from oracle import pyoracle
+    L = 131072
+    rounds = args.steps if args.steps != 2000 else 5
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    cc = mjpl.CollisionConstraint(m)
+    frame = mjpl.site_pose(m, q_init, "ee_site", engine=cc.engine)
+    pc = mjpl.PoseConstraint(m, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), engine=cc.engine)
+    cons = [pc, mjpl.JointLimitConstraint(m), cc]
+    pc.q_step = np.inf
+    q_goal = mjpl.random_config(m, q_init, joints, 7, cons)
+    pc.q_step = 0.05
+    dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=3, goal_biasing_probability=0.05,
+                           batch=L, capacity=1 << 24, pose=pc, comm=(eng_mod.comm_unique_id(), 0, 1))
+    dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 3)
+    info = dev.rrt.round()  # warm-up: the first round grows from two single-node trees
+    rows, new_nodes = [], 0
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        t1 = time.perf_counter()
+        info = dev.rrt.round()
+        rows.append((time.perf_counter() - t1) * 1e3)
+        new_nodes += int(info.new_nodes[0]) + int(info.new_nodes[1])
+    elapsed = time.perf_counter() - t0
+    path_ok = None
+    if info.connected:
+        path = dev.rrt.path()
+        full = np.repeat(q_init[None, :], len(path), axis=0)
+        full[:, qidx] = path
+        orc = pyoracle.Oracle(m, planning_qidx=qidx, qpos_base=q_init)
+        ok_edges = orc.valid_edges(path[:-1], path[1:], 0.01, nthreads=8)
+        path_ok = bool(ok_edges.all() and np.all(pc.valid_configs(full)))
+        if not path_ok:
+            raise SystemExit("bench: the planner's path fails the oracle's collision check / the pose constraint")
+    print(json.dumps({
+        "metric": "RRT samples/sec through the frontier bi-RRT, one GPU's share of BASELINE configs[3]",
+        "value": L * rounds / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": rounds, "warmup": 1,
+        "ms_per_step": elapsed / rounds * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 planner + f32-filter+f64-exact validation", "data": "synthetic",
+        "config": {"workload": f"{L} lanes per round, [PoseConstraint(roll, pitch +-0.1), JointLimit, Collision], "
+                               "eps 0.05, interval 0.01, Franka-P + 16 obstacles, one-rank RCCL exchange per round",
+                   "round_ms": rows, "new_nodes_per_s": new_nodes / elapsed,
+                   "nodes": [int(info.nodes[0]), int(info.nodes[1])], "connected": bool(info.connected),
+                   "path_checked_against_oracle": path_ok}}))
+    dev.rrt.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,16 +347,21 @@ def main():
     ap.add_argument("--edges", type=int, default=EDGES_PER_GPU)
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["edges", "configs", "pose", "ik"], default="edges",
+    ap.add_argument("--workload", choices=["edges", "configs", "pose", "ik", "rrt"], default="edges",
                     help="edges: the headline metric (BASELINE configs[2]).  Extra lines, not the headline: "
                          "configs = configs[1], 65 536 Franka-P self-collision configurations per launch; "
                          "pose = one GPU's share of configs[3], 131 072 PoseConstraint projections; "
-                         "ik = one GPU's share of configs[4], 16 384 IK seeds -> FK -> collision filter")
+                         "ik = one GPU's share of configs[4], 16 384 IK seeds -> FK -> collision filter; "
+                         "rrt = one GPU's share of configs[3] as the planner runs it: rounds of the device-resident "
+                         "frontier bi-RRT, 131 072 samples each, [PoseConstraint, JointLimit, Collision], through a "
+                         "one-rank RCCL communicator (--steps = timed rounds, default 5)")
     args = ap.parse_args()
     if args.workload == "configs":
         return bench_configs(args)
     if args.workload in ("pose", "ik"):
         return bench_next_rows(args)
+    if args.workload == "rrt":
+        return bench_rrt(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
