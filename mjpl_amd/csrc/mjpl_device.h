@@ -1427,11 +1427,9 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
           const int item = (int)((unsigned)wq.flags[owner] >> 2);
           const int ed = ps.item_edge ? ps.item_edge[item] : item;
           const int ix = ps.item_idx ? ps.item_idx[item] : ps.idx;
-          if (ps.src.QA) {  // row `ed` of the caller's configurations (ix = 0), or waypoint ix of edge `ed`
-#ifndef MJPL_X_NOREGEN
+          if (ps.src.QA)  // row `ed` of the caller's configurations (ix = 0), or waypoint ix of edge `ed`
             exact_waypoint(ps.src, ps.perm, ps.nplan, ed, ix, ps.uc.q + (size_t)u * ps.nplan, ps.item_idx ? item : -1);
-#endif
-          } else
+          else
             for (int k = 0; k < ps.nplan; k++) ps.uc.q[(size_t)u * ps.nplan + k] = ps.qcol[k * ps.B + owner * ps.L];
           ps.uc.edge[u] = ed;
           ps.uc.idx[u] = ix;

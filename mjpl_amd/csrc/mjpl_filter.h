@@ -340,13 +340,8 @@ __device__ __forceinline__ void emit_items(const int *__restrict__ gip, const do
   const int total = __shfl(incl, 63);
   if (total == 0) return;
   int base = 0;
-#ifdef MJPL_X_NOATOMIC  // timing-only build: no reservation (slots collide, the count stays 0)
-  const int region = 0;
-  base = (int)(((blockIdx.x * 4u + (threadIdx.x >> 6)) * 320u) % (unsigned)(ib.regcap - 2000));
-#else
   const int region = (int)(blockIdx.x % (unsigned)ib.regions);
   if (lane == 0) base = atomicAdd(ib.count + region * kCounterStride, total);
-#endif
   base = __builtin_amdgcn_readfirstlane(base);
   const int rel = base + incl - K, first = region * ib.regcap + rel;
   if (!done && rel + K > ib.regcap) {  // out of item space: the walking kernel takes the edge
