@@ -16,6 +16,9 @@ def main():
     m = scenes.franka_p(obstacles=True)
     arm = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
     base = m.keyframe("home").qpos.copy()
+    if sys.argv[1:] == ["--path"]:  # where the real library lives (no compilation: usable on the GPU box)
+        print(specialise.spec_path(specialise.dump_program(m, (), arm, base)[3].hash))
+        return
     print(specialise.build(m, (), arm, base, force=not sys.argv[1:]))
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
     for name in sys.argv[1:]:

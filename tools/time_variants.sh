@@ -3,7 +3,7 @@
 # with -DMJPL_X_<NAME>): swaps each in for the real library, runs bench.py, restores the original.
 # usage (GPU box): tools/time_variants.sh NAME...     -> gpurun_out/variant_<NAME>.json
 set -u
-LIB=$(ls mjpl_amd/csrc/spec/libmjpl_spec_acd305195974dc93.so)
+LIB=$(python tools/build_bench_spec.py --path)
 cp "$LIB" /tmp/spec_orig.so
 python bench.py --steps 500 --no-cpu-baseline > gpurun_out/variant_REAL.json 2> gpurun_out/variant_REAL.err
 for v in "$@"; do
