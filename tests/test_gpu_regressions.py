@@ -254,3 +254,24 @@ def test_long_edges_rebuild_undecided_waypoints_from_checkpoints(oracle_mod):
         np.testing.assert_array_equal(gfb, wfb)
         assert e.last_items() > 40 * E and e.last_undecided() > 0
     e.close()
+
+
+@pytest.mark.parametrize("cap", ["3000", "40000"])
+def test_item_regions_overflow_to_the_walking_kernel(oracle_mod, cap):
+    """The item space is split into regions with their own fill counters; an edge whose items do not
+    fit its workgroup's region goes to the walking kernel, and the slots it had reserved are void.
+    With a small item space several regions overflow at once."""
+    m = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    with _Env(MJPL_ITEM_CAP=cap):
+        e = eng_mod.Engine(m)
+    e.set_planning(qidx, base)
+    qa, qb = random_edges(m, qidx, 20000, seed=11, eps=0.08)
+    want, wfb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
+    got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(gfb, wfb)
+    assert e.last_items() > int(cap)  # more was reserved than fits: the surplus took the walking kernel
+    e.close()
