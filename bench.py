@@ -165,7 +165,7 @@ def bench_configs(args):
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         orc = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
-        cores = os.cpu_count() or 1
+        cores = host_cpu()[1]  # (the cores this process may use: cgroup quota, affinity)
         t0 = time.perf_counter()
         v = orc.valid_configs(Q, nthreads=cores)
         dt = time.perf_counter() - t0
@@ -216,7 +216,7 @@ def bench_next_rows(args):
         po = pyoracle.PoseOracle(model, "ee_site", (inv.wxyz_xyz[:4], inv.wxyz_xyz[4:]),
                                  [(-np.inf, np.inf)] * 3 + [(-0.1, 0.1)] * 2 + [(-np.inf, np.inf)], q_step=0.5)
         k = 8192
-        cores = os.cpu_count() or 1
+        cores = host_cpu()[1]
         t0 = time.perf_counter()
         ref, rok, rit = po.apply_batch(Q_old[:k], Q[:k], nthreads=cores)
         dtc = time.perf_counter() - t0
@@ -230,7 +230,7 @@ def bench_next_rows(args):
                    roofline={"bound": "hbm", "achieved": n * (2 * 8 * model.nq + 8 * model.nq + 1) * args.steps / elapsed / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": n * (3 * 8 * model.nq + 1) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "note": "FP64 issue bound (6x6 Jacobi eigen-decomposition per projection step)"},
+                             "note": "FP64 issue / latency bound (FK + Jacobian + a certified 6x6 Cholesky solve per projection step; eigen-decomposition only near singularities)"},
                    cpu_baseline={"value": k / dtc, "unit": "rows/s", "cores": cores, "kind": "port",
                                  "sample": f"first {k} rows, {cores} pthreads"})
     else:

@@ -343,6 +343,8 @@ k_nearest(const double *__restrict__ nodes, int64_t n, int64_t cap, const double
 // world axis/anchor after FK and is overwritten in place by the RPY-Jacobian columns.
 constexpr int kPoseBlock = 64;
 
+constexpr double kPoseMaxCond = 1e6;  // (see k_pose_apply: fast path of the 6x6 pseudo-inverse)
+
 __global__ void __launch_bounds__(kPoseBlock)
 k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
              const double *__restrict__ Q, int64_t N, double *__restrict__ Qout,
@@ -414,8 +416,16 @@ k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const do
               for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
           }
         }
+        // pinv(J J^T) dx (pose_constraint.py:164-171).  Away from kinematic singularities J J^T is
+        // positive definite and modestly conditioned: its inverse by a certified Cholesky solve is
+        // pinv's result to ~cond * 2^-53 (<= 1e-10 relative here) at a hundredth of the
+        // eigen-decomposition's latency; anything the certificate refuses takes the eigen path,
+        // where pinv's singular-value cut-off decides.
         double y[6];
-        pinv_sym6_apply(A, dx, y);
+        const bool fast = spd6_solve_certified(A, dx, y, kPoseMaxCond);
+        if (__ballot(!fast) != 0ull) {
+          if (!fast) pinv_sym6_apply(A, dx, y);
+        }
         ic = PH_SIZE; jk = 0;
         for (int b = 0; b < pi[PH_NBODY]; b++) {
           const int njnt = pi[ic++];

@@ -271,6 +271,69 @@ __device__ __forceinline__ void chol6_solve(double (&A)[6][6], const double *b, 
   }
 }
 
+// y = A^-1 b for a symmetric positive definite, well-conditioned 6x6: Cholesky factor L, its inverse
+// M (so that A^-1 = M^T M), and the certificate  cond_2(A) <= tr(A) tr(A^-1) = tr(A) ||M||_F^2.
+// Returns false -- y untouched, A intact -- unless that bound is below `max_cond`: then the caller
+// takes the eigen-decomposition (np.linalg.pinv's cut-off semantics matter only there).  For a
+// matrix that passes, A^-1 b and pinv(A) b are the same vector up to cond * 2^-53 relative.
+__device__ __forceinline__ bool spd6_solve_certified(const double (&A)[6][6], const double *b, double *y,
+                                                     double max_cond) {
+  double L[6][6], M[6][6];
+  bool good = true;
+  double tr = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    tr = tr + A[j][j];
+    double d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d = d - L[j][k] * L[j][k];
+    good = good && (d > 0.0);  // (also false for NaN)
+    d = sqrt(good ? d : 1.0);
+    L[j][j] = d;
+    const double inv = 1 / d;
+    M[j][j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v = v - L[i][k] * L[j][k];
+      L[i][j] = v * inv;
+    }
+  }
+  // M = L^-1 (lower triangular), column by column
+  double fro = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double v = 0;
+#pragma unroll
+      for (int k = j; k < i; k++) v = v - L[i][k] * M[k][j];
+      M[i][j] = v * M[i][i];
+    }
+#pragma unroll
+    for (int i = j; i < 6; i++) fro = fro + M[i][j] * M[i][j];
+  }
+  good = good && (tr * fro <= max_cond);
+  if (!good) return false;
+  double z[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double v = 0;
+#pragma unroll
+    for (int k = 0; k <= i; k++) v = v + M[i][k] * b[k];
+    z[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double v = 0;
+#pragma unroll
+    for (int k = i; k < 6; k++) v = v + M[k][i] * z[k];
+    y[i] = v;
+  }
+  return true;
+}
+
 // world-frame pose error of the site against the target: e[0..2] = p_t - p,
 // e[3..5] = rotation vector of R_t R^T (quaternion logarithm, shortest way round)
 __device__ __forceinline__ void ik_error(const double *tail, const PoseChainOut &o, double *e) {
