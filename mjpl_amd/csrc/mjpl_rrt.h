@@ -97,8 +97,9 @@ k_rrt_sample(int L, int nplan, uint64_t key, double pgoal, int grow, int ngoal, 
 // extension start: C = node nearest to the target, lane on unless it duplicates a lower biased lane
 __global__ void __launch_bounds__(256)
 k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLanes ln, const int32_t *__restrict__ first,
-            const double *__restrict__ Tgt, int second) {
+            const double *__restrict__ Tgt, int second, int *__restrict__ ctr) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l == 0) { ctr[RC_EDGES] = 0; ctr[RC_ACTIVE] = 0; ctr[RC_ACC] = 0; }  // for the extension's first chunk
   if (l >= L) return;
   bool on;
   if (!second) {
@@ -268,6 +269,8 @@ k_rrt_after_pose(int E, int L, int nplan, int nq, const int *__restrict__ qidx, 
 __global__ void __launch_bounds__(256)
 k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restrict__ ctr) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  // (the host has read this chunk's counts: clear them for the next k_rrt_gen instead of two fills)
+  if (l == 0) { ctr[RC_EDGES] = 0; ctr[RC_ACTIVE] = 0; }
   if (l >= L || !ln.act[l]) return;
   const int n = ln.gcount[l];
   if (n == 0) return;  // waiting for candidate space
@@ -461,6 +464,10 @@ struct mjpl_rrt {
   double *d_F[3] = {nullptr, nullptr, nullptr};  // full-row buffers of the projection
   uint8_t *d_pok = nullptr;
   int *d_ctr = nullptr, *h_ctr = nullptr;
+  // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned
+  // copies and the events that say when each has landed
+  int *h_ring = nullptr;
+  hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // exchange
   int *d_heads = nullptr, *h_heads = nullptr;
   char *d_gather = nullptr;
@@ -498,16 +505,30 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   int rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, Tgt, L, r->ln.near, nullptr);
   if (rc != MJPL_OK) return rc;
   hipLaunchKernelGGL(k_rrt_begin, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->d_Q[t], r->cap, r->ln, r->d_first, Tgt,
-                     second);
-  HIP_TRY(hipMemsetAsync(r->d_ctr + RC_ACC, 0, sizeof(int), st));
+                     second, r->d_ctr);
   const bool projecting = r->pose != nullptr;
   int S = projecting ? 1 : 4;
-  for (;;) {
-    HIP_TRY(hipMemsetAsync(r->d_ctr + RC_EDGES, 0, sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(r->d_ctr + RC_ACTIVE, 0, sizeof(int), st));
+  // With a projecting constraint an extension is hundreds of one-step chunks, the late ones with a
+  // handful of lanes: waiting for every chunk's counters before sizing its launches leaves the GPU
+  // idle while the host enqueues the next dozen kernels.  Lanes only ever leave an extension (every
+  // active lane emits one candidate per chunk when the buffer holds a candidate per lane), so the
+  // count of two chunks ago is an upper bound: chunk i is sized by it -- the surplus rows are the
+  // previous chunks' candidates, validated again and read by nobody -- and the loop ends two chunks
+  // after the last lane has.
+  const bool pipelined = projecting && r->cd.cap >= L;
+  for (int chunk = 0;; chunk++) {
     hipLaunchKernelGGL(k_rrt_gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, projecting ? 1 : 0, r->d_lo, r->d_hi,
                        Tgt, r->ln, r->cd, r->d_ctr);
-    if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
+    if (pipelined) {
+      const int slot = chunk % 4;
+      HIP_TRY(hipMemcpyAsync(r->h_ring + slot * RC_SIZE, r->d_ctr, RC_SIZE * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(r->ring_ev[slot], st));
+      const int look = (chunk < 2 ? chunk : chunk - 2) % 4;  // (the first two chunks: their own counts)
+      HIP_TRY(hipEventSynchronize(r->ring_ev[look]));
+      memcpy(r->h_ctr, r->h_ring + look * RC_SIZE, RC_SIZE * sizeof(int));
+    } else if ((rc = rrt_read_ctr(r)) != MJPL_OK) {
+      return rc;
+    }
     const int E = r->h_ctr[RC_EDGES];
     if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
     if (E == 0) {
@@ -619,6 +640,9 @@ void mjpl_rrt_destroy(mjpl_rrt *r) {
   (void)hipStreamSynchronize(r->e->stream);
   for (void *p : r->owned) (void)hipFree(p);
   if (r->h_ctr) (void)hipHostFree(r->h_ctr);
+  if (r->h_ring) (void)hipHostFree(r->h_ring);
+  for (hipEvent_t ev : r->ring_ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (r->h_heads) (void)hipHostFree(r->h_heads);
   if (r->d_gather) (void)hipFree(r->d_gather);
   delete r;
@@ -668,6 +692,8 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   RA(r->d_first, 1);  // re-allocated by reset for the number of goals
 #undef RA
   HIP_TRY(hipHostMalloc((void **)&r->h_ctr, RC_SIZE * sizeof(int)));
+  HIP_TRY(hipHostMalloc((void **)&r->h_ring, 4 * RC_SIZE * sizeof(int)));
+  for (hipEvent_t &ev : r->ring_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void **)&r->h_heads, 8 * 1024 * sizeof(int)));
   std::vector<uint8_t> isplan(r->nq, 0);
   for (int c : e->qidx) isplan[c] = 1;
