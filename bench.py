@@ -280,6 +280,16 @@ def bench_next_rows(args):
     print(json.dumps(out), flush=True)
 
 
+def _flush_c_stdio():
+    """librccl writes its version banner through C stdio, which is flushed at exit -- after Python's
+    own output -- unless it is flushed here: the JSON line is to be the last line of stdout."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+
+
 def bench_rrt(args):
     """One GPU's share of BASELINE configs[3] as the planner runs it (not the headline): rounds of
     `mjpl_rrt_round` -- sample, nearest, extend with projection, validate, connect, exchange over a
@@ -324,6 +334,7 @@ def bench_rrt(args):
         path_ok = bool(ok_edges.all() and np.all(pc.valid_configs(full)))
         if not path_ok:
             raise SystemExit("bench: the planner's path fails the oracle's collision check / the pose constraint")
+    _flush_c_stdio()
     print(json.dumps({
         "metric": "RRT samples/sec through the frontier bi-RRT, one GPU's share of BASELINE configs[3]",
         "value": L * rounds / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": rounds, "warmup": 1,
@@ -493,6 +504,7 @@ def main():
                 sys.exit("bench.py: GPU verdicts differ from the CPU oracle on the baseline sample")
         else:
             out["cpu_baseline"] = None
+        _flush_c_stdio()
         print(json.dumps(out), flush=True)
 
     if dist is not None:
