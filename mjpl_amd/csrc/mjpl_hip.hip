@@ -869,7 +869,8 @@ constexpr int kNNThreads = 128, kNNMaxPlan = 16, kNNQueries = 4;
 template <int NP>
 __global__ void __launch_bounds__(kNNThreads)
 k_nearest_part(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
-               int64_t M, int nplan_rt, int64_t chunk, int32_t *__restrict__ pidx, double *__restrict__ pd2) {
+               int64_t M, int nplan_rt, int64_t chunk, int32_t *__restrict__ pidx, double *__restrict__ pd2,
+               int64_t stride = 1) {  // (stride > 1: every stride-th node only -- a sample; indices are sample indices)
   constexpr int W = NP ? NP : kNNMaxPlan;
   const int nplan = NP ? NP : nplan_rt;
   __shared__ double tile[W * kNNThreads];
@@ -891,7 +892,7 @@ k_nearest_part(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
   for (int64_t base = lo; base < hi; base += kNNThreads) {
     __syncthreads();
     const int64_t src = base + t;
-    for (int c = 0; c < nplan; c++) tile[c * kNNThreads + t] = (src < hi) ? nodes[(int64_t)c * cap + src] : 0.0;
+    for (int c = 0; c < nplan; c++) tile[c * kNNThreads + t] = (src < hi) ? nodes[(int64_t)c * cap + src * stride] : 0.0;
     __syncthreads();
     const int lim = (int)((hi - base) < kNNThreads ? (hi - base) : kNNThreads);
     for (int k = 0; k < lim; k++) {
@@ -921,13 +922,160 @@ k_nearest_part(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
   }
 }
 
+// The same partial scan with a binary32 screen in front of the float64 arithmetic (large trees and
+// query sets): eight queries per lane held as packed float pairs, the node tile as floats; a node's
+// exact float64 squared distance -- the statements of k_nearest_part, so the same value and the same
+// winner -- is evaluated only when its binary32 estimate does not rule it out:
+//   s32 <= thr,   thr >= (R2 + 2 (2 sqrt(NP) e r + NP e^2)) (1 + 1e-6),   e = 2^-22 X,
+// with R2 = min(best exact squared distance so far in this chunk, bound2), r = sqrt(R2), bound2 = the
+// exact squared distance from the query to SOME node of the tree (found beforehand over a strided
+// sample: the answer is never farther), and X the largest coordinate magnitude among this tile's
+// nodes and the query.  (Rounding node and query to binary32 and their difference: |error| <= e per
+// column; over the NP columns that moves the squared distance of a node no farther than r by at most
+// 2 sqrt(NP) e r + NP e^2; NP fused multiply-adds lose at most NP 2^-24 of it.  The factor two and
+// the 1e-6 are margin.)  A node farther than r cannot be the answer; one at most that far always
+// passes the screen and is then compared exactly, in scan order with a strict <, so ties still go to
+// the lowest index.  The sample keeps the screen tight from the first node on: without it a tree
+// whose later nodes lie closer to the query (chains growing towards it) improves the running best
+// at nearly every step, and every improvement is an exact evaluation.
+constexpr int kNN32Queries = 8;
+
+template <int NP>
+__global__ void __launch_bounds__(kNNThreads, 4)  // (left alone the compiler prefetches tiles into 256 registers)
+k_nearest_part32(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
+                 int64_t M, int64_t chunk, const double *__restrict__ bound2, int32_t *__restrict__ pidx,
+                 double *__restrict__ pd2) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  __shared__ float tile[NP * kNNThreads];
+  __shared__ float wmax[kNNThreads / 64];
+  const int t = threadIdx.x;
+  const int64_t j0 = (int64_t)blockIdx.x * (kNN32Queries * kNNThreads) + t;
+  auto qindex = [&](int a) -> int64_t { return j0 + (int64_t)a * kNNThreads; };
+  v2f q[kNN32Queries / 2][NP];
+  float qmax[kNN32Queries];
+#pragma unroll
+  for (int a = 0; a < kNN32Queries; a++) {
+    float m = 0;
+#pragma unroll
+    for (int c = 0; c < NP; c++) {
+      const double v = qindex(a) < M ? queries[(int64_t)c * M + qindex(a)] : 0.0;
+      const float f = (float)v;
+      if (a & 1) q[a / 2][c].y = f; else q[a / 2][c].x = f;
+      m = fmaxf(m, fminf(fabsf(f), 1e30f));
+    }
+    qmax[a] = m;
+  }
+  const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  const double kInf = std::numeric_limits<double>::infinity();
+  double best[kNN32Queries], ref2[kNN32Queries], ref[kNN32Queries];  // ref2 = min(best, bound2), ref = sqrt(ref2)
+  int32_t bi[kNN32Queries];
+  float thr[kNN32Queries];
+#pragma unroll
+  for (int a = 0; a < kNN32Queries; a++) {
+    best[a] = kInf;
+    ref2[a] = (bound2 && qindex(a) < M) ? bound2[qindex(a)] : kInf;
+    ref[a] = ref2[a] < kInf ? sqrt(ref2[a]) : kInf;
+    bi[a] = -1;
+    thr[a] = std::numeric_limits<float>::infinity();
+  }
+  for (int64_t base = lo; base < hi; base += kNNThreads) {
+    __syncthreads();
+    const int64_t src = base + t;
+    float mine = 0;
+#pragma unroll
+    for (int c = 0; c < NP; c++) {
+      const double dv = (src < hi) ? nodes[(int64_t)c * cap + src] : kInf;
+      const float f = (float)dv;
+      tile[c * kNNThreads + t] = f;
+      // (an infinite node never wins: no part in X; a finite one beyond binary32's range makes the tile "wild")
+      if (fabs(dv) < kInf) mine = fmaxf(mine, fminf(fabsf(f), 1e30f));
+    }
+    for (int o = 32; o > 0; o >>= 1) mine = fmaxf(mine, __shfl_xor(mine, o));
+    if ((t & 63) == 0) wmax[t >> 6] = mine;
+    __syncthreads();
+    float tmax = wmax[0];
+#pragma unroll
+    for (int w = 1; w < kNNThreads / 64; w++) tmax = fmaxf(tmax, wmax[w]);
+    // this tile's thresholds
+#pragma unroll
+    for (int a = 0; a < kNN32Queries; a++) {
+      if (!(fmaxf(tmax, qmax[a]) < 1e18f)) {
+        thr[a] = std::numeric_limits<float>::infinity();  // squares would overflow binary32: no screen here
+      } else if (ref2[a] < kInf) {
+        const double X = (double)fmaxf(tmax, qmax[a]) * (1.0 + 1e-6);
+        const double e = X * 0x1p-22;
+        const double slack = 2.0 * (2.0 * sqrt((double)NP) * e * ref[a] + NP * e * e);
+        const double th = (ref2[a] + slack) * (1.0 + 1e-6);
+        float f = (float)th;
+        if ((double)f < th) f = __int_as_float(__float_as_int(f) + 1);  // (th >= 0: the next float up)
+        thr[a] = f;
+      }
+    }
+    const int lim = (int)((hi - base) < kNNThreads ? (hi - base) : kNNThreads);
+    for (int k = 0; k < lim; k++) {
+      v2f s[kNN32Queries / 2];
+#pragma unroll
+      for (int p2 = 0; p2 < kNN32Queries / 2; p2++) s[p2] = (v2f){0.0f, 0.0f};
+#pragma unroll
+      for (int c = 0; c < NP; c++) {
+        const float v = tile[c * kNNThreads + k];
+        const v2f vv = (v2f){v, v};
+#pragma unroll
+        for (int p2 = 0; p2 < kNN32Queries / 2; p2++) {
+          const v2f d = vv - q[p2][c];
+          s[p2] = __builtin_elementwise_fma(d, d, s[p2]);
+        }
+      }
+      bool hit = false;
+#pragma unroll
+      for (int p2 = 0; p2 < kNN32Queries / 2; p2++) hit = hit || (s[p2].x <= thr[2 * p2]) || (s[p2].y <= thr[2 * p2 + 1]);
+      if (__ballot(hit) != 0ull) {
+        if (hit) {
+          const int64_t node = base + k;
+#pragma unroll
+          for (int a = 0; a < kNN32Queries; a++) {
+            const float sa = (a & 1) ? s[a / 2].y : s[a / 2].x;
+            if (sa <= thr[a] && qindex(a) < M) {
+              double ex = 0;
+#pragma unroll
+              for (int c = 0; c < NP; c++) {
+                const double d = nodes[(int64_t)c * cap + node] - queries[(int64_t)c * M + qindex(a)];
+                ex = ex + d * d;
+              }
+              if (ex < best[a]) {
+                best[a] = ex;
+                bi[a] = (int32_t)node;
+                if (ex < ref2[a]) { ref2[a] = ex; ref[a] = sqrt(ex); }
+                const double X = (double)fmaxf(tmax, qmax[a]) * (1.0 + 1e-6);
+                const double e = X * 0x1p-22;
+                const double th = (ref2[a] + 2.0 * (2.0 * sqrt((double)NP) * e * ref[a] + NP * e * e)) * (1.0 + 1e-6);
+                float f = (float)th;
+                if ((double)f < th) f = __int_as_float(__float_as_int(f) + 1);  // (th >= 0: the next float up)
+                thr[a] = (fmaxf(tmax, qmax[a]) < 1e18f) ? f : std::numeric_limits<float>::infinity();
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < kNN32Queries; a++)
+    if (qindex(a) < M) {
+      pidx[(int64_t)blockIdx.y * M + qindex(a)] = bi[a];
+      pd2[(int64_t)blockIdx.y * M + qindex(a)] = best[a];  // (+inf, -1: nothing within the bound in this chunk)
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_nearest_reduce(const int32_t *__restrict__ pidx, const double *__restrict__ pd2, int64_t M, int nchunks,
-                 int32_t *__restrict__ out_idx, double *__restrict__ out_d2) {
+                 int32_t *__restrict__ out_idx, double *__restrict__ out_d2,
+                 const int32_t *__restrict__ seed_idx = nullptr, const double *__restrict__ seed_d2 = nullptr) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= M) return;
-  double best = std::numeric_limits<double>::infinity();
-  int32_t bi = -1;
+  // (seed: the result over the nodes below the chunks' range -- lower indices, so it goes first)
+  double best = seed_d2 ? seed_d2[j] : std::numeric_limits<double>::infinity();
+  int32_t bi = seed_idx ? seed_idx[j] : -1;
   for (int y = 0; y < nchunks; y++) {
     const double d = pd2[(int64_t)y * M + j];
     if (d < best) { best = d; bi = pidx[(int64_t)y * M + j]; }
@@ -2340,7 +2488,10 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
     int64_t chunk = (n + nchunks - 1) / nchunks;
     chunk = (chunk + kNNThreads - 1) / kNNThreads * kNNThreads;
     nchunks = (n + chunk - 1) / chunk;
-    const size_t need = (size_t)nchunks * (size_t)M * (sizeof(double) + sizeof(int32_t));
+    // partial results: room for twice the chunks of the float64 scan (the screened scan below
+    // cuts the nodes up to twice as fine), and one seed row
+    const size_t maxchunks = 2 * (size_t)nchunks + 1;
+    const size_t need = (maxchunks + 1) * (size_t)M * (sizeof(double) + sizeof(int32_t));
     if (need > e->nn_bytes) {
       if (e->d_nn) HIP_TRY(hipFree(e->d_nn));
       e->d_nn = nullptr; e->nn_bytes = 0;
@@ -2348,21 +2499,62 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
       e->nn_bytes = need;
     }
     double *pd2 = (double *)e->d_nn;
-    int32_t *pidx = (int32_t *)(pd2 + (size_t)nchunks * (size_t)M);
-    const dim3 grid((unsigned)qtiles, (unsigned)nchunks);
-#define MJPL_NN_CASE(NPV)                                                                                   \
-    case NPV:                                                                                               \
-      hipLaunchKernelGGL(k_nearest_part<NPV>, grid, dim3(kNNThreads), 0, e->stream, dnodes, n, cap, dqueries, \
-                         M, nplan, chunk, pidx, pd2);                                                       \
-      break;
-    switch (nplan) {
-      MJPL_NN_CASE(2) MJPL_NN_CASE(3) MJPL_NN_CASE(4) MJPL_NN_CASE(5) MJPL_NN_CASE(6) MJPL_NN_CASE(7)
-      MJPL_NN_CASE(8) MJPL_NN_CASE(9)
-      default:
-        hipLaunchKernelGGL(k_nearest_part<0>, grid, dim3(kNNThreads), 0, e->stream, dnodes, n, cap, dqueries, M,
-                           nplan, chunk, pidx, pd2);
-    }
+    double *seed_d2 = pd2 + maxchunks * (size_t)M;
+    int32_t *pidx = (int32_t *)(seed_d2 + (size_t)M);
+    int32_t *seed_idx = pidx + maxchunks * (size_t)M;
+    // the float64 scan of nodes [0, nn) in chunks of `ch`
+    auto scan64 = [&](int64_t nn, int64_t ch, int64_t nch, int64_t stride = 1) {
+      const dim3 grid((unsigned)qtiles, (unsigned)nch);
+#define MJPL_NN_CASE(NPV)                                                                                    \
+      case NPV:                                                                                              \
+        hipLaunchKernelGGL(k_nearest_part<NPV>, grid, dim3(kNNThreads), 0, e->stream, dnodes, nn, cap, dqueries, \
+                           M, nplan, ch, pidx, pd2, stride);                                                 \
+        break;
+      switch (nplan) {
+        MJPL_NN_CASE(2) MJPL_NN_CASE(3) MJPL_NN_CASE(4) MJPL_NN_CASE(5) MJPL_NN_CASE(6) MJPL_NN_CASE(7)
+        MJPL_NN_CASE(8) MJPL_NN_CASE(9)
+        default:
+          hipLaunchKernelGGL(k_nearest_part<0>, grid, dim3(kNNThreads), 0, e->stream, dnodes, nn, cap, dqueries, M,
+                             nplan, ch, pidx, pd2, stride);
+      }
 #undef MJPL_NN_CASE
+    };
+    const unsigned rgridM = (unsigned)((M + kBlock - 1) / kBlock);
+    constexpr int64_t kSampleNodes = 16384;
+    if (M >= 16384 && n >= 16 * kSampleNodes && nplan >= 2 && nplan <= 9) {
+      // Large trees and query sets.  First a strided sample of the nodes, exactly: every query gets a
+      // bound close to its answer.  Then the binary32-screened scan of all nodes, eight queries per
+      // lane, which evaluates exactly only what lies within that bound.
+      const int64_t stride = n / kSampleNodes;
+      const int64_t nc0 = std::min<int64_t>(maxchunks, kSampleNodes / kNNThreads);
+      const int64_t ch0 = kSampleNodes / nc0;
+      scan64(kSampleNodes, ch0, nc0, stride);
+      hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc0, seed_idx, seed_d2,
+                         (const int32_t *)nullptr, (const double *)nullptr);
+      const int qb32 = kNN32Queries * kNNThreads;
+      const int64_t qt32 = (M + qb32 - 1) / qb32;
+      int64_t nc32 = std::max<int64_t>(1, (8192 + qt32 - 1) / qt32);
+      nc32 = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nc32, (int64_t)maxchunks), n / (8 * kNNThreads)));
+      int64_t ch32 = (n + nc32 - 1) / nc32;
+      ch32 = (ch32 + kNNThreads - 1) / kNNThreads * kNNThreads;
+      nc32 = (n + ch32 - 1) / ch32;
+      const dim3 g32((unsigned)qt32, (unsigned)nc32);
+#define MJPL_NN32_CASE(NPV)                                                                                   \
+      case NPV:                                                                                               \
+        hipLaunchKernelGGL(k_nearest_part32<NPV>, g32, dim3(kNNThreads), 0, e->stream, dnodes, n, cap, dqueries, \
+                           M, ch32, (const double *)seed_d2, pidx, pd2);                                      \
+        break;
+      switch (nplan) {
+        MJPL_NN32_CASE(2) MJPL_NN32_CASE(3) MJPL_NN32_CASE(4) MJPL_NN32_CASE(5) MJPL_NN32_CASE(6) MJPL_NN32_CASE(7)
+        MJPL_NN32_CASE(8) MJPL_NN32_CASE(9)
+      }
+#undef MJPL_NN32_CASE
+      hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc32, dout_idx,
+                         dout_dist2, (const int32_t *)nullptr, (const double *)nullptr);
+      HIP_TRY(hipGetLastError());
+      return MJPL_OK;
+    }
+    scan64(n, chunk, nchunks);
     hipLaunchKernelGGL(k_nearest_reduce, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
                        pidx, pd2, M, (int)nchunks, dout_idx, dout_dist2);
     HIP_TRY(hipGetLastError());

@@ -159,6 +159,40 @@ def test_nearest_neighbour_kernel():
         want = ((nodes2[:, None, :] - q2[:, :, None]) ** 2).sum(0).argmin(1)
         np.testing.assert_array_equal(got, want)
         assert got[0] == min(3, n2 - 1)
+    # large trees and query sets: the first 16 384 nodes exactly, then a binary32 screen in front of the
+    # float64 distances of the rest -- same winners, also among near-ties far below binary32's
+    # resolution, exact duplicates (lowest index, on either side of the seed range), infinite and huge nodes
+    n3, M3 = 300000, 16500
+    nodes3 = rng.uniform(-2.9, 2.9, size=(7, n3))
+    q3 = rng.uniform(-2.9, 2.9, size=(7, M3))
+    for j in range(0, 600):  # a cluster of nodes within 1e-9 .. 1e-13 of each other near the query's nearest one
+        k = int(rng.integers(0, n3 - 40))
+        q3[:, j] = nodes3[:, k] + rng.normal(scale=0.05, size=7)
+        for r in range(1, 12):
+            nodes3[:, k + 3 * r] = nodes3[:, k] + rng.normal(scale=10.0 ** -rng.integers(9, 14), size=7)
+    nodes3[:, 260001] = nodes3[:, 11]    # exact duplicates: the lowest index wins (seed range vs screened range)
+    q3[:, 700] = nodes3[:, 11]
+    nodes3[:, 299000] = nodes3[:, 150000]  # ... and within the screened range
+    q3[:, 702] = nodes3[:, 150000]
+    nodes3[:, 5] = np.inf
+    nodes3[:, 6] = 1e25                  # (finite, beyond what the screen may square)
+    nodes3[:, 200006] = 1e25
+    q3[3, 701] = 1e22
+    dn3, dq3 = e.alloc(nodes3.nbytes).upload(nodes3), e.alloc(q3.nbytes).upload(q3)
+    di3, dd3 = e.alloc(4 * M3), e.alloc(8 * M3)
+    e.nearest_dev(dn3.ptr, n3, n3, dq3.ptr, M3, di3.ptr, dd3.ptr)
+    got3, gd3 = di3.download(np.int32, M3), dd3.download(np.float64, M3)
+    sel = np.concatenate([np.arange(0, 800), rng.integers(800, M3, 200)])
+    for lo in range(0, len(sel), 100):
+        js = sel[lo:lo + 100]
+        with np.errstate(over="ignore", invalid="ignore"):
+            s3 = np.zeros((len(js), n3))
+            for c in range(7):  # the kernel's sum order
+                d = nodes3[c][None, :] - q3[c][js][:, None]
+                s3 = s3 + d * d
+        np.testing.assert_array_equal(got3[js], s3.argmin(1))
+        np.testing.assert_array_equal(gd3[js], s3.min(1))
+    assert got3[700] == 11 and got3[702] == 150000
 
 
 def test_dropin_constraint_and_planner_equivalence(oracle_mod):
