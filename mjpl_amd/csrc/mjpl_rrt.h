@@ -124,9 +124,26 @@ k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLane
 // emits the candidate edges (w -> q) it would like validated.  Without a projecting constraint the
 // candidates do not depend on the verdicts, so S may exceed 1 and the rule checks (joint limits,
 // moved, not farther) are made here; with one, S = 1 and the rules are checked after projection.
+struct RrtFull {  // projecting constraint: where k_rrt_gen leaves the candidates as full qpos rows for k_pose_apply
+  int nq;
+  const int *qidx;
+  const double *qbase;
+  double *Fold, *Fnew;  // null: not projecting
+};
+
+__device__ __forceinline__ void rrt_full_rows(const RrtFull &fr, int nplan, int64_t slot, const double *a, const double *b) {
+  if (!fr.Fold) return;
+  for (int k = 0; k < fr.nq; k++) { fr.Fold[slot * fr.nq + k] = fr.qbase[k]; fr.Fnew[slot * fr.nq + k] = fr.qbase[k]; }
+  for (int c = 0; c < nplan; c++) {
+    fr.Fold[slot * fr.nq + fr.qidx[c]] = a[c];
+    fr.Fnew[slot * fr.nq + fr.qidx[c]] = b[c];
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__restrict__ lo,
-          const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln, RrtCand cd, int *__restrict__ ctr) {
+          const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln, RrtCand cd, int *__restrict__ ctr,
+          RrtFull fr) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool act = l < L && ln.act[l] != 0;
@@ -190,6 +207,11 @@ k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__r
         cd.B[(int64_t)slot * nplan + c] = v;
       }
       cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
+      if (fr.Fold) {
+        double v[kRrtMaxPlan];
+        for (int c = 0; c < nplan; c++) v[c] = ln.C[(int64_t)c * L + l];
+        rrt_full_rows(fr, nplan, slot, v, v);
+      }
     }
     count = 0; end = 0; first = 0;
   }
@@ -215,20 +237,8 @@ k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__r
     cd.level[slot] = lvl0 + s;
     cd.rule[slot] = 1;
     cd.reach[slot] = (r == 2) ? 1 : 0;
+    rrt_full_rows(fr, nplan, slot, w, q);
     for (int c = 0; c < nplan; c++) w[c] = q[c];
-  }
-}
-
-// projecting constraint: planning columns -> full qpos rows for k_pose_apply
-__global__ void __launch_bounds__(256)
-k_rrt_fullrows(int E, int nplan, int nq, const int *__restrict__ qidx, const double *__restrict__ qbase, RrtCand cd,
-               double *__restrict__ Fold, double *__restrict__ Fnew) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= E) return;
-  for (int k = 0; k < nq; k++) { Fold[(int64_t)i * nq + k] = qbase[k]; Fnew[(int64_t)i * nq + k] = qbase[k]; }
-  for (int c = 0; c < nplan; c++) {
-    Fold[(int64_t)i * nq + qidx[c]] = cd.A[(int64_t)i * nplan + c];
-    Fnew[(int64_t)i * nq + qidx[c]] = cd.B[(int64_t)i * nplan + c];
   }
 }
 
@@ -518,7 +528,8 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   const bool pipelined = projecting && r->cd.cap >= L;
   for (int chunk = 0;; chunk++) {
     hipLaunchKernelGGL(k_rrt_gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, projecting ? 1 : 0, r->d_lo, r->d_hi,
-                       Tgt, r->ln, r->cd, r->d_ctr);
+                       Tgt, r->ln, r->cd, r->d_ctr,
+                       RrtFull{r->nq, r->d_qidx, r->d_qbase, projecting ? r->d_F[0] : nullptr, projecting ? r->d_F[1] : nullptr});
     if (pipelined) {
       const int slot = chunk % 4;
       HIP_TRY(hipMemcpyAsync(r->h_ring + slot * RC_SIZE, r->d_ctr, RC_SIZE * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -542,8 +553,6 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     }
     if (r->h_ctr[RC_OVERFLOW] & 1) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
     if (projecting) {
-      hipLaunchKernelGGL(k_rrt_fullrows, dim3(rgrid(E)), dim3(256), 0, st, E, nplan, r->nq, r->d_qidx, r->d_qbase, r->cd, r->d_F[0],
-                         r->d_F[1]);
       rc = mjpl_pose_apply_dev(r->pose, r->d_F[0], r->d_F[1], E, r->d_F[2], r->d_pok, nullptr);
       if (rc != MJPL_OK) return rc;
       hipLaunchKernelGGL(k_rrt_after_pose, dim3(rgrid(E)), dim3(256), 0, st, E, L, nplan, r->nq, r->d_qidx, r->d_qbase, r->d_isplan,
