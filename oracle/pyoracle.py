@@ -60,6 +60,18 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+CPU_REF_PATH = os.path.join(_HERE, "libmjpl_cpu_ref.so")
+
+
+def build_cpu_ref(force: bool = False) -> str:
+    """The oracle behind include/mjpl_hip.h's host-pointer entry points (oracle/mjpl_cpu_ref.c)."""
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f))
+                for f in ("mjpl_cpu_ref.c", "mjpl_oracle.c", "mjpl_oracle_pose.c", "mjpl_oracle.h", "orc_math.h"))
+    if force or not os.path.exists(CPU_REF_PATH) or os.path.getmtime(CPU_REF_PATH) < src_m:
+        subprocess.run(["make", "-C", _HERE, "-B", "libmjpl_cpu_ref.so"], check=True, stdout=subprocess.DEVNULL)
+    return CPU_REF_PATH
+
+
 _lib = None
 
 
