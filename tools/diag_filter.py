@@ -1,3 +1,4 @@
+"""Diagnostic (GPU box): undecided-item counts and verdict agreement of the float32 filter on the bench edges."""
 import sys; sys.path.insert(0,'.')
 import numpy as np
 import bench

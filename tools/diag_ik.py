@@ -1,3 +1,4 @@
+"""Diagnostic (GPU box): which IK seeds do not converge, and why (joint limits, iteration budget)."""
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np

@@ -1,3 +1,4 @@
+"""Diagnostic (GPU box): mismatches of the finger-pad (moving boxes) model against the oracle, per edge."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np

@@ -1,3 +1,4 @@
+"""Diagnostic (GPU box): where a plan_to_pose call spends its time (IK, goal validation, search); cProfile."""
 import time, sys, os
 sys.path.insert(0, '/root/repo')
 import numpy as np

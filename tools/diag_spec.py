@@ -1,3 +1,4 @@
+"""Diagnostic (GPU box): verdicts of a model's specialised kernels against the interpreter and the oracle."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np

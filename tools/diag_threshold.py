@@ -1,3 +1,4 @@
+"""Diagnostic (GPU box): the at-threshold cases of tests/test_gpu_filter_adversarial.py one by one."""
 import sys, numpy as np
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import test_gpu_filter_adversarial as t

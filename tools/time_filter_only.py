@@ -1,3 +1,4 @@
+"""Timing (GPU box): the float32 filter kernels of the bench step alone (no exact re-check)."""
 import sys; sys.path.insert(0,'.')
 import numpy as np
 import bench
