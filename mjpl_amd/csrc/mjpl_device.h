@@ -778,6 +778,15 @@ __device__ __forceinline__ void park_mask(int &lo, int &hi, unsigned long long m
       : "+v"(lo), "+v"(hi)
       : "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "n"(LANE));
 }
+// two masks behind one wait state
+template <int LANE_A, int LANE_B>
+__device__ __forceinline__ void park_mask2(int &lo, int &hi, unsigned long long ma, unsigned long long mb) {
+  asm("s_nop 1\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %1, %3, %6\n\t"
+      "v_writelane_b32 %0, %4, %7\n\tv_writelane_b32 %1, %5, %7"
+      : "+v"(lo), "+v"(hi)
+      : "s"((int)(unsigned)ma), "s"((int)(unsigned)(ma >> 32)), "s"((int)(unsigned)mb), "s"((int)(unsigned)(mb >> 32)),
+        "n"(LANE_A), "n"(LANE_B));
+}
 
 // control words are wave-uniform: pin them to SGPRs so the interpreter's branches are scalar
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
