@@ -24,7 +24,10 @@ constexpr int kStatusNonFinite = 1;
 #endif
 // A model's own straight-line code is asked to fit three waves per SIMD (168 VGPRs): its register
 // pressure is a few registers above that without the bound, and the third wave is worth more
-template <class Spec, int MAXS = 0> constexpr int kMinWaves = std::is_void<Spec>::value ? (MAXS == 24 ? MJPL_MBOX_WAVES : 1) : 3;
+#ifndef MJPL_SPEC_WAVES
+#define MJPL_SPEC_WAVES 3
+#endif
+template <class Spec, int MAXS = 0> constexpr int kMinWaves = std::is_void<Spec>::value ? (MAXS == 24 ? MJPL_MBOX_WAVES : 1) : MJPL_SPEC_WAVES;
 
 // LDS carve shared by all kernels: [tables (A/B build only) | float64 columns | pose saves].
 // With the default build the tables stay in global memory (scalar loads).
