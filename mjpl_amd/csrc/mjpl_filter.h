@@ -18,7 +18,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 4
+#define MJPL_SPEC_ABI 5
 #ifndef MJPL_MBOX_WAVES
 #define MJPL_MBOX_WAVES 1  // the 24-slot moving-box build: ~360 VGPRs; bound to two waves per SIMD it spills 200 dwords and is 4x slower
 #endif
@@ -606,5 +606,214 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
     }
   }
 }
+
+// ---- exact re-check of single geom pairs the filter could not decide -------------------------
+// Item u = (configuration uc.q[u], moving geom uc.ga[u], partner geom uc.gb[u]).  One lane per
+// item: float64 FK of the moving bodies (same statements as run_config), capturing the world
+// pose of the one or two geoms it needs, then the bounding cull and the narrowphase routine of
+// that pair exactly as the full exact kernel would run them.  A contact clears valid[edge] and
+// lowers first_bad[edge] (unsigned min; -1 = valid so far).  Latency of a wave is one FK instead
+// of FK + all culls + every narrowphase call some lane of the wave needs.
+struct GeomTable {           // per model geom, float64 [GT_LEN]
+  const double *t;
+};
+enum : int { GTB_TYPE = 0, GTB_SIZE = 1, GTB_RBOUND = 4, GTB_MARGIN = 5, GTB_STATIC = 6, GTB_XPOS = 7,
+             GTB_XMAT = 10, GTB_LEN = 19 };
+
+// ESpec: void = the float64 FK below walks the compiled program; a generated struct
+// (mjpl_amd/specialise.py: generate_exact) supplies the SAME statements with the model's constants as
+// literals -- a wave of this kernel runs alone on its SIMD, and ~700 scalar table loads per wave,
+// each waited for, were most of its 30 us.
+template <class ESpec>
+__global__ void __launch_bounds__(kBlock)
+k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp, GeomTable gt,
+              UndecidedConfigs uc, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  const int64_t n = *uc.count < uc.cap ? *uc.count : uc.cap;
+  if ((int64_t)blockIdx.x * B >= n) return;
+  const int nplan = gip[H_NPLAN];
+  Carve<double> c = carve_lds<double>(smem, gip, nip, gdp, ndp, nplan, 1, B);
+  // the number of items is read on the device and may exceed the grid: blocks stride over it
+  for (int64_t base = (int64_t)blockIdx.x * B; base < n; base += (int64_t)gridDim.x * B) {
+  const int64_t u = base + threadIdx.x;
+  bool active = u < n;
+  const int ga = active ? uc.ga[u] : -1;
+  const int gb = active ? uc.gb[u] : -1;
+  active = active && ga >= 0;
+  double *q = c.col0 + threadIdx.x;
+  load_columns(q, B, uc.q, n, u < n ? u : 0, nplan, MJPL_AOS, active);
+  if (__ballot(active) == 0ull) continue;
+
+  typedef GeomT<double> Geom;
+  IP ip = c.ip;
+  DP tp = c.tp;
+  double *save = c.save + threadIdx.x;
+  const int sstride = B;
+  Geom A, Bg;
+#pragma unroll
+  for (int k = 0; k < 3; k++) A.pos[k] = Bg.pos[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) A.m[k] = Bg.m[k] = 0;
+  double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if constexpr (!std::is_void<ESpec>::value) {
+    ESpec::fk_pair(q, B, save, sstride, active, ga, gb, A, Bg);
+  } else {
+  const int nbodyops = uni(ip[H_NBODYOPS]);
+  int pc = uni(ip[H_OFF_BODYOPS]);
+  for (int b = 0; b < nbodyops; b++) {
+    const int parent = uni(ip[pc + B_PARENT]);
+    DP bd = tp + uni(ip[pc + B_DOFF]);
+    const int njnt = uni(ip[pc + B_NJNT]);
+    const int save_slot = uni(ip[pc + B_SAVE]);
+    const int ngeom = uni(ip[pc + B_NGEOM]);
+    pc += B_SIZE;
+    double pp[3], pq[4], pR[9];
+    if (parent == PARENT_CUR) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = p[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = qt[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) pR[k] = R[k];
+    } else if (parent == PARENT_STATIC) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = bd[7 + k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = bd[10 + k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) pR[k] = bd[14 + k];
+    } else {
+      const double *sv = save + (size_t)(parent - 1) * 7 * sstride;
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = sv[k * sstride];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pq[k] = sv[(3 + k) * sstride];
+      quat2mat(pR, pq);
+    }
+    double np[3], nq[4];
+    {
+      double bpos[3] = {bd[0], bd[1], bd[2]};
+      double bquat[4] = {bd[3], bd[4], bd[5], bd[6]};
+      mul_mat_vec3(np, pR, bpos);
+      np[0] += pp[0]; np[1] += pp[1]; np[2] += pp[2];
+      mul_quat(nq, pq, bquat);
+    }
+    for (int j = 0; j < njnt; j++) {
+      const int jtype = uni(ip[pc + J_TYPE]);
+      const int qsrc = uni(ip[pc + J_QSRC]);
+      const int jflags = uni(ip[pc + J_FLAGS]);
+      DP jd = tp + uni(ip[pc + J_DOFF]);
+      pc += J_SIZE;
+      const double qv = (qsrc >= 0) ? q[qsrc * B] : jd[7];
+      const double dq = qv - jd[6];
+      double jaxis[3] = {jd[0], jd[1], jd[2]};
+      double jpos[3] = {jd[3], jd[4], jd[5]};
+      if (jtype == JT_SLIDE) {
+        double xaxis[3];
+        rot_vec_quat(xaxis, jaxis, nq);
+        np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq;
+      } else {
+        double xanchor[3] = {np[0], np[1], np[2]};
+        if (jflags & JF_POS_NONZERO) {
+          rot_vec_quat(xanchor, jpos, nq);
+          xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];
+        }
+        double sn, cs;
+        sincos_half(dq * 0.5, &sn, &cs);
+        double qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};
+        mul_quat(nq, nq, qloc);
+        if (jflags & JF_POS_NONZERO) {
+          double vec[3];
+          rot_vec_quat(vec, jpos, nq);
+          np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2];
+        }
+      }
+    }
+    normalize4(nq);
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = np[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) qt[k] = nq[k];
+    quat2mat(R, qt);
+    if (save_slot >= 0) {
+      double *sv = save + (size_t)save_slot * 7 * sstride;
+#pragma unroll
+      for (int k = 0; k < 3; k++) sv[k * sstride] = p[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) sv[(3 + k) * sstride] = qt[k];
+    }
+    for (int g = 0; g < ngeom; g++) {
+      const int gflags = uni(ip[pc + G_FLAGS]);
+      DP gd = tp + uni(ip[pc + G_DOFF]);
+      const int geom_id = uni(ip[pc + G_GEOMID]);
+      pc += G_SIZE + MAX_SLOTS;
+      if (__ballot(active && (geom_id == ga || geom_id == gb)) == 0ull) continue;
+      Geom cur;
+      if (gflags & GF_SAMEPOS) {
+        cur.pos[0] = p[0]; cur.pos[1] = p[1]; cur.pos[2] = p[2];
+      } else {
+        double lpos[3] = {gd[0], gd[1], gd[2]};
+        mul_mat_vec3(cur.pos, R, lpos);
+        cur.pos[0] += p[0]; cur.pos[1] += p[1]; cur.pos[2] += p[2];
+      }
+      if (gflags & GF_SAMEROT) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) cur.m[k] = R[k];
+      } else {
+        double lq[4] = {gd[3], gd[4], gd[5], gd[6]}, gq[4];
+        mul_quat(gq, qt, lq);
+        quat2mat(cur.m, gq);
+      }
+      const bool isa = geom_id == ga, isb = geom_id == gb;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { A.pos[k] = isa ? cur.pos[k] : A.pos[k]; Bg.pos[k] = isb ? cur.pos[k] : Bg.pos[k]; }
+#pragma unroll
+      for (int k = 0; k < 9; k++) { A.m[k] = isa ? cur.m[k] : A.m[k]; Bg.m[k] = isb ? cur.m[k] : Bg.m[k]; }
+    }
+  }
+  }
+  if (!active) continue;
+  const double *ta = gt.t + (size_t)ga * GTB_LEN, *tb = gt.t + (size_t)gb * GTB_LEN;
+  if (tb[GTB_STATIC] != 0.0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) Bg.pos[k] = tb[GTB_XPOS + k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Bg.m[k] = tb[GTB_XMAT + k];
+  }
+  const int tya = (int)ta[GTB_TYPE], tyb = (int)tb[GTB_TYPE];
+  const double sa[3] = {ta[GTB_SIZE], ta[GTB_SIZE + 1], ta[GTB_SIZE + 2]};
+  const bool bplane = tyb == GT_PLANE;  // the interpreter passes no size for a plane
+  const double sb[3] = {bplane ? 0.0 : tb[GTB_SIZE], bplane ? 0.0 : tb[GTB_SIZE + 1], bplane ? 0.0 : tb[GTB_SIZE + 2]};
+  // pair margin and bounding cull in mj_collision's (g1 < g2) order, as compile_program folds them
+  const int g1 = ga < gb ? ga : gb, g2 = ga < gb ? gb : ga;
+  const double *t1 = gt.t + (size_t)g1 * GTB_LEN, *t2 = gt.t + (size_t)g2 * GTB_LEN;
+  const double margin = fmax(t1[GTB_MARGIN], t2[GTB_MARGIN]);
+  const double r1 = t1[GTB_RBOUND], r2 = t2[GTB_RBOUND];
+  bool pass = true;
+  if (tyb == GT_PLANE) {
+    if (ta[GTB_RBOUND] > 0) {
+      const double n[3] = {Bg.m[2], Bg.m[5], Bg.m[8]};
+      const double dif[3] = {A.pos[0] - Bg.pos[0], A.pos[1] - Bg.pos[1], A.pos[2] - Bg.pos[2]};
+      pass = !(dot3(dif, n) > margin + ta[GTB_RBOUND]);
+    }
+  } else if (r1 > 0 && r2 > 0) {
+    const double bsum = r1 + r2 + margin;
+    const double dx = A.pos[0] - Bg.pos[0], dy = A.pos[1] - Bg.pos[1], dz = A.pos[2] - Bg.pos[2];
+    pass = !(dx * dx + dy * dy + dz * dz > bsum * bsum);
+  }
+  if (!pass) continue;
+  // the partner is the first geom of the pair if its type is smaller, geom id breaking ties
+  const bool pfirst = (tyb < tya) || (tyb == tya && gb < ga);
+  const int code = pair_contact<double, true, true>(tya, A, sa, tyb, Bg, sb, pfirst, margin, 0.0);
+  if (code == V_CONTACT) {
+    const int ed = uc.edge[u];
+    valid[ed] = 0;
+    if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)uc.idx[u]);
+  }
+  }
+}
+
+
 
 }  // namespace mjpl

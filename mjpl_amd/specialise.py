@@ -464,6 +464,118 @@ def generate(ip, fp, dp, info) -> str:
     return "\n".join(out) + "\n"
 
 
+
+def dlit(x) -> str:
+    """An exact C++17 hexadecimal literal of a float64."""
+    return float(x).hex()
+
+
+def generate_exact(ip, dp, info) -> str:
+    """HIP source of `struct ExactSpec`: the float64 FK of k_patch_pairs (mjpl_filter.h) for one compiled
+    program -- the interpreter's own statements, body by body, with every table read replaced by the
+    value it would read (exact hexadecimal literals).  Same operations on the same values: the kernel's
+    verdicts are the interpreter's, bit for bit; what goes away is ~700 scalar loads per wave."""
+    out = []
+    o = out.append
+    nbody = int(ip[H_NBODYOPS])
+    pc = int(ip[H_OFF_BODYOPS])
+
+    def arr(vals):
+        return "{" + ", ".join(dlit(v) for v in vals) + "}"
+
+    o("struct ExactSpec {")
+    o("  static __device__ __forceinline__ void fk_pair(const double *q, int qstride, double *save, int sstride, bool active,")
+    o("                                                 int ga, int gb, mjpl::GeomT<double> &A, mjpl::GeomT<double> &Bg) {")
+    o("    using namespace mjpl;")
+    o("    typedef GeomT<double> Geom;")
+    o("    double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};")
+    for b in range(nbody):
+        parent, bdoff, njnt, save_slot, ngeom = (int(ip[pc + k]) for k in (B_PARENT, B_DOFF, B_NJNT, B_SAVE, B_NGEOM))
+        pc += B_SIZE
+        bd = dp[bdoff:]
+        o(f"    {{  // body op {b}")
+        o("      double pp[3], pq[4], pR[9];")
+        if parent == PARENT_CUR:
+            o("      for (int k = 0; k < 3; k++) pp[k] = p[k];")
+            o("      for (int k = 0; k < 4; k++) pq[k] = qt[k];")
+            o("      for (int k = 0; k < 9; k++) pR[k] = R[k];")
+        elif parent == PARENT_STATIC:
+            o(f"      {{ const double a_[3] = {arr(bd[7:10])}, b_[4] = {arr(bd[10:14])}, c_[9] = {arr(bd[14:23])};")
+            o("        for (int k = 0; k < 3; k++) pp[k] = a_[k];")
+            o("        for (int k = 0; k < 4; k++) pq[k] = b_[k];")
+            o("        for (int k = 0; k < 9; k++) pR[k] = c_[k]; }")
+        else:
+            o(f"      {{ const double *sv = save + (size_t){parent - 1} * 7 * sstride;")
+            o("        for (int k = 0; k < 3; k++) pp[k] = sv[k * sstride];")
+            o("        for (int k = 0; k < 4; k++) pq[k] = sv[(3 + k) * sstride];")
+            o("        quat2mat(pR, pq); }")
+        o("      double np[3], nq[4];")
+        o(f"      {{ const double bpos[3] = {arr(bd[0:3])}, bquat[4] = {arr(bd[3:7])};")
+        o("        mul_mat_vec3(np, pR, bpos);")
+        o("        np[0] += pp[0]; np[1] += pp[1]; np[2] += pp[2];")
+        o("        mul_quat(nq, pq, bquat); }")
+        for j in range(njnt):
+            jtype, qsrc, jflags, jdoff = (int(ip[pc + k]) for k in (J_TYPE, J_QSRC, J_FLAGS, J_DOFF))
+            pc += J_SIZE
+            jd = dp[jdoff:]
+            qv = f"q[{qsrc} * qstride]" if qsrc >= 0 else dlit(jd[7])
+            o(f"      {{ const double qv = {qv};")
+            o(f"        const double dq = qv - {dlit(jd[6])};")
+            o(f"        const double jaxis[3] = {arr(jd[0:3])}, jpos[3] = {arr(jd[3:6])};")
+            if jtype == JT_SLIDE:
+                o("        double xaxis[3];")
+                o("        rot_vec_quat(xaxis, jaxis, nq);")
+                o("        np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq; }")
+            else:
+                o("        double xanchor[3] = {np[0], np[1], np[2]};")
+                if jflags & JF_POS_NONZERO:
+                    o("        rot_vec_quat(xanchor, jpos, nq);")
+                    o("        xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];")
+                o("        double sn, cs;")
+                o("        sincos_half(dq * 0.5, &sn, &cs);")
+                o("        double qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};")
+                o("        mul_quat(nq, nq, qloc);")
+                if jflags & JF_POS_NONZERO:
+                    o("        double vec[3];")
+                    o("        rot_vec_quat(vec, jpos, nq);")
+                    o("        np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2];")
+                o("        (void)jpos; (void)xanchor; }")
+        o("      normalize4(nq);")
+        o("      for (int k = 0; k < 3; k++) p[k] = np[k];")
+        o("      for (int k = 0; k < 4; k++) qt[k] = nq[k];")
+        o("      quat2mat(R, qt);")
+        if save_slot >= 0:
+            o(f"      {{ double *sv = save + (size_t){save_slot} * 7 * sstride;")
+            o("        for (int k = 0; k < 3; k++) sv[k * sstride] = p[k];")
+            o("        for (int k = 0; k < 4; k++) sv[(3 + k) * sstride] = qt[k]; }")
+        for gi in range(ngeom):
+            gflags, gdoff, geom_id = (int(ip[pc + k]) for k in (G_FLAGS, G_DOFF, G_GEOMID))
+            pc += G_SIZE + MAX_SLOTS
+            gd = dp[gdoff:]
+            o(f"      if (__ballot(active && (ga == {geom_id} || gb == {geom_id})) != 0ull) {{")
+            o("        Geom cur;")
+            if gflags & GF_SAMEPOS:
+                o("        cur.pos[0] = p[0]; cur.pos[1] = p[1]; cur.pos[2] = p[2];")
+            else:
+                o(f"        {{ const double lpos[3] = {arr(gd[0:3])};")
+                o("          mul_mat_vec3(cur.pos, R, lpos);")
+                o("          cur.pos[0] += p[0]; cur.pos[1] += p[1]; cur.pos[2] += p[2]; }")
+            if gflags & GF_SAMEROT:
+                o("        for (int k = 0; k < 9; k++) cur.m[k] = R[k];")
+            else:
+                o(f"        {{ const double lq[4] = {arr(gd[3:7])};")
+                o("          double gq[4];")
+                o("          mul_quat(gq, qt, lq);")
+                o("          quat2mat(cur.m, gq); }")
+            o(f"        const bool isa = ga == {geom_id}, isb = gb == {geom_id};")
+            o("        for (int k = 0; k < 3; k++) { A.pos[k] = isa ? cur.pos[k] : A.pos[k]; Bg.pos[k] = isb ? cur.pos[k] : Bg.pos[k]; }")
+            o("        for (int k = 0; k < 9; k++) { A.m[k] = isa ? cur.m[k] : A.m[k]; Bg.m[k] = isb ? cur.m[k] : Bg.m[k]; }")
+            o("      }")
+        o("    }")
+    o("  }")
+    o("};")
+    return "\n".join(out) + "\n"
+
 _TU = """// GENERATED translation unit: the float32 filter kernels of mjpl_filter.h around one model's Spec.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -471,6 +583,7 @@ _TU = """// GENERATED translation unit: the float32 filter kernels of mjpl_filte
 
 namespace {
 %(spec)s
+%(exact)s
 }  // namespace
 
 using namespace mjpl;
@@ -506,6 +619,10 @@ int mjpl_spec_launch_items(hipStream_t st, unsigned grid, unsigned block, size_t
                            UndecidedConfigs uc) {
   SPEC_LAUNCH((k_filter_items<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, ib, src, tol, valid, first_bad, ulist, ucount, uc);
 }
+int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const double *dp,
+                           int ndp, GeomTable gt, UndecidedConfigs uc, uint8_t *valid, int32_t *first_bad) {
+  SPEC_LAUNCH((k_patch_pairs<ExactSpec>), ip, nip, dp, ndp, gt, uc, valid, first_bad);
+}
 }
 """
 
@@ -526,7 +643,7 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
     deps = [os.path.join(_build.CSRC, f) for f in ("mjpl_filter.h", "mjpl_device.h", "mjpl_trig.h")] + [__file__]
     if not force and os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
         return target
-    src = _TU % dict(spec=generate(ip, fp, dp, info), hash=info.hash, maxs=info.maxs, wbox="true" if info.wbox else "false")
+    src = _TU % dict(spec=generate(ip, fp, dp, info), exact=generate_exact(ip, dp, info), hash=info.hash, maxs=info.maxs, wbox="true" if info.wbox else "false")
     src_path = os.path.join(SPEC_DIR, f"spec_{info.hash:016x}.hip")
     with open(src_path, "w") as f:
         f.write(src)
