@@ -653,3 +653,34 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
     if not keep_source:
         os.remove(src_path)
     return target
+
+
+def _main(argv=None) -> int:
+    """python -m mjpl_amd.specialise MODEL.xml [--joints a,b,...] [--keyframe NAME] [--allowed bodyA:bodyB,...]
+    Builds the specialised library for (model, planning joints, base configuration) -- a deployment step:
+    needs hipcc, no GPU; engines created for that combination afterwards load it by program hash."""
+    import argparse
+
+    from .model import load_mjcf
+    ap = argparse.ArgumentParser(prog="python -m mjpl_amd.specialise", description=_main.__doc__)
+    ap.add_argument("mjcf", help="primitive-only MJCF file")
+    ap.add_argument("--joints", default="", help="comma-separated planning joints (default: all)")
+    ap.add_argument("--keyframe", default="", help="keyframe holding the non-planning joints (default: qpos0)")
+    ap.add_argument("--allowed", default="", help="allowed collision body pairs, bodyA:bodyB,...")
+    ap.add_argument("--tol", type=float, default=0.0, help="filter tolerance in metres (0: the model's default)")
+    ap.add_argument("--force", action="store_true")
+    args = ap.parse_args(argv)
+    model = load_mjcf(args.mjcf)
+    names = [n for n in args.joints.split(",") if n]
+    qidx = None
+    if names:
+        qidx = np.asarray([int(model.jnt_qposadr[model.joint(n).id]) for n in names], dtype=np.int32)
+    base = model.keyframe(args.keyframe).qpos.copy() if args.keyframe else None
+    allowed = tuple(tuple(p.split(":")) for p in args.allowed.split(",") if p)
+    path = build(model, allowed, qidx, base, args.tol, force=args.force)
+    print(path if path else "this model runs the general builds: nothing to specialise")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(_main())
