@@ -12,7 +12,14 @@ no data-path collective).  Rank 0 prints ONE JSON line.
 The timed K steps are launched through mjpl_time_edges_stages_dev: K back-to-back launches on the
 engine's own stream between two HIP events, every fourth launch also carrying one event after each
 of its kernels; roofline.achieved is the longest kernel's algorithmic bytes over its mean duration
-from those events.  torch is imported only for N > 1 (rendezvous, barrier, max-reduce over RCCL).
+from those events.
+
+N > 1: one process per GPU.  `python bench.py --gpus N` starts its N rank processes itself -- children,
+before anything in this process has touched a GPU -- and `torch.distributed.run` may start them just as
+well (RANK / LOCAL_RANK / WORLD_SIZE in the environment).  Either way PyTorch is not imported: rank 0
+publishes the library's 128-byte ncclUniqueId through a file, every rank attaches an RCCL communicator
+to its engine (mjpl_comm_init), and the barrier and the max over ranks of the elapsed time are
+all-gathers of eight bytes per rank on that communicator (mjpl_allgather_dev).
 """
 import argparse
 import json
@@ -34,6 +41,115 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles on a SIMD-32,
 # 4 SIMDs per CU, 256 CUs, 2.4 GHz max clock -> wave-instructions per second the chip can issue
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+FP64_VECTOR_PEAK = 78.6e12   # MI355X_MICROARCH.md: FP64 vector 78.6 TFLOP/s
+
+
+class World:
+    """This process's place among the ranks of one node, and -- once attached to an engine -- the
+    RCCL communicator the library opened for it: barrier / gather over mjpl_allgather_dev."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # MJPL_BENCH_FORCE_DIST=1: open the communicator with one rank too (exercises the path on one GPU)
+        self.distributed = self.world > 1 or os.environ.get("MJPL_BENCH_FORCE_DIST") == "1"
+        self.eng = None
+        self.uid = None
+
+    def _rendezvous_path(self):
+        p = os.environ.get("MJPL_BENCH_RDZV")
+        if p:
+            return p
+        # started by torch.distributed.run (or any launcher that sets RANK / WORLD_SIZE): all ranks of one
+        # launch share their parent process and the MASTER_PORT, two launches do not
+        return os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                            "mjpl_bench_%s_%s_%d.uid" % (os.environ.get("MASTER_PORT", "0"),
+                                                         os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
+
+    def unique_id(self):
+        """The ncclUniqueId of this launch: rank 0 asks the library for one and publishes it through a
+        file (written aside, then renamed: readers never see half of it); the others wait for it."""
+        if self.uid is not None:
+            return self.uid
+        from mjpl_amd import engine
+        path = self._rendezvous_path()
+        if self.rank == 0:
+            self.uid = engine.comm_unique_id()
+            if self.world > 1:
+                tmp = path + ".%d.tmp" % os.getpid()
+                with open(tmp, "wb") as f:
+                    f.write(self.uid)
+                os.replace(tmp, path)
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        self.uid = f.read()
+                    if len(self.uid) == 128:
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > 300:
+                    sys.exit(f"bench.py rank {self.rank}: no ncclUniqueId at {path} after 300 s")
+                time.sleep(0.01)
+        return self.uid
+
+    def attach(self, eng):
+        """Open the communicator on `eng` (collective over all ranks)."""
+        self.eng = eng
+        if not self.distributed:
+            return
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        eng.comm_init(self.unique_id(), self.rank, self.world)
+        self._buf = eng.alloc(8 * self.world)
+        self.gather(0.0)  # first collective: every rank has read the id by now
+        if self.rank == 0 and self.world > 1:
+            try:
+                os.remove(self._rendezvous_path())
+            except OSError:
+                pass
+
+    def gather(self, x: float) -> np.ndarray:
+        """All ranks' values of x, in rank order (one 8-byte all-gather; also a barrier)."""
+        if not self.distributed:
+            return np.array([float(x)])
+        mine = np.array([float(x)])
+        lib, h = self.eng.lib, self.eng.h
+        self.eng._ok(lib.mjpl_h2d(h, self._buf.ptr + 8 * self.rank, mine.ctypes.data, 8))
+        self.eng.allgather_dev(self._buf.ptr + 8 * self.rank, self._buf.ptr, 8)
+        return self._buf.download(np.float64, self.world)
+
+    def barrier(self):
+        self.eng.sync()
+        self.gather(0.0)
+
+    def close(self):
+        if self.distributed and self.eng is not None:
+            self.barrier()
+            self.eng.comm_destroy()
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N rank processes as children of this
+    one (which never touches a GPU), wait for them, pass rank 0's JSON line through."""
+    import subprocess
+    import tempfile
+    rdzv = os.path.join(tempfile.gettempdir(), "mjpl_bench_%d_%d.uid" % (os.getpid(), int(time.time() * 1e3) & 0xFFFFFF))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MJPL_BENCH_RDZV=rdzv,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    try:
+        os.remove(rdzv)
+    except OSError:
+        pass
+    return rc
 
 
 def make_edges(model, qidx, n, seed):
@@ -121,78 +237,106 @@ def cpu_baseline(model, qidx, base, qa, qb):
                       f"-ffp-contract=off), persistent pool of {cores} threads, 64-edge chunks"}, v, n
 
 
-def profile_record(kernel, E, layout):
+def profile_record(kernel, E, layout, filt=True, spec=True):
     """Counters of the committed rocprofv3 PMC passes of this same command (profiles/pmc.json,
-    written by tools/pmc_summary.py): HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950
-    correction of MI355X_MICROARCH.md "HBM") and wave-level instruction counts; {} if absent."""
+    written by tools/pmc_collect.py): HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950
+    correction of MI355X_MICROARCH.md "HBM") and wave-level instruction counts, keyed by the kernel AND
+    the engine configuration it was captured under (float32 filter on / off, specialised kernels on /
+    off): a record never speaks for another configuration's run.  {} if absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
-            return json.load(f).get("%s_%d_%s" % (kernel, E, layout), {})
+            return json.load(f).get("%s_%d_%s_f%d_s%d" % (kernel, E, layout, int(filt), int(spec)), {})
     except (OSError, ValueError):
         return {}
 
 
-def bench_configs(args):
-    """BASELINE configs[1] on one GPU: N = 65 536 Franka-P configurations, self-collision + floor,
-    q ~ U[jnt_range] (default_rng(1)), verdicts checked against the oracle on a sample."""
+def flop_record():
+    """The oracle's static operation count of one step of the headline workload (profiles/flops.json,
+    written by tools/count_flops.py from oracle/libmjpl_oracle_count.so); {} if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "flops.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def aggregate(world, n_units, steps, elapsed):
+    """Whole-job rate: the units all ranks processed / the slowest rank's time."""
+    slowest = float(world.gather(elapsed).max())
+    return n_units * world.world * steps / slowest, slowest
+
+
+def bench_configs(args, world):
+    """BASELINE configs[1], per GPU: N = 65 536 Franka-P configurations, self-collision + floor,
+    q ~ U[jnt_range] (default_rng(1 + rank)), verdicts checked against the oracle."""
     from mjpl_amd import engine, scenes
     model = scenes.franka_p(obstacles=False)
     qidx = scenes.planning_index(model, scenes.FRANKA_ARM_JOINTS)
     base = model.keyframe("home").qpos.copy()
-    eng = engine.Engine(model)
+    eng = engine.Engine(model, device=world.local_rank)
     eng.set_planning(qidx, base)
+    world.attach(eng)
     N = 65536
-    Q = np.random.default_rng(1).uniform(model.jnt_range[qidx, 0], model.jnt_range[qidx, 1], size=(N, len(qidx)))
+    Q = np.random.default_rng(1 + world.rank).uniform(model.jnt_range[qidx, 0], model.jnt_range[qidx, 1], size=(N, len(qidx)))
     h = np.ascontiguousarray(Q.T)
     dq, dv = eng.alloc(h.nbytes).upload(h), eng.alloc(N)
     if args.warmup > 0:
         eng.time_configs_dev(dq.ptr, N, engine.SOA, dv.ptr, args.warmup)
-    eng.sync()
+    world.barrier()
     t0 = time.perf_counter()
     ms = eng.time_configs_dev(dq.ptr, N, engine.SOA, dv.ptr, args.steps)
+    world.barrier()
     elapsed = time.perf_counter() - t0
+    value, slowest = aggregate(world, N, args.steps, elapsed)
     valid = dv.download(np.uint8, N)
-    out = {"metric": "validated configurations/sec, Franka-P self-collision (BASELINE configs[1])",
-           "value": N * args.steps / elapsed, "unit": "configs/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32-filter+f64-exact" if eng.info()["filter_enabled"] else "f64", "data": "synthetic",
-           "config": {"workload": f"configs[1]: Franka-P 7-DoF, self-collision + floor, {N} configurations/launch",
-                      "valid_fraction": float(valid.mean()), "step_ms_hip_events": float(np.mean(ms))},
-           "roofline": {"bound": "hbm", "achieved": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "note": "57 algorithmic bytes per configuration; ALU/issue bound"}}
-    if not args.no_cpu_baseline:
-        from oracle import pyoracle
-        orc = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
-        cores = host_cpu()[1]  # (the cores this process may use: cgroup quota, affinity)
-        t0 = time.perf_counter()
-        v = orc.valid_configs(Q, nthreads=cores)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": N / dt, "unit": "configs/s", "cores": cores, "kind": "port",
-                               "sample": f"one pass over the {N} configurations, {cores} pthreads"}
-        if not np.array_equal(v.astype(np.uint8), valid):
-            sys.exit("bench.py: GPU verdicts differ from the CPU oracle")
-    print(json.dumps(out), flush=True)
+    if world.rank == 0:
+        out = {"metric": "validated configurations/sec, Franka-P self-collision (BASELINE configs[1])",
+               "value": value, "unit": "configs/s", "n_gpus": world.world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": slowest / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32-filter+f64-exact" if eng.info()["filter_enabled"] else "f64", "data": "synthetic",
+               "config": {"workload": f"configs[1]: Franka-P 7-DoF, self-collision + floor, {N} configurations/launch/GPU",
+                          "valid_fraction": float(valid.mean()), "step_ms_hip_events": float(np.mean(ms)),
+                          "parallelism": f"configuration-sharded x{world.world}, no data-path collective"},
+               "roofline": {"bound": "hbm", "achieved": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "note": "57 algorithmic bytes per configuration; ALU/issue bound"}}
+        if not args.no_cpu_baseline:
+            from oracle import pyoracle
+            orc = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
+            cores = host_cpu()[1]  # (the cores this process may use: cgroup quota, affinity)
+            t0 = time.perf_counter()
+            v = orc.valid_configs(Q, nthreads=cores)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": N / dt, "unit": "configs/s", "cores": cores, "kind": "port",
+                                   "sample": f"one pass over rank 0's {N} configurations, {cores} pthreads"}
+            if not np.array_equal(v.astype(np.uint8), valid):
+                sys.exit("bench.py: GPU verdicts differ from the CPU oracle")
+        _flush_c_stdio()
+        print(json.dumps(out), flush=True)
+    world.close()
+    return 0
 
 
-def bench_next_rows(args):
+def bench_next_rows(args, world):
     """One GPU's share of BASELINE configs[3] (PoseConstraint projections of 1 M / 8 samples) or
-    configs[4] (128k / 8 IK seeds -> FK -> collision filter); device-resident inputs for the
-    projection, host buffers (PCIe included) for the IK seeds.  Results are checked against the
-    oracle on a sample."""
+    configs[4] (128k / 8 IK seeds -> FK -> collision filter) on every rank; device-resident inputs for
+    the projection, host buffers (PCIe included) for the IK seeds.  Independent units: no data-path
+    collective.  Rank 0's results are checked against the oracle on a sample."""
     import mjpl_amd as mjpl
     from mjpl_amd import scenes
     from oracle import pyoracle
     model = scenes.franka_p(obstacles=True)
     joints = scenes.FRANKA_ARM_JOINTS
     q_home = model.keyframe("home").qpos.copy()
-    cc = mjpl.CollisionConstraint(model)
+    cc = mjpl.CollisionConstraint(model, device=world.local_rank)
     eng = cc.engine
+    world.attach(eng)
     lo, hi = model.jnt_range[:, 0], model.jnt_range[:, 1]
-    rng = np.random.default_rng(4)
-    common = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+    rng = np.random.default_rng(4 + world.rank)
+    common = {"n_gpus": world.world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
               "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    sharded = f"sharded x{world.world}, no data-path collective"
     if args.workload == "pose":
         frame = mjpl.site_pose(model, q_home, "ee_site", engine=eng)
         pc = mjpl.PoseConstraint(model, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), q_step=0.5, engine=eng)
@@ -205,39 +349,43 @@ def bench_next_rows(args):
         dout, dok, dit = eng.alloc(Q.nbytes), eng.alloc(n), eng.alloc(4 * n)
         for _ in range(max(args.warmup, 1)):
             pc._proj.apply_dev(dqo.ptr, dq.ptr, n, dout.ptr, dok.ptr, dit.ptr)
-        eng.sync()
+        world.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             pc._proj.apply_dev(dqo.ptr, dq.ptr, n, dout.ptr, dok.ptr, dit.ptr)
-        eng.sync()
+        world.barrier()
         elapsed = time.perf_counter() - t0
-        out_q, ok, iters = dout.download(np.float64, n * model.nq).reshape(n, -1), dok.download(np.uint8, n), dit.download(np.int32, n)
-        inv = frame.inverse()
-        po = pyoracle.PoseOracle(model, "ee_site", (inv.wxyz_xyz[:4], inv.wxyz_xyz[4:]),
-                                 [(-np.inf, np.inf)] * 3 + [(-0.1, 0.1)] * 2 + [(-np.inf, np.inf)], q_step=0.5)
-        k = 8192
-        cores = host_cpu()[1]
-        t0 = time.perf_counter()
-        ref, rok, rit = po.apply_batch(Q_old[:k], Q[:k], nthreads=cores)
-        dtc = time.perf_counter() - t0
-        same = (rok == ok[:k].astype(bool)) & (rit == iters[:k])
-        if same.mean() < 0.99 or np.abs(ref[same] - out_q[:k][same]).max() > 1e-8:
-            sys.exit("bench.py: GPU projections differ from the CPU oracle")
-        out = dict(common, metric="PoseConstraint projections/sec, Franka-P ee roll/pitch +-0.1 (one GPU of configs[3])",
-                   value=n * args.steps / elapsed, unit="rows/s", ms_per_step=elapsed / args.steps * 1e3,
-                   config={"workload": f"{n} rows per launch, {np.abs(iters).mean():.1f} projection steps per row on average",
-                           "accepted_fraction": float(ok.mean())},
-                   roofline={"bound": "hbm", "achieved": n * (2 * 8 * model.nq + 8 * model.nq + 1) * args.steps / elapsed / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": n * (3 * 8 * model.nq + 1) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "note": "FP64 issue / latency bound (FK + Jacobian + a certified 6x6 Cholesky solve per projection step; eigen-decomposition only near singularities)"},
-                   cpu_baseline={"value": k / dtc, "unit": "rows/s", "cores": cores, "kind": "port",
-                                 "sample": f"first {k} rows, {cores} pthreads"})
+        value, slowest = aggregate(world, n, args.steps, elapsed)
+        out = None
+        if world.rank == 0:
+            out_q, ok, iters = dout.download(np.float64, n * model.nq).reshape(n, -1), dok.download(np.uint8, n), dit.download(np.int32, n)
+            inv = frame.inverse()
+            po = pyoracle.PoseOracle(model, "ee_site", (inv.wxyz_xyz[:4], inv.wxyz_xyz[4:]),
+                                     [(-np.inf, np.inf)] * 3 + [(-0.1, 0.1)] * 2 + [(-np.inf, np.inf)], q_step=0.5)
+            k = 8192
+            cores = host_cpu()[1]
+            t0 = time.perf_counter()
+            ref, rok, rit = po.apply_batch(Q_old[:k], Q[:k], nthreads=cores)
+            dtc = time.perf_counter() - t0
+            same = (rok == ok[:k].astype(bool)) & (rit == iters[:k])
+            if same.mean() < 0.99 or np.abs(ref[same] - out_q[:k][same]).max() > 1e-8:
+                sys.exit("bench.py: GPU projections differ from the CPU oracle")
+            row_bytes = 3 * 8 * model.nq + 1
+            out = dict(common, metric="PoseConstraint projections/sec, Franka-P ee roll/pitch +-0.1 (one GPU's share of configs[3] per rank)",
+                       value=value, unit="rows/s", ms_per_step=slowest / args.steps * 1e3,
+                       config={"workload": f"{n} rows per launch per GPU, {np.abs(iters).mean():.1f} projection steps per row on average",
+                               "accepted_fraction": float(ok.mean()), "parallelism": "row-" + sharded},
+                       roofline={"bound": "hbm", "achieved": n * row_bytes * args.steps / elapsed / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": n * row_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "note": "FP64 issue / latency bound (FK + Jacobian + a certified 6x6 Cholesky solve per projection step; eigen-decomposition only near singularities)"},
+                       cpu_baseline={"value": k / dtc, "unit": "rows/s", "cores": cores, "kind": "port",
+                                     "sample": f"first {k} rows of rank 0, {cores} pthreads"})
     else:
-        solver = mjpl.HipIKSolver(model, joints, [], seed=3, num_seeds=16384, iterations=200, engine=eng)
+        solver = mjpl.HipIKSolver(model, joints, [], seed=3 + world.rank, num_seeds=16384, iterations=200, engine=eng)
         q_t = mjpl.random_config(model, q_home, joints, 5, [mjpl.JointLimitConstraint(model), cc])
         target = mjpl.site_pose(model, q_t, "ee_site", engine=eng)
-        Q0 = solver._seeds(q_home, np.random.default_rng(3))
+        Q0 = solver._seeds(q_home, np.random.default_rng(3 + world.rank))
 
         def once():
             Qs, ok, its, err = eng.ik_solve("ee_site", target.translation(), target.rotation().wxyz, Q0, solver.movable,
@@ -246,38 +394,47 @@ def bench_next_rows(args):
 
         for _ in range(max(args.warmup, 1)):
             once()
+        world.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             Qs, ok, its, free = once()
+        world.barrier()
         elapsed = time.perf_counter() - t0
-        orc = pyoracle.Oracle(model)
-        sample = np.flatnonzero(ok)[:2048]
-        if not np.array_equal(orc.valid_configs(Qs[sample], nthreads=8).astype(bool), free[:len(sample)]):
-            sys.exit("bench.py: collision filter differs from the CPU oracle")
-        # CPU baseline: the oracle's statement of the same iteration on a bounded sample of the seeds
-        cpu, cores, aff, quota = host_cpu()
-        k = 2048
-        t0 = time.perf_counter()
-        Qc, okc, itc, _ = pyoracle.ik_solve_batch(model, "ee_site", target.translation(), target.rotation().wxyz, Q0[:k],
-                                                  solver.movable, iterations=200, restarts=8, restart_seed=11, nthreads=cores)
-        freec = orc.valid_configs(Qc[okc], nthreads=cores)
-        dtc = time.perf_counter() - t0
-        if abs(float(okc.mean()) - float(ok[:k].mean())) > 0.05:
-            sys.exit("bench.py: GPU and CPU IK converge on different fractions of the same seeds")
-        cpu_ik = {"value": k / dtc, "unit": "seeds/s", "cores": cores, "kind": "port", "cpu_model": cpu, "affinity": aff,
-                  "cpu_quota": quota, "sample": f"first {k} seeds, {cores} threads, converged {okc.mean():.3f} "
-                                                f"(GPU on the same rows {ok[:k].mean():.3f}), {len(freec)} collision checks"}
-        out = dict(common, metric="IK seeds/sec: damped-least-squares seeds -> FK -> collision filter (one GPU of configs[4])",
-                   value=len(Q0) * args.steps / elapsed, unit="seeds/s", ms_per_step=elapsed / args.steps * 1e3,
-                   config={"workload": f"{len(Q0)} seeds per launch, <= 200 iterations, host buffers (PCIe included)",
-                           "converged_fraction": float(ok.mean()), "collision_free_of_converged": float(free.mean()),
-                           "mean_iterations": float(its.mean())},
-                   roofline={"bound": "hbm", "achieved": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "note": "latency of the iteration chain (256 waves on 1 024 SIMDs)"},
-                   cpu_baseline=cpu_ik)
-    print(json.dumps(out), flush=True)
+        value, slowest = aggregate(world, len(Q0), args.steps, elapsed)
+        out = None
+        if world.rank == 0:
+            orc = pyoracle.Oracle(model)
+            sample = np.flatnonzero(ok)[:2048]
+            if not np.array_equal(orc.valid_configs(Qs[sample], nthreads=8).astype(bool), free[:len(sample)]):
+                sys.exit("bench.py: collision filter differs from the CPU oracle")
+            # CPU baseline: the oracle's statement of the same iteration on a bounded sample of the seeds
+            cpu, cores, aff, quota = host_cpu()
+            k = 2048
+            t0 = time.perf_counter()
+            Qc, okc, itc, _ = pyoracle.ik_solve_batch(model, "ee_site", target.translation(), target.rotation().wxyz, Q0[:k],
+                                                      solver.movable, iterations=200, restarts=8, restart_seed=11, nthreads=cores)
+            freec = orc.valid_configs(Qc[okc], nthreads=cores)
+            dtc = time.perf_counter() - t0
+            if abs(float(okc.mean()) - float(ok[:k].mean())) > 0.05:
+                sys.exit("bench.py: GPU and CPU IK converge on different fractions of the same seeds")
+            cpu_ik = {"value": k / dtc, "unit": "seeds/s", "cores": cores, "kind": "port", "cpu_model": cpu, "affinity": aff,
+                      "cpu_quota": quota, "sample": f"first {k} seeds of rank 0, {cores} threads, converged {okc.mean():.3f} "
+                                                    f"(GPU on the same rows {ok[:k].mean():.3f}), {len(freec)} collision checks"}
+            out = dict(common, metric="IK seeds/sec: damped-least-squares seeds -> FK -> collision filter (one GPU's share of configs[4] per rank)",
+                       value=value, unit="seeds/s", ms_per_step=slowest / args.steps * 1e3,
+                       config={"workload": f"{len(Q0)} seeds per launch per GPU, <= 200 iterations, host buffers (PCIe included)",
+                               "converged_fraction": float(ok.mean()), "collision_free_of_converged": float(free.mean()),
+                               "mean_iterations": float(its.mean()), "parallelism": "seed-" + sharded},
+                       roofline={"bound": "hbm", "achieved": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "note": "latency of the iteration chain (256 waves on 1 024 SIMDs)"},
+                       cpu_baseline=cpu_ik)
+    if out is not None:
+        _flush_c_stdio()
+        print(json.dumps(out), flush=True)
+    world.close()
+    return 0
 
 
 def _flush_c_stdio():
@@ -290,63 +447,154 @@ def _flush_c_stdio():
         pass
 
 
-def bench_rrt(args):
-    """One GPU's share of BASELINE configs[3] as the planner runs it (not the headline): rounds of
-    `mjpl_rrt_round` -- sample, nearest, extend with projection, validate, connect, exchange over a
-    one-rank RCCL communicator -- with 131 072 lanes.  A step is one round; round 1 (empty trees)
-    is the warm-up.  The path any round reports is checked against the oracle."""
+def bench_rrt(args, world):
+    """BASELINE configs[3] as the planner runs it (not the headline): rounds of `mjpl_rrt_round` --
+    sample, nearest, extend with projection, validate, connect, then the exchange of every rank's new
+    nodes over the RCCL communicator -- with 131 072 lanes PER RANK (weak scaling: 8 ranks = the 1 M
+    samples per round of configs[3]).  All ranks hold the same two trees after every round.  A step is
+    one round; round 1 (single-node trees) is the warm-up.  The path a round reports is checked
+    against the oracle on rank 0."""
     import mjpl_amd as mjpl
-    from mjpl_amd import engine as eng_mod
     from mjpl_amd import scenes
     from oracle import pyoracle
-    L = 131072
+    L = args.lanes
     rounds = args.steps if args.steps != 2000 else 5
     m = scenes.franka_p(obstacles=True)
     joints = scenes.FRANKA_ARM_JOINTS
     qidx = scenes.planning_index(m, joints)
     q_init = m.keyframe("home").qpos.copy()
-    cc = mjpl.CollisionConstraint(m)
+    cc = mjpl.CollisionConstraint(m, device=world.local_rank)
     frame = mjpl.site_pose(m, q_init, "ee_site", engine=cc.engine)
     pc = mjpl.PoseConstraint(m, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), engine=cc.engine)
     cons = [pc, mjpl.JointLimitConstraint(m), cc]
     pc.q_step = np.inf
     q_goal = mjpl.random_config(m, q_init, joints, 7, cons)
     pc.q_step = 0.05
+    world.distributed = True  # (the exchange always runs through a communicator here, one rank included)
     dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=3, goal_biasing_probability=0.05,
-                           batch=L, capacity=1 << 24, pose=pc, comm=(eng_mod.comm_unique_id(), 0, 1))
+                           batch=L, capacity=args.capacity, pose=pc, comm=(world.unique_id(), world.rank, world.world))
+    world.eng = cc.engine
+    world._buf = cc.engine.alloc(8 * world.world)
+    world.gather(0.0)
     dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 3)
     info = dev.rrt.round()  # warm-up: the first round grows from two single-node trees
-    rows, new_nodes = [], 0
+    rows, new_nodes, exch = [], 0, []
+    nplan = len(qidx)
+    world.barrier()
     t0 = time.perf_counter()
     for _ in range(rounds):
         t1 = time.perf_counter()
         info = dev.rrt.round()
         rows.append((time.perf_counter() - t1) * 1e3)
-        new_nodes += int(info.new_nodes[0]) + int(info.new_nodes[1])
+        nn = int(info.new_nodes[0]) + int(info.new_nodes[1])
+        new_nodes += nn
+        exch.append(nn * (8 * nplan + 4) + 32 * world.world)  # rows + parents of every rank's slabs, + the headers
+        if info.connected:
+            break
+    world.barrier()
     elapsed = time.perf_counter() - t0
+    done = len(rows)
+    slowest = float(world.gather(elapsed).max())
     path_ok = None
-    if info.connected:
-        path = dev.rrt.path()
-        full = np.repeat(q_init[None, :], len(path), axis=0)
-        full[:, qidx] = path
-        orc = pyoracle.Oracle(m, planning_qidx=qidx, qpos_base=q_init)
-        ok_edges = orc.valid_edges(path[:-1], path[1:], 0.01, nthreads=8)
-        path_ok = bool(ok_edges.all() and np.all(pc.valid_configs(full)))
-        if not path_ok:
-            raise SystemExit("bench: the planner's path fails the oracle's collision check / the pose constraint")
-    _flush_c_stdio()
-    print(json.dumps({
-        "metric": "RRT samples/sec through the frontier bi-RRT, one GPU's share of BASELINE configs[3]",
-        "value": L * rounds / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": rounds, "warmup": 1,
-        "ms_per_step": elapsed / rounds * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 planner + f32-filter+f64-exact validation", "data": "synthetic",
-        "config": {"workload": f"{L} lanes per round, [PoseConstraint(roll, pitch +-0.1), JointLimit, Collision], "
-                               "eps 0.05, interval 0.01, Franka-P + 16 obstacles, one-rank RCCL exchange per round",
-                   "round_ms": rows, "new_nodes_per_s": new_nodes / elapsed,
-                   "nodes": [int(info.nodes[0]), int(info.nodes[1])], "connected": bool(info.connected),
-                   "path_checked_against_oracle": path_ok}}))
+    if world.rank == 0:
+        if info.connected:
+            path = dev.rrt.path()
+            full = np.repeat(q_init[None, :], len(path), axis=0)
+            full[:, qidx] = path
+            orc = pyoracle.Oracle(m, planning_qidx=qidx, qpos_base=q_init)
+            ok_edges = orc.valid_edges(path[:-1], path[1:], 0.01, nthreads=8)
+            path_ok = bool(ok_edges.all() and np.all(pc.valid_configs(full)))
+            if not path_ok:
+                raise SystemExit("bench: the planner's path fails the oracle's collision check / the pose constraint")
+        _flush_c_stdio()
+        print(json.dumps({
+            "metric": "RRT samples/sec through the frontier bi-RRT (BASELINE configs[3]: 131 072 samples per GPU per round)",
+            "value": L * world.world * done / slowest, "unit": "samples/s", "n_gpus": world.world, "steps": done, "warmup": 1,
+            "ms_per_step": slowest / done * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 planner + f32-filter+f64-exact validation", "data": "synthetic",
+            "config": {"workload": f"{L} lanes per rank per round, [PoseConstraint(roll, pitch +-0.1), JointLimit, Collision], "
+                                   "eps 0.05, interval 0.01, Franka-P + 16 obstacles, RCCL all-gather of the new nodes per round",
+                       "rccl_ranks": world.world, "round_ms": rows, "exchange_bytes_per_round": exch,
+                       "new_nodes_per_s": new_nodes / slowest,
+                       "nodes": [int(info.nodes[0]), int(info.nodes[1])], "connected": bool(info.connected),
+                       "connecting_rank": int(info.conn_rank) if info.connected else None,
+                       "path_checked_against_oracle": path_ok,
+                       "parallelism": f"frontier-sharded x{world.world}: every rank samples and extends its own lanes, "
+                                      "one all-gather of headers + two of slabs per round"}}), flush=True)
+    world.barrier()
     dev.rrt.close()
+    cc.engine.comm_destroy()
     return 0
+
+
+def bench_plan(args, world):
+    """examples/benchmark.py's loop in the reference's shape (/root/reference/examples/benchmark.py:28-48,
+    83-91: 15 attempts, epsilon 0.05, seed 42, goal bias 0.1, 10 s limit, pose goal through IK, constraints
+    = joint limits + collision) on the device-resident frontier planner, Franka-P + 16 obstacles; every
+    returned path checked against the oracle.  Beside it, as the CPU baseline: the serial `RRT` with the
+    reference's step-by-step extension, every configuration validated by the CPU oracle (the role MuJoCo
+    has in the reference), on a bounded sample of the same attempts.  Replicas only across ranks."""
+    from oracle import pyoracle
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import benchmark as harness
+    from mjpl_amd import scenes
+    from mjpl_amd.constraint import Constraint
+    attempts = 15 if args.steps == 2000 else args.steps
+    model = scenes.franka_p(obstacles=True)
+    orc = pyoracle.Oracle(model)
+
+    def check_path(path):
+        P = np.stack(path)
+        return bool(orc.valid_configs(P, nthreads=4).all() and
+                    np.all((P >= model.jnt_range[:, 0] - 1e-12) & (P <= model.jnt_range[:, 1] + 1e-12)) and
+                    np.linalg.norm(np.diff(P, axis=0), axis=1).max() <= 0.05 + 1e-9)
+
+    harness.run(planner="device", attempts=1, obstacles=True, device=world.local_rank, quiet=True)  # warm-up
+    res = harness.run(planner="device", attempts=attempts, obstacles=True, device=world.local_rank, quiet=True, check_path=check_path)
+    if world.rank == 0:
+        if not res["paths_valid"]:
+            sys.exit("bench.py: a planned path fails the oracle's checks")
+        cpu = None
+        if not args.no_cpu_baseline:
+            class OracleCollision(Constraint):  # (cpu_baseline leg: the oracle behind the Constraint interface)
+                def valid_config(self, q):
+                    return orc.valid_config(q)
+
+                def apply(self, q_old, q):
+                    return q if orc.valid_config(q) else None
+
+            k = min(3, attempts)
+            cres = harness.run(planner="rrt", attempts=k, obstacles=True, device=world.local_rank, quiet=True,
+                               collision=OracleCollision(), check_path=check_path)
+            cpu = {"value": float(np.median(cres["planning_times"])) if cres["planning_times"] else None,
+                   "unit": "s (median planning time)", "cores": 1, "kind": "port",
+                   "sample": f"first {k} attempts: serial RRT, step-by-step _constrained_extend, every configuration "
+                             "validated by oracle/libmjpl_oracle.so on one thread (IK seeds from the batched solver)",
+                   "successes": int(cres["successes"]), "attempts": k}
+        times = res["planning_times"]
+        out = {"metric": "median planning time, examples/benchmark.py in the reference's shape (Franka-P + 16 obstacles, pose goal)",
+               "value": float(np.median(times)) if times else None, "unit": "s", "n_gpus": world.world, "steps": attempts, "warmup": 1,
+               "ms_per_step": float(np.mean(times)) * 1e3 if times else None, "higher_is_better": False, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64 planner + f32-filter+f64-exact validation", "data": "synthetic",
+               "config": {"workload": f"{attempts} attempts of plan_to_pose, epsilon 0.05, seed 42, goal bias 0.1, 10 s limit, "
+                                      "512 lanes per round, constraints [JointLimit, Collision]",
+                          "successes": int(res["successes"]), "attempts": attempts,
+                          "success_rate": res["successes"] / attempts,
+                          "paths_checked_against_oracle": bool(res["paths_valid"]),
+                          "planning_times_s": [float(t) for t in times], "parallelism": "replicas only"},
+               "cpu_baseline": cpu}
+        _flush_c_stdio()
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+def time_variant(eng, engine, dqa, dqb, E, layout, dvalid, steps, warmup):
+    if warmup > 0:
+        eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, warmup, 1 << 30)
+    eng.sync()
+    t0 = time.perf_counter()
+    launch_ms, stage_ms, nsamp = eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, steps, 4)
+    return time.perf_counter() - t0, launch_ms, stage_ms, nsamp
 
 
 def main():
@@ -358,47 +606,57 @@ def main():
     ap.add_argument("--edges", type=int, default=EDGES_PER_GPU)
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["edges", "configs", "pose", "ik", "rrt"], default="edges",
+    ap.add_argument("--no-variants", action="store_true",
+                    help="edges workload: skip the float64-only and interpreter engines timed beside the headline")
+    ap.add_argument("--variant", choices=["headline", "f64", "interpreter"], default="headline",
+                    help="edges workload: which engine configuration the TIMED steps run (profiling passes of the "
+                         "variants: tools/profile_gpu.sh); the default line carries all three")
+    ap.add_argument("--lanes", type=int, default=131072, help="rrt workload: lanes per rank per round")
+    ap.add_argument("--capacity", type=int, default=1 << 24, help="rrt workload: node capacity per tree")
+    ap.add_argument("--workload", choices=["edges", "configs", "pose", "ik", "rrt", "plan"], default="edges",
                     help="edges: the headline metric (BASELINE configs[2]).  Extra lines, not the headline: "
                          "configs = configs[1], 65 536 Franka-P self-collision configurations per launch; "
                          "pose = one GPU's share of configs[3], 131 072 PoseConstraint projections; "
                          "ik = one GPU's share of configs[4], 16 384 IK seeds -> FK -> collision filter; "
-                         "rrt = one GPU's share of configs[3] as the planner runs it: rounds of the device-resident "
-                         "frontier bi-RRT, 131 072 samples each, [PoseConstraint, JointLimit, Collision], through a "
-                         "one-rank RCCL communicator (--steps = timed rounds, default 5)")
+                         "rrt = configs[3] as the planner runs it: rounds of the device-resident frontier bi-RRT, "
+                         "131 072 samples per rank each, [PoseConstraint, JointLimit, Collision], new nodes exchanged "
+                         "over RCCL (--steps = timed rounds, default 5); plan = examples/benchmark.py's 15 attempts")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args.gpus)  # (this process never touches a GPU)
+    world = World()
+    if world.world != args.gpus:
+        args.gpus = world.world
+
     if args.workload == "configs":
-        return bench_configs(args)
+        return bench_configs(args, world)
     if args.workload in ("pose", "ik"):
-        return bench_next_rows(args)
+        return bench_next_rows(args, world)
     if args.workload == "rrt":
-        return bench_rrt(args)
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-
-    dist = torch = None
-    # MJPL_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, barrier, max-reduce) even
-    # with one rank, to exercise it on a single-GPU box
-    if world > 1 or os.environ.get("MJPL_BENCH_FORCE_DIST") == "1":
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        return bench_rrt(args, world)
+    if args.workload == "plan":
+        return bench_plan(args, world)
 
     from mjpl_amd import engine, scenes
 
+    rank = world.rank
     model = scenes.franka_p(obstacles=True)
     qidx = scenes.planning_index(model, scenes.FRANKA_ARM_JOINTS)
     base = model.keyframe("home").qpos.copy()
-    eng = engine.Engine(model, device=local_rank)
-    eng.set_planning(qidx, base)
+
+    def make_engine(filt=True, spec=True):
+        e = engine.Engine(model, device=world.local_rank)
+        if not spec:
+            e.set_spec(False)
+        e.set_planning(qidx, base)
+        if not filt:
+            e.set_filter(False)
+        return e
+
+    timed = {"headline": (True, True), "f64": (False, True), "interpreter": (True, False)}[args.variant]
+    eng = make_engine(*timed)
+    world.attach(eng)
     info = eng.info()
 
     E = args.edges
@@ -410,36 +668,29 @@ def main():
     dvalid = eng.alloc(E)
     eng.sync()
 
-    def barrier():
-        eng.sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-
     # warmup (untimed)
     if args.warmup > 0:
         eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, args.warmup, 1 << 30)
-    barrier()
+    world.barrier()
     t0 = time.perf_counter()
     # EXACTLY args.steps launches, back to back on the engine's stream; every 4th one also carries
     # one HIP event after each of its kernels (the per-kernel durations roofline.achieved uses)
     launch_ms, stage_ms, nsamp = eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr,
                                                            args.steps, 4)  # syncs
-    barrier()
+    world.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = float(world.gather(elapsed).max())
 
     valid = dvalid.download(np.uint8, E)
 
     if rank == 0:
-        total_edges = E * world * args.steps
+        total_edges = E * world.world * args.steps
         value = total_edges / elapsed
         filt = bool(info["filter_enabled"])
+        spec = bool(eng.spec_loaded())
         interior = eng.last_interior_edges() if filt else 0
         items = eng.last_items() if filt else 0
+        undecided = eng.last_undecided()
         # units and SURVEY.md 8(d) algorithmic bytes of every kernel of a step:
         #   endpoint pass: one edge = 2 x 56 B of columns read + 1 B verdict (113 B)
         #   item pass:     one waypoint configuration = 56 B + 1 B (57 B per check) + its 8 B (edge, index)
@@ -447,18 +698,18 @@ def main():
         per_stage = {"k_filter_endpoints": (E, BYTES_PER_EDGE, "edges"),
                      "k_filter_items": (items, 57 + 8, "waypoint configurations"),
                      "k_filter_edges": (max(interior - 0, 0) if items == 0 else 0, BYTES_PER_EDGE + 4, "edges"),
-                     "k_patch_pairs": (eng.last_undecided(), 56 + 16, "undecided geom pairs"),
+                     "k_patch_pairs": (undecided, 56 + 16, "undecided geom pairs"),
                      "k_check_edges": (E if not filt else 0, BYTES_PER_EDGE, "edges")}
         # the dominant kernel of THIS run = the longest stage
         kernel = max(stage_ms, key=lambda k: stage_ms[k])
         kernel_ms = stage_ms[kernel]
         units, unit_bytes, unit_name = per_stage[kernel]
         achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9
-        prof = profile_record(kernel, E, args.layout)
+        prof = profile_record(kernel, E, args.layout, filt, spec)
         workload = (f"configs[2]: Franka-P 7-DoF + 16 box/sphere obstacles + floor, {E} edges/GPU, "
                     f"eps {EPS}, step {STEP} (endpoint + interior waypoints per edge)")
         out = {
-            "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world,
+            "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # what ran: a binary32 filter decides what it can within its tolerance band, binary64
@@ -468,10 +719,14 @@ def main():
             "config": {"workload": workload, "edges_per_gpu": E, "layout": args.layout,
                        "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
                        "float32_filter": filt, "filter_tol_m": info["filter_tol"],
-                       "specialised_kernels": eng.spec_loaded(),
-                       "undecided_items_last_step": eng.last_undecided(),
+                       "specialised_kernels": spec,
+                       "undecided_items_last_step": undecided,
                        "edges_reaching_interior_pass": interior, "interior_waypoint_items": items,
-                       "parallelism": f"edge-sharded x{world}, no data-path collective"},
+                       "parallelism": f"edge-sharded x{world.world}, no data-path collective",
+                       "rank_launcher": ("bench.py (child processes)" if os.environ.get("MJPL_BENCH_RDZV") else
+                                         ("external (RANK / WORLD_SIZE)" if world.world > 1 else "single process")),
+                       "collectives": "mjpl_comm_* (RCCL opened by libmjpl_hip.so): barrier + max of the elapsed time only"
+                                      if world.distributed else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": prof.get("hbm_bytes_per_launch"),
@@ -486,18 +741,55 @@ def main():
         }
         # vector-ALU issue occupancy of the dominant kernel, from the committed counter pass:
         # SQ_INSTS_VALU wave-instructions per launch / (kernel time x issue slots per second)
-        if prof.get("SQ_INSTS_VALU"):
-            iv = float(prof["SQ_INSTS_VALU"])
-            out["valu_issue"] = {"kernel": kernel, "wave_insts_valu_per_launch": iv,
-                                 "wave_insts_salu_per_launch": prof.get("SQ_INSTS_SALU"),
-                                 "achieved_per_s": iv / (kernel_ms * 1e-3), "peak_per_s": VALU_ISSUE_PEAK,
-                                 "frac": iv / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK,
-                                 "source": prof.get("source"),
-                                 "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU "
-                                         "instruction (MI355X_MICROARCH.md, Wave scheduling)"}
-        else:
-            out["valu_issue"] = None
-        if world == 1 and not args.no_cpu_baseline:
+        def valu_issue(kern, ms, rec):
+            if not rec.get("SQ_INSTS_VALU"):
+                return None
+            iv = float(rec["SQ_INSTS_VALU"])
+            return {"kernel": kern, "wave_insts_valu_per_launch": iv,
+                    "wave_insts_salu_per_launch": rec.get("SQ_INSTS_SALU"),
+                    "achieved_per_s": iv / (ms * 1e-3), "peak_per_s": VALU_ISSUE_PEAK,
+                    "frac": iv / (ms * 1e-3) / VALU_ISSUE_PEAK, "source": rec.get("source"),
+                    "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU "
+                            "instruction (MI355X_MICROARCH.md, Wave scheduling)"}
+        out["valu_issue"] = valu_issue(kernel, kernel_ms, prof)
+
+        # ---- the same batch through the other two engine configurations, in this process: the float64
+        # kernels alone (the reference's arithmetic end to end) and the generic interpreting filter kernels
+        # (what a model without a specialised library runs).  Same verdicts required, all E of them.
+        flops = flop_record()
+        if world.world == 1 and not args.no_variants and args.variant == "headline":
+            variants = {}
+            vsteps = max(50, min(args.steps, 200))
+            for name, (vf, vs) in (("f64_only", (False, True)), ("interpreter", (True, False))):
+                ve = make_engine(vf, vs)
+                va, vb, vv = ve.alloc(ha.nbytes).upload(ha), ve.alloc(hb.nbytes).upload(hb), ve.alloc(E)
+                dt, v_launch, v_stage, v_n = time_variant(ve, engine, va, vb, E, layout, vv, vsteps, 5)
+                same = bool(np.array_equal(vv.download(np.uint8, E), valid))
+                if not same:
+                    sys.exit(f"bench.py: the {name} engine's verdicts differ from the headline engine's")
+                vk = max(v_stage, key=lambda k: v_stage[k])
+                rec = profile_record(vk, E, args.layout, vf, vs and bool(ve.spec_loaded()))
+                variants[name] = {"value": E * vsteps / dt, "unit": "edges/s", "steps": vsteps, "ms_per_step": dt / vsteps * 1e3,
+                                  "step_ms_all_kernels": v_launch, "kernels_ms": v_stage, "dtype": "f64" if not vf else "f32-filter+f64-exact",
+                                  "float32_filter": bool(ve.info()["filter_enabled"]), "specialised_kernels": bool(ve.spec_loaded()),
+                                  "verdicts_equal_headline": same, "edges_compared": E,
+                                  "valu_issue": valu_issue(vk, v_stage[vk], rec)}
+                if name == "f64_only" and flops.get("flops_per_edge"):
+                    fpe = float(flops["flops_per_edge"])
+                    variants[name]["achieved_FP64_fraction"] = E * fpe / (v_launch * 1e-3) / FP64_VECTOR_PEAK
+                    variants[name]["fp64"] = {"flops_per_edge": fpe, "achieved_TFLOPs": E * fpe / (v_launch * 1e-3) / 1e12,
+                                              "peak_TFLOPs": FP64_VECTOR_PEAK / 1e12, "source": flops.get("source")}
+                for b in (va, vb, vv):
+                    b.free()
+                ve.close()
+            out["variants"] = variants
+        if flops.get("flops_per_edge"):
+            # the float32 filter does the same geometry in binary32: the float64-equivalent rate is reported for scale
+            out["fp64_equivalent"] = {"flops_per_edge": flops["flops_per_edge"],
+                                      "rate_TFLOPs": value * float(flops["flops_per_edge"]) / 1e12,
+                                      "note": "oracle operation count x edges/s; the filter executes these in binary32",
+                                      "source": flops.get("source")}
+        if world.world == 1 and not args.no_cpu_baseline:
             cb, v_cpu, n = cpu_baseline(model, qidx, base, qa, qb)
             out["cpu_baseline"] = cb
             if not np.array_equal(v_cpu, valid[:n]):
@@ -507,10 +799,9 @@ def main():
         _flush_c_stdio()
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    world.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

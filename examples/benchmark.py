@@ -24,6 +24,65 @@ import mjpl_amd as mjpl  # noqa: E402
 from mjpl_amd import scenes  # noqa: E402
 
 
+def run(planner="device", attempts=15, obstacles=True, goal="pose", interval=0.0, seed=42, vary_seed=False,
+        batch=512, device=0, quiet=False, collision=None, check_path=None):
+    """The reference's loop (examples/benchmark.py:28-91) -> dict(successes, attempts, planning_times, paths,
+    paths_valid).  `collision`: a Constraint to validate with instead of mjpl.CollisionConstraint (the
+    serial planner only: bench.py times it on the CPU oracle that way); `check_path(path) -> bool`: an
+    independent check of every returned path."""
+    model = scenes.franka_p(obstacles=obstacles)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(model, joints)
+    q_init = model.keyframe("home").qpos.copy()
+    cc = mjpl.CollisionConstraint(model, device=device)
+    constraints = [mjpl.JointLimitConstraint(model), collision if collision is not None else cc]
+    step = interval if interval > 0 else None
+    if collision is not None and planner != "rrt":
+        raise ValueError("an external collision constraint drives the serial planner only (--planner rrt)")
+
+    planners = {}
+
+    def planner_for(sd):
+        # planners are built once per seed (device buffers, compiled model); planning is what is timed
+        if sd in planners:
+            return planners[sd]
+        kw = dict(epsilon=0.05, seed=sd, goal_biasing_probability=0.1, max_planning_time=10.0)
+        if planner == "device":
+            p = mjpl.DeviceBiRRT(model, joints, cc, q_init, interval_step=step, batch=batch, capacity=1 << 21, **kw)
+        elif planner == "host":
+            p = mjpl.ParallelBiRRT(model, joints, mjpl.HipEdgeValidator(cc, qidx, q_init), q_init,
+                                   interval_step=step, batch=batch, **kw)
+        else:
+            p = mjpl.RRT(model, joints, constraints,
+                         collision_interval_check=(step, constraints[1]) if step else None, **kw)
+        planners[sd] = p
+        return p
+
+    times, paths, ok, all_valid = [], [], 0, True
+    for k in range(attempts):
+        sd = seed + k if vary_seed else seed
+        q_goal = mjpl.random_config(model, q_init, joints, sd, constraints)
+        goal_pose = mjpl.site_pose(model, q_goal, "ee_site", engine=cc.engine)
+        pl = planner_for(sd)
+        solver = mjpl.HipIKSolver(model, joints, constraints, seed=sd, max_attempts=5, engine=cc.engine)
+        t0 = time.time()
+        if goal == "pose":
+            path = pl.plan_to_pose(q_init, goal_pose, "ee_site", solver=solver)
+        else:
+            path = pl.plan_to_config(q_init, q_goal)
+        dt = time.time() - t0
+        if path:
+            ok += 1
+            times.append(dt)
+            paths.append(path)
+            if check_path is not None and not check_path(path):
+                all_valid = False
+        if not quiet:
+            print(f"attempt {k}: {'ok' if path else 'FAILED'} in {dt:.4f}s, {len(path)} waypoints")
+    return dict(successes=ok, attempts=attempts, planning_times=times, paths=paths, paths_valid=all_valid,
+                model=model, qidx=qidx, q_init=q_init, interval=step)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--attempts", type=int, default=15)
@@ -35,50 +94,10 @@ def main():
     ap.add_argument("--vary-seed", action="store_true", help="seed + k for attempt k instead of one seed")
     ap.add_argument("--batch", type=int, default=512)
     args = ap.parse_args()
-
-    model = scenes.franka_p(obstacles=args.obstacles)
-    joints = scenes.FRANKA_ARM_JOINTS
-    qidx = scenes.planning_index(model, joints)
-    q_init = model.keyframe("home").qpos.copy()
-    cc = mjpl.CollisionConstraint(model)
-    constraints = [mjpl.JointLimitConstraint(model), cc]
-    step = args.interval if args.interval > 0 else None
-
-    planners = {}
-
-    def planner_for(seed):
-        # planners are built once per seed (device buffers, compiled model); planning is what is timed
-        if seed in planners:
-            return planners[seed]
-        kw = dict(epsilon=0.05, seed=seed, goal_biasing_probability=0.1, max_planning_time=10.0)
-        if args.planner == "device":
-            p = mjpl.DeviceBiRRT(model, joints, cc, q_init, interval_step=step, batch=args.batch, capacity=1 << 21, **kw)
-        elif args.planner == "host":
-            p = mjpl.ParallelBiRRT(model, joints, mjpl.HipEdgeValidator(cc, qidx, q_init), q_init,
-                                   interval_step=step, batch=args.batch, **kw)
-        else:
-            p = mjpl.RRT(model, joints, constraints, collision_interval_check=(step, cc) if step else None, **kw)
-        planners[seed] = p
-        return p
-
-    times, ok = [], 0
-    for k in range(args.attempts):
-        seed = args.seed + k if args.vary_seed else args.seed
-        q_goal = mjpl.random_config(model, q_init, joints, seed, constraints)
-        goal_pose = mjpl.site_pose(model, q_goal, "ee_site", engine=cc.engine)
-        planner = planner_for(seed)
-        solver = mjpl.HipIKSolver(model, joints, constraints, seed=seed, max_attempts=5, engine=cc.engine)
-        t0 = time.time()
-        if args.goal == "pose":
-            path = planner.plan_to_pose(q_init, goal_pose, "ee_site", solver=solver)
-        else:
-            path = planner.plan_to_config(q_init, q_goal)
-        dt = time.time() - t0
-        if path:
-            ok += 1
-            times.append(dt)
-        print(f"attempt {k}: {'ok' if path else 'FAILED'} in {dt:.4f}s, {len(path)} waypoints")
-    print(f"planner {args.planner}, goal {args.goal}, interval {step}: success rate {ok}/{args.attempts}; "
+    res = run(planner=args.planner, attempts=args.attempts, obstacles=args.obstacles, goal=args.goal, interval=args.interval,
+              seed=args.seed, vary_seed=args.vary_seed, batch=args.batch)
+    times, ok = res["planning_times"], res["successes"]
+    print(f"planner {args.planner}, goal {args.goal}, interval {res['interval']}: success rate {ok}/{args.attempts}; "
           f"median planning time {np.median(times) if times else float('nan'):.4f}s")
     return 0 if ok else 1
 

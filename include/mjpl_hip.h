@@ -335,7 +335,7 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *desc, const double *dQ
  * model on the host only -- no device needed -- and returns the program and its hash: call it with
  * ip = fp = dp = NULL for the sizes, then with buffers. */
 typedef struct mjpl_program_info {
-  uint64_t hash;            /* FNV-1a of (ip, fp, kernel variant, MJPL_SPEC_ABI) */
+  uint64_t hash;            /* FNV-1a of (ip, fp, dp, kernel variant, MJPL_SPEC_ABI, digest of the shared headers) */
   int32_t maxs, wbox, mbox; /* kernel variant: slot-file width, static / moving boxes present */
   int32_t immediate;        /* 1: the model runs the immediate interpreter (not specialisable yet) */
   int32_t filter_usable;
@@ -349,6 +349,9 @@ int mjpl_program_dump(const mjpl_model_desc *model, const int32_t *allowed_bodie
                       mjpl_program_info *info);
 /* 1 if the engine's current program runs on a specialised library */
 int mjpl_spec_loaded(const mjpl_engine *e);
+/* enable = 0: this engine runs the interpreting kernels whatever libraries exist (A/B measurements,
+ * bench.py's "interpreter" variant); 1: look the program's library up again.  Synchronises. */
+int mjpl_set_spec(mjpl_engine *e, int32_t enable);
 
 /* ---- frontier bi-RRT, device-resident (BASELINE configs[3]) -------------
  * RRT.plan_to_configs' sample / extend / connect loop (src/mjpl/planning/rrt.py:190-235) for `lanes`
@@ -393,8 +396,33 @@ int mjpl_rrt_reset(mjpl_rrt *r, const double *q_init, const double *q_goals, int
 /* one round: sample, extend the growing tree, extend the other towards what was reached, exchange.
  * Synchronises (the host needs the connection flag and the node counts).  request_stop != 0 (a
  * rank's time limit has passed) travels with the exchange, so that all ranks stop after the same
- * round: info->stop_requested. */
+ * round: info->stop_requested.  An error that only one rank runs into (its slab of new nodes is
+ * full, a HIP error) travels the same way: that rank still takes part in the exchange, and every
+ * rank returns the error from the same round. */
 int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info);
+/* The round split at its exchange step, for a launcher that moves the slabs itself (another
+ * transport than RCCL; the tests, which run two ranks on one GPU): mjpl_rrt_round is
+ *   round_begin -> all-gather of the headers -> all-gather of the slabs -> round_finish.
+ * mjpl_rrt_set_world gives a planner its rank identity without a communicator (the sampler is keyed
+ * by it, rrt.py:195-203 per rank); with mjpl_comm_init on the engine and no set_world the
+ * communicator's rank / world are used.
+ * round_begin: sample, extend, connect on this rank; synchronises; head[8] (host) receives this
+ *   rank's exchange header: [0] new nodes of the tree that grew this round, [1] of the other tree,
+ *   [2] connecting lane (INT32_MAX: none), [3] / [4] its node in the start / goal tree (>= 0: node id;
+ *   < 0: -1 - index into this rank's slab), [5] stop request, [6] status of this rank's half
+ *   (MJPL_OK, or the error every rank must return from round_finish), [7] 0.
+ * round_slabs: device pointers of this rank's new nodes of pass p (0: the tree that grew, 1: the
+ *   other): rows [head[p]][nplan] float64 and parents [head[p]] int32 (>= 0 node id, < 0 slab-relative).
+ * round_finish: heads = all ranks' headers in rank order [world][8] (host); drows_all[p] /
+ *   dparents_all[p] = device buffers holding every rank's slab of pass p, rank k at row offset
+ *   k * stride_rows[p] (stride_rows[p] >= the largest head[p]; the pointers may be NULL when every
+ *   count of the pass is 0).  Appends all slabs in rank order, resolves the winner (lowest rank),
+ *   fills info.  The buffers must stay valid until the engine's stream has been synchronised. */
+int mjpl_rrt_set_world(mjpl_rrt *r, int32_t rank, int32_t world);
+int mjpl_rrt_round_begin(mjpl_rrt *r, int32_t request_stop, int32_t *head);
+int mjpl_rrt_round_slabs(mjpl_rrt *r, int32_t pass, const void **drows, const void **dparents);
+int mjpl_rrt_round_finish(mjpl_rrt *r, const int32_t *heads, const void *const *drows_all,
+                          const void *const *dparents_all, const int32_t *stride_rows, mjpl_rrt_round_info *info);
 /* after a round with connected = 1: the path q_init ... goal, rows [len][nplan] */
 int mjpl_rrt_path(mjpl_rrt *r, double *path, int32_t maxlen, int32_t *len);
 /* download a tree (0 = start, 1 = goal): rows Q [n][nplan] and parent ids (-1 = root); either may

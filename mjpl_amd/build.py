@@ -16,8 +16,27 @@ LIB_PATH = os.path.join(CSRC, "libmjpl_hip.so")
 LIB_LDS_PATH = os.path.join(CSRC, "libmjpl_hip_ldstables.so")
 
 # -ffp-contract=off: one IEEE rounding per operation, the contract the CPU path is compared under.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17",
+_BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17",
                "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+# Headers whose struct layouts, table layouts and kernel templates are shared by libmjpl_hip.so and
+# the per-model specialised libraries (mjpl_amd/specialise.py).  Their digest is compiled into both
+# (MJPL_SRC_STAMP) and mixed into the program hash a specialised library is named by, so a library
+# built from other headers is neither found nor accepted (load_spec compares the stamps).
+STAMPED_HEADERS = ("mjpl_filter.h", "mjpl_device.h", "mjpl_trig.h")
+
+
+def src_stamp() -> int:
+    import hashlib
+    h = hashlib.sha256()
+    for name in STAMPED_HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return int.from_bytes(h.digest()[:8], "little")
+
+
+def hipcc_flags() -> list[str]:
+    return [*_BASE_FLAGS, f"-DMJPL_SRC_STAMP=0x{src_stamp():016x}ull"]
 
 
 def _stale(target: str) -> bool:
@@ -40,7 +59,7 @@ def build_hip(force: bool = False, lds_tables: bool = False, verbose: bool = Fal
     """Compile libmjpl_hip.so (or the LDS-staged-tables A/B variant) for gfx950."""
     target = LIB_LDS_PATH if lds_tables else LIB_PATH
     if force or _stale(target):
-        cmd = [hipcc(), *HIPCC_FLAGS, "-o", target, os.path.join(CSRC, "mjpl_hip.hip")]
+        cmd = [hipcc(), *hipcc_flags(), "-o", target, os.path.join(CSRC, "mjpl_hip.hip")]
         if lds_tables:
             cmd.insert(1, "-DMJPL_TABLES_LDS=1")
         if verbose:

@@ -18,7 +18,11 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 5
+#define MJPL_SPEC_ABI 6
+// digest of the headers both sides are built from (mjpl_amd/build.py: src_stamp); 0 = built by hand
+#ifndef MJPL_SRC_STAMP
+#define MJPL_SRC_STAMP 0ull
+#endif
 #ifndef MJPL_MBOX_WAVES
 #define MJPL_MBOX_WAVES 1  // the 24-slot moving-box build: ~360 VGPRs; bound to two waves per SIMD it spills 200 dwords and is 4x slower
 #endif

@@ -947,8 +947,9 @@ struct mjpl_engine {
   double ferr_a = 0, ferr_b = 0;  // |pose error| <= ferr_a + ferr_b * max coordinate
   double fmax_coord = 0;
   int npoisoned = 0;              // static geoms too large / far for binary32: their pairs are always undecided
-  uint64_t program_hash = 0;      // FNV-1a of the compiled tables (ip, fp) and the kernel variant
+  uint64_t program_hash = 0;      // FNV-1a of the compiled tables (ip, fp, dp), the kernel variant and the header digest
   const SpecLib *spec = nullptr;  // this model's own filter kernels, if a library for program_hash was found
+  bool spec_off = false;          // mjpl_set_spec(e, 0): run the interpreting kernels whatever libraries exist
   int *d_ulist = nullptr;   // items (configurations / whole edges) the filter left undecided
   int *d_ucount_base = nullptr;  // both counter sets; d_ucount = the one the last launch used
   bool counters_stale = false;
@@ -1031,7 +1032,7 @@ void load_spec(mjpl_engine *e) {
   e->spec = nullptr;
   if (const char *s = getenv("MJPL_SPEC"))
     if (atoi(s) == 0) return;
-  if (e->exact_general() || !e->filter_usable) return;  // (the generator covers the small queued builds)
+  if (e->spec_off || e->exact_general() || !e->filter_usable) return;  // (the generator covers the small queued builds)
   auto &cache = spec_cache();
   auto it = cache.find(e->program_hash);
   if (it != cache.end()) {
@@ -1056,11 +1057,15 @@ void load_spec(mjpl_engine *e) {
   if (lib) {
     auto abi = (int (*)())dlsym(lib, "mjpl_spec_abi");
     auto hash = (unsigned long long (*)())dlsym(lib, "mjpl_spec_hash");
+    auto stamp = (unsigned long long (*)())dlsym(lib, "mjpl_spec_src_stamp");
     sl.configs = (SpecLib::ConfigsFn)dlsym(lib, "mjpl_spec_launch_configs");
     sl.endpoints = (SpecLib::EndpointsFn)dlsym(lib, "mjpl_spec_launch_endpoints");
     sl.items = (SpecLib::ItemsFn)dlsym(lib, "mjpl_spec_launch_items");
     sl.patch = (SpecLib::PatchFn)dlsym(lib, "mjpl_spec_launch_patch");
-    if (abi && hash && abi() == MJPL_SPEC_ABI && hash() == e->program_hash && sl.configs && sl.endpoints && sl.items && sl.patch)
+    // (the stamp: both libraries built from the same mjpl_filter.h / mjpl_device.h / mjpl_trig.h -- the
+    // structs that cross this boundary by value and the table layouts live there)
+    if (abi && hash && stamp && abi() == MJPL_SPEC_ABI && stamp() == (unsigned long long)MJPL_SRC_STAMP &&
+        hash() == e->program_hash && sl.configs && sl.endpoints && sl.items && sl.patch)
       sl.lib = lib;
     else
       dlclose(lib);
@@ -1546,8 +1551,13 @@ int compile_program(mjpl_engine *e) {
     };
     mix(ip.data(), ip.size() * sizeof(int));
     mix(fp.data(), fp.size() * sizeof(float));
+    // the float64 table as well: the generated exact pair re-check (ExactSpec::fk_pair) carries ITS values
+    // as literals, and two programs may share a binary32 image while their float64 constants differ
+    mix(dp.data(), dp.size() * sizeof(double));
     const int shape[4] = {e->maxs, e->wbox ? 1 : 0, e->mbox ? 1 : 0, MJPL_SPEC_ABI};
     mix(shape, sizeof(shape));
+    const unsigned long long stamp = MJPL_SRC_STAMP;
+    mix(&stamp, sizeof(stamp));
     e->program_hash = h;
   }
   if (e->device < 0) return MJPL_OK;  // mjpl_program_dump: host tables only
@@ -2146,6 +2156,15 @@ int mjpl_program_dump(const mjpl_model_desc *d, const int32_t *allowed_bodies, i
 }
 
 int mjpl_spec_loaded(const mjpl_engine *e) { return (e && e->spec) ? 1 : 0; }
+
+int mjpl_set_spec(mjpl_engine *e, int32_t enable) {
+  if (!e) return fail(MJPL_E_ARG, "mjpl_set_spec: NULL engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->spec_off = enable == 0;
+  load_spec(e);
+  return MJPL_OK;
+}
 
 int mjpl_set_planning(mjpl_engine *e, const int32_t *qidx, int32_t nplan, const double *qpos_base) {
   if (!e || nplan < 0 || (nplan > 0 && !qidx)) return fail(MJPL_E_ARG, "mjpl_set_planning: bad argument");

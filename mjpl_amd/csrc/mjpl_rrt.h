@@ -486,6 +486,12 @@ struct mjpl_rrt {
   std::vector<void *> owned;
   // result of the last successful round
   int conn_start = -1, conn_goal = -1;
+  // rank identity when the caller moves the slabs itself (mjpl_rrt_set_world); else the engine's communicator
+  int rank = 0, world = 1;
+  bool world_set = false;
+  bool in_round = false;     // between round_begin and round_finish
+  int *h_myhead = nullptr;   // pinned: this rank's header (error relay / round_begin's copy)
+  std::string local_err;     // what went wrong on THIS rank in the round in flight
 };
 
 namespace {
@@ -540,11 +546,14 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     } else if ((rc = rrt_read_ctr(r)) != MJPL_OK) {
       return rc;
     }
-    const int E = r->h_ctr[RC_EDGES];
+    // (lanes that were refused candidate space have reserved slots all the same: RC_EDGES may exceed
+    // the buffer, and only RC_ACTIVE says whether any lane emitted)
+    const int E = std::min(r->h_ctr[RC_EDGES], r->cd.cap);
     if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
-    if (E == 0) {
+    if (r->h_ctr[RC_ACTIVE] == 0) {
       if (r->h_ctr[RC_OVERFLOW] & 1) {  // every waiting lane was refused: S is too large for the space left
         HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(r->d_ctr + RC_EDGES, 0, sizeof(int), st));  // (k_rrt_accept clears it otherwise)
         if (S == 1) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer too small for one step per lane");
         S = 1;
         continue;
@@ -653,6 +662,7 @@ void mjpl_rrt_destroy(mjpl_rrt *r) {
   for (hipEvent_t ev : r->ring_ev)
     if (ev) (void)hipEventDestroy(ev);
   if (r->h_heads) (void)hipHostFree(r->h_heads);
+  if (r->h_myhead) (void)hipHostFree(r->h_myhead);
   if (r->d_gather) (void)hipFree(r->d_gather);
   delete r;
 }
@@ -704,6 +714,7 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   HIP_TRY(hipHostMalloc((void **)&r->h_ring, 4 * RC_SIZE * sizeof(int)));
   for (hipEvent_t &ev : r->ring_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void **)&r->h_heads, 8 * 1024 * sizeof(int)));
+  HIP_TRY(hipHostMalloc((void **)&r->h_myhead, 8 * sizeof(int)));
   std::vector<uint8_t> isplan(r->nq, 0);
   for (int c : e->qidx) isplan[c] = 1;
   HIP_TRY(hipMemcpy(r->d_lo, d->lo, nplan * sizeof(double), hipMemcpyHostToDevice));
@@ -745,22 +756,31 @@ int mjpl_rrt_reset(mjpl_rrt *r, const double *q_init, const double *q_goals, int
   r->round = 0;
   r->seed = seed;
   r->conn_start = r->conn_goal = -1;
+  r->in_round = false;
   return MJPL_OK;
 }
 
-int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info) {
-  if (!r || !info) return fail(MJPL_E_ARG, "mjpl_rrt_round: NULL argument");
+namespace {
+
+int rrt_rank(const mjpl_rrt *r) { return r->world_set ? r->rank : (r->e->comm ? r->e->comm_rank : 0); }
+int rrt_world(const mjpl_rrt *r) { return r->world_set ? r->world : (r->e->comm ? r->e->comm_world : 1); }
+
+// First half of a round, asynchronous: sample, extend the growing tree, extend the other towards what was
+// reached, find this rank's connection; leaves the rank's header in d_heads[8 * rank ..] and its new
+// nodes in the pending slabs.  A failure that only THIS rank sees (a full pending slab, a HIP error) must
+// not keep it out of the exchange the other ranks are about to enter: it travels in the header
+// (head[6]) and every rank returns it from the second half.
+int rrt_begin(mjpl_rrt *r, int32_t request_stop) {
   if (r->n[0] < 1 || r->n[1] < 1) return fail(MJPL_E_ARG, "mjpl_rrt_round: call mjpl_rrt_reset first");
+  if (r->in_round) return fail(MJPL_E_ARG, "mjpl_rrt_round_begin: the previous round has not been finished");
   mjpl_engine *e = r->e;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t st = e->stream;
   const int L = r->L, nplan = r->nplan;
-  const int world = e->comm ? e->comm_world : 1, rank = e->comm ? e->comm_rank : 0;
+  const int world = rrt_world(r), rank = rrt_rank(r);
+  if (world > 1024) return fail(MJPL_E_CAPACITY, "rrt: world size %d not supported", world);  // (the same on every rank)
   r->round++;
   const int grow = (r->round - 1) % 2, other = 1 - grow;  // tree swap every round (rrt.py:234-235)
-  memset(info, 0, sizeof(*info));
-  info->round = r->round;
-
   {
     const int nf = std::max(r->ngoal, 1);
     hipLaunchKernelGGL(k_rrt_round_init, dim3(rgrid(std::max(nf, (int)RC_SIZE))), dim3(256), 0, st, r->d_ctr, r->d_first, nf);
@@ -769,64 +789,66 @@ int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info)
                      grow, r->ngoal, r->d_lo, r->d_hi, r->d_qinit, r->d_Q[1], r->cap, r->ln, r->d_first);
   int newA = 0, newB = 0;
   int rc = rrt_extend(r, grow, r->ln.T, 0, &newA);
-  if (rc != MJPL_OK) return rc;
-  rc = rrt_extend(r, other, r->ln.RA, 1, &newB);
-  if (rc != MJPL_OK) return rc;
-  hipLaunchKernelGGL(k_rrt_connect, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->d_ctr);
-  if (world > 1024) return fail(MJPL_E_CAPACITY, "rrt: world size %d not supported", world);
-  // ---- exchange: headers of all ranks, then the new-node slabs padded to the round's largest count
-  hipLaunchKernelGGL(k_rrt_header, dim3(1), dim3(1), 0, st, r->ln, r->d_ctr, grow, request_stop ? 1 : 0,
-                     r->d_heads + 8 * rank);
-  rc = mjpl_allgather_dev(e, r->d_heads + 8 * rank, r->d_heads, 8 * sizeof(int));
-  if (rc != MJPL_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(r->h_heads, r->d_heads, (size_t)world * 8 * sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  int maxA = 0, maxB = 0;
+  if (rc == MJPL_OK) rc = rrt_extend(r, other, r->ln.RA, 1, &newB);
+  if (rc == MJPL_OK) {
+    hipLaunchKernelGGL(k_rrt_connect, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->d_ctr);
+    hipLaunchKernelGGL(k_rrt_header, dim3(1), dim3(1), 0, st, r->ln, r->d_ctr, grow, request_stop ? 1 : 0, r->d_heads + 8 * rank);
+    if (hipGetLastError() != hipSuccess) rc = fail(MJPL_E_HIP, "rrt: a kernel of the round failed to launch");
+  }
+  r->local_err.clear();
+  if (rc != MJPL_OK) {
+    r->local_err = g_err;
+    const int h[8] = {0, 0, 0x7fffffff, 0, 0, request_stop ? 1 : 0, rc, 0};
+    memcpy(r->h_myhead, h, sizeof(h));
+    if (hipMemcpyAsync(r->d_heads + 8 * rank, r->h_myhead, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess)
+      return rc;  // the device itself is gone: nothing can be relayed
+  }
+  r->in_round = true;
+  return MJPL_OK;
+}
+
+// Second half: `heads` = the world's headers in rank order (host); allQ[p] / allP[p] = device buffers with
+// every rank's slab of pass p (0: the tree that grew, 1: the other) at a stride of stride[p] rows.
+int rrt_finish(mjpl_rrt *r, const int *heads, const char *const allQ[2], const char *const allP[2], const int64_t stride[2],
+               mjpl_rrt_round_info *info) {
+  mjpl_engine *e = r->e;
+  hipStream_t st = e->stream;
+  const int nplan = r->nplan;
+  const int world = rrt_world(r), rank = rrt_rank(r);
+  const int grow = (r->round - 1) % 2, other = 1 - grow;
+  r->in_round = false;
+  memset(info, 0, sizeof(*info));
+  info->round = r->round;
+  for (int k = 0; k < world; k++)
+    if (heads[8 * k + 6] != 0)
+      return fail(heads[8 * k + 6], "rrt: rank %d failed in round %d: %s", k, r->round,
+                  k == rank ? r->local_err.c_str() : "(its own mjpl_last_error has the reason)");
   int64_t totA = 0, totB = 0;
   for (int k = 0; k < world; k++) {
-    if (r->h_heads[8 * k + 5]) info->stop_requested = 1;
-    maxA = std::max(maxA, r->h_heads[8 * k]);
-    maxB = std::max(maxB, r->h_heads[8 * k + 1]);
-    totA += r->h_heads[8 * k];
-    totB += r->h_heads[8 * k + 1];
+    if (heads[8 * k + 5]) info->stop_requested = 1;
+    if (heads[8 * k] < 0 || heads[8 * k + 1] < 0 || heads[8 * k] > stride[0] || heads[8 * k + 1] > stride[1])
+      return fail(MJPL_E_ARG, "rrt: rank %d's header counts (%d, %d) do not fit the gathered slabs", k, heads[8 * k], heads[8 * k + 1]);
+    totA += heads[8 * k];
+    totB += heads[8 * k + 1];
   }
   if (r->n[grow] + totA > r->cap || r->n[other] + totB > r->cap) return fail(MJPL_E_CAPACITY, "rrt: node capacity %lld exhausted", (long long)r->cap);
   int win_rank = -1;
   for (int k = 0; k < world && win_rank < 0; k++)
-    if (r->h_heads[8 * k + 2] != 0x7fffffff) win_rank = k;
+    if (heads[8 * k + 2] != 0x7fffffff) win_rank = k;
   int baseA_of_winner = 0, baseB_of_winner = 0;
   for (int pass = 0; pass < 2; pass++) {  // pass 0: the tree that grew; 1: the other
     const int t = pass == 0 ? grow : other;
-    const int mx = pass == 0 ? maxA : maxB;
     int base = r->n[t];
-    if (mx > 0) {
-      const size_t rowb = (size_t)mx * nplan * sizeof(double), parb = (size_t)mx * sizeof(int32_t);
-      const char *srcQ = (const char *)r->d_pendQ[t];
-      const char *srcP = (const char *)r->d_pendpar[t];
-      const char *allQ = srcQ, *allP = srcP;
-      if (world > 1 || e->comm) {
-        const size_t need = (size_t)world * (rowb + parb);
-        if (need > r->gather_bytes) {
-          if (r->d_gather) HIP_TRY(hipFree(r->d_gather));
-          r->d_gather = nullptr; r->gather_bytes = 0;
-          HIP_TRY(hipMalloc((void **)&r->d_gather, need));
-          r->gather_bytes = need;
-        }
-        char *gQ = r->d_gather, *gP = r->d_gather + (size_t)world * rowb;
-        if ((rc = mjpl_allgather_dev(e, srcQ, gQ, rowb)) != MJPL_OK) return rc;
-        if ((rc = mjpl_allgather_dev(e, srcP, gP, parb)) != MJPL_OK) return rc;
-        allQ = gQ; allP = gP;
+    const size_t rowb = (size_t)stride[pass] * nplan * sizeof(double), parb = (size_t)stride[pass] * sizeof(int32_t);
+    for (int k = 0; k < world; k++) {
+      const int cnt = heads[8 * k + pass];
+      if (k == win_rank) (pass == 0 ? baseA_of_winner : baseB_of_winner) = base;
+      if (cnt > 0) {
+        if (!allQ[pass] || !allP[pass]) return fail(MJPL_E_ARG, "rrt: no gathered slab for pass %d", pass);
+        hipLaunchKernelGGL(k_rrt_merge, dim3(rgrid(cnt)), dim3(256), 0, st, cnt, nplan, (const double *)(allQ[pass] + (size_t)k * rowb),
+                           (const int32_t *)(allP[pass] + (size_t)k * parb), r->d_Q[t], r->d_parent[t], r->cap, base);
       }
-      for (int k = 0; k < world; k++) {
-        const int cnt = r->h_heads[8 * k + pass];
-        if (k == win_rank) (pass == 0 ? baseA_of_winner : baseB_of_winner) = base;
-        if (cnt > 0)
-          hipLaunchKernelGGL(k_rrt_merge, dim3(rgrid(cnt)), dim3(256), 0, st, cnt, nplan, (const double *)(allQ + (size_t)k * rowb),
-                             (const int32_t *)(allP + (size_t)k * parb), r->d_Q[t], r->d_parent[t], r->cap, base);
-        base += cnt;
-      }
-    } else if (win_rank >= 0) {
-      (pass == 0 ? baseA_of_winner : baseB_of_winner) = base;
+      base += cnt;
     }
     r->n[t] = base;
   }
@@ -839,7 +861,7 @@ int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info)
   if (win_rank >= 0) {
     // header refs: [3] in the start tree, [4] in the goal tree; pending indices are relative to
     // the winner's block of that tree (pass 0 = the tree that grew)
-    const int ra = r->h_heads[8 * win_rank + 3], rb = r->h_heads[8 * win_rank + 4];
+    const int ra = heads[8 * win_rank + 3], rb = heads[8 * win_rank + 4];
     const int base_start = grow == 0 ? baseA_of_winner : baseB_of_winner;
     const int base_goal = grow == 0 ? baseB_of_winner : baseA_of_winner;
     r->conn_start = ra >= 0 ? ra : base_start + (-1 - ra);
@@ -849,6 +871,108 @@ int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info)
     info->conn_rank = win_rank;
   }
   return MJPL_OK;
+}
+
+}  // namespace
+
+int mjpl_rrt_set_world(mjpl_rrt *r, int32_t rank, int32_t world) {
+  if (!r || world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(MJPL_E_ARG, "mjpl_rrt_set_world: bad rank / world");
+  if (r->in_round) return fail(MJPL_E_ARG, "mjpl_rrt_set_world: a round is in flight");
+  r->rank = rank;
+  r->world = world;
+  r->world_set = true;
+  return MJPL_OK;
+}
+
+int mjpl_rrt_round_begin(mjpl_rrt *r, int32_t request_stop, int32_t *head) {
+  if (!r || !head) return fail(MJPL_E_ARG, "mjpl_rrt_round_begin: NULL argument");
+  int rc = rrt_begin(r, request_stop);
+  if (rc != MJPL_OK) return rc;
+  hipStream_t st = r->e->stream;
+  HIP_TRY(hipMemcpyAsync(r->h_myhead, r->d_heads + 8 * rrt_rank(r), 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  memcpy(head, r->h_myhead, 8 * sizeof(int));
+  return MJPL_OK;
+}
+
+int mjpl_rrt_round_slabs(mjpl_rrt *r, int32_t pass, const void **drows, const void **dparents) {
+  if (!r || pass < 0 || pass > 1 || !drows || !dparents) return fail(MJPL_E_ARG, "mjpl_rrt_round_slabs: bad argument");
+  if (!r->in_round) return fail(MJPL_E_ARG, "mjpl_rrt_round_slabs: no round in flight");
+  const int grow = (r->round - 1) % 2;
+  const int t = pass == 0 ? grow : 1 - grow;
+  *drows = r->d_pendQ[t];
+  *dparents = r->d_pendpar[t];
+  return MJPL_OK;
+}
+
+int mjpl_rrt_round_finish(mjpl_rrt *r, const int32_t *heads, const void *const *drows_all, const void *const *dparents_all,
+                          const int32_t *stride_rows, mjpl_rrt_round_info *info) {
+  if (!r || !heads || !drows_all || !dparents_all || !stride_rows || !info) return fail(MJPL_E_ARG, "mjpl_rrt_round_finish: NULL argument");
+  if (!r->in_round) return fail(MJPL_E_ARG, "mjpl_rrt_round_finish: no round in flight");
+  HIP_TRY(hipSetDevice(r->e->device));
+  const char *q[2] = {(const char *)drows_all[0], (const char *)drows_all[1]};
+  const char *p[2] = {(const char *)dparents_all[0], (const char *)dparents_all[1]};
+  const int64_t stride[2] = {stride_rows[0], stride_rows[1]};
+  return rrt_finish(r, heads, q, p, stride, info);
+}
+
+int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info) {
+  if (!r || !info) return fail(MJPL_E_ARG, "mjpl_rrt_round: NULL argument");
+  mjpl_engine *e = r->e;
+  const int world = rrt_world(r), rank = rrt_rank(r);
+  if (world > 1 && !e->comm)
+    return fail(MJPL_E_ARG, "mjpl_rrt_round: rank %d of %d without a communicator (mjpl_comm_init), use round_begin / round_finish", rank, world);
+  int rc = rrt_begin(r, request_stop);
+  if (rc != MJPL_OK) return rc;
+  hipStream_t st = e->stream;
+  const int nplan = r->nplan;
+  const int grow = (r->round - 1) % 2, other = 1 - grow;
+  // ---- exchange: headers of all ranks, then the new-node slabs padded to the round's largest count
+  auto bail = [&](int code) { r->in_round = false; return code; };
+  rc = mjpl_allgather_dev(e, r->d_heads + 8 * rank, r->d_heads, 8 * sizeof(int));
+  if (rc != MJPL_OK) return bail(rc);
+  if (hipMemcpyAsync(r->h_heads, r->d_heads, (size_t)world * 8 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return bail(fail(MJPL_E_HIP, "rrt: reading the exchange headers failed"));
+  int mx[2] = {0, 0};
+  bool failed = false;
+  for (int k = 0; k < world; k++) {
+    failed = failed || r->h_heads[8 * k + 6] != 0;
+    mx[0] = std::max(mx[0], r->h_heads[8 * k]);
+    mx[1] = std::max(mx[1], r->h_heads[8 * k + 1]);
+  }
+  const char *allQ[2] = {nullptr, nullptr}, *allP[2] = {nullptr, nullptr};
+  const int64_t stride[2] = {mx[0], mx[1]};
+  if (!failed) {  // (every rank sees the same headers: all gather, or none does)
+    const size_t rowb[2] = {(size_t)mx[0] * nplan * sizeof(double), (size_t)mx[1] * nplan * sizeof(double)};
+    const size_t parb[2] = {(size_t)mx[0] * sizeof(int32_t), (size_t)mx[1] * sizeof(int32_t)};
+    if (e->comm) {
+      const size_t need = (size_t)world * (rowb[0] + parb[0] + rowb[1] + parb[1]);
+      if (need > r->gather_bytes) {
+        if (r->d_gather && hipFree(r->d_gather) != hipSuccess) return bail(fail(MJPL_E_HIP, "hipFree failed"));
+        r->d_gather = nullptr; r->gather_bytes = 0;
+        if (hipMalloc((void **)&r->d_gather, need) != hipSuccess) return bail(fail(MJPL_E_HIP, "rrt: no memory for the gathered slabs"));
+        r->gather_bytes = need;
+      }
+      char *at = r->d_gather;
+      for (int pass = 0; pass < 2; pass++) {
+        const int t = pass == 0 ? grow : other;
+        if (mx[pass] == 0) continue;
+        char *gQ = at, *gP = at + (size_t)world * rowb[pass];
+        at = gP + (size_t)world * parb[pass];
+        if ((rc = mjpl_allgather_dev(e, r->d_pendQ[t], gQ, rowb[pass])) != MJPL_OK) return bail(rc);
+        if ((rc = mjpl_allgather_dev(e, r->d_pendpar[t], gP, parb[pass])) != MJPL_OK) return bail(rc);
+        allQ[pass] = gQ; allP[pass] = gP;
+      }
+    } else {  // a world of one: the pending slabs are the gathered ones
+      for (int pass = 0; pass < 2; pass++) {
+        const int t = pass == 0 ? grow : other;
+        allQ[pass] = (const char *)r->d_pendQ[t];
+        allP[pass] = (const char *)r->d_pendpar[t];
+      }
+    }
+  }
+  return rrt_finish(r, r->h_heads, allQ, allP, stride, info);
 }
 
 int mjpl_rrt_path(mjpl_rrt *r, double *path, int32_t maxlen, int32_t *len) {

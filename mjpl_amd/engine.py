@@ -141,6 +141,10 @@ ABI = {
     "mjpl_rrt_destroy": (None, [_VP]),
     "mjpl_rrt_reset": (C.c_int, [_VP, _F64P, _F64P, C.c_int32, C.c_uint64]),
     "mjpl_rrt_round": (C.c_int, [_VP, C.c_int32, C.POINTER(RrtRoundInfo)]),
+    "mjpl_rrt_set_world": (C.c_int, [_VP, C.c_int32, C.c_int32]),
+    "mjpl_rrt_round_begin": (C.c_int, [_VP, C.c_int32, _I32P]),
+    "mjpl_rrt_round_slabs": (C.c_int, [_VP, C.c_int32, C.POINTER(_VP), C.POINTER(_VP)]),
+    "mjpl_rrt_round_finish": (C.c_int, [_VP, _I32P, C.POINTER(_VP), C.POINTER(_VP), _I32P, C.POINTER(RrtRoundInfo)]),
     "mjpl_rrt_path": (C.c_int, [_VP, _F64P, C.c_int32, _I32P]),
     "mjpl_rrt_get_tree": (C.c_int, [_VP, C.c_int32, _F64P, _I32P, C.c_int64, C.POINTER(C.c_int64)]),
     "mjpl_rrt_get_lanes": (C.c_int, [_VP, _F64P, _U8P]),
@@ -150,6 +154,7 @@ ABI = {
     "mjpl_allgather_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     "mjpl_program_dump": (C.c_int, None),   # bound in mjpl_amd/specialise.py
     "mjpl_spec_loaded": (C.c_int, [_VP]),
+    "mjpl_set_spec": (C.c_int, [_VP, C.c_int32]),
     "mjpl_device_count": (C.c_int, []),
     "mjpl_last_error": (C.c_char_p, []),
     "mjpl_version": (C.c_char_p, []),
@@ -283,6 +288,10 @@ class Engine:
         """True if this engine's filter kernels are the model's own specialised ones
         (mjpl_amd/specialise.py), not the interpreter."""
         return bool(self.lib.mjpl_spec_loaded(self.h))
+
+    def set_spec(self, enable: bool):
+        """False: run the interpreting kernels even if this program has a specialised library."""
+        self._ok(self.lib.mjpl_set_spec(self.h, 1 if enable else 0))
 
     def set_filter(self, enable: bool, tol: float = 1e-4):
         """Float32 filter in front of the exact kernels (verdicts are always the exact ones)."""
@@ -570,6 +579,32 @@ class DeviceRRT:
     def round(self, request_stop: bool = False) -> RrtRoundInfo:
         info = RrtRoundInfo()
         self.eng._ok(self.eng.lib.mjpl_rrt_round(self.h, 1 if request_stop else 0, C.byref(info)))
+        return info
+
+    # -- the round split at its exchange step (a launcher that moves the slabs itself)
+    def set_world(self, rank: int, world: int):
+        self.eng._ok(self.eng.lib.mjpl_rrt_set_world(self.h, int(rank), int(world)))
+
+    def round_begin(self, request_stop: bool = False) -> np.ndarray:
+        """-> this rank's exchange header, int32[8] (include/mjpl_hip.h)"""
+        head = np.zeros(8, np.int32)
+        self.eng._ok(self.eng.lib.mjpl_rrt_round_begin(self.h, 1 if request_stop else 0, head.ctypes.data_as(_I32P)))
+        return head
+
+    def round_slabs(self, which: int):
+        """-> (device pointer of the rows, of the parents) of this rank's new nodes of pass `which`"""
+        rows, par = _VP(), _VP()
+        self.eng._ok(self.eng.lib.mjpl_rrt_round_slabs(self.h, int(which), C.byref(rows), C.byref(par)))
+        return rows.value, par.value
+
+    def round_finish(self, heads, drows_all, dparents_all, stride_rows) -> RrtRoundInfo:
+        heads = np.ascontiguousarray(heads, dtype=np.int32)
+        rows = (_VP * 2)(*[p or None for p in drows_all])
+        pars = (_VP * 2)(*[p or None for p in dparents_all])
+        stride = np.ascontiguousarray(stride_rows, dtype=np.int32)
+        info = RrtRoundInfo()
+        self.eng._ok(self.eng.lib.mjpl_rrt_round_finish(self.h, heads.ctypes.data_as(_I32P), rows, pars,
+                                                        stride.ctypes.data_as(_I32P), C.byref(info)))
         return info
 
     def path(self, maxlen: int = 65536) -> np.ndarray:

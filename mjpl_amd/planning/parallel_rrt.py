@@ -148,6 +148,130 @@ class HipEdgeValidator(EdgeValidator):
         return out[:, self.qidx], ok
 
 
+class ThreadGroup:
+    """An in-process stand-in for a process group: `world` planners, one thread each, meet in
+    ``allgather`` at a barrier.  Lets one process run the multi-rank algorithm in lockstep -- what the
+    GPU tests compare a world of device planners with (the gloo flavour of the same exchange is
+    tested on CPU processes, tests/test_parallel_rrt.py)."""
+
+    def __init__(self, world: int):
+        import threading
+        self.world = int(world)
+        self._barrier = threading.Barrier(self.world)
+        self._slots: list = [None] * self.world
+
+    def member(self, rank: int) -> "_ThreadMember":
+        return _ThreadMember(self, int(rank))
+
+    def run(self, fn):
+        """fn(rank, member) on `world` threads -> list of results in rank order (re-raises the first error)."""
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+
+        def work(k):
+            try:
+                out[k] = fn(k, self.member(k))
+            except BaseException as ex:  # noqa: BLE001 -- reported to the caller below
+                err[k] = ex
+                self._barrier.abort()
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for ex in err:
+            if ex is not None and not isinstance(ex, __import__("threading").BrokenBarrierError):
+                raise ex
+        for ex in err:
+            if ex is not None:
+                raise ex
+        return out
+
+
+class _ThreadMember:
+    def __init__(self, group: ThreadGroup, rank: int):
+        self.group, self.rank, self.world = group, rank, group.world
+
+    def allgather(self, arr: np.ndarray) -> np.ndarray:
+        g = self.group
+        g._slots[self.rank] = np.array(arr, copy=True)
+        g._barrier.wait()
+        out = np.stack(g._slots)
+        g._barrier.wait()  # nobody overwrites a slot before everyone has read it
+        return out
+
+
+class _TorchMember:
+    """torch.distributed process group (gloo on CPU) behind the same three members."""
+
+    def __init__(self, group):
+        import torch.distributed as dist
+        self._dist, self._group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allgather(self, arr: np.ndarray) -> np.ndarray:
+        import torch
+        mine = torch.from_numpy(np.ascontiguousarray(arr))
+        out = torch.empty((self.world,) + arr.shape, dtype=mine.dtype)
+        self._dist.all_gather_into_tensor(out.view(-1, *arr.shape[1:]) if arr.ndim > 1 else out.view(-1), mine,
+                                          group=self._group)
+        return out.numpy()
+
+
+def lockstep_round(rrts, request_stop=False):
+    """One round of `world` device planners (:class:`mjpl_amd.engine.DeviceRRT`, rank k = rrts[k],
+    each given its identity with ``set_world(k, world)``) with the exchange done HERE instead of by
+    RCCL: every rank's header and slabs are read back, laid out as an all-gather would leave them
+    (rank k at row k * stride) and handed to every rank's ``round_finish``.  This is the seam
+    ``mjpl_rrt_round`` itself is built on (round_begin -> all-gather -> round_finish), so it runs
+    the multi-rank branch of the library on any number of GPUs, one included.  -> list of infos."""
+    import ctypes as C
+    world = len(rrts)
+    stop = [request_stop] * world if isinstance(request_stop, bool) else list(request_stop)
+    heads = np.stack([r.round_begin(stop[k]) for k, r in enumerate(rrts)])
+    nplan = rrts[0].nplan
+    stride = [int(heads[:, 0].max()), int(heads[:, 1].max())]
+    failed = bool(np.any(heads[:, 6] != 0))
+    gathered = []  # per pass: (rows [world, stride, nplan], parents [world, stride])
+    for which in (0, 1):
+        rows = np.zeros((world, stride[which], nplan))
+        par = np.zeros((world, stride[which]), np.int32)
+        if not failed:
+            for k, r in enumerate(rrts):
+                cnt = int(heads[k, which])
+                if cnt == 0:
+                    continue
+                drows, dpar = r.round_slabs(which)
+                lib, h = r.eng.lib, r.eng.h
+                r.eng._ok(lib.mjpl_d2h(h, rows[k].ctypes.data, drows, cnt * nplan * 8))
+                r.eng._ok(lib.mjpl_d2h(h, par[k].ctypes.data, dpar, cnt * 4))
+                r.eng.sync()
+        gathered.append((rows, par))
+    infos, errors = [], []
+    for r in rrts:
+        bufs = []
+        for which in (0, 1):
+            rows, par = gathered[which]
+            if stride[which] == 0 or failed:
+                bufs.append((None, None))
+                continue
+            bufs.append((r.eng.alloc(rows.nbytes).upload(rows), r.eng.alloc(par.nbytes).upload(par)))
+        try:
+            infos.append(r.round_finish(heads, [b[0].ptr if b[0] else None for b in bufs],
+                                        [b[1].ptr if b[1] else None for b in bufs], stride))
+        except Exception as ex:  # noqa: BLE001 -- every rank must get its turn before the first error is raised
+            errors.append(ex)
+        r.eng.sync()
+        for b in bufs:
+            for x in b:
+                if x is not None:
+                    x.free()
+    if errors:
+        raise errors[0]
+    return infos
+
+
 class _Trees:
     """Start tree (0) and goal tree (1): rows of planning columns + parent ids (-1 = root)."""
 
@@ -229,6 +353,11 @@ class _PlannerBase:
         if not q_goals:
             raise ValueError("`q_goals` cannot be empty")
         fixed = np.setdiff1d(np.arange(self.model.nq), self.qidx)
+        # the validators were compiled with q_template holding the joints outside the planning set
+        # (the reference keeps them at q_init, rrt.py:205-206): a q_init that disagrees would be
+        # searched for another robot configuration than it starts in
+        if not np.array_equal(q_init[fixed], self.q_template[fixed]):
+            raise ValueError("q_init differs from the planner's `q_template` outside of the planning joints")
         for q in q_goals:
             if not np.allclose(q_init[fixed], q[fixed], rtol=0, atol=1e-12):
                 raise ValueError("goal config differs from q_init outside of the planning joints")
@@ -267,11 +396,12 @@ class ParallelBiRRT(_PlannerBase):
         self.validator = validator
         self.interval_step = interval_step
         self.slab_rows = int(max_new_per_round)
-        self.group = group
+        # `group`: a torch.distributed process group (gloo), or anything with rank / world / allgather
+        # (ThreadGroup.member: several ranks in one process)
+        self.group = None
         if group is not None:
-            import torch.distributed as dist
-            self._dist = dist
-            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            self.group = group if hasattr(group, "world") else _TorchMember(group)
+            self.rank, self.world = self.group.rank, self.group.world
         self.trees: _Trees | None = None
 
     def _valid_ends(self, ends):
@@ -369,12 +499,7 @@ class ParallelBiRRT(_PlannerBase):
     def _allgather(self, arr: np.ndarray) -> np.ndarray:
         if self.world == 1:
             return arr[None]
-        import torch
-        mine = torch.from_numpy(np.ascontiguousarray(arr))
-        out = torch.empty((self.world,) + arr.shape, dtype=mine.dtype)
-        self._dist.all_gather_into_tensor(out.view(-1, *arr.shape[1:]) if arr.ndim > 1 else out.view(-1), mine,
-                                          group=self.group)
-        return out.numpy()
+        return self.group.allgather(arr)
 
     def _search(self, a, goals):
         n = len(self.qidx)
@@ -426,7 +551,8 @@ class ParallelBiRRT(_PlannerBase):
                 break
             if heads[:, 5].any():
                 break
-        self.stats = dict(rounds=rounds, nodes=tuple(self.trees.n), world=self.world, seconds=time.time() - t0)
+        self.stats = dict(rounds=rounds, nodes=tuple(self.trees.n), world=self.world, seconds=time.time() - t0,
+                          win_rank=win_rank, last_heads=np.array(heads))
         if winner is None:
             return None
         ia, ib = winner

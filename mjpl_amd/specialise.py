@@ -600,6 +600,7 @@ using namespace mjpl;
 
 extern "C" {
 int mjpl_spec_abi(void) { return MJPL_SPEC_ABI; }
+unsigned long long mjpl_spec_src_stamp(void) { return MJPL_SRC_STAMP; }
 unsigned long long mjpl_spec_hash(void) { return 0x%(hash)016xull; }
 int mjpl_spec_launch_configs(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
                              int nfp, const double *Q, int64_t N, int layout, float tol, uint8_t *valid, int *ulist, int *ucount,
@@ -647,7 +648,7 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
     src_path = os.path.join(SPEC_DIR, f"spec_{info.hash:016x}.hip")
     with open(src_path, "w") as f:
         f.write(src)
-    cmd = [_build.hipcc(), *_build.HIPCC_FLAGS, "-Wno-unused-variable", "-Wno-unused-but-set-variable", f"-I{_build.CSRC}",
+    cmd = [_build.hipcc(), *_build.hipcc_flags(), "-Wno-unused-variable", "-Wno-unused-but-set-variable", f"-I{_build.CSRC}",
            *extra_flags, "-o", target, src_path]
     subprocess.run(cmd, check=True)
     if not keep_source:

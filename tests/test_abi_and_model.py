@@ -158,7 +158,7 @@ def test_program_dump_and_code_generation_need_no_gpu():
         assert info.hash == info2.hash and np.array_equal(ip, ip2) and np.array_equal(fp.view(np.uint32), fp2.view(np.uint32))
         assert info.hash not in seen, name
         seen.add(info.hash)
-        assert not info.immediate and info.filter_usable and info.spec_abi == 5
+        assert not info.immediate and info.filter_usable and info.spec_abi == 6
         np.testing.assert_allclose(fp[np.isfinite(fp)], dp[np.isfinite(fp)].astype(np.float32), rtol=2e-5, atol=2e-4)
         src = specialise.generate(ip, fp, dp, info)
         assert src.count("MJPL_SPEC_CULL(") + 2 * src.count("MJPL_SPEC_CULL2(") + src.count("MJPL_SPEC_SLOTCULL(") + src.count("MJPL_SPEC_HIT(") >= 10
@@ -169,3 +169,27 @@ def test_program_dump_and_code_generation_need_no_gpu():
     with pytest.raises(ValueError, match="immediate"):
         specialise.generate(*specialise.dump_program(m))
     assert specialise.build(m) is None
+
+
+def test_program_hash_covers_the_float64_constants_and_the_shared_headers():
+    """A specialised library carries its program's float64 constants as literals (the exact pair
+    re-check, ExactSpec::fk_pair) and is built from the same headers as libmjpl_hip.so.  Two programs
+    whose constants differ by less than a binary32 ulp share their float32 image -- they must not
+    share a hash, or one would be re-checked against the other's constants; and the digest of the
+    shared headers is part of both the library (flag MJPL_SRC_STAMP) and the hash."""
+    from mjpl_amd import build, scenes, specialise
+    m = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    ip, fp, dp, info = specialise.dump_program(m, (), qidx, base)
+    base2 = base.copy()
+    base2[7] += 1e-10  # a finger opening: a non-planning joint's constant, far below a binary32 ulp of 0.04
+    ip2, fp2, dp2, info2 = specialise.dump_program(m, (), qidx, base2)
+    assert np.array_equal(ip, ip2) and np.array_equal(fp.view(np.uint32), fp2.view(np.uint32))
+    assert (dp != dp2).sum() == 1
+    assert info.hash != info2.hash
+    # the stamp: a digest of the three shared headers, passed to both compilations
+    stamp = build.src_stamp()
+    assert stamp != 0 and f"-DMJPL_SRC_STAMP=0x{stamp:016x}ull" in build.hipcc_flags()
+    src = specialise._TU % dict(spec="", exact="", hash=info.hash, maxs=info.maxs, wbox="true")
+    assert "mjpl_spec_src_stamp" in src and "MJPL_SRC_STAMP" in src

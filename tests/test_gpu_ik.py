@@ -84,8 +84,10 @@ def test_config5_shape_seeds_fk_collision_filter(oracle_mod):
     solver = mjpl.HipIKSolver(m, joints, [], seed=3, num_seeds=16384, iterations=200, engine=cc.engine)
     Q0 = solver._seeds(q_init, np.random.default_rng(3))
     Q, ok, iters, err = cc.engine.ik_solve(site, target.translation(), target.rotation().wxyz, Q0,
-                                            solver.movable, iterations=200)
-    assert ok.mean() > 0.3, ok.mean()
+                                            solver.movable, iterations=200, restarts=8, restart_seed=11)
+    # measured on this target and these seeds: 0.977 (profiles/r02f_ik.json, target_seed 5, uniform);
+    # the other targets of that file 0.81 - 0.98
+    assert ok.mean() >= 0.75, ok.mean()
     assert (err[ok, 0] <= 1e-3).all() and (err[ok, 1] <= 1e-3).all()
     lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
     assert np.all((Q >= lo - 1e-15) & (Q <= hi + 1e-15))

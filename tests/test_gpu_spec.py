@@ -90,3 +90,29 @@ def test_specialised_kernels_in_every_interior_pass_mode(oracle_mod):
         np.testing.assert_array_equal(got, want, err_msg=str(env))
         np.testing.assert_array_equal(gfb, wfb, err_msg=str(env))
         e.close()
+
+
+def test_a_program_with_other_float64_constants_does_not_load_this_library():
+    """Finger opening 0.04 vs 0.04 + 1e-10: the same float32 image, one float64 constant apart.  The
+    library of the first program bakes ITS float64 constants into the exact pair re-check, so the
+    second program must not find it (the hash once covered the float32 image only) --
+    and its verdicts, from the interpreting kernels, equal the float64 path's."""
+    name, m, allowed, qidx, base = spec_models()[0]
+    e = eng_mod.Engine(m, allowed)
+    e.set_planning(qidx, base)
+    assert e.spec_loaded()
+    base2 = base.copy()
+    base2[7] += 1e-10
+    e.set_planning(qidx, base2)
+    assert not e.spec_loaded()
+    rng = np.random.default_rng(5)
+    Q = rng.uniform(m.jnt_range[qidx, 0], m.jnt_range[qidx, 1], size=(20000, len(qidx)))
+    got = e.check_configs(Q)
+    e.set_filter(False)
+    np.testing.assert_array_equal(got, e.check_configs(Q))
+    e.set_planning(qidx, base)
+    e.set_spec(False)
+    assert not e.spec_loaded()
+    e.set_spec(True)
+    assert e.spec_loaded()
+    e.close()

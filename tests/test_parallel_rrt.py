@@ -168,6 +168,37 @@ def test_world_size_two_gloo_ranks_agree():
     assert (r0, r1, w0, w1) == (0, 1, 2, 2)
     assert path0 == path1, "both ranks must return the same path"
     assert n0 == n1 and Q0 == Q1 and par0 == par1, "replicated trees must be bit-identical"
+    # the in-process ThreadGroup (what the GPU tests compare a world of device planners with) is the
+    # same exchange: same trees, same path as the two gloo processes
+    from mjpl_amd.planning.parallel_rrt import ThreadGroup
+
+    def one(rank, member):
+        m, qidx, v, p, q_init, g = _make(world_group=member, batch=24)
+        path = p.plan_to_config(q_init, g)
+        return (np.array(path).tobytes(), tuple(p.trees.n), p.trees.nodes(0).tobytes() + p.trees.nodes(1).tobytes(),
+                p.trees.parent[0][: p.trees.n[0]].tobytes() + p.trees.parent[1][: p.trees.n[1]].tobytes())
+
+    for got in ThreadGroup(2).run(one):
+        assert got == (path0, n0, Q0, par0)
+
+
+def test_thread_group_multi_round_and_rank_one_winner():
+    """Lanes few enough that the search takes several rounds; seeds chosen so that rank 1 holds the
+    connecting lane and that a rank contributes an empty slab to a round."""
+    from mjpl_amd.planning.parallel_rrt import INT_MAX, ThreadGroup
+    seen = []
+    for seed, batch in ((1, 4), (11, 2)):
+        def one(rank, member):
+            m, qidx, v, p, q_init, g = _make(world_group=member, seed=seed, batch=batch)
+            path = p.plan_to_config(q_init, g)
+            _check_path(m, qidx, v, path, q_init, g)
+            return np.array(path).tobytes(), tuple(p.trees.n), p.stats["rounds"], p.stats["win_rank"], p.stats["last_heads"]
+
+        a, b = ThreadGroup(2).run(one)
+        assert a[:4] == b[:4] and np.array_equal(a[4], b[4])
+        assert a[2] > 1 and a[3] == 1 and a[4][0, 2] == INT_MAX
+        seen.append(a[4])
+    assert (seen[1][:, :2] == 0).any(), "a rank with an empty slab"
 
 
 def test_projecting_validator_on_the_cpu(oracle_mod):

@@ -1,7 +1,9 @@
 """Fold the per-kernel PMC summaries of one profiling round (profiles/<tag>_pmc_<kernel>.json,
 written by tools/pmc_summary.py from separate rocprofv3 --pmc passes) into profiles/pmc.json, the
 file bench.py reads `roofline.traffic` and `valu_issue` from.
-usage: python tools/pmc_collect.py <tag> [E] [layout]"""
+Records are keyed by kernel, batch size, layout AND the engine configuration the pass ran under
+(float32 filter on / off, specialised kernels on / off: bench.py --variant).
+usage: python tools/pmc_collect.py <tag> [E] [layout] [filter 0|1] [spec 0|1]"""
 import glob
 import json
 import os
@@ -14,6 +16,8 @@ def main():
     tag = sys.argv[1]
     E = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
     layout = sys.argv[3] if len(sys.argv) > 3 else "soa"
+    filt = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    spec = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     path = os.path.join(ROOT, "profiles", "pmc.json")
     try:
         with open(path) as f:
@@ -34,7 +38,7 @@ def main():
             rec["correction"] = ("gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); "
                                  "FETCH_SIZE and WRITE_SIZE from separate --pmc passes")
         rec["source"] = f"profiles/{os.path.basename(p)} (tools/profile_gpu.sh {tag})"
-        out[f"{kernel}_{E}_{layout}"] = rec
+        out[f"{kernel}_{E}_{layout}_f{filt}_s{spec}"] = rec
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v.get("source") for k, v in out.items()}, indent=1))
