@@ -489,8 +489,7 @@ def bench_rrt(args, world):
         nn = int(info.new_nodes[0]) + int(info.new_nodes[1])
         new_nodes += nn
         exch.append(nn * (8 * nplan + 4) + 32 * world.world)  # rows + parents of every rank's slabs, + the headers
-        if info.connected:
-            break
+        # (a connection does not end the measurement: the trees keep growing, as for a query still unsolved)
     world.barrier()
     elapsed = time.perf_counter() - t0
     done = len(rows)

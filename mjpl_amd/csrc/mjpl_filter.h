@@ -6,6 +6,8 @@
 // (libmjpl_spec_<hash>.so) and launched by the engine instead of the generic ones.
 #pragma once
 
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/mjpl_hip.h"
@@ -18,7 +20,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 6
+#define MJPL_SPEC_ABI 7
 // digest of the headers both sides are built from (mjpl_amd/build.py: src_stamp); 0 = built by hand
 #ifndef MJPL_SRC_STAMP
 #define MJPL_SRC_STAMP 0ull
@@ -216,7 +218,11 @@ constexpr int kItemRegions = 32;
 // endpoint passed, unused, edges left to the walking kernel), the per-region item fills, the per-region
 // survivor counts.  The engine keeps two such sets and alternates: the first kernel of a launch clears
 // the set the NEXT launch will use (nobody touches it meanwhile), which saves a fill kernel per launch.
-constexpr int kNumCounters = 5 + 2 * kItemRegions;
+constexpr int kNumCounters = 5 + 4 * kItemRegions;
+// tile queues of the persistent kernels (k_filter_endpoints_pw / k_filter_items_pw), one per region:
+// the next tile of that region to hand out
+constexpr int kCtrEndpointTiles = 5 + 2 * kItemRegions;
+constexpr int kCtrItemTiles = 5 + 3 * kItemRegions;
 __device__ __forceinline__ void zero_counters(int *next) {
   if (next && blockIdx.x == 0)
     for (int k = threadIdx.x; k < kNumCounters * kCounterStride; k += blockDim.x) next[k] = 0;
@@ -331,7 +337,7 @@ __device__ __forceinline__ int count_waypoints(const int *__restrict__ gip, cons
 __device__ __forceinline__ void emit_items(const int *__restrict__ gip, const double *__restrict__ QA, int64_t E,
                                            int64_t i, double step, int layout, bool survive, int K,
                                            const double *qe, int B, double *qw, int ws, const ItemBuffers &ib,
-                                           int nplan) {
+                                           int nplan, int region_of_wave = -1) {
   const int lane = threadIdx.x & 63;
   bool done = !survive;
   if (!done && K < 0) {  // the walking kernel takes the edge
@@ -347,7 +353,7 @@ __device__ __forceinline__ void emit_items(const int *__restrict__ gip, const do
   const int total = __shfl(incl, 63);
   if (total == 0) return;
   int base = 0;
-  const int region = (int)(blockIdx.x % (unsigned)ib.regions);
+  const int region = region_of_wave >= 0 ? region_of_wave : (int)(blockIdx.x % (unsigned)ib.regions);
   if (lane == 0) base = atomicAdd(ib.count + region * kCounterStride, total);
   base = __builtin_amdgcn_readfirstlane(base);
   const int rel = base + incl - K, first = region * ib.regcap + rel;
@@ -609,6 +615,332 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
       if (!handed && atomicExch(&ib.claim[ed], ib.gen) != ib.gen) ulist[atomicAdd(ucount, 1)] = ed;
     }
   }
+}
+
+// ---- persistent kernels: one wavefront per tile of 64, tiles handed out by a device counter -----------
+// k_filter_endpoints / k_filter_items give every workgroup 256 consecutive units and die with it: a
+// workgroup's four waves hold their SIMD slots and its 50 KiB of LDS until the slowest of them is through
+// (a wave whose lanes drain more candidates takes longer), the last third of a round of workgroups runs
+// on a third of the wave slots, and the item kernel is launched for the whole item SPACE because the host
+// does not know the count.  Measured: 2.0 of 3 wave slots occupied on average (SQ_WAVE_CYCLES).  Here the
+// grid is what the chip holds at once (three workgroups per CU) for the whole kernel; every WAVE takes
+// the next tile of 64 units from a counter until there is none, with its own private slice of the
+// workgroup's LDS -- [columns | pose saves | candidate queues], contiguous per wave, so that no barrier
+// is needed after the one that publishes the workgroup's copy of the constant table.
+template <class T, bool MBOX>
+struct WaveLds {
+  float *col;   // [nplan][64] binary32 planning columns of this wave's lanes
+  T *save;      // [nsave * 7][64]
+  char *qmem;   // this wave's candidate queues
+  T *ltab;      // the workgroup's copy of the constant table
+  char *base;   // start of the wave's slice (the endpoint kernel lays its float64 walking rows over it)
+  size_t bytes; // of the slice
+};
+__host__ __device__ constexpr size_t wave_slice_bytes(int nplan, int nsave, size_t scalar, size_t qbytes) {
+  return (((size_t)nplan * 64 * sizeof(float) + 7) & ~(size_t)7) + (((size_t)nsave * 7 * 64 * scalar + 7) & ~(size_t)7) + ((qbytes + 7) & ~(size_t)7);
+}
+template <class T, bool MBOX>
+__device__ __forceinline__ WaveLds<T, MBOX> carve_wave(double *smem, const T *__restrict__ gtp, int ntp, int nplan, int nsave) {
+  WaveLds<T, MBOX> w;
+  const size_t qbytes = WaveQueue<T, MBOX>::bytes();
+  w.bytes = wave_slice_bytes(nplan, nsave, sizeof(T), qbytes);
+  const int nwaves = blockDim.x >> 6;
+  char *b = reinterpret_cast<char *>(smem) + (size_t)(threadIdx.x >> 6) * w.bytes;
+  w.base = b;
+  w.col = reinterpret_cast<float *>(b);
+  w.save = reinterpret_cast<T *>(b + (((size_t)nplan * 64 * sizeof(float) + 7) & ~(size_t)7));
+  w.qmem = reinterpret_cast<char *>(w.save) + (((size_t)nsave * 7 * 64 * sizeof(T) + 7) & ~(size_t)7);
+  w.ltab = reinterpret_cast<T *>(reinterpret_cast<char *>(smem) + (size_t)nwaves * w.bytes);
+  for (int k = threadIdx.x; k < ntp; k += blockDim.x) w.ltab[k] = gtp[k];
+  return w;
+}
+
+// the per-configuration check on a wave's private slice (queued interpreter or the model's own code)
+template <int MAXS, bool WBOX, bool MBOX, class Spec>
+__device__ __forceinline__ int check_wave(const int *__restrict__ gip, const float *__restrict__ gfp, const WaveLds<float, MBOX> &w,
+                                          bool active, float tol, int64_t row, const UndecidedConfigs &uc,
+                                          const int *item_edge, const int *item_idx, const EdgeSource &src) {
+  const int lane = threadIdx.x & 63;
+  PatchSink ps;
+  ps.uc = uc;
+  ps.qcol = nullptr;  // (src is always set here: what goes to the exact re-check is read / rebuilt from the caller's rows)
+  ps.B = 64;
+  ps.L = 1;
+  ps.nplan = gip[H_NPLAN];
+  ps.idx = 0;
+  ps.item_edge = item_edge;
+  ps.item_idx = item_idx;
+  ps.src = src;
+  ps.perm = (IP)gip + gip[H_OFF_PERM];
+  WaveQueue<float, MBOX> wq;
+  wq.carve(w.qmem);
+  if constexpr (!std::is_void<Spec>::value)
+    return Spec::run((FP)gfp, w.ltab, w.col + lane, 64, w.save + lane, 64, active, tol, wq, (int)row, ps);
+  else
+    return run_config_queued<float, MAXS, WBOX, MBOX>((IP)gip, (FP)gfp, w.ltab, w.col + lane, 64, w.save + lane, 64, active, tol, wq,
+                                                      (int)row, ps);
+}
+
+// Tile queues.  One counter for the whole grid does not work: returning atomics on ONE address are served
+// at about 18 ns apiece on this chip, whoever asks -- 10 354 item tiles + one failed attempt per wave made
+// the item kernel 0.185 ms long (0.128 without the counter), the endpoint kernel 0.126 (0.096).  So there
+// is a queue per region (up to 32 addresses, a 128-byte line each): a wave starts at the queue of its own
+// number in the grid and moves on to the next queue when one is empty; after a full turn without a tile
+// it is done.  Within a queue the tiles go out in order.
+struct TileQueues {
+  int *ctr;         // [nq] counters, kCounterStride ints apart
+  int nq, q;        // queues; the one this wave is on
+  int rank, peers;  // this wave's number among the `peers` waves whose home is queue q
+  int nwaves;
+  int round = 0, home_rounds = -1;  // static rounds taken / to take on the home queue (-1: not known yet)
+  bool outstanding = false;         // an ask() has gone out whose answer take() has not looked at
+  bool dynamic;                     // false: the remainder is dealt out statically, too (no counter at all)
+  __device__ __forceinline__ TileQueues(int *c, int n, bool dyn) : ctr(c), nq(n), dynamic(dyn) {
+    const int w = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    q = w % n;
+    rank = w / n;
+    peers = (nwaves - q + n - 1) / n;
+  }
+  // Tiles of a queue come in two parts.  The first peers * floor(ntiles / peers) of them are dealt out
+  // statically -- the r-th round of the home wave with rank u is tile u + r * peers: no memory operation,
+  // and every home wave of the queue gets the same number.  The remainder (less than one round) goes
+  // through the queue's counter, and so does whatever other queues still hold when this one is empty:
+  // that is what evens out the end of the kernel.  (A returning atomic per tile, even spread over 32
+  // addresses, costs more than it balances -- item kernel 0.153 ms against 0.130 with static tiles
+  // only; asked for one tile ahead and only for the remainder it does not show.)
+  __device__ __forceinline__ int static_part(int nt, int qq) const {
+    const int p = (nwaves - qq + nq - 1) / nq;
+    return p > 0 ? (nt / p) * p : 0;
+  }
+  __device__ __forceinline__ int ask() const {
+    int j = 0;
+    if ((threadIdx.x & 63) == 0) j = atomicAdd(ctr + q * kCounterStride, 1);
+    return j;
+  }
+  // Called before a tile's arithmetic: if the NEXT take() will be answered by a counter, ask it now, so
+  // that the answer's round trip is over when it is needed.  -> the value to hand to take().
+  __device__ __forceinline__ int ask_ahead(int asked) {
+    if (dynamic && home_rounds >= 0 && round >= home_rounds && !outstanding) {
+      outstanding = true;
+      return ask();
+    }
+    return asked;
+  }
+  // ntiles(q): how many tiles queue q holds.  -> queue of the next tile (index in *index), or -1: nothing
+  // is left.  When a counter's answer says its queue is empty the wave looks at ALL counters at once (one
+  // load, a lane per queue; a counter only grows, so a queue seen empty is empty), moves to the nearest
+  // queue that still has tiles and asks there; a wave that sees none is done.
+  template <class F>
+  __device__ __forceinline__ int take(int asked, F &&ntiles, int *index) {
+    if (home_rounds < 0) home_rounds = peers > 0 ? ntiles(q) / peers : 0;
+    if (round < home_rounds) {
+      *index = rank + round * peers;
+      round++;
+      return q;
+    }
+    if (!dynamic) {  // the remainder: one more tile for the lowest ranks, and that is all
+      const int j = rank + round * peers;
+      if (round > home_rounds || j >= ntiles(q)) return -1;
+      round++;
+      *index = j;
+      return q;
+    }
+    if (!outstanding) asked = ask();
+    outstanding = false;
+    int j = __builtin_amdgcn_readfirstlane(asked);
+    for (;;) {
+      const int nt = ntiles(q), base = static_part(nt, q);
+      if (base + j < nt) {
+        *index = base + j;
+        return q;
+      }
+      const int lane = threadIdx.x & 63;
+      int left = 0;
+      if (lane < nq) {
+        const int ntl = ntiles(lane);
+        left = ntl - static_part(ntl, lane) - __hip_atomic_load(ctr + lane * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned long long m = __ballot(left > 0);
+      if (m == 0ull) return -1;
+      // the first queue with tiles at or after q + 1, cyclically (nq <= 64)
+      const int s = q + 1 == nq ? 0 : q + 1;
+      const unsigned long long hi = m >> s;
+      q = hi ? s + (int)__builtin_ctzll(hi) : (int)__builtin_ctzll(m);
+      j = __builtin_amdgcn_readfirstlane(ask());
+    }
+  }
+};
+// a wave's LDS slice changes hands between differently typed views (float64 walking rows, binary32
+// columns, queue records) without a workgroup barrier: keep the compiler and the LDS queue in order
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class Spec, int MAXS, bool WBOX, bool MBOX>
+__global__ void __launch_bounds__(kBlock, (kMinWaves<Spec, MAXS>))
+k_filter_items_pw(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp, ItemBuffers ib,
+                  EdgeSource src, float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
+                  int *__restrict__ ulist, int *__restrict__ ucount, UndecidedConfigs uc, int *__restrict__ tiles) {
+  static_assert(kQueued<float, MAXS>, "persistent kernels serve the queued interpreter");
+  extern __shared__ double smem[];
+  const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
+  WaveLds<float, MBOX> w = carve_wave<float, MBOX>(smem, gfp, nfp, nplan, gip[H_NSAVE]);
+  __syncthreads();  // the table copy; from here on every wave is on its own
+  const int lane = threadIdx.x & 63;
+  // a tile = 64 consecutive items of one region; the regions are the queues.  Tiles cost what their
+  // candidates cost (a wave that drains more takes longer): the remainder is dealt out dynamically
+  TileQueues tq(tiles, ib.regions, true);
+  auto ntiles = [&](int r) {
+    const int f = ib.count[r * kCounterStride];
+    return ((f < ib.regcap ? f : ib.regcap) + 63) >> 6;
+  };
+  int asked = 0;
+  for (;;) {
+    int j = 0;
+    const int region = tq.take(asked, ntiles, &j);
+    if (region < 0) break;
+    const int fill = ib.count[region * kCounterStride];
+    const int64_t n = (int64_t)region * ib.regcap + (fill < ib.regcap ? fill : ib.regcap);
+    const int64_t it = (int64_t)region * ib.regcap + (int64_t)j * 64 + lane;
+    const int64_t itc = it < (int64_t)ib.cap ? it : 0;
+    const int ed = it < n ? ib.edge[itc] : -1;
+    const bool active = ed >= 0;  // (a void slot: reserved by an edge that did not fit)
+    float *qw = w.col + lane;
+    {
+      const int64_t e0 = active ? ed : 0;
+      double tt = active ? (double)ib.idx[itc] * ib.tstep[e0] : 0.0;
+      tt = tt < 1.0 ? tt : 1.0;
+      for_rows(src.QA, src.QB, src.E, e0, nplan, src.layout, true, [&](int k, double a, double b) {
+        qw[k * 64] = active ? (float)fma(tt, b - a, a) : 0.0f;
+      });
+    }
+    wave_lds_fence();
+    asked = tq.ask_ahead(asked);  // (the next tile, if a counter hands it out: answered while this one is checked)
+    const int code = check_wave<MAXS, WBOX, MBOX, Spec>(gip, gfp, w, active, tol, it, uc, ib.edge, ib.idx, src);
+    if (active && code != V_NONE) {
+      if (code == V_CONTACT) {
+        valid[ed] = 0;
+        if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)ib.idx[it]);
+      } else if (atomicExch(&ib.claim[ed], ib.gen) != ib.gen) {
+        ulist[atomicAdd(ucount, 1)] = ed;  // (see k_filter_items: the exact edge kernel redoes the whole edge, once)
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+template <class Spec, int MAXS, bool WBOX, bool MBOX>
+__global__ void __launch_bounds__(kBlock, (kMinWaves<Spec, MAXS>))
+k_filter_endpoints_pw(const int *__restrict__ gip, int nip, const float *__restrict__ gfp, int nfp,
+                      const double *__restrict__ QA, const double *__restrict__ QB, int64_t E, int layout,
+                      float tol, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad,
+                      int *__restrict__ status, int *__restrict__ ulist, int *__restrict__ ucount,
+                      UndecidedConfigs uc, ItemBuffers ib, double step, int *__restrict__ zero_next, int *__restrict__ tiles) {
+  static_assert(kQueued<float, MAXS>, "persistent kernels serve the queued interpreter");
+  extern __shared__ double smem[];
+  zero_counters(zero_next);
+  const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
+  WaveLds<float, MBOX> w = carve_wave<float, MBOX>(smem, gfp, nfp, nplan, gip[H_NSAVE]);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int ntile = (int)((E + 63) >> 6);
+  // the two float64 rows per lane of the waypoint count lie over the wave's own slice
+  const bool fits = (size_t)2 * nplan * 64 * sizeof(double) <= w.bytes;
+  double *qe = reinterpret_cast<double *>(w.base) + lane;
+  double *qx = qe + (size_t)nplan * 64;
+  // tile t = edges [64 t, 64 t + 64); queue (= item region) t % regions holds the tiles t = j * regions + q
+  // (endpoint tiles cost much the same: all static -- measured 0.096 ms against 0.109 with a dynamic remainder)
+  TileQueues tq(tiles, ib.regions, false);
+  auto ntiles = [&](int q) { return (ntile - q + ib.regions - 1) / ib.regions; };
+  int asked = 0;
+  for (;;) {
+    int j = 0;
+    const int region = tq.take(asked, ntiles, &j);
+    if (region < 0) break;
+    const int64_t i = ((int64_t)j * ib.regions + region) * 64 + lane;
+    const bool active = i < E;
+    bool finite = true;
+    for_rows(QA, QB, E, i, nplan, layout, active, [&](int, double a, double b) {
+      finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
+    });
+    // the waypoint COUNT first (see k_filter_endpoints); with checkpoints the count follows the check
+    const bool early = fits && !ib.ckpt;
+    int K = 0;
+    if (early) {
+      load_columns(qe, 64, QB, E, i, nplan, layout, active);
+      K = count_waypoints(gip, QA, E, i, step, layout, active && finite, qe, 64, qx, 64, ib, nplan);
+      wave_lds_fence();
+    }
+    float *qw = w.col + lane;
+    load_columns(qw, 64, QB, E, i, nplan, layout, active);
+    wave_lds_fence();
+    const bool run = active && finite;
+    asked = tq.ask_ahead(asked);  // (the next tile, if a counter hands it out: answered while this one is checked)
+    const int code = check_wave<MAXS, WBOX, MBOX, Spec>(gip, gfp, w, run, tol, i, uc, nullptr, nullptr,
+                                                        EdgeSource{QB, QB, E, layout, 0.0, nullptr});
+    bool survive = run && code != V_CONTACT;
+    if (active) {
+      if (!finite) {
+        valid[i] = 0;
+        if (first_bad) first_bad[i] = -2;
+        atomicOr(status, kStatusNonFinite);
+      } else if (code == V_CONTACT) {
+        valid[i] = 0;
+        if (first_bad) first_bad[i] = 0;
+      } else if (code == V_UNSURE) {  // (queued interpreter: the whole edge goes to the exact edge kernel)
+        ulist[atomicAdd(ucount, 1)] = (int)i;
+        survive = false;
+      } else {
+        valid[i] = 1;  // so far; the interior pass and the patch pass may clear it
+        if (first_bad) first_bad[i] = -1;
+      }
+    }
+    const unsigned long long m = __ballot(survive);
+    wave_lds_fence();
+    if (m == 0ull) continue;
+    if (!fits) {
+      if (survive) ib.llist[atomicAdd(ib.lcount, 1)] = (int)i;  // too many columns: walking kernel
+      continue;
+    }
+    if (!early) {
+      load_columns(qe, 64, QB, E, i, nplan, layout, active);
+      K = count_waypoints(gip, QA, E, i, step, layout, survive, qe, 64, qx, 64, ib, nplan);
+    }
+    emit_items(gip, QA, E, i, step, layout, survive, K, early ? nullptr : qe, 64, early ? nullptr : qx, 64, ib, nplan, region);
+    if (lane == 0) atomicAdd(ib.scount + region * kCounterStride, (int)__builtin_popcountll(m));
+    wave_lds_fence();
+  }
+}
+
+// dynamic LDS of a persistent kernel's workgroup: the waves' slices, then the table copy
+inline size_t persistent_lds_bytes(int nplan, int nsave, size_t ntab, bool mbox, int block = kBlock) {
+  const size_t q = mbox ? WaveQueue<float, true>::bytes() : WaveQueue<float, false>::bytes();
+  return (size_t)(block / 64) * wave_slice_bytes(nplan, nsave, sizeof(float), q) + ((ntab * sizeof(float) + 7) & ~(size_t)7);
+}
+// grid of a persistent kernel: as many workgroups as the device holds at once (asked of the runtime once
+// per kernel and LDS size), never more than there are tiles for (four per workgroup)
+template <class K>
+inline unsigned persistent_grid(K kernel, size_t lds, long long ntile) {
+  static thread_local const void *last_k = nullptr;
+  static thread_local size_t last_lds = 0;
+  static thread_local int last_dev = -1, resident = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (last_k != reinterpret_cast<const void *>(kernel) || last_lds != lds || last_dev != dev) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (const char *f = getenv("MJPL_PW_BLOCKS_PER_CU")) {  // (A/B measurements)
+      fprintf(stderr, "persistent_grid: runtime says %d workgroups per CU at %zu B of LDS, %d CUs\n", per_cu, lds, cus);
+      if (atoi(f) > 0) per_cu = atoi(f);
+    }
+    resident = per_cu * cus;
+    last_k = reinterpret_cast<const void *>(kernel); last_lds = lds; last_dev = dev;
+  }
+  const long long want = (ntile + kBlock / 64 - 1) / (kBlock / 64);
+  return (unsigned)(want < 1 ? 1 : (want < resident ? want : resident));
 }
 
 // ---- exact re-check of single geom pairs the filter could not decide -------------------------

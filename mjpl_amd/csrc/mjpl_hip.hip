@@ -913,6 +913,12 @@ struct SpecLib {
                          UndecidedConfigs, uint8_t *, int32_t *);
   typedef int (*ItemsFn)(hipStream_t, unsigned, unsigned, size_t, const int *, int, const float *, int, ItemBuffers, EdgeSource, float,
                          uint8_t *, int32_t *, int *, int *, UndecidedConfigs);
+  typedef int (*EndpointsPwFn)(hipStream_t, size_t, const int *, int, const float *, int, const double *, const double *, int64_t, int,
+                               float, uint8_t *, int32_t *, int *, int *, int *, UndecidedConfigs, ItemBuffers, double, int *, int *);
+  typedef int (*ItemsPwFn)(hipStream_t, size_t, const int *, int, const float *, int, ItemBuffers, EdgeSource, float, uint8_t *,
+                           int32_t *, int *, int *, UndecidedConfigs, int *);
+  EndpointsPwFn endpoints_pw = nullptr;
+  ItemsPwFn items_pw = nullptr;
   void *lib = nullptr;
   ConfigsFn configs = nullptr;
   EndpointsFn endpoints = nullptr;
@@ -972,6 +978,11 @@ struct mjpl_engine {
   int claim_gen = 0;
   size_t item_cap = 0, llist_cap = 0;
   bool expand = true;
+  // endpoint and item kernels as persistent grids of waves with tile queues (queued interpreter only).
+  // -1: where it pays -- a model's own specialised kernels (0.257 -> 0.245 ms per step); the interpreting
+  // kernels, whose waves differ more in what a tile costs them, are faster as ordinary grids (0.397 vs
+  // 0.459 ms).  MJPL_PERSIST=0 / 1 forces either (tests run both ways).
+  int persist = -1;
   size_t item_cap_limit = (size_t)1 << 26;  // MJPL_ITEM_CAP: edges beyond it take the walking kernel
   void *d_nn = nullptr;         // nearest neighbour: per-chunk partial results
   size_t nn_bytes = 0;
@@ -1062,10 +1073,12 @@ void load_spec(mjpl_engine *e) {
     sl.endpoints = (SpecLib::EndpointsFn)dlsym(lib, "mjpl_spec_launch_endpoints");
     sl.items = (SpecLib::ItemsFn)dlsym(lib, "mjpl_spec_launch_items");
     sl.patch = (SpecLib::PatchFn)dlsym(lib, "mjpl_spec_launch_patch");
+    sl.endpoints_pw = (SpecLib::EndpointsPwFn)dlsym(lib, "mjpl_spec_launch_endpoints_pw");
+    sl.items_pw = (SpecLib::ItemsPwFn)dlsym(lib, "mjpl_spec_launch_items_pw");
     // (the stamp: both libraries built from the same mjpl_filter.h / mjpl_device.h / mjpl_trig.h -- the
     // structs that cross this boundary by value and the table layouts live there)
     if (abi && hash && stamp && abi() == MJPL_SPEC_ABI && stamp() == (unsigned long long)MJPL_SRC_STAMP &&
-        hash() == e->program_hash && sl.configs && sl.endpoints && sl.items && sl.patch)
+        hash() == e->program_hash && sl.configs && sl.endpoints && sl.items && sl.patch && sl.endpoints_pw && sl.items_pw)
       sl.lib = lib;
     else
       dlclose(lib);
@@ -1877,7 +1890,30 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       }
       rlist = e->d_slist;
       rcount = e->d_ucount + 2 * kCtr;
-      if (e->spec)
+      // persistent grids (one wave per tile of 64, tiles from a device counter): the default for the
+      // queued interpreter when the interior waypoints become items
+      const bool pw = (e->persist < 0 ? e->spec != nullptr : e->persist != 0) && expand && !e->immediate();
+      const size_t ldsp = persistent_lds_bytes((int)e->qidx.size(), e->nsave, e->fp.size(), e->filter_mbox());
+      int *etiles = e->d_ucount + kCtrEndpointTiles * kCtr;
+      if (pw && e->spec)
+        rc = e->spec->endpoints_pw(e->stream, ldsp, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQA, dQB, E, layout,
+                                   e->filter_tol, dvalid, dfb, e->d_status, e->d_ulist, e->d_ucount, uc, ib, step, zero_next,
+                                   etiles) == 0 ? MJPL_OK : fail(MJPL_E_HIP, "specialised endpoint kernel failed to launch");
+      else if (pw)
+        rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
+          if constexpr (decltype(S)::value <= kQueuedMaxSlots) {
+            auto kern = k_filter_endpoints_pw<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+            int r = allow_lds(kern, ldsp);
+            if (r != MJPL_OK) return r;
+            hipLaunchKernelGGL(kern, dim3(persistent_grid(kern, ldsp, (E + 63) / 64)), dim3(kBlock), ldsp, e->stream, e->d_ip,
+                               (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQA, dQB, E, layout, e->filter_tol, dvalid, dfb,
+                               e->d_status, e->d_ulist, e->d_ucount, uc, ib, step, zero_next, etiles);
+            return MJPL_OK;
+          } else {
+            return fail(MJPL_E_ARG, "persistent kernels serve the queued interpreter");
+          }
+        });
+      else if (e->spec)
         rc = e->spec->endpoints(e->stream, fgrid, (unsigned)fblock, ldse, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQA,
                                 dQB, E, layout, e->filter_tol, dvalid, dfb, e->d_status, e->d_ulist, e->d_ucount, uc, e->d_slist,
                                 e->d_ucount + 2 * kCtr, ib, step, zero_next) == 0 ? MJPL_OK
@@ -1899,7 +1935,28 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     if (expand) {
       const unsigned igrid = (unsigned)(ib.cap / fblock);  // (regions of whole blocks)
       const EdgeSource src = {dQA, dQB, (long long)E, layout, step, ib.ckpt};
-      if (e->spec)
+      const bool pw = (e->persist < 0 ? e->spec != nullptr : e->persist != 0) && !e->immediate();
+      const size_t ldsp = persistent_lds_bytes((int)e->qidx.size(), e->nsave, e->fp.size(), e->filter_mbox());
+      int *itiles = e->d_ucount + kCtrItemTiles * kCtr;
+      if (pw && e->spec)
+        rc = e->spec->items_pw(e->stream, ldsp, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib, src, e->filter_tol, dvalid,
+                               dfb, e->d_ulist, e->d_ucount, uc, itiles) == 0 ? MJPL_OK
+             : fail(MJPL_E_HIP, "specialised item kernel failed to launch");
+      else if (pw)
+        rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
+          if constexpr (decltype(S)::value <= kQueuedMaxSlots) {
+            auto kern = k_filter_items_pw<void, decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+            int r = allow_lds(kern, ldsp);
+            if (r != MJPL_OK) return r;
+            hipLaunchKernelGGL(kern, dim3(persistent_grid(kern, ldsp, (long long)ib.cap / 64)), dim3(kBlock), ldsp, e->stream, e->d_ip,
+                               (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib, src, e->filter_tol, dvalid, dfb, e->d_ulist,
+                               e->d_ucount, uc, itiles);
+            return MJPL_OK;
+          } else {
+            return fail(MJPL_E_ARG, "persistent kernels serve the queued interpreter");
+          }
+        });
+      else if (e->spec)
         rc = e->spec->items(e->stream, igrid, (unsigned)fblock, ldsq, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), ib,
                             src, e->filter_tol, dvalid, dfb, e->d_ulist, e->d_ucount, uc) == 0 ? MJPL_OK
              : fail(MJPL_E_HIP, "specialised item kernel failed to launch");
@@ -2049,6 +2106,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_TWO_PASS")) e->two_pass = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FORCE_IMMEDIATE")) e->force_immediate = atoi(f) != 0;
   if (const char *f = getenv("MJPL_EXPAND")) e->expand = atoi(f) != 0;
+  if (const char *f = getenv("MJPL_PERSIST")) e->persist = atoi(f) != 0 ? 1 : 0;
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
   if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));
   if (const char *t = getenv("MJPL_FILTER_TOL")) {

@@ -156,6 +156,30 @@ def quat_mat_np(q):
                      2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z])
 
 
+def expanded_threshold(X, bound, reach: float) -> float:
+    """Threshold of the expanded bounding cull of a static partner at X (binary32 coordinates) whose
+    difference-form bound is `bound` (already widened by the filter's tolerance): the test
+        fl(|c|^2 - 2 c.X) <= THR
+    must pass whenever the real-arithmetic |c - X|^2 <= bound for a centre c with |c| <= reach.
+    |c|^2 costs three roundings of at most u |c|^2 (u = 2^-24), each of the three multiply-adds one of at
+    most u (|c| + |X|)^2 (every partial sum is bounded by that): the computed value exceeds the real one by
+    no more than 6 u (|c| + |X|)^2.  The allowance below takes 8 u, a reach larger by one percent, and the
+    threshold is rounded up to binary32."""
+    X = np.asarray([float(np.float32(v)) for v in X], dtype=np.float64)
+    nx = float(np.linalg.norm(X))
+    b = float(np.float32(bound))
+    if not math.isfinite(b):
+        return b
+    if not math.isfinite(reach):
+        return math.inf  # (nothing bounds the centre: every lane is a candidate; the narrowphase decides)
+    allow = 8.0 * 2.0 ** -24 * (1.01 * reach + nx) ** 2
+    thr = b - float(X @ X) + allow
+    f = np.float32(thr)
+    if float(f) < thr:
+        f = np.nextafter(f, np.float32(np.inf))
+    return float(f)
+
+
 class _Gen:
     def __init__(self, ip, fp, dp, info):
         self.ip, self.fp, self.dp, self.info = ip, fp, dp, info
@@ -176,8 +200,13 @@ class _Gen:
         self.w(f"  {dst}2 = {lit(v[2])} + 2.0f * ({qn[1]} * t1_ - {qn[2]} * t0_); }}")
 
 
-def generate(ip, fp, dp, info) -> str:
-    """HIP source of `struct Spec` for one compiled program."""
+def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
+    """HIP source of `struct Spec` for one compiled program.
+    cull_form: "expanded" (default) tests a static partner as  |c|^2 - 2 c.X <= bound - |X|^2  -- three
+    fused multiply-adds and a compare per partner on top of one |c|^2 per geom -- with the threshold
+    raised by a bound of the form's own rounding (see `expanded_threshold`); "difference" is the
+    interpreter's |c - X|^2 <= bound (six operations and a compare, two partners per packed instruction)."""
+    cull_form = cull_form or os.environ.get("MJPL_SPEC_CULL", "expanded")
     if info.immediate or not info.filter_usable:
         raise ValueError("this model runs the immediate interpreter / has no usable filter: nothing to specialise")
     g = _Gen(ip, fp, dp, info)
@@ -197,11 +226,37 @@ def generate(ip, fp, dp, info) -> str:
     pc = int(ip[H_OFF_BODYOPS])
     state_known = None  # (p, q) as numpy constants while the chain so far is constant (static parent, fixed joints)
 
+    # How far from the world origin can a moving geom's centre be while its lane is still alive?  The body
+    # origins by the triangle inequality along the chain (hinges keep lengths; an off-centre hinge adds
+    # twice its offset), or -- below a slide joint, whose travel the program does not know -- by the
+    # per-lane range check: a lane whose body origin leaves [-maxcoord, maxcoord]^3 is dead from there on.
+    maxcoord = float(fp[fconst + FC_MAXCOORD])
+    box_reach = math.sqrt(3.0) * maxcoord
+    body_reach_cur = 0.0      # of the body the walk is at (PARENT_CUR refers to it)
+    saved_reach: dict[int, float] = {}
+
     for b in range(nbody):
         parent, bdoff, njnt, save_slot, ngeom = (int(ip[pc + k]) for k in (B_PARENT, B_DOFF, B_NJNT, B_SAVE, B_NGEOM))
         pc += B_SIZE
         bd = dp[bdoff:]
         g.lines, body_lines = [], None
+        if parent == PARENT_STATIC:
+            parent_reach = float(np.linalg.norm(bd[7:10]))
+        elif parent == PARENT_CUR:
+            parent_reach = body_reach_cur
+        else:
+            parent_reach = saved_reach[parent - 1]
+        geom_reach = parent_reach + float(np.linalg.norm(bd[0:3]))
+        for j in range(njnt):
+            jtype_, jdoff_ = int(ip[pc + j * J_SIZE + J_TYPE]), int(ip[pc + j * J_SIZE + J_DOFF])
+            if jtype_ == JT_SLIDE:
+                geom_reach = math.inf
+            else:
+                geom_reach += 2.0 * float(np.linalg.norm(dp[jdoff_ + 3: jdoff_ + 6]))
+        geom_reach = min(geom_reach, box_reach)
+        body_reach_cur = geom_reach
+        if save_slot >= 0:
+            saved_reach[save_slot] = geom_reach
         # ---- parent pose
         if parent == PARENT_STATIC:
             pp, pq, pR = bd[7:10].copy(), bd[10:14].copy(), bd[14:23].copy()
@@ -319,8 +374,10 @@ def generate(ip, fp, dp, info) -> str:
                 dot = lin([(pz[0], "cx"), (pz[1], "cy"), (pz[2], "cz")], -(np.float32(pz[0]) * np.float32(ppos[0]) + np.float32(pz[1]) * np.float32(ppos[1]) + np.float32(pz[2]) * np.float32(ppos[2])))
                 w(f"MJPL_SPEC_HIT({k}, !({dot} + dead > {lit(wbound[wrow])}));")
                 partners.append((EK_PLANE, wrow, GT_PLANE, 1, 0))
-            # other static geoms, two per packed cull
+            # other static geoms
             w("const float ux = cx + dead;")
+            if cull_form == "expanded":
+                w("const float cc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, ux * ux));")
             statics = []
             for wrow in range(64):
                 if not (wmask >> wrow) & 1:
@@ -331,12 +388,22 @@ def generate(ip, fp, dp, info) -> str:
                 X, Y, Z = (float(fp[wc_at(wrow, f)]) for f in range(3))
                 statics.append((len(partners), X, Y, Z, wbound[wrow]))
                 partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if ptype == GT_BOX else 0))
-            for a, b in zip(statics[0::2], statics[1::2]):
-                w(f"MJPL_SPEC_CULL2({a[0]}, {b[0]}, {lit(a[1])}, {lit(b[1])}, {lit(a[2])}, {lit(b[2])}, {lit(a[3])}, {lit(b[3])}, "
-                  f"{lit(a[4])}, {lit(b[4])});")
-            if len(statics) % 2:
-                k, X, Y, Z, bound = statics[-1]
-                w(f"MJPL_SPEC_CULL({k}, {lit(X)}, {lit(Y)}, {lit(Z)}, {lit(bound)});")
+            if cull_form == "expanded":
+                reach = geom_reach + float(np.linalg.norm(np.asarray(lpos, dtype=np.float64)))
+                for a, b in zip(statics[0::2], statics[1::2]):
+                    ta, tb = expanded_threshold(a[1:4], a[4], reach), expanded_threshold(b[1:4], b[4], reach)
+                    w(f"MJPL_SPEC_CULLX2({a[0]}, {b[0]}, {lit(-2 * a[1])}, {lit(-2 * a[2])}, {lit(-2 * a[3])}, {lit(ta)}, "
+                      f"{lit(-2 * b[1])}, {lit(-2 * b[2])}, {lit(-2 * b[3])}, {lit(tb)});")
+                if len(statics) % 2:
+                    k, X, Y, Z, bound = statics[-1]
+                    w(f"MJPL_SPEC_CULLX({k}, {lit(-2 * X)}, {lit(-2 * Y)}, {lit(-2 * Z)}, {lit(expanded_threshold((X, Y, Z), bound, reach))});")
+            else:
+                for a, b in zip(statics[0::2], statics[1::2]):
+                    w(f"MJPL_SPEC_CULL2({a[0]}, {b[0]}, {lit(a[1])}, {lit(b[1])}, {lit(a[2])}, {lit(b[2])}, {lit(a[3])}, {lit(b[3])}, "
+                      f"{lit(a[4])}, {lit(b[4])});")
+                if len(statics) % 2:
+                    k, X, Y, Z, bound = statics[-1]
+                    w(f"MJPL_SPEC_CULL({k}, {lit(X)}, {lit(Y)}, {lit(Z)}, {lit(bound)});")
             # earlier moving geoms in the slot file
             for n in range(maxs):
                 if not (smask >> n) & 1:
@@ -381,6 +448,17 @@ def generate(ip, fp, dp, info) -> str:
     o("       const spec_v2f s_ = __builtin_elementwise_fma(dx_, dx_, __builtin_elementwise_fma(dy_, dy_, dz_ * dz_)); \\")
     o("       const unsigned long long ma_ = __builtin_amdgcn_ballot_w64(!(s_.x > (BOUNDA))); \\")
     o("       const unsigned long long mb_ = __builtin_amdgcn_ballot_w64(!(s_.y > (BOUNDB))); \\")
+    o("       mjpl::park_mask2<ka, kb>(mlo, mhi, ma_, mb_); } while (0)")
+    o("// expanded form: t = |c|^2 - 2 c.X against THR = bound - |X|^2 (+ the form's rounding allowance); cc = |c|^2 with")
+    o("// ux in it, so a lane that is not to report anything carries +inf or NaN here and fails the ordered compare")
+    o("#define MJPL_SPEC_CULLX(k, M2X, M2Y, M2Z, THR) \\")
+    o("  do { const float t_ = __builtin_fmaf(cz, (M2Z), __builtin_fmaf(cy, (M2Y), __builtin_fmaf(ux, (M2X), cc))); \\")
+    o("       MJPL_SPEC_HIT(k, t_ <= (THR)); } while (0)")
+    o("#define MJPL_SPEC_CULLX2(ka, kb, AX, AY, AZ, ATHR, BX, BY, BZ, BTHR) \\")
+    o("  do { const float ta_ = __builtin_fmaf(cz, (AZ), __builtin_fmaf(cy, (AY), __builtin_fmaf(ux, (AX), cc))); \\")
+    o("       const float tb_ = __builtin_fmaf(cz, (BZ), __builtin_fmaf(cy, (BY), __builtin_fmaf(ux, (BX), cc))); \\")
+    o("       const unsigned long long ma_ = __builtin_amdgcn_ballot_w64(ta_ <= (ATHR)); \\")
+    o("       const unsigned long long mb_ = __builtin_amdgcn_ballot_w64(tb_ <= (BTHR)); \\")
     o("       mjpl::park_mask2<ka, kb>(mlo, mhi, ma_, mb_); } while (0)")
     o("#define MJPL_SPEC_SLOTCULL(k, n, BOUND) \\")
     o("  do { const float dx_ = ux - sf.f[0][n], dy_ = cy - sf.f[1][n], dz_ = cz - sf.f[2][n]; \\")
@@ -587,13 +665,15 @@ namespace {
 }  // namespace
 
 using namespace mjpl;
+#define SPEC_GRANT(kern)                                                                            \\
+  static size_t granted = 0;                                                                        \\
+  if (lds > granted) {                                                                              \\
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1; \\
+    granted = lds;                                                                                  \\
+  }
 #define SPEC_LAUNCH(kern, ...)                                                                      \\
   do {                                                                                              \\
-    static size_t granted = 0;                                                                      \\
-    if (lds > granted) {                                                                            \\
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1; \\
-      granted = lds;                                                                                \\
-    }                                                                                               \\
+    SPEC_GRANT(kern)                                                                                \\
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, __VA_ARGS__);                        \\
     return hipGetLastError() == hipSuccess ? 0 : -1;                                                \\
   } while (0)
@@ -619,6 +699,27 @@ int mjpl_spec_launch_items(hipStream_t st, unsigned grid, unsigned block, size_t
                            int nfp, ItemBuffers ib, EdgeSource src, float tol, uint8_t *valid, int32_t *first_bad, int *ulist, int *ucount,
                            UndecidedConfigs uc) {
   SPEC_LAUNCH((k_filter_items<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, ib, src, tol, valid, first_bad, ulist, ucount, uc);
+}
+// persistent kernels (one wave per tile of 64, tiles from a device counter): the launcher sizes the grid
+int mjpl_spec_launch_endpoints_pw(hipStream_t st, size_t lds, const int *ip, int nip, const float *fp, int nfp, const double *QA,
+                                  const double *QB, int64_t E, int layout, float tol, uint8_t *valid, int32_t *first_bad,
+                                  int *status, int *ulist, int *ucount, UndecidedConfigs uc, ItemBuffers ib, double step,
+                                  int *zero_next, int *tiles) {
+  auto kern = k_filter_endpoints_pw<Spec, %(maxs)d, %(wbox)s, false>;
+  SPEC_GRANT(kern);
+  const unsigned grid = persistent_grid(kern, lds, (E + 63) / 64);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, ip, nip, fp, nfp, QA, QB, E, layout, tol, valid, first_bad, status, ulist,
+                     ucount, uc, ib, step, zero_next, tiles);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int mjpl_spec_launch_items_pw(hipStream_t st, size_t lds, const int *ip, int nip, const float *fp, int nfp, ItemBuffers ib,
+                              EdgeSource src, float tol, uint8_t *valid, int32_t *first_bad, int *ulist, int *ucount,
+                              UndecidedConfigs uc, int *tiles) {
+  auto kern = k_filter_items_pw<Spec, %(maxs)d, %(wbox)s, false>;
+  SPEC_GRANT(kern);
+  const unsigned grid = persistent_grid(kern, lds, (long long)ib.cap / 64);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, ip, nip, fp, nfp, ib, src, tol, valid, first_bad, ulist, ucount, uc, tiles);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const double *dp,
                            int ndp, GeomTable gt, UndecidedConfigs uc, uint8_t *valid, int32_t *first_bad) {
@@ -648,7 +749,10 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
     src_path = os.path.join(SPEC_DIR, f"spec_{info.hash:016x}.hip")
     with open(src_path, "w") as f:
         f.write(src)
-    cmd = [_build.hipcc(), *_build.hipcc_flags(), "-Wno-unused-variable", "-Wno-unused-but-set-variable", f"-I{_build.CSRC}",
+    # -fno-slp-vectorize: left alone, the SLP vectoriser pairs the scalar binary32 arithmetic of the generated
+    # code into v_pk_* instructions -- which issue no faster than the two instructions they replace -- at the
+    # price of ~700 v_mov to assemble the pairs and of spilled registers: 0.279 -> 0.259 ms per step
+    cmd = [_build.hipcc(), *_build.hipcc_flags(), "-fno-slp-vectorize", "-Wno-unused-variable", "-Wno-unused-but-set-variable", f"-I{_build.CSRC}",
            *extra_flags, "-o", target, src_path]
     subprocess.run(cmd, check=True)
     if not keep_source:

@@ -158,10 +158,12 @@ def test_program_dump_and_code_generation_need_no_gpu():
         assert info.hash == info2.hash and np.array_equal(ip, ip2) and np.array_equal(fp.view(np.uint32), fp2.view(np.uint32))
         assert info.hash not in seen, name
         seen.add(info.hash)
-        assert not info.immediate and info.filter_usable and info.spec_abi == 6
+        assert not info.immediate and info.filter_usable and info.spec_abi == 7
         np.testing.assert_allclose(fp[np.isfinite(fp)], dp[np.isfinite(fp)].astype(np.float32), rtol=2e-5, atol=2e-4)
         src = specialise.generate(ip, fp, dp, info)
-        assert src.count("MJPL_SPEC_CULL(") + 2 * src.count("MJPL_SPEC_CULL2(") + src.count("MJPL_SPEC_SLOTCULL(") + src.count("MJPL_SPEC_HIT(") >= 10
+        culls = (src.count("MJPL_SPEC_CULLX(") + 2 * src.count("MJPL_SPEC_CULLX2(") + src.count("MJPL_SPEC_CULL(") +
+                 2 * src.count("MJPL_SPEC_CULL2(") + src.count("MJPL_SPEC_SLOTCULL(") + src.count("MJPL_SPEC_HIT("))
+        assert culls >= 10
         assert "struct Spec" in src and f"{info.hash:016x}" in src
     m = scenes.franka_p(True, True)  # moving boxes: immediate interpreter, nothing to specialise
     _, _, _, info = specialise.dump_program(m)

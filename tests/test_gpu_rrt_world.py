@@ -57,7 +57,7 @@ def _host_world(oracle_mod, world, seed, batch):
     return pr.ThreadGroup(world).run(one)
 
 
-def _device_world(world, seed, batch, m, joints, qidx, q_init, g, **desc):
+def _device_world(world, seed, batch, m, joints, qidx, q_init, g, desc=None):
     ccs = [mjpl.CollisionConstraint(m) for _ in range(world)]
     rrts = []
     for k, cc in enumerate(ccs):
@@ -65,7 +65,7 @@ def _device_world(world, seed, batch, m, joints, qidx, q_init, g, **desc):
         cc._ensure_planning()
         r = eng_mod.DeviceRRT(cc.engine, batch, 1 << 18, m.jnt_range[qidx, 0], m.jnt_range[qidx, 1], epsilon=KW["epsilon"],
                               interval_step=KW["interval_step"], goal_bias=KW["goal_biasing_probability"], seed=seed,
-                              **(desc.get(k, {})))
+                              **((desc or {}).get(k, {})))
         r.set_world(k, world)
         r.reset(q_init[qidx], g[qidx][None], seed)
         rrts.append(r)
@@ -119,7 +119,7 @@ def test_a_rank_that_fails_takes_every_rank_out_of_the_same_round(oracle_mod):
     deliver a header -- the other ranks are about to enter the exchange -- and every rank returns the
     error from round_finish of that round (with RCCL: nobody is left waiting in a collective)."""
     m, joints, qidx, q_init, g = _scene(oracle_mod)
-    ccs, rrts = _device_world(2, 1, 64, m, joints, qidx, q_init, g, **{0: dict(max_new_per_round=4)})
+    ccs, rrts = _device_world(2, 1, 64, m, joints, qidx, q_init, g, desc={0: dict(max_new_per_round=4)})
     heads = [r.round_begin() for r in rrts]
     assert heads[0][6] == -4 and heads[0][0] == 0 and heads[0][1] == 0 and heads[0][2] == pr.INT_MAX
     assert heads[1][6] == 0 and heads[1][0] > 0

@@ -81,11 +81,15 @@ def test_specialised_kernels_in_every_interior_pass_mode(oracle_mod):
     qb = np.clip(qa + 0.05 * d / np.linalg.norm(d, axis=1, keepdims=True), lo, hi)
     with oracle_mod.portable_trig():
         want, wfb, _ = oracle_mod.Oracle(m, allowed, planning_qidx=qidx, qpos_base=base).valid_edges(qa, qb, 0.01, nthreads=8, info=True)
-    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_ITEM_CAP": "3000"}, {"MJPL_UC_CAP": "16"}):
+    # (MJPL_PERSIST: the endpoint / item kernels as persistent grids of waves with tile queues -- the default
+    # with a specialised library -- or as ordinary grids; with the interpreter it is the other way round)
+    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_ITEM_CAP": "3000"}, {"MJPL_UC_CAP": "16"},
+                {"MJPL_PERSIST": "0"}, {"MJPL_PERSIST": "0", "MJPL_ITEM_CAP": "3000"}, {"MJPL_PERSIST": "1", "MJPL_UC_CAP": "16"},
+                {"MJPL_PERSIST": "1", "MJPL_SPEC": "0"}, {"MJPL_PERSIST": "1", "MJPL_SPEC": "0", "MJPL_ITEM_CAP": "3000"}):
         with _Env(**env):
             e = eng_mod.Engine(m, allowed)
-        e.set_planning(qidx, base)
-        assert e.spec_loaded()
+            e.set_planning(qidx, base)
+        assert e.spec_loaded() == (env.get("MJPL_SPEC") != "0")
         got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
         np.testing.assert_array_equal(got, want, err_msg=str(env))
         np.testing.assert_array_equal(gfb, wfb, err_msg=str(env))

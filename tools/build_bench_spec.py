@@ -3,6 +3,9 @@
 obstacles, arm joints planned) -- optionally as timing-only variants for tools/time_variants.sh:
     python tools/build_bench_spec.py                 -> mjpl_amd/csrc/spec/libmjpl_spec_<hash>.so
     python tools/build_bench_spec.py NOCHECK NODRAIN -> variants/spec_<NAME>.so (-DMJPL_X_<NAME>)
+    python tools/build_bench_spec.py NOSLP:-fno-slp-vectorize DIFF:cull=difference
+                                                     -> variants/spec_<NAME>.so with the given compiler
+                                                        flags / generator options instead of a -DMJPL_X_ define
 Prints the library paths (the first is the real one's: time_variants.sh swaps the variants in there)."""
 import os
 import sys
@@ -21,9 +24,16 @@ def main():
         return
     print(specialise.build(m, (), arm, base, force=not sys.argv[1:]))
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
-    for name in sys.argv[1:]:
-        print(specialise.build(m, (), arm, base, force=True, extra_flags=[f"-DMJPL_X_{name}"],
+    for arg in sys.argv[1:]:
+        name, _, opts = arg.partition(":")
+        flags = [f"-DMJPL_X_{name}"] if not opts else [o for o in opts.split(",") if o.startswith("-")]
+        os.environ.pop("MJPL_SPEC_CULL", None)
+        for o in opts.split(","):
+            if o.startswith("cull="):
+                os.environ["MJPL_SPEC_CULL"] = o[5:]
+        print(specialise.build(m, (), arm, base, force=True, extra_flags=flags,
                                output=os.path.join(ROOT, "variants", f"spec_{name}.so")))
+        os.environ.pop("MJPL_SPEC_CULL", None)
 
 
 if __name__ == "__main__":

@@ -5,9 +5,9 @@
 set -u
 LIB=$(python tools/build_bench_spec.py --path)
 cp "$LIB" /tmp/spec_orig.so
-python bench.py --steps 500 --no-cpu-baseline > gpurun_out/variant_REAL.json 2> gpurun_out/variant_REAL.err
+python bench.py --steps 500 --no-cpu-baseline --no-variants > gpurun_out/variant_REAL.json 2> gpurun_out/variant_REAL.err
 for v in "$@"; do
   cp "variants/spec_$v.so" "$LIB"
-  python bench.py --steps 500 --no-cpu-baseline > "gpurun_out/variant_$v.json" 2> "gpurun_out/variant_$v.err"
+  python bench.py --steps 500 --no-cpu-baseline --no-variants > "gpurun_out/variant_$v.json" 2> "gpurun_out/variant_$v.err"
 done
 cp /tmp/spec_orig.so "$LIB"
