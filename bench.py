@@ -699,6 +699,14 @@ def main():
                      "k_filter_edges": (max(interior - 0, 0) if items == 0 else 0, BYTES_PER_EDGE + 4, "edges"),
                      "k_patch_pairs": (undecided, 56 + 16, "undecided geom pairs"),
                      "k_check_edges": (E if not filt else 0, BYTES_PER_EDGE, "edges")}
+        # kernel names as a profiler shows them for this engine's launch layout
+        names = {}
+        if filt and info.get("persistent_kernels"):
+            names.update({"k_filter_endpoints": "k_filter_endpoints_pw", "k_filter_items": "k_filter_items_pw"})
+        if filt and info.get("fused_tail"):
+            names["k_patch_pairs"] = "k_tail"
+        stage_ms = {names.get(k, k): v for k, v in stage_ms.items()}
+        per_stage = {names.get(k, k): v for k, v in per_stage.items()}
         # the dominant kernel of THIS run = the longest stage
         kernel = max(stage_ms, key=lambda k: stage_ms[k])
         kernel_ms = stage_ms[kernel]
@@ -719,6 +727,7 @@ def main():
                        "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
                        "float32_filter": filt, "filter_tol_m": info["filter_tol"],
                        "specialised_kernels": spec,
+                       "persistent_kernels": bool(info.get("persistent_kernels")), "fused_tail": bool(info.get("fused_tail")),
                        "undecided_items_last_step": undecided,
                        "edges_reaching_interior_pass": interior, "interior_waypoint_items": items,
                        "parallelism": f"edge-sharded x{world.world}, no data-path collective",

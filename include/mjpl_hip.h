@@ -112,6 +112,11 @@ typedef struct mjpl_info {
    * general 24-slot build with moving boxes in the box queue; 2 = immediate narrowphase (more
    * than 24 stored geoms, or MJPL_FORCE_IMMEDIATE=1 at creation: tests) */
   int32_t filter_interpreter;
+  /* how an edge launch is laid out on the device (defaults; MJPL_PERSIST / MJPL_TAIL at creation):
+   * persistent_kernels = 1: endpoint and item kernels run as persistent grids of waves with tile queues;
+   * fused_tail = 1: walking kernel, pair re-check and exact edge kernel are roles of one launch (k_tail) */
+  int32_t persistent_kernels;
+  int32_t fused_tail;
 } mjpl_info;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -226,7 +231,9 @@ void *mjpl_stream(mjpl_engine *e);
 #define MJPL_STAGE_ENDPOINTS 0  /* k_filter_endpoints (incl. the counter memset)          */
 #define MJPL_STAGE_ITEMS     1  /* k_filter_items                                          */
 #define MJPL_STAGE_WALK      2  /* k_filter_edges                                          */
-#define MJPL_STAGE_PATCH     3  /* k_patch_pairs (moving boxes: k_check_configs, patch mode) */
+#define MJPL_STAGE_PATCH     3  /* k_patch_pairs (moving boxes: k_check_configs, patch mode); with mjpl_info.fused_tail:
+                                  * k_tail, the one launch that holds the walking, pair and exact-edge roles (stages
+                                  * 2 and 4 are then empty) */
 #define MJPL_STAGE_EXACT     4  /* k_check_edges                                           */
 #define MJPL_NSTAGES         5
 

@@ -20,7 +20,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 7
+#define MJPL_SPEC_ABI 8
 // digest of the headers both sides are built from (mjpl_amd/build.py: src_stamp); 0 = built by hand
 #ifndef MJPL_SRC_STAMP
 #define MJPL_SRC_STAMP 0ull
@@ -218,7 +218,8 @@ constexpr int kItemRegions = 32;
 // endpoint passed, unused, edges left to the walking kernel), the per-region item fills, the per-region
 // survivor counts.  The engine keeps two such sets and alternates: the first kernel of a launch clears
 // the set the NEXT launch will use (nobody touches it meanwhile), which saves a fill kernel per launch.
-constexpr int kNumCounters = 5 + 4 * kItemRegions;
+constexpr int kNumCounters = 5 + 4 * kItemRegions + 1;
+constexpr int kCtrTailDone = 5 + 4 * kItemRegions;  // k_tail: walking workgroups that are through
 // tile queues of the persistent kernels (k_filter_endpoints_pw / k_filter_items_pw), one per region:
 // the next tile of that region to hand out
 constexpr int kCtrEndpointTiles = 5 + 2 * kItemRegions;
@@ -617,6 +618,175 @@ k_filter_items(const int *__restrict__ gip, int nip, const float *__restrict__ g
   }
 }
 
+// ---- the walking kernel's body (one lane per edge): float32 checks for the filter, float64 for the verdicts
+// Work assignment shared by the exact kernels: lane j of (virtual) block vb takes item j, or -- when
+// re-running the filter's uncertain items -- item ulist[j] for j < *ucount.
+__device__ __forceinline__ bool pick_item(int64_t n, const int *__restrict__ ulist,
+                                          const int *__restrict__ ucount, int64_t *item, int64_t vb) {
+  const int64_t j = vb * blockDim.x + threadIdx.x;
+  if (ulist) {
+    const bool a = j < (int64_t)*ucount;
+    *item = a ? (int64_t)ulist[j] : 0;
+    return a;
+  }
+  *item = j;
+  return j < n;
+}
+__device__ __forceinline__ bool pick_item(int64_t n, const int *__restrict__ ulist,
+                                          const int *__restrict__ ucount, int64_t *item) {
+  return pick_item(n, ulist, ucount, item, (int64_t)blockIdx.x);
+}
+
+constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
+
+// One lane per edge.  Check 0 is the endpoint QB; checks 1..K are the interior waypoints of
+// _valid_collision_interval(QA, QB, step) generated on chip by the reference's own recurrence
+//   w <- w + ((QB - w)/||QB - w||) * min(step, ||QB - w||)      (planning/utils.py:182-185)
+// until w == QB (np.array_equal, :211).  ||.|| is the sequential-sum 2-norm over qpos
+// addresses in ascending order (see DESIGN.md "waypoint semantics").  The recurrence always
+// runs in float64, also in the filter kernel (FILTER = true), whose per-configuration checks
+// run in float32 and which hands every edge it cannot decide within `tol` to the exact kernel
+// through `ulist` / `ucount`.
+template <class T, int MAXS, bool WBOX, bool MBOX>
+__device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, const T *__restrict__ gtp,
+                                          int ntp, const double *__restrict__ QA,
+                                          const double *__restrict__ QB, int64_t E, double step, int layout,
+                                          int flags, T tol, uint8_t *__restrict__ valid,
+                                          int32_t *__restrict__ first_bad, int *__restrict__ status,
+                                          int *__restrict__ ulist, int *__restrict__ ucount,
+                                          const int *__restrict__ rlist, const int *__restrict__ rcount,
+                                          UndecidedConfigs uc, int vblock0 = -1, int nvblocks = 0) {
+  extern __shared__ double smem[];
+  const int B = blockDim.x;
+  // (virtual) blocks vblock0, vblock0 + nvblocks, ... of the work: a kernel of its own passes nothing and
+  // every workgroup takes the block of its own number, once; a role inside k_tail strides over the list
+  if (vblock0 < 0) { vblock0 = (int)blockIdx.x; nvblocks = (int)gridDim.x; }
+  const int64_t total = rlist ? (int64_t)*rcount : E;
+  if ((int64_t)vblock0 * B >= total) return;
+  const int nplan = gip[H_NPLAN];
+  Carve<T> c = carve_lds<T>(smem, gip, nip, gtp, ntp, nplan, 1, B, sizeof(double), WaveQueue<T, MBOX>::bytes());
+  for (int64_t vb = vblock0; vb * B < total; vb += nvblocks) {
+  if (vb != vblock0) __syncthreads();  // the columns and queues change hands
+  int64_t i;
+  const bool active = pick_item(E, rlist, rcount, &i, vb);
+  // The walking waypoint lives in LDS (starts at QB for check 0, then QA + steps); the edge end
+  // is re-read from global memory when needed (L2-resident, coalesced in the SoA layout):
+  // halving the per-lane LDS footprint buys an extra wave per SIMD.
+  double *qw = c.col0 + threadIdx.x;
+  auto end_col = [&](int k) -> double {
+    return active ? ((layout == MJPL_SOA) ? QB[(int64_t)k * E + i] : QB[i * nplan + k]) : 0.0;
+  };
+  auto start_col = [&](int k) -> double {
+    return active ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
+  };
+  load_columns(qw, B, QB, E, i, nplan, layout, active);
+  __syncthreads();
+  IP perm = c.ip + c.ip[H_OFF_PERM];
+
+  bool finite = true, at_end = true;
+  for (int k = 0; k < nplan; k++) {
+    double a = start_col(k), b = qw[k * B];
+    finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
+    at_end = at_end && (a == b);
+  }
+  bool done = !active;
+  bool ok = true, unsure = false;
+  int fb = -1;
+  if (active && finite) {
+    // an edge that needs more than kMaxWaypoints steps would only be found out after walking
+    // them all: say so at once (same verdict: reported like a non-finite edge)
+    double s0 = 0;
+    for (int k = 0; k < nplan; k++) {
+      const double d = qw[k * B] - start_col(k);
+      s0 = s0 + d * d;
+    }
+    if (!(sqrt(s0) <= step * (kMaxWaypoints + 2.0))) finite = false;
+  }
+  if (active && !finite) {
+    done = true; ok = false; fb = -2;
+    atomicOr(status, kStatusNonFinite);
+  }
+
+  // Iteration 0 checks the endpoint (apply_constraints validates q before the interval,
+  // utils.py:144); every later iteration advances the waypoint and checks it.  One call site
+  // of run_config keeps a single copy of the interpreter in the instruction stream.
+  int idx = 0;
+  bool stepped = false;
+  bool first = (flags & MJPL_EDGE_INTERIOR_ONLY) == 0;
+  if (!first && !done && at_end) done = true;
+  while (__ballot(!done) != 0ull) {
+    if (!first && !done) {
+      if (idx == 0 && !stepped) {  // leaving check 0: the walk starts at QA
+        for (int k = 0; k < nplan; k++) qw[k * B] = start_col(k);
+        stepped = true;
+      }
+      // _step(w, QB, step)
+      double s = 0;
+      for (int k = 0; k < nplan; k++) {
+        const int col = perm[k];
+        double d = end_col(col) - qw[col * B];
+        s = s + d * d;
+      }
+      const double mag = sqrt(s);
+      const double sm = step < mag ? step : mag;
+      bool eq = true;
+      for (int k = 0; k < nplan; k++) {
+        const double ek = end_col(k);
+        double d = ek - qw[k * B];
+        double nw = qw[k * B] + (d / mag) * sm;
+        qw[k * B] = nw;
+        eq = eq && (nw == ek);
+      }
+      if (!(mag > 0.0) || !(mag <= 1.79769313486231570815e+308)) {
+        // the squared distance under- or overflowed: the reference's recurrence yields NaN from
+        // here on and never ends -- reported like a non-finite edge
+        done = true; ok = false; fb = -2;
+        atomicOr(status, kStatusNonFinite);
+      } else if (eq) {
+        done = true;  // reached QB: that element is dropped by waypoints[1:-1]
+      } else {
+        idx++;
+        if (idx > kMaxWaypoints) {
+          done = true; ok = false; fb = -2;
+          atomicOr(status, kStatusNonFinite);
+        }
+      }
+    }
+    // idx is the same for every lane that is still walking (they all started together)
+    const unsigned long long walking = __ballot(!done);
+    const int widx = __builtin_amdgcn_readfirstlane(__shfl(idx, walking ? __ffsll((long long)walking) - 1 : 0));
+    const int code = check_one<T, MAXS, WBOX, MBOX>(c, qw, B, !done, tol, i, uc, widx);
+    if (!done && code == V_CONTACT) { done = true; ok = false; fb = idx; }
+    if (!done && code == V_UNSURE) {
+      // the filter cannot decide this configuration: hand IT (not the whole edge) to the exact
+      // configuration kernel and walk on as if it were valid; that kernel lowers first_bad and
+      // clears valid if it finds a contact.  Only if the hand-off buffer is full does the whole
+      // edge go to the exact edge kernel.  (The queued interpreter hands over single pairs by
+      // itself; when IT reports a configuration undecidable, the whole edge goes.)
+      const int j = kQueued<T, MAXS> ? uc.cap : atomicAdd(uc.count, 1);
+      if (j < uc.cap) {
+        for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
+        uc.edge[j] = (int)i;
+        uc.idx[j] = idx;
+        uc.ga[j] = uc.gb[j] = -1;  // the whole configuration (immediate interpreter)
+      } else {
+        done = true; unsure = true;
+      }
+    }
+    if (first && !done && at_end) done = true;  // waypoints == [start]: nothing interior
+    first = false;
+  }
+  if (active) {
+    if (unsure) {
+      ulist[atomicAdd(ucount, 1)] = (int)i;  // the exact kernel writes valid / first_bad
+    } else {
+      valid[i] = ok ? 1 : 0;
+      if (first_bad) first_bad[i] = fb;
+    }
+  }
+  }
+}
+
 // ---- persistent kernels: one wavefront per tile of 64, tiles handed out by a device counter -----------
 // k_filter_endpoints / k_filter_items give every workgroup 256 consecutive units and die with it: a
 // workgroup's four waves hold their SIMD slots and its 50 KiB of LDS until the slowest of them is through
@@ -961,17 +1131,17 @@ enum : int { GTB_TYPE = 0, GTB_SIZE = 1, GTB_RBOUND = 4, GTB_MARGIN = 5, GTB_STA
 // literals -- a wave of this kernel runs alone on its SIMD, and ~700 scalar table loads per wave,
 // each waited for, were most of its 30 us.
 template <class ESpec>
-__global__ void __launch_bounds__(kBlock)
-k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp, GeomTable gt,
-              UndecidedConfigs uc, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad) {
+__device__ __forceinline__ void patch_pairs_body(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp,
+                                                 GeomTable gt, UndecidedConfigs uc, uint8_t *__restrict__ valid,
+                                                 int32_t *__restrict__ first_bad, int vblock0, int nvblocks) {
   extern __shared__ double smem[];
   const int B = blockDim.x;
   const int64_t n = *uc.count < uc.cap ? *uc.count : uc.cap;
-  if ((int64_t)blockIdx.x * B >= n) return;
+  if ((int64_t)vblock0 * B >= n) return;
   const int nplan = gip[H_NPLAN];
   Carve<double> c = carve_lds<double>(smem, gip, nip, gdp, ndp, nplan, 1, B);
   // the number of items is read on the device and may exceed the grid: blocks stride over it
-  for (int64_t base = (int64_t)blockIdx.x * B; base < n; base += (int64_t)gridDim.x * B) {
+  for (int64_t base = (int64_t)vblock0 * B; base < n; base += (int64_t)nvblocks * B) {
   const int64_t u = base + threadIdx.x;
   bool active = u < n;
   const int ga = active ? uc.ga[u] : -1;
@@ -1148,6 +1318,84 @@ k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ g
     if (first_bad) atomicMin(reinterpret_cast<unsigned *>(first_bad) + ed, (unsigned)uc.idx[u]);
   }
   }
+}
+
+template <class ESpec>
+__global__ void __launch_bounds__(kBlock)
+k_patch_pairs(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int ndp, GeomTable gt,
+              UndecidedConfigs uc, uint8_t *__restrict__ valid, int32_t *__restrict__ first_bad) {
+  patch_pairs_body<ESpec>(gip, nip, gdp, ndp, gt, uc, valid, first_bad, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- one kernel for everything behind the item pass ---------------------------------------------------
+// What is left when the endpoint and item kernels are through: (W) the edges that did not become items --
+// longer than the item space allows per edge, or more than a region held -- for the walking body, (P) the
+// geom pairs the filter could not decide, for the float64 pair re-check, (X) the edges that have to be
+// redone in float64 as a whole.  In an RRT batch W and X are empty and P is ~30 waves: three launches cost
+// three kernel boundaries (6.5 + 21 + 6.5 us of a 0.25 ms step) for one wave's worth of work.  Here they are
+// roles of ONE grid: workgroups [0, nw) walk, the next np re-check pairs, the last nx redo edges, each
+// role striding over its list.  W may add to the lists of P and X, so those wait for it: every W workgroup
+// counts itself out (release), P and X spin on that count (a handful of microseconds when W has nothing to
+// do).  W comes first in the grid, so it is resident before anything waits for it; a wait that outlasts
+// every plausible W pass sets a status bit instead of hanging.
+constexpr int kStatusTailTimeout = 2;
+struct TailArgs {
+  const int *ip; int nip;
+  const float *fp; int nfp;
+  const double *dp; int ndp;
+  GeomTable gt;
+  UndecidedConfigs uc;
+  const double *QA, *QB;
+  long long E;
+  double step;
+  int layout, flags;
+  float tol;
+  uint8_t *valid;
+  int32_t *first_bad;
+  int *status, *ulist, *ucount;
+  const int *llist, *lcount;
+  int *done;       // W workgroups that are through (cleared with the launch's counters)
+  int nw, np, nx;  // workgroups per role
+};
+
+template <class ESpec, int MAXS_F, int MAXS_D, bool WBOX, bool MBOX>
+__global__ void __launch_bounds__(kBlock)
+k_tail(TailArgs a) {
+  const int b = (int)blockIdx.x;
+  if (b < a.nw) {
+    // (interior waypoints only: check 0 was the endpoint kernel's)
+    edge_body<float, MAXS_F, WBOX, MBOX>(a.ip, a.nip, a.fp, a.nfp, a.QA, a.QB, a.E, a.step, a.layout,
+                                         a.flags | MJPL_EDGE_INTERIOR_ONLY, a.tol, a.valid, a.first_bad, a.status, a.ulist,
+                                         a.ucount, a.llist, a.lcount, a.uc, b, a.nw);
+    if (*a.lcount > 0) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __threadfence();  // what this workgroup added to the lists, before its count
+        __hip_atomic_fetch_add(a.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  // (the walking list was closed by the endpoint kernel: when it is empty -- the usual case -- the walking
+  // workgroups add nothing to anybody's list and nobody waits for them)
+  if (*a.lcount > 0 && threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(a.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.nw) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1 << 24)) {  // (seconds: no W pass takes that long -- report, do not hang)
+        atomicOr(a.status, kStatusTailTimeout);
+        break;
+      }
+    }
+    __threadfence();
+  }
+  __syncthreads();
+  if (b < a.nw + a.np)
+    patch_pairs_body<ESpec>(a.ip, a.nip, a.dp, a.ndp, a.gt, a.uc, a.valid, a.first_bad, b - a.nw, a.np);
+  else
+    edge_body<double, MAXS_D, WBOX, MBOX>(a.ip, a.nip, a.dp, a.ndp, a.QA, a.QB, a.E, a.step, a.layout, a.flags, 0.0, a.valid,
+                                          a.first_bad, a.status, nullptr, nullptr, a.ulist, a.ucount, UndecidedConfigs{}, b - a.nw - a.np,
+                                          a.nx);
 }
 
 

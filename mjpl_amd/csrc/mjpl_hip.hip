@@ -32,7 +32,6 @@ namespace {
 
 using namespace mjpl;
 
-constexpr int kMaxWaypoints = 1 << 20;  // per-edge guard; the reference would spin forever
 constexpr int kCtr = kCounterStride;  // ints between device counters: one 128-byte line each
 constexpr int kNumCtr = kNumCounters;
 
@@ -57,21 +56,6 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 // ------------------------------------------------------------------------------- kernels
-
-// Work assignment shared by the exact kernels: lane j takes item j, or -- when re-running the
-// filter's uncertain items -- item ulist[j] for j < *ucount.
-__device__ __forceinline__ bool pick_item(int64_t n, const int *__restrict__ ulist,
-                                          const int *__restrict__ ucount, int64_t *item) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ulist) {
-    const bool a = j < (int64_t)*ucount;
-    *item = a ? (int64_t)ulist[j] : 0;
-    return a;
-  }
-  *item = j;
-  return j < n;
-}
-
 
 // ---- exact path (float64): final verdicts --------------------------------------------------
 
@@ -134,147 +118,6 @@ k_fk(const int *__restrict__ gip, int nip, const double *__restrict__ gdp, int n
   __syncthreads();
   run_config<double, 1, true, true, true>(c.ip, c.tp, c.col0 + threadIdx.x, B, c.save + threadIdx.x, B,
                                           active, 0.0, out, i);
-}
-
-// One lane per edge.  Check 0 is the endpoint QB; checks 1..K are the interior waypoints of
-// _valid_collision_interval(QA, QB, step) generated on chip by the reference's own recurrence
-//   w <- w + ((QB - w)/||QB - w||) * min(step, ||QB - w||)      (planning/utils.py:182-185)
-// until w == QB (np.array_equal, :211).  ||.|| is the sequential-sum 2-norm over qpos
-// addresses in ascending order (see DESIGN.md "waypoint semantics").  The recurrence always
-// runs in float64, also in the filter kernel (FILTER = true), whose per-configuration checks
-// run in float32 and which hands every edge it cannot decide within `tol` to the exact kernel
-// through `ulist` / `ucount`.
-template <class T, int MAXS, bool WBOX, bool MBOX>
-__device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, const T *__restrict__ gtp,
-                                          int ntp, const double *__restrict__ QA,
-                                          const double *__restrict__ QB, int64_t E, double step, int layout,
-                                          int flags, T tol, uint8_t *__restrict__ valid,
-                                          int32_t *__restrict__ first_bad, int *__restrict__ status,
-                                          int *__restrict__ ulist, int *__restrict__ ucount,
-                                          const int *__restrict__ rlist, const int *__restrict__ rcount,
-                                          UndecidedConfigs uc) {
-  extern __shared__ double smem[];
-  const int B = blockDim.x;
-  if (rlist && (int64_t)blockIdx.x * B >= (int64_t)*rcount) return;
-  const int nplan = gip[H_NPLAN];
-  Carve<T> c = carve_lds<T>(smem, gip, nip, gtp, ntp, nplan, 1, B, sizeof(double), WaveQueue<T, MBOX>::bytes());
-  int64_t i;
-  const bool active = pick_item(E, rlist, rcount, &i);
-  // The walking waypoint lives in LDS (starts at QB for check 0, then QA + steps); the edge end
-  // is re-read from global memory when needed (L2-resident, coalesced in the SoA layout):
-  // halving the per-lane LDS footprint buys an extra wave per SIMD.
-  double *qw = c.col0 + threadIdx.x;
-  auto end_col = [&](int k) -> double {
-    return active ? ((layout == MJPL_SOA) ? QB[(int64_t)k * E + i] : QB[i * nplan + k]) : 0.0;
-  };
-  auto start_col = [&](int k) -> double {
-    return active ? ((layout == MJPL_SOA) ? QA[(int64_t)k * E + i] : QA[i * nplan + k]) : 0.0;
-  };
-  load_columns(qw, B, QB, E, i, nplan, layout, active);
-  __syncthreads();
-  IP perm = c.ip + c.ip[H_OFF_PERM];
-
-  bool finite = true, at_end = true;
-  for (int k = 0; k < nplan; k++) {
-    double a = start_col(k), b = qw[k * B];
-    finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
-    at_end = at_end && (a == b);
-  }
-  bool done = !active;
-  bool ok = true, unsure = false;
-  int fb = -1;
-  if (active && finite) {
-    // an edge that needs more than kMaxWaypoints steps would only be found out after walking
-    // them all: say so at once (same verdict: reported like a non-finite edge)
-    double s0 = 0;
-    for (int k = 0; k < nplan; k++) {
-      const double d = qw[k * B] - start_col(k);
-      s0 = s0 + d * d;
-    }
-    if (!(sqrt(s0) <= step * (kMaxWaypoints + 2.0))) finite = false;
-  }
-  if (active && !finite) {
-    done = true; ok = false; fb = -2;
-    atomicOr(status, kStatusNonFinite);
-  }
-
-  // Iteration 0 checks the endpoint (apply_constraints validates q before the interval,
-  // utils.py:144); every later iteration advances the waypoint and checks it.  One call site
-  // of run_config keeps a single copy of the interpreter in the instruction stream.
-  int idx = 0;
-  bool stepped = false;
-  bool first = (flags & MJPL_EDGE_INTERIOR_ONLY) == 0;
-  if (!first && !done && at_end) done = true;
-  while (__ballot(!done) != 0ull) {
-    if (!first && !done) {
-      if (idx == 0 && !stepped) {  // leaving check 0: the walk starts at QA
-        for (int k = 0; k < nplan; k++) qw[k * B] = start_col(k);
-        stepped = true;
-      }
-      // _step(w, QB, step)
-      double s = 0;
-      for (int k = 0; k < nplan; k++) {
-        const int col = perm[k];
-        double d = end_col(col) - qw[col * B];
-        s = s + d * d;
-      }
-      const double mag = sqrt(s);
-      const double sm = step < mag ? step : mag;
-      bool eq = true;
-      for (int k = 0; k < nplan; k++) {
-        const double ek = end_col(k);
-        double d = ek - qw[k * B];
-        double nw = qw[k * B] + (d / mag) * sm;
-        qw[k * B] = nw;
-        eq = eq && (nw == ek);
-      }
-      if (!(mag > 0.0) || !(mag <= 1.79769313486231570815e+308)) {
-        // the squared distance under- or overflowed: the reference's recurrence yields NaN from
-        // here on and never ends -- reported like a non-finite edge
-        done = true; ok = false; fb = -2;
-        atomicOr(status, kStatusNonFinite);
-      } else if (eq) {
-        done = true;  // reached QB: that element is dropped by waypoints[1:-1]
-      } else {
-        idx++;
-        if (idx > kMaxWaypoints) {
-          done = true; ok = false; fb = -2;
-          atomicOr(status, kStatusNonFinite);
-        }
-      }
-    }
-    // idx is the same for every lane that is still walking (they all started together)
-    const unsigned long long walking = __ballot(!done);
-    const int widx = __builtin_amdgcn_readfirstlane(__shfl(idx, walking ? __ffsll((long long)walking) - 1 : 0));
-    const int code = check_one<T, MAXS, WBOX, MBOX>(c, qw, B, !done, tol, i, uc, widx);
-    if (!done && code == V_CONTACT) { done = true; ok = false; fb = idx; }
-    if (!done && code == V_UNSURE) {
-      // the filter cannot decide this configuration: hand IT (not the whole edge) to the exact
-      // configuration kernel and walk on as if it were valid; that kernel lowers first_bad and
-      // clears valid if it finds a contact.  Only if the hand-off buffer is full does the whole
-      // edge go to the exact edge kernel.  (The queued interpreter hands over single pairs by
-      // itself; when IT reports a configuration undecidable, the whole edge goes.)
-      const int j = kQueued<T, MAXS> ? uc.cap : atomicAdd(uc.count, 1);
-      if (j < uc.cap) {
-        for (int k = 0; k < nplan; k++) uc.q[(size_t)j * nplan + k] = qw[k * B];
-        uc.edge[j] = (int)i;
-        uc.idx[j] = idx;
-        uc.ga[j] = uc.gb[j] = -1;  // the whole configuration (immediate interpreter)
-      } else {
-        done = true; unsure = true;
-      }
-    }
-    if (first && !done && at_end) done = true;  // waypoints == [start]: nothing interior
-    first = false;
-  }
-  if (active) {
-    if (unsure) {
-      ulist[atomicAdd(ucount, 1)] = (int)i;  // the exact kernel writes valid / first_bad
-    } else {
-      valid[i] = ok ? 1 : 0;
-      if (first_bad) first_bad[i] = fb;
-    }
-  }
 }
 
 template <int MAXS, bool WBOX, bool MBOX>
@@ -917,8 +760,10 @@ struct SpecLib {
                                float, uint8_t *, int32_t *, int *, int *, int *, UndecidedConfigs, ItemBuffers, double, int *, int *);
   typedef int (*ItemsPwFn)(hipStream_t, size_t, const int *, int, const float *, int, ItemBuffers, EdgeSource, float, uint8_t *,
                            int32_t *, int *, int *, UndecidedConfigs, int *);
+  typedef int (*TailFn)(hipStream_t, size_t, TailArgs);
   EndpointsPwFn endpoints_pw = nullptr;
   ItemsPwFn items_pw = nullptr;
+  TailFn tail = nullptr;
   void *lib = nullptr;
   ConfigsFn configs = nullptr;
   EndpointsFn endpoints = nullptr;
@@ -983,6 +828,7 @@ struct mjpl_engine {
   // kernels, whose waves differ more in what a tile costs them, are faster as ordinary grids (0.397 vs
   // 0.459 ms).  MJPL_PERSIST=0 / 1 forces either (tests run both ways).
   int persist = -1;
+  bool fused_tail = true;  // MJPL_TAIL: walking kernel, pair re-check and exact edge kernel as roles of one launch (k_tail)
   size_t item_cap_limit = (size_t)1 << 26;  // MJPL_ITEM_CAP: edges beyond it take the walking kernel
   void *d_nn = nullptr;         // nearest neighbour: per-chunk partial results
   size_t nn_bytes = 0;
@@ -1075,10 +921,11 @@ void load_spec(mjpl_engine *e) {
     sl.patch = (SpecLib::PatchFn)dlsym(lib, "mjpl_spec_launch_patch");
     sl.endpoints_pw = (SpecLib::EndpointsPwFn)dlsym(lib, "mjpl_spec_launch_endpoints_pw");
     sl.items_pw = (SpecLib::ItemsPwFn)dlsym(lib, "mjpl_spec_launch_items_pw");
+    sl.tail = (SpecLib::TailFn)dlsym(lib, "mjpl_spec_launch_tail");
     // (the stamp: both libraries built from the same mjpl_filter.h / mjpl_device.h / mjpl_trig.h -- the
     // structs that cross this boundary by value and the table layouts live there)
     if (abi && hash && stamp && abi() == MJPL_SPEC_ABI && stamp() == (unsigned long long)MJPL_SRC_STAMP &&
-        hash() == e->program_hash && sl.configs && sl.endpoints && sl.items && sl.patch && sl.endpoints_pw && sl.items_pw)
+        hash() == e->program_hash && sl.configs && sl.endpoints && sl.items && sl.patch && sl.endpoints_pw && sl.items_pw && sl.tail)
       sl.lib = lib;
     else
       dlclose(lib);
@@ -1974,6 +1821,49 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       rcount = e->d_icount + kCtr;
     }
     MJPL_MARK(2);  // after k_filter_items
+    if (expand && e->fused_tail && !e->immediate()) {
+      // everything behind the item pass in one launch: walking role over the long-edge list, pair
+      // re-check, exact edge role over the undecided-edge list (k_tail)
+      MJPL_MARK(3);
+      const size_t ldst = std::max(ldsf, lds_bytes(e, 1));
+      TailArgs ta = {};
+      ta.ip = e->d_ip; ta.nip = (int)e->ip.size();
+      ta.fp = e->d_fp; ta.nfp = (int)e->fp.size();
+      ta.dp = e->d_dp; ta.ndp = (int)e->dp.size();
+      ta.gt = GeomTable{e->d_geomtab};
+      ta.uc = uc;
+      ta.QA = dQA; ta.QB = dQB; ta.E = (long long)E; ta.step = step; ta.layout = layout; ta.flags = flags;
+      ta.tol = e->filter_tol;
+      ta.valid = dvalid; ta.first_bad = dfb;
+      ta.status = e->d_status; ta.ulist = e->d_ulist; ta.ucount = e->d_ucount;
+      ta.llist = e->d_llist; ta.lcount = e->d_icount + kCtr;
+      ta.done = e->d_ucount + kCtrTailDone * kCtr;
+      const int eblocks = (int)std::min<int64_t>((E + kBlock - 1) / kBlock, 64);
+      ta.nw = eblocks;
+      ta.np = (int)std::min<size_t>((uc.cap + kBlock - 1) / kBlock, 64);
+      ta.nx = eblocks;
+      if (e->spec) {
+        rc = e->spec->tail(e->stream, ldst, ta) == 0 ? MJPL_OK : fail(MJPL_E_HIP, "specialised tail kernel failed to launch");
+      } else {
+        auto go = [&](auto SF, auto SD, auto W, auto M) -> int {
+          auto kern = k_tail<void, decltype(SF)::value, decltype(SD)::value, decltype(W)::value, decltype(M)::value>;
+          int r = allow_lds(kern, ldst);
+          if (r != MJPL_OK) return r;
+          hipLaunchKernelGGL(kern, dim3((unsigned)(ta.nw + ta.np + ta.nx)), dim3(kBlock), ldst, e->stream, ta);
+          return MJPL_OK;
+        };
+        if (e->exact_general())  // (moving boxes: 24-slot queued filter build, general exact build)
+          rc = go(std::integral_constant<int, kQueuedMaxSlots>{}, std::integral_constant<int, 32>{}, std::true_type{}, std::true_type{});
+        else
+          rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int { return go(S, S, W, M); });
+      }
+      if (rc != MJPL_OK) return rc;
+      guard.armed = false;
+      MJPL_MARK(4);
+      MJPL_MARK(5);
+      HIP_TRY(hipGetLastError());
+      return MJPL_OK;
+    }
     rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
       auto kern = k_filter_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
       int r = allow_lds(kern, ldsf);
@@ -2107,6 +1997,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_FORCE_IMMEDIATE")) e->force_immediate = atoi(f) != 0;
   if (const char *f = getenv("MJPL_EXPAND")) e->expand = atoi(f) != 0;
   if (const char *f = getenv("MJPL_PERSIST")) e->persist = atoi(f) != 0 ? 1 : 0;
+  if (const char *f = getenv("MJPL_TAIL")) e->fused_tail = atoi(f) != 0;
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
   if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));
   if (const char *t = getenv("MJPL_FILTER_TOL")) {
@@ -2313,6 +2204,8 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
   out->filter_block_threads = e->immediate() ? kBlock : kFilterBlock;
   out->lds_bytes_filter = (int)lds_bytes(e, 1, sizeof(float), out->filter_block_threads, !e->immediate(),
                                          e->immediate() ? sizeof(double) : sizeof(float));
+  out->persistent_kernels = ((e->persist < 0 ? e->spec != nullptr : e->persist != 0) && e->two_pass && e->expand && !e->immediate()) ? 1 : 0;
+  out->fused_tail = (e->fused_tail && e->two_pass && e->expand && !e->immediate()) ? 1 : 0;
   out->block_threads = kBlock;
   out->compute_units = e->prop.multiProcessorCount;
   strncpy(out->arch, e->prop.gcnArchName, sizeof(out->arch) - 1);
@@ -2354,6 +2247,7 @@ int mjpl_take_status(mjpl_engine *e, int32_t *status) {
   HIP_TRY(hipMemcpyAsync(&s, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (s & kStatusTailTimeout) return fail(MJPL_E_HIP, "the tail kernel gave up waiting for its walking workgroups");
   *status = (s & kStatusNonFinite) ? MJPL_E_NONFINITE : MJPL_OK;
   return MJPL_OK;
 }
@@ -2522,6 +2416,7 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
     if (first_bad) memcpy(first_bad, hout + vb, fbb);
     int status = 0;
     memcpy(&status, hout + vb + fbb, sizeof(int));
+    if (status & kStatusTailTimeout) return fail(MJPL_E_HIP, "the tail kernel gave up waiting for its walking workgroups");
     if (status & kStatusNonFinite)
       return fail(MJPL_E_NONFINITE, "an edge holds NaN/inf or needs more than %d waypoints", kMaxWaypoints);
     return MJPL_OK;
@@ -2541,6 +2436,7 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
   if (first_bad) HIP_TRY(hipMemcpyAsync(first_bad, e->stage[3], (size_t)E * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemcpyAsync(&status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (status & kStatusTailTimeout) return fail(MJPL_E_HIP, "the tail kernel gave up waiting for its walking workgroups");
   if (status & kStatusNonFinite)
     return fail(MJPL_E_NONFINITE, "an edge holds NaN/inf or needs more than %d waypoints", kMaxWaypoints);
   return MJPL_OK;

@@ -53,6 +53,7 @@ class Info(C.Structure):
         ("arch", C.c_char * 32),
         ("filter_max_coord", C.c_float), ("filter_err_a", C.c_float), ("filter_err_b", C.c_float),
         ("filter_poisoned_geoms", C.c_int32), ("filter_interpreter", C.c_int32),
+        ("persistent_kernels", C.c_int32), ("fused_tail", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -401,6 +402,9 @@ class Engine:
         return (ms, ms1) if first_kernel else ms
 
     STAGES = ("k_filter_endpoints", "k_filter_items", "k_filter_edges", "k_patch_pairs", "k_check_edges")
+    # with info()["fused_tail"] the fourth stage is k_tail (walking role + pair re-check + exact edge role in
+    # one launch) and stages three and five are empty; with info()["persistent_kernels"] the first two
+    # kernels are k_filter_endpoints_pw / k_filter_items_pw
 
     def time_edges_stages_dev(self, dQA, dQB, n, step_dist, layout, dvalid, iters, sample_every=4):
         """`iters` back-to-back edge launches -> (mean ms per launch, {stage kernel: mean ms},

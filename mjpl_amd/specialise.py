@@ -721,6 +721,12 @@ int mjpl_spec_launch_items_pw(hipStream_t st, size_t lds, const int *ip, int nip
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, ip, nip, fp, nfp, ib, src, tol, valid, first_bad, ulist, ucount, uc, tiles);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+int mjpl_spec_launch_tail(hipStream_t st, size_t lds, TailArgs a) {
+  auto kern = k_tail<ExactSpec, %(maxs)d, %(maxs)d, %(wbox)s, false>;
+  SPEC_GRANT(kern);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nw + a.np + a.nx)), dim3(kBlock), lds, st, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const double *dp,
                            int ndp, GeomTable gt, UndecidedConfigs uc, uint8_t *valid, int32_t *first_bad) {
   SPEC_LAUNCH((k_patch_pairs<ExactSpec>), ip, nip, dp, ndp, gt, uc, valid, first_bad);
