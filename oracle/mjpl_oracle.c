@@ -36,6 +36,14 @@ static double *scratch(int slot, size_t ndoubles) {
 
 #include "orc_math.h"
 
+#ifdef ORC_COUNT_FLOPS
+orc_flops_t orc_flops;
+void orc_flops_reset(void) { memset(&orc_flops, 0, sizeof(orc_flops)); }
+void orc_flops_get(long long *out5) {
+  out5[0] = orc_flops.add; out5[1] = orc_flops.mul; out5[2] = orc_flops.div; out5[3] = orc_flops.sqrt; out5[4] = orc_flops.sincos;
+}
+#endif
+
 int orc_trig_mode = 0;
 void orc_set_trig(int mode) { orc_trig_mode = mode ? 1 : 0; }
 int orc_get_trig(void) { return orc_trig_mode; }
@@ -67,6 +75,7 @@ int orc_kinematics(const orc_model *m, const double *qpos,
     /* fixed translation and rotation relative to the parent */
     mul_mat_vec3(p, xmat + 9 * pid, bodypos);
     p[0] += xpos[3 * pid]; p[1] += xpos[3 * pid + 1]; p[2] += xpos[3 * pid + 2];
+    ORC_FL(3, 0, 0, 0);
     mul_quat(q, xquat + 4 * pid, bodyquat);
 
     /* accumulate joints */
@@ -79,10 +88,12 @@ int orc_kinematics(const orc_model *m, const double *qpos,
       rot_vec_quat(xaxis, m->jnt_axis + 3 * jid, q);
       rot_vec_quat(xanchor, m->jnt_pos + 3 * jid, q);
       xanchor[0] += p[0]; xanchor[1] += p[1]; xanchor[2] += p[2];
+      ORC_FL(3, 0, 0, 0);
 
       if (jtype == ORC_JNT_SLIDE) {
         const double d = qpos[qadr] - m->qpos0[qadr];
         p[0] += xaxis[0] * d; p[1] += xaxis[1] * d; p[2] += xaxis[2] * d;
+        ORC_FL(4, 3, 0, 0);
       } else if (jtype == ORC_JNT_HINGE) {
         double qloc[4], vec[3];
         axis_angle2quat(qloc, m->jnt_axis + 3 * jid, qpos[qadr] - m->qpos0[qadr]);
@@ -90,6 +101,7 @@ int orc_kinematics(const orc_model *m, const double *qpos,
         /* correct for off-centre rotation */
         rot_vec_quat(vec, m->jnt_pos + 3 * jid, q);
         p[0] = xanchor[0] - vec[0]; p[1] = xanchor[1] - vec[1]; p[2] = xanchor[2] - vec[2];
+        ORC_FL(4, 0, 0, 0);  /* + the joint value minus its reference */
       } else {
         status = ORC_E_JOINT;
       }
@@ -110,6 +122,7 @@ int orc_kinematics(const orc_model *m, const double *qpos,
       geom_xpos[3 * g + 0] = p[0] + xpos[3 * b + 0];
       geom_xpos[3 * g + 1] = p[1] + xpos[3 * b + 1];
       geom_xpos[3 * g + 2] = p[2] + xpos[3 * b + 2];
+      ORC_FL(3, 0, 0, 0);
     }
     if (geom_xmat) {
       double q[4];
@@ -135,6 +148,7 @@ static int raw_sphere_sphere(double margin, const double *pos1, double r1,
   double dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
   double cdist_sqr = dot3(dif, dif);
   double min_dist = margin + r1 + r2;
+  ORC_FL(5, 1, 0, 0);
   if (cdist_sqr > min_dist * min_dist) return 0;
   return 1;
 }
@@ -145,6 +159,7 @@ static int plane_sphere(double margin, const double *pos1, const double *mat1,
   double n[3] = {mat1[2], mat1[5], mat1[8]};
   double tmp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
   double cdist = dot3(tmp, n);
+  ORC_FL(4, 0, 0, 0);
   if (cdist > margin + r2) return 0;
   return 1;
 }
@@ -155,6 +170,7 @@ static int plane_capsule(double margin, const double *pos1, const double *mat1,
   double axis[3] = {mat2[2], mat2[5], mat2[8]};
   double seg[3] = {size2[1] * axis[0], size2[1] * axis[1], size2[1] * axis[2]};
   double e[3];
+  ORC_FL(6, 3, 0, 0);
   e[0] = pos2[0] + seg[0]; e[1] = pos2[1] + seg[1]; e[2] = pos2[2] + seg[2];
   int n1 = plane_sphere(margin, pos1, mat1, e, size2[0]);
   e[0] = pos2[0] - seg[0]; e[1] = pos2[1] - seg[1]; e[2] = pos2[2] - seg[2];
@@ -168,6 +184,7 @@ static int plane_box(double margin, const double *pos1, const double *mat1,
   double norm[3] = {mat1[2], mat1[5], mat1[8]};
   double dif[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
   double dist = dot3(dif, norm);
+  ORC_FL(3, 0, 0, 0);
   int cnt = 0;
   for (int i = 0; i < 8; i++) {
     double vec[3], corner[3];
@@ -176,6 +193,7 @@ static int plane_box(double margin, const double *pos1, const double *mat1,
     vec[2] = (i & 4) ? size2[2] : -size2[2];
     mul_mat_vec3(corner, mat2, vec);
     double ldist = dot3(norm, corner);
+    ORC_FL(1, 0, 0, 0);
     if (dist + ldist > margin || ldist > 0) continue;
     if (++cnt >= 4) return 4;
   }
@@ -189,6 +207,7 @@ static int sphere_capsule(double margin, const double *pos1, double r1,
   double axis[3] = {mat2[2], mat2[5], mat2[8]};
   double vec[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
   double x = clipd(dot3(axis, vec), -len, len);
+  ORC_FL(6, 3, 0, 0);
   vec[0] = axis[0] * x + pos2[0];
   vec[1] = axis[1] * x + pos2[1];
   vec[2] = axis[2] * x + pos2[2];
@@ -210,25 +229,32 @@ static int capsule_capsule(double margin, const double *pos1, const double *mat1
   double v = dot3(axis2, dif);
   double det = ma * mc - mb * mb;
   double vec1[3], vec2[3];
+  ORC_FL(4, 8, 0, 0);  /* the two scaled axes, dif, det (the five dot products count themselves) */
 
   if (fabs(det) >= ORC_MINVAL) {
     double x1 = (mc * u - mb * v) / det;
     double x2 = (ma * v - mb * u) / det;
+    ORC_FL(2, 4, 2, 0);
 
     if (x1 > 1) {
       x1 = 1;
       x2 = (v - mb) / mc;
+      ORC_FL(1, 0, 1, 0);
     } else if (x1 < -1) {
       x1 = -1;
       x2 = (v + mb) / mc;
+      ORC_FL(1, 0, 1, 0);
     }
     if (x2 > 1) {
       x2 = 1;
       x1 = clipd((u - mb) / ma, -1, 1);
+      ORC_FL(1, 0, 1, 0);
     } else if (x2 < -1) {
       x2 = -1;
       x1 = clipd((u + mb) / ma, -1, 1);
+      ORC_FL(1, 0, 1, 0);
     }
+    ORC_FL(6, 6, 0, 0);
 
     for (int k = 0; k < 3; k++) {
       vec1[k] = pos1[k] + axis1[k] * x1;
@@ -238,6 +264,7 @@ static int capsule_capsule(double margin, const double *pos1, const double *mat1
   }
 
   /* parallel axes: up to two sphere tests per end */
+  ORC_FL(4 * 7, 4 * 3, 4, 0);  /* (rare: counted as all four end tests) */
   int n = 0;
   double x1, x2;
   /* x1 = 1 */
@@ -272,6 +299,7 @@ static int sphere_box_local(double margin, const double *c, double r, const doub
   double d[3];
   for (int k = 0; k < 3; k++) d[k] = clipd(c[k], -size2[k], size2[k]) - c[k];
   double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  ORC_FL(3 + 2 + 1, 3, 0, 1);
   if (dist - r > margin) return 0;
   return 1;
 }
@@ -281,6 +309,7 @@ static int sphere_box(double margin, const double *pos1, double r1,
                       const double *pos2, const double *mat2, const double *size2) {
   double tmp[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
   double center[3];
+  ORC_FL(3, 0, 0, 0);
   mul_matT_vec3(center, mat2, tmp);
   return sphere_box_local(margin, center, r1, size2);
 }
@@ -298,6 +327,7 @@ static double capbox_g(const double *p, const double *h, const double *s, double
     double x = p[k] + t * h[k];
     double e = x - fmin(fmax(x, -s[k]), s[k]);
     g = g + h[k] * e;
+    ORC_FL(3, 2, 0, 0);
   }
   return g;
 }
@@ -313,6 +343,7 @@ static int capsule_box(double margin, const double *pos1, const double *mat1,
   for (int k = 0; k < 3; k++) {
     h[k] = a[k] * size1[1];
     inv[k] = 1 / h[k]; /* h == 0: +-inf, the breakpoint becomes +-inf or NaN and is skipped */
+    ORC_FL(1, 1, 1, 0); /* (+ one subtraction of tmp per axis) */
   }
 
   double lo = -1, hi = 1;
@@ -322,6 +353,7 @@ static int capsule_box(double margin, const double *pos1, const double *mat1,
   for (int k = 0; k < 3; k++) {
     for (int sgn = -1; sgn <= 1; sgn += 2) {
       double tb = (sgn * size2[k] - p[k]) * inv[k];
+      ORC_FL(1, 2, 0, 0);
       int inside = (tb > lo && tb < hi);
       double gb = capbox_g(p, h, size2, tb);
       if (inside && gb <= 0) { lo = tb; glo = gb; }
@@ -330,6 +362,7 @@ static int capsule_box(double margin, const double *pos1, const double *mat1,
   }
   double den = ghi - glo;
   double t = (den > 0) ? lo + (hi - lo) * ((0 - glo) / den) : lo;
+  ORC_FL(1 + 3 + 3, 1 + 3, 1, 0);  /* den, the linear piece, and the point p + t h */
   /* minimum at an end of the segment (decided on the values at -1 and +1) */
   double g_m1 = capbox_g(p, h, size2, -1), g_p1 = capbox_g(p, h, size2, 1);
   if (g_m1 >= 0) t = -1;
@@ -350,16 +383,19 @@ static int box_box(double margin, const double *pos1, const double *mat1, const 
     for (int j = 0; j < 3; j++)
       R[3 * i + j] = mat1[i] * mat2[j] + mat1[3 + i] * mat2[3 + j] + mat1[6 + i] * mat2[6 + j];
   mul_matT_vec3(t, mat1, d);
+  ORC_FL(3 + 18, 27, 0, 0);
   for (int k = 0; k < 9; k++) A[k] = fabs(R[k]);
   /* face axes of box 1 */
   for (int i = 0; i < 3; i++) {
     double rb = size2[0] * A[3 * i] + size2[1] * A[3 * i + 1] + size2[2] * A[3 * i + 2];
+    ORC_FL(4, 3, 0, 0);
     if (fabs(t[i]) - (size1[i] + rb) > margin) return 0;
   }
   /* face axes of box 2 */
   for (int j = 0; j < 3; j++) {
     double ra = size1[0] * A[j] + size1[1] * A[3 + j] + size1[2] * A[6 + j];
     double tj = t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j];
+    ORC_FL(6, 6, 0, 0);
     if (fabs(tj) - (ra + size2[j]) > margin) return 0;
   }
   /* edge x edge axes, normalised so that margin keeps its metric meaning */
@@ -368,10 +404,12 @@ static int box_box(double margin, const double *pos1, const double *mat1, const 
     for (int j = 0; j < 3; j++) {
       const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
       double len2 = 1 - R[3 * i + j] * R[3 * i + j];
+      ORC_FL(1, 1, 0, 0);
       if (len2 < 1e-12) continue; /* near-parallel edges: covered by the face axes */
       double ra = size1[i1] * A[3 * i2 + j] + size1[i2] * A[3 * i1 + j];
       double rb = size2[j1] * A[3 * i + j2] + size2[j2] * A[3 * i + j1];
       double tl = t[i2] * R[3 * i1 + j] - t[i1] * R[3 * i2 + j];
+      ORC_FL(5, 7, 0, 1);
       if (fabs(tl) - (ra + rb) > margin * sqrt(len2)) return 0;
     }
   }
@@ -440,6 +478,7 @@ static int bound_skip(const orc_model *m, const double *gx, const double *gm, in
     const double *a = gx + 3 * g1, *b = gx + 3 * g2;
     double dif[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
     double bound = r1 + r2 + margin;
+    ORC_FL(5, 1, 0, 0);
     if (dot3(dif, dif) > bound * bound) return 1;
     return 0;
   }
@@ -452,6 +491,7 @@ static int bound_skip(const orc_model *m, const double *gx, const double *gm, in
     double n[3] = {pm[2], pm[5], pm[8]};
     double dif[3] = {gx[3 * gs] - gx[3 * gp], gx[3 * gs + 1] - gx[3 * gp + 1],
                      gx[3 * gs + 2] - gx[3 * gp + 2]};
+    ORC_FL(4, 0, 0, 0);
     if (dot3(dif, n) > margin + m->geom_rbound[gs]) return 1;
   }
   return 0;
@@ -532,6 +572,7 @@ int orc_valid_config(const orc_model *m, const int32_t *allowed, int32_t nallowe
 static double norm_seq(const double *v, int n) {
   double s = 0;
   for (int k = 0; k < n; k++) s = s + v[k] * v[k];
+  ORC_FL(n, n, 0, 1);
   return sqrt(s);
 }
 
@@ -553,6 +594,7 @@ void orc_step(const double *start, const double *target, int32_t n, double max_s
   double mag = norm_seq(d, n);                                 /* :183 */
   double stepmag = max_step < mag ? max_step : mag;            /* min(max_step_dist, magnitude) */
   for (int k = 0; k < n; k++) out[k] = start[k] + (d[k] / mag) * stepmag; /* :184-185 */
+  ORC_FL(2 * n, n, n, 0);
   if (d != dir) free(d);
 }
 

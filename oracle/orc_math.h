@@ -10,20 +10,39 @@
 #define ORC_MINVAL 1e-15 /* mjMINVAL [MJ-recalled: mjmodel.h] */
 #define ORC_UNUSED __attribute__((unused))
 
+/* Operation count of the float64 arithmetic the oracle executes ("exact static count emitted by
+ * cpu_ref").  Built only into libmjpl_oracle_count.so (-DORC_COUNT_FLOPS, oracle/Makefile; tools/count_flops.py):
+ * every routine adds the additions / subtractions, multiplications, divisions and square roots of the statements
+ * it has just executed -- read off the expressions, in the branch that was taken -- to one global tally; sin/cos
+ * pairs are tallied as calls (the fdlibm restatement below executes 27 additions and 28 multiplications per pair).
+ * Comparisons, negations, fabs, fmin / fmax and copies are not counted.  Single-threaded use only. */
+#ifdef ORC_COUNT_FLOPS
+typedef struct { long long add, mul, div, sqrt, sincos; } orc_flops_t;
+extern orc_flops_t orc_flops;
+#define ORC_FL(a, m, d, s) ((void)(orc_flops.add += (a), orc_flops.mul += (m), orc_flops.div += (d), orc_flops.sqrt += (s)))
+#define ORC_FL_SINCOS() ((void)(orc_flops.sincos += 1))
+#else
+#define ORC_FL(a, m, d, s) ((void)0)
+#define ORC_FL_SINCOS() ((void)0)
+#endif
+
 /* ------------------------------------------------------------------ small vector helpers
  * [MJ-recalled: engine_util_blas.c / engine_util_spatial.c]; operation order is the contract. */
 
 ORC_UNUSED static double dot3(const double *a, const double *b) {
+  ORC_FL(2, 3, 0, 0);
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 
 ORC_UNUSED static void mul_mat_vec3(double *res, const double *mat, const double *vec) {
+  ORC_FL(6, 9, 0, 0);
   res[0] = mat[0] * vec[0] + mat[1] * vec[1] + mat[2] * vec[2];
   res[1] = mat[3] * vec[0] + mat[4] * vec[1] + mat[5] * vec[2];
   res[2] = mat[6] * vec[0] + mat[7] * vec[1] + mat[8] * vec[2];
 }
 
 ORC_UNUSED static void mul_matT_vec3(double *res, const double *mat, const double *vec) {
+  ORC_FL(6, 9, 0, 0);
   res[0] = mat[0] * vec[0] + mat[3] * vec[1] + mat[6] * vec[2];
   res[1] = mat[1] * vec[0] + mat[4] * vec[1] + mat[7] * vec[2];
   res[2] = mat[2] * vec[0] + mat[5] * vec[1] + mat[8] * vec[2];
@@ -31,6 +50,7 @@ ORC_UNUSED static void mul_matT_vec3(double *res, const double *mat, const doubl
 
 /* mju_mulQuat */
 ORC_UNUSED static void mul_quat(double *res, const double *a, const double *b) {
+  ORC_FL(12, 16, 0, 0);
   double t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
   double t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
   double t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
@@ -45,6 +65,7 @@ ORC_UNUSED static void rot_vec_quat(double *res, const double *vec, const double
   } else if (quat[0] == 1 && quat[1] == 0 && quat[2] == 0 && quat[3] == 0) {
     res[0] = vec[0]; res[1] = vec[1]; res[2] = vec[2];
   } else {
+    ORC_FL(12, 18, 0, 0);
     double t0 = quat[0] * vec[0] + quat[2] * vec[2] - quat[3] * vec[1];
     double t1 = quat[0] * vec[1] + quat[3] * vec[0] - quat[1] * vec[2];
     double t2 = quat[0] * vec[2] + quat[1] * vec[1] - quat[2] * vec[0];
@@ -87,6 +108,7 @@ ORC_UNUSED static double orc_kcos(double x, double y) {
 }
 
 ORC_UNUSED static void orc_sincos(double x, double *s, double *c) {
+  ORC_FL_SINCOS();
   if (orc_trig_mode == 0 || !(fabs(x) < 8.2e5)) { *s = sin(x); *c = cos(x); return; }
   /* x = n * pi/2 + (y0 + y1), pi/2 in three 33-bit pieces (Cody-Waite) */
   const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
@@ -115,6 +137,7 @@ ORC_UNUSED static void axis_angle2quat(double *res, const double *axis, double a
   } else {
     double s, c;
     orc_sincos(angle * 0.5, &s, &c);
+    ORC_FL(0, 4, 0, 0);
     res[0] = c;
     res[1] = axis[0] * s;
     res[2] = axis[1] * s;
@@ -125,9 +148,11 @@ ORC_UNUSED static void axis_angle2quat(double *res, const double *axis, double a
 /* mju_normalize4 */
 ORC_UNUSED static void normalize4(double *v) {
   double norm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+  ORC_FL(3, 4, 0, 1);
   if (norm < ORC_MINVAL) {
     v[0] = 1; v[1] = 0; v[2] = 0; v[3] = 0;
-  } else if (fabs(norm - 1) > ORC_MINVAL) {
+  } else if ((ORC_FL(1, 0, 0, 0), fabs(norm - 1) > ORC_MINVAL)) {
+    ORC_FL(0, 4, 1, 0);
     double inv = 1 / norm;
     v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
   }
@@ -140,6 +165,7 @@ ORC_UNUSED static void quat2mat(double *res, const double *q) {
     res[3] = 0; res[4] = 1; res[5] = 0;
     res[6] = 0; res[7] = 0; res[8] = 1;
   } else {
+    ORC_FL(15, 16, 0, 0);
     const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
     const double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
     const double q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];

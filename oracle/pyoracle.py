@@ -79,7 +79,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
+        # MJPL_ORACLE_LIB: another build of the same sources (tools/count_flops.py loads the counting one)
+        _lib = C.CDLL(os.environ.get("MJPL_ORACLE_LIB") or _LIB_PATH)
         _lib.orc_kinematics.restype = C.c_int
         _lib.orc_collision.restype = C.c_int
         _lib.orc_obeys_ruleset.restype = C.c_int

@@ -8,6 +8,8 @@ import pytest
 
 from mjpl_amd import scenes
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -107,3 +109,32 @@ def test_franka_home_is_valid_and_floor_contact_detected(oracle_mod):
     q2 = home.copy()
     q2[7:] = 0.0
     assert orc.valid_config(q2)  # 3 mm gap when closed
+
+
+def test_operation_count_of_the_oracle(tmp_path):
+    """tools/count_flops.py: the counting build of the oracle (every routine tallies the float64 operations it
+    executed) gives the same verdicts as the ordinary build and a count that only depends on the inputs.  One
+    configuration of Franka-P + 16 obstacles costs seven sin/cos pairs (its seven hinges away from their
+    reference) and a few thousand operations; the committed profiles/flops.json is this tool's output."""
+    import subprocess
+    import sys
+    out = tmp_path / "flops.json"
+    tool = os.path.join(ROOT, "tools", "count_flops.py")
+    recs = []
+    for _ in range(2):
+        subprocess.run([sys.executable, tool, "--edges", "512", "--out", str(out)], check=True, capture_output=True)
+        recs.append(json.load(open(out)))
+    assert recs[0]["ops_per_edge"] == recs[1]["ops_per_edge"]
+    r = recs[0]
+    assert r["ops_per_config"]["sincos"] == 7.0
+    assert 3000 < r["flops_per_config"] < 12000 and r["flops_per_edge"] > 2 * r["flops_per_config"]
+    from mjpl_amd import scenes
+    import bench
+    from oracle import pyoracle
+    m = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    qa, qb = bench.make_edges(m, qidx, bench.EDGES_PER_GPU, seed=2)
+    v = pyoracle.Oracle(m, planning_qidx=qidx, qpos_base=m.keyframe("home").qpos.copy()).valid_edges(qa[:512], qb[:512], bench.STEP, nthreads=2)
+    assert abs(float(np.mean(v)) - r["valid_fraction_of_sample"]) < 1e-12
+    committed = json.load(open(os.path.join(ROOT, "profiles", "flops.json")))
+    assert abs(committed["flops_per_config"] - r["flops_per_config"]) / r["flops_per_config"] < 0.05
