@@ -138,3 +138,68 @@ def test_operation_count_of_the_oracle(tmp_path):
     assert abs(float(np.mean(v)) - r["valid_fraction_of_sample"]) < 1e-12
     committed = json.load(open(os.path.join(ROOT, "profiles", "flops.json")))
     assert abs(committed["flops_per_config"] - r["flops_per_config"]) / r["flops_per_config"] < 0.05
+
+
+# ---- fixtures made by REAL MuJoCo, whenever somebody has run tools/crosscheck_mujoco.py --write ----------------
+def _mujoco_fixtures():
+    import glob
+    return sorted(glob.glob(os.path.join(GOLDEN, "mujoco_*.json")))
+
+
+def _crosscheck():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import crosscheck_mujoco
+    return crosscheck_mujoco
+
+
+@pytest.mark.parametrize("path", _mujoco_fixtures() or [None], ids=lambda p: os.path.basename(p)[:-5] if p else "none-committed")
+def test_oracle_against_fixtures_written_by_mujoco(oracle_mod, path):
+    """Every tests/golden/mujoco_<model>.json present (tools/crosscheck_mujoco.py --write on a machine that has
+    the mujoco wheel; none can be made in the build container) pins the oracle to MuJoCo itself: verdicts of the
+    seeded configurations, and FK of the first rows to 1e-12.  Capsule-box / box-box disagreements -- the two
+    routines restated by another algorithm -- are told apart from any other."""
+    if path is None:
+        pytest.skip("no MuJoCo-written fixture is committed: the oracle is pinned by the reference's known answers, "
+                    "the scipy FK fixtures and the independent narrowphase fixtures only ('parity unpinned' against MuJoCo)")
+    rep = _crosscheck().check_fixture(path, oracle_mod)
+    assert not rep["stale"], "the model this fixture was made with has changed: regenerate it"
+    assert rep["fk_max_abs_err"] < 1e-12, rep
+    assert rep["mismatches_other"] == 0, rep
+    assert rep["mismatches_capsule_box_or_box_box_only"] == 0, rep  # (reported apart: DESIGN.md section 2's two deviations)
+
+
+def test_the_fixture_consumer_itself(oracle_mod, tmp_path):
+    """The consumer on a fixture written through the same writer from the oracle's own outputs (labelled so: it
+    pins nothing) -- it must pass, notice a flipped verdict and a shifted FK number, and name the pair types."""
+    cm = _crosscheck()
+    name = "pair_capsule_box"
+    model = cm.model_by_name(name)
+    k, seed = 300, 11
+    Q = np.random.default_rng(seed).uniform(model.jnt_range[:, 0], model.jnt_range[:, 1], size=(k, model.nq))
+    orc = oracle_mod.Oracle(model)
+    valid = orc.valid_configs(Q, nthreads=2).astype(bool)
+    contacts = [[[int(a), int(b)] for a, b in orc.contacts(q)] for q in Q]
+    fk_o = orc.fk(Q[:16])
+    fk = {key: np.asarray(fk_o[key]).reshape(16, -1).tolist() for key in ("xpos", "xquat", "geom_xpos", "geom_xmat")}
+    fix = cm.make_fixture(name, model, seed, k, valid, contacts, fk, "SELF-TEST: the oracle's own outputs")
+    path = tmp_path / f"mujoco_{name}.json"
+    json.dump(fix, open(path, "w"))
+    rep = cm.check_fixture(str(path), oracle_mod)
+    assert not rep["stale"] and rep["mismatches"] == 0 and rep["fk_max_abs_err"] == 0.0
+    # a configuration whose only contact is the capsule-box pair, reported the other way round
+    row = next(i for i in range(k) if not valid[i] and all(sorted(c) == [1, 2] for c in contacts[i]))
+    bad = dict(fix)
+    v = valid.copy()
+    v[row] = True
+    bad["valid_bits"] = np.packbits(v).tobytes().hex()
+    bad["contacts"] = [c if i != row else [] for i, c in enumerate(contacts)]
+    bad["fk_first_rows"] = {key: [list(r) for r in rows] for key, rows in fk.items()}
+    bad["fk_first_rows"]["xpos"][3][4] += 1e-9
+    json.dump(bad, open(path, "w"))
+    rep = cm.check_fixture(str(path), oracle_mod)
+    assert rep["mismatches"] == 1 and rep["mismatches_capsule_box_or_box_box_only"] == 1 and rep["mismatches_other"] == 0
+    assert rep["examples"][0]["pairs"] == ["box-capsule"] and 0.5e-9 < rep["fk_max_abs_err"] < 2e-9
+    bad["mjcf_sha256"] = "0" * 64
+    json.dump(bad, open(path, "w"))
+    assert cm.check_fixture(str(path), oracle_mod)["stale"]

@@ -105,6 +105,67 @@ def compare_tables(model, mj):
     return bad
 
 
+def make_fixture(name, model, seed, k, valid, contacts, fk, engine):
+    """tests/golden/mujoco_<name>.json: the verdicts, contact lists and (first rows') FK an engine -- MuJoCo --
+    gave the first k configurations of default_rng(seed).uniform(jnt_range) on the model `name` of models();
+    the digest of the emitted MJCF ties the file to the model it was made with."""
+    import hashlib
+    return {"model": name, "seed": int(seed), "n": int(k), "engine": engine,
+            "generator": "tools/crosscheck_mujoco.py --write (inputs: default_rng(seed).uniform(jnt_range), first n rows)",
+            "mjcf_sha256": hashlib.sha256(to_mjcf(model, name).encode()).hexdigest(),
+            "valid_bits": np.packbits(np.asarray(valid, bool)).tobytes().hex(),
+            "contacts": contacts, "fk_first_rows": fk}
+
+
+def model_by_name(name, seed=20250523):
+    """The model a fixture names (same construction as main(): seeded)."""
+    for group in ("franka_p", "franka_p_pads", "ur5e", "pairs", "random"):
+        ms = models({group}, np.random.default_rng(seed))
+        if name in ms:
+            return ms[name]
+    raise KeyError(name)
+
+
+def check_fixture(path, oracle_mod=None):
+    """Compare the CPU oracle with one tests/golden/mujoco_*.json.  -> report dict: verdict mismatches in all,
+    split into those whose differing contacts involve ONLY capsule-box / box-box pairs (the two routines the
+    oracle does not restate op for op) and the others, and the largest FK difference."""
+    import hashlib
+    if oracle_mod is None:
+        from oracle import pyoracle as oracle_mod
+    fix = json.load(open(path))
+    model = model_by_name(fix["model"])
+    if hashlib.sha256(to_mjcf(model, fix["model"]).encode()).hexdigest() != fix["mjcf_sha256"]:
+        return {"model": fix["model"], "stale": True}
+    k = fix["n"]
+    Q = np.random.default_rng(fix["seed"]).uniform(model.jnt_range[:, 0], model.jnt_range[:, 1], size=(k, model.nq))
+    want = np.unpackbits(np.frombuffer(bytes.fromhex(fix["valid_bits"]), np.uint8))[:k].astype(bool)
+    orc = oracle_mod.Oracle(model)
+    got = orc.valid_configs(Q, nthreads=2).astype(bool)
+    deviating, other, examples = 0, 0, []
+    for i in np.flatnonzero(got != want):
+        mine = {tuple(sorted(int(x) for x in c)) for c in orc.contacts(Q[i])}
+        theirs = {tuple(sorted(c)) for c in fix["contacts"][i]}
+        kinds = {"-".join(sorted((TYPE_NAMES.get(int(model.geom_type[a]), "?"), TYPE_NAMES.get(int(model.geom_type[b]), "?"))))
+                 for a, b in mine ^ theirs}
+        if kinds and kinds <= {"box-capsule", "box-box"}:
+            deviating += 1
+        else:
+            other += 1
+        if len(examples) < 5:
+            examples.append({"row": int(i), "pairs": sorted(kinds)})
+    nfk = len(fix["fk_first_rows"]["xpos"])
+    fk_err = 0.0
+    if nfk:
+        fk_o = orc.fk(Q[:nfk])
+        for key in ("xpos", "xquat", "geom_xpos", "geom_xmat"):
+            ref = np.asarray(fix["fk_first_rows"][key], float)
+            fk_err = max(fk_err, float(np.abs(ref - np.asarray(fk_o[key]).reshape(nfk, -1)).max()))
+    return {"model": fix["model"], "engine": fix["engine"], "stale": False, "n": k, "mismatches": int((got != want).sum()),
+            "mismatches_capsule_box_or_box_box_only": deviating, "mismatches_other": other, "fk_max_abs_err": fk_err,
+            "examples": examples}
+
+
 def check_model(name, model, n, seed, mujoco, write_dir):
     from oracle import pyoracle
     xml = to_mjcf(model, name)
@@ -143,9 +204,16 @@ def check_model(name, model, n, seed, mujoco, write_dir):
                   mujoco_version=mujoco.__version__)
     if write_dir:
         k = min(n, 2000)
-        fix = {"model": name, "seed": seed, "n": k, "mujoco_version": mujoco.__version__,
-               "generator": "tools/crosscheck_mujoco.py --write (inputs: default_rng(seed).uniform(jnt_range), first n rows)",
-               "valid_bits": np.packbits(got[:k]).tobytes().hex(), "xpos_row0": np.asarray(fk_o["xpos"][0]).tolist()}
+        contacts, fk = [], {"xpos": [], "xquat": [], "geom_xpos": [], "geom_xmat": []}
+        for i in range(k):  # MuJoCo's own outputs, configuration by configuration
+            data.qpos[:] = Q[i]
+            mujoco.mj_kinematics(mj, data)
+            mujoco.mj_collision(mj, data)
+            contacts.append([[int(x) for x in data.contact.geom[c]] for c in range(data.ncon)])
+            if i < 16:
+                for key, arr in (("xpos", data.xpos), ("xquat", data.xquat), ("geom_xpos", data.geom_xpos), ("geom_xmat", data.geom_xmat)):
+                    fk[key].append(np.asarray(arr, float).reshape(-1).tolist())
+        fix = make_fixture(name, model, seed, k, got[:k], contacts, fk, "mujoco " + mujoco.__version__)
         with open(os.path.join(write_dir, f"mujoco_{name}.json"), "w") as f:
             json.dump(fix, f)
     return report
