@@ -607,7 +607,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="edges workload: skip the float64-only and interpreter engines timed beside the headline")
-    ap.add_argument("--variant", choices=["headline", "f64", "interpreter"], default="headline",
+    ap.add_argument("--variant", choices=["headline", "f64", "interpreter", "generic"], default="headline",
                     help="edges workload: which engine configuration the TIMED steps run (profiling passes of the "
                          "variants: tools/profile_gpu.sh); the default line carries all three")
     ap.add_argument("--lanes", type=int, default=131072, help="rrt workload: lanes per rank per round")
@@ -646,14 +646,14 @@ def main():
 
     def make_engine(filt=True, spec=True):
         e = engine.Engine(model, device=world.local_rank)
-        if not spec:
-            e.set_spec(False)
+        if spec is not True:
+            e.set_spec(int(spec))  # (0: interpreter; 2: the robot's scene-generic library)
         e.set_planning(qidx, base)
         if not filt:
             e.set_filter(False)
         return e
 
-    timed = {"headline": (True, True), "f64": (False, True), "interpreter": (True, False)}[args.variant]
+    timed = {"headline": (True, True), "f64": (False, True), "interpreter": (True, False), "generic": (True, 2)}[args.variant]
     eng = make_engine(*timed)
     world.attach(eng)
     info = eng.info()
@@ -768,7 +768,8 @@ def main():
         if world.world == 1 and not args.no_variants and args.variant == "headline":
             variants = {}
             vsteps = max(50, min(args.steps, 200))
-            for name, (vf, vs) in (("f64_only", (False, True)), ("interpreter", (True, False))):
+            # ... and the robot's scene-generic library (obstacles from a table: any scene without a compiler)
+            for name, (vf, vs) in (("f64_only", (False, True)), ("interpreter", (True, False)), ("scene_generic", (True, 2))):
                 ve = make_engine(vf, vs)
                 va, vb, vv = ve.alloc(ha.nbytes).upload(ha), ve.alloc(hb.nbytes).upload(hb), ve.alloc(E)
                 dt, v_launch, v_stage, v_n = time_variant(ve, engine, va, vb, E, layout, vv, vsteps, 5)
@@ -780,6 +781,7 @@ def main():
                 variants[name] = {"value": E * vsteps / dt, "unit": "edges/s", "steps": vsteps, "ms_per_step": dt / vsteps * 1e3,
                                   "step_ms_all_kernels": v_launch, "kernels_ms": v_stage, "dtype": "f64" if not vf else "f32-filter+f64-exact",
                                   "float32_filter": bool(ve.info()["filter_enabled"]), "specialised_kernels": bool(ve.spec_loaded()),
+                                  "library": {0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[ve.spec_kind()],
                                   "verdicts_equal_headline": same, "edges_compared": E,
                                   "valu_issue": valu_issue(vk, v_stage[vk], rec)}
                 if name == "f64_only" and flops.get("flops_per_edge"):

@@ -349,15 +349,26 @@ typedef struct mjpl_program_info {
   float   filter_tol;
   int32_t nslots, nsave;
   int32_t spec_abi;
+  /* scene-generic libraries (one per ROBOT: static geoms may change without a compiler): the hash of what
+   * such a library carries as literals -- moving bodies, their geoms and self pairs, planning set,
+   * tolerance -- the number of cull rows per moving geom it reads from the engine's scene table, and
+   * whether this program can run on one (<= scene_rows static geoms, <= 24 moving geoms numbered
+   * consecutively, no moving boxes) */
+  uint64_t robot_hash;
+  int32_t scene_rows;
+  int32_t scene_ok;
 } mjpl_program_info;
 int mjpl_program_dump(const mjpl_model_desc *model, const int32_t *allowed_bodies, int32_t nallowed,
                       const int32_t *qidx, int32_t nplan, const double *qpos_base, double filter_tol,
                       int32_t *ip, int32_t *nip, float *fp, double *dp, int32_t *ntab,
                       mjpl_program_info *info);
-/* 1 if the engine's current program runs on a specialised library */
+/* 1 if the engine's current program runs on its own specialised library (hash of the whole program), 2 if
+ * on the robot's scene-generic one (obstacles from a table), 0: the interpreting kernels */
 int mjpl_spec_loaded(const mjpl_engine *e);
 /* enable = 0: this engine runs the interpreting kernels whatever libraries exist (A/B measurements,
- * bench.py's "interpreter" variant); 1: look the program's library up again.  Synchronises. */
+ * bench.py's "interpreter" variant); 1: look the libraries up again (the program's own first, then the
+ * robot's scene-generic one); 2: the scene-generic one only (bench.py's "scene_generic" variant).
+ * Synchronises. */
 int mjpl_set_spec(mjpl_engine *e, int32_t enable);
 
 /* ---- frontier bi-RRT, device-resident (BASELINE configs[3]) -------------

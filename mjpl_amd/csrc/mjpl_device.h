@@ -788,6 +788,22 @@ __device__ __forceinline__ void park_mask2(int &lo, int &hi, unsigned long long 
         "n"(LANE_A), "n"(LANE_B));
 }
 
+// ... two masks in lanes `lane` and `lane + 1` chosen at run time (wave-uniform).  v_writelane takes its
+// value from the scalar side already, so the lane select cannot be a second SGPR (one constant-bus read
+// per instruction on gfx9): it travels in M0, whose old value is put back -- the compiler does not treat
+// M0 as clobbered by inline assembly.
+__device__ __forceinline__ void park_mask_at2(int &lo, int &hi, unsigned long long ma, unsigned long long mb, int lane) {
+  int keep;
+  asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %7\n\ts_nop 1\n\t"
+      "v_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\t"
+      "s_add_u32 m0, m0, 1\n\ts_nop 0\n\t"
+      "v_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"
+      "s_mov_b32 m0, %2"
+      : "+v"(lo), "+v"(hi), "=&s"(keep)
+      : "s"((int)(unsigned)ma), "s"((int)(unsigned)(ma >> 32)), "s"((int)(unsigned)mb), "s"((int)(unsigned)(mb >> 32)), "s"(lane)
+      : "scc");
+}
+
 // control words are wave-uniform: pin them to SGPRs so the interpreter's branches are scalar
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

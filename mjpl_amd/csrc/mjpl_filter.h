@@ -20,7 +20,14 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 8
+#define MJPL_SPEC_ABI 9
+// scene-generic specialised libraries: cull rows per moving geom, moving geoms at most,
+// floats of the scene header in front of the rows
+// Table: [header | per moving geom: kSceneRows cull rows of 4 floats, then kSceneRows descriptor words | one
+// spare chunk of four rows (the code fetches two rows ahead)].  Rows 0 and 1 of a geom are its plane partners.
+constexpr int kSceneRows = 32, kScenePlaneRows = 2, kSceneMaxStages = 24, kSceneHeader = 32;
+constexpr int kSceneStageFloats = kSceneRows * 4 + kSceneRows;
+inline size_t scene_floats(int nstage) { return (size_t)kSceneHeader + (size_t)nstage * kSceneStageFloats + 16; }
 // digest of the headers both sides are built from (mjpl_amd/build.py: src_stamp); 0 = built by hand
 #ifndef MJPL_SRC_STAMP
 #define MJPL_SRC_STAMP 0ull
@@ -1122,6 +1129,7 @@ inline unsigned persistent_grid(K kernel, size_t lds, long long ntile) {
 // of FK + all culls + every narrowphase call some lane of the wave needs.
 struct GeomTable {           // per model geom, float64 [GT_LEN]
   const double *t;
+  int moving_base;           // id of the first moving geom (a scene-generic ExactSpec numbers geoms from it)
 };
 enum : int { GTB_TYPE = 0, GTB_SIZE = 1, GTB_RBOUND = 4, GTB_MARGIN = 5, GTB_STATIC = 6, GTB_XPOS = 7,
              GTB_XMAT = 10, GTB_LEN = 19 };
@@ -1163,7 +1171,7 @@ __device__ __forceinline__ void patch_pairs_body(const int *__restrict__ gip, in
   for (int k = 0; k < 9; k++) A.m[k] = Bg.m[k] = 0;
   double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   if constexpr (!std::is_void<ESpec>::value) {
-    ESpec::fk_pair(q, B, save, sstride, active, ga, gb, A, Bg);
+    ESpec::fk_pair(q, B, save, sstride, active, ga - ESpec::kRelative * gt.moving_base, gb - ESpec::kRelative * gt.moving_base, A, Bg);
   } else {
   const int nbodyops = uni(ip[H_NBODYOPS]);
   int pc = uni(ip[H_OFF_BODYOPS]);

@@ -765,6 +765,7 @@ struct SpecLib {
   ItemsPwFn items_pw = nullptr;
   TailFn tail = nullptr;
   void *lib = nullptr;
+  int generic_rows = 0, generic_stages = 0;  // scene-generic libraries: rows per moving geom, moving geoms
   ConfigsFn configs = nullptr;
   EndpointsFn endpoints = nullptr;
   ItemsFn items = nullptr;
@@ -800,7 +801,17 @@ struct mjpl_engine {
   int npoisoned = 0;              // static geoms too large / far for binary32: their pairs are always undecided
   uint64_t program_hash = 0;      // FNV-1a of the compiled tables (ip, fp, dp), the kernel variant and the header digest
   const SpecLib *spec = nullptr;  // this model's own filter kernels, if a library for program_hash was found
+  // ... or, failing that, a scene-generic library of the ROBOT (robot_hash: moving bodies, their geoms and
+  // self pairs, planning set, tolerance -- nothing of the static geoms): its generated code takes every
+  // static partner's cull row from a table in front of the float32 tables (scene_floats of them), so the
+  // obstacles may change without a compiler
+  bool spec_generic = false;
+  uint64_t robot_hash = 0;
+  int moving_base = 0;           // model id of the first moving geom
+  std::vector<float> scene;      // [scene header | per moving geom: kSceneRows rows of 8] (compile_program)
+  float *d_fp_base = nullptr;    // allocation behind d_fp (= d_fp_base + scene.size())
   bool spec_off = false;          // mjpl_set_spec(e, 0): run the interpreting kernels whatever libraries exist
+  bool spec_generic_only = false; // mjpl_set_spec(e, 2): pass over the program's own library, take the robot's scene-generic one
   int *d_ulist = nullptr;   // items (configurations / whole edges) the filter left undecided
   int *d_ucount_base = nullptr;  // both counter sets; d_ucount = the one the last launch used
   bool counters_stale = false;
@@ -863,7 +874,7 @@ struct mjpl_engine {
 
 namespace {
 
-void load_spec(mjpl_engine *e);
+void load_spec(mjpl_engine *e, bool generic_ok, int nstage);
 
 int stage_reserve(mjpl_engine *e, int k, size_t bytes) {
   if (bytes <= e->stage_bytes[k]) return MJPL_OK;
@@ -885,17 +896,12 @@ std::map<uint64_t, SpecLib> &spec_cache() {
   return c;
 }
 
-void load_spec(mjpl_engine *e) {
-  e->spec = nullptr;
-  if (const char *s = getenv("MJPL_SPEC"))
-    if (atoi(s) == 0) return;
-  if (e->spec_off || e->exact_general() || !e->filter_usable) return;  // (the generator covers the small queued builds)
+// dlopen <dir>/<prefix><hash>.so and check that it was built for this hash from these headers
+const SpecLib *find_spec(uint64_t hash, bool generic) {
   auto &cache = spec_cache();
-  auto it = cache.find(e->program_hash);
-  if (it != cache.end()) {
-    e->spec = it->second.lib ? &it->second : nullptr;
-    return;
-  }
+  const uint64_t key = hash ^ (generic ? 0x9e3779b97f4a7c15ull : 0ull);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second.lib ? &it->second : nullptr;
   SpecLib sl;
   std::string dir;
   if (const char *d = getenv("MJPL_SPEC_DIR")) {
@@ -909,12 +915,13 @@ void load_spec(mjpl_engine *e) {
     }
   }
   char name[64];
-  snprintf(name, sizeof(name), "/libmjpl_spec_%016llx.so", (unsigned long long)e->program_hash);
+  snprintf(name, sizeof(name), "/libmjpl_spec%s_%016llx.so", generic ? "g" : "", (unsigned long long)hash);
   void *lib = dir.empty() ? nullptr : dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
   if (lib) {
     auto abi = (int (*)())dlsym(lib, "mjpl_spec_abi");
-    auto hash = (unsigned long long (*)())dlsym(lib, "mjpl_spec_hash");
+    auto hashf = (unsigned long long (*)())dlsym(lib, "mjpl_spec_hash");
     auto stamp = (unsigned long long (*)())dlsym(lib, "mjpl_spec_src_stamp");
+    auto gen = (int (*)())dlsym(lib, "mjpl_spec_generic");  // 0, or rows per moving geom << 8 | moving geoms
     sl.configs = (SpecLib::ConfigsFn)dlsym(lib, "mjpl_spec_launch_configs");
     sl.endpoints = (SpecLib::EndpointsFn)dlsym(lib, "mjpl_spec_launch_endpoints");
     sl.items = (SpecLib::ItemsFn)dlsym(lib, "mjpl_spec_launch_items");
@@ -924,14 +931,34 @@ void load_spec(mjpl_engine *e) {
     sl.tail = (SpecLib::TailFn)dlsym(lib, "mjpl_spec_launch_tail");
     // (the stamp: both libraries built from the same mjpl_filter.h / mjpl_device.h / mjpl_trig.h -- the
     // structs that cross this boundary by value and the table layouts live there)
-    if (abi && hash && stamp && abi() == MJPL_SPEC_ABI && stamp() == (unsigned long long)MJPL_SRC_STAMP &&
-        hash() == e->program_hash && sl.configs && sl.endpoints && sl.items && sl.patch && sl.endpoints_pw && sl.items_pw && sl.tail)
+    const int g = gen ? gen() : 0;
+    if (abi && hashf && stamp && abi() == MJPL_SPEC_ABI && stamp() == (unsigned long long)MJPL_SRC_STAMP && hashf() == hash &&
+        (g != 0) == generic && sl.configs && sl.endpoints && sl.items && sl.patch && sl.endpoints_pw && sl.items_pw && sl.tail) {
       sl.lib = lib;
-    else
+      sl.generic_rows = g >> 8;
+      sl.generic_stages = g & 255;
+    } else {
       dlclose(lib);
+    }
   }
-  cache[e->program_hash] = sl;
-  e->spec = cache[e->program_hash].lib ? &cache[e->program_hash] : nullptr;
+  cache[key] = sl;
+  return cache[key].lib ? &cache[key] : nullptr;
+}
+
+// `generic_ok`: the program satisfies what a scene-generic library assumes (compile_program)
+void load_spec(mjpl_engine *e, bool generic_ok = false, int nstage = 0) {
+  e->spec = nullptr;
+  e->spec_generic = false;
+  if (const char *s = getenv("MJPL_SPEC"))
+    if (atoi(s) == 0) return;
+  if (e->spec_off || e->exact_general() || !e->filter_usable) return;  // (the generator covers the small queued builds)
+  if (!e->spec_generic_only) e->spec = find_spec(e->program_hash, false);
+  if (e->spec || !generic_ok) return;
+  const SpecLib *g = find_spec(e->robot_hash, true);
+  if (g && g->generic_rows == kSceneRows && g->generic_stages == nstage) {
+    e->spec = g;
+    e->spec_generic = true;
+  }
 }
 
 int pin_reserve(mjpl_engine *e, size_t bytes) {
@@ -1420,21 +1447,164 @@ int compile_program(mjpl_engine *e) {
     mix(&stamp, sizeof(stamp));
     e->program_hash = h;
   }
+  // ---- identity of the ROBOT alone, and the cull table a scene-generic library reads.
+  // Everything the generated code of such a library carries as literals goes into robot_hash: the moving
+  // bodies with their constants, joints (planning column or constant), geoms, register slots and self
+  // pairs with their bounds, tolerance, kernel shape.  Nothing of the static geoms: those reach the code
+  // through `scene` -- a header, then for every moving geom kSceneRows cull rows [a0 a1 a2 thr] followed by
+  // kSceneRows descriptor words: a plane partner (rows 0, 1) passes its cull when a . c <= thr (a =
+  // normal), any other (rows 2 ..) when |c|^2 + a . c <= thr (a = -2 X: the expanded form, threshold
+  // raised by the form's rounding bound for a centre within the geom's reach); the descriptor says what a
+  // candidate of that pair is queued as.  Rows that are no pair of the geom never pass (thr = -inf).
+  const int nstage = nm;
+  e->moving_base = nm > 0 ? mgeoms[0] : 0;
+  int nplanes = 0;
+  for (int w = 0; w < nworld; w++) nplanes += (winfo[w] & 255) == GT_PLANE ? 1 : 0;
+  bool generic_ok = !e->exact_general() && e->filter_usable && nplanes <= kScenePlaneRows && nworld - nplanes <= kSceneRows - kScenePlaneRows &&
+                    nstage <= kSceneMaxStages && nstage > 0;
+  for (int k = 1; k < nm && generic_ok; k++) generic_ok = mgeoms[k] == mgeoms[0] + k;  // (the pair re-check counts geoms from the first moving one)
+  {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](const void *ptr, size_t n) {
+      const unsigned char *b = (const unsigned char *)ptr;
+      for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 0x100000001b3ull; }
+    };
+    auto mixi = [&](int v) { mix(&v, sizeof(v)); };
+    auto mixd = [&](const double *v, int n) { mix(v, sizeof(double) * (size_t)n); };
+    mixi(nplan); mixi(e->maxs); mixi(e->nslots); mixi(nsave); mixi(MJPL_SPEC_ABI); mixi(kSceneRows);
+    const unsigned long long stamp = MJPL_SRC_STAMP;
+    mix(&stamp, sizeof(stamp));
+    const float tolf = e->filter_tol;
+    mix(&tolf, sizeof(tolf));
+    int gk2 = 0;
+    for (size_t k = 0; k < order.size(); k++) {
+      const int b = order[k], p = m.body_parentid[b];
+      const int psrc = e->body_static[p] ? (int)PARENT_STATIC : ((k > 0 && order[k - 1] == p) ? (int)PARENT_CUR : save_slot[p] + 1);
+      mixi(psrc);
+      mixd(&m.body_pos[3 * b], 3); mixd(&m.body_quat[4 * b], 4);
+      if (psrc == PARENT_STATIC) { mixd(&e->st_xpos[3 * p], 3); mixd(&e->st_xquat[4 * p], 4); mixd(&st_xmat[9 * p], 9); }
+      mixi(m.body_jntnum[b]); mixi(save_slot[b]);
+      for (int j = 0; j < m.body_jntnum[b]; j++) {
+        const int jid = m.body_jntadr[b] + j, qadr = m.jnt_qposadr[jid];
+        mixi(m.jnt_type[jid]); mixi(col_of[qadr]);
+        mixd(&m.jnt_axis[3 * jid], 3); mixd(&m.jnt_pos[3 * jid], 3); mixd(&m.qpos0[qadr], 1);
+        const double qc = col_of[qadr] < 0 ? e->qbase[qadr] : 0.0;
+        mixd(&qc, 1);
+      }
+      for (; gk2 < nm && m.geom_bodyid[mgeoms[gk2]] == b; gk2++) {
+        const int g = mgeoms[gk2];
+        mixi(m.geom_type[g]); mixi(slot_of[gk2]);
+        mixd(&m.geom_pos[3 * g], 3); mixd(&m.geom_quat[4 * g], 4); mixd(&m.geom_size[3 * g], 3);
+        mixd(&m.geom_rbound[g], 1); mixd(&m.geom_margin[g], 1);
+        for (int k2 : stored_partners[gk2]) { mixi(k2); mixi(slot_of[k2]); }
+        mixi(-1);
+      }
+      mixi(-2);
+    }
+    e->robot_hash = h;
+  }
+  e->scene.clear();
+  if (generic_ok) {
+    const size_t S = scene_floats(nstage);
+    e->scene.assign(S, 0.0f);
+    auto seti = [&](size_t at, int v) { memcpy(&e->scene[at], &v, sizeof(float)); };
+    const double u24 = std::ldexp(1.0, -24);
+    auto round_up = [](double v) {
+      float f = (float)v;
+      if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+      return f;
+    };
+    // how far from the origin a moving geom's centre can be while its lane is alive (specialise.py: the same)
+    const double box_reach = std::sqrt(3.0) * (double)(float)e->fmax_coord;
+    std::vector<double> breach(nb, 0.0);
+    auto n3 = [](const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    for (int b : order) {
+      const int p = m.body_parentid[b];
+      double r = (e->body_static[p] ? n3(&e->st_xpos[3 * p]) : breach[p]) + n3(&m.body_pos[3 * b]);
+      for (int j = 0; j < m.body_jntnum[b]; j++) {
+        const int jid = m.body_jntadr[b] + j;
+        if (m.jnt_type[jid] == JT_SLIDE) r = std::numeric_limits<double>::infinity();
+        else r += 2.0 * n3(&m.jnt_pos[3 * jid]);
+      }
+      breach[b] = std::fmin(r, box_reach);
+    }
+    // [0] rows in use (a multiple of four: the code takes them four at a time), [2] nwpad, [3] offset of the narrowphase table
+    seti(0, nplanes); seti(1, nworld > nplanes ? ((kScenePlaneRows + nworld - nplanes + 3) & ~3) : (nplanes ? kScenePlaneRows : 0));
+    seti(2, nwpad); seti(3, ip[H_OFF_WNARROW]);
+    e->scene[4] = (float)e->fmax_coord;
+    e->scene[5] = kFilterMaxAngle;
+    int gk3 = 0, pc = ip[H_OFF_BODYOPS];
+    for (size_t k = 0; k < order.size(); k++) {
+      const int b = order[k];
+      const int njnt = ip[pc + B_NJNT], ngeom_here = ip[pc + B_NGEOM];
+      pc += B_SIZE + njnt * J_SIZE;
+      for (int gi = 0; gi < ngeom_here; gi++, gk3++) {
+        const int g = mgeoms[gk3], gtype = m.geom_type[g], gdoff = ip[pc + G_DOFF];
+        pc += G_SIZE + MAX_SLOTS;
+        seti(8 + gk3, gdoff);
+        const double reach = breach[b] + n3(&m.geom_pos[3 * g]);
+        std::set<int> partners(world_partners[gk3].begin(), world_partners[gk3].end());
+        float *rows = &e->scene[(size_t)kSceneHeader + (size_t)gk3 * kSceneStageFloats];
+        float *descs = rows + (size_t)kSceneRows * 4;
+        for (int r0 = 0; r0 < kSceneRows; r0++) rows[(size_t)r0 * 4 + 3] = -std::numeric_limits<float>::infinity();
+        for (int pass = 0; pass < 2; pass++) {  // planes in rows 0 and 1, the others from row 2 on
+          int r = pass == 0 ? 0 : kScenePlaneRows;
+          for (int sgeom = 0; sgeom < ng; sgeom++) {
+            if (!e->geom_static[sgeom] || world_row[sgeom] < 0) continue;
+            const int w = world_row[sgeom], ptype = winfo[w] & 255;
+            if ((ptype == GT_PLANE) != (pass == 0)) continue;
+            float *row = rows + (size_t)r * 4;
+            float *dword = descs + r;
+            r++;
+            if (!partners.count(sgeom)) continue;  // (not a pair of this geom: a row that never passes)
+            const double X[3] = {(double)fp[wc_at(w, 0)], (double)fp[wc_at(w, 1)], (double)fp[wc_at(w, 2)]};
+            const double bound = (double)fp[(size_t)gdoff + GD_WBOUND + w];
+            int desc;
+            if (ptype == GT_PLANE) {
+              const float *rw = &fp[(size_t)ip[H_OFF_WNARROW] + (size_t)w * WN_LEN];
+              const double n[3] = {(double)rw[WN_ZAXIS], (double)rw[WN_ZAXIS + 1], (double)rw[WN_ZAXIS + 2]};
+              const double off = n[0] * X[0] + n[1] * X[1] + n[2] * X[2];
+              for (int c = 0; c < 3; c++) row[c] = (float)n[c];
+              // three fused multiply-adds on a centre within `reach`: each rounds by at most u (reach + |n . p0| + |bound|)
+              row[3] = std::isfinite(reach) ? round_up(bound + off + 4.0 * u24 * (1.01 * reach + std::fabs(off) + std::fabs(bound)))
+                                            : std::numeric_limits<float>::infinity();
+              desc = EK_PLANE | (w << 2) | (GT_PLANE << 10) | (1 << 14);
+            } else {
+              const double nx = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+              for (int c = 0; c < 3; c++) row[c] = (float)(-2.0 * X[c]);
+              // (the allowance of specialise.py: expanded_threshold)
+              const double allow = 8.0 * u24 * (1.01 * reach + nx) * (1.01 * reach + nx);
+              row[3] = std::isfinite(reach) ? round_up(bound - (X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) + allow)
+                                            : std::numeric_limits<float>::infinity();
+              if (!std::isfinite(bound)) row[3] = (float)bound;
+              const int pgid = winfo[w] >> 8;
+              const int pfirst = (ptype < gtype || (ptype == gtype && pgid < g)) ? 1 : 0;
+              desc = EK_STATIC | (w << 2) | (ptype << 10) | (pfirst << 14) | ((ptype == GT_BOX ? 1 : 0) << 15);
+            }
+            memcpy(dword, &desc, sizeof(float));
+          }
+        }
+      }
+    }
+  }
   if (e->device < 0) return MJPL_OK;  // mjpl_program_dump: host tables only
-  load_spec(e);
+  load_spec(e, generic_ok, nstage);
+  if (!e->spec_generic) e->scene.clear();
 
   // ---- upload
   if (e->d_ip) (void)hipFree(e->d_ip);
   if (e->d_dp) (void)hipFree(e->d_dp);
-  if (e->d_fp) (void)hipFree(e->d_fp);
+  if (e->d_fp_base) (void)hipFree(e->d_fp_base);
   e->d_ip = nullptr;
   e->d_dp = nullptr;
-  e->d_fp = nullptr;
+  e->d_fp = e->d_fp_base = nullptr;
   HIP_TRY(hipMalloc(&e->d_ip, ip.size() * sizeof(int)));
   HIP_TRY(hipMalloc(&e->d_dp, dp.size() * sizeof(double)));
-  HIP_TRY(hipMalloc(&e->d_fp, fp.size() * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->d_fp_base, (e->scene.size() + fp.size()) * sizeof(float)));
+  e->d_fp = e->d_fp_base + e->scene.size();  // (the kernels' table pointer: a scene-generic library reads backwards from it)
   HIP_TRY(hipMemcpy(e->d_ip, ip.data(), ip.size() * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_dp, dp.data(), dp.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (!e->scene.empty()) HIP_TRY(hipMemcpy(e->d_fp_base, e->scene.data(), e->scene.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_fp, fp.data(), fp.size() * sizeof(float), hipMemcpyHostToDevice));
   return MJPL_OK;
 }
@@ -1567,7 +1737,7 @@ int dispatch_filter(const mjpl_engine *e, F &&f) {
 
 // exact re-check of the undecided pairs: the model's own straight-line float64 FK if it has a library
 int launch_patch(mjpl_engine *e, unsigned pgrid, size_t ldsc, const UndecidedConfigs &uc, uint8_t *dvalid, int32_t *dfb) {
-  GeomTable gt = {e->d_geomtab};
+  GeomTable gt = {e->d_geomtab, e->moving_base};
   if (e->spec)
     return e->spec->patch(e->stream, pgrid, (unsigned)kBlock, ldsc, e->d_ip, (int)e->ip.size(), e->d_dp, (int)e->dp.size(), gt,
                           uc, dvalid, dfb) == 0 ? MJPL_OK : fail(MJPL_E_HIP, "specialised pair kernel failed to launch");
@@ -1830,7 +2000,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       ta.ip = e->d_ip; ta.nip = (int)e->ip.size();
       ta.fp = e->d_fp; ta.nfp = (int)e->fp.size();
       ta.dp = e->d_dp; ta.ndp = (int)e->dp.size();
-      ta.gt = GeomTable{e->d_geomtab};
+      ta.gt = GeomTable{e->d_geomtab, e->moving_base};
       ta.uc = uc;
       ta.QA = dQA; ta.QB = dQB; ta.E = (long long)E; ta.step = step; ta.layout = layout; ta.flags = flags;
       ta.tol = e->filter_tol;
@@ -2047,7 +2217,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->h_pin) (void)hipHostFree(e->h_pin);
   if (e->d_ip) (void)hipFree(e->d_ip);
   if (e->d_dp) (void)hipFree(e->d_dp);
-  if (e->d_fp) (void)hipFree(e->d_fp);
+  if (e->d_fp_base) (void)hipFree(e->d_fp_base);
   if (e->d_ulist) (void)hipFree(e->d_ulist);
   if (e->d_ucount_base) (void)hipFree(e->d_ucount_base);
   if (e->d_slist) (void)hipFree(e->d_slist);
@@ -2092,6 +2262,9 @@ int mjpl_program_dump(const mjpl_model_desc *d, const int32_t *allowed_bodies, i
   info->maxs = e->maxs; info->wbox = e->wbox; info->mbox = e->mbox; info->immediate = e->exact_general();  // ("general builds only": nothing to specialise)
   info->filter_usable = e->filter_usable; info->filter_tol = e->filter_tol; info->nslots = e->nslots; info->nsave = e->nsave;
   info->spec_abi = MJPL_SPEC_ABI;
+  info->robot_hash = e->robot_hash;
+  info->scene_rows = kSceneRows;
+  info->scene_ok = e->scene.empty() ? 0 : 1;
   const int32_t want_ip = (int32_t)e->ip.size(), want_tab = (int32_t)e->fp.size();
   const bool fits = ip && fp && *nip >= want_ip && *ntab >= want_tab;
   *nip = want_ip;
@@ -2104,15 +2277,15 @@ int mjpl_program_dump(const mjpl_model_desc *d, const int32_t *allowed_bodies, i
   return MJPL_OK;
 }
 
-int mjpl_spec_loaded(const mjpl_engine *e) { return (e && e->spec) ? 1 : 0; }
+int mjpl_spec_loaded(const mjpl_engine *e) { return (e && e->spec) ? (e->spec_generic ? 2 : 1) : 0; }
 
 int mjpl_set_spec(mjpl_engine *e, int32_t enable) {
   if (!e) return fail(MJPL_E_ARG, "mjpl_set_spec: NULL engine");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->spec_off = enable == 0;
-  load_spec(e);
-  return MJPL_OK;
+  e->spec_generic_only = enable == 2;
+  return compile_program(e);  // (a scene-generic library wants its cull table in front of the float32 tables)
 }
 
 int mjpl_set_planning(mjpl_engine *e, const int32_t *qidx, int32_t nplan, const double *qpos_base) {

@@ -290,9 +290,14 @@ class Engine:
         (mjpl_amd/specialise.py), not the interpreter."""
         return bool(self.lib.mjpl_spec_loaded(self.h))
 
-    def set_spec(self, enable: bool):
-        """False: run the interpreting kernels even if this program has a specialised library."""
-        self._ok(self.lib.mjpl_set_spec(self.h, 1 if enable else 0))
+    def set_spec(self, enable):
+        """False / 0: run the interpreting kernels even if this program has a specialised library; True / 1:
+        look the libraries up (the program's own, else the robot's scene-generic one); 2: the generic one only."""
+        self._ok(self.lib.mjpl_set_spec(self.h, int(enable)))
+
+    def spec_kind(self) -> int:
+        """0 interpreter, 1 the program's own specialised library, 2 the robot's scene-generic one."""
+        return int(self.lib.mjpl_spec_loaded(self.h))
 
     def set_filter(self, enable: bool, tol: float = 1e-4):
         """Float32 filter in front of the exact kernels (verdicts are always the exact ones)."""

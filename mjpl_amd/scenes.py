@@ -80,6 +80,36 @@ def franka_p(obstacles=False, pads=False) -> Model:
     return franka_p_builder(obstacles, pads).compile()
 
 
+def random_obstacles(n_boxes: int, n_spheres: int, seed: int, n_capsules: int = 0) -> list[dict]:
+    """Seeded obstacles in the spirit of examples/models/franka_emika_panda/scene_with_obstacles.xml:23-30: centres
+    uniform in x, y in [-0.8, 0.8], z in [0.1, 1.0], kept 0.3 m away from the robot's column; box half-extents
+    U[0.02, 0.15], sphere radii U[0.03, 0.12], capsules r U[0.02, 0.06] x half-length U[0.05, 0.2] at random attitudes."""
+    rng = np.random.default_rng(seed)
+    out = []
+    kinds = ["box"] * n_boxes + ["sphere"] * n_spheres + ["capsule"] * n_capsules
+    for k, kind in enumerate(kinds):
+        while True:
+            pos = np.array([rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(0.1, 1.0)])
+            if np.hypot(pos[0], pos[1]) >= 0.3:
+                break
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        if kind == "box":
+            size = tuple(float(x) for x in rng.uniform(0.02, 0.15, 3))
+        elif kind == "sphere":
+            size, q = (float(rng.uniform(0.03, 0.12)),), np.array([1.0, 0, 0, 0])
+        else:
+            size = (float(rng.uniform(0.02, 0.06)), float(rng.uniform(0.05, 0.2)))
+        out.append({"type": kind, "size": size, "pos": tuple(float(x) for x in pos), "quat": tuple(float(x) for x in q),
+                    "name": f"obstacle_{seed}_{k}"})
+    return out
+
+
+def franka_p_scene(n_boxes: int, n_spheres: int, seed: int, n_capsules: int = 0) -> Model:
+    """Franka-P among seeded random obstacles (another scene per seed: what a scene-generic library is for)."""
+    return franka_p_builder(random_obstacles(n_boxes, n_spheres, seed, n_capsules)).compile()
+
+
 def ur5e() -> Model:
     return parse_mjcf(os.path.join(_MODELS, "ur5e_c.xml")).compile()
 

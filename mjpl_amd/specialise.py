@@ -58,7 +58,8 @@ FC_MAXCOORD, FC_MAXANGLE = 0, 1
 class ProgramInfo(C.Structure):
     _fields_ = [("hash", C.c_uint64), ("maxs", C.c_int32), ("wbox", C.c_int32), ("mbox", C.c_int32),
                 ("immediate", C.c_int32), ("filter_usable", C.c_int32), ("filter_tol", C.c_float),
-                ("nslots", C.c_int32), ("nsave", C.c_int32), ("spec_abi", C.c_int32)]
+                ("nslots", C.c_int32), ("nsave", C.c_int32), ("spec_abi", C.c_int32),
+                ("robot_hash", C.c_uint64), ("scene_rows", C.c_int32), ("scene_ok", C.c_int32)]
 
 
 def dump_program(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_tol: float = 0.0):
@@ -200,8 +201,17 @@ class _Gen:
         self.w(f"  {dst}2 = {lit(v[2])} + 2.0f * ({qn[1]} * t1_ - {qn[2]} * t0_); }}")
 
 
-def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
+SCENE_ROWS, SCENE_HEADER, SCENE_SLOT_LANE0 = 32, 32, 40  # (mjpl_filter.h: kSceneRows, kSceneHeader)
+SCENE_PLANE_ROWS, SCENE_STAGE = 2, 32 * 4 + 32              # (kScenePlaneRows, kSceneStageFloats)
+
+
+def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = False) -> str:
     """HIP source of `struct Spec` for one compiled program.
+    generic: the ROBOT's code only -- forward kinematics, geom poses, the culls against earlier moving geoms --
+    as literals; every static partner (floor, obstacles, the robot's own world-welded base) is a row of the
+    scene table the engine keeps in front of the float32 tables (`tp[-S ...]`, scalar loads): [a0 a1 a2 thr
+    desc], tested in one rolled loop per moving geom.  One such library serves the robot in any scene of up
+    to 32 static geoms.
     cull_form: "expanded" (default) tests a static partner as  |c|^2 - 2 c.X <= bound - |X|^2  -- three
     fused multiply-adds and a compare per partner on top of one |c|^2 per geom -- with the threshold
     raised by a bound of the form's own rounding (see `expanded_threshold`); "difference" is the
@@ -220,6 +230,13 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
     def wc_at(wrow, f):
         return off_wcull + ((wrow >> 2) << 4) + (f << 2) + (wrow & 3)
 
+    nstage_total = 0
+    _pc = int(ip[H_OFF_BODYOPS])
+    for _b in range(nbody):
+        _nj, _ng = int(ip[_pc + B_NJNT]), int(ip[_pc + B_NGEOM])
+        _pc += B_SIZE + _nj * J_SIZE + _ng * (G_SIZE + MAX_SLOTS)
+        nstage_total += _ng
+    SC = -(SCENE_HEADER + nstage_total * SCENE_STAGE + 16)  # where the scene table starts, relative to tp
     stages = []       # (case body lines, gtype, gdoff, store)
     desc = []         # per stage: list of packed partner descriptors
     pending_fk: list[str] = []   # FK of bodies since the last stage (bodies without geoms)
@@ -362,6 +379,8 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
                 w(f"{{ const float g0 = {e[0]}, g1 = {e[1]}, g2 = {e[2]}, g3 = {e[3]};")
                 w("  zx = 2.0f * (g1 * g3 + g0 * g2); zy = 2.0f * (g2 * g3 - g0 * g1); zz = g0 * g0 - g1 * g1 - g2 * g2 + g3 * g3; }")
             partners = []
+            if generic:
+                pmask = wmask = 0  # (static partners: rows of the scene table, tested after the switch)
             wbound = fgd[GD_WBOUND: GD_WBOUND + nwpad]
             sbound = fgd[GD_WBOUND + 2 * nwpad: GD_WBOUND + 2 * nwpad + MAX_SLOTS]
             # static planes
@@ -376,7 +395,7 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
                 partners.append((EK_PLANE, wrow, GT_PLANE, 1, 0))
             # other static geoms
             w("const float ux = cx + dead;")
-            if cull_form == "expanded":
+            if cull_form == "expanded" and not generic:
                 w("const float cc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, ux * ux));")
             statics = []
             for wrow in range(64):
@@ -388,7 +407,7 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
                 X, Y, Z = (float(fp[wc_at(wrow, f)]) for f in range(3))
                 statics.append((len(partners), X, Y, Z, wbound[wrow]))
                 partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if ptype == GT_BOX else 0))
-            if cull_form == "expanded":
+            if cull_form == "expanded" and statics:
                 reach = geom_reach + float(np.linalg.norm(np.asarray(lpos, dtype=np.float64)))
                 for a, b in zip(statics[0::2], statics[1::2]):
                     ta, tb = expanded_threshold(a[1:4], a[4], reach), expanded_threshold(b[1:4], b[4], reach)
@@ -409,6 +428,9 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
                 if not (smask >> n) & 1:
                     continue
                 pw = swords[n]
+                if generic:  # (lanes 0 .. 31 belong to the scene rows)
+                    while len(partners) < SCENE_SLOT_LANE0:
+                        partners.append((0, 0, 0, 0, 0))
                 k = len(partners)
                 w(f"MJPL_SPEC_SLOTCULL({k}, {n}, {lit(sbound[n])});")
                 partners.append((EK_SLOT, n, (pw >> 12) & 15, 1 if (pw & P_FIRST) else 0, 0))
@@ -425,7 +447,7 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
     o = out.append
     o("// GENERATED by mjpl_amd/specialise.py -- straight-line per-configuration check of ONE compiled program.")
     o(f"// program hash {info.hash:016x}, {nbody} moving bodies, {nstage} moving geoms, "
-      f"{sum(len(d) for d in desc)} enabled pairs, slot file width {maxs}")
+      f"{sum(1 for d in desc for x in d if x)} literal pairs{' (static partners: scene table)' if generic else ''}, slot file width {maxs}")
     o("#define MJPL_SPEC_QUAT2MAT() \\")
     o("  do { R0 = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3; R4 = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3; \\")
     o("       R8 = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3; R1 = 2.0f * (q1 * q2 - q0 * q3); R2 = 2.0f * (q1 * q3 + q0 * q2); \\")
@@ -485,9 +507,17 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
     o("    bool far = false;")
     o("    int fl = 0, qn = 0, qb = 0;")
     o("    wq.flags[lane] = (int)((unsigned)item << 2);")
-    o(f"    const float maxcoord = {lit(fp[fconst + FC_MAXCOORD])}, maxangle = {lit(fp[fconst + FC_MAXANGLE])};")
-    o(f"    const int nwpad = {nwpad};")
-    o(f"    const float *lwcull = ltab + {off_wcull}, *lwnarrow = ltab + {off_wnarrow};")
+    if generic:
+        o(f"    // the scene table in front of the float32 tables: header, then per moving geom {SCENE_ROWS} cull rows and {SCENE_ROWS} descriptors")
+        o(f"    const FP sc = tp + ({SC});")
+        o("    const int sc_nplane = info_bits(sc[0]), sc_nrows = info_bits(sc[1]);")
+        o("    const float maxcoord = sc[4], maxangle = sc[5];")
+        o("    const int nwpad = info_bits(sc[2]);")
+        o("    const float *lwcull = ltab, *lwnarrow = ltab + info_bits(sc[3]);")
+    else:
+        o(f"    const float maxcoord = {lit(fp[fconst + FC_MAXCOORD])}, maxangle = {lit(fp[fconst + FC_MAXANGLE])};")
+        o(f"    const int nwpad = {nwpad};")
+        o(f"    const float *lwcull = ltab + {off_wcull}, *lwnarrow = ltab + {off_wnarrow};")
     o("#pragma nounroll")
     o(f"    for (int g = 0; g < {nstage}; g++) {{")
     o("      if (__builtin_amdgcn_ballot_w64(dead == 0.0f) == 0ull && qn == 0 && qb == 0) break;  // every lane decided")
@@ -495,17 +525,58 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
     o("      int mlo = 0, mhi = 0;  // lane k holds the hit mask of this geom's partner k")
     o("      // ... and the descriptor of partner k: one vector load per stage, issued ahead of the stage's")
     o("      // arithmetic (a scalar load per hit stalls the wave for its whole latency)")
-    o("      const int dv = kSpecDesc[64 * g + lane];")
+    if generic:
+        o(f"      const int dv = lane < {SCENE_ROWS} ? info_bits(sc[{SCENE_HEADER} + g * {SCENE_STAGE} + {SCENE_ROWS * 4} + lane]) : kSpecDesc[64 * g + lane];")
+    else:
+        o("      const int dv = kSpecDesc[64 * g + lane];")
     o("      int gtype = 0, gdoff = 0;")
     o("      switch (g) {")
     for si, (lines, gtype, gdoff, store) in enumerate(stages):
         o(f"        case {si}: {{")
         for ln in lines:
             o("      " + ln)
-        o(f"          gtype = {gtype}; gdoff = {gdoff};")
+        if generic:
+            o(f"          gtype = {gtype}; gdoff = info_bits(sc[8 + {si}]);")
+        else:
+            o(f"          gtype = {gtype}; gdoff = {gdoff};")
         o("        } break;")
     o("        default: break;")
     o("      }")
+    if generic:
+        o("      {  // static partners: one row [a0 a1 a2 thr] of the scene table each, two rows per scalar load, the next")
+        o("         // pair fetched while this one is tested (two buffers taking turns: no copies, 16 scalar registers).")
+        o("         // Rows 0, 1: planes, a . c <= thr; rows 2 ..: |c|^2 + a . c <= thr")
+        o("        const float ux = cx + dead;")
+        o("        const float cc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, ux * ux));")
+        o("        const float zd = 0.0f * ux;  // 0, or NaN on a lane that is not to report anything")
+        o(f"        const FP rows = sc + ({SCENE_HEADER} + g * {SCENE_STAGE});")
+        o("        float ra[8], rb[8];")
+        o("#define MJPL_SCENE_LOAD(dst, at) _Pragma(\"unroll\") for (int k_ = 0; k_ < 8; k_++) dst[k_] = rows[4 * (at) + k_]")
+        o("        // (a fetch is waited for behind the arithmetic of the pair before it: scalar loads return out of order, so")
+        o("        //  a wait at its first use -- after the NEXT fetch has gone out -- would drain that one, too)")
+        o("#define MJPL_SCENE_WAIT(buf) asm volatile(\"\" ::\"s\"(buf[0]), \"s\"(buf[7]))")
+        o("#define MJPL_SCENE_PAIR(buf, acc, at) do { \\")
+        o("          const float t0_ = __builtin_fmaf(cz, buf[2], __builtin_fmaf(cy, buf[1], __builtin_fmaf(ux, buf[0], acc))); \\")
+        o("          const float t1_ = __builtin_fmaf(cz, buf[6], __builtin_fmaf(cy, buf[5], __builtin_fmaf(ux, buf[4], acc))); \\")
+        o("          const unsigned long long m0_ = __builtin_amdgcn_ballot_w64(t0_ <= buf[3]); \\")
+        o("          const unsigned long long m1_ = __builtin_amdgcn_ballot_w64(t1_ <= buf[7]); \\")
+        o("          mjpl::park_mask_at2(mlo, mhi, m0_, m1_, at); } while (0)")
+        o("        MJPL_SCENE_LOAD(ra, 0);")
+        o("        MJPL_SCENE_WAIT(ra);")
+        o("#pragma nounroll")
+        o("        for (int r = 0; r < sc_nrows; r += 4) {")
+        o("          MJPL_SCENE_LOAD(rb, r + 2);")
+        o("          const float acc = r == 0 ? zd : cc;")
+        o("          if (r != 0 || sc_nplane != 0) MJPL_SCENE_PAIR(ra, acc, r);")
+        o("          MJPL_SCENE_WAIT(rb);")
+        o("          MJPL_SCENE_LOAD(ra, r + 4);  // (the table ends with a spare chunk)")
+        o("          MJPL_SCENE_PAIR(rb, cc, r + 2);")
+        o("          MJPL_SCENE_WAIT(ra);")
+        o("        }")
+        o("#undef MJPL_SCENE_LOAD")
+        o("#undef MJPL_SCENE_WAIT")
+        o("#undef MJPL_SCENE_PAIR")
+        o("      }")
     o("      const float cur6[6] = {cx, cy, cz, zx, zy, zz};")
     o("      // partners some lane passed: bit k of the ballot <=> lane k's stored mask is non-zero")
     o("      for (unsigned long long ab = __builtin_amdgcn_ballot_w64((mlo | mhi) != 0); ab; ab &= ab - 1) {")
@@ -532,7 +603,7 @@ def generate(ip, fp, dp, info, cull_form: str | None = None) -> str:
     o("      }")
     o("    }")
     o("    if (qn > 0) queue_drain<float, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
-    if info.wbox:
+    if info.wbox or generic:  # (a scene-generic library serves scenes with static boxes whatever scene it was generated from)
         o("    if (qb > 0) queue_drain<float, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
     o("    fl = wq.flags[lane] & 3;")
     o("    if (active && far) return V_UNSURE;  // nothing this lane's candidates said can be trusted")
@@ -548,7 +619,7 @@ def dlit(x) -> str:
     return float(x).hex()
 
 
-def generate_exact(ip, dp, info) -> str:
+def generate_exact(ip, dp, info, generic: bool = False) -> str:
     """HIP source of `struct ExactSpec`: the float64 FK of k_patch_pairs (mjpl_filter.h) for one compiled
     program -- the interpreter's own statements, body by body, with every table read replaced by the
     value it would read (exact hexadecimal literals).  Same operations on the same values: the kernel's
@@ -562,11 +633,14 @@ def generate_exact(ip, dp, info) -> str:
         return "{" + ", ".join(dlit(v) for v in vals) + "}"
 
     o("struct ExactSpec {")
+    o("  // 1: geoms are numbered from the first moving one (a scene-generic library: model ids shift with the scene)")
+    o(f"  static constexpr int kRelative = {1 if generic else 0};")
     o("  static __device__ __forceinline__ void fk_pair(const double *q, int qstride, double *save, int sstride, bool active,")
     o("                                                 int ga, int gb, mjpl::GeomT<double> &A, mjpl::GeomT<double> &Bg) {")
     o("    using namespace mjpl;")
     o("    typedef GeomT<double> Geom;")
     o("    double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};")
+    stage = 0
     for b in range(nbody):
         parent, bdoff, njnt, save_slot, ngeom = (int(ip[pc + k]) for k in (B_PARENT, B_DOFF, B_NJNT, B_SAVE, B_NGEOM))
         pc += B_SIZE
@@ -630,6 +704,9 @@ def generate_exact(ip, dp, info) -> str:
             gflags, gdoff, geom_id = (int(ip[pc + k]) for k in (G_FLAGS, G_DOFF, G_GEOMID))
             pc += G_SIZE + MAX_SLOTS
             gd = dp[gdoff:]
+            if generic:
+                geom_id = stage
+            stage += 1
             o(f"      if (__ballot(active && (ga == {geom_id} || gb == {geom_id})) != 0ull) {{")
             o("        Geom cur;")
             if gflags & GF_SAMEPOS:
@@ -681,6 +758,8 @@ using namespace mjpl;
 extern "C" {
 int mjpl_spec_abi(void) { return MJPL_SPEC_ABI; }
 unsigned long long mjpl_spec_src_stamp(void) { return MJPL_SRC_STAMP; }
+// 0: the whole program in literals; else rows per moving geom << 8 | moving geoms of a scene-generic library
+int mjpl_spec_generic(void) { return %(generic)d; }
 unsigned long long mjpl_spec_hash(void) { return 0x%(hash)016xull; }
 int mjpl_spec_launch_configs(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
                              int nfp, const double *Q, int64_t N, int layout, float tol, uint8_t *valid, int *ulist, int *ucount,
@@ -735,24 +814,36 @@ int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t
 """
 
 
-def spec_path(hash_: int) -> str:
-    return os.path.join(SPEC_DIR, f"libmjpl_spec_{hash_:016x}.so")
+def spec_path(hash_: int, generic: bool = False) -> str:
+    return os.path.join(SPEC_DIR, f"libmjpl_spec{'g' if generic else ''}_{hash_:016x}.so")
 
 
 def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_tol: float = 0.0, force: bool = False,
-          keep_source: bool = True, extra_flags=(), output: str | None = None) -> str | None:
+          keep_source: bool = True, extra_flags=(), output: str | None = None, generic: bool = False) -> str | None:
     """Generate and compile the specialised library of (model, planning set, tolerance).  Returns the
-    path of the library, or None if the model cannot be specialised (immediate interpreter)."""
+    path of the library, or None if the model cannot be specialised (immediate interpreter).
+    generic: the ROBOT's scene-generic library instead (named by the robot hash): built from any scene that
+    holds the robot, it serves every scene with it -- the static geoms come from the engine's scene table."""
     ip, fp, dp, info = dump_program(model, allowed_collision_bodies, qidx, qpos_base, filter_tol)
-    if info.immediate or not info.filter_usable:
+    if info.immediate or not info.filter_usable or (generic and not info.scene_ok):
         return None
     os.makedirs(SPEC_DIR, exist_ok=True)
-    target = output or spec_path(info.hash)  # (output, extra_flags: timing-only variants, tools/time_variants.sh)
+    key = info.robot_hash if generic else info.hash
+    target = output or spec_path(key, generic)  # (output, extra_flags: timing-only variants, tools/time_variants.sh)
     deps = [os.path.join(_build.CSRC, f) for f in ("mjpl_filter.h", "mjpl_device.h", "mjpl_trig.h")] + [__file__]
     if not force and os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
         return target
-    src = _TU % dict(spec=generate(ip, fp, dp, info), exact=generate_exact(ip, dp, info), hash=info.hash, maxs=info.maxs, wbox="true" if info.wbox else "false")
-    src_path = os.path.join(SPEC_DIR, f"spec_{info.hash:016x}.hip")
+    nstage = 0
+    if generic:
+        pc = int(ip[H_OFF_BODYOPS])
+        for _ in range(int(ip[H_NBODYOPS])):
+            nj, ng = int(ip[pc + B_NJNT]), int(ip[pc + B_NGEOM])
+            pc += B_SIZE + nj * J_SIZE + ng * (G_SIZE + MAX_SLOTS)
+            nstage += ng
+    src = _TU % dict(spec=generate(ip, fp, dp, info, generic=generic), exact=generate_exact(ip, dp, info, generic=generic), hash=key,
+                     maxs=info.maxs, wbox="true" if (info.wbox or generic) else "false",
+                     generic=(SCENE_ROWS << 8 | nstage) if generic else 0)  # (kSceneRows, moving geoms)
+    src_path = os.path.join(SPEC_DIR, f"spec{'g' if generic else ''}_{key:016x}.hip")
     with open(src_path, "w") as f:
         f.write(src)
     # -fno-slp-vectorize: left alone, the SLP vectoriser pairs the scalar binary32 arithmetic of the generated
@@ -780,6 +871,9 @@ def _main(argv=None) -> int:
     ap.add_argument("--allowed", default="", help="allowed collision body pairs, bodyA:bodyB,...")
     ap.add_argument("--tol", type=float, default=0.0, help="filter tolerance in metres (0: the model's default)")
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--generic", action="store_true",
+                    help="the robot's scene-generic library: static geoms (<= 32) come from a table, so obstacles may change "
+                         "without a compiler (about 10 % slower than the scene's own library)")
     args = ap.parse_args(argv)
     model = load_mjcf(args.mjcf)
     names = [n for n in args.joints.split(",") if n]
@@ -788,7 +882,7 @@ def _main(argv=None) -> int:
         qidx = np.asarray([int(model.jnt_qposadr[model.joint(n).id]) for n in names], dtype=np.int32)
     base = model.keyframe(args.keyframe).qpos.copy() if args.keyframe else None
     allowed = tuple(tuple(p.split(":")) for p in args.allowed.split(",") if p)
-    path = build(model, allowed, qidx, base, args.tol, force=args.force)
+    path = build(model, allowed, qidx, base, args.tol, force=args.force, generic=args.generic)
     print(path if path else "this model runs the general builds: nothing to specialise")
     return 0
 

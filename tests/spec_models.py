@@ -24,3 +24,20 @@ def spec_models():
         rm, allowed = random_model(seed, moving_boxes=False)
         out.append((f"random_model({seed})", rm, tuple(allowed), np.arange(rm.nq, dtype=np.int32), np.asarray(rm.qpos0, float).copy()))
     return out
+
+
+def generic_scenes():
+    """Scenes of ONE robot (Franka-P, arm joints planned from the home keyframe) for the scene-generic library
+    __graft_entry__.build() compiles from the first of them: (name, model, expected mjpl_spec_loaded --
+    1 where the scene's own literal library exists and wins, 2 where the robot's generic one serves)."""
+    return [("franka_p + the 16 committed obstacles (has its own library)", scenes.franka_p(obstacles=True), 1),
+            ("franka_p alone (floor + base)", scenes.franka_p(obstacles=False), 2),
+            ("franka_p + 6 boxes + 4 spheres, seed 1", scenes.franka_p_scene(6, 4, 1), 2),
+            ("franka_p + 3 boxes + 3 spheres + 5 capsules, seed 2", scenes.franka_p_scene(3, 3, 2, n_capsules=5), 2),
+            ("franka_p + 14 boxes + 12 spheres, seed 3 (30 static geoms)", scenes.franka_p_scene(14, 12, 3), 2)]
+
+
+def generic_robot():
+    """(model, allowed, planning indices, base) the generic library is generated from."""
+    m = scenes.franka_p(obstacles=True)
+    return m, (), scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos.copy()

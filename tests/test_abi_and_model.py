@@ -158,7 +158,7 @@ def test_program_dump_and_code_generation_need_no_gpu():
         assert info.hash == info2.hash and np.array_equal(ip, ip2) and np.array_equal(fp.view(np.uint32), fp2.view(np.uint32))
         assert info.hash not in seen, name
         seen.add(info.hash)
-        assert not info.immediate and info.filter_usable and info.spec_abi == 8
+        assert not info.immediate and info.filter_usable and info.spec_abi == 9
         np.testing.assert_allclose(fp[np.isfinite(fp)], dp[np.isfinite(fp)].astype(np.float32), rtol=2e-5, atol=2e-4)
         src = specialise.generate(ip, fp, dp, info)
         culls = (src.count("MJPL_SPEC_CULLX(") + 2 * src.count("MJPL_SPEC_CULLX2(") + src.count("MJPL_SPEC_CULL(") +
@@ -193,5 +193,39 @@ def test_program_hash_covers_the_float64_constants_and_the_shared_headers():
     # the stamp: a digest of the three shared headers, passed to both compilations
     stamp = build.src_stamp()
     assert stamp != 0 and f"-DMJPL_SRC_STAMP=0x{stamp:016x}ull" in build.hipcc_flags()
-    src = specialise._TU % dict(spec="", exact="", hash=info.hash, maxs=info.maxs, wbox="true")
+    src = specialise._TU % dict(spec="", exact="", hash=info.hash, maxs=info.maxs, wbox="true", generic=0)
     assert "mjpl_spec_src_stamp" in src and "MJPL_SRC_STAMP" in src
+
+
+def test_robot_hash_and_scene_generic_generation():
+    """The hash a scene-generic library is named by covers the robot only: the same for Franka-P alone, among the
+    16 committed obstacles and among seeded random ones -- and another for another planning set, base
+    configuration or tolerance.  Generated generic code carries no static geom: no literal static cull, a loop
+    over the scene table instead, geoms numbered from the first moving one in the exact pair re-check."""
+    from mjpl_amd import scenes, specialise
+    arm = None
+    hashes, programs = set(), {}
+    for m in (scenes.franka_p(False), scenes.franka_p(True), scenes.franka_p_scene(5, 5, 4), scenes.franka_p_scene(2, 1, 5, n_capsules=3)):
+        arm = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+        base = m.keyframe("home").qpos.copy()
+        ip, fp, dp, info = specialise.dump_program(m, (), arm, base)
+        assert info.scene_ok == 1 and info.scene_rows == 32
+        hashes.add(info.robot_hash)
+        programs[info.hash] = (ip, fp, dp, info)
+    assert len(hashes) == 1 and len(programs) == 4
+    m = scenes.franka_p(True)
+    base = m.keyframe("home").qpos.copy()
+    other = base.copy()
+    other[7] = 0.02
+    for kw in (dict(qidx=np.arange(m.nq, dtype=np.int32), qpos_base=base), dict(qidx=arm, qpos_base=other),
+               dict(qidx=arm, qpos_base=base, filter_tol=2e-4)):
+        assert specialise.dump_program(m, (), **kw)[3].robot_hash not in hashes
+    assert specialise.dump_program(scenes.franka_p_scene(16, 16, 9), (), arm, base)[3].scene_ok == 0  # 34 static geoms
+    ip, fp, dp, info = next(iter(programs.values()))
+    src = specialise.generate(ip, fp, dp, info, generic=True)
+    assert "MJPL_SPEC_CULLX" not in src.split("struct Spec")[1] and "MJPL_SCENE_PAIR(ra, acc, r)" in src
+    assert src.count("MJPL_SPEC_SLOTCULL(") == 33 + 1  # Franka-P's 33 self pairs (and the macro itself), in either kind of library
+    srcs = {specialise.generate(*p, generic=True) for p in programs.values()}
+    assert len({s.split("program hash")[1].split("\n", 1)[1] for s in srcs}) == 1, "generic code must not depend on the scene"
+    ex = specialise.generate_exact(ip, dp, info, generic=True)
+    assert "kRelative = 1" in ex and "ga == 0 || gb == 0" in ex
