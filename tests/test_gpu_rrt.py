@@ -195,3 +195,36 @@ def test_plan_to_poses_through_batched_ik(oracle_mod):
     assert err < 2e-3
     P = np.stack(path)
     assert v.valid_edges(P[:-1, qidx], P[1:, qidx], 0.01).all()
+
+
+def test_first_round_of_131072_lanes_equals_the_host_planner_on_a_lane_prefix(oracle_mod):
+    """configs[3]'s per-GPU lane count, round 1: lanes are independent (every lane extends from q_init; the
+    sampler is counter-based, keyed by seed, rank and round, lane l drawing from its own counters), so the new
+    nodes of lanes 0 .. 4095 -- a prefix of the round's block, nodes being ordered (lane, level) -- must be, bit
+    for bit, what the NumPy planner on the CPU oracle adds in ITS first round with 4 096 lanes: same rows, same
+    parents, for the extension towards the samples and for the other tree's extension towards what was reached.
+    [JointLimit, Collision] with interval checks (the projecting set is compared through properties in
+    test_one_gpu_share_of_configs3_through_rccl: the CPU projection differs from the device's in the last bits)."""
+    m, joints, qidx, q_init, v, goals = _scene(oracle_mod, seed=77)
+    kw = dict(epsilon=0.05, interval_step=0.01, seed=21, goal_biasing_probability=0.05, max_planning_time=600.0)
+    host = pr.ParallelBiRRT(m, joints, v, q_init, batch=4096, max_rounds=1, **kw)
+    host.plan_to_configs(q_init, goals[:1])
+    assert host.stats["rounds"] == 1
+    cc = mjpl.CollisionConstraint(m)
+    dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, batch=131072, capacity=1 << 25, **kw)
+    dev.rrt.reset(q_init[qidx], goals[0][qidx][None], 21)
+    info = dev.rrt.round()
+    T, on = dev.rrt.lanes_state()
+    Th, onh = pr.sample_targets(pr.rrt_key(21, 0, 1), 4096, m.jnt_range[qidx, 0], m.jnt_range[qidx, 1], 0.05, 0, q_init[qidx],
+                                goals[0][qidx][None])
+    np.testing.assert_array_equal(T[:4096], Th)
+    # (of the biased lanes that share a target the lowest takes part: the lowest of all 131 072 is the lowest of the prefix)
+    np.testing.assert_array_equal(on[:4096], onh)
+    for t in (0, 1):
+        Q, par = dev.rrt.tree(t)
+        hq, hp = host.trees.nodes(t), host.trees.parent[t][: host.trees.n[t]]
+        k = len(hq)
+        assert info.nodes[t] > 20 * k > 1000  # the prefix is a small part of a big round
+        np.testing.assert_array_equal(Q[:k], hq)
+        np.testing.assert_array_equal(par[:k], hp)
+        assert par[k] == 0  # the next chain starts at the root, too: lane 4096 (or later) begins
