@@ -788,7 +788,17 @@ def main():
                     fpe = float(flops["flops_per_edge"])
                     variants[name]["achieved_FP64_fraction"] = E * fpe / (v_launch * 1e-3) / FP64_VECTOR_PEAK
                     variants[name]["fp64"] = {"flops_per_edge": fpe, "achieved_TFLOPs": E * fpe / (v_launch * 1e-3) / 1e12,
-                                              "peak_TFLOPs": FP64_VECTOR_PEAK / 1e12, "source": flops.get("source")}
+                                              "peak_TFLOPs": FP64_VECTOR_PEAK / 1e12, "source": flops.get("source"),
+                                              "note": "the oracle's operation count of the reference's algorithm x edges/s (SURVEY.md 8d)"}
+                    if rec.get("SQ_INSTS_VALU_FMA_F64") is not None:
+                        # what the kernel ISSUES: wave-level float64 instructions of the committed counter pass x 64 lanes
+                        # (masked lanes included; an FMA counts two) over this run's kernel time
+                        wi = {k: float(rec[f"SQ_INSTS_VALU_{k}_F64"]) for k in ("ADD", "MUL", "FMA", "TRANS")}
+                        issued = 64.0 * (wi["ADD"] + wi["MUL"] + 2.0 * wi["FMA"] + wi["TRANS"])
+                        variants[name]["fp64"]["issued"] = {
+                            "wave_insts_per_launch": wi, "flops_per_launch": issued,
+                            "TFLOPs": issued / (v_stage[vk] * 1e-3) / 1e12,
+                            "frac_of_peak": issued / (v_stage[vk] * 1e-3) / FP64_VECTOR_PEAK, "source": rec.get("flops_source")}
                 for b in (va, vb, vv):
                     b.free()
                 ve.close()

@@ -962,10 +962,26 @@ k_filter_items_pw(const int *__restrict__ gip, int nip, const float *__restrict_
                   int *__restrict__ ulist, int *__restrict__ ucount, UndecidedConfigs uc, int *__restrict__ tiles) {
   static_assert(kQueued<float, MAXS>, "persistent kernels serve the queued interpreter");
   extern __shared__ double smem[];
+  const int lane = threadIdx.x & 63;
+  // The grid is sized for the item SPACE (the host does not know the count).  A launch with few items -- the
+  // late chunks of a planner's extension: a handful of lanes -- needs few workgroups: when no queue holds a
+  // round of tiles for all its home waves, every tile goes out through the counters, any wave can take any
+  // of them, and workgroups beyond the tile count leave before they stage anything (a launch of 768
+  // workgroups for three tiles took 60 us, most of it table copies nobody used).
+  {
+    int nt = 0, stat = 0;
+    if (lane < ib.regions) {
+      const int f = ib.count[lane * kCounterStride];
+      nt = ((f < ib.regcap ? f : ib.regcap) + 63) >> 6;
+      const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+      stat = nt >= (nwaves - lane + ib.regions - 1) / ib.regions ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) { nt += __shfl_xor(nt, o); stat |= __shfl_xor(stat, o); }
+    if (!stat && (int)(blockIdx.x * (blockDim.x >> 6)) >= nt) return;
+  }
   const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : gip[H_NPLAN];
   WaveLds<float, MBOX> w = carve_wave<float, MBOX>(smem, gfp, nfp, nplan, gip[H_NSAVE]);
   __syncthreads();  // the table copy; from here on every wave is on its own
-  const int lane = threadIdx.x & 63;
   // a tile = 64 consecutive items of one region; the regions are the queues.  Tiles cost what their
   // candidates cost (a wave that drains more takes longer): the remainder is dealt out dynamically
   TileQueues tq(tiles, ib.regions, true);

@@ -188,10 +188,29 @@ constexpr int kPoseBlock = 64;
 
 constexpr double kPoseMaxCond = 1e6;  // (see k_pose_apply: fast path of the 6x6 pseudo-inverse)
 
+// What the frontier planner does with a projected candidate (mjpl_rrt.h: the rules of _constrained_extend after
+// constraints that project, planning/utils.py:139-164) and the chunk's counters for the host, as an epilogue of
+// the projection kernel: one launch and one copy less per extension step, of which a round has a thousand.
+struct PoseEpilogue {
+  int on;                      // 0: plain mjpl_pose_apply
+  int L, nplan;
+  const int *qidx;             // [nplan] planning columns -> qpos
+  const double *qbase;         // [nq]
+  const uint8_t *isplan;       // [nq]
+  const double *lo, *hi, *Tgt; // limits [nplan]; targets [nplan][L]
+  const double *A;             // [E][nplan] where every candidate starts
+  double *B;                   // [E][nplan] <- the projected planning columns (or A: a harmless edge)
+  const int32_t *lane;         // [E]
+  uint8_t *rule, *reach;       // [E]
+  const int *ctr;              // the chunk's device counters ...
+  int *host_slot;              // ... copied to this pinned block (RC_SIZE ints + a sequence word), if not null
+  int seq;
+};
+
 __global__ void __launch_bounds__(kPoseBlock)
 k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
              const double *__restrict__ Q, int64_t N, double *__restrict__ Qout,
-             uint8_t *__restrict__ ok, int32_t *__restrict__ iters) {
+             uint8_t *__restrict__ ok, int32_t *__restrict__ iters, PoseEpilogue ep) {
   extern __shared__ double smem[];
   constexpr int B = kPoseBlock;
   const int lane = threadIdx.x;
@@ -297,6 +316,38 @@ k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const do
     for (int k = 0; k < nq; k++) Qout[i * nq + k] = qw[k * B];
     ok[i] = result == 1 ? 1 : 0;
     if (iters) iters[i] = result == 2 ? -it : it;
+  }
+  if (ep.on) {
+    if (ep.host_slot && blockIdx.x == 0 && lane < 16) {
+      // (this kernel follows the one that closed the counters: stream order)
+      __hip_atomic_store(ep.host_slot + lane, ep.ctr[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(ep.host_slot + 16, ep.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (active) {
+      const int l = ep.lane[i];
+      bool good = result == 1;
+      for (int k = 0; k < nq; k++)  // a projection that moves a joint outside the planning set is rejected
+        if (!ep.isplan[k]) good = good && (qw[k * B] == ep.qbase[k]);
+      constexpr int kMaxPlan = 16;
+      double q[kMaxPlan], d[kMaxPlan];
+      bool reach = true;
+      for (int c = 0; c < ep.nplan; c++) {
+        q[c] = qw[ep.qidx[c] * B];
+        reach = reach && (q[c] == ep.Tgt[(int64_t)c * ep.L + l]);
+        good = good && (q[c] >= ep.lo[c] && q[c] <= ep.hi[c]);
+      }
+      auto seqn = [&](const double *v) { double s2 = 0; for (int c = 0; c < ep.nplan; c++) s2 = s2 + v[c] * v[c]; return sqrt(s2); };
+      for (int c = 0; c < ep.nplan; c++) d[c] = q[c] - ep.A[(int64_t)i * ep.nplan + c];
+      good = good && !(seqn(d) < 1e-8);
+      for (int c = 0; c < ep.nplan; c++) d[c] = ep.Tgt[(int64_t)c * ep.L + l] - q[c];
+      const double after = seqn(d);
+      for (int c = 0; c < ep.nplan; c++) d[c] = ep.Tgt[(int64_t)c * ep.L + l] - ep.A[(int64_t)i * ep.nplan + c];
+      good = good && !(after > seqn(d));
+      for (int c = 0; c < ep.nplan; c++) ep.B[(int64_t)i * ep.nplan + c] = good ? q[c] : ep.A[(int64_t)i * ep.nplan + c];
+      ep.rule[i] = good ? 1 : 0;
+      ep.reach[i] = (good && reach) ? 1 : 0;
+    }
   }
 }
 
@@ -2899,10 +2950,23 @@ int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQold, const double *dQ, int
   HIP_TRY(hipSetDevice(p->e->device));
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
   hipLaunchKernelGGL(k_pose_apply, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd,
-                     dQold, dQ, N, dQout, dok, diters);
+                     dQold, dQ, N, dQout, dok, diters, PoseEpilogue{});
   HIP_TRY(hipGetLastError());
   return MJPL_OK;
 }
+
+namespace {
+// the planner's launch: projection + the extension rules + the chunk counters for the host (mjpl_rrt.h)
+int pose_apply_epilogue(mjpl_pose *p, const double *dQold, const double *dQ, int64_t N, double *dQout, uint8_t *dok,
+                        const PoseEpilogue &ep) {
+  HIP_TRY(hipSetDevice(p->e->device));
+  const unsigned grid = (unsigned)std::max<int64_t>(1, (N + kPoseBlock - 1) / kPoseBlock);
+  hipLaunchKernelGGL(k_pose_apply, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd, dQold, dQ, N, dQout,
+                     dok, (int32_t *)nullptr, ep);
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+}  // namespace
 
 int mjpl_pose_valid_dev(mjpl_pose *p, const double *dQ, int64_t N, uint8_t *dvalid, double *dxpos, double *dxmat) {
   int rc = pose_check(p, dQ, N);

@@ -65,6 +65,7 @@ __device__ __forceinline__ double seqnorm(const double *d, int n) {  // the sum 
 }
 
 constexpr int kRrtMaxPlan = 16;
+constexpr int kRingStride = 32;  // ints per slot of the pinned counter ring
 
 __global__ void __launch_bounds__(256)
 k_rrt_sample(int L, int nplan, uint64_t key, double pgoal, int grow, int ngoal, const double *__restrict__ lo,
@@ -476,7 +477,8 @@ struct mjpl_rrt {
   int *d_ctr = nullptr, *h_ctr = nullptr;
   // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned
   // copies and the events that say when each has landed
-  int *h_ring = nullptr;
+  int *h_ring = nullptr;      // 4 slots of kRingStride ints: RC_SIZE counters, then the sequence word
+  int ring_seq0 = 1;          // sequence number of chunk 0 of the extension under way (never repeats within the ring)
   hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // exchange
   int *d_heads = nullptr, *h_heads = nullptr;
@@ -532,18 +534,24 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   // previous chunks' candidates, validated again and read by nobody -- and the loop ends two chunks
   // after the last lane has.
   const bool pipelined = projecting && r->cd.cap >= L;
+  int chunks_done = 0;
   for (int chunk = 0;; chunk++) {
+    chunks_done = chunk + 1;
     hipLaunchKernelGGL(k_rrt_gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, projecting ? 1 : 0, r->d_lo, r->d_hi,
                        Tgt, r->ln, r->cd, r->d_ctr,
                        RrtFull{r->nq, r->d_qidx, r->d_qbase, projecting ? r->d_F[0] : nullptr, projecting ? r->d_F[1] : nullptr});
-    if (pipelined) {
-      const int slot = chunk % 4;
-      HIP_TRY(hipMemcpyAsync(r->h_ring + slot * RC_SIZE, r->d_ctr, RC_SIZE * sizeof(int), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipEventRecord(r->ring_ev[slot], st));
-      const int look = (chunk < 2 ? chunk : chunk - 2) % 4;  // (the first two chunks: their own counts)
-      HIP_TRY(hipEventSynchronize(r->ring_ev[look]));
-      memcpy(r->h_ctr, r->h_ring + look * RC_SIZE, RC_SIZE * sizeof(int));
-    } else if ((rc = rrt_read_ctr(r)) != MJPL_OK) {
+    if (pipelined && chunk >= 2) {
+      // the counters of two chunks ago, which that chunk's projection kernel left in pinned memory (slot
+      // (chunk - 2) % 4: RC_SIZE ints and a sequence word written last): no copy, no event, the host spins
+      const int look = (chunk - 2) % 4;
+      volatile int *slot = r->h_ring + look * kRingStride;
+      const int want = r->ring_seq0 + chunk - 2;
+      for (long spins = 0; __atomic_load_n(slot + 16, __ATOMIC_ACQUIRE) != want; spins++) {
+        if (spins > 2000000000L) return fail(MJPL_E_HIP, "rrt: the counters of an extension chunk never arrived");
+        __builtin_ia32_pause();
+      }
+      for (int k = 0; k < RC_SIZE; k++) r->h_ctr[k] = slot[k];
+    } else if ((rc = rrt_read_ctr(r)) != MJPL_OK) {  // (the first two chunks: their own counts)
       return rc;
     }
     // (lanes that were refused candidate space have reserved slots all the same: RC_EDGES may exceed
@@ -562,10 +570,18 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     }
     if (r->h_ctr[RC_OVERFLOW] & 1) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
     if (projecting) {
-      rc = mjpl_pose_apply_dev(r->pose, r->d_F[0], r->d_F[1], E, r->d_F[2], r->d_pok, nullptr);
+      // projection, then the rules of the extension on what it returns, as that kernel's epilogue; it also
+      // leaves this chunk's counters where the host will look for them two chunks from now
+      PoseEpilogue ep = {};
+      ep.on = 1; ep.L = L; ep.nplan = nplan;
+      ep.qidx = r->d_qidx; ep.qbase = r->d_qbase; ep.isplan = r->d_isplan;
+      ep.lo = r->d_lo; ep.hi = r->d_hi; ep.Tgt = Tgt;
+      ep.A = r->cd.A; ep.B = r->cd.B; ep.lane = r->cd.lane; ep.rule = r->cd.rule; ep.reach = r->cd.reach;
+      ep.ctr = r->d_ctr;
+      ep.host_slot = pipelined ? r->h_ring + (chunk % 4) * kRingStride : nullptr;
+      ep.seq = r->ring_seq0 + chunk;
+      rc = pose_apply_epilogue(r->pose, r->d_F[0], r->d_F[1], E, r->d_F[2], r->d_pok, ep);
       if (rc != MJPL_OK) return rc;
-      hipLaunchKernelGGL(k_rrt_after_pose, dim3(rgrid(E)), dim3(256), 0, st, E, L, nplan, r->nq, r->d_qidx, r->d_qbase, r->d_isplan,
-                         r->d_lo, r->d_hi, Tgt, r->cd, r->d_F[2], r->d_pok);
     }
     if (r->istep > 0)
       rc = launch_edges(e, r->cd.A, r->cd.B, E, r->istep, MJPL_AOS, 0, r->cd.valid, nullptr);
@@ -579,6 +595,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
       S = (int)std::max<int64_t>(1, std::min<int64_t>(2 * S, room));
     }
   }
+  r->ring_seq0 += chunks_done + 8;  // (sequence numbers of the pinned ring never repeat)
   // node order of the extension: lanes ascending, levels ascending within a lane
   hipLaunchKernelGGL(k_rrt_scan, dim3(1), dim3(1024), 0, st, L, r->ln.cnt, r->ln.off, r->d_ctr + (t == (r->round - 1) % 2 ? RC_NEWA : RC_NEWB));
   if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
@@ -711,7 +728,8 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   RA(r->d_first, 1);  // re-allocated by reset for the number of goals
 #undef RA
   HIP_TRY(hipHostMalloc((void **)&r->h_ctr, RC_SIZE * sizeof(int)));
-  HIP_TRY(hipHostMalloc((void **)&r->h_ring, 4 * RC_SIZE * sizeof(int)));
+  HIP_TRY(hipHostMalloc((void **)&r->h_ring, 4 * kRingStride * sizeof(int)));
+  memset(r->h_ring, 0, 4 * kRingStride * sizeof(int));
   for (hipEvent_t &ev : r->ring_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void **)&r->h_heads, 8 * 1024 * sizeof(int)));
   HIP_TRY(hipHostMalloc((void **)&r->h_myhead, 8 * sizeof(int)));
