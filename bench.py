@@ -771,6 +771,10 @@ def main():
             # ... and the robot's scene-generic library (obstacles from a table: any scene without a compiler)
             for name, (vf, vs) in (("f64_only", (False, True)), ("interpreter", (True, False)), ("scene_generic", (True, 2))):
                 ve = make_engine(vf, vs)
+                want_kind = {"f64_only": None, "interpreter": 0, "scene_generic": 2}[name]
+                if want_kind is not None and ve.spec_kind() != want_kind:
+                    sys.exit(f"bench.py: the {name} variant found library kind {ve.spec_kind()} instead of {want_kind}: the "
+                             "libraries under mjpl_amd/csrc/spec are not the ones __graft_entry__.build() makes from these sources")
                 va, vb, vv = ve.alloc(ha.nbytes).upload(ha), ve.alloc(hb.nbytes).upload(hb), ve.alloc(E)
                 dt, v_launch, v_stage, v_n = time_variant(ve, engine, va, vb, E, layout, vv, vsteps, 5)
                 same = bool(np.array_equal(vv.download(np.uint8, E), valid))

@@ -188,40 +188,17 @@ constexpr int kPoseBlock = 64;
 
 constexpr double kPoseMaxCond = 1e6;  // (see k_pose_apply: fast path of the 6x6 pseudo-inverse)
 
-// What the frontier planner does with a projected candidate (mjpl_rrt.h: the rules of _constrained_extend after
-// constraints that project, planning/utils.py:139-164) and the chunk's counters for the host, as an epilogue of
-// the projection kernel: one launch and one copy less per extension step, of which a round has a thousand.
-struct PoseEpilogue {
-  int on;                      // 0: plain mjpl_pose_apply
-  int L, nplan;
-  const int *qidx;             // [nplan] planning columns -> qpos
-  const double *qbase;         // [nq]
-  const uint8_t *isplan;       // [nq]
-  const double *lo, *hi, *Tgt; // limits [nplan]; targets [nplan][L]
-  const double *A;             // [E][nplan] where every candidate starts
-  double *B;                   // [E][nplan] <- the projected planning columns (or A: a harmless edge)
-  const int32_t *lane;         // [E]
-  uint8_t *rule, *reach;       // [E]
-  const int *ctr;              // the chunk's device counters ...
-  int *host_slot;              // ... copied to this pinned block (RC_SIZE ints + a sequence word), if not null
-  int seq;
-};
-
-__global__ void __launch_bounds__(kPoseBlock)
-k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
-             const double *__restrict__ Q, int64_t N, double *__restrict__ Qout,
-             uint8_t *__restrict__ ok, int32_t *__restrict__ iters, PoseEpilogue ep) {
-  extern __shared__ double smem[];
+// One lane's PoseConstraint.apply (pose_constraint.py:78-91): qw ([nq] at a stride of kPoseBlock, LDS) holds the
+// configuration to project on entry and what the projection made of it on return; qo[k * qos] is q_old; jst the
+// lane's [6 * njoint] store.  Every lane of the wave calls it (`active` false: the lane only keeps company).
+// Returns 1: within tolerance, 0: left the joint limits or went farther than 2 q_step from q_old, 2: iteration
+// bound; *iters counts the Newton steps taken.
+__device__ __forceinline__ int pose_project_lane(const int *__restrict__ pi, const double *__restrict__ pd, double *qw,
+                                                 double *jst, const double *qo, int qos, bool active, int *iters) {
   constexpr int B = kPoseBlock;
-  const int lane = threadIdx.x;
   const int nq = pi[PH_NQ], nj = pi[PH_NJOINT], maxit = pi[PH_MAXIT];
   const double *tail = pd + pi[PH_OFF_TAIL];
   const double *jrange = pd + pi[PH_OFF_JRANGE];
-  double *qw = smem + lane;                    // [nq][B]
-  double *jst = smem + (size_t)nq * B + lane;  // [6 * nj][B]
-  const int64_t i = (int64_t)blockIdx.x * B + lane;
-  const bool active = i < N;
-  for (int k = 0; k < nq; k++) qw[k * B] = active ? Q[i * nq + k] : 0.0;
   const double tol = tail[PT_TOL], far_at = 2 * tail[PT_QSTEP];
   // joint ids / types of the chain, in chain order, follow the per-body counts in `pi`
   bool done = !active;
@@ -304,7 +281,7 @@ k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const do
         for (int k = 0; k < nq; k++) {
           const double v = qw[k * B];
           viol = viol || !(v >= jrange[2 * k] && v <= jrange[2 * k + 1]);
-          const double d = v - Qold[i * nq + k];
+          const double d = v - qo[k * qos];
           s = s + d * d;
         }
         it++;
@@ -312,42 +289,29 @@ k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const do
       }
     }
   }
+  *iters = it;
+  return result;
+}
+
+__global__ void __launch_bounds__(kPoseBlock)
+k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
+             const double *__restrict__ Q, int64_t N, double *__restrict__ Qout,
+             uint8_t *__restrict__ ok, int32_t *__restrict__ iters) {
+  extern __shared__ double smem[];
+  constexpr int B = kPoseBlock;
+  const int lane = threadIdx.x;
+  const int nq = pi[PH_NQ];
+  double *qw = smem + lane;                    // [nq][B]
+  double *jst = smem + (size_t)nq * B + lane;  // [6 * nj][B]
+  const int64_t i = (int64_t)blockIdx.x * B + lane;
+  const bool active = i < N;
+  for (int k = 0; k < nq; k++) qw[k * B] = active ? Q[i * nq + k] : 0.0;
+  int it = 0;
+  const int result = pose_project_lane(pi, pd, qw, jst, Qold + (active ? i : 0) * nq, 1, active, &it);
   if (active) {
     for (int k = 0; k < nq; k++) Qout[i * nq + k] = qw[k * B];
     ok[i] = result == 1 ? 1 : 0;
     if (iters) iters[i] = result == 2 ? -it : it;
-  }
-  if (ep.on) {
-    if (ep.host_slot && blockIdx.x == 0 && lane < 16) {
-      // (this kernel follows the one that closed the counters: stream order)
-      __hip_atomic_store(ep.host_slot + lane, ep.ctr[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __threadfence_system();
-      if (lane == 0) __hip_atomic_store(ep.host_slot + 16, ep.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (active) {
-      const int l = ep.lane[i];
-      bool good = result == 1;
-      for (int k = 0; k < nq; k++)  // a projection that moves a joint outside the planning set is rejected
-        if (!ep.isplan[k]) good = good && (qw[k * B] == ep.qbase[k]);
-      constexpr int kMaxPlan = 16;
-      double q[kMaxPlan], d[kMaxPlan];
-      bool reach = true;
-      for (int c = 0; c < ep.nplan; c++) {
-        q[c] = qw[ep.qidx[c] * B];
-        reach = reach && (q[c] == ep.Tgt[(int64_t)c * ep.L + l]);
-        good = good && (q[c] >= ep.lo[c] && q[c] <= ep.hi[c]);
-      }
-      auto seqn = [&](const double *v) { double s2 = 0; for (int c = 0; c < ep.nplan; c++) s2 = s2 + v[c] * v[c]; return sqrt(s2); };
-      for (int c = 0; c < ep.nplan; c++) d[c] = q[c] - ep.A[(int64_t)i * ep.nplan + c];
-      good = good && !(seqn(d) < 1e-8);
-      for (int c = 0; c < ep.nplan; c++) d[c] = ep.Tgt[(int64_t)c * ep.L + l] - q[c];
-      const double after = seqn(d);
-      for (int c = 0; c < ep.nplan; c++) d[c] = ep.Tgt[(int64_t)c * ep.L + l] - ep.A[(int64_t)i * ep.nplan + c];
-      good = good && !(after > seqn(d));
-      for (int c = 0; c < ep.nplan; c++) ep.B[(int64_t)i * ep.nplan + c] = good ? q[c] : ep.A[(int64_t)i * ep.nplan + c];
-      ep.rule[i] = good ? 1 : 0;
-      ep.reach[i] = (good && reach) ? 1 : 0;
-    }
   }
 }
 
@@ -1579,8 +1543,12 @@ int compile_program(mjpl_engine *e) {
       }
       breach[b] = std::fmin(r, box_reach);
     }
-    // [0] rows in use (a multiple of four: the code takes them four at a time), [2] nwpad, [3] offset of the narrowphase table
-    seti(0, nplanes); seti(1, nworld > nplanes ? ((kScenePlaneRows + nworld - nplanes + 3) & ~3) : (nplanes ? kScenePlaneRows : 0));
+    // [0] planes (0 .. 2: the last rows), [1] first pair of rows in use, [2] nwpad, [3] offset of the narrowphase table
+    // The rows of a geom are filled from the END: the planes last, the bounded geoms below them; the code is one
+    // straight line over all kSceneRows rows, entered at the first pair of rows that holds anything ([1]).
+    const int nbounded = nworld - nplanes;
+    const int first_row = std::min(kSceneRows - 2, (kSceneRows - nplanes - nbounded) & ~1);
+    seti(0, nplanes); seti(1, first_row);
     seti(2, nwpad); seti(3, ip[H_OFF_WNARROW]);
     e->scene[4] = (float)e->fmax_coord;
     e->scene[5] = kFilterMaxAngle;
@@ -1598,8 +1566,8 @@ int compile_program(mjpl_engine *e) {
         float *rows = &e->scene[(size_t)kSceneHeader + (size_t)gk3 * kSceneStageFloats];
         float *descs = rows + (size_t)kSceneRows * 4;
         for (int r0 = 0; r0 < kSceneRows; r0++) rows[(size_t)r0 * 4 + 3] = -std::numeric_limits<float>::infinity();
-        for (int pass = 0; pass < 2; pass++) {  // planes in rows 0 and 1, the others from row 2 on
-          int r = pass == 0 ? 0 : kScenePlaneRows;
+        for (int pass = 0; pass < 2; pass++) {  // the planes in the last rows, the others below them
+          int r = pass == 0 ? kSceneRows - nplanes : kSceneRows - nplanes - nbounded;
           for (int sgeom = 0; sgeom < ng; sgeom++) {
             if (!e->geom_static[sgeom] || world_row[sgeom] < 0) continue;
             const int w = world_row[sgeom], ptype = winfo[w] & 255;
@@ -2950,23 +2918,10 @@ int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQold, const double *dQ, int
   HIP_TRY(hipSetDevice(p->e->device));
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
   hipLaunchKernelGGL(k_pose_apply, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd,
-                     dQold, dQ, N, dQout, dok, diters, PoseEpilogue{});
+                     dQold, dQ, N, dQout, dok, diters);
   HIP_TRY(hipGetLastError());
   return MJPL_OK;
 }
-
-namespace {
-// the planner's launch: projection + the extension rules + the chunk counters for the host (mjpl_rrt.h)
-int pose_apply_epilogue(mjpl_pose *p, const double *dQold, const double *dQ, int64_t N, double *dQout, uint8_t *dok,
-                        const PoseEpilogue &ep) {
-  HIP_TRY(hipSetDevice(p->e->device));
-  const unsigned grid = (unsigned)std::max<int64_t>(1, (N + kPoseBlock - 1) / kPoseBlock);
-  hipLaunchKernelGGL(k_pose_apply, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd, dQold, dQ, N, dQout,
-                     dok, (int32_t *)nullptr, ep);
-  HIP_TRY(hipGetLastError());
-  return MJPL_OK;
-}
-}  // namespace
 
 int mjpl_pose_valid_dev(mjpl_pose *p, const double *dQ, int64_t N, uint8_t *dvalid, double *dxpos, double *dxmat) {
   int rc = pose_check(p, dQ, N);

@@ -121,30 +121,13 @@ k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLane
   ln.cnt[l] = 0;
 }
 
-// One chunk of an extension: every active lane walks up to S steps from C towards its target and
-// emits the candidate edges (w -> q) it would like validated.  Without a projecting constraint the
-// candidates do not depend on the verdicts, so S may exceed 1 and the rule checks (joint limits,
-// moved, not farther) are made here; with one, S = 1 and the rules are checked after projection.
-struct RrtFull {  // projecting constraint: where k_rrt_gen leaves the candidates as full qpos rows for k_pose_apply
-  int nq;
-  const int *qidx;
-  const double *qbase;
-  double *Fold, *Fnew;  // null: not projecting
-};
-
-__device__ __forceinline__ void rrt_full_rows(const RrtFull &fr, int nplan, int64_t slot, const double *a, const double *b) {
-  if (!fr.Fold) return;
-  for (int k = 0; k < fr.nq; k++) { fr.Fold[slot * fr.nq + k] = fr.qbase[k]; fr.Fnew[slot * fr.nq + k] = fr.qbase[k]; }
-  for (int c = 0; c < nplan; c++) {
-    fr.Fold[slot * fr.nq + fr.qidx[c]] = a[c];
-    fr.Fnew[slot * fr.nq + fr.qidx[c]] = b[c];
-  }
-}
-
+// One chunk of an extension without a projecting constraint: every active lane walks up to S steps
+// from C towards its target and emits the candidate edges (w -> q) it would like validated.  The
+// candidates do not depend on the verdicts, so S may exceed 1; the rule checks (joint limits, moved,
+// not farther) are made here.  (k_rrt_gen_project below: the same with a PoseConstraint.)
 __global__ void __launch_bounds__(256)
-k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__restrict__ lo,
-          const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln, RrtCand cd, int *__restrict__ ctr,
-          RrtFull fr) {
+k_rrt_gen(int L, int nplan, int S, double eps, const double *__restrict__ lo,
+          const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln, RrtCand cd, int *__restrict__ ctr) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool act = l < L && ln.act[l] != 0;
@@ -165,7 +148,6 @@ k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__r
     reach = reach || (mag <= eps);
     if (reach)
       for (int c = 0; c < nplan; c++) q[c] = T[c];  // a step of at most eps lands on the target
-    if (projecting) return reach ? 2 : 1;
     bool ok = true;
     for (int c = 0; c < nplan; c++) ok = ok && (q[c] >= lo[c] && q[c] <= hi[c]);
     for (int c = 0; c < nplan; c++) d[c] = q[c] - w[c];
@@ -182,7 +164,7 @@ k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__r
       if (r == 0) { end = 1; break; }
       count++;
       for (int c = 0; c < nplan; c++) w[c] = q[c];
-      if (r == 2 && !projecting) { end = 1; break; }  // (projecting: arrival is judged after the projection)
+      if (r == 2) { end = 1; break; }
     }
   }
   // one reservation per wave
@@ -208,11 +190,6 @@ k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__r
         cd.B[(int64_t)slot * nplan + c] = v;
       }
       cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
-      if (fr.Fold) {
-        double v[kRrtMaxPlan];
-        for (int c = 0; c < nplan; c++) v[c] = ln.C[(int64_t)c * L + l];
-        rrt_full_rows(fr, nplan, slot, v, v);
-      }
     }
     count = 0; end = 0; first = 0;
   }
@@ -238,49 +215,144 @@ k_rrt_gen(int L, int nplan, int S, double eps, int projecting, const double *__r
     cd.level[slot] = lvl0 + s;
     cd.rule[slot] = 1;
     cd.reach[slot] = (r == 2) ? 1 : 0;
-    rrt_full_rows(fr, nplan, slot, w, q);
     for (int c = 0; c < nplan; c++) w[c] = q[c];
   }
 }
 
-// after the projection: B <- projected planning columns; rules of _constrained_extend
-__global__ void __launch_bounds__(256)
-k_rrt_after_pose(int E, int L, int nplan, int nq, const int *__restrict__ qidx, const double *__restrict__ qbase,
-                 const uint8_t *__restrict__ isplan, const double *__restrict__ lo, const double *__restrict__ hi,
-                 const double *__restrict__ Tgt, RrtCand cd, const double *__restrict__ Fout,
-                 const uint8_t *__restrict__ ok) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= E) return;
-  const int l = cd.lane[i];
-  bool good = ok[i] != 0;
-  for (int k = 0; k < nq; k++)  // a projection that moves a joint outside the planning set is rejected
-    if (!isplan[k]) good = good && (Fout[(int64_t)i * nq + k] == qbase[k]);
-  double q[kRrtMaxPlan], d[kRrtMaxPlan];
-  bool reach = true;
-  for (int c = 0; c < nplan; c++) {
-    q[c] = Fout[(int64_t)i * nq + qidx[c]];
-    reach = reach && (q[c] == Tgt[(int64_t)c * L + l]);
-    good = good && (q[c] >= lo[c] && q[c] <= hi[c]);
+// One chunk of an extension under a projecting constraint (PoseConstraint): every active lane takes up to
+// S steps -- _step towards the target, the projection of that step (pose_project_lane: PoseConstraint.apply),
+// the rules of _constrained_extend on what comes back (planning/utils.py:139-164: joint limits, moved >= 1e-8,
+// not farther from the target; a projection that moves a joint outside the planning set is rejected) -- each from
+// where the step before ended.  The projection depends on the previous step's result, not on its collision
+// verdict, so a lane's S candidates are generated on the spot and validated together; k_rrt_accept keeps the
+// leading valid ones, which are exactly what S chunks of one step would have kept.  The host takes S > 1 when
+// few lanes are left and a chunk costs the latency of its kernels whatever it holds.
+// Every emitting lane owns S slots: those behind its last candidate carry a zero-length edge nobody reads.
+// One workgroup of 64 lanes; LDS per lane: qw[nq] | jst[6 * njoint] | qo[nq].
+__global__ void __launch_bounds__(kPoseBlock)
+k_rrt_gen_project(int L, int nplan, int S, double eps, const int *__restrict__ pi, const double *__restrict__ pd,
+                  const int *__restrict__ qidx, const double *__restrict__ qbase, const uint8_t *__restrict__ isplan,
+                  const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln,
+                  RrtCand cd, int *__restrict__ ctr) {
+  extern __shared__ double smem[];
+  constexpr int B = kPoseBlock;
+  const int lane = threadIdx.x;
+  const int l = blockIdx.x * B + lane;
+  const int nq = pi[PH_NQ], nj = pi[PH_NJOINT];
+  const bool act = l < L && ln.act[l] != 0;
+  const unsigned long long am = __ballot(act);
+  if (am == 0ull) return;
+  double *qw = smem + lane;
+  double *jst = smem + (size_t)nq * B + lane;
+  double *qo = smem + ((size_t)nq + 6 * (size_t)nj) * B + lane;
+  // S slots per active lane, one reservation per wave
+  int base = 0;
+  if (lane == 0) {
+    const int nact = __popcll(am);
+    base = atomicAdd(&ctr[RC_EDGES], nact * S);
+    atomicAdd(&ctr[RC_ACTIVE], nact);
   }
-  for (int c = 0; c < nplan; c++) d[c] = q[c] - cd.A[(int64_t)i * nplan + c];
-  good = good && !(seqnorm(d, nplan) < 1e-8);
-  for (int c = 0; c < nplan; c++) d[c] = Tgt[(int64_t)c * L + l] - q[c];
-  const double after = seqnorm(d, nplan);
-  for (int c = 0; c < nplan; c++) d[c] = Tgt[(int64_t)c * L + l] - cd.A[(int64_t)i * nplan + c];
-  good = good && !(after > seqnorm(d, nplan));
-  if (good)
-    for (int c = 0; c < nplan; c++) cd.B[(int64_t)i * nplan + c] = q[c];
-  else  // keep a harmless edge for the validation launch
-    for (int c = 0; c < nplan; c++) cd.B[(int64_t)i * nplan + c] = cd.A[(int64_t)i * nplan + c];
-  cd.rule[i] = good ? 1 : 0;
-  cd.reach[i] = (good && reach) ? 1 : 0;
+  base = __builtin_amdgcn_readfirstlane(base);
+  int first = base + __popcll(am & ((1ull << lane) - 1ull)) * S;
+  bool going = act;
+  if (going && first + S > cd.cap) {  // (the host sizes S for the space there is: a lane refused here waits for the next chunk)
+    atomicOr(&ctr[RC_OVERFLOW], 1);
+    for (int slot = first; slot < cd.cap; slot++) {
+      for (int c = 0; c < nplan; c++) {
+        const double v = ln.C[(int64_t)c * L + l];
+        cd.A[(int64_t)slot * nplan + c] = v;
+        cd.B[(int64_t)slot * nplan + c] = v;
+      }
+      cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
+    }
+    ln.gfirst[l] = 0; ln.gcount[l] = 0; ln.gend[l] = 0;
+    going = false;
+  }
+  const bool mine = going;
+  double T[kRrtMaxPlan], w[kRrtMaxPlan], q[kRrtMaxPlan], d[kRrtMaxPlan];
+  if (going)
+    for (int c = 0; c < nplan; c++) { T[c] = Tgt[(int64_t)c * L + l]; w[c] = ln.C[(int64_t)c * L + l]; }
+  const int lvl0 = mine ? ln.cnt[l] : 0;
+  int count = 0, end = 0;
+  for (int s = 0; s < S && __ballot(going) != 0ull; s++) {
+    if (going) {
+      // _step(w, T, eps) (planning/utils.py:167-186)
+      for (int c = 0; c < nplan; c++) d[c] = T[c] - w[c];
+      const double mag = seqnorm(d, nplan);
+      const double sm = eps < mag ? eps : mag;
+      bool reach = true;
+      for (int c = 0; c < nplan; c++) {
+        q[c] = w[c] + (d[c] / mag) * sm;
+        reach = reach && (q[c] == T[c]);
+      }
+      reach = reach || (mag <= eps);
+      if (reach)
+        for (int c = 0; c < nplan; c++) q[c] = T[c];  // a step of at most eps lands on the target
+      for (int k = 0; k < nq; k++) { qo[k * B] = qbase[k]; qw[k * B] = qbase[k]; }
+      for (int c = 0; c < nplan; c++) { qo[qidx[c] * B] = w[c]; qw[qidx[c] * B] = q[c]; }
+    }
+    int it = 0;
+    const int result = pose_project_lane(pi, pd, qw, jst, qo, B, going, &it);
+    if (going) {
+      bool good = result == 1;
+      for (int k = 0; k < nq; k++)  // a projection that moves a joint outside the planning set is rejected
+        if (!isplan[k]) good = good && (qw[k * B] == qbase[k]);
+      bool reach = true;
+      for (int c = 0; c < nplan; c++) {
+        q[c] = qw[qidx[c] * B];
+        reach = reach && (q[c] == T[c]);
+        good = good && (q[c] >= lo[c] && q[c] <= hi[c]);
+      }
+      for (int c = 0; c < nplan; c++) d[c] = q[c] - w[c];
+      good = good && !(seqnorm(d, nplan) < 1e-8);
+      for (int c = 0; c < nplan; c++) d[c] = T[c] - q[c];
+      const double after = seqnorm(d, nplan);
+      for (int c = 0; c < nplan; c++) d[c] = T[c] - w[c];
+      good = good && !(after > seqnorm(d, nplan));
+      const int slot = first + s;
+      for (int c = 0; c < nplan; c++) {
+        cd.A[(int64_t)slot * nplan + c] = w[c];
+        cd.B[(int64_t)slot * nplan + c] = good ? q[c] : w[c];  // (refused: a harmless edge for the validation launch)
+      }
+      cd.lane[slot] = l;
+      cd.level[slot] = lvl0 + s;
+      cd.rule[slot] = good ? 1 : 0;
+      cd.reach[slot] = (good && reach) ? 1 : 0;
+      count++;
+      if (good) {
+        for (int c = 0; c < nplan; c++) w[c] = q[c];
+        if (reach) { end = 1; going = false; }
+      } else {
+        end = 1; going = false;
+      }
+    }
+  }
+  if (mine) {
+    for (int slot = first + count; slot < first + S; slot++) {
+      for (int c = 0; c < nplan; c++) {
+        cd.A[(int64_t)slot * nplan + c] = w[c];
+        cd.B[(int64_t)slot * nplan + c] = w[c];
+      }
+      cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
+    }
+    ln.gfirst[l] = first;
+    ln.gcount[l] = count;
+    ln.gend[l] = (uint8_t)end;
+  }
 }
 
 // accept the leading valid candidates of every lane
 __global__ void __launch_bounds__(256)
-k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restrict__ ctr) {
+k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restrict__ ctr, int *__restrict__ host_slot, int seq) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  // (the host has read this chunk's counts: clear them for the next k_rrt_gen instead of two fills)
+  // The chunk's counts are closed (the generating kernel is through): leave them in the pinned block the host
+  // will look at two chunks from now (RC_SIZE ints and a sequence word written last) ...
+  if (host_slot && l < RC_SIZE) {
+    __hip_atomic_store(host_slot + l, ctr[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (l == 0) __hip_atomic_store(host_slot + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // ... and clear them for the next chunk instead of two fills
   if (l == 0) { ctr[RC_EDGES] = 0; ctr[RC_ACTIVE] = 0; }
   if (l >= L || !ln.act[l]) return;
   const int n = ln.gcount[l];
@@ -472,14 +544,14 @@ struct mjpl_rrt {
   double *d_pendQ[2] = {nullptr, nullptr};
   int32_t *d_pendpar[2] = {nullptr, nullptr};
   int pendcap = 0;
-  double *d_F[3] = {nullptr, nullptr, nullptr};  // full-row buffers of the projection
-  uint8_t *d_pok = nullptr;
+  // projecting extensions: most steps a lane takes per chunk, and the candidate slots a chunk is sized for
+  // (S = min(proj_steps_max, proj_slots / active lanes); MJPL_RRT_PROJ_STEPS / MJPL_RRT_PROJ_SLOTS)
+  int proj_steps_max = 32;
+  int64_t proj_slots = 32768;
   int *d_ctr = nullptr, *h_ctr = nullptr;
-  // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned
-  // copies and the events that say when each has landed
+  // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned copies
   int *h_ring = nullptr;      // 4 slots of kRingStride ints: RC_SIZE counters, then the sequence word
   int ring_seq0 = 1;          // sequence number of chunk 0 of the extension under way (never repeats within the ring)
-  hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // exchange
   int *d_heads = nullptr, *h_heads = nullptr;
   char *d_gather = nullptr;
@@ -526,69 +598,73 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
                      second, r->d_ctr);
   const bool projecting = r->pose != nullptr;
   int S = projecting ? 1 : 4;
-  // With a projecting constraint an extension is hundreds of one-step chunks, the late ones with a
-  // handful of lanes: waiting for every chunk's counters before sizing its launches leaves the GPU
-  // idle while the host enqueues the next dozen kernels.  Lanes only ever leave an extension (every
-  // active lane emits one candidate per chunk when the buffer holds a candidate per lane), so the
-  // count of two chunks ago is an upper bound: chunk i is sized by it -- the surplus rows are the
-  // previous chunks' candidates, validated again and read by nobody -- and the loop ends two chunks
-  // after the last lane has.
-  const bool pipelined = projecting && r->cd.cap >= L;
+  // With a projecting constraint an extension is hundreds of chunks, the late ones with a handful of lanes:
+  // waiting for every chunk's counters before sizing its launches would leave the GPU idle while the host
+  // enqueues the next kernels.  Lanes only ever leave an extension, and every active lane owns S slots of the
+  // chunk's candidates, so the active count of two chunks ago bounds this chunk's: chunk i is sized by it -- the
+  // surplus rows are earlier chunks' candidates, validated again and read by nobody -- and the loop ends two
+  // chunks after the last lane has.  The counters come from a pinned ring k_rrt_accept writes (slot chunk % 4):
+  // no copy, no event, the host spins on a sequence word.
+  if (projecting && r->cd.cap < L) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer too small for one step per lane");
   int chunks_done = 0;
+  int active_bound = L;  // (projecting) no more lanes than this are active in the chunk about to be launched
   for (int chunk = 0;; chunk++) {
     chunks_done = chunk + 1;
-    hipLaunchKernelGGL(k_rrt_gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, projecting ? 1 : 0, r->d_lo, r->d_hi,
-                       Tgt, r->ln, r->cd, r->d_ctr,
-                       RrtFull{r->nq, r->d_qidx, r->d_qbase, projecting ? r->d_F[0] : nullptr, projecting ? r->d_F[1] : nullptr});
-    if (pipelined && chunk >= 2) {
-      // the counters of two chunks ago, which that chunk's projection kernel left in pinned memory (slot
-      // (chunk - 2) % 4: RC_SIZE ints and a sequence word written last): no copy, no event, the host spins
-      const int look = (chunk - 2) % 4;
-      volatile int *slot = r->h_ring + look * kRingStride;
-      const int want = r->ring_seq0 + chunk - 2;
-      for (long spins = 0; __atomic_load_n(slot + 16, __ATOMIC_ACQUIRE) != want; spins++) {
-        if (spins > 2000000000L) return fail(MJPL_E_HIP, "rrt: the counters of an extension chunk never arrived");
-        __builtin_ia32_pause();
+    if (projecting) {
+      if (chunk >= 2) {
+        const int look = (chunk - 2) % 4;
+        volatile int *slot = r->h_ring + look * kRingStride;
+        const int want = r->ring_seq0 + chunk - 2;
+        for (long spins = 0; __atomic_load_n(slot + 16, __ATOMIC_ACQUIRE) != want; spins++) {
+          if (spins > 2000000000L) return fail(MJPL_E_HIP, "rrt: the counters of an extension chunk never arrived");
+          __builtin_ia32_pause();
+        }
+        for (int k = 0; k < RC_SIZE; k++) r->h_ctr[k] = slot[k];
+        if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
+        if (r->h_ctr[RC_OVERFLOW] & 1) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer overrun in a projecting extension");
+        if (r->h_ctr[RC_ACTIVE] == 0) break;
+        active_bound = r->h_ctr[RC_ACTIVE];
       }
-      for (int k = 0; k < RC_SIZE; k++) r->h_ctr[k] = slot[k];
-    } else if ((rc = rrt_read_ctr(r)) != MJPL_OK) {  // (the first two chunks: their own counts)
-      return rc;
+      // Steps per chunk: one while the chunk's kernels are busy with the lanes there are; more when they are
+      // not -- a chunk then costs the latency of its launches whatever it holds, and S steps share it.  The
+      // speculation costs slots (S per lane) and nothing else: a lane that stops early stops generating.
+      S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(r->proj_steps_max, r->proj_slots / std::max(1, active_bound)),
+                                                      (int64_t)r->cd.cap / std::max(1, active_bound)));
+      hipLaunchKernelGGL(k_rrt_gen_project, dim3((unsigned)((L + kPoseBlock - 1) / kPoseBlock)), dim3(kPoseBlock),
+                         pose_lds(r->pose) + (size_t)kPoseBlock * sizeof(double) * (size_t)r->nq, st, L, nplan, S, r->eps,
+                         r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase, r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+      if (chunk < 2) {  // (the first two chunks: their own counts)
+        if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
+        if (r->h_ctr[RC_OVERFLOW] & 3) return fail(MJPL_E_CAPACITY, "rrt: buffer overrun in a projecting extension");
+        if (r->h_ctr[RC_ACTIVE] == 0) break;
+        active_bound = r->h_ctr[RC_ACTIVE];
+      }
+    } else {
+      hipLaunchKernelGGL(k_rrt_gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+      if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
+      if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
+      if (r->h_ctr[RC_ACTIVE] == 0) {
+        if (r->h_ctr[RC_OVERFLOW] & 1) {  // every waiting lane was refused: S is too large for the space left
+          HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
+          HIP_TRY(hipMemsetAsync(r->d_ctr + RC_EDGES, 0, sizeof(int), st));  // (k_rrt_accept clears it otherwise)
+          if (S == 1) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer too small for one step per lane");
+          S = 1;
+          continue;
+        }
+        break;
+      }
+      if (r->h_ctr[RC_OVERFLOW] & 1) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
     }
     // (lanes that were refused candidate space have reserved slots all the same: RC_EDGES may exceed
     // the buffer, and only RC_ACTIVE says whether any lane emitted)
-    const int E = std::min(r->h_ctr[RC_EDGES], r->cd.cap);
-    if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
-    if (r->h_ctr[RC_ACTIVE] == 0) {
-      if (r->h_ctr[RC_OVERFLOW] & 1) {  // every waiting lane was refused: S is too large for the space left
-        HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
-        HIP_TRY(hipMemsetAsync(r->d_ctr + RC_EDGES, 0, sizeof(int), st));  // (k_rrt_accept clears it otherwise)
-        if (S == 1) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer too small for one step per lane");
-        S = 1;
-        continue;
-      }
-      break;
-    }
-    if (r->h_ctr[RC_OVERFLOW] & 1) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_OVERFLOW, 0, sizeof(int), st));
-    if (projecting) {
-      // projection, then the rules of the extension on what it returns, as that kernel's epilogue; it also
-      // leaves this chunk's counters where the host will look for them two chunks from now
-      PoseEpilogue ep = {};
-      ep.on = 1; ep.L = L; ep.nplan = nplan;
-      ep.qidx = r->d_qidx; ep.qbase = r->d_qbase; ep.isplan = r->d_isplan;
-      ep.lo = r->d_lo; ep.hi = r->d_hi; ep.Tgt = Tgt;
-      ep.A = r->cd.A; ep.B = r->cd.B; ep.lane = r->cd.lane; ep.rule = r->cd.rule; ep.reach = r->cd.reach;
-      ep.ctr = r->d_ctr;
-      ep.host_slot = pipelined ? r->h_ring + (chunk % 4) * kRingStride : nullptr;
-      ep.seq = r->ring_seq0 + chunk;
-      rc = pose_apply_epilogue(r->pose, r->d_F[0], r->d_F[1], E, r->d_F[2], r->d_pok, ep);
-      if (rc != MJPL_OK) return rc;
-    }
+    const int E = projecting ? (int)std::min<int64_t>((int64_t)S * active_bound, r->cd.cap) : std::min(r->h_ctr[RC_EDGES], r->cd.cap);
     if (r->istep > 0)
       rc = launch_edges(e, r->cd.A, r->cd.B, E, r->istep, MJPL_AOS, 0, r->cd.valid, nullptr);
     else
       rc = launch_configs(e, r->cd.B, E, MJPL_AOS, r->cd.valid, nullptr);
     if (rc != MJPL_OK) return rc;
-    hipLaunchKernelGGL(k_rrt_accept, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->cd, r->acc, r->d_ctr);
+    hipLaunchKernelGGL(k_rrt_accept, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->cd, r->acc, r->d_ctr,
+                       projecting ? r->h_ring + (chunk % 4) * kRingStride : (int *)nullptr, r->ring_seq0 + chunk);
     // chunk sizes double: a chain of n steps costs O(log n) chunks and at most 2x its own checks
     if (!projecting && S < 64) {
       const int64_t room = (int64_t)r->cd.cap / std::max(1, r->h_ctr[RC_ACTIVE]);
@@ -599,6 +675,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   // node order of the extension: lanes ascending, levels ascending within a lane
   hipLaunchKernelGGL(k_rrt_scan, dim3(1), dim3(1024), 0, st, L, r->ln.cnt, r->ln.off, r->d_ctr + (t == (r->round - 1) % 2 ? RC_NEWA : RC_NEWB));
   if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
+  if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
   const int nacc = r->h_ctr[RC_ACC];
   *nnew = nacc;
   if (nacc > r->pendcap) return fail(MJPL_E_CAPACITY, "rrt: %d new nodes in one extension, pending slab holds %d", nacc, r->pendcap);
@@ -676,8 +753,6 @@ void mjpl_rrt_destroy(mjpl_rrt *r) {
   for (void *p : r->owned) (void)hipFree(p);
   if (r->h_ctr) (void)hipHostFree(r->h_ctr);
   if (r->h_ring) (void)hipHostFree(r->h_ring);
-  for (hipEvent_t ev : r->ring_ev)
-    if (ev) (void)hipEventDestroy(ev);
   if (r->h_heads) (void)hipHostFree(r->h_heads);
   if (r->h_myhead) (void)hipHostFree(r->h_myhead);
   if (r->d_gather) (void)hipFree(r->d_gather);
@@ -720,17 +795,14 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   r->acc.cap = r->pendcap;
   RA(r->acc.Q, (size_t)r->acc.cap * nplan); RA(r->acc.lane, r->acc.cap); RA(r->acc.level, r->acc.cap);
   for (int t = 0; t < 2; t++) { RA(r->d_pendQ[t], (size_t)r->pendcap * nplan); RA(r->d_pendpar[t], r->pendcap); }
-  if (r->pose) {
-    for (int k = 0; k < 3; k++) RA(r->d_F[k], (size_t)r->cd.cap * r->nq);
-    RA(r->d_pok, r->cd.cap);
-  }
   RA(r->d_ctr, RC_SIZE); RA(r->d_heads, 8 * 1024); RA(r->d_path, (size_t)nplan * 65536);
   RA(r->d_first, 1);  // re-allocated by reset for the number of goals
 #undef RA
   HIP_TRY(hipHostMalloc((void **)&r->h_ctr, RC_SIZE * sizeof(int)));
   HIP_TRY(hipHostMalloc((void **)&r->h_ring, 4 * kRingStride * sizeof(int)));
   memset(r->h_ring, 0, 4 * kRingStride * sizeof(int));
-  for (hipEvent_t &ev : r->ring_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (const char *v = getenv("MJPL_RRT_PROJ_STEPS")) r->proj_steps_max = std::max(1, atoi(v));
+  if (const char *v = getenv("MJPL_RRT_PROJ_SLOTS")) r->proj_slots = std::max(1, atoi(v));
   HIP_TRY(hipHostMalloc((void **)&r->h_heads, 8 * 1024 * sizeof(int)));
   HIP_TRY(hipHostMalloc((void **)&r->h_myhead, 8 * sizeof(int)));
   std::vector<uint8_t> isplan(r->nq, 0);

@@ -510,7 +510,8 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
     if generic:
         o(f"    // the scene table in front of the float32 tables: header, then per moving geom {SCENE_ROWS} cull rows and {SCENE_ROWS} descriptors")
         o(f"    const FP sc = tp + ({SC});")
-        o("    const int sc_nplane = info_bits(sc[0]), sc_nrows = info_bits(sc[1]);")
+        o("    const int sc_nplane = info_bits(sc[0]);  // the last 0 .. 2 rows of a geom are planes")
+        o("    const int sc_first = info_bits(sc[1]);   // first pair of rows in use (the rows of a geom fill its table from the end)")
         o("    const float maxcoord = sc[4], maxangle = sc[5];")
         o("    const int nwpad = info_bits(sc[2]);")
         o("    const float *lwcull = ltab, *lwnarrow = ltab + info_bits(sc[3]);")
@@ -545,33 +546,49 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
     if generic:
         o("      {  // static partners: one row [a0 a1 a2 thr] of the scene table each, two rows per scalar load, the next")
         o("         // pair fetched while this one is tested (two buffers taking turns: no copies, 16 scalar registers).")
-        o("         // Rows 0, 1: planes, a . c <= thr; rows 2 ..: |c|^2 + a . c <= thr")
+        o("         // The planes (the last rows): a . c <= thr; the others: |c|^2 + a . c <= thr; a row that is no partner: thr = -inf.")
+        o("         // One straight line over all rows, entered at the first pair in use: row offsets and the lanes")
+        o("         // the masks are parked in are literals, and what a stage pays beside the tests is the one dispatch (a")
+        o("         // rolled loop spent thirty scalar instructions per four rows: addresses, the lane select in M0, the counter).")
         o("        const float ux = cx + dead;")
         o("        const float cc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, ux * ux));")
         o("        const float zd = 0.0f * ux;  // 0, or NaN on a lane that is not to report anything")
-        o(f"        const FP rows = sc + ({SCENE_HEADER} + g * {SCENE_STAGE});")
+        o("        const float acc_a = sc_nplane >= 2 ? zd : cc, acc_b = sc_nplane >= 1 ? zd : cc;  // (the last two rows)")
+        o(f"        FP rows = sc + ({SCENE_HEADER} + g * {SCENE_STAGE});")
         o("        float ra[8], rb[8];")
         o("#define MJPL_SCENE_LOAD(dst, at) _Pragma(\"unroll\") for (int k_ = 0; k_ < 8; k_++) dst[k_] = rows[4 * (at) + k_]")
         o("        // (a fetch is waited for behind the arithmetic of the pair before it: scalar loads return out of order, so")
-        o("        //  a wait at its first use -- after the NEXT fetch has gone out -- would drain that one, too)")
-        o("#define MJPL_SCENE_WAIT(buf) asm volatile(\"\" ::\"s\"(buf[0]), \"s\"(buf[7]))")
-        o("#define MJPL_SCENE_PAIR(buf, acc, at) do { \\")
-        o("          const float t0_ = __builtin_fmaf(cz, buf[2], __builtin_fmaf(cy, buf[1], __builtin_fmaf(ux, buf[0], acc))); \\")
-        o("          const float t1_ = __builtin_fmaf(cz, buf[6], __builtin_fmaf(cy, buf[5], __builtin_fmaf(ux, buf[4], acc))); \\")
+        o("        //  a wait at its first use -- after the NEXT fetch has gone out -- would drain that one, too; `rows` passes")
+        o("        //  through the wait so that the next fetch cannot be moved above it, the scheduling barriers keep fetch,")
+        o("        //  arithmetic and wait in this order)")
+        o("#define MJPL_SCENE_WAIT(buf) asm volatile(\"\" : \"+s\"(rows) : \"s\"(buf[0]), \"s\"(buf[7]))")
+        o("#define MJPL_SCENE_PAIR(buf, acca, accb, ka, kb) do { \\")
+        o("          const float t0_ = __builtin_fmaf(cz, buf[2], __builtin_fmaf(cy, buf[1], __builtin_fmaf(ux, buf[0], acca))); \\")
+        o("          const float t1_ = __builtin_fmaf(cz, buf[6], __builtin_fmaf(cy, buf[5], __builtin_fmaf(ux, buf[4], accb))); \\")
         o("          const unsigned long long m0_ = __builtin_amdgcn_ballot_w64(t0_ <= buf[3]); \\")
         o("          const unsigned long long m1_ = __builtin_amdgcn_ballot_w64(t1_ <= buf[7]); \\")
-        o("          mjpl::park_mask_at2(mlo, mhi, m0_, m1_, at); } while (0)")
-        o("        MJPL_SCENE_LOAD(ra, 0);")
-        o("        MJPL_SCENE_WAIT(ra);")
-        o("#pragma nounroll")
-        o("        for (int r = 0; r < sc_nrows; r += 4) {")
-        o("          MJPL_SCENE_LOAD(rb, r + 2);")
-        o("          const float acc = r == 0 ? zd : cc;")
-        o("          if (r != 0 || sc_nplane != 0) MJPL_SCENE_PAIR(ra, acc, r);")
-        o("          MJPL_SCENE_WAIT(rb);")
-        o("          MJPL_SCENE_LOAD(ra, r + 4);  // (the table ends with a spare chunk)")
-        o("          MJPL_SCENE_PAIR(rb, cc, r + 2);")
-        o("          MJPL_SCENE_WAIT(ra);")
+        o("          mjpl::park_mask2<ka, kb>(mlo, mhi, m0_, m1_); } while (0)")
+        o("        // (one copy of the line per entry point: falling through case labels, the buffers would arrive at every")
+        o("        //  label from two places and the compiler would copy eight registers there)")
+        o("        switch (sc_first) {")
+        npair = SCENE_ROWS // 2
+        for first in range(0, SCENE_ROWS, 2):
+            o(f"          {'default' if first == SCENE_ROWS - 2 else f'case {first}'}: {{")
+            o(f"        MJPL_SCENE_LOAD(ra, {first});")
+            for pr in range(first // 2, npair):
+                k = pr - first // 2
+                cur, nxt = ("ra", "rb") if k % 2 == 0 else ("rb", "ra")
+                o(f"        MJPL_SCENE_WAIT({cur});")
+                o("        __builtin_amdgcn_sched_barrier(0);")
+                if pr + 1 < npair:
+                    o(f"        MJPL_SCENE_LOAD({nxt}, {2 * (pr + 1)});")
+                o("        __builtin_amdgcn_sched_barrier(0);")
+                if pr == npair - 1:
+                    o(f"        MJPL_SCENE_PAIR({cur}, acc_a, acc_b, {2 * pr}, {2 * pr + 1});")
+                else:
+                    o(f"        MJPL_SCENE_PAIR({cur}, cc, cc, {2 * pr}, {2 * pr + 1});")
+                o("        __builtin_amdgcn_sched_barrier(0);")
+            o("          } break;")
         o("        }")
         o("#undef MJPL_SCENE_LOAD")
         o("#undef MJPL_SCENE_WAIT")

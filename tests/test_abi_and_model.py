@@ -158,7 +158,7 @@ def test_program_dump_and_code_generation_need_no_gpu():
         assert info.hash == info2.hash and np.array_equal(ip, ip2) and np.array_equal(fp.view(np.uint32), fp2.view(np.uint32))
         assert info.hash not in seen, name
         seen.add(info.hash)
-        assert not info.immediate and info.filter_usable and info.spec_abi == 9
+        assert not info.immediate and info.filter_usable and info.spec_abi == 11
         np.testing.assert_allclose(fp[np.isfinite(fp)], dp[np.isfinite(fp)].astype(np.float32), rtol=2e-5, atol=2e-4)
         src = specialise.generate(ip, fp, dp, info)
         culls = (src.count("MJPL_SPEC_CULLX(") + 2 * src.count("MJPL_SPEC_CULLX2(") + src.count("MJPL_SPEC_CULL(") +
@@ -223,7 +223,7 @@ def test_robot_hash_and_scene_generic_generation():
     assert specialise.dump_program(scenes.franka_p_scene(16, 16, 9), (), arm, base)[3].scene_ok == 0  # 34 static geoms
     ip, fp, dp, info = next(iter(programs.values()))
     src = specialise.generate(ip, fp, dp, info, generic=True)
-    assert "MJPL_SPEC_CULLX" not in src.split("struct Spec")[1] and "MJPL_SCENE_PAIR(ra, acc, r)" in src
+    assert "MJPL_SPEC_CULLX" not in src.split("struct Spec")[1] and "MJPL_SCENE_PAIR(ra, cc, cc, 0, 1)" in src and "acc_a, acc_b, 30, 31)" in src
     assert src.count("MJPL_SPEC_SLOTCULL(") == 33 + 1  # Franka-P's 33 self pairs (and the macro itself), in either kind of library
     srcs = {specialise.generate(*p, generic=True) for p in programs.values()}
     assert len({s.split("program hash")[1].split("\n", 1)[1] for s in srcs}) == 1, "generic code must not depend on the scene"
