@@ -211,6 +211,11 @@ int mjpl_check_configs_bits_dev(mjpl_engine *e, const double *dQ, int64_t N, int
 int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap,
                      const double *dqueries, int64_t M, int32_t *dout_idx, double *dout_dist2);
 
+/* Which screen the last mjpl_nearest_dev ran in front of its float64 distances: 0 none (plain float64 scan),
+ * 1 binary32 on the vector units, 2 binary16 operands on the matrix cores (large trees and query sets whose
+ * coordinates are all below 256 in magnitude).  The result is the float64 scan's either way.  Synchronises. */
+int32_t mjpl_nearest_last_screen(mjpl_engine *e);
+
 /* ---- device memory and stream helpers (so that hosts need no other GPU runtime) -- */
 
 int mjpl_dev_alloc(mjpl_engine *e, size_t bytes, void **out);

@@ -603,8 +603,9 @@ template <int NP>
 __global__ void __launch_bounds__(kNNThreads, 4)  // (left alone the compiler prefetches tiles into 256 registers)
 k_nearest_part32(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
                  int64_t M, int64_t chunk, const double *__restrict__ bound2, int32_t *__restrict__ pidx,
-                 double *__restrict__ pd2) {
+                 double *__restrict__ pd2, const unsigned *__restrict__ only_if_wild = nullptr) {
   typedef float v2f __attribute__((ext_vector_type(2)));
+  if (only_if_wild && only_if_wild[1] == 0u) return;  // (the matrix-core screen below serves this call)
   __shared__ float tile[NP * kNNThreads];
   __shared__ float wmax[kNNThreads / 64];
   const int t = threadIdx.x;
@@ -724,6 +725,193 @@ k_nearest_part32(const double *__restrict__ nodes, int64_t n, int64_t cap, const
       pidx[(int64_t)blockIdx.y * M + qindex(a)] = bi[a];
       pd2[(int64_t)blockIdx.y * M + qindex(a)] = best[a];  // (+inf, -1: nothing within the bound in this chunk)
     }
+}
+
+// ---- the same screen on the matrix cores (large trees and query sets, coordinates of ordinary size) --------------
+// Squared distances expand to |x|^2 - 2 q . x + |q|^2, and the cross terms of 32 nodes x 32 queries are ONE
+// v_mfma_f32_32x32x16_f16: nodes and queries are rounded to binary16 once per call (k_nn_pack), a node's row of
+// the A operand is [x_1 .. x_8 | n_hi, n_lo 2^11, 0 ...] with n = |x~|^2 (the rounded coordinates' squares summed in
+// binary32, split in two binary16 parts -- the second scaled into the normal range), a query's column of B is
+// [-2 q_1 .. -2 q_8 | 1, 2^-11, 0 ...]: the instruction returns t = |x~|^2 - 2 q~ . x~ for 1024 pairs, node on the
+// register index, query on the lane, and a pair passes when t <= T_q = thr - |q~|^2.  Sixteen results per lane are
+// folded with eight v_min3 and compared once; only a wave that sees a pass looks at the sixteen one by one and
+// evaluates the exact float64 distance of those -- k_nearest_part's statements, in scan order with a strict <.
+//   thr >= (R2 + 2 (4 sqrt(NP) e r + 4 NP e^2 + a)) (1 + 1e-6),  e = max(2^-11 X (1 + 2^-10), 2^-14),  a = 2^-17 NP X^2,
+// R2 = min(best exact squared distance so far of this lane, bound2), r = sqrt(R2), X = the largest finite coordinate
+// magnitude among all nodes and queries (k_nn_pack).  (Rounding a coordinate to binary16, through binary32, moves
+// it by at most 2^-11 |v| (1 + 2^-13), or by all of it, < 2^-14, where the matrix core flushes a subnormal: e per
+// column, on either side; so the rounded pair's distance differs from the true one by at most 2 sqrt(NP) e, and a
+// node no farther than r has a rounded squared distance of at most R2 + 4 sqrt(NP) e r + 4 NP e^2.  Arithmetic: the
+// squares are exact in binary32, their sums, the split of n, the ten-term accumulation of the instruction and the
+// subtraction of |q~|^2 lose at most 2^-19 (|x~| + |q~|)^2 <= 2^-17 NP X^2 together.  The factor two and the 1e-6
+// are margin.)  A node at +inf gives +inf or NaN, which v_min3 and the ordered compare ignore: never nearest, as in
+// the other kernels.  Two lanes share a query (rows 4h .. 4h+3 of every eight: h = lane / 32), each keeps its own
+// best; the reduction breaks ties by index.  Coordinates of 256 or more (or NaN) anywhere: k_nn_pack raises a flag,
+// this kernel returns at once and the binary32 screen above does the work.
+typedef _Float16 nn_h8 __attribute__((ext_vector_type(8)));
+typedef float nn_f16 __attribute__((ext_vector_type(16)));
+constexpr int kNNMSets = 4, kNNMWaves = 4;              // 32-query sets per wave, waves per workgroup
+constexpr int kNNMQueries = kNNMSets * kNNMWaves * 32;  // 512 queries per workgroup
+constexpr float kNNMWild = 256.0f;
+
+// nodes / queries -> the operand rows (32 bytes each: two 16-byte halves, k = 0..7 | 8..15), |x~|^2, and X
+__global__ void __launch_bounds__(256)
+k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int64_t padded, int nplan, int is_query,
+          uint4 *__restrict__ out16, float *__restrict__ nrm, unsigned *__restrict__ xbits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float mx = 0;
+  bool wild = false;
+  if (i < padded) {
+    union { _Float16 h[16]; uint4 u[2]; } row;
+    for (int k = 0; k < 16; k++) row.h[k] = (_Float16)0.0f;
+    float n2 = 0;
+    if (i < count) {
+      for (int c = 0; c < nplan; c++) {
+        const double v = src[(int64_t)c * col_stride + i];
+        const float f = (float)v;
+        const _Float16 hv = (_Float16)f;
+        if (v != v) wild = true;
+        if (fabs(v) < std::numeric_limits<double>::infinity()) {
+          if (!(fabs(v) < (double)kNNMWild)) wild = true;
+          mx = fmaxf(mx, fminf(fabsf(f), 1e30f));
+        }
+        const float hf = (float)hv;
+        n2 = n2 + hf * hf;
+        row.h[c] = is_query ? (_Float16)(-2.0f * hf) : hv;
+      }
+    } else if (!is_query) {
+      row.h[0] = (_Float16)std::numeric_limits<float>::infinity();  // padding: a node that never passes
+      n2 = std::numeric_limits<float>::infinity();
+    }
+    if (is_query) {
+      row.h[8] = (_Float16)1.0f;
+      row.h[9] = (_Float16)0x1p-11f;
+    } else {
+      const _Float16 hi = (_Float16)n2;
+      const float rest = n2 - (float)hi;  // exact; |rest| <= 2^-11 n2
+      row.h[8] = hi;
+      row.h[9] = (n2 < std::numeric_limits<float>::infinity()) ? (_Float16)(rest * 0x1p11f) : (_Float16)0.0f;
+    }
+    out16[2 * i] = row.u[0];
+    out16[2 * i + 1] = row.u[1];
+    if (nrm) nrm[i] = n2;
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(&xbits[0], __float_as_uint(mx));
+  if (__ballot(wild) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&xbits[1], 1u);
+}
+
+template <int NP>
+__device__ __forceinline__ float nn_mfma_threshold(double ref2, double ref, double e, double a, float nq) {
+  const double th = (ref2 + 2.0 * (4.0 * sqrt((double)NP) * e * ref + 4.0 * NP * e * e + a)) * (1.0 + 1e-6) - (double)nq;
+  float f = (float)th;
+  if ((double)f < th) f = nextafterf(f, std::numeric_limits<float>::infinity());
+  return f;
+}
+
+template <int NP>
+__global__ void __launch_bounds__(kNNMWaves * 64, 2)
+k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries, int64_t M,
+               const uint4 *__restrict__ nodes16, const uint4 *__restrict__ queries16, const float *__restrict__ qnorm,
+               const unsigned *__restrict__ xbits, int64_t chunk, const double *__restrict__ bound2,
+               int32_t *__restrict__ pidx, double *__restrict__ pd2) {
+  if (xbits[1] != 0u) return;  // wild coordinates: the binary32 screen serves this call
+  const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, w = threadIdx.x >> 6;
+  const int64_t q0 = ((int64_t)blockIdx.x * kNNMWaves + w) * (kNNMSets * 32) + r;
+  const double kInf = std::numeric_limits<double>::infinity();
+  const double X = (double)__uint_as_float(xbits[0]);
+  const double e = fmax(X * 0x1p-11 * (1.0 + 0x1p-10), 0x1p-14), a = 0x1p-17 * NP * X * X;
+  nn_h8 b[kNNMSets];
+  float nq[kNNMSets], T[kNNMSets];
+  double best[kNNMSets], ref2[kNNMSets];
+  int32_t bi[kNNMSets];
+#pragma unroll
+  for (int s = 0; s < kNNMSets; s++) {
+    const int64_t q = q0 + 32 * s;  // (the packed queries are padded to whole workgroups)
+    const uint4 u = queries16[2 * q + h];
+    __builtin_memcpy(&b[s], &u, 16);
+    nq[s] = qnorm[q];
+    best[s] = kInf;
+    bi[s] = -1;
+    ref2[s] = (q < M) ? bound2[q] : 0.0;
+    T[s] = ref2[s] < kInf ? nn_mfma_threshold<NP>(ref2[s], sqrt(ref2[s]), e, a, nq[s]) : std::numeric_limits<float>::infinity();
+    if (q >= M) T[s] = -std::numeric_limits<float>::infinity();
+  }
+  const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  const nn_f16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint4 ua = (lo < hi) ? nodes16[2 * (lo + r) + h] : uint4{0, 0, 0, 0};
+  for (int64_t base = lo; base < hi; base += 32) {
+    nn_h8 av;
+    __builtin_memcpy(&av, &ua, 16);
+    if (base + 32 < hi) ua = nodes16[2 * (base + 32 + r) + h];  // (the next tile travels during this one's arithmetic)
+    bool hit = false;
+#pragma unroll
+    for (int s = 0; s < kNNMSets; s++) {
+      const nn_f16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b[s], zero, 0, 0, 0);
+      float m = __builtin_fminf(__builtin_fminf(t[0], t[1]), t[2]);
+#pragma unroll
+      for (int i = 3; i < 15; i += 2) m = __builtin_fminf(__builtin_fminf(m, t[i]), t[i + 1]);
+      m = __builtin_fminf(m, t[15]);
+      hit = hit || (m <= T[s]);
+    }
+    if (__ballot(hit) != 0ull) {
+#pragma unroll
+      for (int s = 0; s < kNNMSets; s++) {
+        const nn_f16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b[s], zero, 0, 0, 0);
+        const int64_t q = q0 + 32 * s;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          if (t[i] <= T[s]) {
+            const int64_t node = base + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (node < hi) {
+              double ex = 0;
+#pragma unroll
+              for (int c = 0; c < NP; c++) {
+                const double d = nodes[(int64_t)c * cap + node] - queries[(int64_t)c * M + q];
+                ex = ex + d * d;
+              }
+              if (ex < best[s]) {
+                best[s] = ex;
+                bi[s] = (int32_t)node;
+                if (ex < ref2[s]) {
+                  ref2[s] = ex;
+                  T[s] = nn_mfma_threshold<NP>(ex, sqrt(ex), e, a, nq[s]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < kNNMSets; s++) {
+    const int64_t q = q0 + 32 * s;
+    if (q < M) {
+      const int64_t at = ((int64_t)blockIdx.y * 2 + h) * M + q;
+      pidx[at] = bi[s];
+      pd2[at] = best[s];  // (+inf, -1: nothing within the bound among this lane's rows)
+    }
+  }
+}
+
+// (partial results that are not in index order -- the two lanes of a query above: equal distances go to the lower index)
+__global__ void __launch_bounds__(kBlock)
+k_nearest_reduce_ties(const int32_t *__restrict__ pidx, const double *__restrict__ pd2, int64_t M, int nparts,
+                      int32_t *__restrict__ out_idx, double *__restrict__ out_d2, const unsigned *__restrict__ xbits,
+                      const int32_t *__restrict__ wild_pidx, const double *__restrict__ wild_pd2, int wild_nparts) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  if (xbits[1] != 0u) { pidx = wild_pidx; pd2 = wild_pd2; nparts = wild_nparts; }  // (the binary32 screen did the work)
+  double best = std::numeric_limits<double>::infinity();
+  int32_t bi = -1;
+  for (int y = 0; y < nparts; y++) {
+    const double d = pd2[(int64_t)y * M + j];
+    const int32_t k = pidx[(int64_t)y * M + j];
+    if (k >= 0 && (d < best || (d == best && (bi < 0 || k < bi)))) { best = d; bi = k; }
+  }
+  out_idx[j] = bi;
+  if (out_d2) out_d2[j] = best;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -858,6 +1046,10 @@ struct mjpl_engine {
   size_t item_cap_limit = (size_t)1 << 26;  // MJPL_ITEM_CAP: edges beyond it take the walking kernel
   void *d_nn = nullptr;         // nearest neighbour: per-chunk partial results
   size_t nn_bytes = 0;
+  void *d_nn16 = nullptr;       // ... the matrix-core screen's operands (binary16 rows) and partial results
+  size_t nn16_bytes = 0;
+  int nn_mfma = 1;              // MJPL_NN_MFMA=0: binary32 screen only
+  int nn_last = 0;              // what the last mjpl_nearest_dev launched: 0 float64 scan, 1 binary32 screen, 2 matrix-core screen (or 1: see its flag)
   size_t uc_cap = 0, uc_cap_limit = 0;
   int nslots = 0, nsave = 0, maxs = 4;
   bool wbox = false, mbox = false;
@@ -2186,6 +2378,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_FORCE_IMMEDIATE")) e->force_immediate = atoi(f) != 0;
   if (const char *f = getenv("MJPL_EXPAND")) e->expand = atoi(f) != 0;
   if (const char *f = getenv("MJPL_PERSIST")) e->persist = atoi(f) != 0 ? 1 : 0;
+  if (const char *f = getenv("MJPL_NN_MFMA")) e->nn_mfma = atoi(f) != 0 ? 1 : 0;
   if (const char *f = getenv("MJPL_TAIL")) e->fused_tail = atoi(f) != 0;
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
   if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));
@@ -2244,6 +2437,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_ucgb) (void)hipFree(e->d_ucgb);
   if (e->d_geomtab) (void)hipFree(e->d_geomtab);
   if (e->d_nn) (void)hipFree(e->d_nn);
+  if (e->d_nn16) (void)hipFree(e->d_nn16);
   if (e->d_tstep) (void)hipFree(e->d_tstep);
   if (e->d_itemck) (void)hipFree(e->d_itemck);
   if (e->d_itemedge) (void)hipFree(e->d_itemedge);
@@ -2444,6 +2638,16 @@ int mjpl_take_status(mjpl_engine *e, int32_t *status) {
   return MJPL_OK;
 }
 
+int32_t mjpl_nearest_last_screen(mjpl_engine *e) {
+  if (!e) return -1;
+  if (e->nn_last != 2) return e->nn_last;
+  unsigned x[2] = {0, 0};
+  if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
+      hipMemcpy(x, e->d_nn16, sizeof(x), hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return x[1] ? 1 : 2;  // (coordinates too large for binary16: the binary32 screen ran)
+}
+
 int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap, const double *dqueries,
                      int64_t M, int32_t *dout_idx, double *dout_dist2) {
   if (!e || n < 0 || M < 0 || cap < n) return fail(MJPL_E_ARG, "mjpl_nearest_dev: bad sizes");
@@ -2506,6 +2710,56 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
       scan64(kSampleNodes, ch0, nc0, stride);
       hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc0, seed_idx, seed_d2,
                          (const int32_t *)nullptr, (const double *)nullptr);
+      // the screened scan on the matrix cores (nplan <= 8), unless some coordinate is too large for binary16 -- which the
+      // device finds out while it packs the operands: then that kernel returns at once and the binary32 one runs
+      const bool mfma = e->nn_mfma && nplan <= 8;
+      e->nn_last = mfma ? 2 : 1;
+      unsigned *xbits = nullptr;
+      int32_t *mp_idx = nullptr;
+      double *mp_d2 = nullptr;
+      int mparts = 0;
+      if (mfma) {
+        const int64_t npad = (n + 31) / 32 * 32, Mpad = (M + kNNMQueries - 1) / kNNMQueries * kNNMQueries;
+        const int64_t qblocks = Mpad / kNNMQueries;
+        int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((2048 + qblocks - 1) / qblocks, n / 4096));
+        int64_t chm = ((n + nsplit - 1) / nsplit + 31) / 32 * 32;
+        nsplit = (n + chm - 1) / chm;
+        mparts = (int)(2 * nsplit);
+        const size_t b_nodes = (size_t)npad * 32, b_q = (size_t)Mpad * 32, b_qn = (size_t)Mpad * sizeof(float);
+        const size_t b_pd = (size_t)mparts * (size_t)M * sizeof(double), b_pi = (size_t)mparts * (size_t)M * sizeof(int32_t);
+        const size_t need16 = 256 + b_nodes + b_q + b_qn + b_pd + b_pi + 32;
+        if (need16 > e->nn16_bytes) {
+          // (trees grow call by call, and a reallocation stalls the stream: room for four times the nodes, within the slab)
+          const size_t room = need16 - b_nodes + (size_t)std::min<int64_t>((cap + 31) / 32 * 32, 4 * npad) * 32;
+          if (e->d_nn16) HIP_TRY(hipFree(e->d_nn16));
+          e->d_nn16 = nullptr; e->nn16_bytes = 0;
+          HIP_TRY(hipMalloc(&e->d_nn16, room));
+          e->nn16_bytes = room;
+        }
+        char *at = (char *)e->d_nn16;  // (the node rows last: they are what grows)
+        xbits = (unsigned *)at; at += 256;
+        uint4 *q16 = (uint4 *)at; at += b_q;
+        mp_d2 = (double *)at; at += b_pd;
+        float *qn = (float *)at; at += b_qn;
+        mp_idx = (int32_t *)at; at += (b_pi + 31) / 32 * 32;
+        uint4 *nodes16 = (uint4 *)at;
+        HIP_TRY(hipMemsetAsync(xbits, 0, 8, e->stream));
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, dnodes, n, cap, npad, nplan, 0,
+                           nodes16, (float *)nullptr, xbits);
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16,
+                           qn, xbits);
+        const dim3 gm((unsigned)qblocks, (unsigned)nsplit);
+#define MJPL_NNM_CASE(NPV)                                                                                                \
+        case NPV:                                                                                                         \
+          hipLaunchKernelGGL(k_nearest_mfma<NPV>, gm, dim3(kNNMWaves * 64), 0, e->stream, dnodes, n, cap, dqueries, M,    \
+                             (const uint4 *)nodes16, (const uint4 *)q16, (const float *)qn, (const unsigned *)xbits, chm, \
+                             (const double *)seed_d2, mp_idx, mp_d2);                                                     \
+          break;
+        switch (nplan) {
+          MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7) MJPL_NNM_CASE(8)
+        }
+#undef MJPL_NNM_CASE
+      }
       const int qb32 = kNN32Queries * kNNThreads;
       const int64_t qt32 = (M + qb32 - 1) / qb32;
       int64_t nc32 = std::max<int64_t>(1, (8192 + qt32 - 1) / qt32);
@@ -2517,18 +2771,23 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
 #define MJPL_NN32_CASE(NPV)                                                                                   \
       case NPV:                                                                                               \
         hipLaunchKernelGGL(k_nearest_part32<NPV>, g32, dim3(kNNThreads), 0, e->stream, dnodes, n, cap, dqueries, \
-                           M, ch32, (const double *)seed_d2, pidx, pd2);                                      \
+                           M, ch32, (const double *)seed_d2, pidx, pd2, (const unsigned *)xbits);             \
         break;
       switch (nplan) {
         MJPL_NN32_CASE(2) MJPL_NN32_CASE(3) MJPL_NN32_CASE(4) MJPL_NN32_CASE(5) MJPL_NN32_CASE(6) MJPL_NN32_CASE(7)
         MJPL_NN32_CASE(8) MJPL_NN32_CASE(9)
       }
 #undef MJPL_NN32_CASE
-      hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc32, dout_idx,
-                         dout_dist2, (const int32_t *)nullptr, (const double *)nullptr);
+      if (mfma)
+        hipLaunchKernelGGL(k_nearest_reduce_ties, dim3(rgridM), dim3(kBlock), 0, e->stream, (const int32_t *)mp_idx, (const double *)mp_d2, M,
+                           mparts, dout_idx, dout_dist2, (const unsigned *)xbits, (const int32_t *)pidx, (const double *)pd2, (int)nc32);
+      else
+        hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc32, dout_idx,
+                           dout_dist2, (const int32_t *)nullptr, (const double *)nullptr);
       HIP_TRY(hipGetLastError());
       return MJPL_OK;
     }
+    e->nn_last = 0;
     scan64(n, chunk, nchunks);
     hipLaunchKernelGGL(k_nearest_reduce, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
                        pidx, pd2, M, (int)nchunks, dout_idx, dout_dist2);

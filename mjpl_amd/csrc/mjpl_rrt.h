@@ -24,6 +24,8 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
+
 namespace {
 
 using namespace mjpl;
@@ -581,6 +583,21 @@ int rrt_alloc(mjpl_rrt *r, T **p, size_t count) {
 
 inline unsigned rgrid(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// MJPL_RRT_TRACE=1: where a round's wall time goes (stderr; synchronises the stream at every mark)
+struct RrtTrace {
+  bool on = getenv("MJPL_RRT_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(hipStream_t st, const char *what, long n = -1) {
+    if (!on) return;
+    (void)hipStreamSynchronize(st);
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rrt] %-28s %9.3f ms", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    if (n >= 0) fprintf(stderr, "  (%ld)", n);
+    fprintf(stderr, "\n");
+    t0 = std::chrono::steady_clock::now();
+  }
+};
+
 int rrt_read_ctr(mjpl_rrt *r) {
   HIP_TRY(hipMemcpyAsync(r->h_ctr, r->d_ctr, RC_SIZE * sizeof(int), hipMemcpyDeviceToHost, r->e->stream));
   HIP_TRY(hipStreamSynchronize(r->e->stream));
@@ -592,8 +609,11 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   mjpl_engine *e = r->e;
   hipStream_t st = e->stream;
   const int L = r->L, nplan = r->nplan;
+  RrtTrace tr;
+  tr.mark(st, "(before the extension)");
   int rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, Tgt, L, r->ln.near, nullptr);
   if (rc != MJPL_OK) return rc;
+  tr.mark(st, "nearest neighbour", r->n[t]);
   hipLaunchKernelGGL(k_rrt_begin, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->d_Q[t], r->cap, r->ln, r->d_first, Tgt,
                      second, r->d_ctr);
   const bool projecting = r->pose != nullptr;
@@ -671,6 +691,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
       S = (int)std::max<int64_t>(1, std::min<int64_t>(2 * S, room));
     }
   }
+  tr.mark(st, "extension chunks", chunks_done);
   r->ring_seq0 += chunks_done + 8;  // (sequence numbers of the pinned ring never repeat)
   // node order of the extension: lanes ascending, levels ascending within a lane
   hipLaunchKernelGGL(k_rrt_scan, dim3(1), dim3(1024), 0, st, L, r->ln.cnt, r->ln.off, r->d_ctr + (t == (r->round - 1) % 2 ? RC_NEWA : RC_NEWB));
@@ -685,6 +706,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   hipLaunchKernelGGL(k_rrt_finish, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, second ? r->ln.refB : r->ln.refA,
                      second ? (double *)nullptr : r->ln.RA);
   HIP_TRY(hipGetLastError());
+  tr.mark(st, "scan, place, finish", nacc);
   return MJPL_OK;
 }
 
@@ -1012,9 +1034,11 @@ int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info)
   const int world = rrt_world(r), rank = rrt_rank(r);
   if (world > 1 && !e->comm)
     return fail(MJPL_E_ARG, "mjpl_rrt_round: rank %d of %d without a communicator (mjpl_comm_init), use round_begin / round_finish", rank, world);
+  hipStream_t st = e->stream;
+  RrtTrace tr;
   int rc = rrt_begin(r, request_stop);
   if (rc != MJPL_OK) return rc;
-  hipStream_t st = e->stream;
+  tr.mark(st, "round_begin");
   const int nplan = r->nplan;
   const int grow = (r->round - 1) % 2, other = 1 - grow;
   // ---- exchange: headers of all ranks, then the new-node slabs padded to the round's largest count
@@ -1062,7 +1086,10 @@ int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info)
       }
     }
   }
-  return rrt_finish(r, r->h_heads, allQ, allP, stride, info);
+  tr.mark(st, "exchange");
+  rc = rrt_finish(r, r->h_heads, allQ, allP, stride, info);
+  tr.mark(st, "round_finish");
+  return rc;
 }
 
 int mjpl_rrt_path(mjpl_rrt *r, double *path, int32_t maxlen, int32_t *len) {

@@ -193,6 +193,37 @@ def test_nearest_neighbour_kernel():
         np.testing.assert_array_equal(got3[js], s3.argmin(1))
         np.testing.assert_array_equal(gd3[js], s3.min(1))
     assert got3[700] == 11 and got3[702] == 150000
+    assert e.nearest_last_screen() == 1  # (coordinates of 1e25: not for binary16 operands)
+    # ... and with coordinates of ordinary size the screen runs on the matrix cores (binary16 operands, one
+    # v_mfma per 32 nodes x 32 queries): same winners and distances, bit for bit, among the same near-ties,
+    # duplicates (in one tile, in the two lanes that share a query, across chunks) and the sink node
+    for bad in (6, 200006):
+        nodes3[:, bad] = rng.uniform(-2.9, 2.9, size=7)
+    q3[3, 701] = 0.5
+    nodes3[:, 150004] = nodes3[:, 150000]  # rows 0 and 4 of one tile of eight: the two lanes of a query
+    nodes3[:, 40] = 1e-6 * rng.normal(size=7)  # below binary16's normal range
+    q3[:, 703] = 2e-6 * rng.normal(size=7)
+    dn3.upload(nodes3)
+    dq3.upload(q3)
+    for env_on in (True, False):
+        e.nearest_dev(dn3.ptr, n3, n3, dq3.ptr, M3, di3.ptr, dd3.ptr)
+        got4, gd4 = di3.download(np.int32, M3), dd3.download(np.float64, M3)
+        assert e.nearest_last_screen() == 2
+        for lo in range(0, len(sel), 100):
+            js = sel[lo:lo + 100]
+            s3 = np.zeros((len(js), n3))
+            for c in range(7):
+                d = nodes3[c][None, :] - q3[c][js][:, None]
+                s3 = s3 + d * d
+            np.testing.assert_array_equal(got4[js], s3.argmin(1))
+            np.testing.assert_array_equal(gd4[js], s3.min(1))
+        assert got4[700] == 11 and got4[702] == 150000
+        # queries that are not a multiple of the workgroup's 512, nodes not a multiple of 32
+        n3, M3 = n3 - 13, M3 - 77
+        nodes3 = np.ascontiguousarray(nodes3[:, :n3])
+        q3 = np.ascontiguousarray(q3[:, :M3])
+        sel = sel[sel < M3]
+        dn3, dq3 = e.alloc(nodes3.nbytes).upload(nodes3), e.alloc(q3.nbytes).upload(q3)
 
 
 def test_dropin_constraint_and_planner_equivalence(oracle_mod):
