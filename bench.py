@@ -45,17 +45,33 @@ FP64_VECTOR_PEAK = 78.6e12   # MI355X_MICROARCH.md: FP64 vector 78.6 TFLOP/s (SU
 
 
 class World:
-    """This process's place among the ranks of one node, and -- once attached to an engine -- the
-    RCCL communicator the library opened for it: barrier / gather over mjpl_allgather_dev."""
+    """This process's place among the ranks of one node.  What every workload needs from the other ranks -- a
+    barrier either side of the timed region and the slowest rank's time -- travels over a Unix-domain socket
+    that rank 0 opens (no data-path collective, no GPU runtime involved: BASELINE's north_star shards the
+    edges, and the ranks never exchange any).  The planner workload has one real exchange step per round:
+    for it `attach(eng, rccl=True)` also opens the library's RCCL communicator, whose ncclUniqueId travels
+    over the same socket."""
 
     def __init__(self):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        # MJPL_BENCH_FORCE_DIST=1: open the communicator with one rank too (exercises the path on one GPU)
-        self.distributed = self.world > 1 or os.environ.get("MJPL_BENCH_FORCE_DIST") == "1"
+        self.distributed = self.world > 1
         self.eng = None
-        self.uid = None
+        self.rccl = False
+        self._peers = None   # rank 0: sockets of ranks 1 .. W-1, by rank
+        self._sock = None    # other ranks: the socket to rank 0
+        self._listener = None
+
+    @property
+    def device(self) -> int:
+        """The GPU of this rank: its local rank -- modulo the devices there are when MJPL_BENCH_SHARE_GPU=1
+        (several ranks on one GPU: exercises the launch, the rendezvous and the timing protocol on a
+        one-GPU box; never a measurement)."""
+        if os.environ.get("MJPL_BENCH_SHARE_GPU") == "1":
+            from mjpl_amd import engine
+            return self.local_rank % max(1, engine.device_count())
+        return self.local_rank
 
     def _rendezvous_path(self):
         p = os.environ.get("MJPL_BENCH_RDZV")
@@ -64,71 +80,107 @@ class World:
         # started by torch.distributed.run (or any launcher that sets RANK / WORLD_SIZE): all ranks of one
         # launch share their parent process and the MASTER_PORT, two launches do not
         return os.path.join(os.environ.get("TMPDIR", "/tmp"),
-                            "mjpl_bench_%s_%s_%d.uid" % (os.environ.get("MASTER_PORT", "0"),
-                                                         os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
+                            "mjpl_bench_%s_%s_%d.sock" % (os.environ.get("MASTER_PORT", "0"),
+                                                          os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
 
-    def unique_id(self):
-        """The ncclUniqueId of this launch: rank 0 asks the library for one and publishes it through a
-        file (written aside, then renamed: readers never see half of it); the others wait for it."""
-        if self.uid is not None:
-            return self.uid
-        from mjpl_amd import engine
+    @staticmethod
+    def _recv(sock, n):
+        buf = b""
+        while len(buf) < n:
+            part = sock.recv(n - len(buf))
+            if not part:
+                raise ConnectionError("bench.py: a rank closed the rendezvous socket")
+            buf += part
+        return buf
+
+    def connect(self):
+        """Rank 0 listens, the others connect (retrying until it does) and say who they are."""
+        if not self.distributed or self._peers is not None or self._sock is not None:
+            return
+        import socket
         path = self._rendezvous_path()
         if self.rank == 0:
-            self.uid = engine.comm_unique_id()
-            if self.world > 1:
-                tmp = path + ".%d.tmp" % os.getpid()
-                with open(tmp, "wb") as f:
-                    f.write(self.uid)
-                os.replace(tmp, path)
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+            self._listener = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            self._listener.bind(path)
+            self._listener.listen(self.world)
+            self._listener.settimeout(600)
+            self._peers = {}
+            while len(self._peers) < self.world - 1:
+                c, _ = self._listener.accept()
+                c.settimeout(600)
+                self._peers[int.from_bytes(self._recv(c, 4), "little")] = c
+            try:
+                os.remove(path)  # (everybody is in: the name is not needed any more)
+            except OSError:
+                pass
         else:
             t0 = time.time()
             while True:
+                sk = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
                 try:
-                    with open(path, "rb") as f:
-                        self.uid = f.read()
-                    if len(self.uid) == 128:
-                        break
+                    sk.connect(path)
+                    break
                 except OSError:
-                    pass
-                if time.time() - t0 > 300:
-                    sys.exit(f"bench.py rank {self.rank}: no ncclUniqueId at {path} after 300 s")
-                time.sleep(0.01)
-        return self.uid
+                    sk.close()
+                    if time.time() - t0 > 600:
+                        sys.exit(f"bench.py rank {self.rank}: rank 0 never opened {path}")
+                    time.sleep(0.01)
+            sk.settimeout(600)
+            sk.sendall(self.rank.to_bytes(4, "little"))
+            self._sock = sk
 
-    def attach(self, eng):
-        """Open the communicator on `eng` (collective over all ranks)."""
-        self.eng = eng
+    def exchange(self, payload: bytes) -> list:
+        """All ranks' payloads (equal lengths), in rank order; also a barrier."""
         if not self.distributed:
-            return
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        eng.comm_init(self.unique_id(), self.rank, self.world)
-        self._buf = eng.alloc(8 * self.world)
-        self.gather(0.0)  # first collective: every rank has read the id by now
-        if self.rank == 0 and self.world > 1:
-            try:
-                os.remove(self._rendezvous_path())
-            except OSError:
-                pass
+            return [payload]
+        self.connect()
+        if self.rank == 0:
+            parts = [payload] + [self._recv(self._peers[r], len(payload)) for r in range(1, self.world)]
+            blob = b"".join(parts)
+            for r in range(1, self.world):
+                self._peers[r].sendall(blob)
+            return parts
+        self._sock.sendall(payload)
+        blob = self._recv(self._sock, len(payload) * self.world)
+        return [blob[k * len(payload):(k + 1) * len(payload)] for k in range(self.world)]
+
+    def attach(self, eng, rccl: bool = False):
+        """Meet the other ranks; with rccl=True also open the library's communicator on `eng` (collective)."""
+        self.eng = eng
+        self.connect()
+        if rccl and not self.rccl:
+            from mjpl_amd import engine
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            uid = self.exchange(engine.comm_unique_id() if self.rank == 0 else bytes(128))[0]
+            eng.comm_init(uid, self.rank, self.world)
+            self.rccl = True
+        self.gather(0.0)
 
     def gather(self, x: float) -> np.ndarray:
-        """All ranks' values of x, in rank order (one 8-byte all-gather; also a barrier)."""
-        if not self.distributed:
-            return np.array([float(x)])
-        mine = np.array([float(x)])
-        lib, h = self.eng.lib, self.eng.h
-        self.eng._ok(lib.mjpl_h2d(h, self._buf.ptr + 8 * self.rank, mine.ctypes.data, 8))
-        self.eng.allgather_dev(self._buf.ptr + 8 * self.rank, self._buf.ptr, 8)
-        return self._buf.download(np.float64, self.world)
+        """All ranks' values of x, in rank order (also a barrier)."""
+        return np.array([np.frombuffer(b, dtype=np.float64)[0] for b in self.exchange(np.float64(x).tobytes())])
 
     def barrier(self):
-        self.eng.sync()
+        if self.eng is not None:
+            self.eng.sync()
         self.gather(0.0)
 
     def close(self):
-        if self.distributed and self.eng is not None:
+        if self.eng is not None:
             self.barrier()
-            self.eng.comm_destroy()
+            if self.rccl:
+                self.eng.comm_destroy()
+                self.rccl = False
+        for sk in ([self._sock] if self._sock else []) + list((self._peers or {}).values()) + ([self._listener] if self._listener else []):
+            try:
+                sk.close()
+            except OSError:
+                pass
+        self._sock = self._peers = self._listener = None
 
 
 def spawn_ranks(n: int) -> int:
@@ -136,7 +188,7 @@ def spawn_ranks(n: int) -> int:
     one (which never touches a GPU), wait for them, pass rank 0's JSON line through."""
     import subprocess
     import tempfile
-    rdzv = os.path.join(tempfile.gettempdir(), "mjpl_bench_%d_%d.uid" % (os.getpid(), int(time.time() * 1e3) & 0xFFFFFF))
+    rdzv = os.path.join(tempfile.gettempdir(), "mjpl_bench_%d_%d.sock" % (os.getpid(), int(time.time() * 1e3) & 0xFFFFFF))
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MJPL_BENCH_RDZV=rdzv,
@@ -273,7 +325,7 @@ def bench_configs(args, world):
     model = scenes.franka_p(obstacles=False)
     qidx = scenes.planning_index(model, scenes.FRANKA_ARM_JOINTS)
     base = model.keyframe("home").qpos.copy()
-    eng = engine.Engine(model, device=world.local_rank)
+    eng = engine.Engine(model, device=world.device)
     eng.set_planning(qidx, base)
     world.attach(eng)
     N = 65536
@@ -329,7 +381,7 @@ def bench_next_rows(args, world):
     model = scenes.franka_p(obstacles=True)
     joints = scenes.FRANKA_ARM_JOINTS
     q_home = model.keyframe("home").qpos.copy()
-    cc = mjpl.CollisionConstraint(model, device=world.local_rank)
+    cc = mjpl.CollisionConstraint(model, device=world.device)
     eng = cc.engine
     world.attach(eng)
     lo, hi = model.jnt_range[:, 0], model.jnt_range[:, 1]
@@ -463,19 +515,21 @@ def bench_rrt(args, world):
     joints = scenes.FRANKA_ARM_JOINTS
     qidx = scenes.planning_index(m, joints)
     q_init = m.keyframe("home").qpos.copy()
-    cc = mjpl.CollisionConstraint(m, device=world.local_rank)
+    cc = mjpl.CollisionConstraint(m, device=world.device)
     frame = mjpl.site_pose(m, q_init, "ee_site", engine=cc.engine)
     pc = mjpl.PoseConstraint(m, "ee_site", frame, roll=(-0.1, 0.1), pitch=(-0.1, 0.1), engine=cc.engine)
     cons = [pc, mjpl.JointLimitConstraint(m), cc]
     pc.q_step = np.inf
     q_goal = mjpl.random_config(m, q_init, joints, 7, cons)
     pc.q_step = 0.05
-    world.distributed = True  # (the exchange always runs through a communicator here, one rank included)
+    # (the exchange always runs through a communicator here, one rank included; the id travels over the ranks' socket)
+    from mjpl_amd import engine as _engine
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    uid = world.exchange(_engine.comm_unique_id() if world.rank == 0 else bytes(128))[0]
     dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=3, goal_biasing_probability=0.05,
-                           batch=L, capacity=args.capacity, pose=pc, comm=(world.unique_id(), world.rank, world.world))
-    world.eng = cc.engine
-    world._buf = cc.engine.alloc(8 * world.world)
-    world.gather(0.0)
+                           batch=L, capacity=args.capacity, pose=pc, comm=(uid, world.rank, world.world))
+    world.rccl = True
+    world.attach(cc.engine)
     dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 3)
     info = dev.rrt.round()  # warm-up: the first round grows from two single-node trees
     rows, new_nodes, exch = [], 0, []
@@ -522,7 +576,7 @@ def bench_rrt(args, world):
                                       "one all-gather of headers + two of slabs per round"}}), flush=True)
     world.barrier()
     dev.rrt.close()
-    cc.engine.comm_destroy()
+    world.close()
     return 0
 
 
@@ -548,8 +602,8 @@ def bench_plan(args, world):
                     np.all((P >= model.jnt_range[:, 0] - 1e-12) & (P <= model.jnt_range[:, 1] + 1e-12)) and
                     np.linalg.norm(np.diff(P, axis=0), axis=1).max() <= 0.05 + 1e-9)
 
-    harness.run(planner="device", attempts=1, obstacles=True, device=world.local_rank, quiet=True)  # warm-up
-    res = harness.run(planner="device", attempts=attempts, obstacles=True, device=world.local_rank, quiet=True, check_path=check_path)
+    harness.run(planner="device", attempts=1, obstacles=True, device=world.device, quiet=True)  # warm-up
+    res = harness.run(planner="device", attempts=attempts, obstacles=True, device=world.device, quiet=True, check_path=check_path)
     if world.rank == 0:
         if not res["paths_valid"]:
             sys.exit("bench.py: a planned path fails the oracle's checks")
@@ -563,7 +617,7 @@ def bench_plan(args, world):
                     return q if orc.valid_config(q) else None
 
             k = min(3, attempts)
-            cres = harness.run(planner="rrt", attempts=k, obstacles=True, device=world.local_rank, quiet=True,
+            cres = harness.run(planner="rrt", attempts=k, obstacles=True, device=world.device, quiet=True,
                                collision=OracleCollision(), check_path=check_path)
             cpu = {"value": float(np.median(cres["planning_times"])) if cres["planning_times"] else None,
                    "unit": "s (median planning time)", "cores": 1, "kind": "port",
@@ -645,7 +699,7 @@ def main():
     base = model.keyframe("home").qpos.copy()
 
     def make_engine(filt=True, spec=True):
-        e = engine.Engine(model, device=world.local_rank)
+        e = engine.Engine(model, device=world.device)
         if spec is not True:
             e.set_spec(int(spec))  # (0: interpreter; 2: the robot's scene-generic library)
         e.set_planning(qidx, base)
@@ -733,8 +787,9 @@ def main():
                        "parallelism": f"edge-sharded x{world.world}, no data-path collective",
                        "rank_launcher": ("bench.py (child processes)" if os.environ.get("MJPL_BENCH_RDZV") else
                                          ("external (RANK / WORLD_SIZE)" if world.world > 1 else "single process")),
-                       "collectives": "mjpl_comm_* (RCCL opened by libmjpl_hip.so): barrier + max of the elapsed time only"
-                                      if world.distributed else None},
+                       "collectives": "none on the GPUs: barrier + max of the elapsed time over the ranks' Unix socket"
+                                      if world.distributed else None,
+                       "ranks_share_a_gpu": os.environ.get("MJPL_BENCH_SHARE_GPU") == "1" and world.distributed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": prof.get("hbm_bytes_per_launch"),

@@ -728,33 +728,39 @@ k_nearest_part32(const double *__restrict__ nodes, int64_t n, int64_t cap, const
 }
 
 // ---- the same screen on the matrix cores (large trees and query sets, coordinates of ordinary size) --------------
-// Squared distances expand to |x|^2 - 2 q . x + |q|^2, and the cross terms of 32 nodes x 32 queries are ONE
-// v_mfma_f32_32x32x16_f16: nodes and queries are rounded to binary16 once per call (k_nn_pack), a node's row of
-// the A operand is [x_1 .. x_8 | n_hi, n_lo 2^11, 0 ...] with n = |x~|^2 (the rounded coordinates' squares summed in
-// binary32, split in two binary16 parts -- the second scaled into the normal range), a query's column of B is
-// [-2 q_1 .. -2 q_8 | 1, 2^-11, 0 ...]: the instruction returns t = |x~|^2 - 2 q~ . x~ for 1024 pairs, node on the
-// register index, query on the lane, and a pair passes when t <= T_q = thr - |q~|^2.  Sixteen results per lane are
-// folded with eight v_min3 and compared once; only a wave that sees a pass looks at the sixteen one by one and
-// evaluates the exact float64 distance of those -- k_nearest_part's statements, in scan order with a strict <.
-//   thr >= (R2 + 2 (4 sqrt(NP) e r + 4 NP e^2 + a)) (1 + 1e-6),  e = max(2^-11 X (1 + 2^-10), 2^-14),  a = 2^-17 NP X^2,
+// Squared distances expand to |x|^2 - 2 q . x + |q|^2, and the cross terms of 32 nodes x 32 queries are two chained
+// v_mfma_f32_32x32x16_f16.  Once per call (k_nn_pack) every coordinate v of a node or query is written as
+// v_h + v_l, two binary16 numbers (v_h = v rounded, v_l = the rest rounded: 22 bits of v).  A node's row of the A
+// operand is [x_h (7), n_1 | x_l (7), n_2] with n = |x~|^2, x~ = x_h + x_l, summed in binary32 and split in two
+// binary16 parts; a query has two columns of B: [-2 q_h (7), 1 | -2 q_h (7), 1] and [-2 q_l (7), 0 | -2 q_l (7), 0].
+// The first instruction returns n - 2 q_h . x~, the second adds -2 q_l . x~: t = |x~|^2 - 2 q~ . x~ for 1024 pairs,
+// node on the register index, query on the lane, and a pair passes when t <= T_q = thr - |q~|^2.  Sixteen results
+// per lane are folded with eight v_min3 and compared once; only a wave that sees a pass looks at the sixteen one
+// by one and evaluates the exact float64 distance of those -- k_nearest_part's statements, in scan order with a
+// strict <.
+//   thr >= (R2 + 2 (4 sqrt(NP) e r + 4 NP e^2 + a)) (1 + 1e-6),  e = 1.5 2^-22 X + 2^-24,  a = 2^-16 NP X^2,
 // R2 = min(best exact squared distance so far of this lane, bound2), r = sqrt(R2), X = the largest finite coordinate
-// magnitude among all nodes and queries (k_nn_pack).  (Rounding a coordinate to binary16, through binary32, moves
-// it by at most 2^-11 |v| (1 + 2^-13), or by all of it, < 2^-14, where the matrix core flushes a subnormal: e per
-// column, on either side; so the rounded pair's distance differs from the true one by at most 2 sqrt(NP) e, and a
-// node no farther than r has a rounded squared distance of at most R2 + 4 sqrt(NP) e r + 4 NP e^2.  Arithmetic: the
-// squares are exact in binary32, their sums, the split of n, the ten-term accumulation of the instruction and the
-// subtraction of |q~|^2 lose at most 2^-19 (|x~| + |q~|)^2 <= 2^-17 NP X^2 together.  The factor two and the 1e-6
-// are margin.)  A node at +inf gives +inf or NaN, which v_min3 and the ordered compare ignore: never nearest, as in
-// the other kernels.  Two lanes share a query (rows 4h .. 4h+3 of every eight: h = lane / 32), each keeps its own
-// best; the reduction breaks ties by index.  Coordinates of 256 or more (or NaN) anywhere: k_nn_pack raises a flag,
-// this kernel returns at once and the binary32 screen above does the work.
+// magnitude among all nodes and queries (k_nn_pack).  (v -> binary32 loses 2^-24 |v|; v_h is within 2^-11 |v| of
+// that, v_l within 2^-11 of the rest or 2^-25 where it is subnormal -- the matrix cores keep binary16 subnormals,
+// tools/micro/mfma_f16_denorm.hip --: e per column, on either side; so the represented pair's distance differs from
+// the true one by at most 2 sqrt(NP) e, and a node no farther than r has a represented squared distance of at most
+// R2 + 4 sqrt(NP) e r + 4 NP e^2.  Arithmetic: the products are exact in binary32; the seven-term sums of |x~|^2
+// and |q~|^2, the split of n (2^-22 n), the 32-term accumulation of the two instructions and the subtraction of
+// |q~|^2 lose at most 50 2^-24 (|x~| + |q~|)^2 <= 2^-16 NP X^2 together.  The factor two and the 1e-6 are margin.)
+// With single binary16 coordinates -- one instruction, e = 2^-11 X -- the screen let through every node within
+// 0.02 rad of the bound: a quarter of a tree whose chains all start at one root.  A node at +inf gives +inf or NaN,
+// which v_min3 and the ordered compare ignore: never nearest, as in the other kernels.  Two lanes share a query
+// (rows 4h .. 4h+3 of every eight: h = lane / 32), each keeps its own best; the reduction breaks ties by index.
+// Coordinates of 256 or more (or NaN) anywhere: k_nn_pack raises a flag, this kernel returns at once and the
+// binary32 screen above does the work.  nplan <= 7.
 typedef _Float16 nn_h8 __attribute__((ext_vector_type(8)));
 typedef float nn_f16 __attribute__((ext_vector_type(16)));
 constexpr int kNNMSets = 4, kNNMWaves = 4;              // 32-query sets per wave, waves per workgroup
 constexpr int kNNMQueries = kNNMSets * kNNMWaves * 32;  // 512 queries per workgroup
+constexpr int kNNMMaxPlan = 7;
 constexpr float kNNMWild = 256.0f;
 
-// nodes / queries -> the operand rows (32 bytes each: two 16-byte halves, k = 0..7 | 8..15), |x~|^2, and X
+// nodes / queries -> the operand rows, |x~|^2, and X.  Nodes: 32 bytes (k = 0..7 | 8..15); queries: 64 (two columns).
 __global__ void __launch_bounds__(256)
 k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int64_t padded, int nplan, int is_query,
           uint4 *__restrict__ out16, float *__restrict__ nrm, unsigned *__restrict__ xbits) {
@@ -762,38 +768,49 @@ k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int
   float mx = 0;
   bool wild = false;
   if (i < padded) {
-    union { _Float16 h[16]; uint4 u[2]; } row;
-    for (int k = 0; k < 16; k++) row.h[k] = (_Float16)0.0f;
+    union { _Float16 h[16]; uint4 u[2]; } hi, lo;
+    for (int k = 0; k < 16; k++) { hi.h[k] = (_Float16)0.0f; lo.h[k] = (_Float16)0.0f; }
     float n2 = 0;
     if (i < count) {
       for (int c = 0; c < nplan; c++) {
         const double v = src[(int64_t)c * col_stride + i];
         const float f = (float)v;
-        const _Float16 hv = (_Float16)f;
         if (v != v) wild = true;
         if (fabs(v) < std::numeric_limits<double>::infinity()) {
           if (!(fabs(v) < (double)kNNMWild)) wild = true;
           mx = fmaxf(mx, fminf(fabsf(f), 1e30f));
         }
-        const float hf = (float)hv;
-        n2 = n2 + hf * hf;
-        row.h[c] = is_query ? (_Float16)(-2.0f * hf) : hv;
+        const _Float16 vh = (_Float16)f;
+        const float rest = f - (float)vh;  // exact (or inf - inf: a node that never passes)
+        const _Float16 vl = (_Float16)rest;
+        const float rep = (float)vh + (float)vl;
+        n2 = n2 + rep * rep;
+        if (is_query) {
+          hi.h[c] = hi.h[8 + c] = (_Float16)(-2.0f * (float)vh);
+          lo.h[c] = lo.h[8 + c] = (_Float16)(-2.0f * (float)vl);
+        } else {
+          hi.h[c] = vh;
+          hi.h[8 + c] = vl;
+        }
       }
     } else if (!is_query) {
-      row.h[0] = (_Float16)std::numeric_limits<float>::infinity();  // padding: a node that never passes
+      hi.h[0] = (_Float16)std::numeric_limits<float>::infinity();  // padding: a node that never passes
       n2 = std::numeric_limits<float>::infinity();
     }
     if (is_query) {
-      row.h[8] = (_Float16)1.0f;
-      row.h[9] = (_Float16)0x1p-11f;
+      hi.h[7] = hi.h[15] = (_Float16)1.0f;
+      out16[4 * i] = hi.u[0];
+      out16[4 * i + 1] = hi.u[1];
+      out16[4 * i + 2] = lo.u[0];
+      out16[4 * i + 3] = lo.u[1];
     } else {
-      const _Float16 hi = (_Float16)n2;
-      const float rest = n2 - (float)hi;  // exact; |rest| <= 2^-11 n2
-      row.h[8] = hi;
-      row.h[9] = (n2 < std::numeric_limits<float>::infinity()) ? (_Float16)(rest * 0x1p11f) : (_Float16)0.0f;
+      const _Float16 n1 = (_Float16)n2;
+      const float rest = n2 - (float)n1;  // exact; |rest| <= 2^-11 n2
+      hi.h[7] = n1;
+      hi.h[15] = (n2 < std::numeric_limits<float>::infinity()) ? (_Float16)rest : (_Float16)0.0f;
+      out16[2 * i] = hi.u[0];
+      out16[2 * i + 1] = hi.u[1];
     }
-    out16[2 * i] = row.u[0];
-    out16[2 * i + 1] = row.u[1];
     if (nrm) nrm[i] = n2;
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -815,21 +832,23 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
                const uint4 *__restrict__ nodes16, const uint4 *__restrict__ queries16, const float *__restrict__ qnorm,
                const unsigned *__restrict__ xbits, int64_t chunk, const double *__restrict__ bound2,
                int32_t *__restrict__ pidx, double *__restrict__ pd2) {
+  static_assert(NP <= kNNMMaxPlan, "seven coordinate slots per half of the operand");
   if (xbits[1] != 0u) return;  // wild coordinates: the binary32 screen serves this call
   const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, w = threadIdx.x >> 6;
   const int64_t q0 = ((int64_t)blockIdx.x * kNNMWaves + w) * (kNNMSets * 32) + r;
   const double kInf = std::numeric_limits<double>::infinity();
   const double X = (double)__uint_as_float(xbits[0]);
-  const double e = fmax(X * 0x1p-11 * (1.0 + 0x1p-10), 0x1p-14), a = 0x1p-17 * NP * X * X;
-  nn_h8 b[kNNMSets];
+  const double e = 1.5 * 0x1p-22 * X + 0x1p-24, a = 0x1p-16 * NP * X * X;
+  nn_h8 bh[kNNMSets], bl[kNNMSets];
   float nq[kNNMSets], T[kNNMSets];
   double best[kNNMSets], ref2[kNNMSets];
   int32_t bi[kNNMSets];
 #pragma unroll
   for (int s = 0; s < kNNMSets; s++) {
     const int64_t q = q0 + 32 * s;  // (the packed queries are padded to whole workgroups)
-    const uint4 u = queries16[2 * q + h];
-    __builtin_memcpy(&b[s], &u, 16);
+    const uint4 u = queries16[4 * q + h], v = queries16[4 * q + 2 + h];
+    __builtin_memcpy(&bh[s], &u, 16);
+    __builtin_memcpy(&bl[s], &v, 16);
     nq[s] = qnorm[q];
     best[s] = kInf;
     bi[s] = -1;
@@ -844,20 +863,23 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     nn_h8 av;
     __builtin_memcpy(&av, &ua, 16);
     if (base + 32 < hi) ua = nodes16[2 * (base + 32 + r) + h];  // (the next tile travels during this one's arithmetic)
-    bool hit = false;
+    bool hit[kNNMSets];
+    bool any = false;
 #pragma unroll
     for (int s = 0; s < kNNMSets; s++) {
-      const nn_f16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b[s], zero, 0, 0, 0);
+      const nn_f16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], zero, 0, 0, 0), 0, 0, 0);
       float m = __builtin_fminf(__builtin_fminf(t[0], t[1]), t[2]);
 #pragma unroll
       for (int i = 3; i < 15; i += 2) m = __builtin_fminf(__builtin_fminf(m, t[i]), t[i + 1]);
       m = __builtin_fminf(m, t[15]);
-      hit = hit || (m <= T[s]);
+      hit[s] = m <= T[s];
+      any = any || hit[s];
     }
-    if (__ballot(hit) != 0ull) {
+    if (__ballot(any) != 0ull) {
 #pragma unroll
       for (int s = 0; s < kNNMSets; s++) {
-        const nn_f16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b[s], zero, 0, 0, 0);
+        if (__ballot(hit[s]) == 0ull) continue;
+        const nn_f16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], zero, 0, 0, 0), 0, 0, 0);
         const int64_t q = q0 + 32 * s;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -2710,9 +2732,9 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
       scan64(kSampleNodes, ch0, nc0, stride);
       hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc0, seed_idx, seed_d2,
                          (const int32_t *)nullptr, (const double *)nullptr);
-      // the screened scan on the matrix cores (nplan <= 8), unless some coordinate is too large for binary16 -- which the
+      // the screened scan on the matrix cores (nplan <= 7), unless some coordinate is too large for binary16 -- which the
       // device finds out while it packs the operands: then that kernel returns at once and the binary32 one runs
-      const bool mfma = e->nn_mfma && nplan <= 8;
+      const bool mfma = e->nn_mfma && nplan <= kNNMMaxPlan;
       e->nn_last = mfma ? 2 : 1;
       unsigned *xbits = nullptr;
       int32_t *mp_idx = nullptr;
@@ -2725,7 +2747,7 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
         int64_t chm = ((n + nsplit - 1) / nsplit + 31) / 32 * 32;
         nsplit = (n + chm - 1) / chm;
         mparts = (int)(2 * nsplit);
-        const size_t b_nodes = (size_t)npad * 32, b_q = (size_t)Mpad * 32, b_qn = (size_t)Mpad * sizeof(float);
+        const size_t b_nodes = (size_t)npad * 32, b_q = (size_t)Mpad * 64, b_qn = (size_t)Mpad * sizeof(float);
         const size_t b_pd = (size_t)mparts * (size_t)M * sizeof(double), b_pi = (size_t)mparts * (size_t)M * sizeof(int32_t);
         const size_t need16 = 256 + b_nodes + b_q + b_qn + b_pd + b_pi + 32;
         if (need16 > e->nn16_bytes) {
@@ -2756,7 +2778,7 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
                              (const double *)seed_d2, mp_idx, mp_d2);                                                     \
           break;
         switch (nplan) {
-          MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7) MJPL_NNM_CASE(8)
+          MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7)
         }
 #undef MJPL_NNM_CASE
       }
