@@ -195,8 +195,18 @@ def spawn_ranks(n: int) -> int:
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:  # (a rank that dies must not leave the others waiting at the rendezvous)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = max(rc, abs(code))
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
     try:
         os.remove(rdzv)
     except OSError:
@@ -835,8 +845,15 @@ def main():
                 same = bool(np.array_equal(vv.download(np.uint8, E), valid))
                 if not same:
                     sys.exit(f"bench.py: the {name} engine's verdicts differ from the headline engine's")
+                vinfo = ve.info()
+                vnames = {}
+                if vf and vinfo.get("persistent_kernels"):
+                    vnames.update({"k_filter_endpoints": "k_filter_endpoints_pw", "k_filter_items": "k_filter_items_pw"})
+                if vf and vinfo.get("fused_tail"):
+                    vnames["k_patch_pairs"] = "k_tail"
+                v_stage = {vnames.get(k, k): v for k, v in v_stage.items()}
                 vk = max(v_stage, key=lambda k: v_stage[k])
-                rec = profile_record(vk, E, args.layout, vf, vs and bool(ve.spec_loaded()))
+                rec = profile_record(vk, E, args.layout, vf, ve.spec_kind() if vs else 0)  # (s1: the program's own library, s2: the robot's)
                 variants[name] = {"value": E * vsteps / dt, "unit": "edges/s", "steps": vsteps, "ms_per_step": dt / vsteps * 1e3,
                                   "step_ms_all_kernels": v_launch, "kernels_ms": v_stage, "dtype": "f64" if not vf else "f32-filter+f64-exact",
                                   "float32_filter": bool(ve.info()["filter_enabled"]), "specialised_kernels": bool(ve.spec_loaded()),

@@ -263,7 +263,14 @@ __device__ __forceinline__ int pose_project_lane(const int *__restrict__ pi, con
         double y[6];
         const bool fast = spd6_solve_certified(A, dx, y, kPoseMaxCond);
         if (__ballot(!fast) != 0ull) {
-          if (!fast) pinv_sym6_apply(A, dx, y);
+          if (!fast) {  // (a copy: only this branch needs the matrix in memory, for the call)
+            double Ae[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+              for (int c = 0; c < 6; c++) Ae[r][c] = A[r][c];
+            pinv_sym6_apply(Ae, dx, y);
+          }
         }
         ic = PH_SIZE; jk = 0;
         for (int b = 0; b < pi[PH_NBODY]; b++) {
@@ -865,9 +872,16 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     if (base + 32 < hi) ua = nodes16[2 * (base + 32 + r) + h];  // (the next tile travels during this one's arithmetic)
     bool hit[kNNMSets];
     bool any = false;
+    // (all eight instructions first, four accumulators: the matrix pipe runs back to back while the folds of the
+    //  sets that are through occupy the vector pipe)
+    nn_f16 tt[kNNMSets];
+#pragma unroll
+    for (int s = 0; s < kNNMSets; s++) tt[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], zero, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < kNNMSets; s++) tt[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], tt[s], 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < kNNMSets; s++) {
-      const nn_f16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], zero, 0, 0, 0), 0, 0, 0);
+      const nn_f16 t = tt[s];
       float m = __builtin_fminf(__builtin_fminf(t[0], t[1]), t[2]);
 #pragma unroll
       for (int i = 3; i < 15; i += 2) m = __builtin_fminf(__builtin_fminf(m, t[i]), t[i + 1]);
@@ -879,7 +893,7 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
 #pragma unroll
       for (int s = 0; s < kNNMSets; s++) {
         if (__ballot(hit[s]) == 0ull) continue;
-        const nn_f16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], zero, 0, 0, 0), 0, 0, 0);
+        const nn_f16 t = tt[s];
         const int64_t q = q0 + 32 * s;
 #pragma unroll
         for (int i = 0; i < 16; i++) {

@@ -86,8 +86,10 @@ __device__ __forceinline__ void jacobi_rotate(double (&A)[6][6], double (&V)[6][
   A[P][Q] = 0; A[Q][P] = 0;
 }
 
-// y = pinv(A) x for symmetric A (np.linalg.pinv semantics); A is destroyed.
-__device__ __forceinline__ void pinv_sym6_apply(double (&A)[6][6], const double *x, double *y) {
+// y = pinv(A) x for symmetric A (np.linalg.pinv semantics); A is destroyed.  Not inlined: it is the path of
+// the rare ill-conditioned step, and its 72 doubles of A and V inside the caller cost the common path its
+// registers (k_rrt_gen_project: 328 registers and 272 bytes of scratch with it inlined).
+__device__ __attribute__((noinline)) void pinv_sym6_apply(double (&A)[6][6], const double *x, double *y) {
   double V[6][6];
 #pragma unroll
   for (int i = 0; i < 6; i++)

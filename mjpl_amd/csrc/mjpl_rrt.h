@@ -548,8 +548,8 @@ struct mjpl_rrt {
   int pendcap = 0;
   // projecting extensions: most steps a lane takes per chunk, and the candidate slots a chunk is sized for
   // (S = min(proj_steps_max, proj_slots / active lanes); MJPL_RRT_PROJ_STEPS / MJPL_RRT_PROJ_SLOTS)
-  int proj_steps_max = 32;
-  int64_t proj_slots = 32768;
+  int proj_steps_max = 64;
+  int64_t proj_slots = 65536;
   int *d_ctr = nullptr, *h_ctr = nullptr;
   // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned copies
   int *h_ring = nullptr;      // 4 slots of kRingStride ints: RC_SIZE counters, then the sequence word

@@ -70,3 +70,18 @@ def test_planner_workload_through_a_one_rank_communicator():
     assert res.returncode == 0, res.stderr[-3000:]
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["config"]["nodes"][0] > 1
+
+
+def test_a_failing_rank_ends_the_launch():
+    """Without a GPU every rank fails when it creates its engine ("no CPU fallback"); the launcher must pass that on
+    at once instead of leaving ranks at the rendezvous (here: no GPU in the container; on the GPU box: skipped)."""
+    from mjpl_amd import engine
+    try:
+        if engine.device_count() > 0:
+            pytest.skip("a GPU is present")
+    except Exception:
+        pass
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5"], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0
+    assert "no CPU fallback" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

@@ -3,7 +3,7 @@ written by tools/pmc_summary.py from separate rocprofv3 --pmc passes) into profi
 file bench.py reads `roofline.traffic` and `valu_issue` from.
 Records are keyed by kernel, batch size, layout AND the engine configuration the pass ran under
 (float32 filter on / off, specialised kernels on / off: bench.py --variant).
-usage: python tools/pmc_collect.py <tag> [E] [layout] [filter 0|1] [spec 0|1]"""
+usage: python tools/pmc_collect.py <tag> [E] [layout] [filter 0|1] [spec 0|1|2] [flops tag]"""
 import glob
 import json
 import os
@@ -18,14 +18,18 @@ def main():
     layout = sys.argv[3] if len(sys.argv) > 3 else "soa"
     filt = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     spec = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    flops_tag = sys.argv[6] if len(sys.argv) > 6 else None
     path = os.path.join(ROOT, "profiles", "pmc.json")
     try:
         with open(path) as f:
             out = json.load(f)
     except (OSError, ValueError):
         out = {}
+    edge_kernels = ("k_filter_", "k_tail", "k_check_edges", "k_patch_pairs")  # (the headline workload's; the next rows' are not keyed here)
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_pmc_*.json"))):
         kernel = os.path.basename(p)[len(tag) + 5:-5]
+        if not kernel.startswith(edge_kernels):
+            continue
         with open(p) as f:
             r = json.load(f)
         rec = {k: r[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES",
@@ -38,6 +42,15 @@ def main():
             rec["correction"] = ("gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); "
                                  "FETCH_SIZE and WRITE_SIZE from separate --pmc passes")
         rec["source"] = f"profiles/{os.path.basename(p)} (tools/profile_gpu.sh {tag})"
+        # the kernel's floating-point instruction mix, from its own counter pass (tools/profile_next_rows.sh <flops tag>)
+        fl = os.path.join(ROOT, "profiles", f"{flops_tag}_pmc_flops_{kernel}.json") if flops_tag else None
+        if fl and os.path.exists(fl):
+            with open(fl) as f:
+                fr = json.load(f)
+            for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"):
+                if k in fr:
+                    rec[k] = fr[k]
+            rec["flops_source"] = f"profiles/{os.path.basename(fl)} (tools/profile_next_rows.sh {flops_tag})"
         out[f"{kernel}_{E}_{layout}_f{filt}_s{spec}"] = rec
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

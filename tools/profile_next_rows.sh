@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes for the kernels of the "next" rows: k_pose_apply (bench --workload pose),
-# k_nearest_part32 (--workload rrt), k_ik_solve (--workload ik); kernel-trace stats of each.  Run through gpurun.
+# k_nearest_mfma and k_rrt_gen_project (--workload rrt), k_ik_solve (--workload ik); kernel-trace stats of each.  Run through gpurun.
 # usage: tools/profile_next_rows.sh <tag>  -> gpurun_out/<tag>_pmc_<kernel>.json, gpurun_out/<tag>_<workload>_kernel_stats.csv
 set -u
 TAG=${1:-run}
@@ -19,7 +19,8 @@ for W in "pose:--steps 5 --warmup 1" "rrt:--steps 1" "ik:--steps 2 --warmup 1"; 
 done
 cd $R
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_pose k_pose_apply gpurun_out/${TAG}_pmc_k_pose_apply.json > /dev/null
-python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_nearest_part32 gpurun_out/${TAG}_pmc_k_nearest_part32.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_nearest_mfma gpurun_out/${TAG}_pmc_k_nearest_mfma.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_rrt_gen_project gpurun_out/${TAG}_pmc_k_rrt_gen_project.json > /dev/null
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_ik k_ik_solve gpurun_out/${TAG}_pmc_k_ik_solve.json > /dev/null
 # the float64 edge kernel's issued floating-point instruction mix (bench --variant f64)
 OUT=$R/gpurun_out/prof_${TAG}_f64flops
