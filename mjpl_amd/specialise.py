@@ -555,38 +555,45 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
         o("        const float zd = 0.0f * ux;  // 0, or NaN on a lane that is not to report anything")
         o("        const float acc_a = sc_nplane >= 2 ? zd : cc, acc_b = sc_nplane >= 1 ? zd : cc;  // (the last two rows)")
         o(f"        FP rows = sc + ({SCENE_HEADER} + g * {SCENE_STAGE});")
-        o("        float ra[8], rb[8];")
-        o("#define MJPL_SCENE_LOAD(dst, at) _Pragma(\"unroll\") for (int k_ = 0; k_ < 8; k_++) dst[k_] = rows[4 * (at) + k_]")
-        o("        // (a fetch is waited for behind the arithmetic of the pair before it: scalar loads return out of order, so")
+        # rows per scalar load: two (two buffers of 8 registers); MJPL_GEN_SCENE_WIDE=1: four (2 x 16 registers) -- measured
+        # slower, item pass 0.142 vs 0.137 ms: the kernels sit at the scalar-register limit and spill into vector lanes
+        wide = int(os.environ.get("MJPL_GEN_SCENE_WIDE", "0"))
+        o(f"        float ra[{16 if wide else 8}], rb[{16 if wide else 8}];")
+        o("#define MJPL_SCENE_LOAD(dst, at, n) _Pragma(\"unroll\") for (int k_ = 0; k_ < (n); k_++) dst[k_] = rows[4 * (at) + k_]")
+        o("        // (a fetch is waited for behind the arithmetic of the rows before it: scalar loads return out of order, so")
         o("        //  a wait at its first use -- after the NEXT fetch has gone out -- would drain that one, too; `rows` passes")
         o("        //  through the wait so that the next fetch cannot be moved above it, the scheduling barriers keep fetch,")
         o("        //  arithmetic and wait in this order)")
-        o("#define MJPL_SCENE_WAIT(buf) asm volatile(\"\" : \"+s\"(rows) : \"s\"(buf[0]), \"s\"(buf[7]))")
+        o("#define MJPL_SCENE_WAIT(buf, n) asm volatile(\"\" : \"+s\"(rows) : \"s\"(buf[0]), \"s\"(buf[(n) - 1]))")
         o("#define MJPL_SCENE_PAIR(buf, acca, accb, ka, kb) do { \\")
-        o("          const float t0_ = __builtin_fmaf(cz, buf[2], __builtin_fmaf(cy, buf[1], __builtin_fmaf(ux, buf[0], acca))); \\")
-        o("          const float t1_ = __builtin_fmaf(cz, buf[6], __builtin_fmaf(cy, buf[5], __builtin_fmaf(ux, buf[4], accb))); \\")
-        o("          const unsigned long long m0_ = __builtin_amdgcn_ballot_w64(t0_ <= buf[3]); \\")
-        o("          const unsigned long long m1_ = __builtin_amdgcn_ballot_w64(t1_ <= buf[7]); \\")
+        o("          const float t0_ = __builtin_fmaf(cz, (buf)[2], __builtin_fmaf(cy, (buf)[1], __builtin_fmaf(ux, (buf)[0], acca))); \\")
+        o("          const float t1_ = __builtin_fmaf(cz, (buf)[6], __builtin_fmaf(cy, (buf)[5], __builtin_fmaf(ux, (buf)[4], accb))); \\")
+        o("          const unsigned long long m0_ = __builtin_amdgcn_ballot_w64(t0_ <= (buf)[3]); \\")
+        o("          const unsigned long long m1_ = __builtin_amdgcn_ballot_w64(t1_ <= (buf)[7]); \\")
         o("          mjpl::park_mask2<ka, kb>(mlo, mhi, m0_, m1_); } while (0)")
         o("        // (one copy of the line per entry point: falling through case labels, the buffers would arrive at every")
-        o("        //  label from two places and the compiler would copy eight registers there)")
+        o("        //  label from two places and the compiler would copy the registers there)")
         o("        switch (sc_first) {")
-        npair = SCENE_ROWS // 2
         for first in range(0, SCENE_ROWS, 2):
             o(f"          {'default' if first == SCENE_ROWS - 2 else f'case {first}'}: {{")
-            o(f"        MJPL_SCENE_LOAD(ra, {first});")
-            for pr in range(first // 2, npair):
-                k = pr - first // 2
+            # the rows from `first` on, in fetches of four (a leading pair where `first` is not a multiple of four) or of two
+            chunks = []
+            r = first
+            while r < SCENE_ROWS:
+                nr = 4 if (wide and r % 4 == 0) else 2
+                chunks.append((r, nr))
+                r += nr
+            o(f"        MJPL_SCENE_LOAD(ra, {chunks[0][0]}, {4 * chunks[0][1]});")
+            for k, (r, nr) in enumerate(chunks):
                 cur, nxt = ("ra", "rb") if k % 2 == 0 else ("rb", "ra")
-                o(f"        MJPL_SCENE_WAIT({cur});")
+                o(f"        MJPL_SCENE_WAIT({cur}, {4 * nr});")
                 o("        __builtin_amdgcn_sched_barrier(0);")
-                if pr + 1 < npair:
-                    o(f"        MJPL_SCENE_LOAD({nxt}, {2 * (pr + 1)});")
+                if k + 1 < len(chunks):
+                    o(f"        MJPL_SCENE_LOAD({nxt}, {chunks[k + 1][0]}, {4 * chunks[k + 1][1]});")
                 o("        __builtin_amdgcn_sched_barrier(0);")
-                if pr == npair - 1:
-                    o(f"        MJPL_SCENE_PAIR({cur}, acc_a, acc_b, {2 * pr}, {2 * pr + 1});")
-                else:
-                    o(f"        MJPL_SCENE_PAIR({cur}, cc, cc, {2 * pr}, {2 * pr + 1});")
+                for j in range(0, nr, 2):
+                    last = r + j == SCENE_ROWS - 2
+                    o(f"        MJPL_SCENE_PAIR({cur} + {4 * j}, {'acc_a' if last else 'cc'}, {'acc_b' if last else 'cc'}, {r + j}, {r + j + 1});")
                 o("        __builtin_amdgcn_sched_barrier(0);")
             o("          } break;")
         o("        }")

@@ -223,7 +223,7 @@ def test_robot_hash_and_scene_generic_generation():
     assert specialise.dump_program(scenes.franka_p_scene(16, 16, 9), (), arm, base)[3].scene_ok == 0  # 34 static geoms
     ip, fp, dp, info = next(iter(programs.values()))
     src = specialise.generate(ip, fp, dp, info, generic=True)
-    assert "MJPL_SPEC_CULLX" not in src.split("struct Spec")[1] and "MJPL_SCENE_PAIR(ra, cc, cc, 0, 1)" in src and "acc_a, acc_b, 30, 31)" in src
+    assert "MJPL_SPEC_CULLX" not in src.split("struct Spec")[1] and "MJPL_SCENE_PAIR(ra + 0, cc, cc, 0, 1)" in src and "acc_a, acc_b, 30, 31)" in src
     assert src.count("MJPL_SPEC_SLOTCULL(") == 33 + 1  # Franka-P's 33 self pairs (and the macro itself), in either kind of library
     srcs = {specialise.generate(*p, generic=True) for p in programs.values()}
     assert len({s.split("program hash")[1].split("\n", 1)[1] for s in srcs}) == 1, "generic code must not depend on the scene"
