@@ -582,6 +582,8 @@ def bench_rrt(args, world):
                        "nodes": [int(info.nodes[0]), int(info.nodes[1])], "connected": bool(info.connected),
                        "connecting_rank": int(info.conn_rank) if info.connected else None,
                        "path_checked_against_oracle": path_ok,
+                       "nearest_neighbour_screen": {0: "none", 1: "binary32 (vector units)", 2: "binary16 x 2 (matrix cores)"}.get(
+                           cc.engine.nearest_last_screen(), "?"),
                        "parallelism": f"frontier-sharded x{world.world}: every rank samples and extends its own lanes, "
                                       "one all-gather of headers + two of slabs per round"}}), flush=True)
     world.barrier()

@@ -27,6 +27,7 @@
 #include "mjpl_device.h"
 #include "mjpl_filter.h"
 #include "mjpl_pose.h"
+#include "mjpl_nearest.h"
 
 namespace {
 
@@ -145,41 +146,6 @@ k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ g
   edge_body<float, MAXS, WBOX, MBOX>(gip, nip, gfp, nfp, QA, QB, E, step, layout, flags, tol, valid,
                                      first_bad, status, ulist, ucount, rlist, rcount, uc);
 }
-
-// Tree.nearest_neighbor (planning/tree.py:57-66) for a batch of queries: squared Euclidean
-// distance in float64, node tiles staged through LDS, ties to the lowest node index.
-__global__ void __launch_bounds__(kBlock)
-k_nearest(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
-          int64_t M, int nplan, int32_t *__restrict__ out_idx, double *__restrict__ out_d2) {
-  extern __shared__ double smem[];
-  const int B = blockDim.x;
-  double *qs = smem;                       // [nplan][B] this block's queries
-  double *tile = smem + (size_t)nplan * B; // [nplan][B] node tile
-  const int64_t j = (int64_t)blockIdx.x * B + threadIdx.x;
-  for (int c = 0; c < nplan; c++) qs[c * B + threadIdx.x] = (j < M) ? queries[(int64_t)c * M + j] : 0.0;
-  double best = std::numeric_limits<double>::infinity();
-  int32_t besti = -1;
-  for (int64_t base = 0; base < n; base += B) {
-    __syncthreads();
-    const int64_t src = base + threadIdx.x;
-    for (int c = 0; c < nplan; c++) tile[c * B + threadIdx.x] = (src < n) ? nodes[(int64_t)c * cap + src] : 0.0;
-    __syncthreads();
-    const int lim = (int)((n - base) < B ? (n - base) : B);
-    for (int t = 0; t < lim; t++) {
-      double s = 0;
-      for (int c = 0; c < nplan; c++) {
-        double d = tile[c * B + t] - qs[c * B + threadIdx.x];
-        s = s + d * d;
-      }
-      if (s < best) { best = s; besti = (int32_t)(base + t); }
-    }
-  }
-  if (j < M) {
-    out_idx[j] = besti;
-    if (out_d2) out_d2[j] = best;
-  }
-}
-
 
 // ---- row f1: batched PoseConstraint (pose_constraint.py:72-171), one lane per configuration ----
 // LDS per lane: the working qpos [nq] and a [6][njoint] store that holds the chain joints'
@@ -523,449 +489,6 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
   }
 }
 
-
-// Partial nearest neighbour: block (x, y) scans node chunk y for 512 queries (four per thread, held
-// in registers; node tiles are staged through LDS and read as broadcasts: 84 float64 operations
-// per 7 LDS reads for a 7-joint arm).  Distances are the same sequential-sum squared norms as on
-// the host (s = s + d * d, the product rounded on its own: numpy's norm of a row); ties go to the
-// lowest node index (strict `<`, chunks reduced in order).  NP: the number of planning columns
-// when it is one of the instantiated ones (registers and loops sized for it), 0 = any up to 16.
-constexpr int kNNThreads = 128, kNNMaxPlan = 16, kNNQueries = 4;
-
-template <int NP>
-__global__ void __launch_bounds__(kNNThreads)
-k_nearest_part(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
-               int64_t M, int nplan_rt, int64_t chunk, int32_t *__restrict__ pidx, double *__restrict__ pd2,
-               int64_t stride = 1) {  // (stride > 1: every stride-th node only -- a sample; indices are sample indices)
-  constexpr int W = NP ? NP : kNNMaxPlan;
-  const int nplan = NP ? NP : nplan_rt;
-  __shared__ double tile[W * kNNThreads];
-  const int t = threadIdx.x;
-  const int64_t j0 = (int64_t)blockIdx.x * (kNNQueries * kNNThreads) + t;
-  double q[kNNQueries][W];
-#pragma unroll
-  for (int a = 0; a < kNNQueries; a++)
-#pragma unroll
-    for (int c = 0; c < W; c++) {
-      const int64_t j = j0 + (int64_t)a * kNNThreads;
-      q[a][c] = (c < nplan && j < M) ? queries[(int64_t)c * M + j] : 0.0;
-    }
-  const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-  double best[kNNQueries];
-  int32_t bi[kNNQueries];
-#pragma unroll
-  for (int a = 0; a < kNNQueries; a++) { best[a] = std::numeric_limits<double>::infinity(); bi[a] = -1; }
-  for (int64_t base = lo; base < hi; base += kNNThreads) {
-    __syncthreads();
-    const int64_t src = base + t;
-    for (int c = 0; c < nplan; c++) tile[c * kNNThreads + t] = (src < hi) ? nodes[(int64_t)c * cap + src * stride] : 0.0;
-    __syncthreads();
-    const int lim = (int)((hi - base) < kNNThreads ? (hi - base) : kNNThreads);
-    for (int k = 0; k < lim; k++) {
-      double s[kNNQueries];
-#pragma unroll
-      for (int a = 0; a < kNNQueries; a++) s[a] = 0;
-#pragma unroll
-      for (int c = 0; c < W; c++) {
-        if (NP || c < nplan) {
-          const double v = tile[c * kNNThreads + k];
-#pragma unroll
-          for (int a = 0; a < kNNQueries; a++) {
-            const double d = v - q[a][c];
-            s[a] = s[a] + d * d;
-          }
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < kNNQueries; a++)
-        if (s[a] < best[a]) { best[a] = s[a]; bi[a] = (int32_t)(base + k); }
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < kNNQueries; a++) {
-    const int64_t j = j0 + (int64_t)a * kNNThreads;
-    if (j < M) { pidx[(int64_t)blockIdx.y * M + j] = bi[a]; pd2[(int64_t)blockIdx.y * M + j] = best[a]; }
-  }
-}
-
-// The same partial scan with a binary32 screen in front of the float64 arithmetic (large trees and
-// query sets): eight queries per lane held as packed float pairs, the node tile as floats; a node's
-// exact float64 squared distance -- the statements of k_nearest_part, so the same value and the same
-// winner -- is evaluated only when its binary32 estimate does not rule it out:
-//   s32 <= thr,   thr >= (R2 + 2 (2 sqrt(NP) e r + NP e^2)) (1 + 1e-6),   e = 2^-22 X,
-// with R2 = min(best exact squared distance so far in this chunk, bound2), r = sqrt(R2), bound2 = the
-// exact squared distance from the query to SOME node of the tree (found beforehand over a strided
-// sample: the answer is never farther), and X the largest coordinate magnitude among this tile's
-// nodes and the query.  (Rounding node and query to binary32 and their difference: |error| <= e per
-// column; over the NP columns that moves the squared distance of a node no farther than r by at most
-// 2 sqrt(NP) e r + NP e^2; NP fused multiply-adds lose at most NP 2^-24 of it.  The factor two and
-// the 1e-6 are margin.)  A node farther than r cannot be the answer; one at most that far always
-// passes the screen and is then compared exactly, in scan order with a strict <, so ties still go to
-// the lowest index.  The sample keeps the screen tight from the first node on: without it a tree
-// whose later nodes lie closer to the query (chains growing towards it) improves the running best
-// at nearly every step, and every improvement is an exact evaluation.
-constexpr int kNN32Queries = 8;
-
-template <int NP>
-__global__ void __launch_bounds__(kNNThreads, 4)  // (left alone the compiler prefetches tiles into 256 registers)
-k_nearest_part32(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
-                 int64_t M, int64_t chunk, const double *__restrict__ bound2, int32_t *__restrict__ pidx,
-                 double *__restrict__ pd2, const unsigned *__restrict__ only_if_wild = nullptr) {
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  if (only_if_wild && only_if_wild[1] == 0u) return;  // (the matrix-core screen below serves this call)
-  __shared__ float tile[NP * kNNThreads];
-  __shared__ float wmax[kNNThreads / 64];
-  const int t = threadIdx.x;
-  const int64_t j0 = (int64_t)blockIdx.x * (kNN32Queries * kNNThreads) + t;
-  auto qindex = [&](int a) -> int64_t { return j0 + (int64_t)a * kNNThreads; };
-  v2f q[kNN32Queries / 2][NP];
-  float qmax[kNN32Queries];
-#pragma unroll
-  for (int a = 0; a < kNN32Queries; a++) {
-    float m = 0;
-#pragma unroll
-    for (int c = 0; c < NP; c++) {
-      const double v = qindex(a) < M ? queries[(int64_t)c * M + qindex(a)] : 0.0;
-      const float f = (float)v;
-      if (a & 1) q[a / 2][c].y = f; else q[a / 2][c].x = f;
-      m = fmaxf(m, fminf(fabsf(f), 1e30f));
-    }
-    qmax[a] = m;
-  }
-  const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-  const double kInf = std::numeric_limits<double>::infinity();
-  double best[kNN32Queries], ref2[kNN32Queries], ref[kNN32Queries];  // ref2 = min(best, bound2), ref = sqrt(ref2)
-  int32_t bi[kNN32Queries];
-  float thr[kNN32Queries];
-#pragma unroll
-  for (int a = 0; a < kNN32Queries; a++) {
-    best[a] = kInf;
-    ref2[a] = (bound2 && qindex(a) < M) ? bound2[qindex(a)] : kInf;
-    ref[a] = ref2[a] < kInf ? sqrt(ref2[a]) : kInf;
-    bi[a] = -1;
-    thr[a] = std::numeric_limits<float>::infinity();
-  }
-  for (int64_t base = lo; base < hi; base += kNNThreads) {
-    __syncthreads();
-    const int64_t src = base + t;
-    float mine = 0;
-#pragma unroll
-    for (int c = 0; c < NP; c++) {
-      const double dv = (src < hi) ? nodes[(int64_t)c * cap + src] : kInf;
-      const float f = (float)dv;
-      tile[c * kNNThreads + t] = f;
-      // (an infinite node never wins: no part in X; a finite one beyond binary32's range makes the tile "wild")
-      if (fabs(dv) < kInf) mine = fmaxf(mine, fminf(fabsf(f), 1e30f));
-    }
-    for (int o = 32; o > 0; o >>= 1) mine = fmaxf(mine, __shfl_xor(mine, o));
-    if ((t & 63) == 0) wmax[t >> 6] = mine;
-    __syncthreads();
-    float tmax = wmax[0];
-#pragma unroll
-    for (int w = 1; w < kNNThreads / 64; w++) tmax = fmaxf(tmax, wmax[w]);
-    // this tile's thresholds
-#pragma unroll
-    for (int a = 0; a < kNN32Queries; a++) {
-      if (!(fmaxf(tmax, qmax[a]) < 1e18f)) {
-        thr[a] = std::numeric_limits<float>::infinity();  // squares would overflow binary32: no screen here
-      } else if (ref2[a] < kInf) {
-        const double X = (double)fmaxf(tmax, qmax[a]) * (1.0 + 1e-6);
-        const double e = X * 0x1p-22;
-        const double slack = 2.0 * (2.0 * sqrt((double)NP) * e * ref[a] + NP * e * e);
-        const double th = (ref2[a] + slack) * (1.0 + 1e-6);
-        float f = (float)th;
-        if ((double)f < th) f = __int_as_float(__float_as_int(f) + 1);  // (th >= 0: the next float up)
-        thr[a] = f;
-      }
-    }
-    const int lim = (int)((hi - base) < kNNThreads ? (hi - base) : kNNThreads);
-    for (int k = 0; k < lim; k++) {
-      v2f s[kNN32Queries / 2];
-#pragma unroll
-      for (int p2 = 0; p2 < kNN32Queries / 2; p2++) s[p2] = (v2f){0.0f, 0.0f};
-#pragma unroll
-      for (int c = 0; c < NP; c++) {
-        const float v = tile[c * kNNThreads + k];
-        const v2f vv = (v2f){v, v};
-#pragma unroll
-        for (int p2 = 0; p2 < kNN32Queries / 2; p2++) {
-          const v2f d = vv - q[p2][c];
-          s[p2] = __builtin_elementwise_fma(d, d, s[p2]);
-        }
-      }
-      bool hit = false;
-#pragma unroll
-      for (int p2 = 0; p2 < kNN32Queries / 2; p2++) hit = hit || (s[p2].x <= thr[2 * p2]) || (s[p2].y <= thr[2 * p2 + 1]);
-      if (__ballot(hit) != 0ull) {
-        if (hit) {
-          const int64_t node = base + k;
-#pragma unroll
-          for (int a = 0; a < kNN32Queries; a++) {
-            const float sa = (a & 1) ? s[a / 2].y : s[a / 2].x;
-            if (sa <= thr[a] && qindex(a) < M) {
-              double ex = 0;
-#pragma unroll
-              for (int c = 0; c < NP; c++) {
-                const double d = nodes[(int64_t)c * cap + node] - queries[(int64_t)c * M + qindex(a)];
-                ex = ex + d * d;
-              }
-              if (ex < best[a]) {
-                best[a] = ex;
-                bi[a] = (int32_t)node;
-                if (ex < ref2[a]) { ref2[a] = ex; ref[a] = sqrt(ex); }
-                const double X = (double)fmaxf(tmax, qmax[a]) * (1.0 + 1e-6);
-                const double e = X * 0x1p-22;
-                const double th = (ref2[a] + 2.0 * (2.0 * sqrt((double)NP) * e * ref[a] + NP * e * e)) * (1.0 + 1e-6);
-                float f = (float)th;
-                if ((double)f < th) f = __int_as_float(__float_as_int(f) + 1);  // (th >= 0: the next float up)
-                thr[a] = (fmaxf(tmax, qmax[a]) < 1e18f) ? f : std::numeric_limits<float>::infinity();
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < kNN32Queries; a++)
-    if (qindex(a) < M) {
-      pidx[(int64_t)blockIdx.y * M + qindex(a)] = bi[a];
-      pd2[(int64_t)blockIdx.y * M + qindex(a)] = best[a];  // (+inf, -1: nothing within the bound in this chunk)
-    }
-}
-
-// ---- the same screen on the matrix cores (large trees and query sets, coordinates of ordinary size) --------------
-// Squared distances expand to |x|^2 - 2 q . x + |q|^2, and the cross terms of 32 nodes x 32 queries are two chained
-// v_mfma_f32_32x32x16_f16.  Once per call (k_nn_pack) every coordinate v of a node or query is written as
-// v_h + v_l, two binary16 numbers (v_h = v rounded, v_l = the rest rounded: 22 bits of v).  A node's row of the A
-// operand is [x_h (7), n_1 | x_l (7), n_2] with n = |x~|^2, x~ = x_h + x_l, summed in binary32 and split in two
-// binary16 parts; a query has two columns of B: [-2 q_h (7), 1 | -2 q_h (7), 1] and [-2 q_l (7), 0 | -2 q_l (7), 0].
-// The first instruction returns n - 2 q_h . x~, the second adds -2 q_l . x~: t = |x~|^2 - 2 q~ . x~ for 1024 pairs,
-// node on the register index, query on the lane, and a pair passes when t <= T_q = thr - |q~|^2.  Sixteen results
-// per lane are folded with eight v_min3 and compared once; only a wave that sees a pass looks at the sixteen one
-// by one and evaluates the exact float64 distance of those -- k_nearest_part's statements, in scan order with a
-// strict <.
-//   thr >= (R2 + 2 (4 sqrt(NP) e r + 4 NP e^2 + a)) (1 + 1e-6),  e = 1.5 2^-22 X + 2^-24,  a = 2^-16 NP X^2,
-// R2 = min(best exact squared distance so far of this lane, bound2), r = sqrt(R2), X = the largest finite coordinate
-// magnitude among all nodes and queries (k_nn_pack).  (v -> binary32 loses 2^-24 |v|; v_h is within 2^-11 |v| of
-// that, v_l within 2^-11 of the rest or 2^-25 where it is subnormal -- the matrix cores keep binary16 subnormals,
-// tools/micro/mfma_f16_denorm.hip --: e per column, on either side; so the represented pair's distance differs from
-// the true one by at most 2 sqrt(NP) e, and a node no farther than r has a represented squared distance of at most
-// R2 + 4 sqrt(NP) e r + 4 NP e^2.  Arithmetic: the products are exact in binary32; the seven-term sums of |x~|^2
-// and |q~|^2, the split of n (2^-22 n), the 32-term accumulation of the two instructions and the subtraction of
-// |q~|^2 lose at most 50 2^-24 (|x~| + |q~|)^2 <= 2^-16 NP X^2 together.  The factor two and the 1e-6 are margin.)
-// With single binary16 coordinates -- one instruction, e = 2^-11 X -- the screen let through every node within
-// 0.02 rad of the bound: a quarter of a tree whose chains all start at one root.  A node at +inf gives +inf or NaN,
-// which v_min3 and the ordered compare ignore: never nearest, as in the other kernels.  Two lanes share a query
-// (rows 4h .. 4h+3 of every eight: h = lane / 32), each keeps its own best; the reduction breaks ties by index.
-// Coordinates of 256 or more (or NaN) anywhere: k_nn_pack raises a flag, this kernel returns at once and the
-// binary32 screen above does the work.  nplan <= 7.
-typedef _Float16 nn_h8 __attribute__((ext_vector_type(8)));
-typedef float nn_f16 __attribute__((ext_vector_type(16)));
-constexpr int kNNMSets = 4, kNNMWaves = 4;              // 32-query sets per wave, waves per workgroup
-constexpr int kNNMQueries = kNNMSets * kNNMWaves * 32;  // 512 queries per workgroup
-constexpr int kNNMMaxPlan = 7;
-constexpr float kNNMWild = 256.0f;
-
-// nodes / queries -> the operand rows, |x~|^2, and X.  Nodes: 32 bytes (k = 0..7 | 8..15); queries: 64 (two columns).
-__global__ void __launch_bounds__(256)
-k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int64_t padded, int nplan, int is_query,
-          uint4 *__restrict__ out16, float *__restrict__ nrm, unsigned *__restrict__ xbits) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float mx = 0;
-  bool wild = false;
-  if (i < padded) {
-    union { _Float16 h[16]; uint4 u[2]; } hi, lo;
-    for (int k = 0; k < 16; k++) { hi.h[k] = (_Float16)0.0f; lo.h[k] = (_Float16)0.0f; }
-    float n2 = 0;
-    if (i < count) {
-      for (int c = 0; c < nplan; c++) {
-        const double v = src[(int64_t)c * col_stride + i];
-        const float f = (float)v;
-        if (v != v) wild = true;
-        if (fabs(v) < std::numeric_limits<double>::infinity()) {
-          if (!(fabs(v) < (double)kNNMWild)) wild = true;
-          mx = fmaxf(mx, fminf(fabsf(f), 1e30f));
-        }
-        const _Float16 vh = (_Float16)f;
-        const float rest = f - (float)vh;  // exact (or inf - inf: a node that never passes)
-        const _Float16 vl = (_Float16)rest;
-        const float rep = (float)vh + (float)vl;
-        n2 = n2 + rep * rep;
-        if (is_query) {
-          hi.h[c] = hi.h[8 + c] = (_Float16)(-2.0f * (float)vh);
-          lo.h[c] = lo.h[8 + c] = (_Float16)(-2.0f * (float)vl);
-        } else {
-          hi.h[c] = vh;
-          hi.h[8 + c] = vl;
-        }
-      }
-    } else if (!is_query) {
-      hi.h[0] = (_Float16)std::numeric_limits<float>::infinity();  // padding: a node that never passes
-      n2 = std::numeric_limits<float>::infinity();
-    }
-    if (is_query) {
-      hi.h[7] = hi.h[15] = (_Float16)1.0f;
-      out16[4 * i] = hi.u[0];
-      out16[4 * i + 1] = hi.u[1];
-      out16[4 * i + 2] = lo.u[0];
-      out16[4 * i + 3] = lo.u[1];
-    } else {
-      const _Float16 n1 = (_Float16)n2;
-      const float rest = n2 - (float)n1;  // exact; |rest| <= 2^-11 n2
-      hi.h[7] = n1;
-      hi.h[15] = (n2 < std::numeric_limits<float>::infinity()) ? (_Float16)rest : (_Float16)0.0f;
-      out16[2 * i] = hi.u[0];
-      out16[2 * i + 1] = hi.u[1];
-    }
-    if (nrm) nrm[i] = n2;
-  }
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(&xbits[0], __float_as_uint(mx));
-  if (__ballot(wild) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&xbits[1], 1u);
-}
-
-template <int NP>
-__device__ __forceinline__ float nn_mfma_threshold(double ref2, double ref, double e, double a, float nq) {
-  const double th = (ref2 + 2.0 * (4.0 * sqrt((double)NP) * e * ref + 4.0 * NP * e * e + a)) * (1.0 + 1e-6) - (double)nq;
-  float f = (float)th;
-  if ((double)f < th) f = nextafterf(f, std::numeric_limits<float>::infinity());
-  return f;
-}
-
-template <int NP>
-__global__ void __launch_bounds__(kNNMWaves * 64, 2)
-k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries, int64_t M,
-               const uint4 *__restrict__ nodes16, const uint4 *__restrict__ queries16, const float *__restrict__ qnorm,
-               const unsigned *__restrict__ xbits, int64_t chunk, const double *__restrict__ bound2,
-               int32_t *__restrict__ pidx, double *__restrict__ pd2) {
-  static_assert(NP <= kNNMMaxPlan, "seven coordinate slots per half of the operand");
-  if (xbits[1] != 0u) return;  // wild coordinates: the binary32 screen serves this call
-  const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, w = threadIdx.x >> 6;
-  const int64_t q0 = ((int64_t)blockIdx.x * kNNMWaves + w) * (kNNMSets * 32) + r;
-  const double kInf = std::numeric_limits<double>::infinity();
-  const double X = (double)__uint_as_float(xbits[0]);
-  const double e = 1.5 * 0x1p-22 * X + 0x1p-24, a = 0x1p-16 * NP * X * X;
-  nn_h8 bh[kNNMSets], bl[kNNMSets];
-  float nq[kNNMSets], T[kNNMSets];
-  double best[kNNMSets], ref2[kNNMSets];
-  int32_t bi[kNNMSets];
-#pragma unroll
-  for (int s = 0; s < kNNMSets; s++) {
-    const int64_t q = q0 + 32 * s;  // (the packed queries are padded to whole workgroups)
-    const uint4 u = queries16[4 * q + h], v = queries16[4 * q + 2 + h];
-    __builtin_memcpy(&bh[s], &u, 16);
-    __builtin_memcpy(&bl[s], &v, 16);
-    nq[s] = qnorm[q];
-    best[s] = kInf;
-    bi[s] = -1;
-    ref2[s] = (q < M) ? bound2[q] : 0.0;
-    T[s] = ref2[s] < kInf ? nn_mfma_threshold<NP>(ref2[s], sqrt(ref2[s]), e, a, nq[s]) : std::numeric_limits<float>::infinity();
-    if (q >= M) T[s] = -std::numeric_limits<float>::infinity();
-  }
-  const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-  const nn_f16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint4 ua = (lo < hi) ? nodes16[2 * (lo + r) + h] : uint4{0, 0, 0, 0};
-  for (int64_t base = lo; base < hi; base += 32) {
-    nn_h8 av;
-    __builtin_memcpy(&av, &ua, 16);
-    if (base + 32 < hi) ua = nodes16[2 * (base + 32 + r) + h];  // (the next tile travels during this one's arithmetic)
-    bool hit[kNNMSets];
-    bool any = false;
-    // (all eight instructions first, four accumulators: the matrix pipe runs back to back while the folds of the
-    //  sets that are through occupy the vector pipe)
-    nn_f16 tt[kNNMSets];
-#pragma unroll
-    for (int s = 0; s < kNNMSets; s++) tt[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], zero, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < kNNMSets; s++) tt[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], tt[s], 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < kNNMSets; s++) {
-      const nn_f16 t = tt[s];
-      float m = __builtin_fminf(__builtin_fminf(t[0], t[1]), t[2]);
-#pragma unroll
-      for (int i = 3; i < 15; i += 2) m = __builtin_fminf(__builtin_fminf(m, t[i]), t[i + 1]);
-      m = __builtin_fminf(m, t[15]);
-      hit[s] = m <= T[s];
-      any = any || hit[s];
-    }
-    if (__ballot(any) != 0ull) {
-#pragma unroll
-      for (int s = 0; s < kNNMSets; s++) {
-        if (__ballot(hit[s]) == 0ull) continue;
-        const nn_f16 t = tt[s];
-        const int64_t q = q0 + 32 * s;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          if (t[i] <= T[s]) {
-            const int64_t node = base + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (node < hi) {
-              double ex = 0;
-#pragma unroll
-              for (int c = 0; c < NP; c++) {
-                const double d = nodes[(int64_t)c * cap + node] - queries[(int64_t)c * M + q];
-                ex = ex + d * d;
-              }
-              if (ex < best[s]) {
-                best[s] = ex;
-                bi[s] = (int32_t)node;
-                if (ex < ref2[s]) {
-                  ref2[s] = ex;
-                  T[s] = nn_mfma_threshold<NP>(ex, sqrt(ex), e, a, nq[s]);
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < kNNMSets; s++) {
-    const int64_t q = q0 + 32 * s;
-    if (q < M) {
-      const int64_t at = ((int64_t)blockIdx.y * 2 + h) * M + q;
-      pidx[at] = bi[s];
-      pd2[at] = best[s];  // (+inf, -1: nothing within the bound among this lane's rows)
-    }
-  }
-}
-
-// (partial results that are not in index order -- the two lanes of a query above: equal distances go to the lower index)
-__global__ void __launch_bounds__(kBlock)
-k_nearest_reduce_ties(const int32_t *__restrict__ pidx, const double *__restrict__ pd2, int64_t M, int nparts,
-                      int32_t *__restrict__ out_idx, double *__restrict__ out_d2, const unsigned *__restrict__ xbits,
-                      const int32_t *__restrict__ wild_pidx, const double *__restrict__ wild_pd2, int wild_nparts) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= M) return;
-  if (xbits[1] != 0u) { pidx = wild_pidx; pd2 = wild_pd2; nparts = wild_nparts; }  // (the binary32 screen did the work)
-  double best = std::numeric_limits<double>::infinity();
-  int32_t bi = -1;
-  for (int y = 0; y < nparts; y++) {
-    const double d = pd2[(int64_t)y * M + j];
-    const int32_t k = pidx[(int64_t)y * M + j];
-    if (k >= 0 && (d < best || (d == best && (bi < 0 || k < bi)))) { best = d; bi = k; }
-  }
-  out_idx[j] = bi;
-  if (out_d2) out_d2[j] = best;
-}
-
-__global__ void __launch_bounds__(kBlock)
-k_nearest_reduce(const int32_t *__restrict__ pidx, const double *__restrict__ pd2, int64_t M, int nchunks,
-                 int32_t *__restrict__ out_idx, double *__restrict__ out_d2,
-                 const int32_t *__restrict__ seed_idx = nullptr, const double *__restrict__ seed_d2 = nullptr) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= M) return;
-  // (seed: the result over the nodes below the chunks' range -- lower indices, so it goes first)
-  double best = seed_d2 ? seed_d2[j] : std::numeric_limits<double>::infinity();
-  int32_t bi = seed_idx ? seed_idx[j] : -1;
-  for (int y = 0; y < nchunks; y++) {
-    const double d = pd2[(int64_t)y * M + j];
-    if (d < best) { best = d; bi = pidx[(int64_t)y * M + j]; }
-  }
-  out_idx[j] = bi;
-  if (out_d2) out_d2[j] = best;
-}
 
 // ------------------------------------------------------------------------------- host model
 

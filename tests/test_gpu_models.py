@@ -226,6 +226,37 @@ def test_nearest_neighbour_kernel():
         dn3, dq3 = e.alloc(nodes3.nbytes).upload(nodes3), e.alloc(q3.nbytes).upload(q3)
 
 
+@pytest.mark.parametrize("nplan", [2, 3, 5, 6])
+def test_nearest_neighbour_matrix_core_screen_for_other_planning_sets(nplan):
+    """The screened scan for planning sets other than the arm's seven joints (the operand rows keep seven coordinate
+    slots per half; unused ones are zero): winners and float64 distances of the plain scan, exact duplicates included."""
+    m = scenes.franka_p()
+    e = eng_mod.Engine(m)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)[:nplan]
+    e.set_planning(qidx, m.keyframe("home").qpos)
+    rng = np.random.default_rng(40 + nplan)
+    n, M = 280000 + 17 * nplan, 16384 + 5 * nplan
+    nodes = rng.uniform(-2.9, 2.9, size=(nplan, n))
+    qs = rng.uniform(-2.9, 2.9, size=(nplan, M))
+    nodes[:, 270000] = nodes[:, 12]
+    qs[:, 1] = nodes[:, 12]
+    qs[:, 2] = nodes[:, 270000] + 1e-12
+    dn, dq = e.alloc(nodes.nbytes).upload(nodes), e.alloc(qs.nbytes).upload(qs)
+    di, dd = e.alloc(4 * M), e.alloc(8 * M)
+    e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
+    assert e.nearest_last_screen() == 2
+    got, gd = di.download(np.int32, M), dd.download(np.float64, M)
+    sel = np.concatenate([np.arange(0, 64), rng.integers(64, M, 200)])
+    s = np.zeros((len(sel), n))
+    for c in range(nplan):  # the kernel's sum order
+        d = nodes[c][None, :] - qs[c][sel][:, None]
+        s = s + d * d
+    np.testing.assert_array_equal(got[sel], s.argmin(1))
+    np.testing.assert_array_equal(gd[sel], s.min(1))
+    assert got[1] == 12 and gd[1] == 0.0
+    e.close()
+
+
 def test_dropin_constraint_and_planner_equivalence(oracle_mod):
     """The HIP CollisionConstraint dropped into the reference-shaped planner makes the same
     decisions as the CPU path: identical waypoint lists for a fixed seed (UR5e, config 1)."""
