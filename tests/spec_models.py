@@ -34,7 +34,16 @@ def generic_scenes():
             ("franka_p alone (floor + base)", scenes.franka_p(obstacles=False), 2),
             ("franka_p + 6 boxes + 4 spheres, seed 1", scenes.franka_p_scene(6, 4, 1), 2),
             ("franka_p + 3 boxes + 3 spheres + 5 capsules, seed 2", scenes.franka_p_scene(3, 3, 2, n_capsules=5), 2),
-            ("franka_p + 14 boxes + 12 spheres, seed 3 (30 static geoms)", scenes.franka_p_scene(14, 12, 3), 2)]
+            ("franka_p + 14 boxes + 12 spheres, seed 3 (30 static geoms)", scenes.franka_p_scene(14, 12, 3), 2),
+            ("franka_p + a wall (two planes) + 4 boxes + 3 spheres, seed 5", _with_wall(scenes.random_obstacles(4, 3, 5)), 2),
+            ("franka_p + a wall (two planes) + 3 boxes, seed 6 (odd number of bounded rows)", _with_wall(scenes.random_obstacles(3, 0, 6)), 2)]
+
+
+def _with_wall(obstacles):
+    """... and a second plane: a wall behind the robot at x = -0.55, its normal along +x."""
+    wall = {"type": "plane", "size": (0.0, 0.0, 0.05), "pos": (-0.55, 0.0, 0.0), "quat": (np.sqrt(0.5), 0.0, np.sqrt(0.5), 0.0),
+            "name": "wall"}
+    return scenes.franka_p_builder([wall] + list(obstacles)).compile()
 
 
 def generic_robot():
