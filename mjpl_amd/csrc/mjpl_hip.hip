@@ -738,6 +738,12 @@ int pin_reserve(mjpl_engine *e, size_t bytes) {
   return MJPL_OK;
 }
 constexpr size_t kFusedHostBytes = (size_t)256 << 10;  // batches up to this size take the fused path
+// ... and up to this size the kernels read the pinned block and write into it themselves, over the bus: no copy
+// operation on the stream at all (a scalar valid_config pays launches and one synchronisation; MJPL_ZERO_COPY_BYTES)
+size_t zero_copy_bytes() {
+  static const size_t v = [] { const char *s = getenv("MJPL_ZERO_COPY_BYTES"); return s ? (size_t)atoll(s) : (size_t)256 << 10; }();
+  return v;
+}
 
 // mj_collision pair filters [MJ-recalled: engine_collision_driver.c filterBitmask /
 // filterBodyPair] + the a6 ruleset folded in.  returns true if the pair is tested.
@@ -2374,6 +2380,16 @@ int mjpl_check_configs(mjpl_engine *e, const double *Q, int64_t N, int32_t layou
   const size_t qb = (size_t)N * e->qidx.size() * sizeof(double);
   if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
   if ((rc = stage_reserve(e, 2, (size_t)N)) != MJPL_OK) return rc;
+  if (qb + (size_t)N <= zero_copy_bytes()) {
+    if ((rc = pin_reserve(e, qb + (size_t)N)) != MJPL_OK) return rc;
+    char *pin = (char *)e->h_pin, *dpin = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&dpin, pin, 0));
+    memcpy(pin, Q, qb);
+    if ((rc = launch_configs(e, (const double *)dpin, N, layout, (uint8_t *)(dpin + qb), nullptr)) != MJPL_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(valid, pin + qb, (size_t)N);
+    return MJPL_OK;
+  }
   if (qb + (size_t)N <= kFusedHostBytes) {
     // planner-sized batch: through the pinned block, one copy each way
     if ((rc = pin_reserve(e, qb + (size_t)N)) != MJPL_OK) return rc;
@@ -2402,6 +2418,29 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
   if (!QB || !valid) return fail(MJPL_E_ARG, "NULL pointer");
   HIP_TRY(hipSetDevice(e->device));
   const size_t qb = (size_t)E * e->qidx.size() * sizeof(double);
+  if (2 * qb + 5 * (size_t)E + 16 <= zero_copy_bytes()) {
+    const size_t vb = ((size_t)E + 7) & ~(size_t)7, fbb = (size_t)E * sizeof(int32_t);
+    if ((rc = pin_reserve(e, 2 * qb + vb + fbb + 8)) != MJPL_OK) return rc;
+    char *pin = (char *)e->h_pin, *dpin = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&dpin, pin, 0));
+    memcpy(pin, QA, qb);
+    memcpy(pin + qb, QB, qb);
+    HIP_TRY(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
+    char *dout = dpin + 2 * qb, *hout = pin + 2 * qb;
+    if ((rc = launch_edges(e, (const double *)dpin, (const double *)(dpin + qb), E, step_dist, layout, flags, (uint8_t *)dout,
+                           first_bad ? (int32_t *)(dout + vb) : nullptr)) != MJPL_OK)
+      return rc;
+    HIP_TRY(hipMemcpyAsync(hout + vb + fbb, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(valid, hout, (size_t)E);
+    if (first_bad) memcpy(first_bad, hout + vb, fbb);
+    int status = 0;
+    memcpy(&status, hout + vb + fbb, sizeof(int));
+    if (status & kStatusTailTimeout) return fail(MJPL_E_HIP, "the tail kernel gave up waiting for its walking workgroups");
+    if (status & kStatusNonFinite)
+      return fail(MJPL_E_NONFINITE, "an edge holds NaN/inf or needs more than %d waypoints", kMaxWaypoints);
+    return MJPL_OK;
+  }
   if (2 * qb + 5 * (size_t)E + 16 <= kFusedHostBytes) {
     // planner-sized batch: QA | QB go up in one copy from the pinned block, valid | first_bad |
     // status come back in one
