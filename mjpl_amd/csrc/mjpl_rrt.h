@@ -790,6 +790,8 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   if (!(d->epsilon > 0.0)) return fail(MJPL_E_ARG, "`epsilon` must be > 0.0");
   if (!(d->goal_bias >= 0.0 && d->goal_bias <= 1.0)) return fail(MJPL_E_ARG, "`goal_biasing_probability` must be within [0.0, 1.0].");
   if (d->pose && d->pose->e != e) return fail(MJPL_E_ARG, "the pose handle belongs to another engine");
+  if (d->pose && pose_lds(d->pose) + (size_t)kPoseBlock * sizeof(double) * (size_t)e->m.nq > 64 * 1024)
+    return fail(MJPL_E_CAPACITY, "rrt: %d qpos + %d chain joints exceed the LDS budget of the projecting extension", e->m.nq, d->pose->nj);
   HIP_TRY(hipSetDevice(e->device));
   std::unique_ptr<mjpl_rrt, void (*)(mjpl_rrt *)> r(new mjpl_rrt(), mjpl_rrt_destroy);
   r->e = e;
