@@ -275,3 +275,42 @@ def test_item_regions_overflow_to_the_walking_kernel(oracle_mod, cap):
     np.testing.assert_array_equal(gfb, wfb)
     assert e.last_items() > int(cap)  # more was reserved than fits: the surplus took the walking kernel
     e.close()
+
+
+def test_host_pointer_paths_agree():
+    """The host-pointer entry points have three ways to move a batch: the kernels reading and writing a pinned block
+    themselves (up to 256 KiB, the default), one copy each way through that block (MJPL_ZERO_COPY_BYTES=0), and
+    pageable copies for large batches.  Same verdicts, first-bad indices and error reports on all three."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, hashlib
+        import numpy as np
+        sys.path.insert(0, {root!r})
+        import bench
+        from mjpl_amd import engine, scenes
+        m = scenes.franka_p(obstacles=True)
+        qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+        e = engine.Engine(m); e.set_planning(qidx, m.keyframe("home").qpos.copy())
+        h = hashlib.sha256()
+        for E in (1, 7, 300, 2000, 40000):
+            qa, qb = bench.make_edges(m, qidx, E, 5 + E)
+            v, fb = e.check_edges(qa, qb, 0.01, first_bad=True)
+            c = e.check_configs(qb)
+            h.update(v.tobytes()); h.update(fb.tobytes()); h.update(c.tobytes())
+        bad = qa.copy(); bad[3, 2] = np.nan
+        try:
+            e.check_edges(bad, qb, 0.01)
+            h.update(b"no error")
+        except engine.MjplError as err:
+            h.update(str(err.code).encode())
+        print(h.hexdigest())
+    """)
+    outs = []
+    for env in ({}, {"MJPL_ZERO_COPY_BYTES": "0"}, {"MJPL_ZERO_COPY_BYTES": "2000"}):
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2], outs
