@@ -3,6 +3,8 @@ restatement running on the CPU oracle: same seed -> the same targets, the same t
 the same path; multi-goal / pose goals; the RCCL exchange with a one-rank communicator; and one
 GPU's share of BASELINE configs[3] (131 072 lanes per round under [PoseConstraint, JointLimit,
 Collision]) checked through properties every accepted node and edge must have."""
+import os
+
 import numpy as np
 import pytest
 
@@ -195,6 +197,39 @@ def test_plan_to_poses_through_batched_ik(oracle_mod):
     assert err < 2e-3
     P = np.stack(path)
     assert v.valid_edges(P[:-1, qidx], P[1:, qidx], 0.01).all()
+
+
+@pytest.mark.parametrize("policy", [("1", "32768"), ("3", "100"), ("64", "65536"), ("7", "1000000")])
+def test_projecting_extension_makes_the_same_trees_whatever_the_steps_per_launch(policy):
+    """Under a PoseConstraint a lane's candidates depend on the projection of the step before, not on its collision
+    verdict: the device walks up to S steps of every active lane in one launch (k_rrt_gen_project), validates them
+    together and keeps each lane's leading valid ones.  The trees must be, bit for bit, those of S = 1 -- one step
+    per launch, the level-synchronous loop -- for any S and any slot budget (MJPL_RRT_PROJ_STEPS / _SLOTS)."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    cc, pc, q_goal = _constrained(m, q_init, 7)
+    trees = []
+    for steps, slots in (("1", "1"), policy):
+        old = {k: os.environ.get(k) for k in ("MJPL_RRT_PROJ_STEPS", "MJPL_RRT_PROJ_SLOTS")}
+        os.environ.update(MJPL_RRT_PROJ_STEPS=steps, MJPL_RRT_PROJ_SLOTS=slots)
+        try:
+            dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=11, goal_biasing_probability=0.05,
+                                   batch=4096, capacity=1 << 21, pose=pc)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+        dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 11)
+        infos = [dev.rrt.round() for _ in range(3)]
+        assert infos[-1].nodes[0] > 5000 and infos[-1].nodes[1] > 5000
+        trees.append([dev.rrt.tree(t) for t in (0, 1)])
+        dev.rrt.close()
+    for t in (0, 1):
+        np.testing.assert_array_equal(trees[0][t][0], trees[1][t][0])
+        np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
 
 
 def test_first_round_of_131072_lanes_equals_the_host_planner_on_a_lane_prefix(oracle_mod):
