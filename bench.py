@@ -670,6 +670,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--edges", type=int, default=EDGES_PER_GPU)
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="edges workload: engines (HIP streams) that take the steps in turns -- batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="edges workload: skip the float64-only and interpreter engines timed beside the headline")
@@ -732,21 +734,66 @@ def main():
     dqa, dqb = eng.alloc(ha.nbytes).upload(ha), eng.alloc(hb.nbytes).upload(hb)
     dvalid = eng.alloc(E)
     eng.sync()
+    # Batches in flight: S engines of the same model, each with its own HIP stream and scratch, take the K steps in
+    # turns (step i on engine i mod S; the inputs are shared, every engine writes its own verdicts).  A step is
+    # three kernels, each ending in a tail where the chip drains (and the last one a 20 us latency chain of 30
+    # waves): with a second stream the next batch's kernels fill those -- what a planner with more than one
+    # batch to validate does with `mjpl_check_edges_dev` on two engines.  --streams 1: one engine, as in rounds 1-3.
+    S = max(1, min(args.streams, args.steps))
+    engs = [eng] + [make_engine(*timed) for _ in range(S - 1)]
+    outs = [dvalid] + [e.alloc(E) for e in engs[1:]]
+    share = [args.steps // S + (1 if k < args.steps % S else 0) for k in range(S)]
+
+    def run_all(steps_of, sample):
+        """steps_of[k] launches on engine k, all engines at once (one host thread each: the call blocks until its
+        stream is through; ctypes releases the GIL).  Returns per engine (launch_ms, stage_ms, nsamp)."""
+        import threading
+        res = [None] * S
+        errs = []
+
+        def one(k):
+            try:
+                res[k] = engs[k].time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, outs[k].ptr, steps_of[k], sample)
+            except Exception as ex:  # noqa: BLE001 -- reported below, on the main thread
+                errs.append(ex)
+        th = [threading.Thread(target=one, args=(k,)) for k in range(1, S) if steps_of[k] > 0]
+        for t in th:
+            t.start()
+        one(0)
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        return res
 
     # warmup (untimed)
     if args.warmup > 0:
-        eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, args.warmup, 1 << 30)
+        run_all([args.warmup] * S, 1 << 30)
     world.barrier()
     t0 = time.perf_counter()
-    # EXACTLY args.steps launches, back to back on the engine's stream; every 4th one also carries
+    # EXACTLY args.steps launches, back to back on their engines' streams; every 4th one of an engine also carries
     # one HIP event after each of its kernels (the per-kernel durations roofline.achieved uses)
-    launch_ms, stage_ms, nsamp = eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr,
-                                                           args.steps, 4)  # syncs
+    timed_res = run_all(share, 4)  # every call synchronises its stream
     world.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = float(world.gather(elapsed).max())
+    wsum = float(sum(share))
+    launch_ms = sum(r[0] * n for r, n in zip(timed_res, share) if r) / wsum
+    stage_ms = {k: sum(r[1][k] * n for r, n in zip(timed_res, share) if r) / wsum for k in timed_res[0][1]}
+    nsamp = sum(r[2] for r in timed_res if r)
 
     valid = dvalid.download(np.uint8, E)
+    for k in range(1, S):
+        if share[k] > 0 and not np.array_equal(outs[k].download(np.uint8, E), valid):
+            sys.exit(f"bench.py: engine {k} of {S} returned other verdicts than engine 0 for the same batch")
+    one_stream = None
+    if S > 1:  # ... and the same K steps on ONE stream (not the measurement: the figure of rounds 1-3, and the kernels alone)
+        eng.sync()
+        t1 = time.perf_counter()
+        l1, st1, _ = eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, max(100, args.steps // 4), 4)
+        dt1 = time.perf_counter() - t1
+        one_stream = {"value": E * max(100, args.steps // 4) / dt1, "unit": "edges/s", "steps": max(100, args.steps // 4),
+                      "ms_per_step": dt1 / max(100, args.steps // 4) * 1e3, "step_ms_all_kernels": l1, "kernels_ms": st1}
 
     if rank == 0:
         total_edges = E * world.world * args.steps
@@ -793,6 +840,10 @@ def main():
                        "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
                        "float32_filter": filt, "filter_tol_m": info["filter_tol"],
                        "specialised_kernels": spec,
+                       "streams": S, "batches_in_flight": S,
+                       "streams_note": (f"{S} engines (one HIP stream and one scratch set each) take the steps in turns: the kernels of "
+                                        "consecutive batches overlap; ms_per_step = elapsed / steps; one_stream = the same steps on one engine")
+                                       if S > 1 else "one engine, one stream",
                        "persistent_kernels": bool(info.get("persistent_kernels")), "fused_tail": bool(info.get("fused_tail")),
                        "undecided_items_last_step": undecided,
                        "edges_reaching_interior_pass": interior, "interior_waypoint_items": items,
@@ -806,12 +857,14 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": prof.get("hbm_bytes_per_launch"),
                          "kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms,
-                         "kernels_ms": stage_ms, "kernel_samples": nsamp,
+                         "kernels_ms": stage_ms, "kernel_samples": nsamp, "streams": S,
+                         "kernel_ms_note": ("durations between HIP events on the kernels' own streams while the other stream's kernels share "
+                                            "the chip: longer than the kernel alone (one_stream.kernels_ms)") if S > 1 else None,
                          "algorithmic_bytes_per_unit": unit_bytes, "units_in_this_kernel": units,
                          "unit_of_work": unit_name,
                          "whole_step": {"algorithmic_bytes": BYTES_PER_EDGE * E,
-                                        "achieved_GBs": BYTES_PER_EDGE * E / (launch_ms * 1e-3) / 1e9,
-                                        "frac": BYTES_PER_EDGE * E / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                        "achieved_GBs": BYTES_PER_EDGE * E * args.steps / elapsed / 1e9,
+                                        "frac": BYTES_PER_EDGE * E * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
                          "note": "vector-issue / latency bound, not HBM bound (SURVEY.md 8d); see valu_issue"},
         }
         # vector-ALU issue occupancy of the dominant kernel, from the committed counter pass:
@@ -826,7 +879,18 @@ def main():
                     "frac": iv / (ms * 1e-3) / VALU_ISSUE_PEAK, "source": rec.get("source"),
                     "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU "
                             "instruction (MI355X_MICROARCH.md, Wave scheduling)"}
-        out["valu_issue"] = valu_issue(kernel, kernel_ms, prof)
+        # (the kernel's own rate: its duration alone on the chip, as the counter passes ran it)
+        out["valu_issue"] = valu_issue(kernel, one_stream["kernels_ms"].get(
+            {"k_filter_endpoints_pw": "k_filter_endpoints", "k_filter_items_pw": "k_filter_items", "k_tail": "k_patch_pairs"}.get(kernel, kernel),
+            kernel_ms) if one_stream else kernel_ms, prof)
+        # ... and of the chip over a whole step: the vector instructions of all its kernels / the time a step takes
+        recs = [profile_record(k, E, args.layout, filt, spec) for k in stage_ms]
+        if all(r.get("SQ_INSTS_VALU") for r, k in zip(recs, stage_ms) if stage_ms[k] > 0.01):
+            iv = sum(float(r.get("SQ_INSTS_VALU", 0.0)) for r in recs)
+            out["valu_issue_whole_step"] = {"wave_insts_valu_per_step": iv, "ms_per_step": elapsed / args.steps * 1e3,
+                                            "frac": iv / (elapsed / args.steps) / VALU_ISSUE_PEAK, "peak_per_s": VALU_ISSUE_PEAK,
+                                            "kernels": [k for k in stage_ms if stage_ms[k] > 0.01]}
+        out["one_stream"] = one_stream
 
         # ---- the same batch through the other two engine configurations, in this process: the float64
         # kernels alone (the reference's arithmetic end to end) and the generic interpreting filter kernels
@@ -857,6 +921,7 @@ def main():
                 vk = max(v_stage, key=lambda k: v_stage[k])
                 rec = profile_record(vk, E, args.layout, vf, ve.spec_kind() if vs else 0)  # (s1: the program's own library, s2: the robot's)
                 variants[name] = {"value": E * vsteps / dt, "unit": "edges/s", "steps": vsteps, "ms_per_step": dt / vsteps * 1e3,
+                                  "streams": 1,  # (compare with one_stream, not with value)
                                   "step_ms_all_kernels": v_launch, "kernels_ms": v_stage, "dtype": "f64" if not vf else "f32-filter+f64-exact",
                                   "float32_filter": bool(ve.info()["filter_enabled"]), "specialised_kernels": bool(ve.spec_loaded()),
                                   "library": {0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[ve.spec_kind()],
@@ -897,6 +962,8 @@ def main():
         _flush_c_stdio()
         print(json.dumps(out), flush=True)
 
+    for e2 in engs[1:]:
+        e2.close()
     world.close()
     return 0
 

@@ -22,6 +22,8 @@ def main():
         for k, v in acc.items():
             res[k] = sum(v) / len(v)
     for path in glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True):
+        if "trace_streams" in path:  # (the bench line's own mode, kernels of several streams overlapping: not a kernel alone)
+            continue
         with open(path) as f:
             for row in csv.DictReader(f):
                 if kern in row["Name"]:

@@ -26,5 +26,6 @@ for v in "" _f64 _interp _generic; do
   f=$(ls gpurun_out/prof_${TAG}${v}/trace/*/*kernel_stats.csv | head -1)
   cp "$f" gpurun_out/${TAG}${v}_kernel_stats.csv
 done
+cp "$(ls gpurun_out/prof_${TAG}/trace_streams/*/*kernel_stats.csv | head -1)" gpurun_out/${TAG}_streams_kernel_stats.csv
 rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}_f64 gpurun_out/prof_${TAG}_interp gpurun_out/prof_${TAG}_generic
 ls gpurun_out/${TAG}*
