@@ -314,3 +314,32 @@ def test_host_pointer_paths_agree():
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] == outs[2], outs
+
+
+def test_engines_taking_batches_in_turns_return_a_single_engine_s_verdicts(oracle_mod):
+    """EngineRing: three engines (three streams) validate six different batches in turns, all enqueued before the
+    first synchronisation; every batch's verdicts and first-bad indices are the oracle's."""
+    import bench
+    m = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    ring = eng_mod.EngineRing(m, engines=3, planning_qidx=qidx, qpos_base=base)
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    batches, bufs = [], []
+    for k in range(6):
+        E = 30000 + 777 * k
+        qa, qb = bench.make_edges(m, qidx, E, 50 + k)
+        e0 = ring.engines[0]
+        da, db = e0.alloc(qa.nbytes).upload(qa), e0.alloc(qb.nbytes).upload(qb)
+        dv, df = e0.alloc(E), e0.alloc(4 * E)
+        batches.append((qa, qb, E))
+        bufs.append((da, db, dv, df))
+    ring.sync()
+    for (qa, qb, E), (da, db, dv, df) in zip(batches, bufs):
+        ring.check_edges_dev(da.ptr, db.ptr, E, 0.01, eng_mod.AOS, dv.ptr, df.ptr)
+    ring.sync()
+    for (qa, qb, E), (da, db, dv, df) in zip(batches, bufs):
+        want, wfb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
+        np.testing.assert_array_equal(dv.download(np.uint8, E), want)
+        np.testing.assert_array_equal(df.download(np.int32, E), wfb)
+    ring.close()
