@@ -744,36 +744,43 @@ def main():
     outs = [dvalid] + [e.alloc(E) for e in engs[1:]]
     share = [args.steps // S + (1 if k < args.steps % S else 0) for k in range(S)]
 
-    def run_all(steps_of, sample):
+    def run_all(steps_of, sample, before=None):
         """steps_of[k] launches on engine k, all engines at once (one host thread each: the call blocks until its
-        stream is through; ctypes releases the GIL).  Returns per engine (launch_ms, stage_ms, nsamp)."""
+        stream is through; ctypes releases the GIL).  The threads are up and waiting when `before` -- the barrier
+        and the clock of the timed region -- runs.  Returns (what `before` returned, per engine (launch_ms, stage_ms, nsamp))."""
         import threading
         res = [None] * S
         errs = []
+        go = threading.Event()
 
         def one(k):
             try:
+                go.wait()
                 res[k] = engs[k].time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, outs[k].ptr, steps_of[k], sample)
             except Exception as ex:  # noqa: BLE001 -- reported below, on the main thread
                 errs.append(ex)
         th = [threading.Thread(target=one, args=(k,)) for k in range(1, S) if steps_of[k] > 0]
         for t in th:
             t.start()
+        stamp = before() if before else None
+        go.set()
         one(0)
         for t in th:
             t.join()
         if errs:
             raise errs[0]
-        return res
+        return stamp, res
 
     # warmup (untimed)
     if args.warmup > 0:
         run_all([args.warmup] * S, 1 << 30)
-    world.barrier()
-    t0 = time.perf_counter()
+
+    def start_of_timed_region():
+        world.barrier()
+        return time.perf_counter()
     # EXACTLY args.steps launches, back to back on their engines' streams; every 4th one of an engine also carries
     # one HIP event after each of its kernels (the per-kernel durations roofline.achieved uses)
-    timed_res = run_all(share, 4)  # every call synchronises its stream
+    t0, timed_res = run_all(share, 4, start_of_timed_region)  # every call synchronises its stream
     world.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = float(world.gather(elapsed).max())
