@@ -740,15 +740,17 @@ def main():
     # waves): with a second stream the next batch's kernels fill those -- what a planner with more than one
     # batch to validate does with `mjpl_check_edges_dev` on two engines.  --streams 1: one engine, as in rounds 1-3.
     S = max(1, min(args.streams, args.steps))
-    engs = [eng] + [make_engine(*timed) for _ in range(S - 1)]
-    outs = [dvalid] + [e.alloc(E) for e in engs[1:]]
+    engs = engs_default = [eng] + [make_engine(*timed) for _ in range(S - 1)]
+    outs = outs_default = [dvalid] + [e.alloc(E) for e in engs[1:]]
     share = [args.steps // S + (1 if k < args.steps % S else 0) for k in range(S)]
 
-    def run_all(steps_of, sample, before=None):
+    def run_all(steps_of, sample, before=None, engs=None, outs=None):
         """steps_of[k] launches on engine k, all engines at once (one host thread each: the call blocks until its
         stream is through; ctypes releases the GIL).  The threads are up and waiting when `before` -- the barrier
         and the clock of the timed region -- runs.  Returns (what `before` returned, per engine (launch_ms, stage_ms, nsamp))."""
         import threading
+        engs = engs_default if engs is None else engs
+        outs = outs_default if outs is None else outs
         res = [None] * S
         errs = []
         go = threading.Event()
@@ -927,8 +929,24 @@ def main():
                 v_stage = {vnames.get(k, k): v for k, v in v_stage.items()}
                 vk = max(v_stage, key=lambda k: v_stage[k])
                 rec = profile_record(vk, E, args.layout, vf, ve.spec_kind() if vs else 0)  # (s1: the program's own library, s2: the robot's)
+                in_turns = None
+                if S > 1:  # ... and as the headline runs: S engines of this configuration taking the steps in turns
+                    ves = [ve] + [make_engine(vf, vs) for _ in range(S - 1)]
+                    vouts = [vv] + [x.alloc(E) for x in ves[1:]]
+                    vshare = [vsteps // S + (1 if k < vsteps % S else 0) for k in range(S)]
+                    run_all([5] * S, 1 << 30, None, ves, vouts)
+                    tv, _ = run_all(vshare, 1 << 30, time.perf_counter, ves, vouts)
+                    dtv = time.perf_counter() - tv
+                    same = same and all(np.array_equal(o.download(np.uint8, E), valid) for o in vouts)
+                    if not same:
+                        sys.exit(f"bench.py: an engine of the {name} variant returned other verdicts than the headline engine's")
+                    in_turns = {"value": E * vsteps / dtv, "unit": "edges/s", "streams": S, "ms_per_step": dtv / vsteps * 1e3}
+                    for x, o in zip(ves[1:], vouts[1:]):
+                        o.free()
+                        x.close()
                 variants[name] = {"value": E * vsteps / dt, "unit": "edges/s", "steps": vsteps, "ms_per_step": dt / vsteps * 1e3,
-                                  "streams": 1,  # (compare with one_stream, not with value)
+                                  "streams": 1,  # (compare with one_stream; in_turns compares with the line's value)
+                                  "in_turns": in_turns,
                                   "step_ms_all_kernels": v_launch, "kernels_ms": v_stage, "dtype": "f64" if not vf else "f32-filter+f64-exact",
                                   "float32_filter": bool(ve.info()["filter_enabled"]), "specialised_kernels": bool(ve.spec_loaded()),
                                   "library": {0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[ve.spec_kind()],
