@@ -117,6 +117,12 @@ typedef struct mjpl_info {
    * fused_tail = 1: walking kernel, pair re-check and exact edge kernel are roles of one launch (k_tail) */
   int32_t persistent_kernels;
   int32_t fused_tail;
+  /* fused_edges = 1 (default where the model runs the queued float32 interpreter or its own kernels; MJPL_FUSED=0
+   * at creation restores the two persistent kernels): ONE filter kernel per edge launch -- endpoint tiles and
+   * waypoint tiles of a batch served by the same resident workgroups from a work pool in LDS (k_edges_fused) --
+   * followed by k_tail.  fused_waves: wavefronts per workgroup of that kernel. */
+  int32_t fused_edges;
+  int32_t fused_waves;
 } mjpl_info;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -213,7 +219,8 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
 
 /* Which screen the last mjpl_nearest_dev ran in front of its float64 distances: 0 none (plain float64 scan),
  * 1 binary32 on the vector units, 2 binary16 operands on the matrix cores (large trees and query sets whose
- * coordinates are all below 256 in magnitude).  The result is the float64 scan's either way.  Synchronises. */
+ * coordinates are all below 256 in magnitude and whose nodes' squared norms are below 65504, the range of
+ * binary16).  The result is the float64 scan's either way.  Synchronises. */
 int32_t mjpl_nearest_last_screen(mjpl_engine *e);
 
 /* ---- device memory and stream helpers (so that hosts need no other GPU runtime) -- */
@@ -233,7 +240,8 @@ void *mjpl_stream(mjpl_engine *e);
  * per waypoint item, the walking kernel for what was not expanded, the float64 re-check of the
  * undecided pairs / configurations, the float64 edge kernel for undecided whole edges.  With the
  * filter off the float64 edge kernel is the whole launch. */
-#define MJPL_STAGE_ENDPOINTS 0  /* k_filter_endpoints (incl. the counter memset)          */
+#define MJPL_STAGE_ENDPOINTS 0  /* k_filter_endpoints (incl. the counter memset); with mjpl_info.fused_edges:
+                                  * k_edges_fused, the whole float32 filter of the launch (stage 1 is then empty) */
 #define MJPL_STAGE_ITEMS     1  /* k_filter_items                                          */
 #define MJPL_STAGE_WALK      2  /* k_filter_edges                                          */
 #define MJPL_STAGE_PATCH     3  /* k_patch_pairs (moving boxes: k_check_configs, patch mode); with mjpl_info.fused_tail:
@@ -367,6 +375,11 @@ int mjpl_program_dump(const mjpl_model_desc *model, const int32_t *allowed_bodie
                       const int32_t *qidx, int32_t nplan, const double *qpos_base, double filter_tol,
                       int32_t *ip, int32_t *nip, float *fp, double *dp, int32_t *ntab,
                       mjpl_program_info *info);
+/* Host-only look-up, no device needed: is there a loadable library for this hash (mjpl_program_info.hash with
+ * generic = 0, .robot_hash with generic = 1) that was built for this version of the engine?  1 / 0.  A
+ * deployment step calls it after mjpl_amd/specialise.py; it is the look-up mjpl_create performs, and like it
+ * may be called from any number of threads at once (the table of loaded libraries is the process's). */
+int mjpl_spec_probe(uint64_t hash, int32_t generic);
 /* 1 if the engine's current program runs on its own specialised library (hash of the whole program), 2 if
  * on the robot's scene-generic one (obstacles from a table), 0: the interpreting kernels */
 int mjpl_spec_loaded(const mjpl_engine *e);

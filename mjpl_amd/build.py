@@ -23,7 +23,7 @@ _BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-m
 # the per-model specialised libraries (mjpl_amd/specialise.py).  Their digest is compiled into both
 # (MJPL_SRC_STAMP) and mixed into the program hash a specialised library is named by, so a library
 # built from other headers is neither found nor accepted (load_spec compares the stamps).
-STAMPED_HEADERS = ("mjpl_filter.h", "mjpl_device.h", "mjpl_trig.h")
+STAMPED_HEADERS = ("mjpl_filter.h", "mjpl_fused.h", "mjpl_device.h", "mjpl_trig.h")
 
 
 def src_stamp() -> int:
@@ -59,10 +59,16 @@ def build_hip(force: bool = False, lds_tables: bool = False, verbose: bool = Fal
     """Compile libmjpl_hip.so (or the LDS-staged-tables A/B variant) for gfx950."""
     target = LIB_LDS_PATH if lds_tables else LIB_PATH
     if force or _stale(target):
-        cmd = [hipcc(), *hipcc_flags(), "-o", target, os.path.join(CSRC, "mjpl_hip.hip")]
+        tmp = f"{target}.tmp{os.getpid()}"  # (complete under its final name or not at all)
+        cmd = [hipcc(), *hipcc_flags(), "-o", tmp, os.path.join(CSRC, "mjpl_hip.hip")]
         if lds_tables:
             cmd.insert(1, "-DMJPL_TABLES_LDS=1")
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.run(cmd, check=True)
+        try:
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, target)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return target

@@ -20,7 +20,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 11
+#define MJPL_SPEC_ABI 12
 // scene-generic specialised libraries: cull rows per moving geom, moving geoms at most,
 // floats of the scene header in front of the rows
 // Table: [header | per moving geom: kSceneRows cull rows of 4 floats, then kSceneRows descriptor words | one
@@ -302,10 +302,10 @@ __device__ __forceinline__ bool walk_step(Perm perm, int nplan, const double *qe
 // (its float32 bounds absorb 1e-5; the exact re-check rebuilds the waypoint by the recurrence).
 // So the walk is needed for the COUNT only -- where `step` divides the edge length the count
 // hangs on the last bit of the running distance -- and no waypoint is stored.
-__device__ __forceinline__ int count_waypoints(const int *__restrict__ gip, const double *__restrict__ QA,
-                                               int64_t E, int64_t i, double step, int layout, bool todo,
-                                               const double *qe, int B, double *qw, int ws,
-                                               const ItemBuffers &ib, int nplan) {
+__device__ __forceinline__ int count_waypoints_ts(const int *__restrict__ gip, const double *__restrict__ QA,
+                                                  int64_t E, int64_t i, double step, int layout, bool todo,
+                                                  const double *qe, int B, double *qw, int ws,
+                                                  int kmax, int nplan, double &tstep) {
   const int *perm = gip + gip[H_OFF_PERM];
   bool at_end = true;
   for_row(QA, E, i, nplan, layout, todo, [&](int k, double a) {
@@ -318,23 +318,33 @@ __device__ __forceinline__ int count_waypoints(const int *__restrict__ gip, cons
     const double d = qe[col * B] - qw[col * ws];
     s0 = s0 + d * d;
   }
+  tstep = 0.0;
   if (!todo || at_end) return 0;
-  const bool long_edge = !(sqrt(s0) <= step * (double)(ib.kmax - 2));
+  const bool long_edge = !(sqrt(s0) <= step * (double)(kmax - 2));
   int K = 0;
   bool degenerate = false;
   bool walking = !long_edge;
   while (__ballot(walking) != 0ull) {
     if (walking) {
       if (walk_step(perm, nplan, qe, B, qw, ws, step, degenerate)) walking = false;
-      else if (++K > ib.kmax) walking = false;
+      else if (++K > kmax) walking = false;
 #ifdef MJPL_X_SHORTWALK  // timing-only build: one step of the walk
       walking = false;
 #endif
-      if (degenerate) { walking = false; K = ib.kmax + 1; }
+      if (degenerate) { walking = false; K = kmax + 1; }
     }
   }
-  if (long_edge || K > ib.kmax) return -1;  // (the estimate can be off by a step)
-  if (K > 0) ib.tstep[i] = step / sqrt(s0);
+  if (long_edge || K > kmax) return -1;  // (the estimate can be off by a step)
+  if (K > 0) tstep = step / sqrt(s0);
+  return K;
+}
+__device__ __forceinline__ int count_waypoints(const int *__restrict__ gip, const double *__restrict__ QA,
+                                               int64_t E, int64_t i, double step, int layout, bool todo,
+                                               const double *qe, int B, double *qw, int ws,
+                                               const ItemBuffers &ib, int nplan) {
+  double ts;
+  const int K = count_waypoints_ts(gip, QA, E, i, step, layout, todo, qe, B, qw, ws, ib.kmax, nplan, ts);
+  if (K > 0) ib.tstep[i] = ts;
   return K;
 }
 
@@ -1414,6 +1424,10 @@ k_tail(TailArgs a) {
     __threadfence();
   }
   __syncthreads();
+  // (a wait that gave up: the lists may still be growing under a walking workgroup, so nothing read from them
+  // now can be trusted -- leave the batch alone; the status bit is sticky and every synchronising entry point,
+  // mjpl_take_status and the planner's rounds report it as MJPL_E_HIP)
+  if (*a.lcount > 0 && (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusTailTimeout)) return;
   if (b < a.nw + a.np)
     patch_pairs_body<ESpec>(a.ip, a.nip, a.dp, a.ndp, a.gt, a.uc, a.valid, a.first_bad, b - a.nw, a.np);
   else
@@ -1423,5 +1437,6 @@ k_tail(TailArgs a) {
 }
 
 
-
 }  // namespace mjpl
+
+#include "mjpl_fused.h"

@@ -17,6 +17,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 #include <type_traits>
@@ -35,6 +36,7 @@ using namespace mjpl;
 
 constexpr int kCtr = kCounterStride;  // ints between device counters: one 128-byte line each
 constexpr int kNumCtr = kNumCounters;
+constexpr size_t kFusedDbgWaves = 256 * 4 * 3 * 2;  // (wave slots of the chip, with room)
 
 thread_local std::string g_err;
 
@@ -523,6 +525,8 @@ struct SpecLib {
   typedef int (*ItemsPwFn)(hipStream_t, size_t, const int *, int, const float *, int, ItemBuffers, EdgeSource, float, uint8_t *,
                            int32_t *, int *, int *, UndecidedConfigs, int *);
   typedef int (*TailFn)(hipStream_t, size_t, TailArgs);
+  typedef int (*FusedFn)(hipStream_t, int, size_t, FusedArgs);  // (waves per workgroup, LDS bytes, arguments)
+  FusedFn fused = nullptr;
   EndpointsPwFn endpoints_pw = nullptr;
   ItemsPwFn items_pw = nullptr;
   TailFn tail = nullptr;
@@ -602,6 +606,13 @@ struct mjpl_engine {
   // 0.459 ms).  MJPL_PERSIST=0 / 1 forces either (tests run both ways).
   int persist = -1;
   bool fused_tail = true;  // MJPL_TAIL: walking kernel, pair re-check and exact edge kernel as roles of one launch (k_tail)
+  // ONE filter kernel per edge launch (k_edges_fused, mjpl_fused.h): endpoint and waypoint tiles served by the same
+  // resident workgroups from a work pool in LDS.  MJPL_FUSED=0 restores the two persistent kernels; MJPL_FUSED_WAVES
+  // (6 | 12: workgroups per CU 2 | 1), MJPL_FUSED_POLICY (bit 0: item tiles first), MJPL_FUSED_KMAX: A/B measurements
+  bool fused = true;
+  int fused_waves = kFusedWaves, fused_policy = 0, fused_kmax = 4096;
+  const char *fused_dbg_path = nullptr;  // MJPL_FUSED_DEBUG=<file> (with a -DMJPL_FUSED_DEBUG build of the kernels)
+  unsigned long long *d_fused_dbg = nullptr;
   size_t item_cap_limit = (size_t)1 << 26;  // MJPL_ITEM_CAP: edges beyond it take the walking kernel
   void *d_nn = nullptr;         // nearest neighbour: per-chunk partial results
   size_t nn_bytes = 0;
@@ -657,13 +668,21 @@ int stage_reserve(mjpl_engine *e, int k, size_t bytes) {
 // A library libmjpl_spec_<hash>.so holds the three float32 filter kernels of mjpl_filter.h instantiated
 // with generated straight-line code for ONE compiled program.  It is looked up by the program's hash
 // in $MJPL_SPEC_DIR (default: the directory `spec` next to this library); MJPL_SPEC=0 disables it.
+// The cache belongs to the process, engines to their threads ("one engine per thread", include/mjpl_hip.h):
+// every look-up and insertion happens under spec_mutex().  Entries are never erased and std::map never moves
+// its nodes, so the pointer an engine keeps stays valid without the lock.
 std::map<uint64_t, SpecLib> &spec_cache() {
   static std::map<uint64_t, SpecLib> c;
   return c;
 }
+std::mutex &spec_mutex() {
+  static std::mutex m;
+  return m;
+}
 
 // dlopen <dir>/<prefix><hash>.so and check that it was built for this hash from these headers
 const SpecLib *find_spec(uint64_t hash, bool generic) {
+  std::lock_guard<std::mutex> lock(spec_mutex());
   auto &cache = spec_cache();
   const uint64_t key = hash ^ (generic ? 0x9e3779b97f4a7c15ull : 0ull);
   auto it = cache.find(key);
@@ -695,11 +714,12 @@ const SpecLib *find_spec(uint64_t hash, bool generic) {
     sl.endpoints_pw = (SpecLib::EndpointsPwFn)dlsym(lib, "mjpl_spec_launch_endpoints_pw");
     sl.items_pw = (SpecLib::ItemsPwFn)dlsym(lib, "mjpl_spec_launch_items_pw");
     sl.tail = (SpecLib::TailFn)dlsym(lib, "mjpl_spec_launch_tail");
+    sl.fused = (SpecLib::FusedFn)dlsym(lib, "mjpl_spec_launch_fused");
     // (the stamp: both libraries built from the same mjpl_filter.h / mjpl_device.h / mjpl_trig.h -- the
     // structs that cross this boundary by value and the table layouts live there)
     const int g = gen ? gen() : 0;
     if (abi && hashf && stamp && abi() == MJPL_SPEC_ABI && stamp() == (unsigned long long)MJPL_SRC_STAMP && hashf() == hash &&
-        (g != 0) == generic && sl.configs && sl.endpoints && sl.items && sl.patch && sl.endpoints_pw && sl.items_pw && sl.tail) {
+        (g != 0) == generic && sl.configs && sl.endpoints && sl.items && sl.patch && sl.endpoints_pw && sl.items_pw && sl.tail && sl.fused) {
       sl.lib = lib;
       sl.generic_rows = g >> 8;
       sl.generic_stages = g & 255;
@@ -707,8 +727,8 @@ const SpecLib *find_spec(uint64_t hash, bool generic) {
       dlclose(lib);
     }
   }
-  cache[key] = sl;
-  return cache[key].lib ? &cache[key] : nullptr;
+  auto ins = cache.emplace(key, sl).first;
+  return ins->second.lib ? &ins->second : nullptr;
 }
 
 // `generic_ok`: the program satisfies what a scene-generic library assumes (compile_program)
@@ -1474,6 +1494,26 @@ int allow_lds(K kernel, size_t bytes) {
   return MJPL_OK;
 }
 
+// Can this engine's edge launches run the fused filter kernel (mjpl_fused.h), and how: waves per workgroup
+// (twelve = one workgroup per CU at three waves per SIMD; six = two per CU, A/B; four for the one-wave-per-SIMD
+// build of models with moving boxes), entries of a workgroup's pool (what its share of the CU's LDS leaves, at
+// least 64 per wave: every wave's first endpoint tile must find room) and the dynamic LDS of a workgroup.
+bool fused_plan(const mjpl_engine *e, int *nwaves, size_t *lds, int *ring = nullptr) {
+  if (!e->fused || !e->filter || !e->filter_usable || !e->two_pass || !e->expand || e->immediate()) return false;
+  const int nplan = (int)e->qidx.size();
+  const bool mbox = e->filter_mbox();
+  if (!fused_fits(nplan, e->nsave, mbox)) return false;
+  const int nw = mbox ? 4 : (e->spec ? e->fused_waves : kFusedWaves);
+  const size_t budget = nw == 6 ? (size_t)79 * 1024 : (size_t)160 * 1024;  // (two workgroups per CU: a little less than half each)
+  const size_t base = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, 0);
+  if (base + (size_t)64 * nw * 16 > budget) return false;
+  const int r = (int)std::min<size_t>(4096, (budget - base) / 16 / 64 * 64);
+  if (nwaves) *nwaves = nw;
+  if (lds) *lds = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, r);
+  if (ring) *ring = r;
+  return true;
+}
+
 // A filter launch takes the cleared counter set and returns the other one, which its first kernel is
 // to clear for the launch after it.
 int *next_counters(mjpl_engine *e) {
@@ -1630,32 +1670,44 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     const bool expand = two_pass && e->expand;
     const int *rlist = nullptr, *rcount = nullptr;  // work list of the walking kernel
     ItemBuffers ib = {};
+    int fwaves = 0, fring = 0;
+    size_t flds = 0;
+    const bool fused = expand && fused_plan(e, &fwaves, &flds, &fring);
     if (expand) {
-      // room for 8 waypoints per edge on average, and never less than a quarter of a million items:
-      // a handful of long edges (path shortcutting) is best served one waypoint per lane, too
-      size_t want = std::min<size_t>(std::max<size_t>((size_t)E * 8, (size_t)1 << 18) + 4096, e->item_cap_limit);
-      want = (want + fblock - 1) / fblock * fblock;  // whole blocks (the item space is split into regions of them)
-      if (want > e->item_cap || (size_t)E > e->llist_cap) {
-        for (void *ptr : {(void *)e->d_tstep, (void *)e->d_itemedge, (void *)e->d_itemidx, (void *)e->d_llist,
-                          (void *)e->d_eclaim})
+      // per-edge scratch: walking list, step fractions, claim words of the undecided-edge list
+      if ((size_t)E > e->llist_cap) {
+        for (void *ptr : {(void *)e->d_tstep, (void *)e->d_llist, (void *)e->d_eclaim})
           if (ptr) HIP_TRY(hipFree(ptr));
         e->d_tstep = nullptr;
-        e->d_itemedge = e->d_itemidx = e->d_llist = e->d_eclaim = nullptr;
-        e->item_cap = e->llist_cap = 0;
-        HIP_TRY(hipMalloc(&e->d_itemedge, want * sizeof(int)));
-        HIP_TRY(hipMalloc(&e->d_itemidx, want * sizeof(int)));
+        e->d_llist = e->d_eclaim = nullptr;
+        e->llist_cap = 0;
         HIP_TRY(hipMalloc(&e->d_llist, (size_t)E * sizeof(int)));
         HIP_TRY(hipMalloc(&e->d_tstep, (size_t)E * sizeof(double)));
         HIP_TRY(hipMalloc(&e->d_eclaim, (size_t)E * sizeof(int)));
         HIP_TRY(hipMemsetAsync(e->d_eclaim, 0, (size_t)E * sizeof(int), e->stream));
         e->claim_gen = 0;
-        e->item_cap = want; e->llist_cap = (size_t)E;
+        e->llist_cap = (size_t)E;
       }
-      const int kmax = (int)std::min<size_t>(std::max<size_t>(e->item_cap / (size_t)E, kExpandMinWaypoints), 1 << 16);
       if (++e->claim_gen == std::numeric_limits<int>::max()) {  // generations never repeat between clears
         HIP_TRY(hipMemsetAsync(e->d_eclaim, 0, e->llist_cap * sizeof(int), e->stream));
         e->claim_gen = 1;
       }
+    }
+    if (expand && !fused) {
+      // room for 8 waypoints per edge on average, and never less than a quarter of a million items:
+      // a handful of long edges (path shortcutting) is best served one waypoint per lane, too
+      size_t want = std::min<size_t>(std::max<size_t>((size_t)E * 8, (size_t)1 << 18) + 4096, e->item_cap_limit);
+      want = (want + fblock - 1) / fblock * fblock;  // whole blocks (the item space is split into regions of them)
+      if (want > e->item_cap) {
+        for (void *ptr : {(void *)e->d_itemedge, (void *)e->d_itemidx})
+          if (ptr) HIP_TRY(hipFree(ptr));
+        e->d_itemedge = e->d_itemidx = nullptr;
+        e->item_cap = 0;
+        HIP_TRY(hipMalloc(&e->d_itemedge, want * sizeof(int)));
+        HIP_TRY(hipMalloc(&e->d_itemidx, want * sizeof(int)));
+        e->item_cap = want;
+      }
+      const int kmax = (int)std::min<size_t>(std::max<size_t>(e->item_cap / (size_t)E, kExpandMinWaypoints), 1 << 16);
       double *ckpt = nullptr;
       if (kmax >= kCkptEvery) {
         // rows are sized by nq, the upper bound of nplan (mjpl_set_planning may widen the planning set)
@@ -1674,7 +1726,55 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
                        e->d_ucount + (5 + kItemRegions) * kCtr, e->d_llist,
                        e->d_icount + kCtr, kmax, e->d_tstep, ckpt, e->d_eclaim, e->claim_gen};
     }
-    if (two_pass) {
+    if (fused) {
+      // ---- ONE filter kernel for the launch (mjpl_fused.h): endpoint tiles and waypoint tiles from one work pool
+      FusedArgs fa = {};
+      fa.ip = e->d_ip; fa.nip = (int)e->ip.size();
+      fa.fp = e->d_fp; fa.nfp = (int)e->fp.size();
+      fa.QA = dQA; fa.QB = dQB; fa.E = (long long)E; fa.layout = layout;
+      fa.tol = e->filter_tol; fa.step = step;
+      fa.valid = dvalid; fa.first_bad = dfb;
+      fa.status = e->d_status; fa.ulist = e->d_ulist; fa.ucount = e->d_ucount;
+      fa.uc = uc;
+      fa.llist = e->d_llist; fa.lcount = e->d_icount + kCtr;
+      fa.claim = e->d_eclaim; fa.gen = e->claim_gen;
+      fa.tstep = e->d_tstep;
+      fa.item_count = e->d_ucount + 5 * kCtr;
+      fa.surv_count = e->d_ucount + (5 + kItemRegions) * kCtr;
+      fa.tiles = e->d_ucount + kCtrEndpointTiles * kCtr;
+      fa.zero_next = zero_next;
+      fa.kmax = e->fused_kmax; fa.ring = fring; fa.policy = e->fused_policy;
+      if (e->fused_dbg_path) {  // diagnostic runs: per-wave counters of the most recent launch, written out at mjpl_destroy
+        if (!e->d_fused_dbg) {
+          HIP_TRY(hipMalloc(&e->d_fused_dbg, kFusedDbgWaves * 8 * sizeof(unsigned long long)));
+        }
+        HIP_TRY(hipMemsetAsync(e->d_fused_dbg, 0, kFusedDbgWaves * 8 * sizeof(unsigned long long), e->stream));
+        fa.dbg = e->d_fused_dbg;
+      }
+      if (e->spec) {
+        rc = e->spec->fused(e->stream, fwaves, flds, fa) == 0 ? MJPL_OK : fail(MJPL_E_HIP, "specialised fused kernel failed to launch");
+      } else {
+        rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
+          if constexpr (decltype(S)::value <= kQueuedMaxSlots) {
+            constexpr int NW = decltype(M)::value ? 4 : kFusedWaves;
+            auto kern = k_edges_fused<void, decltype(S)::value, decltype(W)::value, decltype(M)::value, NW>;
+            if (fwaves != NW) return fail(MJPL_E_ARG, "fused kernel: %d waves per workgroup asked for, this build has %d", fwaves, NW);
+            int r = allow_lds(kern, flds);
+            if (r != MJPL_OK) return r;
+            hipLaunchKernelGGL(kern, dim3(fused_grid(kern, NW * 64, flds, (long long)((E + 63) / 64))), dim3(NW * 64), flds, e->stream, fa);
+            return MJPL_OK;
+          } else {
+            return fail(MJPL_E_ARG, "the fused kernel serves the queued interpreter");
+          }
+        });
+      }
+      if (rc != MJPL_OK) return rc;
+      guard.armed = false;
+      MJPL_MARK(1);
+      rlist = e->d_llist;  // what is left for the walking role
+      rcount = e->d_icount + kCtr;
+    }
+    if (two_pass && !fused) {
       if ((size_t)E > e->slist_cap) {
         if (e->d_slist) HIP_TRY(hipFree(e->d_slist));
         e->d_slist = nullptr; e->slist_cap = 0;
@@ -1724,8 +1824,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       if (rc != MJPL_OK) return rc;
       guard.armed = false;
     }
-    MJPL_MARK(1);  // after k_filter_endpoints (nothing ran yet in a one-pass launch)
-    if (expand) {
+    if (!fused) MJPL_MARK(1);  // after k_filter_endpoints (nothing ran yet in a one-pass launch)
+    if (expand && !fused) {
       const unsigned igrid = (unsigned)(ib.cap / fblock);  // (regions of whole blocks)
       const EdgeSource src = {dQA, dQB, (long long)E, layout, step, ib.ckpt};
       const bool pw = (e->persist < 0 ? e->spec != nullptr : e->persist != 0) && !e->immediate();
@@ -1945,6 +2045,11 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_PERSIST")) e->persist = atoi(f) != 0 ? 1 : 0;
   if (const char *f = getenv("MJPL_NN_MFMA")) e->nn_mfma = atoi(f) != 0 ? 1 : 0;
   if (const char *f = getenv("MJPL_TAIL")) e->fused_tail = atoi(f) != 0;
+  if (const char *f = getenv("MJPL_FUSED")) e->fused = atoi(f) != 0;
+  if (const char *f = getenv("MJPL_FUSED_WAVES")) e->fused_waves = atoi(f) == 6 ? 6 : kFusedWaves;
+  if (const char *f = getenv("MJPL_FUSED_POLICY")) e->fused_policy = atoi(f);
+  e->fused_dbg_path = getenv("MJPL_FUSED_DEBUG");
+  if (const char *f = getenv("MJPL_FUSED_KMAX")) e->fused_kmax = std::max(2, std::min(atoi(f), 1 << 16));
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
   if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));
   if (const char *t = getenv("MJPL_FILTER_TOL")) {
@@ -1985,6 +2090,17 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
 }
 
 void mjpl_destroy(mjpl_engine *e) {
+  if (e && e->d_fused_dbg && e->fused_dbg_path) {
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    std::vector<unsigned long long> h(kFusedDbgWaves * 8);
+    if (hipMemcpy(h.data(), e->d_fused_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess)
+      if (FILE *f = fopen(e->fused_dbg_path, "wb")) {
+        fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+        fclose(f);
+      }
+    (void)hipFree(e->d_fused_dbg);
+  }
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -2053,6 +2169,12 @@ int mjpl_program_dump(const mjpl_model_desc *d, const int32_t *allowed_bodies, i
   memcpy(fp, e->fp.data(), e->fp.size() * sizeof(float));
   if (dp) memcpy(dp, e->dp.data(), e->dp.size() * sizeof(double));
   return MJPL_OK;
+}
+
+int mjpl_spec_probe(uint64_t hash, int32_t generic) {
+  if (const char *s = getenv("MJPL_SPEC"))
+    if (atoi(s) == 0) return 0;
+  return find_spec(hash, generic != 0) ? 1 : 0;
 }
 
 int mjpl_spec_loaded(const mjpl_engine *e) { return (e && e->spec) ? (e->spec_generic ? 2 : 1) : 0; }
@@ -2157,6 +2279,11 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
                                          e->immediate() ? sizeof(double) : sizeof(float));
   out->persistent_kernels = ((e->persist < 0 ? e->spec != nullptr : e->persist != 0) && e->two_pass && e->expand && !e->immediate()) ? 1 : 0;
   out->fused_tail = (e->fused_tail && e->two_pass && e->expand && !e->immediate()) ? 1 : 0;
+  {
+    int nw = 0;
+    out->fused_edges = fused_plan(e, &nw, nullptr) ? 1 : 0;
+    out->fused_waves = out->fused_edges ? nw : 0;
+  }
   out->block_threads = kBlock;
   out->compute_units = e->prop.multiProcessorCount;
   strncpy(out->arch, e->prop.gcnArchName, sizeof(out->arch) - 1);
@@ -2198,7 +2325,7 @@ int mjpl_take_status(mjpl_engine *e, int32_t *status) {
   HIP_TRY(hipMemcpyAsync(&s, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  if (s & kStatusTailTimeout) return fail(MJPL_E_HIP, "the tail kernel gave up waiting for its walking workgroups");
+  if (s & (kStatusTailTimeout | kStatusFusedTimeout)) return fail(MJPL_E_HIP, "a kernel of the edge pipeline gave up waiting (status %d: 2 = the tail kernel for its walking workgroups, 4 = a wave of the fused kernel for its work pool)", s);
   *status = (s & kStatusNonFinite) ? MJPL_E_NONFINITE : MJPL_OK;
   return MJPL_OK;
 }
@@ -2436,7 +2563,7 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
     if (first_bad) memcpy(first_bad, hout + vb, fbb);
     int status = 0;
     memcpy(&status, hout + vb + fbb, sizeof(int));
-    if (status & kStatusTailTimeout) return fail(MJPL_E_HIP, "the tail kernel gave up waiting for its walking workgroups");
+    if (status & (kStatusTailTimeout | kStatusFusedTimeout)) return fail(MJPL_E_HIP, "a kernel of the edge pipeline gave up waiting (status %d: 2 = the tail kernel for its walking workgroups, 4 = a wave of the fused kernel for its work pool)", status);
     if (status & kStatusNonFinite)
       return fail(MJPL_E_NONFINITE, "an edge holds NaN/inf or needs more than %d waypoints", kMaxWaypoints);
     return MJPL_OK;
@@ -2465,7 +2592,7 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
     if (first_bad) memcpy(first_bad, hout + vb, fbb);
     int status = 0;
     memcpy(&status, hout + vb + fbb, sizeof(int));
-    if (status & kStatusTailTimeout) return fail(MJPL_E_HIP, "the tail kernel gave up waiting for its walking workgroups");
+    if (status & (kStatusTailTimeout | kStatusFusedTimeout)) return fail(MJPL_E_HIP, "a kernel of the edge pipeline gave up waiting (status %d: 2 = the tail kernel for its walking workgroups, 4 = a wave of the fused kernel for its work pool)", status);
     if (status & kStatusNonFinite)
       return fail(MJPL_E_NONFINITE, "an edge holds NaN/inf or needs more than %d waypoints", kMaxWaypoints);
     return MJPL_OK;
@@ -2485,7 +2612,7 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
   if (first_bad) HIP_TRY(hipMemcpyAsync(first_bad, e->stage[3], (size_t)E * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemcpyAsync(&status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  if (status & kStatusTailTimeout) return fail(MJPL_E_HIP, "the tail kernel gave up waiting for its walking workgroups");
+  if (status & (kStatusTailTimeout | kStatusFusedTimeout)) return fail(MJPL_E_HIP, "a kernel of the edge pipeline gave up waiting (status %d: 2 = the tail kernel for its walking workgroups, 4 = a wave of the fused kernel for its work pool)", status);
   if (status & kStatusNonFinite)
     return fail(MJPL_E_NONFINITE, "an edge holds NaN/inf or needs more than %d waypoints", kMaxWaypoints);
   return MJPL_OK;

@@ -282,8 +282,9 @@ k_nearest_part32(const double *__restrict__ nodes, int64_t n, int64_t cap, const
 // 0.02 rad of the bound: a quarter of a tree whose chains all start at one root.  A node at +inf gives +inf or NaN,
 // which v_min3 and the ordered compare ignore: never nearest, as in the other kernels.  Two lanes share a query
 // (rows 4h .. 4h+3 of every eight: h = lane / 32), each keeps its own best; the reduction breaks ties by index.
-// Coordinates of 256 or more (or NaN) anywhere: k_nn_pack raises a flag, this kernel returns at once and the
-// binary32 screen above does the work.  nplan <= 7.
+// Coordinates of 256 or more (or NaN) anywhere, or a finite node whose squared norm does not fit binary16
+// (>= 65504): k_nn_pack raises a flag, this kernel returns at once and the binary32 screen above does the work.
+// nplan <= 7.
 typedef _Float16 nn_h8 __attribute__((ext_vector_type(8)));
 typedef float nn_f16 __attribute__((ext_vector_type(16)));
 constexpr int kNNMSets = 4, kNNMWaves = 4;              // 32-query sets per wave, waves per workgroup
@@ -335,6 +336,10 @@ k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int
       out16[4 * i + 2] = lo.u[0];
       out16[4 * i + 3] = lo.u[1];
     } else {
+      // |x~|^2 travels as two binary16 numbers: beyond binary16's largest finite value (65504: one coordinate of
+      // 256, or seven of 97) n1 would be +inf, the rest -inf and the instruction's sum NaN -- a node that can
+      // never pass the screen although it may be the nearest.  Such a call belongs to the binary32 screen.
+      if (n2 < std::numeric_limits<float>::infinity() && !(n2 < 65504.0f)) wild = true;
       const _Float16 n1 = (_Float16)n2;
       const float rest = n2 - (float)n1;  // exact; |rest| <= 2^-11 n2
       hi.h[7] = n1;

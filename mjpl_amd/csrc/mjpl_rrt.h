@@ -25,6 +25,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <mutex>
 
 namespace {
 
@@ -534,11 +535,12 @@ struct Rccl {
   const char *(*GetErrorString)(int) = nullptr;
 };
 
+// (every engine of the process shares the one table: std::call_once, so that two threads creating their
+// first communicators together load the library once and both see the filled table)
 Rccl *rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] {
     for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (r.lib) break;
@@ -551,7 +553,7 @@ Rccl *rccl() {
       r.GetErrorString = (const char *(*)(int))dlsym(r.lib, "ncclGetErrorString");
       if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { dlclose(r.lib); r.lib = nullptr; }
     }
-  }
+  });
   return r.lib ? &r : nullptr;
 }
 
@@ -663,6 +665,17 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   // no copy, no event, the host spins on a sequence word.
   if (projecting && r->cd.cap < L) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer too small for one step per lane");
   int chunks_done = 0;
+  // Sequence numbers of the pinned ring never repeat -- on ANY way out of this function: an extension that
+  // fails half-way has k_rrt_accept launches in flight that still write their slots, and the next extension
+  // on this planner must neither meet their numbers again nor find a stale slot that already carries the
+  // number it waits for.  A failing exit therefore also waits for the stream before the numbers move on.
+  struct RingGuard {
+    mjpl_rrt *r; const int *chunks; hipStream_t st; bool ok;
+    ~RingGuard() {
+      if (!ok) (void)hipStreamSynchronize(st);
+      r->ring_seq0 += *chunks + 8;
+    }
+  } ring_guard{r, &chunks_done, st, false};
   int active_bound = L;  // (projecting) no more lanes than this are active in the chunk about to be launched
   for (int chunk = 0;; chunk++) {
     chunks_done = chunk + 1;
@@ -728,7 +741,6 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     }
   }
   tr.mark(st, "extension chunks", chunks_done);
-  r->ring_seq0 += chunks_done + 8;  // (sequence numbers of the pinned ring never repeat)
   // node order of the extension: lanes ascending, levels ascending within a lane
   {
     const int nsb = (L + kScanBlock - 1) / kScanBlock;
@@ -738,6 +750,12 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   }
   if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
   if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
+  {  // the validation launches of this extension never synchronised: a tail kernel that gave up waiting says so here
+    int vstatus = 0;
+    HIP_TRY(hipMemcpyAsync(&vstatus, e->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (vstatus & (kStatusTailTimeout | kStatusFusedTimeout)) return fail(MJPL_E_HIP, "rrt: a kernel of a validation launch gave up waiting (status %d)", vstatus);
+  }
   const int nacc = r->h_ctr[RC_ACC];
   *nnew = nacc;
   if (nacc > r->pendcap) return fail(MJPL_E_CAPACITY, "rrt: %d new nodes in one extension, pending slab holds %d", nacc, r->pendcap);
@@ -748,6 +766,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
                      second ? (double *)nullptr : r->ln.RA);
   HIP_TRY(hipGetLastError());
   tr.mark(st, "scan, place, finish", nacc);
+  ring_guard.ok = true;
   return MJPL_OK;
 }
 

@@ -53,7 +53,7 @@ class Info(C.Structure):
         ("arch", C.c_char * 32),
         ("filter_max_coord", C.c_float), ("filter_err_a", C.c_float), ("filter_err_b", C.c_float),
         ("filter_poisoned_geoms", C.c_int32), ("filter_interpreter", C.c_int32),
-        ("persistent_kernels", C.c_int32), ("fused_tail", C.c_int32),
+        ("persistent_kernels", C.c_int32), ("fused_tail", C.c_int32), ("fused_edges", C.c_int32), ("fused_waves", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -155,6 +155,7 @@ ABI = {
     "mjpl_comm_destroy": (C.c_int, [_VP]),
     "mjpl_allgather_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     "mjpl_program_dump": (C.c_int, None),   # bound in mjpl_amd/specialise.py
+    "mjpl_spec_probe": (C.c_int, [C.c_uint64, C.c_int32]),
     "mjpl_spec_loaded": (C.c_int, [_VP]),
     "mjpl_set_spec": (C.c_int, [_VP, C.c_int32]),
     "mjpl_device_count": (C.c_int, []),

@@ -27,6 +27,7 @@ import ctypes as C
 import math
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -758,6 +759,7 @@ def generate_exact(ip, dp, info, generic: bool = False) -> str:
 _TU = """// GENERATED translation unit: the float32 filter kernels of mjpl_filter.h around one model's Spec.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "mjpl_filter.h"
 
 namespace {
@@ -767,10 +769,11 @@ namespace {
 
 using namespace mjpl;
 #define SPEC_GRANT(kern)                                                                            \\
-  static size_t granted = 0;                                                                        \\
-  if (lds > granted) {                                                                              \\
+  static std::atomic<size_t> granted{0};  /* (engines of several threads share the library) */      \\
+  if (lds > granted.load(std::memory_order_relaxed)) {                                              \\
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1; \\
-    granted = lds;                                                                                  \\
+    size_t have = granted.load(std::memory_order_relaxed);                                          \\
+    while (have < lds && !granted.compare_exchange_weak(have, lds, std::memory_order_relaxed)) {}   \\
   }
 #define SPEC_LAUNCH(kern, ...)                                                                      \\
   do {                                                                                              \\
@@ -830,6 +833,22 @@ int mjpl_spec_launch_tail(hipStream_t st, size_t lds, TailArgs a) {
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.nw + a.np + a.nx)), dim3(kBlock), lds, st, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+// the whole float32 filter of an edge launch as one kernel (mjpl_fused.h); nwaves: wavefronts per workgroup
+int mjpl_spec_launch_fused(hipStream_t st, int nwaves, size_t lds, FusedArgs a) {
+  const long long ntile = (a.E + 63) / 64;
+  if (nwaves == 12) {
+    auto kern = k_edges_fused<Spec, %(maxs)d, %(wbox)s, false, 12>;
+    SPEC_GRANT(kern);
+    hipLaunchKernelGGL(kern, dim3(fused_grid(kern, 12 * 64, lds, ntile)), dim3(12 * 64), lds, st, a);
+  } else if (nwaves == 6) {
+    auto kern = k_edges_fused<Spec, %(maxs)d, %(wbox)s, false, 6>;
+    SPEC_GRANT(kern);
+    hipLaunchKernelGGL(kern, dim3(fused_grid(kern, 6 * 64, lds, ntile)), dim3(6 * 64), lds, st, a);
+  } else {
+    return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const double *dp,
                            int ndp, GeomTable gt, UndecidedConfigs uc, uint8_t *valid, int32_t *first_bad) {
   SPEC_LAUNCH((k_patch_pairs<ExactSpec>), ip, nip, dp, ndp, gt, uc, valid, first_bad);
@@ -854,7 +873,7 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
     os.makedirs(SPEC_DIR, exist_ok=True)
     key = info.robot_hash if generic else info.hash
     target = output or spec_path(key, generic)  # (output, extra_flags: timing-only variants, tools/time_variants.sh)
-    deps = [os.path.join(_build.CSRC, f) for f in ("mjpl_filter.h", "mjpl_device.h", "mjpl_trig.h")] + [__file__]
+    deps = [os.path.join(_build.CSRC, f) for f in _build.STAMPED_HEADERS] + [__file__]
     if not force and os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
         return target
     nstage = 0
@@ -867,17 +886,29 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
     src = _TU % dict(spec=generate(ip, fp, dp, info, generic=generic), exact=generate_exact(ip, dp, info, generic=generic), hash=key,
                      maxs=info.maxs, wbox="true" if (info.wbox or generic) else "false",
                      generic=(SCENE_ROWS << 8 | nstage) if generic else 0)  # (kSceneRows, moving geoms)
+    # Source and library appear under their final names complete or not at all (os.replace): an engine created
+    # while a rebuild is running finds the old library or the new one, never half a file -- a failed dlopen would
+    # be remembered as "no library" for the life of that process -- and two builds of one hash cannot interleave.
     src_path = os.path.join(SPEC_DIR, f"spec{'g' if generic else ''}_{key:016x}.hip")
-    with open(src_path, "w") as f:
+    tag = f".tmp{os.getpid()}_{threading.get_ident():x}"
+    src_tmp = src_path[:-4] + tag + ".hip"
+    lib_tmp = target + tag
+    with open(src_tmp, "w") as f:
         f.write(src)
     # -fno-slp-vectorize: left alone, the SLP vectoriser pairs the scalar binary32 arithmetic of the generated
     # code into v_pk_* instructions -- which issue no faster than the two instructions they replace -- at the
     # price of ~700 v_mov to assemble the pairs and of spilled registers: 0.279 -> 0.259 ms per step
     cmd = [_build.hipcc(), *_build.hipcc_flags(), "-fno-slp-vectorize", "-Wno-unused-variable", "-Wno-unused-but-set-variable", f"-I{_build.CSRC}",
-           *extra_flags, "-o", target, src_path]
-    subprocess.run(cmd, check=True)
-    if not keep_source:
-        os.remove(src_path)
+           *extra_flags, "-o", lib_tmp, src_tmp]
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(lib_tmp, target)
+        if keep_source:
+            os.replace(src_tmp, src_path)
+    finally:
+        for leftover in (lib_tmp, src_tmp):
+            if os.path.exists(leftover):
+                os.remove(leftover)
     return target
 
 

@@ -226,6 +226,36 @@ def test_nearest_neighbour_kernel():
         dn3, dq3 = e.alloc(nodes3.nbytes).upload(nodes3), e.alloc(q3.nbytes).upload(q3)
 
 
+@pytest.mark.parametrize("scale,screen", [(30.0, 2), (96.0, 2), (110.0, 1), (250.0, 1)])
+def test_nearest_neighbour_large_coordinates(scale, screen):
+    """Coordinates below the 256 limit of the matrix-core screen but whose squared norms leave binary16's range
+    (65504: seven coordinates of 97, one of 256): the node norm travels as two binary16 numbers, and a node beyond
+    that range would turn into inf - inf = NaN inside the instruction and never pass the screen.  Such a call
+    must be served by the binary32 screen; either way the winners are the float64 scan's."""
+    m = scenes.franka_p()
+    e = eng_mod.Engine(m)
+    e.set_planning(scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos)
+    rng = np.random.default_rng(int(scale))
+    n, M = 270000, 16400
+    nodes = rng.uniform(0.3 * scale, scale, size=(7, n)) * rng.choice([-1.0, 1.0], size=(7, n))
+    # with the largest scales EVERY node's squared norm is beyond binary16: nothing would pass a broken screen
+    qs = nodes[:, rng.integers(0, n, M)] + rng.normal(scale=0.02 * scale, size=(7, M))
+    qs = np.clip(qs, -scale, scale)
+    dn, dq = e.alloc(nodes.nbytes).upload(nodes), e.alloc(qs.nbytes).upload(qs)
+    di, dd = e.alloc(4 * M), e.alloc(8 * M)
+    e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
+    got, gd = di.download(np.int32, M), dd.download(np.float64, M)
+    assert e.nearest_last_screen() == screen
+    assert (got >= 0).all()
+    sel = rng.integers(0, M, 160)
+    s = np.zeros((len(sel), n))
+    for c in range(7):  # the kernel's sum order
+        d = nodes[c][None, :] - qs[c][sel][:, None]
+        s = s + d * d
+    np.testing.assert_array_equal(got[sel], s.argmin(1))
+    np.testing.assert_array_equal(gd[sel], s.min(1))
+
+
 @pytest.mark.parametrize("nplan", [2, 3, 5, 6])
 def test_nearest_neighbour_matrix_core_screen_for_other_planning_sets(nplan):
     """The screened scan for planning sets other than the arm's seven joints (the operand rows keep seven coordinate
