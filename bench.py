@@ -569,8 +569,66 @@ def bench_rrt(args, world):
             path_ok = bool(ok_edges.all() and np.all(pc.valid_configs(full)))
             if not path_ok:
                 raise SystemExit("bench: the planner's path fails the oracle's collision check / the pose constraint")
+        # ---- roofline of a round.  A round is ~60 launches of a dozen kernels; 80 % of its GPU time is k_rrt_gen_project, a
+        # float64 chain per lane (profiles/r03u_rrt_kernel_stats.csv, r04*_rrt_kernel_stats.csv): latency of that chain binds,
+        # not HBM.  Algorithmic bytes of a round: per sample its target read and what it reached written
+        # (2 x 8 nplan + 11 B), per new node its row and parent written (8 nplan + 4 B), and the two nearest-neighbour scans
+        # (row f2: 8 nplan B per node per 512-query tile).
+        nn_bytes = sum(int(n) for n in info.nodes) * 8 * nplan * ((L + 511) // 512)
+        round_bytes = L * (2 * 8 * nplan + 11) + (new_nodes / max(done, 1)) * (8 * nplan + 4) + nn_bytes
+        round_s = slowest / done
+        roofline = {"bound": "hbm", "achieved": round_bytes / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round_bytes / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "whole round (k_rrt_gen_project holds ~80 % of its GPU time)",
+                    "kernel_ms": round_s * 1e3, "algorithmic_bytes_per_round": round_bytes,
+                    "of_which_nearest_neighbour_scans": nn_bytes,
+                    "note": "latency bound: one lane's float64 Newton chain per projection step (DESIGN.md section 7); the HBM figure is "
+                            "what north_star asks for, over the whole round because its kernels are not bracketed by events one by one"}
+        cpu = None
+        if not args.no_cpu_baseline:
+            # the same algorithm stated in NumPy (mjpl_amd.planning.parallel_rrt.ParallelBiRRT: what the GPU planner's trees are
+            # compared with node for node in tests/test_gpu_rrt.py) with the CPU oracle behind every constraint, on a bounded
+            # sample: 512 lanes per round from the same start to the same goal, until it connects or 15 s have passed
+            from mjpl_amd.lie import SE3, SO3
+            from mjpl_amd.planning.parallel_rrt import EdgeValidator, ParallelBiRRT
+            cpu_model, cores, aff, quota = host_cpu()
+            ident = pyoracle.PoseOracle(m, "ee_site", (np.array([1.0, 0, 0, 0]), np.zeros(3)), [(-np.inf, np.inf)] * 6)
+            pos, mat = ident.site_pose(q_init)
+            inv = SE3.from_rotation_and_translation(SO3.from_matrix(mat), pos).inverse()
+            unb = (-np.inf, np.inf)
+            po = pyoracle.PoseOracle(m, "ee_site", (inv.wxyz_xyz[:4], inv.wxyz_xyz[4:]), [unb, unb, unb, (-0.1, 0.1), (-0.1, 0.1), unb], q_step=0.05)
+            orc = pyoracle.Oracle(m, planning_qidx=qidx, qpos_base=q_init)
+
+            class OracleSet(EdgeValidator):  # [PoseConstraint, JointLimit, Collision] on the oracle
+                def full(self, Qp):
+                    F = np.repeat(q_init[None], len(Qp), axis=0)
+                    F[:, qidx] = Qp
+                    return F
+
+                def valid_edges(self, QA, QB, step):
+                    if step is None:
+                        ok = orc.valid_configs(QB, nthreads=cores).astype(bool)
+                        return ok & np.array([po.valid_config(r) for r in self.full(QB)], dtype=bool)
+                    return orc.valid_edges(QA, QB, step, nthreads=cores).astype(bool)
+
+                def project(self, Q_old, Q):
+                    o, ok, _ = po.apply_batch(self.full(Q_old), self.full(Q), nthreads=cores)
+                    return o[:, qidx], ok
+
+            lanes_cpu = 512
+            host = ParallelBiRRT(m, joints, OracleSet(), q_init, epsilon=0.05, interval_step=0.01, seed=3, batch=lanes_cpu,
+                                 goal_biasing_probability=0.05, max_planning_time=15.0)
+            tc = time.perf_counter()
+            cpath = host.plan_to_config(q_init, q_goal)
+            dtc = time.perf_counter() - tc
+            cpu = {"value": lanes_cpu * host.stats["rounds"] / dtc, "unit": "samples/s", "cores": cores, "kind": "port",
+                   "cpu_model": cpu_model, "affinity": aff, "cpu_quota": quota,
+                   "sample": f"{host.stats['rounds']} rounds of {lanes_cpu} lanes ({dtc:.1f} s, {'connected' if cpath else 'time limit'}), "
+                             f"trees of {tuple(int(x) for x in host.stats['nodes'])} nodes: ParallelBiRRT (NumPy) with oracle/libmjpl_oracle.so "
+                             f"validating and projecting on {cores} threads"}
         _flush_c_stdio()
         print(json.dumps({
+            "roofline": roofline, "cpu_baseline": cpu,
             "metric": "RRT samples/sec through the frontier bi-RRT (BASELINE configs[3]: 131 072 samples per GPU per round)",
             "value": L * world.world * done / slowest, "unit": "samples/s", "n_gpus": world.world, "steps": done, "warmup": 1,
             "ms_per_step": slowest / done * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -670,8 +728,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--edges", type=int, default=EDGES_PER_GPU)
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="edges workload: engines (HIP streams) that take the steps in turns -- batches in flight per GPU")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="edges workload: engines (HIP streams) that take the steps in turns -- batches in flight per GPU. "
+                         "The line's value is ONE engine on one stream (what every caller of mjpl_check_edges_dev gets); "
+                         "the line also carries `in_turns`, the same steps taken in turns by three engines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="edges workload: skip the float64-only and interpreter engines timed beside the headline")
@@ -751,7 +811,8 @@ def main():
         import threading
         engs = engs_default if engs is None else engs
         outs = outs_default if outs is None else outs
-        res = [None] * S
+        n_eng = len(engs)
+        res = [None] * n_eng
         errs = []
         go = threading.Event()
 
@@ -761,7 +822,7 @@ def main():
                 res[k] = engs[k].time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, outs[k].ptr, steps_of[k], sample)
             except Exception as ex:  # noqa: BLE001 -- reported below, on the main thread
                 errs.append(ex)
-        th = [threading.Thread(target=one, args=(k,)) for k in range(1, S) if steps_of[k] > 0]
+        th = [threading.Thread(target=one, args=(k,)) for k in range(1, n_eng) if steps_of[k] > 0]
         for t in th:
             t.start()
         stamp = before() if before else None
@@ -808,35 +869,71 @@ def main():
         total_edges = E * world.world * args.steps
         value = total_edges / elapsed
         filt = bool(info["filter_enabled"])
-        spec = bool(eng.spec_loaded())
+        spec = eng.spec_kind()  # 0 interpreting kernels, 1 the program's own library, 2 the robot's scene-generic one
         interior = eng.last_interior_edges() if filt else 0
         items = eng.last_items() if filt else 0
         undecided = eng.last_undecided()
+        fused = bool(filt and info.get("fused_edges"))
         # units and SURVEY.md 8(d) algorithmic bytes of every kernel of a step:
-        #   endpoint pass: one edge = 2 x 56 B of columns read + 1 B verdict (113 B)
-        #   item pass:     one waypoint configuration = 56 B + 1 B (57 B per check) + its 8 B (edge, index)
-        #   walking pass:  one edge, 113 B + the 4 B list entry
+        #   fused filter:  one edge = 2 x 56 B of columns read + 1 B verdict (113 B); its waypoints are generated on chip
+        #   endpoint pass: the same 113 B per edge;  item pass: one waypoint configuration = 57 B + its 8 B (edge, index)
+        #   walking pass:  one edge, 113 B + the 4 B list entry;  pair re-check: 56 B + 16 B per undecided pair
         per_stage = {"k_filter_endpoints": (E, BYTES_PER_EDGE, "edges"),
-                     "k_filter_items": (items, 57 + 8, "waypoint configurations"),
+                     "k_filter_items": (0 if fused else items, 57 + 8, "waypoint configurations"),
                      "k_filter_edges": (max(interior - 0, 0) if items == 0 else 0, BYTES_PER_EDGE + 4, "edges"),
                      "k_patch_pairs": (undecided, 56 + 16, "undecided geom pairs"),
                      "k_check_edges": (E if not filt else 0, BYTES_PER_EDGE, "edges")}
         # kernel names as a profiler shows them for this engine's launch layout
-        names = {}
-        if filt and info.get("persistent_kernels"):
-            names.update({"k_filter_endpoints": "k_filter_endpoints_pw", "k_filter_items": "k_filter_items_pw"})
-        if filt and info.get("fused_tail"):
-            names["k_patch_pairs"] = "k_tail"
+
+        def stage_names(inf, with_filter):
+            n = {}
+            if with_filter and inf.get("fused_edges"):
+                n["k_filter_endpoints"] = "k_edges_fused"
+            elif with_filter and inf.get("persistent_kernels"):
+                n.update({"k_filter_endpoints": "k_filter_endpoints_pw", "k_filter_items": "k_filter_items_pw"})
+            if with_filter and inf.get("fused_tail"):
+                n["k_patch_pairs"] = "k_tail"
+            return n
+        names = stage_names(info, filt)
         stage_ms = {names.get(k, k): v for k, v in stage_ms.items()}
         per_stage = {names.get(k, k): v for k, v in per_stage.items()}
-        # the dominant kernel of THIS run = the longest stage
-        kernel = max(stage_ms, key=lambda k: stage_ms[k])
-        kernel_ms = stage_ms[kernel]
+        # The dominant kernel and its duration: HIP events around the kernel ALONE on the chip -- this run's own with one
+        # stream; with several streams the events of the timed region bracket kernels that share the chip, so the
+        # kernel's figure comes from the same steps taken on one engine (one_stream), never from the overlapped ones.
+        alone_ms = stage_ms if S == 1 else {names.get(k, k): v for k, v in one_stream["kernels_ms"].items()}
+        kernel = max(alone_ms, key=lambda k: alone_ms[k])
+        kernel_ms = alone_ms[kernel]
         units, unit_bytes, unit_name = per_stage[kernel]
         achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9
         prof = profile_record(kernel, E, args.layout, filt, spec)
         workload = (f"configs[2]: Franka-P 7-DoF + 16 box/sphere obstacles + floor, {E} edges/GPU, "
                     f"eps {EPS}, step {STEP} (endpoint + interior waypoints per edge)")
+        # what binds: vector-ALU issue (not HBM, not MFMA) -- SQ_INSTS_VALU wave-instructions of the committed
+        # counter pass of this kernel / (its duration alone x the chip's issue slots per second)
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": prof.get("hbm_bytes_per_launch"),
+               "algorithmic_bytes_per_unit": unit_bytes, "units_in_this_kernel": units, "unit_of_work": unit_name,
+               "whole_step": {"algorithmic_bytes": BYTES_PER_EDGE * E,
+                              "achieved_GBs": BYTES_PER_EDGE * E * args.steps / elapsed / 1e9,
+                              "frac": BYTES_PER_EDGE * E * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+               "note": "the figure north_star asks for; the path is not HBM bound (SURVEY.md 8d): 113 algorithmic bytes per edge "
+                       "against ~22 600 flop"}
+        roof = {"kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms if S == 1 else one_stream["step_ms_all_kernels"],
+                "kernels_ms": alone_ms, "kernel_samples": nsamp, "streams_of_these_durations": 1,
+                "kernel_ms_source": "HIP events on the engine's own stream around every kernel of every 4th launch, nothing else on the chip"
+                                    + ("" if S == 1 else " (the one_stream run of this line; the timed region overlaps kernels of several engines)"),
+                "hbm": hbm}
+        if prof.get("SQ_INSTS_VALU"):
+            iv = float(prof["SQ_INSTS_VALU"])
+            roof.update({"bound": "valu_issue", "achieved": iv / (kernel_ms * 1e-3), "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
+                         "frac": iv / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK, "traffic": prof.get("hbm_bytes_per_launch"),
+                         "wave_insts_valu_per_launch": iv, "wave_insts_salu_per_launch": prof.get("SQ_INSTS_SALU"),
+                         "counters_source": prof.get("source"),
+                         "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md, Wave "
+                                 "scheduling); the HBM figure north_star asks for is in `hbm`"})
+        else:  # no committed counter pass for this kernel / configuration: the HBM object alone
+            roof.update({k: hbm[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")})
+            roof["note"] = "no committed SQ_INSTS_VALU record for this kernel and configuration (profiles/pmc.json): HBM figure only"
         out = {
             "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -848,12 +945,14 @@ def main():
             "config": {"workload": workload, "edges_per_gpu": E, "layout": args.layout,
                        "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
                        "float32_filter": filt, "filter_tol_m": info["filter_tol"],
-                       "specialised_kernels": spec,
+                       "specialised_kernels": bool(spec), "library": {0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[spec],
                        "streams": S, "batches_in_flight": S,
                        "streams_note": (f"{S} engines (one HIP stream and one scratch set each) take the steps in turns: the kernels of "
                                         "consecutive batches overlap; ms_per_step = elapsed / steps; one_stream = the same steps on one engine")
-                                       if S > 1 else "one engine, one stream",
+                                       if S > 1 else "one engine, one stream: what every caller of mjpl_check_edges_dev gets",
+                       "fused_edges": fused, "fused_waves_per_workgroup": info.get("fused_waves"),
                        "persistent_kernels": bool(info.get("persistent_kernels")), "fused_tail": bool(info.get("fused_tail")),
+                       "kernels_per_launch": len([k for k in stage_ms if stage_ms[k] > 0.008]),
                        "undecided_items_last_step": undecided,
                        "edges_reaching_interior_pass": interior, "interior_waypoint_items": items,
                        "parallelism": f"edge-sharded x{world.world}, no data-path collective",
@@ -862,22 +961,8 @@ def main():
                        "collectives": "none on the GPUs: barrier + max of the elapsed time over the ranks' Unix socket"
                                       if world.distributed else None,
                        "ranks_share_a_gpu": os.environ.get("MJPL_BENCH_SHARE_GPU") == "1" and world.distributed},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": prof.get("hbm_bytes_per_launch"),
-                         "kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms,
-                         "kernels_ms": stage_ms, "kernel_samples": nsamp, "streams": S,
-                         "kernel_ms_note": ("durations between HIP events on the kernels' own streams while the other stream's kernels share "
-                                            "the chip: longer than the kernel alone (one_stream.kernels_ms)") if S > 1 else None,
-                         "algorithmic_bytes_per_unit": unit_bytes, "units_in_this_kernel": units,
-                         "unit_of_work": unit_name,
-                         "whole_step": {"algorithmic_bytes": BYTES_PER_EDGE * E,
-                                        "achieved_GBs": BYTES_PER_EDGE * E * args.steps / elapsed / 1e9,
-                                        "frac": BYTES_PER_EDGE * E * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
-                         "note": "vector-issue / latency bound, not HBM bound (SURVEY.md 8d); see valu_issue"},
+            "roofline": roof,
         }
-        # vector-ALU issue occupancy of the dominant kernel, from the committed counter pass:
-        # SQ_INSTS_VALU wave-instructions per launch / (kernel time x issue slots per second)
         def valu_issue(kern, ms, rec):
             if not rec.get("SQ_INSTS_VALU"):
                 return None
@@ -885,14 +970,8 @@ def main():
             return {"kernel": kern, "wave_insts_valu_per_launch": iv,
                     "wave_insts_salu_per_launch": rec.get("SQ_INSTS_SALU"),
                     "achieved_per_s": iv / (ms * 1e-3), "peak_per_s": VALU_ISSUE_PEAK,
-                    "frac": iv / (ms * 1e-3) / VALU_ISSUE_PEAK, "source": rec.get("source"),
-                    "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU "
-                            "instruction (MI355X_MICROARCH.md, Wave scheduling)"}
-        # (the kernel's own rate: its duration alone on the chip, as the counter passes ran it)
-        out["valu_issue"] = valu_issue(kernel, one_stream["kernels_ms"].get(
-            {"k_filter_endpoints_pw": "k_filter_endpoints", "k_filter_items_pw": "k_filter_items", "k_tail": "k_patch_pairs"}.get(kernel, kernel),
-            kernel_ms) if one_stream else kernel_ms, prof)
-        # ... and of the chip over a whole step: the vector instructions of all its kernels / the time a step takes
+                    "frac": iv / (ms * 1e-3) / VALU_ISSUE_PEAK, "source": rec.get("source")}
+        # the vector-issue rate of the chip over a whole step: the vector instructions of all its kernels / the time a step takes
         recs = [profile_record(k, E, args.layout, filt, spec) for k in stage_ms]
         if all(r.get("SQ_INSTS_VALU") for r, k in zip(recs, stage_ms) if stage_ms[k] > 0.01):
             iv = sum(float(r.get("SQ_INSTS_VALU", 0.0)) for r in recs)
@@ -900,6 +979,24 @@ def main():
                                             "frac": iv / (elapsed / args.steps) / VALU_ISSUE_PEAK, "peak_per_s": VALU_ISSUE_PEAK,
                                             "kernels": [k for k in stage_ms if stage_ms[k] > 0.01]}
         out["one_stream"] = one_stream
+        if S == 1 and world.world == 1 and not args.no_variants and args.variant == "headline":
+            # ... and the same steps taken in turns by three engines (three HIP streams: batches in flight): what a caller
+            # with several batches to validate can add on top (mjpl_amd.engine.EngineRing); never the line's value
+            T = 3
+            tsteps = max(60, min(args.steps, 600))
+            tengs = [eng] + [make_engine(*timed) for _ in range(T - 1)]
+            touts = [dvalid] + [x.alloc(E) for x in tengs[1:]]
+            tshare = [tsteps // T + (1 if k < tsteps % T else 0) for k in range(T)]
+            run_all([5] * T, 1 << 30, None, tengs, touts)
+            tv, _ = run_all(tshare, 1 << 30, time.perf_counter, tengs, touts)
+            dtv = time.perf_counter() - tv
+            if not all(np.array_equal(o.download(np.uint8, E), valid) for o in touts):
+                sys.exit("bench.py: an engine of the in-turns run returned other verdicts than the line's engine")
+            out["in_turns"] = {"value": E * tsteps / dtv, "unit": "edges/s", "streams": T, "steps": tsteps, "ms_per_step": dtv / tsteps * 1e3,
+                               "note": "three engines of this model, one HIP stream each, taking the steps in turns; verdicts equal"}
+            for x, o in zip(tengs[1:], touts[1:]):
+                o.free()
+                x.close()
 
         # ---- the same batch through the other two engine configurations, in this process: the float64
         # kernels alone (the reference's arithmetic end to end) and the generic interpreting filter kernels
@@ -921,11 +1018,7 @@ def main():
                 if not same:
                     sys.exit(f"bench.py: the {name} engine's verdicts differ from the headline engine's")
                 vinfo = ve.info()
-                vnames = {}
-                if vf and vinfo.get("persistent_kernels"):
-                    vnames.update({"k_filter_endpoints": "k_filter_endpoints_pw", "k_filter_items": "k_filter_items_pw"})
-                if vf and vinfo.get("fused_tail"):
-                    vnames["k_patch_pairs"] = "k_tail"
+                vnames = stage_names(vinfo, vf)
                 v_stage = {vnames.get(k, k): v for k, v in v_stage.items()}
                 vk = max(v_stage, key=lambda k: v_stage[k])
                 rec = profile_record(vk, E, args.layout, vf, ve.spec_kind() if vs else 0)  # (s1: the program's own library, s2: the robot's)
@@ -948,8 +1041,12 @@ def main():
                                   "streams": 1,  # (compare with one_stream; in_turns compares with the line's value)
                                   "in_turns": in_turns,
                                   "step_ms_all_kernels": v_launch, "kernels_ms": v_stage, "dtype": "f64" if not vf else "f32-filter+f64-exact",
-                                  "float32_filter": bool(ve.info()["filter_enabled"]), "specialised_kernels": bool(ve.spec_loaded()),
-                                  "library": {0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[ve.spec_kind()],
+                                  "float32_filter": bool(ve.info()["filter_enabled"]),
+                                  # (with the filter off no kernel of a per-model library runs, whatever the engine has loaded)
+                                  "specialised_kernels": bool(ve.spec_loaded()) and vf,
+                                  "library": ({0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[ve.spec_kind()]
+                                              if vf else "none: k_check_edges, the interpreting float64 kernel of libmjpl_hip.so, is the whole launch"),
+                                  "fused_edges": bool(vf and vinfo.get("fused_edges")),
                                   "verdicts_equal_headline": same, "edges_compared": E,
                                   "valu_issue": valu_issue(vk, v_stage[vk], rec)}
                 if name == "f64_only" and flops.get("flops_per_edge"):

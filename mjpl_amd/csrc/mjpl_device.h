@@ -837,6 +837,7 @@ struct EdgeSource {
   int layout;
   double step;
   const double *ckpt;     // [item slot][nplan] exact waypoints of the items with idx % kCkptEvery == 0, or null
+  int idx0_end;           // != 0: check index 0 of an item is the edge's END, QB (launches that make the endpoint an item, too)
 };
 constexpr int kCkptEvery = 32;
 
@@ -853,6 +854,10 @@ __device__ inline void exact_waypoint(const EdgeSource &src, Perm perm, int npla
     return (src.layout == MJPL_SOA) ? Q[(long long)k * src.E + i] : Q[i * nplan + k];
   };
   int from = 0;
+  if (src.idx0_end && idx == 0) {
+    for (int k = 0; k < nplan; k++) out[k] = at(src.QB, k);
+    return;
+  }
   if (src.ckpt && slot >= 0 && idx >= kCkptEvery) {
     from = idx - idx % kCkptEvery;
     const double *row = src.ckpt + (size_t)(slot - (idx - from)) * nplan;

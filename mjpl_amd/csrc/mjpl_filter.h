@@ -302,16 +302,25 @@ __device__ __forceinline__ bool walk_step(Perm perm, int nplan, const double *qe
 // (its float32 bounds absorb 1e-5; the exact re-check rebuilds the waypoint by the recurrence).
 // So the walk is needed for the COUNT only -- where `step` divides the edge length the count
 // hangs on the last bit of the running distance -- and no waypoint is stored.
+__device__ __forceinline__ int count_waypoints_walk(const int *__restrict__ gip, double step, bool todo, bool at_end,
+                                                    const double *qe, int B, double *qw, int ws, int kmax, int nplan,
+                                                    double &tstep);
 __device__ __forceinline__ int count_waypoints_ts(const int *__restrict__ gip, const double *__restrict__ QA,
                                                   int64_t E, int64_t i, double step, int layout, bool todo,
                                                   const double *qe, int B, double *qw, int ws,
                                                   int kmax, int nplan, double &tstep) {
-  const int *perm = gip + gip[H_OFF_PERM];
   bool at_end = true;
   for_row(QA, E, i, nplan, layout, todo, [&](int k, double a) {
     qw[k * ws] = a;
     at_end = at_end && (a == qe[k * B]);
   });
+  return count_waypoints_walk(gip, step, todo, at_end, qe, B, qw, ws, kmax, nplan, tstep);
+}
+// ... the walk itself: qw holds the lane's QA row on entry (at_end: QA == QB)
+__device__ __forceinline__ int count_waypoints_walk(const int *__restrict__ gip, double step, bool todo, bool at_end,
+                                                    const double *qe, int B, double *qw, int ws, int kmax, int nplan,
+                                                    double &tstep) {
+  const int *perm = gip + gip[H_OFF_PERM];
   double s0 = 0;
   for (int k = 0; k < nplan; k++) {
     const int col = perm[k];
@@ -457,7 +466,9 @@ k_filter_endpoints(const int *__restrict__ gip, int nip, const float *__restrict
     __syncthreads();
   }
   QT *qw = reinterpret_cast<QT *>(c.col0) + threadIdx.x;
-  load_columns(qw, B, QB, E, i, nplan, layout, active);
+  // (a NaN / inf row never reaches the check, not even on a lane that only keeps company: zeros in its place --
+  // a NaN passes the negated compare of the plane culls, and the lane would queue candidates)
+  load_columns(qw, B, QB, E, i, nplan, layout, active && finite);
   __syncthreads();
   const bool run = active && finite;
   const int code = check_one<float, MAXS, WBOX, MBOX, Spec>(c, qw, B, run, tol, i, uc, 0, nullptr, nullptr,
@@ -699,6 +710,9 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
   load_columns(qw, B, QB, E, i, nplan, layout, active);
   __syncthreads();
   IP perm = c.ip + c.ip[H_OFF_PERM];
+  // the walking list of a launch that made the endpoints items (mjpl_fused.h, small batches): an edge whose endpoint
+  // was found in contact has its verdict already -- the interior walk must not write over it
+  const bool verdict_stands = active && rlist && (flags & MJPL_EDGE_INTERIOR_ONLY) && valid[i] == 0;
 
   bool finite = true, at_end = true;
   for (int k = 0; k < nplan; k++) {
@@ -706,7 +720,7 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
     finite = finite && (fabs(a) <= 1.79769313486231570815e+308) && (fabs(b) <= 1.79769313486231570815e+308);
     at_end = at_end && (a == b);
   }
-  bool done = !active;
+  bool done = !active || verdict_stands;
   bool ok = true, unsure = false;
   int fb = -1;
   if (active && finite) {
@@ -719,10 +733,12 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
     }
     if (!(sqrt(s0) <= step * (kMaxWaypoints + 2.0))) finite = false;
   }
-  if (active && !finite) {
+  if (active && !finite && !verdict_stands) {
     done = true; ok = false; fb = -2;
     atomicOr(status, kStatusNonFinite);
   }
+  if (active && !finite)  // (the lane keeps company through the checks: zeros, never a NaN / inf row -- see k_filter_endpoints)
+    for (int k = 0; k < nplan; k++) qw[k * B] = 0.0;
 
   // Iteration 0 checks the endpoint (apply_constraints validates q before the interval,
   // utils.py:144); every later iteration advances the waypoint and checks it.  One call site
@@ -793,7 +809,7 @@ __device__ __forceinline__ void edge_body(const int *__restrict__ gip, int nip, 
     if (first && !done && at_end) done = true;  // waypoints == [start]: nothing interior
     first = false;
   }
-  if (active) {
+  if (active && !verdict_stands) {
     if (unsure) {
       ulist[atomicAdd(ucount, 1)] = (int)i;  // the exact kernel writes valid / first_bad
     } else {
@@ -1077,7 +1093,7 @@ k_filter_endpoints_pw(const int *__restrict__ gip, int nip, const float *__restr
       wave_lds_fence();
     }
     float *qw = w.col + lane;
-    load_columns(qw, 64, QB, E, i, nplan, layout, active);
+    load_columns(qw, 64, QB, E, i, nplan, layout, active && finite);  // (see k_filter_endpoints)
     wave_lds_fence();
     const bool run = active && finite;
     asked = tq.ask_ahead(asked);  // (the next tile, if a counter hands it out: answered while this one is checked)

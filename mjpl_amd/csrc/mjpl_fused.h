@@ -28,7 +28,7 @@
 namespace mjpl {
 
 constexpr int kFusedWaves = 12;   // waves of a workgroup (one workgroup per CU at three waves per SIMD)
-constexpr int kFusedShards = 8;   // device counters the dynamic endpoint tiles are dealt from
+constexpr int kFusedMaxPool = 4096;  // entries of a workgroup's pool at most (two rounds of the 64-way search)
 constexpr int kStatusFusedTimeout = 4;
 
 struct FusedArgs {
@@ -43,26 +43,34 @@ struct FusedArgs {
   int *claim; int gen;           // per-edge claim words of the undecided-edge list (see k_filter_items)
   double *tstep;                 // [E] scratch: an edge's step fraction between its count and its pool entry
   int *item_count, *surv_count;  // statistics: kItemRegions counters each, kCounterStride apart
-  int *tiles;                    // kFusedShards counters, kCounterStride apart: dynamic endpoint tiles
   int *zero_next;
+  long long tile0, tile1;        // this launch serves endpoint tiles [tile0, tile1) of the batch (64 edges each)
   int kmax;                      // edges with more interior waypoints take the walking list
-  int ring;                      // entries of a workgroup's pool (>= 64 per wave)
+  int pool;                      // slots of a workgroup's ring of entries (>= 64 per wave)
   int policy;                    // bit 0: item tiles before further endpoint tiles (default: endpoint tiles first)
+  // != 0: the endpoint is an item, too -- an endpoint tile only counts waypoints, and every edge enters the pool with
+  // checks 0 .. K.  Costs the interior checks of the edges whose endpoint is in contact (never made otherwise) and
+  // saves a batch that does not fill the chip the latency of one of its two rounds of checks.
+  int single;
   // diagnostic builds (-DMJPL_FUSED_DEBUG; null otherwise): eight 64-bit words per wave of the grid --
-  // endpoint tiles, item tiles, polls while waiting; clocks in endpoint tiles, item tiles, waiting, the lock, in all
+  // endpoint tiles, item tiles, polls while waiting; clocks in endpoint tiles, item tiles, waiting, deciding, in all
   unsigned long long *dbg;
 };
 
 // control words of a workgroup's pool (LDS)
-enum : int { RG_LOCK = 0, RG_HEAD, RG_TAIL, RG_OFF, RG_PENDING, RG_RESERVED, RG_EXHAUSTED, RG_WORDS = 8 };
+// RG_HEAD (64 bits, 8-byte aligned): [waypoints claimed so far | number of the first entry that still holds an
+// unclaimed waypoint]; RG_NEED + w: the first entry wave w is still reading (kFusedIdle: none)
+enum : int { RG_HEAD = 0, RG_LOCK = 2, RG_ENT, RG_COMMIT, RG_NEXT, RG_PRODUCED, RG_RESERVED, RG_NEED = 8, RG_WORDS = 8 + 16 };
+constexpr int kFusedIdle = 0x7fffffff;
 
 __host__ __device__ constexpr size_t fused_wave_bytes(int nplan, int nsave, size_t qbytes) {
   return wave_slice_bytes(nplan, nsave, sizeof(float), qbytes) + 2 * 64 * sizeof(int);  // + (edge, index) of the wave's items
 }
-inline size_t fused_lds_bytes(int nwaves, int nplan, int nsave, size_t ntab, bool mbox, int ring) {
+constexpr size_t kFusedEntryBytes = sizeof(double) + 2 * sizeof(int);  // step fraction, edge, first waypoint number
+inline size_t fused_lds_bytes(int nwaves, int nplan, int nsave, size_t ntab, bool mbox, int pool) {
   const size_t q = mbox ? WaveQueue<float, true>::bytes() : WaveQueue<float, false>::bytes();
   return (size_t)nwaves * fused_wave_bytes(nplan, nsave, q) + ((ntab * sizeof(float) + 7) & ~(size_t)7) +
-         (size_t)ring * (sizeof(double) + 2 * sizeof(int)) + RG_WORDS * sizeof(int);
+         (size_t)pool * kFusedEntryBytes + RG_WORDS * sizeof(int);
 }
 // the float64 walking rows of the waypoint count lie over a wave's slice
 inline bool fused_fits(int nplan, int nsave, bool mbox) {
@@ -70,6 +78,28 @@ inline bool fused_fits(int nplan, int nsave, bool mbox) {
   return (size_t)2 * nplan * 64 * sizeof(double) <= wave_slice_bytes(nplan, nsave, sizeof(float), q);
 }
 
+// How the pool works.  A workgroup OWNS the endpoint tiles tile0 + b, tile0 + b + grid, ... (b its number): nothing is
+// dealt between workgroups, so every workgroup carries the same number of edges (+-64) and their waypoints -- a greedy
+// device-wide queue of endpoint tiles was measured first: whoever takes an endpoint tile also takes its ~2.5 item tiles
+// of later work, and the workgroups that were quick at the start ended 40 % after the slow ones.  Its waves take the
+// tiles in order (an LDS counter).  The survivors of a tile become ENTRIES [edge, number of its first waypoint in the
+// pool's running count, step fraction], numbered as they come and kept in a ring of `pool` slots; they are appended
+// under a lock that only producers take (sixteen times per workgroup at config-3 size).  `commit` = waypoints
+// entered so far.  Consumers take no lock: the pool's HEAD is one 64-bit word [waypoints claimed, first entry that
+// still holds an unclaimed one]; a wave reads it, reads the first numbers of the 64 entries from there on (every entry
+// holds at least one waypoint, so they cover a claim; the slot behind the last entry holds the number the next one
+// will start at, so an entry's end is always the next slot's number), works out where a claim of up to 64 waypoints
+// ends, and moves
+// the head there with one compare-and-swap -- which fails, and is tried again, exactly when another wave moved it
+// first.  Its lanes then find their entries among those 64 by a binary search through the wave's registers.
+// A slot of the ring is written again only when no wave can still read it: a consumer publishes the number of the
+// first entry of its claim (RG_NEED + wave) BEFORE its compare-and-swap and withdraws it after its last read; a
+// producer that wants room reads the head FIRST and the published numbers after it, and everything below the
+// smallest of them is free (a consumer whose publication the producer missed read the head before the producer
+// did, so its entries are not below the producer's bound -- or its compare-and-swap fails).  A wave starts an
+// endpoint tile only with 64 free slots set aside for it (RG_RESERVED), so a commit never waits; when the ring is
+// full it takes an item tile instead.  With a ring that holds all entries of the launch none of this is needed
+// and the reservation is skipped (`a.pool >= 64 * tiles of the workgroup`).
 template <class Spec, int MAXS, bool WBOX, bool MBOX, int NW>
 __global__ void __launch_bounds__(NW * 64, (kMinWaves<Spec, MAXS>))
 k_edges_fused(FusedArgs a) {
@@ -79,7 +109,7 @@ k_edges_fused(FusedArgs a) {
   const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : a.ip[H_NPLAN];
   const int nsave = a.ip[H_NSAVE];
   const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-  const int R = a.ring;
+  const int R = a.pool;
   // ---- LDS: [wave slices, each followed by the wave's item table | table copy | pool entries | pool control]
   const size_t qbytes = WaveQueue<float, MBOX>::bytes();
   WaveLds<float, MBOX> w;
@@ -94,19 +124,18 @@ k_edges_fused(FusedArgs a) {
   w.ltab = reinterpret_cast<float *>(shared);
   for (int k = threadIdx.x; k < a.nfp; k += blockDim.x) w.ltab[k] = a.fp[k];
   double *r_ts = reinterpret_cast<double *>(shared + (((size_t)a.nfp * sizeof(float) + 7) & ~(size_t)7));
-  int *r_edge = reinterpret_cast<int *>(r_ts + R), *r_K = r_edge + R;
-  volatile int *ctl = r_K + R;
-  // endpoint tiles: the first round is dealt statically -- wave v of workgroup b takes tile v * grid + b, so a
-  // launch with fewer tiles than waves spreads them over the workgroups -- the rest through the shard counters
-  const long long ntile = (a.E + 63) >> 6;
-  const long long nstatic = ntile < (long long)NW * gridDim.x ? ntile : (long long)NW * gridDim.x;
-  const int ndyn = (int)(ntile - nstatic);
-  if (threadIdx.x < RG_WORDS) {
-    // (the static tiles' room in the pool is set aside from the start: up to 64 entries each)
-    int nstat_wg = 0;
-    for (int v = 0; v < NW; v++) nstat_wg += ((long long)v * gridDim.x + blockIdx.x < nstatic) ? 1 : 0;
-    ctl[threadIdx.x] = threadIdx.x == RG_EXHAUSTED ? (ndyn == 0 ? 1 : 0) : (threadIdx.x == RG_RESERVED ? 64 * nstat_wg : 0);
-  }
+  int *r_edge = reinterpret_cast<int *>(r_ts + R), *r_first = r_edge + R;
+  volatile int *ctl = r_first + R;
+  // this workgroup's endpoint tiles: ordinal n -> tile0 + b + n * grid
+  const long long span = a.tile1 - a.tile0 - (long long)blockIdx.x;
+  const int ntw = span > 0 ? (int)((span + gridDim.x - 1) / gridDim.x) : 0;
+  // (the first NW tiles: one per wave, their room in the ring set aside from the start)
+  if (threadIdx.x < RG_WORDS)
+    ctl[threadIdx.x] = threadIdx.x == RG_NEXT ? (ntw < NW ? ntw : NW)
+                     : threadIdx.x == RG_RESERVED ? 64 * (ntw < NW ? ntw : NW)
+                     : threadIdx.x >= RG_NEED ? kFusedIdle : 0;
+  if (threadIdx.x == 0) r_first[0] = 0;  // (first[ENT] == COMMIT from the start)
+  const bool reuse = (long long)ntw * 64 + 1 > (long long)R;  // slots are written more than once in this launch
   __syncthreads();  // the table copy and the pool's control words; from here on a wave is on its own
 
   auto lock = [&]() {
@@ -122,32 +151,12 @@ k_edges_fused(FusedArgs a) {
     if (lane == 0) __hip_atomic_store(const_cast<int *>(&ctl[RG_LOCK]), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_wave_barrier();
   };
-  auto shard_tiles = [&](int q) { return q < ndyn ? (ndyn - q + kFusedShards - 1) / kFusedShards : 0; };
-  // the next dynamic endpoint tile, or -1 when every shard is empty
-  auto dequeue = [&]() -> long long {
-    int q = (int)(blockIdx.x % kFusedShards);
-    for (;;) {
-      int j = 0;
-      if (lane == 0) j = atomicAdd(a.tiles + q * kCounterStride, 1);
-      j = __builtin_amdgcn_readfirstlane(j);
-      if (j < shard_tiles(q)) return nstatic + q + (long long)kFusedShards * j;
-      int left = 0;  // this shard is empty: look at all of them at once (a counter only grows)
-      if (lane < kFusedShards)
-        left = shard_tiles(lane) - __hip_atomic_load(a.tiles + lane * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long m = __ballot(left > 0);
-      if (m == 0ull) return -1;
-      const int s = q + 1 == kFusedShards ? 0 : q + 1;
-      const unsigned long long hi = m >> s;
-      q = hi ? s + (int)__builtin_ctzll(hi) : (int)__builtin_ctzll(m);
-    }
-  };
 
   const bool fits = (size_t)2 * nplan * 64 * sizeof(double) <= w.bytes;  // (the launcher has checked)
   double *qe = reinterpret_cast<double *>(w.base) + lane;
   double *qx = qe + (size_t)nplan * 64;
   float *qw = w.col + lane;
-  long long my_static = (long long)wv * gridDim.x + blockIdx.x;
-  if (my_static >= nstatic) my_static = -1;
+  int my_first = wv < ntw ? wv : -1;  // the wave's first endpoint tile (ordinal), dealt statically
   int stat_items = 0, stat_surv = 0;
   int spins = 0;
 #ifdef MJPL_FUSED_DEBUG
@@ -159,155 +168,199 @@ k_edges_fused(FusedArgs a) {
 #define MJPL_DG(k, v)
 #define MJPL_DG_NOW() 0ull
 #endif
-  enum : int { ACT_WAIT = 0, ACT_EXIT, ACT_EP, ACT_EP_DYN, ACT_IT };
 
   for (;;) {
-    // ---- what next?  Decided (and, for an item tile, claimed) under the pool's lock.
-    int act = ACT_WAIT;
-    int ed = -1, idx = 0;   // item tile: this lane's waypoint
-    double ts = 0.0;
+    // ---- what next?
     const unsigned long long dg_a = MJPL_DG_NOW();
     (void)dg_a;
-    lock();
-    {
-      const int head = ctl[RG_HEAD], tail = ctl[RG_TAIL], pending = ctl[RG_PENDING], reserved = ctl[RG_RESERVED];
-      const bool exhausted = ctl[RG_EXHAUSTED] != 0;
-      const bool room = R - (tail - head) - reserved >= 64;  // an endpoint tile adds up to 64 entries
-      int take = 0;
-      if (my_static >= 0) {
-        act = ACT_EP;
-      } else if (a.policy & 1) {
-        if (pending >= 64) take = 64;
-        else if (!exhausted && room) act = ACT_EP_DYN;
-        else if (pending > 0 && exhausted) take = pending;
-      } else {
-        if (!exhausted && room) act = ACT_EP_DYN;
-        else if (pending >= 64) take = 64;
-        else if (pending > 0 && exhausted) take = pending;
+    int tile_n = -1;        // endpoint tile (ordinal in this workgroup), or
+    int h = 0, take = 0;    // waypoints [h, h + take) of the pool
+    int ed = -1, idx = 0;   // item tile: this lane's waypoint
+    double ts = 0.0;
+    bool leave = false;
+    if (my_first >= 0) {
+      tile_n = my_first;
+      my_first = -1;
+    } else {
+      // (read in this order: `produced` == ntw means `commit` is final)
+      const int produced = __hip_atomic_load(const_cast<int *>(&ctl[RG_PRODUCED]), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned long long head = __hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int commit = __hip_atomic_load(const_cast<int *>(&ctl[RG_COMMIT]), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int claimed = (int)(unsigned)(head >> 32), he = (int)(unsigned)head;
+      const int next = ctl[RG_NEXT];
+      const int avail = commit - claimed;
+      const bool tiles_left = next < ntw;
+      bool want_tile = tiles_left && !((a.policy & 1) && avail >= 64);
+      if (want_tile && reuse) {
+        // room for the tile's entries (up to 64)?  Entries below the head's and below every entry a wave is still
+        // reading are free.  (head first, the publications after it: see above)
+        lock();
+        const unsigned long long hd = __hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int lowest = lane < NW ? ctl[RG_NEED + lane] : kFusedIdle;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          const int other = __shfl_xor(lowest, o);
+          lowest = other < lowest ? other : lowest;
+        }
+        lowest = __builtin_amdgcn_readfirstlane(lowest);
+        const int free_below = lowest < (int)(unsigned)hd ? lowest : (int)(unsigned)hd;
+        const int reserved = ctl[RG_RESERVED];
+        const bool room = R - (ctl[RG_ENT] - free_below) - reserved >= 65;  // (64 entries and the slot behind them)
+        if (room && lane == 0) ctl[RG_RESERVED] = reserved + 64;
+        unlock();
+        want_tile = room;
       }
-      if (act == ACT_EP_DYN) {
-        if (lane == 0) ctl[RG_RESERVED] = reserved + 64;
-      } else if (act == ACT_EP) {
-        // (reserved at the start)
-      } else if (take > 0) {
-        // claim the next `take` waypoints of the pool: entries head, head + 1, ... (the first `off` waypoints of
-        // entry `head` were claimed before); every entry still holds at least one, so 64 entries cover the claim
-        act = ACT_IT;
-        const int off = ctl[RG_OFF];
-        const int navail = tail - head < 64 ? tail - head : 64;
-        int slot = head + lane;
-        slot = slot >= R ? slot - R : slot;  // (head < R is kept below; lane < 64 <= R)
-        int kj = lane < navail ? r_K[slot] - (lane == 0 ? off : 0) : 0;
-        int cum = kj;  // inclusive prefix sum over the lanes
+      if (want_tile) {
+        int n = 0;
+        if (lane == 0) n = atomicAdd(const_cast<int *>(&ctl[RG_NEXT]), 1);
+        n = __builtin_amdgcn_readfirstlane(n);
+        if (n < ntw) {
+          tile_n = n;
+        } else {  // (another wave was quicker)
+          if (reuse) {
+            lock();
+            if (lane == 0) ctl[RG_RESERVED] = ctl[RG_RESERVED] - 64;
+            unlock();
+          }
+          continue;
+        }
+      } else if (avail >= 64 || (avail > 0 && (!tiles_left || reuse))) {
+        // (with no tile left to take -- or no room for one -- a partial claim beats waiting for the producers)
+        take = avail < 64 ? avail : 64;
+        // (sharing a workgroup's last waypoints out evenly, so that all its waves end together, was measured: part-filled
+        // tiles cost nearly what full ones do -- 40 % more tiles, 9 % more time per batch)
+        h = claimed;
+        // the first numbers of the entries behind the head's: g[j] = first[he + 1 + j] (the end of entry he + j),
+        // `commit` for the entry behind the last one, +inf beyond
+        if (lane == 0) ctl[RG_NEED + wv] = he;  // BEFORE the compare-and-swap
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const int nent = ctl[RG_ENT];  // (read after `commit`: covers every waypoint below it)
+        const int hslot = he % R;
+        int gs = hslot + 1 + lane;
+        gs = gs >= R ? gs - R : gs;
+        gs = gs >= R ? gs - R : gs;
+        const int ge = he + 1 + lane;
+        // (slot `nent` holds the number the next entry will start at -- the end of the last one: the producers keep
+        // first[ENT] == COMMIT.  `nent` may be newer than `commit`: the numbers beyond it are real, and the claim
+        // ends at `commit` whatever lies behind)
+        const int g = ge <= nent ? r_first[gs] : 0x7fffffff;
+        const int f0 = r_first[hslot];  // (he < nent: a waypoint is pending)
+        const int adv = (int)__builtin_popcountll(__ballot(g <= h + take));  // entries used up by this claim
+        int got = 0;
+        if (lane == 0)
+          got = atomicCAS(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])), head,
+                          ((unsigned long long)(unsigned)(h + take) << 32) | (unsigned)(he + adv)) == head ? 1 : 0;
+        if (!__builtin_amdgcn_readfirstlane(got)) {  // (another wave was quicker: look again)
+          if (lane == 0) ctl[RG_NEED + wv] = kFusedIdle;
+          take = 0;
+          continue;
+        }
+        // this lane's entry: he + (number of j with g[j] <= its waypoint number)
+        const int s = h + lane;
+        int jl = 0, jh = 64;  // invariant: g[jl - 1] <= s < g[jh - 1]   (g[-1] = f0 <= h)
+        int fl = f0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int up = __shfl_up(cum, o);
-          if (lane >= o) cum += up;
+        for (int it = 0; it < 6; it++) {  // (every lane takes part in every shuffle)
+          const int mid = (jl + jh) >> 1;  // 1 .. 63
+          const int gm = __shfl(g, mid - 1);
+          const bool le = gm <= s;
+          jl = le ? mid : jl;
+          fl = le ? gm : fl;
+          jh = le ? jh : mid;
         }
-        // lane = waypoint number `lane` of the claim: its entry is the first whose prefix exceeds it
-        int lo = 0, hi = navail;
-#pragma unroll
-        for (int it = 0; it < 7; it++) {  // (every lane takes part in every shuffle)
-          const int mid = (lo + hi) >> 1;
-          const int c = __shfl(cum, mid < 63 ? mid : 63);
-          const bool go = lo < hi, below = c <= lane;
-          lo = (go && below) ? mid + 1 : lo;
-          hi = (go && !below) ? mid : hi;
+        if (lane < take) {
+          int es = hslot + jl;
+          es = es >= R ? es - R : es;
+          ed = r_edge[es];
+          ts = r_ts[es];
+          idx = s - fl + 1;
         }
-        const int ent = lo < navail ? lo : (navail > 0 ? navail - 1 : 0);
-        const int before_raw = __shfl(cum, ent > 0 ? ent - 1 : 0);
-        const int before = ent > 0 ? before_raw : 0;
-        const bool mine = lane < take;
-        int es = head + ent;
-        es = es >= R ? es - R : es;
-        ed = mine ? r_edge[es] : -1;
-        ts = mine ? r_ts[es] : 0.0;
-        idx = lane - before + (ent == 0 ? off : 0) + 1;
-        // the pool's new head: entries whose prefix is within the claim are used up
-        const int adv = (int)__builtin_popcountll(__ballot(lane < navail && cum <= take));
-        const int cum_adv = __shfl(cum, adv > 0 ? adv - 1 : 0);
-        if (lane == 0) {
-          int nh = head + adv, nt = tail;
-          if (nh >= R) { nh -= R; nt -= R; }  // (head stays below R; tail - head is what counts)
-          ctl[RG_HEAD] = nh;
-          ctl[RG_TAIL] = nt;
-          ctl[RG_OFF] = adv > 0 ? take - cum_adv : off + take;
-          ctl[RG_PENDING] = pending - take;
-        }
-      } else if (act == ACT_WAIT && exhausted && reserved == 0 && pending == 0) {
-        act = ACT_EXIT;
+        wave_lds_fence();  // (the reads above before the withdrawal)
+        if (lane == 0) ctl[RG_NEED + wv] = kFusedIdle;
+      } else if (produced >= ntw && avail == 0) {
+        leave = true;
       }
     }
-    unlock();
-    const unsigned long long dg_b = MJPL_DG_NOW();
-    (void)dg_b;
-    MJPL_DG(6, dg_b - dg_a);
-    if (act == ACT_EXIT) break;
-    if (act != ACT_WAIT) spins = 0;
-    if (act == ACT_WAIT) {
-      __builtin_amdgcn_s_sleep(64);
+    if (leave) break;
+    if (tile_n < 0 && take == 0) {  // nothing to take: the last endpoint tiles of the workgroup are still being checked
+      __builtin_amdgcn_s_sleep(32);
       MJPL_DG(2, 1);
-      MJPL_DG(5, MJPL_DG_NOW() - dg_b);
+      MJPL_DG(5, MJPL_DG_NOW() - dg_a);
       if (++spins > (1 << 22)) {  // (seconds: report, do not hang)
         if (lane == 0) atomicOr(a.status, kStatusFusedTimeout);
         break;
       }
       continue;
     }
-    long long tile = -1;
-    if (act == ACT_EP) {
-      tile = my_static;
-      my_static = -1;
-    } else if (act == ACT_EP_DYN) {
-      tile = dequeue();
-      if (tile < 0) {  // nothing left anywhere: give the reservation back, tell the workgroup
-        lock();
-        if (lane == 0) {
-          ctl[RG_RESERVED] = ctl[RG_RESERVED] - 64;
-          ctl[RG_EXHAUSTED] = 1;
-        }
-        unlock();
-        continue;
-      }
-    }
-    const bool ep = tile >= 0;
+    spins = 0;
+    const bool ep = tile_n >= 0;
+    const unsigned long long dg_b = MJPL_DG_NOW();
+    (void)dg_b;
+    MJPL_DG(6, dg_b - dg_a);
     // ---- the tile's configurations -> this wave's binary32 columns
+    const long long tile = ep ? a.tile0 + blockIdx.x + (long long)tile_n * gridDim.x : -1;
     const long long i = ep ? tile * 64 + lane : (long long)(ed >= 0 ? ed : 0);
     bool active = ep ? i < a.E : ed >= 0;
     bool finite = true;
     int K = 0;
     if (ep) {
-      for_rows(a.QA, a.QB, a.E, i, nplan, a.layout, active, [&](int, double x, double y) {
-        finite = finite && (fabs(x) <= 1.79769313486231570815e+308) && (fabs(y) <= 1.79769313486231570815e+308);
-      });
-      // the waypoint COUNT first (see k_filter_endpoints): float64 rows laid over the wave's slice
       if (fits) {
-        load_columns(qe, 64, a.QB, a.E, i, nplan, a.layout, active);
+        // ONE pass over the edge's rows: QA -> the walking row, QB -> the end row (float64, laid over the wave's
+        // slice), then the waypoint COUNT by the reference's recurrence (see k_filter_endpoints), then the end row
+        // becomes the check's binary32 columns in place: column k lies inside float64 row k / 2, which has been
+        // read by the time it is written (eight columns at a time: all reads of a group before its writes)
+        bool at_end = true;
+        for_rows(a.QA, a.QB, a.E, i, nplan, a.layout, active, [&](int k, double x, double y) {
+          finite = finite && (fabs(x) <= 1.79769313486231570815e+308) && (fabs(y) <= 1.79769313486231570815e+308);
+          qx[k * 64] = x;
+          qe[k * 64] = y;
+          at_end = at_end && (x == y);
+        });
         double tsw;
-        K = count_waypoints_ts(a.ip, a.QA, a.E, i, a.step, a.layout, active && finite, qe, 64, qx, 64, a.kmax, nplan, tsw);
-        if (K > 0) a.tstep[i] = tsw;  // (parked in memory across the check: two registers less to keep alive)
+        K = count_waypoints_walk(a.ip, a.step, active && finite, at_end, qe, 64, qx, 64, a.kmax, nplan, tsw);
+        if (K > 0 || a.single) a.tstep[i] = tsw;  // (parked in memory across the check: two registers less to keep alive)
         wave_lds_fence();
-      } else {
+        for (int k0 = 0; k0 < nplan; k0 += 8) {
+          double v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = k0 + j < nplan ? qe[(k0 + j) * 64] : 0.0;
+          wave_lds_fence();
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            if (k0 + j < nplan) qw[(k0 + j) * 64] = finite ? (float)v[j] : 0.0f;  // (a NaN / inf row never reaches the check, not even on a lane that only keeps company: a NaN passes the plane culls' negated compare)
+          wave_lds_fence();
+        }
+      } else {  // too many columns for the float64 rows: every surviving edge takes the walking list
+        for_rows(a.QA, a.QB, a.E, i, nplan, a.layout, active, [&](int, double x, double y) {
+          finite = finite && (fabs(x) <= 1.79769313486231570815e+308) && (fabs(y) <= 1.79769313486231570815e+308);
+        });
         K = -1;
+        load_columns(qw, 64, a.QB, a.E, i, nplan, a.layout, active && finite);
       }
-      load_columns(qw, 64, a.QB, a.E, i, nplan, a.layout, active);
       active = active && finite;
     } else {
+      if (a.single) idx -= 1;  // (an edge's items are its checks 0 .. K: 0 is the endpoint)
       w_edge[lane] = ed >= 0 ? ed : 0;
       w_idx[lane] = idx;
       // the waypoint in closed form (see count_waypoints): QA + min(idx * step / |QB - QA|, 1) (QB - QA),
-      // rounded to binary32 as the check would round it anyway
+      // rounded to binary32 as the check would round it anyway; check 0 of a single-round launch: QB itself
       double tt = active ? (double)idx * ts : 0.0;
       tt = tt < 1.0 ? tt : 1.0;
+      const bool at_end = a.single && idx == 0;
       for_rows(a.QA, a.QB, a.E, i, nplan, a.layout, true, [&](int k, double x, double y) {
-        qw[k * 64] = active ? (float)fma(tt, y - x, x) : 0.0f;
+        qw[k * 64] = active ? (at_end ? (float)y : (float)fma(tt, y - x, x)) : 0.0f;
       });
     }
     wave_lds_fence();
     // ---- ONE call site of the per-configuration check for both kinds of tile
-    const EdgeSource src = {ep ? a.QB : a.QA, a.QB, a.E, a.layout, ep ? 0.0 : a.step, nullptr};
-    const int code = check_wave<MAXS, WBOX, MBOX, Spec>(a.ip, a.fp, w, active, a.tol, ep ? i : (long long)lane, a.uc,
-                                                        ep ? (const int *)nullptr : w_edge, ep ? (const int *)nullptr : w_idx, src);
+    const EdgeSource src = {ep ? a.QB : a.QA, a.QB, a.E, a.layout, ep ? 0.0 : a.step, nullptr, a.single};
+    int code = V_NONE;
+    if (!(ep && a.single))  // (an endpoint tile of a single-round launch only counts)
+      code = check_wave<MAXS, WBOX, MBOX, Spec>(a.ip, a.fp, w, active, a.tol, ep ? i : (long long)lane, a.uc,
+                                                ep ? (const int *)nullptr : w_edge, ep ? (const int *)nullptr : w_idx, src);
     wave_lds_fence();
     if (!ep) {
       if (active && code != V_NONE) {
@@ -342,29 +395,40 @@ k_edges_fused(FusedArgs a) {
       }
     }
     if (survive && K < 0) a.llist[atomicAdd(a.lcount, 1)] = (int)i;  // too long (or too many columns): walking kernel
+    if (a.single) K = K < 0 ? 1 : K + 1;  // (the endpoint is check 0 of the edge's items; of a walking edge the only one)
     const bool entry = survive && K > 0;
     const unsigned long long me = __ballot(entry);
     const int nent = (int)__builtin_popcountll(me);
-    int total = entry ? K : 0;
+    int incl = entry ? K : 0;  // this lane's first waypoint number, relative to the tile's: an exclusive prefix sum
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    const int total = __shfl(incl, 63);
     const double tse = entry ? a.tstep[i] : 0.0;
     stat_surv += (int)__builtin_popcountll(__ballot(survive));
     lock();
     {
-      const int tail = ctl[RG_TAIL];
+      const int e0 = ctl[RG_ENT], f0 = ctl[RG_COMMIT];
       if (entry) {
-        int slot = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(me >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)me, 0u));
+        int slot = e0 % R + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(me >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)me, 0u));
         slot = slot >= R ? slot - R : slot;
-        slot = slot >= R ? slot - R : slot;  // (tail < 2 R: head < R and at most R entries)
         r_edge[slot] = (int)i;
-        r_K[slot] = K;
+        r_first[slot] = f0 + incl - K;
         r_ts[slot] = tse;
       }
+      if (lane == 0) {  // the slot behind the last entry: where the next one will start (first[ENT] == COMMIT)
+        int send = e0 % R + nent;
+        send = send >= R ? send - R : send;
+        r_first[send] = f0 + total;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entries (and this tile's verdict bytes) before the counts
       if (lane == 0) {
-        ctl[RG_TAIL] = tail + nent;
-        ctl[RG_PENDING] = ctl[RG_PENDING] + total;
-        ctl[RG_RESERVED] = ctl[RG_RESERVED] - 64;
+        ctl[RG_ENT] = e0 + nent;
+        __hip_atomic_store(const_cast<int *>(&ctl[RG_COMMIT]), f0 + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (reuse) ctl[RG_RESERVED] = ctl[RG_RESERVED] - 64;
+        __hip_atomic_store(const_cast<int *>(&ctl[RG_PRODUCED]), ctl[RG_PRODUCED] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
     unlock();
@@ -386,9 +450,10 @@ k_edges_fused(FusedArgs a) {
   }
 }
 
-// grid of the fused kernel: what the device holds at once, never more workgroups than endpoint tiles
+// Launch the fused kernel over the whole batch: the grid is what the device holds at once, never more workgroups
+// than endpoint tiles (a launch of a few tiles spreads them: one per workgroup, whose other waves take its waypoints).
 template <class K>
-inline unsigned fused_grid(K kernel, int block, size_t lds, long long ntile) {
+inline hipError_t fused_launch(K kernel, int nwaves, size_t lds, FusedArgs a, hipStream_t st) {
   static thread_local const void *last_k = nullptr;
   static thread_local size_t last_lds = 0;
   static thread_local int last_dev = -1, resident = 0;
@@ -396,12 +461,16 @@ inline unsigned fused_grid(K kernel, int block, size_t lds, long long ntile) {
   (void)hipGetDevice(&dev);
   if (last_k != reinterpret_cast<const void *>(kernel) || last_lds != lds || last_dev != dev) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), block, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), nwaves * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     resident = per_cu * cus;
     last_k = reinterpret_cast<const void *>(kernel); last_lds = lds; last_dev = dev;
   }
-  return (unsigned)(ntile < 1 ? 1 : (ntile < resident ? ntile : resident));
+  const long long ntile = (a.E + 63) / 64;
+  a.tile0 = 0;
+  a.tile1 = ntile;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(ntile < resident ? ntile : resident)), dim3(nwaves * 64), lds, st, a);
+  return hipGetLastError();
 }
 
 }  // namespace mjpl

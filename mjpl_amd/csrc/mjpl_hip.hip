@@ -607,10 +607,11 @@ struct mjpl_engine {
   int persist = -1;
   bool fused_tail = true;  // MJPL_TAIL: walking kernel, pair re-check and exact edge kernel as roles of one launch (k_tail)
   // ONE filter kernel per edge launch (k_edges_fused, mjpl_fused.h): endpoint and waypoint tiles served by the same
-  // resident workgroups from a work pool in LDS.  MJPL_FUSED=0 restores the two persistent kernels; MJPL_FUSED_WAVES
-  // (6 | 12: workgroups per CU 2 | 1), MJPL_FUSED_POLICY (bit 0: item tiles first), MJPL_FUSED_KMAX: A/B measurements
+  // resident workgroups from a work pool in LDS.  MJPL_FUSED=0 restores the two persistent kernels;
+  // MJPL_FUSED_POLICY (bit 0: item tiles first), MJPL_FUSED_KMAX: A/B measurements
   bool fused = true;
-  int fused_waves = kFusedWaves, fused_policy = 0, fused_kmax = 4096;
+  int fused_policy = 0, fused_kmax = 4096, fused_pool_cap = 0;  // (MJPL_FUSED_POOL: at most that many ring slots)
+  int fused_single_max = 32768;  // MJPL_FUSED_SINGLE: batches up to this many edges check every configuration of an edge in one round (measured: 0.068 vs 0.087 ms at 1 024 edges, 0.090 vs 0.102 at 32 768, 0.116 vs 0.106 at 65 536)
   const char *fused_dbg_path = nullptr;  // MJPL_FUSED_DEBUG=<file> (with a -DMJPL_FUSED_DEBUG build of the kernels)
   unsigned long long *d_fused_dbg = nullptr;
   size_t item_cap_limit = (size_t)1 << 26;  // MJPL_ITEM_CAP: edges beyond it take the walking kernel
@@ -1495,19 +1496,20 @@ int allow_lds(K kernel, size_t bytes) {
 }
 
 // Can this engine's edge launches run the fused filter kernel (mjpl_fused.h), and how: waves per workgroup
-// (twelve = one workgroup per CU at three waves per SIMD; six = two per CU, A/B; four for the one-wave-per-SIMD
-// build of models with moving boxes), entries of a workgroup's pool (what its share of the CU's LDS leaves, at
-// least 64 per wave: every wave's first endpoint tile must find room) and the dynamic LDS of a workgroup.
+// (twelve = one workgroup per CU at three waves per SIMD; four for the one-wave-per-SIMD build of models with
+// moving boxes), entries of a workgroup's pool (what the CU's LDS leaves, at least 64 per wave: one endpoint tile
+// each) and the dynamic LDS of a workgroup.
 bool fused_plan(const mjpl_engine *e, int *nwaves, size_t *lds, int *ring = nullptr) {
   if (!e->fused || !e->filter || !e->filter_usable || !e->two_pass || !e->expand || e->immediate()) return false;
   const int nplan = (int)e->qidx.size();
   const bool mbox = e->filter_mbox();
   if (!fused_fits(nplan, e->nsave, mbox)) return false;
-  const int nw = mbox ? 4 : (e->spec ? e->fused_waves : kFusedWaves);
-  const size_t budget = nw == 6 ? (size_t)79 * 1024 : (size_t)160 * 1024;  // (two workgroups per CU: a little less than half each)
+  const int nw = mbox ? 4 : kFusedWaves;
+  const size_t budget = (size_t)160 * 1024;
   const size_t base = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, 0);
-  if (base + (size_t)64 * nw * 16 > budget) return false;
-  const int r = (int)std::min<size_t>(4096, (budget - base) / 16 / 64 * 64);
+  if (base + (size_t)(64 * nw + 64) * kFusedEntryBytes > budget) return false;
+  int r = (int)std::min<size_t>(kFusedMaxPool, (budget - base) / kFusedEntryBytes / 64 * 64);
+  if (e->fused_pool_cap > 0) r = std::max(64 * nw + 64, std::min(r, e->fused_pool_cap / 64 * 64));  // (tests: a ring that wraps)
   if (nwaves) *nwaves = nw;
   if (lds) *lds = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, r);
   if (ring) *ring = r;
@@ -1741,9 +1743,10 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       fa.tstep = e->d_tstep;
       fa.item_count = e->d_ucount + 5 * kCtr;
       fa.surv_count = e->d_ucount + (5 + kItemRegions) * kCtr;
-      fa.tiles = e->d_ucount + kCtrEndpointTiles * kCtr;
       fa.zero_next = zero_next;
-      fa.kmax = e->fused_kmax; fa.ring = fring; fa.policy = e->fused_policy;
+      fa.kmax = e->fused_kmax; fa.pool = fring; fa.policy = e->fused_policy;
+      // a batch that leaves most of the chip idle: one round of checks instead of two (the endpoint as an item)
+      fa.single = (E <= (int64_t)e->fused_single_max) ? 1 : 0;
       if (e->fused_dbg_path) {  // diagnostic runs: per-wave counters of the most recent launch, written out at mjpl_destroy
         if (!e->d_fused_dbg) {
           HIP_TRY(hipMalloc(&e->d_fused_dbg, kFusedDbgWaves * 8 * sizeof(unsigned long long)));
@@ -1761,7 +1764,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
             if (fwaves != NW) return fail(MJPL_E_ARG, "fused kernel: %d waves per workgroup asked for, this build has %d", fwaves, NW);
             int r = allow_lds(kern, flds);
             if (r != MJPL_OK) return r;
-            hipLaunchKernelGGL(kern, dim3(fused_grid(kern, NW * 64, flds, (long long)((E + 63) / 64))), dim3(NW * 64), flds, e->stream, fa);
+            if (fused_launch(kern, NW, flds, fa, e->stream) != hipSuccess) return fail(MJPL_E_HIP, "the fused kernel failed to launch");
             return MJPL_OK;
           } else {
             return fail(MJPL_E_ARG, "the fused kernel serves the queued interpreter");
@@ -2046,9 +2049,10 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_NN_MFMA")) e->nn_mfma = atoi(f) != 0 ? 1 : 0;
   if (const char *f = getenv("MJPL_TAIL")) e->fused_tail = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FUSED")) e->fused = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_FUSED_WAVES")) e->fused_waves = atoi(f) == 6 ? 6 : kFusedWaves;
   if (const char *f = getenv("MJPL_FUSED_POLICY")) e->fused_policy = atoi(f);
   e->fused_dbg_path = getenv("MJPL_FUSED_DEBUG");
+  if (const char *f = getenv("MJPL_FUSED_POOL")) e->fused_pool_cap = atoi(f);
+  if (const char *f = getenv("MJPL_FUSED_SINGLE")) e->fused_single_max = std::max(0, atoi(f));
   if (const char *f = getenv("MJPL_FUSED_KMAX")) e->fused_kmax = std::max(2, std::min(atoi(f), 1 << 16));
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
   if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));

@@ -835,19 +835,10 @@ int mjpl_spec_launch_tail(hipStream_t st, size_t lds, TailArgs a) {
 }
 // the whole float32 filter of an edge launch as one kernel (mjpl_fused.h); nwaves: wavefronts per workgroup
 int mjpl_spec_launch_fused(hipStream_t st, int nwaves, size_t lds, FusedArgs a) {
-  const long long ntile = (a.E + 63) / 64;
-  if (nwaves == 12) {
-    auto kern = k_edges_fused<Spec, %(maxs)d, %(wbox)s, false, 12>;
-    SPEC_GRANT(kern);
-    hipLaunchKernelGGL(kern, dim3(fused_grid(kern, 12 * 64, lds, ntile)), dim3(12 * 64), lds, st, a);
-  } else if (nwaves == 6) {
-    auto kern = k_edges_fused<Spec, %(maxs)d, %(wbox)s, false, 6>;
-    SPEC_GRANT(kern);
-    hipLaunchKernelGGL(kern, dim3(fused_grid(kern, 6 * 64, lds, ntile)), dim3(6 * 64), lds, st, a);
-  } else {
-    return -1;
-  }
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (nwaves != kFusedWaves) return -1;
+  auto kern = k_edges_fused<Spec, %(maxs)d, %(wbox)s, false, kFusedWaves>;
+  SPEC_GRANT(kern);
+  return fused_launch(kern, nwaves, lds, a, st) == hipSuccess ? 0 : -1;
 }
 int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const double *dp,
                            int ndp, GeomTable gt, UndecidedConfigs uc, uint8_t *valid, int32_t *first_bad) {

@@ -1,0 +1,149 @@
+"""The fused edge kernel (mjpl_amd/csrc/mjpl_fused.h): one launch serves the endpoint tiles and the waypoint tiles
+of a batch from a work pool in each workgroup's LDS.  Verdicts AND first-bad indices must be the oracle's -- and
+those of the two persistent kernels it replaced -- in every state the pool can be in: a ring that wraps many times,
+waypoint tiles before endpoint tiles, endpoints as items of their own (small batches), edges too long for the pool,
+non-finite edges, the interpreting kernels, the one-wave-per-SIMD build of models with moving boxes, and launch
+after launch on one engine with batch sizes that change."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from mjpl_amd import engine as eng_mod
+from mjpl_amd import scenes
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import random_edges  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("MJPL_FUSED", "MJPL_FUSED_POOL", "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX", "MJPL_SPEC", "MJPL_UC_CAP")
+
+
+def _engine(m, qidx=None, base=None, allowed=(), **env):
+    old = {k: os.environ.pop(k, None) for k in KEYS}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        e = eng_mod.Engine(m, allowed)
+        if qidx is not None:
+            e.set_planning(qidx, base)
+    finally:
+        for k in KEYS:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
+    return e
+
+
+def _franka():
+    m = scenes.franka_p(obstacles=True)
+    return m, scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos.copy()
+
+
+def test_ring_that_wraps_and_every_policy_at_full_size(oracle_mod):
+    """300 000 edges: nineteen endpoint tiles per workgroup.  With MJPL_FUSED_POOL=832 a workgroup's ring of pool
+    entries holds thirteen tiles' worth and is written several times over; every combination must return what
+    the two persistent kernels return, on all edges, and what the oracle returns on a sample."""
+    m, qidx, base = _franka()
+    E = 300000
+    qa, qb = random_edges(m, qidx, E, seed=21)
+    ref = _engine(m, qidx, base, MJPL_FUSED=0)
+    assert not ref.info()["fused_edges"]
+    want, wfb = ref.check_edges(qa, qb, 0.01, first_bad=True)
+    ref.close()
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    n = 20000
+    ov, ofb, _ = orc.valid_edges(qa[:n], qb[:n], 0.01, nthreads=8, info=True)
+    np.testing.assert_array_equal(want[:n], ov)
+    np.testing.assert_array_equal(wfb[:n], ofb)
+    for env in ({}, {"MJPL_FUSED_POOL": 832}, {"MJPL_FUSED_POLICY": 1}, {"MJPL_FUSED_POOL": 832, "MJPL_FUSED_POLICY": 1},
+                {"MJPL_FUSED_POOL": 832, "MJPL_UC_CAP": 64}, {"MJPL_FUSED_SINGLE": 100000000, "MJPL_FUSED_POOL": 832},
+                {"MJPL_FUSED_POOL": 832, "MJPL_SPEC": 0}):
+        e = _engine(m, qidx, base, **env)
+        assert e.info()["fused_edges"] and e.info()["fused_waves"] == 12
+        for rep in range(3):  # (the counter sets alternate between launches)
+            got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+            np.testing.assert_array_equal(got, want, err_msg=f"{env} launch {rep}")
+            np.testing.assert_array_equal(gfb, wfb, err_msg=f"{env} launch {rep}")
+        assert e.last_items() > E
+        e.close()
+
+
+def test_batch_sizes_that_change_between_launches(oracle_mod):
+    """One engine, batches of 1 .. 70 000 edges in an order that goes up and down: the small ones run with the
+    endpoint as an item (one round of checks), the large ones with endpoint tiles; buffers grow; every launch's
+    verdicts are the oracle's."""
+    m, qidx, base = _franka()
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    e = _engine(m, qidx, base)
+    for k, E in enumerate((1, 700, 63, 64, 65, 40000, 5, 33000, 70000, 1000, 8193, 2)):
+        qa, qb = random_edges(m, qidx, E, seed=100 + k)
+        want, wfb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
+        got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+        np.testing.assert_array_equal(got, want, err_msg=f"E = {E}")
+        np.testing.assert_array_equal(gfb, wfb, err_msg=f"E = {E}")
+    e.close()
+
+
+@pytest.mark.parametrize("single", [0, 100000000])
+def test_long_short_and_broken_edges_in_one_batch(oracle_mod, single):
+    """Edges of zero, one, a few, a hundred and a thousand waypoints, edges beyond the pool's waypoint limit (the
+    walking list: MJPL_FUSED_KMAX=200 here), exact multiples of the step, and NaN / inf edges -- mixed in one batch
+    on the wall scene, where first_bad depends on every single waypoint.  In both launch shapes."""
+    m = scenes.one_dof_ball()
+    orc = oracle_mod.Oracle(m)
+    rng = np.random.default_rng(9)
+    step = 0.001
+    starts, ends = [], []
+    for a in rng.uniform(0.0, 0.84, 400):
+        for length in (0.0, 1e-12, 0.4 * step, step, np.nextafter(step, 1), 3 * step, 7 * step, 0.05, 0.1, 0.15, 0.33, 0.7, 1.1):
+            starts.append([a])
+            ends.append([a + length])
+    qa, qb = np.array(starts), np.array(ends)
+    want, wfb, ncheck = orc.valid_edges(qa, qb, step, nthreads=8, info=True)
+    assert ncheck.max() > 800 and 0 < want.sum() < len(want)
+    for env in ({"MJPL_FUSED_KMAX": 200}, {}, {"MJPL_FUSED_KMAX": 200, "MJPL_FUSED_POOL": 832}):
+        e = _engine(m, MJPL_FUSED_SINGLE=single, **env)
+        assert e.info()["fused_edges"]
+        got, gfb = e.check_edges(qa, qb, step, first_bad=True)
+        np.testing.assert_array_equal(got, want, err_msg=str(env))
+        np.testing.assert_array_equal(gfb, wfb, err_msg=str(env))
+        # non-finite edges among good ones: reported, the others keep their verdicts
+        qa2, qb2 = qa.copy(), qb.copy()
+        qa2[5, 0], qb2[77, 0], qb2[300, 0] = np.nan, np.inf, -np.inf
+        da, db = e.alloc(qa2.nbytes).upload(qa2), e.alloc(qb2.nbytes).upload(qb2)
+        dv, dfb = e.alloc(len(qa2)), e.alloc(4 * len(qa2))
+        e.check_edges_dev(da.ptr, db.ptr, len(qa2), step, eng_mod.AOS, dv.ptr, dfb.ptr)
+        v2, fb2 = dv.download(np.uint8, len(qa2)), dfb.download(np.int32, len(qa2))
+        assert e.take_status() == -7
+        bad = np.zeros(len(qa2), bool)
+        bad[[5, 77, 300]] = True
+        assert (v2[bad] == 0).all() and (fb2[bad] == -2).all()
+        np.testing.assert_array_equal(v2[~bad], want[~bad])
+        np.testing.assert_array_equal(fb2[~bad], wfb[~bad])
+        e.close()
+
+
+def test_models_with_moving_boxes_and_the_interpreter(oracle_mod):
+    """The interpreting kernels run the fused kernel, too: twelve waves per workgroup for the small builds, four
+    for the 24-slot build of models with moving boxes (one wave per SIMD)."""
+    from test_gpu_models import random_model
+    for seed, boxes in ((1002, False), (1003, True), (1007, True)):
+        m, allowed = random_model(seed, moving_boxes=boxes)
+        qidx = np.arange(m.nq, dtype=np.int32)
+        base = np.asarray(m.qpos0, float).copy()
+        orc = oracle_mod.Oracle(m, allowed, planning_qidx=qidx, qpos_base=base)
+        qa, qb = random_edges(m, qidx, 30000, seed=seed)
+        want, wfb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
+        for env in ({"MJPL_SPEC": 0}, {"MJPL_SPEC": 0, "MJPL_FUSED_POOL": 320}, {"MJPL_SPEC": 0, "MJPL_FUSED_SINGLE": 100000000}):
+            e = _engine(m, qidx, base, allowed, **env)
+            info = e.info()
+            if info["filter_interpreter"] == 2 or not info["filter_enabled"]:
+                e.close()
+                continue
+            assert info["fused_edges"] and info["fused_waves"] == (4 if info["filter_interpreter"] == 1 else 12), info
+            got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+            np.testing.assert_array_equal(got, want, err_msg=f"{seed} {env}")
+            np.testing.assert_array_equal(gfb, wfb, err_msg=f"{seed} {env}")
+            e.close()

@@ -182,23 +182,36 @@ def test_two_pass_and_one_pass_filter_agree(monkeypatch):
     qa, qb = _bench.make_edges(m, qidx, 20000, seed=77)
     qb[:50] = qa[:50]  # waypoints == [start]: nothing interior
     out = {}
-    for tag, env in (("two", {"MJPL_TWO_PASS": "1"}), ("one", {"MJPL_TWO_PASS": "0"}), ("f64", {"MJPL_FILTER": "0"}),
-                     ("walk", {"MJPL_EXPAND": "0"}), ("tight", {"MJPL_ITEM_CAP": "3000"})):
-        for k in ("MJPL_TWO_PASS", "MJPL_FILTER", "MJPL_EXPAND", "MJPL_ITEM_CAP"):
+    # ("two": the fused kernel, one launch for endpoints and waypoints; "kernels2": the two persistent kernels it
+    # replaced; the MJPL_FUSED_* switches: a ring of pool entries that wraps, waypoint tiles first, endpoints as items
+    # of their own -- the mode of small batches -- and not, a waypoint limit that sends most edges to the walking list)
+    keys = ("MJPL_TWO_PASS", "MJPL_FILTER", "MJPL_EXPAND", "MJPL_ITEM_CAP", "MJPL_FUSED", "MJPL_FUSED_POOL",
+            "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX")
+    for tag, env in (("two", {"MJPL_TWO_PASS": "1", "MJPL_FUSED_SINGLE": "0"}), ("auto", {}), ("one", {"MJPL_TWO_PASS": "0"}), ("f64", {"MJPL_FILTER": "0"}),
+                     ("walk", {"MJPL_EXPAND": "0"}), ("kernels2", {"MJPL_FUSED": "0"}),
+                     ("tight", {"MJPL_ITEM_CAP": "3000", "MJPL_FUSED": "0"}),
+                     ("pool", {"MJPL_FUSED_POOL": "832"}), ("items_first", {"MJPL_FUSED_POLICY": "1"}),
+                     ("single", {"MJPL_FUSED_SINGLE": "100000000"}), ("rounds2", {"MJPL_FUSED_SINGLE": "0"}),
+                     ("kmax3", {"MJPL_FUSED_KMAX": "3"}), ("single_kmax3", {"MJPL_FUSED_SINGLE": "100000000", "MJPL_FUSED_KMAX": "3"})):
+        for k in keys:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         e = engine.Engine(m)
         e.set_planning(qidx, base)
         out[tag] = e.check_edges(qa, qb, 0.01, first_bad=True)
-        if tag == "two":
+        if tag in ("two", "kernels2"):
+            assert bool(e.info()["fused_edges"]) == (tag == "two")
             n_int = e.last_interior_edges()
             assert 0 < n_int < len(qa)
             assert e.last_items() > n_int  # one lane per interior waypoint
         if tag == "tight":  # the item buffer overflows: the rest of the edges take the walking kernel
             assert e.last_items() > 3000
+        if tag == "kmax3":  # edges of four waypoints take the walking list
+            assert e.last_items() < out["two"][2]
+        out[tag] = out[tag] + (e.last_items(),)
         e.close()
-    for tag in ("one", "f64", "walk", "tight"):
+    for tag in [t for t in out if t != "two"]:
         np.testing.assert_array_equal(out["two"][0], out[tag][0])
         np.testing.assert_array_equal(out["two"][1], out[tag][1])
     assert 0 < out["two"][0].sum() < len(qa)
@@ -223,15 +236,18 @@ def test_waypoint_recurrence_corner_cases(oracle_mod):
     want, wfb, ncheck = orc.valid_edges(qa, qb, step, nthreads=4, info=True)
     assert 0 < want.sum() < len(want) and ncheck.max() > 50
     import os
-    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_ITEM_CAP": "500"}):
-        old = {k: os.environ.pop(k, None) for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_ITEM_CAP")}
+    mode_keys = ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_ITEM_CAP", "MJPL_FUSED", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX", "MJPL_FUSED_POOL")
+    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_FUSED": "0"}, {"MJPL_ITEM_CAP": "500", "MJPL_FUSED": "0"},
+                {"MJPL_FUSED_SINGLE": "0"}, {"MJPL_FUSED_KMAX": "5"}, {"MJPL_FUSED_KMAX": "5", "MJPL_FUSED_SINGLE": "0"},
+                {"MJPL_FUSED_POOL": "832"}):
+        old = {k: os.environ.pop(k, None) for k in mode_keys}
         os.environ.update(env)
         try:
             e = eng_mod.Engine(m)
             got, gfb = e.check_edges(qa, qb, step, first_bad=True)
             gi = e.check_edges(qa, qb, step, interior_only=True)
         finally:
-            for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_ITEM_CAP"):
+            for k in mode_keys:
                 os.environ.pop(k, None)
                 if old[k] is not None:
                     os.environ[k] = old[k]
@@ -257,8 +273,8 @@ def test_underflowing_edge_is_reported_not_walked(oracle_mod):
     orc = oracle_mod.Oracle(m)
     with pytest.raises(RuntimeError):
         orc.valid_edges(qa2, qb2, 0.01)
-    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_FILTER": "0"}):
-        old = {k: os.environ.pop(k, None) for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_FILTER")}
+    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_FILTER": "0"}, {"MJPL_FUSED": "0"}, {"MJPL_FUSED_SINGLE": "0"}):
+        old = {k: os.environ.pop(k, None) for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_FILTER", "MJPL_FUSED", "MJPL_FUSED_SINGLE")}
         os.environ.update(env)
         try:
             e = eng_mod.Engine(m)
@@ -269,7 +285,7 @@ def test_underflowing_edge_is_reported_not_walked(oracle_mod):
             assert time.time() - t0 < 5.0
             e.close()
         finally:
-            for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_FILTER"):
+            for k in ("MJPL_EXPAND", "MJPL_TWO_PASS", "MJPL_FILTER", "MJPL_FUSED", "MJPL_FUSED_SINGLE"):
                 os.environ.pop(k, None)
                 if old[k] is not None:
                     os.environ[k] = old[k]

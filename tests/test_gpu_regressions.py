@@ -102,7 +102,8 @@ def test_edges_straddling_the_filter_range(oracle_mod):
     qa, qb = np.concatenate([far, near]), np.concatenate([near, far])
     want, wfb, _ = orc.valid_edges(qa, qb, 0.05, nthreads=8, info=True)
     assert 0.05 < want.mean() < 0.95
-    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_UC_CAP": "16"}):
+    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_UC_CAP": "16"}, {"MJPL_FUSED": "0"},
+                {"MJPL_FUSED": "0", "MJPL_UC_CAP": "16"}, {"MJPL_FUSED_SINGLE": "0"}, {"MJPL_FUSED_POLICY": "1", "MJPL_UC_CAP": "16"}):
         with _Env(**env):
             e = eng_mod.Engine(m)
         got, gfb = e.check_edges(qa, qb, 0.05, first_bad=True)
@@ -198,8 +199,11 @@ def test_item_count_is_the_reference_walk(oracle_mod):
     qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
     base = m.keyframe("home").qpos.copy()
     orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
-    e = eng_mod.Engine(m)
+    with _Env(MJPL_FUSED_SINGLE="0"):  # (endpoint tiles and waypoint tiles: an edge's items are its interior waypoints)
+        e = eng_mod.Engine(m)
     e.set_planning(qidx, base)
+    e1 = eng_mod.Engine(m)  # ... a batch this small by default: the endpoint is an item, too (one more per edge)
+    e1.set_planning(qidx, base)
     rng = np.random.default_rng(77)
     E, step = 6000, 0.01
     # around the home pose nothing is near contact: every endpoint survives, nothing is undecided,
@@ -230,17 +234,23 @@ def test_item_count_is_the_reference_walk(oracle_mod):
     assert e.last_undecided() == 0
     assert e.last_items() == want
     e.close()
+    np.testing.assert_array_equal(e1.check_edges(qa, qb, step), got_valid)
+    assert e1.last_items() == want + E
+    e1.close()
 
 
-def test_long_edges_rebuild_undecided_waypoints_from_checkpoints(oracle_mod):
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_long_edges_rebuild_undecided_waypoints_from_checkpoints(oracle_mod, fused):
     """A few long edges (path shortcutting) become hundreds of lane-per-waypoint items each; the
     items the filter cannot decide are rebuilt for the exact re-check by the reference's
-    recurrence from the nearest stored checkpoint (every 32nd waypoint), not from the start."""
+    recurrence -- by the two persistent kernels from the nearest stored checkpoint (every 32nd
+    waypoint), by the fused kernel from the start of the edge."""
     m = scenes.franka_p(obstacles=True)
     qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
     base = m.keyframe("home").qpos.copy()
     orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
-    e = eng_mod.Engine(m)
+    with _Env(MJPL_FUSED=fused):
+        e = eng_mod.Engine(m)
     e.set_planning(qidx, base)
     e.set_filter(True, 2e-2)  # a wide tolerance band: many undecided pairs, at every index
     rng = np.random.default_rng(9)
@@ -265,7 +275,7 @@ def test_item_regions_overflow_to_the_walking_kernel(oracle_mod, cap):
     qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
     base = m.keyframe("home").qpos.copy()
     orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
-    with _Env(MJPL_ITEM_CAP=cap):
+    with _Env(MJPL_ITEM_CAP=cap, MJPL_FUSED="0"):  # (the two persistent kernels: the fused one has no item space)
         e = eng_mod.Engine(m)
     e.set_planning(qidx, base)
     qa, qb = random_edges(m, qidx, 20000, seed=11, eps=0.08)

@@ -83,9 +83,14 @@ def test_specialised_kernels_in_every_interior_pass_mode(oracle_mod):
         want, wfb, _ = oracle_mod.Oracle(m, allowed, planning_qidx=qidx, qpos_base=base).valid_edges(qa, qb, 0.01, nthreads=8, info=True)
     # (MJPL_PERSIST: the endpoint / item kernels as persistent grids of waves with tile queues -- the default
     # with a specialised library -- or as ordinary grids; with the interpreter it is the other way round)
-    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_ITEM_CAP": "3000"}, {"MJPL_UC_CAP": "16"},
-                {"MJPL_PERSIST": "0"}, {"MJPL_PERSIST": "0", "MJPL_ITEM_CAP": "3000"}, {"MJPL_PERSIST": "1", "MJPL_UC_CAP": "16"},
-                {"MJPL_PERSIST": "1", "MJPL_SPEC": "0"}, {"MJPL_PERSIST": "1", "MJPL_SPEC": "0", "MJPL_ITEM_CAP": "3000"}):
+    # ... and since round 4 one fused kernel in their place (MJPL_FUSED=0 restores them), whose own switches follow
+    F0 = {"MJPL_FUSED": "0"}
+    for env in ({}, {"MJPL_EXPAND": "0"}, {"MJPL_TWO_PASS": "0"}, {"MJPL_UC_CAP": "16"}, {"MJPL_SPEC": "0"},
+                {"MJPL_FUSED_POOL": "832"}, {"MJPL_FUSED_POLICY": "1"}, {"MJPL_FUSED_SINGLE": "100000000"}, {"MJPL_FUSED_SINGLE": "0"},
+                {"MJPL_FUSED_KMAX": "3", "MJPL_UC_CAP": "16"}, {"MJPL_FUSED_SINGLE": "100000000", "MJPL_SPEC": "0"},
+                F0, dict(F0, MJPL_ITEM_CAP="3000"), dict(F0, MJPL_UC_CAP="16"),
+                dict(F0, MJPL_PERSIST="0"), dict(F0, MJPL_PERSIST="0", MJPL_ITEM_CAP="3000"), dict(F0, MJPL_PERSIST="1", MJPL_UC_CAP="16"),
+                dict(F0, MJPL_PERSIST="1", MJPL_SPEC="0"), dict(F0, MJPL_PERSIST="1", MJPL_SPEC="0", MJPL_ITEM_CAP="3000")):
         with _Env(**env):
             e = eng_mod.Engine(m, allowed)
             e.set_planning(qidx, base)

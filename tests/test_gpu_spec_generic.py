@@ -47,7 +47,7 @@ def test_one_robot_library_serves_every_scene(oracle_mod, which):
     e.set_spec(True)
     assert e.lib.mjpl_spec_loaded(e.h) == expect
     # both launch layouts
-    for env in ({"MJPL_PERSIST": "0"}, {"MJPL_TAIL": "0"}):
+    for env in ({"MJPL_FUSED": "0"}, {"MJPL_FUSED": "0", "MJPL_PERSIST": "0"}, {"MJPL_TAIL": "0"}, {"MJPL_FUSED_SINGLE": "0"}):
         import os
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)

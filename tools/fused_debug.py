@@ -39,7 +39,19 @@ mean, st, _ = e.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, 0.01, engine.SOA, dv.
 e.close()
 d = np.fromfile(path, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
 os.remove(path)
+full = d
 d = d[d[:, 7] > 0]
+nw = info["fused_waves"] or 12
+if len(full) >= nw and len(d) % nw == 0:
+    g = d.reshape(-1, nw, 8)
+    end = g[:, :, 7].max(axis=1) / 100.0
+    busy = (g[:, :, 3] + g[:, :, 4] + g[:, :, 6]).sum(axis=1) / 100.0 / nw
+    items = g[:, :, 1].sum(axis=1)
+    print(f"workgroups {len(g)}: last wave ends at us min {end.min():.1f} p5 {np.percentile(end,5):.1f} p50 {np.median(end):.1f} p95 {np.percentile(end,95):.1f} "
+          f"max {end.max():.1f}; busy time per wave of a workgroup min {busy.min():.1f} mean {busy.mean():.1f} max {busy.max():.1f}; "
+          f"item tiles per workgroup min {items.min():.0f} mean {items.mean():.1f} max {items.max():.0f}")
+    print(f"  correlation(end, busy) {np.corrcoef(end, busy)[0,1]:.2f}; idle inside workgroups (end - mean wave lifetime) mean "
+          f"{(end - g[:, :, 7].mean(axis=1) / 100.0).mean():.1f} us")
 us = d[:, 3:] / 100.0  # wall_clock64: 100 MHz
 print(f"env {args.env or '-'}: fused {info['fused_edges']} waves/wg {info['fused_waves']}  step {mean*1e3:.1f} us, stages {st}")
 print(f"waves {len(d)}: endpoint tiles {d[:,0].sum():.0f} (per wave min/mean/max {d[:,0].min():.0f}/{d[:,0].mean():.2f}/{d[:,0].max():.0f}), "
