@@ -612,6 +612,7 @@ struct mjpl_engine {
   bool fused = true;
   int fused_policy = 0, fused_kmax = 4096, fused_pool_cap = 0;  // (MJPL_FUSED_POOL: at most that many ring slots)
   int fused_single_max = 32768;  // MJPL_FUSED_SINGLE: batches up to this many edges check every configuration of an edge in one round (measured: 0.068 vs 0.087 ms at 1 024 edges, 0.090 vs 0.102 at 32 768, 0.116 vs 0.106 at 65 536)
+  bool fused_skip_once = false;  // mjpl_check_edges: this launch holds a few long edges -> the kernels with checkpoints
   const char *fused_dbg_path = nullptr;  // MJPL_FUSED_DEBUG=<file> (with a -DMJPL_FUSED_DEBUG build of the kernels)
   unsigned long long *d_fused_dbg = nullptr;
   size_t item_cap_limit = (size_t)1 << 26;  // MJPL_ITEM_CAP: edges beyond it take the walking kernel
@@ -1674,7 +1675,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     ItemBuffers ib = {};
     int fwaves = 0, fring = 0;
     size_t flds = 0;
-    const bool fused = expand && fused_plan(e, &fwaves, &flds, &fring);
+    const bool fused = expand && !e->fused_skip_once && fused_plan(e, &fwaves, &flds, &fring);
+    e->fused_skip_once = false;  // (set by the host-pointer entry point for the launch that follows it)
     if (expand) {
       // per-edge scratch: walking list, step fractions, claim words of the undecided-edge list
       if ((size_t)E > e->llist_cap) {
@@ -2549,6 +2551,24 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
   if (!QB || !valid) return fail(MJPL_E_ARG, "NULL pointer");
   HIP_TRY(hipSetDevice(e->device));
   const size_t qb = (size_t)E * e->qidx.size() * sizeof(double);
+  // A handful of LONG edges (path shortcutting, smooth_path: planning/utils.py:9-87) is better served by the two
+  // persistent kernels, which keep every 32nd exact waypoint as a checkpoint: the fused kernel rebuilds an undecided
+  // waypoint by the recurrence from the start of its edge (measured: 64 edges of 2 400 waypoints 3.9 vs 7.6 ms).  The
+  // rows are in host memory here, so a small batch can simply be looked at.
+  e->fused_skip_once = false;
+  if (E <= 4096) {
+    const int64_t np = (int64_t)e->qidx.size();
+    double longest2 = 0;
+    for (int64_t i = 0; i < E; i++) {
+      double s = 0;
+      for (int64_t k = 0; k < np; k++) {
+        const double d = layout == MJPL_SOA ? QB[k * E + i] - QA[k * E + i] : QB[i * np + k] - QA[i * np + k];
+        s += d * d;
+      }
+      if (s > longest2) longest2 = s;  // (a NaN never compares greater: such an edge is reported by the kernels)
+    }
+    e->fused_skip_once = std::sqrt(longest2) > 64.0 * step_dist;
+  }
   if (2 * qb + 5 * (size_t)E + 16 <= zero_copy_bytes()) {
     const size_t vb = ((size_t)E + 7) & ~(size_t)7, fbb = (size_t)E * sizeof(int32_t);
     if ((rc = pin_reserve(e, 2 * qb + vb + fbb + 8)) != MJPL_OK) return rc;
