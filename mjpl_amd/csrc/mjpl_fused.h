@@ -33,7 +33,8 @@ constexpr int kStatusFusedTimeout = 4;
 
 struct FusedArgs {
   const int *ip; int nip;
-  const float *fp; int nfp;
+  const float *fp; int nfp;      // the float32 tables (k_edges_fused)
+  const double *dp; int ndp;     // the float64 tables (k_edges_fused_f64)
   const double *QA, *QB; long long E; int layout;
   float tol; double step;
   uint8_t *valid; int32_t *first_bad;
@@ -100,6 +101,230 @@ inline bool fused_fits(int nplan, int nsave, bool mbox) {
 // endpoint tile only with 64 free slots set aside for it (RG_RESERVED), so a commit never waits; when the ring is
 // full it takes an item tile instead.  With a ring that holds all entries of the launch none of this is needed
 // and the reservation is skipped (`a.pool >= 64 * tiles of the workgroup`).
+
+// A workgroup's pool and one wave's view of it (every member function is called by whole waves).
+struct WorkPool {
+  double *r_ts;
+  int *r_edge, *r_first;
+  volatile int *ctl;
+  int R, ntw, lane, wv, nw;
+  bool reuse;
+  int my_first;  // the wave's first endpoint tile (ordinal), dealt statically
+  enum : int { LEAVE = 0, WAIT, RETRY, TILE, ITEMS };
+
+  static __host__ __device__ constexpr size_t bytes(int pool) { return (size_t)pool * kFusedEntryBytes + RG_WORDS * sizeof(int); }
+
+  // carve the pool at `mem` (8-byte aligned) and set its control words; the caller's workgroup barrier publishes them
+  __device__ __forceinline__ void init(char *mem, int pool, long long tile0, long long tile1, int nwaves) {
+    R = pool;
+    nw = nwaves;
+    lane = (int)(threadIdx.x & 63);
+    wv = (int)(threadIdx.x >> 6);
+    r_ts = reinterpret_cast<double *>(mem);
+    r_edge = reinterpret_cast<int *>(r_ts + R);
+    r_first = r_edge + R;
+    ctl = r_first + R;
+    // this workgroup's endpoint tiles: ordinal n -> tile0 + b + n * grid
+    const long long span = tile1 - tile0 - (long long)blockIdx.x;
+    ntw = span > 0 ? (int)((span + gridDim.x - 1) / gridDim.x) : 0;
+    // (the first `nwaves` tiles: one per wave, their room in the ring set aside from the start)
+    if (threadIdx.x < RG_WORDS)
+      ctl[threadIdx.x] = threadIdx.x == RG_NEXT ? (ntw < nw ? ntw : nw)
+                       : threadIdx.x == RG_RESERVED ? 64 * (ntw < nw ? ntw : nw)
+                       : threadIdx.x >= RG_NEED ? kFusedIdle : 0;
+    if (threadIdx.x == 0) r_first[0] = 0;  // (first[ENT] == COMMIT from the start)
+    reuse = (long long)ntw * 64 + 1 > (long long)R;  // slots are written more than once in this launch
+    my_first = wv < ntw ? wv : -1;
+  }
+  __device__ __forceinline__ long long tile_of(int n, long long tile0) const { return tile0 + blockIdx.x + (long long)n * gridDim.x; }
+
+  __device__ __forceinline__ void lock() const {
+    if (lane == 0)
+      while (atomicCAS(const_cast<int *>(&ctl[RG_LOCK]), 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void unlock() const {
+    // (release: every store of this wave -- pool entries in LDS, verdict bytes on their way to L2 -- has been
+    // performed before another wave can see the lock free)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(const_cast<int *>(&ctl[RG_LOCK]), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // What next for this wave?  TILE: endpoint tile `tile_n` (ordinal in the workgroup).  ITEMS: waypoints
+  // [.., + take) of the pool, this lane's in (ed, idx, ts): edge, 1-based position among the edge's items, step
+  // fraction; ed < 0 on the lanes beyond `take`.  WAIT: nothing to take yet, look again later.  RETRY: another wave
+  // was quicker, look again at once.  LEAVE: the workgroup's work is done.
+  __device__ __forceinline__ int next(int policy, int &tile_n, int &take, int &ed, int &idx, double &ts) {
+    tile_n = -1;
+    take = 0;
+    ed = -1;
+    idx = 0;
+    ts = 0.0;
+    if (my_first >= 0) {
+      tile_n = my_first;
+      my_first = -1;
+      return TILE;
+    }
+    // (read in this order: `produced` == ntw means `commit` is final)
+    const int produced = __hip_atomic_load(const_cast<int *>(&ctl[RG_PRODUCED]), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long head = __hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int commit = __hip_atomic_load(const_cast<int *>(&ctl[RG_COMMIT]), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int claimed = (int)(unsigned)(head >> 32), he = (int)(unsigned)head;
+    const int next_tile = ctl[RG_NEXT];
+    const int avail = commit - claimed;
+    const bool tiles_left = next_tile < ntw;
+    bool want_tile = tiles_left && !((policy & 1) && avail >= 64);
+    if (want_tile && reuse) {
+      // room for the tile's entries (up to 64)?  Entries below the head's and below every entry a wave is still
+      // reading are free.  (head first, the publications after it: see above)
+      lock();
+      const unsigned long long hd = __hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      int lowest = lane < nw ? ctl[RG_NEED + lane] : kFusedIdle;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const int other = __shfl_xor(lowest, o);
+        lowest = other < lowest ? other : lowest;
+      }
+      lowest = __builtin_amdgcn_readfirstlane(lowest);
+      const int free_below = lowest < (int)(unsigned)hd ? lowest : (int)(unsigned)hd;
+      const int reserved = ctl[RG_RESERVED];
+      const bool room = R - (ctl[RG_ENT] - free_below) - reserved >= 65;  // (64 entries and the slot behind them)
+      if (room && lane == 0) ctl[RG_RESERVED] = reserved + 64;
+      unlock();
+      want_tile = room;
+    }
+    if (want_tile) {
+      int n = 0;
+      if (lane == 0) n = atomicAdd(const_cast<int *>(&ctl[RG_NEXT]), 1);
+      n = __builtin_amdgcn_readfirstlane(n);
+      if (n < ntw) {
+        tile_n = n;
+        return TILE;
+      }
+      if (reuse) {  // (another wave was quicker)
+        lock();
+        if (lane == 0) ctl[RG_RESERVED] = ctl[RG_RESERVED] - 64;
+        unlock();
+      }
+      return RETRY;
+    }
+    if (avail >= 64 || (avail > 0 && (!tiles_left || reuse))) {
+      // (with no tile left to take -- or no room for one -- a partial claim beats waiting for the producers; sharing a
+      // workgroup's last waypoints out evenly, so that all its waves end together, was measured: part-filled tiles
+      // cost nearly what full ones do -- 40 % more tiles, 9 % more time per batch)
+      const int want = avail < 64 ? avail : 64;
+      const int h = claimed;
+      // the first numbers of the entries behind the head's: g[j] = first[he + 1 + j] (the end of entry he + j)
+      if (lane == 0) ctl[RG_NEED + wv] = he;  // BEFORE the compare-and-swap
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      const int nent = ctl[RG_ENT];  // (read after `commit`: covers every waypoint below it)
+      const int hslot = he % R;
+      int gs = hslot + 1 + lane;
+      gs = gs >= R ? gs - R : gs;
+      gs = gs >= R ? gs - R : gs;
+      const int ge = he + 1 + lane;
+      // (slot `nent` holds the number the next entry will start at -- the end of the last one: the producers keep
+      // first[ENT] == COMMIT.  `nent` may be newer than `commit`: the numbers beyond it are real, and the claim
+      // ends at `commit` whatever lies behind)
+      const int g = ge <= nent ? r_first[gs] : 0x7fffffff;
+      const int f0 = r_first[hslot];  // (he < nent: a waypoint is pending)
+      const int adv = (int)__builtin_popcountll(__ballot(g <= h + want));  // entries used up by this claim
+      int got = 0;
+      if (lane == 0)
+        got = atomicCAS(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])), head,
+                        ((unsigned long long)(unsigned)(h + want) << 32) | (unsigned)(he + adv)) == head ? 1 : 0;
+      if (!__builtin_amdgcn_readfirstlane(got)) {  // (another wave was quicker: look again)
+        if (lane == 0) ctl[RG_NEED + wv] = kFusedIdle;
+        return RETRY;
+      }
+      // this lane's entry: he + (number of j with g[j] <= its waypoint number)
+      const int s = h + lane;
+      int jl = 0, jh = 64;  // invariant: g[jl - 1] <= s < g[jh - 1]   (g[-1] = f0 <= h)
+      int fl = f0;
+#pragma unroll
+      for (int it = 0; it < 6; it++) {  // (every lane takes part in every shuffle)
+        const int mid = (jl + jh) >> 1;  // 1 .. 63
+        const int gm = __shfl(g, mid - 1);
+        const bool le = gm <= s;
+        jl = le ? mid : jl;
+        fl = le ? gm : fl;
+        jh = le ? jh : mid;
+      }
+      if (lane < want) {
+        int es = hslot + jl;
+        es = es >= R ? es - R : es;
+        ed = r_edge[es];
+        ts = r_ts[es];
+        idx = s - fl + 1;
+      }
+      wave_lds_fence();  // (the reads above before the withdrawal)
+      if (lane == 0) ctl[RG_NEED + wv] = kFusedIdle;
+      take = want;
+      return ITEMS;
+    }
+    return (produced >= ntw && avail == 0) ? LEAVE : WAIT;
+  }
+
+  // An endpoint tile is through: its surviving lanes (`entry`) enter the pool with K items each.
+  __device__ __forceinline__ void commit(bool entry, int K, long long i, double tse) {
+    const unsigned long long me = __ballot(entry);
+    const int nent = (int)__builtin_popcountll(me);
+    int incl = entry ? K : 0;  // this lane's first waypoint number, relative to the tile's: an exclusive prefix sum
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    const int total = __shfl(incl, 63);
+    lock();
+    {
+      const int e0 = ctl[RG_ENT], f0 = ctl[RG_COMMIT];
+      if (entry) {
+        int slot = e0 % R + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(me >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)me, 0u));
+        slot = slot >= R ? slot - R : slot;
+        r_edge[slot] = (int)i;
+        r_first[slot] = f0 + incl - K;
+        r_ts[slot] = tse;
+      }
+      if (lane == 0) {  // the slot behind the last entry: where the next one will start (first[ENT] == COMMIT)
+        int send = e0 % R + nent;
+        send = send >= R ? send - R : send;
+        r_first[send] = f0 + total;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entries (and this tile's verdict bytes) before the counts
+      if (lane == 0) {
+        ctl[RG_ENT] = e0 + nent;
+        __hip_atomic_store(const_cast<int *>(&ctl[RG_COMMIT]), f0 + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (reuse) ctl[RG_RESERVED] = ctl[RG_RESERVED] - 64;
+        __hip_atomic_store(const_cast<int *>(&ctl[RG_PRODUCED]), ctl[RG_PRODUCED] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    unlock();
+  }
+};
+
+#ifdef MJPL_FUSED_DEBUG
+#define MJPL_DG_DECL unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long dg_t0 = wall_clock64()
+#define MJPL_DG(k, v) dg[k] += (v)
+#define MJPL_DG_NOW() wall_clock64()
+#define MJPL_DG_FLUSH(a, nwaves)                                                          \
+  if ((a).dbg && (threadIdx.x & 63) == 0) {                                               \
+    dg[7] = wall_clock64() - dg_t0;                                                       \
+    unsigned long long *row = (a).dbg + ((size_t)blockIdx.x * (nwaves) + (threadIdx.x >> 6)) * 8; \
+    for (int k = 0; k < 8; k++) row[k] = dg[k];                                           \
+  }
+#else
+#define MJPL_DG_DECL
+#define MJPL_DG(k, v)
+#define MJPL_DG_NOW() 0ull
+#define MJPL_DG_FLUSH(a, nwaves)
+#endif
+
 template <class Spec, int MAXS, bool WBOX, bool MBOX, int NW>
 __global__ void __launch_bounds__(NW * 64, (kMinWaves<Spec, MAXS>))
 k_edges_fused(FusedArgs a) {
@@ -109,7 +334,6 @@ k_edges_fused(FusedArgs a) {
   const int nplan = StaticNplan<Spec>::value ? StaticNplan<Spec>::value : a.ip[H_NPLAN];
   const int nsave = a.ip[H_NSAVE];
   const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-  const int R = a.pool;
   // ---- LDS: [wave slices, each followed by the wave's item table | table copy | pool entries | pool control]
   const size_t qbytes = WaveQueue<float, MBOX>::bytes();
   WaveLds<float, MBOX> w;
@@ -123,169 +347,28 @@ k_edges_fused(FusedArgs a) {
   char *shared = reinterpret_cast<char *>(smem) + (size_t)NW * wbytes;
   w.ltab = reinterpret_cast<float *>(shared);
   for (int k = threadIdx.x; k < a.nfp; k += blockDim.x) w.ltab[k] = a.fp[k];
-  double *r_ts = reinterpret_cast<double *>(shared + (((size_t)a.nfp * sizeof(float) + 7) & ~(size_t)7));
-  int *r_edge = reinterpret_cast<int *>(r_ts + R), *r_first = r_edge + R;
-  volatile int *ctl = r_first + R;
-  // this workgroup's endpoint tiles: ordinal n -> tile0 + b + n * grid
-  const long long span = a.tile1 - a.tile0 - (long long)blockIdx.x;
-  const int ntw = span > 0 ? (int)((span + gridDim.x - 1) / gridDim.x) : 0;
-  // (the first NW tiles: one per wave, their room in the ring set aside from the start)
-  if (threadIdx.x < RG_WORDS)
-    ctl[threadIdx.x] = threadIdx.x == RG_NEXT ? (ntw < NW ? ntw : NW)
-                     : threadIdx.x == RG_RESERVED ? 64 * (ntw < NW ? ntw : NW)
-                     : threadIdx.x >= RG_NEED ? kFusedIdle : 0;
-  if (threadIdx.x == 0) r_first[0] = 0;  // (first[ENT] == COMMIT from the start)
-  const bool reuse = (long long)ntw * 64 + 1 > (long long)R;  // slots are written more than once in this launch
+  WorkPool pool;
+  pool.init(shared + (((size_t)a.nfp * sizeof(float) + 7) & ~(size_t)7), a.pool, a.tile0, a.tile1, NW);
   __syncthreads();  // the table copy and the pool's control words; from here on a wave is on its own
-
-  auto lock = [&]() {
-    if (lane == 0)
-      while (atomicCAS(const_cast<int *>(&ctl[RG_LOCK]), 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-  };
-  auto unlock = [&]() {
-    // (release: every store of this wave -- pool entries in LDS, verdict bytes on their way to L2 -- has been
-    // performed before another wave can see the lock free)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(const_cast<int *>(&ctl[RG_LOCK]), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __builtin_amdgcn_wave_barrier();
-  };
 
   const bool fits = (size_t)2 * nplan * 64 * sizeof(double) <= w.bytes;  // (the launcher has checked)
   double *qe = reinterpret_cast<double *>(w.base) + lane;
   double *qx = qe + (size_t)nplan * 64;
   float *qw = w.col + lane;
-  int my_first = wv < ntw ? wv : -1;  // the wave's first endpoint tile (ordinal), dealt statically
   int stat_items = 0, stat_surv = 0;
   int spins = 0;
-#ifdef MJPL_FUSED_DEBUG
-  unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long dg_t0 = wall_clock64();
-#define MJPL_DG(k, v) dg[k] += (v)
-#define MJPL_DG_NOW() wall_clock64()
-#else
-#define MJPL_DG(k, v)
-#define MJPL_DG_NOW() 0ull
-#endif
+  MJPL_DG_DECL;
 
   for (;;) {
     // ---- what next?
     const unsigned long long dg_a = MJPL_DG_NOW();
     (void)dg_a;
-    int tile_n = -1;        // endpoint tile (ordinal in this workgroup), or
-    int h = 0, take = 0;    // waypoints [h, h + take) of the pool
-    int ed = -1, idx = 0;   // item tile: this lane's waypoint
-    double ts = 0.0;
-    bool leave = false;
-    if (my_first >= 0) {
-      tile_n = my_first;
-      my_first = -1;
-    } else {
-      // (read in this order: `produced` == ntw means `commit` is final)
-      const int produced = __hip_atomic_load(const_cast<int *>(&ctl[RG_PRODUCED]), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const unsigned long long head = __hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])),
-                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const int commit = __hip_atomic_load(const_cast<int *>(&ctl[RG_COMMIT]), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const int claimed = (int)(unsigned)(head >> 32), he = (int)(unsigned)head;
-      const int next = ctl[RG_NEXT];
-      const int avail = commit - claimed;
-      const bool tiles_left = next < ntw;
-      bool want_tile = tiles_left && !((a.policy & 1) && avail >= 64);
-      if (want_tile && reuse) {
-        // room for the tile's entries (up to 64)?  Entries below the head's and below every entry a wave is still
-        // reading are free.  (head first, the publications after it: see above)
-        lock();
-        const unsigned long long hd = __hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])),
-                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        int lowest = lane < NW ? ctl[RG_NEED + lane] : kFusedIdle;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          const int other = __shfl_xor(lowest, o);
-          lowest = other < lowest ? other : lowest;
-        }
-        lowest = __builtin_amdgcn_readfirstlane(lowest);
-        const int free_below = lowest < (int)(unsigned)hd ? lowest : (int)(unsigned)hd;
-        const int reserved = ctl[RG_RESERVED];
-        const bool room = R - (ctl[RG_ENT] - free_below) - reserved >= 65;  // (64 entries and the slot behind them)
-        if (room && lane == 0) ctl[RG_RESERVED] = reserved + 64;
-        unlock();
-        want_tile = room;
-      }
-      if (want_tile) {
-        int n = 0;
-        if (lane == 0) n = atomicAdd(const_cast<int *>(&ctl[RG_NEXT]), 1);
-        n = __builtin_amdgcn_readfirstlane(n);
-        if (n < ntw) {
-          tile_n = n;
-        } else {  // (another wave was quicker)
-          if (reuse) {
-            lock();
-            if (lane == 0) ctl[RG_RESERVED] = ctl[RG_RESERVED] - 64;
-            unlock();
-          }
-          continue;
-        }
-      } else if (avail >= 64 || (avail > 0 && (!tiles_left || reuse))) {
-        // (with no tile left to take -- or no room for one -- a partial claim beats waiting for the producers)
-        take = avail < 64 ? avail : 64;
-        // (sharing a workgroup's last waypoints out evenly, so that all its waves end together, was measured: part-filled
-        // tiles cost nearly what full ones do -- 40 % more tiles, 9 % more time per batch)
-        h = claimed;
-        // the first numbers of the entries behind the head's: g[j] = first[he + 1 + j] (the end of entry he + j),
-        // `commit` for the entry behind the last one, +inf beyond
-        if (lane == 0) ctl[RG_NEED + wv] = he;  // BEFORE the compare-and-swap
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        const int nent = ctl[RG_ENT];  // (read after `commit`: covers every waypoint below it)
-        const int hslot = he % R;
-        int gs = hslot + 1 + lane;
-        gs = gs >= R ? gs - R : gs;
-        gs = gs >= R ? gs - R : gs;
-        const int ge = he + 1 + lane;
-        // (slot `nent` holds the number the next entry will start at -- the end of the last one: the producers keep
-        // first[ENT] == COMMIT.  `nent` may be newer than `commit`: the numbers beyond it are real, and the claim
-        // ends at `commit` whatever lies behind)
-        const int g = ge <= nent ? r_first[gs] : 0x7fffffff;
-        const int f0 = r_first[hslot];  // (he < nent: a waypoint is pending)
-        const int adv = (int)__builtin_popcountll(__ballot(g <= h + take));  // entries used up by this claim
-        int got = 0;
-        if (lane == 0)
-          got = atomicCAS(reinterpret_cast<unsigned long long *>(const_cast<int *>(&ctl[RG_HEAD])), head,
-                          ((unsigned long long)(unsigned)(h + take) << 32) | (unsigned)(he + adv)) == head ? 1 : 0;
-        if (!__builtin_amdgcn_readfirstlane(got)) {  // (another wave was quicker: look again)
-          if (lane == 0) ctl[RG_NEED + wv] = kFusedIdle;
-          take = 0;
-          continue;
-        }
-        // this lane's entry: he + (number of j with g[j] <= its waypoint number)
-        const int s = h + lane;
-        int jl = 0, jh = 64;  // invariant: g[jl - 1] <= s < g[jh - 1]   (g[-1] = f0 <= h)
-        int fl = f0;
-#pragma unroll
-        for (int it = 0; it < 6; it++) {  // (every lane takes part in every shuffle)
-          const int mid = (jl + jh) >> 1;  // 1 .. 63
-          const int gm = __shfl(g, mid - 1);
-          const bool le = gm <= s;
-          jl = le ? mid : jl;
-          fl = le ? gm : fl;
-          jh = le ? jh : mid;
-        }
-        if (lane < take) {
-          int es = hslot + jl;
-          es = es >= R ? es - R : es;
-          ed = r_edge[es];
-          ts = r_ts[es];
-          idx = s - fl + 1;
-        }
-        wave_lds_fence();  // (the reads above before the withdrawal)
-        if (lane == 0) ctl[RG_NEED + wv] = kFusedIdle;
-      } else if (produced >= ntw && avail == 0) {
-        leave = true;
-      }
-    }
-    if (leave) break;
-    if (tile_n < 0 && take == 0) {  // nothing to take: the last endpoint tiles of the workgroup are still being checked
+    int tile_n, take, ed, idx;
+    double ts;
+    const int kind = pool.next(a.policy, tile_n, take, ed, idx, ts);
+    if (kind == WorkPool::LEAVE) break;
+    if (kind == WorkPool::RETRY) continue;
+    if (kind == WorkPool::WAIT) {  // nothing to take (the last endpoint tiles of the workgroup are still being checked), or a lost race
       __builtin_amdgcn_s_sleep(32);
       MJPL_DG(2, 1);
       MJPL_DG(5, MJPL_DG_NOW() - dg_a);
@@ -296,12 +379,12 @@ k_edges_fused(FusedArgs a) {
       continue;
     }
     spins = 0;
-    const bool ep = tile_n >= 0;
+    const bool ep = kind == WorkPool::TILE;
     const unsigned long long dg_b = MJPL_DG_NOW();
     (void)dg_b;
     MJPL_DG(6, dg_b - dg_a);
     // ---- the tile's configurations -> this wave's binary32 columns
-    const long long tile = ep ? a.tile0 + blockIdx.x + (long long)tile_n * gridDim.x : -1;
+    const long long tile = ep ? pool.tile_of(tile_n, a.tile0) : -1;
     const long long i = ep ? tile * 64 + lane : (long long)(ed >= 0 ? ed : 0);
     bool active = ep ? i < a.E : ed >= 0;
     bool finite = true;
@@ -397,52 +480,154 @@ k_edges_fused(FusedArgs a) {
     if (survive && K < 0) a.llist[atomicAdd(a.lcount, 1)] = (int)i;  // too long (or too many columns): walking kernel
     if (a.single) K = K < 0 ? 1 : K + 1;  // (the endpoint is check 0 of the edge's items; of a walking edge the only one)
     const bool entry = survive && K > 0;
-    const unsigned long long me = __ballot(entry);
-    const int nent = (int)__builtin_popcountll(me);
-    int incl = entry ? K : 0;  // this lane's first waypoint number, relative to the tile's: an exclusive prefix sum
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o);
-      if (lane >= o) incl += up;
-    }
-    const int total = __shfl(incl, 63);
     const double tse = entry ? a.tstep[i] : 0.0;
     stat_surv += (int)__builtin_popcountll(__ballot(survive));
-    lock();
-    {
-      const int e0 = ctl[RG_ENT], f0 = ctl[RG_COMMIT];
-      if (entry) {
-        int slot = e0 % R + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(me >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)me, 0u));
-        slot = slot >= R ? slot - R : slot;
-        r_edge[slot] = (int)i;
-        r_first[slot] = f0 + incl - K;
-        r_ts[slot] = tse;
-      }
-      if (lane == 0) {  // the slot behind the last entry: where the next one will start (first[ENT] == COMMIT)
-        int send = e0 % R + nent;
-        send = send >= R ? send - R : send;
-        r_first[send] = f0 + total;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entries (and this tile's verdict bytes) before the counts
-      if (lane == 0) {
-        ctl[RG_ENT] = e0 + nent;
-        __hip_atomic_store(const_cast<int *>(&ctl[RG_COMMIT]), f0 + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (reuse) ctl[RG_RESERVED] = ctl[RG_RESERVED] - 64;
-        __hip_atomic_store(const_cast<int *>(&ctl[RG_PRODUCED]), ctl[RG_PRODUCED] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-    unlock();
+    pool.commit(entry, K, i, tse);
     MJPL_DG(0, 1);
     MJPL_DG(3, MJPL_DG_NOW() - dg_b);
   }
-#ifdef MJPL_FUSED_DEBUG
-  if (a.dbg && lane == 0) {
-    dg[7] = wall_clock64() - dg_t0;
-    unsigned long long *row = a.dbg + ((size_t)blockIdx.x * NW + wv) * 8;
-    for (int k = 0; k < 8; k++) row[k] = dg[k];
-  }
-#endif
+  MJPL_DG_FLUSH(a, NW);
   // statistics of the launch (mjpl_filter_last_items / _last_interior_edges)
+  if (lane == 0) {
+    const int region = (int)(blockIdx.x % kItemRegions);
+    if (stat_items) atomicAdd(a.item_count + region * kCounterStride, stat_items);
+    if (stat_surv) atomicAdd(a.surv_count + region * kCounterStride, stat_surv);
+  }
+}
+
+// ---- the float64 path with the same launch shape (filter off: mjpl_set_filter(e, 0), or a model the filter refuses) ----
+// k_check_edges gives every edge a lane for all of its checks: a wave lives as long as its longest edge, lanes whose
+// edge ended at its endpoint idle through every later waypoint, and with 64 unrelated configurations per wave most
+// pairs' narrowphase runs for a lane or two.  Here the float64 checks go through the pool: the endpoints of a tile
+// (exact verdicts: nothing is left undecided), then the interior waypoints of the survivors as items -- consecutive
+// waypoints of an edge on neighbouring lanes, which pass the same bounding culls, so that the interpreter's "some lane
+// needs this routine" runs it for many lanes at once.  A waypoint is the reference's own: rebuilt by the recurrence
+// from QA (k steps for waypoint k), never the closed form the float32 filter may test -- so edges of more than
+// kFusedF64Kmax interior waypoints take the walking kernel (k_check_edges over the walking list), whose lane carries
+// the waypoint along.  Verdicts are those of k_check_edges bit for bit: same statements on the same values.
+constexpr int kFusedF64Waves = 8;   // 186 .. 256 VGPRs: two waves per SIMD
+constexpr int kFusedF64Kmax = 31;
+__host__ __device__ constexpr size_t fused_f64_wave_bytes(int nplan, int nsave) {
+  const size_t rows = (size_t)nplan * 64 * sizeof(double), saves = (size_t)nsave * 7 * 64 * sizeof(double);
+  return rows + (saves > rows ? saves : rows);  // [columns / end row | pose saves / walking row]
+}
+inline size_t fused_f64_lds_bytes(int nwaves, int nplan, int nsave, int pool) {
+  return (size_t)nwaves * fused_f64_wave_bytes(nplan, nsave) + WorkPool::bytes(pool);
+}
+
+template <int MAXS, bool WBOX, bool MBOX, int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_edges_fused_f64(FusedArgs a) {
+  extern __shared__ double smem[];
+  zero_counters(a.zero_next);
+  const int nplan = a.ip[H_NPLAN], nsave = a.ip[H_NSAVE];
+  const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+  const size_t wbytes = fused_f64_wave_bytes(nplan, nsave);
+  double *col = reinterpret_cast<double *>(reinterpret_cast<char *>(smem) + (size_t)wv * wbytes) + lane;  // [nplan][64]
+  double *aux = col + (size_t)nplan * 64;  // pose saves during a check, the walking / end row between checks
+  WorkPool pool;
+  pool.init(reinterpret_cast<char *>(smem) + (size_t)NW * wbytes, a.pool, a.tile0, a.tile1, NW);
+  __syncthreads();
+  const int *perm = a.ip + a.ip[H_OFF_PERM];
+  FkOut none = {};
+  int stat_items = 0, stat_surv = 0, spins = 0;
+  MJPL_DG_DECL;
+  for (;;) {
+    const unsigned long long dg_a = MJPL_DG_NOW();
+    (void)dg_a;
+    int tile_n, take, ed, idx;
+    double ts;
+    const int kind = pool.next(a.policy, tile_n, take, ed, idx, ts);
+    if (kind == WorkPool::LEAVE) break;
+    if (kind == WorkPool::RETRY) continue;
+    if (kind == WorkPool::WAIT) {
+      __builtin_amdgcn_s_sleep(32);
+      MJPL_DG(2, 1);
+      MJPL_DG(5, MJPL_DG_NOW() - dg_a);
+      if (++spins > (1 << 22)) {
+        if (lane == 0) atomicOr(a.status, kStatusFusedTimeout);
+        break;
+      }
+      continue;
+    }
+    spins = 0;
+    const bool ep = kind == WorkPool::TILE;
+    const unsigned long long dg_b = MJPL_DG_NOW();
+    (void)dg_b;
+    MJPL_DG(6, dg_b - dg_a);
+    const long long i = ep ? pool.tile_of(tile_n, a.tile0) * 64 + lane : (long long)(ed >= 0 ? ed : 0);
+    bool active = ep ? i < a.E : ed >= 0;
+    bool finite = true;
+    int K = 0;
+    if (ep) {
+      // QB -> the columns (it is check 0 and the end of the walk), QA -> the walking row; the waypoint count
+      bool at_end = true;
+      for_rows(a.QA, a.QB, a.E, i, nplan, a.layout, active, [&](int k, double x, double y) {
+        finite = finite && (fabs(x) <= 1.79769313486231570815e+308) && (fabs(y) <= 1.79769313486231570815e+308);
+        aux[k * 64] = x;
+        col[k * 64] = y;
+        at_end = at_end && (x == y);
+      });
+      double tsw;
+      K = count_waypoints_walk(a.ip, a.step, active && finite, at_end, col, 64, aux, 64, a.kmax, nplan, tsw);
+      if (!finite)  // (never a NaN / inf row in a check, not even on a lane that keeps company: see k_filter_endpoints)
+        for (int k = 0; k < nplan; k++) col[k * 64] = 0.0;
+      active = active && finite;
+    } else {
+      // waypoint idx of edge ed by the reference's recurrence: idx steps from QA towards QB (planning/utils.py:182-185,
+      // the statements of edge_body); the end row sits in `aux`, the walking waypoint in the columns
+      for_rows(a.QA, a.QB, a.E, i, nplan, a.layout, true, [&](int k, double x, double y) {
+        col[k * 64] = x;
+        aux[k * 64] = y;
+      });
+      for (int n = 0; __ballot(active && n < idx) != 0ull; n++) {
+        if (active && n < idx) {
+          double sq = 0;
+          for (int k = 0; k < nplan; k++) {
+            const int c = perm[k];
+            const double d = aux[c * 64] - col[c * 64];
+            sq = sq + d * d;
+          }
+          const double mag = sqrt(sq);
+          const double sm = a.step < mag ? a.step : mag;
+          for (int k = 0; k < nplan; k++) {
+            const double d = aux[k * 64] - col[k * 64];
+            col[k * 64] = col[k * 64] + (d / mag) * sm;
+          }
+        }
+      }
+    }
+    wave_lds_fence();
+    const bool hit = run_config<double, MAXS, false, WBOX, MBOX>((IP)a.ip, (DP)a.dp, col, 64, aux, 64, active, 0.0, none, i) == V_CONTACT;
+    wave_lds_fence();
+    if (!ep) {
+      if (active && hit) {
+        a.valid[ed] = 0;
+        if (a.first_bad) atomicMin(reinterpret_cast<unsigned *>(a.first_bad) + ed, (unsigned)idx);
+      }
+      stat_items += (int)__builtin_popcountll(__ballot(active));
+      MJPL_DG(1, 1);
+      MJPL_DG(4, MJPL_DG_NOW() - dg_b);
+      continue;
+    }
+    const bool survive = active && !hit;
+    if (i < a.E) {
+      if (!finite) {
+        a.valid[i] = 0;
+        if (a.first_bad) a.first_bad[i] = -2;
+        atomicOr(a.status, kStatusNonFinite);
+      } else {
+        a.valid[i] = hit ? 0 : 1;  // (a survivor's: so far; its item tiles or the walking kernel may clear it)
+        if (a.first_bad) a.first_bad[i] = hit ? 0 : -1;
+      }
+    }
+    if (survive && K < 0) a.llist[atomicAdd(a.lcount, 1)] = (int)i;  // long (or degenerate): the walking kernel
+    stat_surv += (int)__builtin_popcountll(__ballot(survive));
+    pool.commit(survive && K > 0, K, i, 0.0);
+    MJPL_DG(0, 1);
+    MJPL_DG(3, MJPL_DG_NOW() - dg_b);
+  }
+  MJPL_DG_FLUSH(a, NW);
   if (lane == 0) {
     const int region = (int)(blockIdx.x % kItemRegions);
     if (stat_items) atomicAdd(a.item_count + region * kCounterStride, stat_items);

@@ -1950,6 +1950,74 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       if (rc != MJPL_OK) return rc;
     }
     MJPL_MARK(4);  // after the exact re-check of undecided pairs / configurations
+  } else if (e->fused && e->two_pass && e->expand && !(flags & MJPL_EDGE_INTERIOR_ONLY) && !e->exact_general() && E < (int64_t)1 << 30 &&
+             fused_f64_lds_bytes(kFusedF64Waves, (int)e->qidx.size(), e->nsave, 64 * kFusedF64Waves + 64) <= (size_t)160 * 1024) {
+    // ---- filter off, the float64 checks through the pool (mjpl_fused.h: k_edges_fused_f64): endpoints, then the interior
+    // waypoints of the survivors as items; edges of more than kFusedF64Kmax waypoints are left to k_check_edges below
+    int rc = ulist_reserve(e, E);
+    if (rc != MJPL_OK) return rc;
+    if ((size_t)E > e->llist_cap) {
+      for (void *ptr : {(void *)e->d_tstep, (void *)e->d_llist, (void *)e->d_eclaim})
+        if (ptr) HIP_TRY(hipFree(ptr));
+      e->d_tstep = nullptr;
+      e->d_llist = e->d_eclaim = nullptr;
+      e->llist_cap = 0;
+      HIP_TRY(hipMalloc(&e->d_llist, (size_t)E * sizeof(int)));
+      HIP_TRY(hipMalloc(&e->d_tstep, (size_t)E * sizeof(double)));
+      HIP_TRY(hipMalloc(&e->d_eclaim, (size_t)E * sizeof(int)));
+      HIP_TRY(hipMemsetAsync(e->d_eclaim, 0, (size_t)E * sizeof(int), e->stream));
+      e->claim_gen = 0;
+      e->llist_cap = (size_t)E;
+    }
+    int *zero_next = next_counters(e);
+    CounterGuard guard{e, true};
+    const int nplan = (int)e->qidx.size();
+    const size_t base = fused_f64_lds_bytes(kFusedF64Waves, nplan, e->nsave, 0);
+    int pool = (int)std::min<size_t>(kFusedMaxPool, ((size_t)160 * 1024 - base) / kFusedEntryBytes / 64 * 64);
+    if (e->fused_pool_cap > 0) pool = std::max(64 * kFusedF64Waves + 64, std::min(pool, e->fused_pool_cap / 64 * 64));
+    const size_t flds = fused_f64_lds_bytes(kFusedF64Waves, nplan, e->nsave, pool);
+    FusedArgs fa = {};
+    fa.ip = e->d_ip; fa.nip = (int)e->ip.size();
+    fa.dp = e->d_dp; fa.ndp = (int)e->dp.size();
+    fa.QA = dQA; fa.QB = dQB; fa.E = (long long)E; fa.layout = layout;
+    fa.step = step;
+    fa.valid = dvalid; fa.first_bad = dfb;
+    fa.status = e->d_status;
+    fa.llist = e->d_llist; fa.lcount = e->d_icount + kCtr;
+    fa.item_count = e->d_ucount + 5 * kCtr;
+    fa.surv_count = e->d_ucount + (5 + kItemRegions) * kCtr;
+    fa.zero_next = zero_next;
+    fa.kmax = kFusedF64Kmax; fa.pool = pool; fa.policy = e->fused_policy;
+    MJPL_MARK(0);
+    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+      if constexpr (!decltype(M)::value) {
+        auto kern = k_edges_fused_f64<decltype(S)::value, decltype(W)::value, false, kFusedF64Waves>;
+        int r = allow_lds(kern, flds);
+        if (r != MJPL_OK) return r;
+        if (fused_launch(kern, kFusedF64Waves, flds, fa, e->stream) != hipSuccess) return fail(MJPL_E_HIP, "the float64 pool kernel failed to launch");
+        return MJPL_OK;
+      } else {
+        return fail(MJPL_E_ARG, "the float64 pool kernel serves the small builds");
+      }
+    });
+    if (rc != MJPL_OK) return rc;
+    guard.armed = false;
+    for (int k = 1; k <= 4; k++) MJPL_MARK(k);
+    // the walking list (long edges): k_check_edges, interior waypoints only (the endpoint's verdict stands)
+    const size_t ldsw = lds_bytes(e, 1);
+    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+      auto kern = k_check_edges<decltype(S)::value, decltype(W)::value, decltype(M)::value>;
+      int r = allow_lds(kern, ldsw);
+      if (r != MJPL_OK) return r;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), ldsw, e->stream, e->d_ip, (int)e->ip.size(), e->d_dp, (int)e->dp.size(),
+                         dQA, dQB, E, step, layout, flags | MJPL_EDGE_INTERIOR_ONLY, dvalid, dfb, e->d_status,
+                         (const int *)e->d_llist, (const int *)(e->d_icount + kCtr));
+      return MJPL_OK;
+    });
+    if (rc != MJPL_OK) return rc;
+    MJPL_MARK(5);
+    HIP_TRY(hipGetLastError());
+    return MJPL_OK;
   } else {
     for (int k = 0; k <= 4; k++) MJPL_MARK(k);  // filter off: the exact kernel is the whole launch
   }

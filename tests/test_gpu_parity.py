@@ -188,6 +188,7 @@ def test_two_pass_and_one_pass_filter_agree(monkeypatch):
     keys = ("MJPL_TWO_PASS", "MJPL_FILTER", "MJPL_EXPAND", "MJPL_ITEM_CAP", "MJPL_FUSED", "MJPL_FUSED_POOL",
             "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX")
     for tag, env in (("two", {"MJPL_TWO_PASS": "1", "MJPL_FUSED_SINGLE": "0"}), ("auto", {}), ("one", {"MJPL_TWO_PASS": "0"}), ("f64", {"MJPL_FILTER": "0"}),
+                     ("f64_lane_per_edge", {"MJPL_FILTER": "0", "MJPL_FUSED": "0"}), ("f64_items_first", {"MJPL_FILTER": "0", "MJPL_FUSED_POLICY": "1"}),
                      ("walk", {"MJPL_EXPAND": "0"}), ("kernels2", {"MJPL_FUSED": "0"}),
                      ("tight", {"MJPL_ITEM_CAP": "3000", "MJPL_FUSED": "0"}),
                      ("pool", {"MJPL_FUSED_POOL": "832"}), ("items_first", {"MJPL_FUSED_POLICY": "1"}),
@@ -209,7 +210,7 @@ def test_two_pass_and_one_pass_filter_agree(monkeypatch):
             assert e.last_items() > 3000
         if tag == "kmax3":  # edges of four waypoints take the walking list
             assert e.last_items() < out["two"][2]
-        out[tag] = out[tag] + (e.last_items(),)
+        out[tag] = out[tag] + ((e.last_items() if e.info()["filter_enabled"] else 0),)
         e.close()
     for tag in [t for t in out if t != "two"]:
         np.testing.assert_array_equal(out["two"][0], out[tag][0])
