@@ -841,9 +841,10 @@ def main():
     def start_of_timed_region():
         world.barrier()
         return time.perf_counter()
-    # EXACTLY args.steps launches, back to back on their engines' streams; every 4th one of an engine also carries
-    # one HIP event after each of its kernels (the per-kernel durations roofline.achieved uses)
-    t0, timed_res = run_all(share, 4, start_of_timed_region)  # every call synchronises its stream
+    # EXACTLY args.steps launches, back to back on their engines' streams; every 16th one of an engine also carries
+    # one HIP event after each of its kernels (the per-kernel durations roofline.achieved uses; bracketing every 4th
+    # launch cost the one-stream line 2 % of its rate)
+    t0, timed_res = run_all(share, 16, start_of_timed_region)  # every call synchronises its stream
     world.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = float(world.gather(elapsed).max())
@@ -860,7 +861,7 @@ def main():
     if S > 1:  # ... and the same K steps on ONE stream (not the measurement: the figure of rounds 1-3, and the kernels alone)
         eng.sync()
         t1 = time.perf_counter()
-        l1, st1, _ = eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, max(100, args.steps // 4), 4)
+        l1, st1, _ = eng.time_edges_stages_dev(dqa.ptr, dqb.ptr, E, STEP, layout, dvalid.ptr, max(100, args.steps // 4), 16)
         dt1 = time.perf_counter() - t1
         one_stream = {"value": E * max(100, args.steps // 4) / dt1, "unit": "edges/s", "steps": max(100, args.steps // 4),
                       "ms_per_step": dt1 / max(100, args.steps // 4) * 1e3, "step_ms_all_kernels": l1, "kernels_ms": st1}
@@ -882,12 +883,14 @@ def main():
                      "k_filter_items": (0 if fused else items, 57 + 8, "waypoint configurations"),
                      "k_filter_edges": (max(interior - 0, 0) if items == 0 else 0, BYTES_PER_EDGE + 4, "edges"),
                      "k_patch_pairs": (undecided, 56 + 16, "undecided geom pairs"),
-                     "k_check_edges": (E if not filt else 0, BYTES_PER_EDGE, "edges")}
+                     "k_check_edges": (E if (not filt and not info.get("fused_edges")) else 0, BYTES_PER_EDGE, "edges")}
         # kernel names as a profiler shows them for this engine's launch layout
 
         def stage_names(inf, with_filter):
             n = {}
-            if with_filter and inf.get("fused_edges"):
+            if not with_filter and inf.get("fused_edges"):
+                n["k_filter_endpoints"] = "k_edges_fused_f64"
+            elif with_filter and inf.get("fused_edges"):
                 n["k_filter_endpoints"] = "k_edges_fused"
             elif with_filter and inf.get("persistent_kernels"):
                 n.update({"k_filter_endpoints": "k_filter_endpoints_pw", "k_filter_items": "k_filter_items_pw"})
@@ -920,7 +923,7 @@ def main():
                        "against ~22 600 flop"}
         roof = {"kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms if S == 1 else one_stream["step_ms_all_kernels"],
                 "kernels_ms": alone_ms, "kernel_samples": nsamp, "streams_of_these_durations": 1,
-                "kernel_ms_source": "HIP events on the engine's own stream around every kernel of every 4th launch, nothing else on the chip"
+                "kernel_ms_source": "HIP events on the engine's own stream around every kernel of every 16th launch, nothing else on the chip"
                                     + ("" if S == 1 else " (the one_stream run of this line; the timed region overlaps kernels of several engines)"),
                 "hbm": hbm}
         if prof.get("SQ_INSTS_VALU"):
@@ -1045,7 +1048,7 @@ def main():
                                   # (with the filter off no kernel of a per-model library runs, whatever the engine has loaded)
                                   "specialised_kernels": bool(ve.spec_loaded()) and vf,
                                   "library": ({0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[ve.spec_kind()]
-                                              if vf else "none: k_check_edges, the interpreting float64 kernel of libmjpl_hip.so, is the whole launch"),
+                                              if vf else "none: the interpreting float64 kernels of libmjpl_hip.so (k_edges_fused_f64, then k_check_edges over the edges too long for its pool)"),
                                   "fused_edges": bool(vf and vinfo.get("fused_edges")),
                                   "verdicts_equal_headline": same, "edges_compared": E,
                                   "valu_issue": valu_issue(vk, v_stage[vk], rec)}

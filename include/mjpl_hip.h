@@ -120,7 +120,9 @@ typedef struct mjpl_info {
   /* fused_edges = 1 (default where the model runs the queued float32 interpreter or its own kernels; MJPL_FUSED=0
    * at creation restores the two persistent kernels): ONE filter kernel per edge launch -- endpoint tiles and
    * waypoint tiles of a batch served by the same resident workgroups from a work pool in LDS (k_edges_fused) --
-   * followed by k_tail.  fused_waves: wavefronts per workgroup of that kernel. */
+   * followed by k_tail.  With the filter off (filter_enabled = 0) the float64 checks take the same route
+   * (k_edges_fused_f64, then k_check_edges over the edges too long for the pool).  fused_waves: wavefronts per
+   * workgroup of that kernel. */
   int32_t fused_edges;
   int32_t fused_waves;
 } mjpl_info;

@@ -611,6 +611,7 @@ struct mjpl_engine {
   // MJPL_FUSED_POLICY (bit 0: item tiles first), MJPL_FUSED_KMAX: A/B measurements
   bool fused = true;
   int fused_policy = 0, fused_kmax = 4096, fused_pool_cap = 0;  // (MJPL_FUSED_POOL: at most that many ring slots)
+  bool fused_mbox = false;
   int fused_single_max = 32768;  // MJPL_FUSED_SINGLE: batches up to this many edges check every configuration of an edge in one round (measured: 0.068 vs 0.087 ms at 1 024 edges, 0.090 vs 0.102 at 32 768, 0.116 vs 0.106 at 65 536)
   bool fused_skip_once = false;  // mjpl_check_edges: this launch holds a few long edges -> the kernels with checkpoints
   const char *fused_dbg_path = nullptr;  // MJPL_FUSED_DEBUG=<file> (with a -DMJPL_FUSED_DEBUG build of the kernels)
@@ -1504,6 +1505,9 @@ bool fused_plan(const mjpl_engine *e, int *nwaves, size_t *lds, int *ring = null
   if (!e->fused || !e->filter || !e->filter_usable || !e->two_pass || !e->expand || e->immediate()) return false;
   const int nplan = (int)e->qidx.size();
   const bool mbox = e->filter_mbox();
+  // (models with moving boxes run one wave per SIMD: four waves per workgroup, and measured 5 % SLOWER fused than as the
+  // two kernels -- 1.63 vs 1.55 ms on Franka-P with the ten pad boxes; MJPL_FUSED_MBOX=1 runs them fused all the same)
+  if (mbox && !e->fused_mbox) return false;
   if (!fused_fits(nplan, e->nsave, mbox)) return false;
   const int nw = mbox ? 4 : kFusedWaves;
   const size_t budget = (size_t)160 * 1024;
@@ -1515,6 +1519,12 @@ bool fused_plan(const mjpl_engine *e, int *nwaves, size_t *lds, int *ring = null
   if (lds) *lds = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, r);
   if (ring) *ring = r;
   return true;
+}
+
+// ... and with the filter off: the float64 checks through the same pool (k_edges_fused_f64)
+bool fused_f64_ok(const mjpl_engine *e) {
+  return e->fused && e->two_pass && e->expand &&
+         fused_f64_lds_bytes(kFusedF64Waves, (int)e->qidx.size(), e->nsave, 64 * kFusedF64Waves + 64) <= (size_t)160 * 1024;
 }
 
 // A filter launch takes the cleared counter set and returns the other one, which its first kernel is
@@ -1950,8 +1960,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       if (rc != MJPL_OK) return rc;
     }
     MJPL_MARK(4);  // after the exact re-check of undecided pairs / configurations
-  } else if (e->fused && e->two_pass && e->expand && !(flags & MJPL_EDGE_INTERIOR_ONLY) && !e->exact_general() && E < (int64_t)1 << 30 &&
-             fused_f64_lds_bytes(kFusedF64Waves, (int)e->qidx.size(), e->nsave, 64 * kFusedF64Waves + 64) <= (size_t)160 * 1024) {
+  } else if (fused_f64_ok(e) && !(flags & MJPL_EDGE_INTERIOR_ONLY) && E < (int64_t)1 << 30) {
     // ---- filter off, the float64 checks through the pool (mjpl_fused.h: k_edges_fused_f64): endpoints, then the interior
     // waypoints of the survivors as items; edges of more than kFusedF64Kmax waypoints are left to k_check_edges below
     int rc = ulist_reserve(e, E);
@@ -1990,15 +1999,11 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     fa.kmax = kFusedF64Kmax; fa.pool = pool; fa.policy = e->fused_policy;
     MJPL_MARK(0);
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
-      if constexpr (!decltype(M)::value) {
-        auto kern = k_edges_fused_f64<decltype(S)::value, decltype(W)::value, false, kFusedF64Waves>;
-        int r = allow_lds(kern, flds);
-        if (r != MJPL_OK) return r;
-        if (fused_launch(kern, kFusedF64Waves, flds, fa, e->stream) != hipSuccess) return fail(MJPL_E_HIP, "the float64 pool kernel failed to launch");
-        return MJPL_OK;
-      } else {
-        return fail(MJPL_E_ARG, "the float64 pool kernel serves the small builds");
-      }
+      auto kern = k_edges_fused_f64<decltype(S)::value, decltype(W)::value, decltype(M)::value, kFusedF64Waves>;
+      int r = allow_lds(kern, flds);
+      if (r != MJPL_OK) return r;
+      if (fused_launch(kern, kFusedF64Waves, flds, fa, e->stream) != hipSuccess) return fail(MJPL_E_HIP, "the float64 pool kernel failed to launch");
+      return MJPL_OK;
     });
     if (rc != MJPL_OK) return rc;
     guard.armed = false;
@@ -2122,6 +2127,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_FUSED_POLICY")) e->fused_policy = atoi(f);
   e->fused_dbg_path = getenv("MJPL_FUSED_DEBUG");
   if (const char *f = getenv("MJPL_FUSED_POOL")) e->fused_pool_cap = atoi(f);
+  if (const char *f = getenv("MJPL_FUSED_MBOX")) e->fused_mbox = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FUSED_SINGLE")) e->fused_single_max = std::max(0, atoi(f));
   if (const char *f = getenv("MJPL_FUSED_KMAX")) e->fused_kmax = std::max(2, std::min(atoi(f), 1 << 16));
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
@@ -2353,10 +2359,13 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {
                                          e->immediate() ? sizeof(double) : sizeof(float));
   out->persistent_kernels = ((e->persist < 0 ? e->spec != nullptr : e->persist != 0) && e->two_pass && e->expand && !e->immediate()) ? 1 : 0;
   out->fused_tail = (e->fused_tail && e->two_pass && e->expand && !e->immediate()) ? 1 : 0;
-  {
+  if (e->filter && e->filter_usable) {
     int nw = 0;
     out->fused_edges = fused_plan(e, &nw, nullptr) ? 1 : 0;
     out->fused_waves = out->fused_edges ? nw : 0;
+  } else {  // (filter off: the float64 checks through the pool)
+    out->fused_edges = fused_f64_ok(e) ? 1 : 0;
+    out->fused_waves = out->fused_edges ? kFusedF64Waves : 0;
   }
   out->block_threads = kBlock;
   out->compute_units = e->prop.multiProcessorCount;

@@ -18,7 +18,7 @@ from helpers import random_edges  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-KEYS = ("MJPL_FUSED", "MJPL_FUSED_POOL", "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX", "MJPL_SPEC", "MJPL_UC_CAP", "MJPL_FILTER")
+KEYS = ("MJPL_FUSED", "MJPL_FUSED_MBOX", "MJPL_FUSED_POOL", "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX", "MJPL_SPEC", "MJPL_UC_CAP", "MJPL_FILTER")
 
 
 def _engine(m, qidx=None, base=None, allowed=(), **env):
@@ -142,8 +142,15 @@ def test_models_with_moving_boxes_and_the_interpreter(oracle_mod):
         orc = oracle_mod.Oracle(m, allowed, planning_qidx=qidx, qpos_base=base)
         qa, qb = random_edges(m, qidx, 30000, seed=seed)
         want, wfb, _ = orc.valid_edges(qa, qb, 0.01, nthreads=8, info=True)
-        for env in ({"MJPL_SPEC": 0}, {"MJPL_SPEC": 0, "MJPL_FUSED_POOL": 320}, {"MJPL_SPEC": 0, "MJPL_FUSED_SINGLE": 100000000}):
-            e = _engine(m, qidx, base, allowed, **env)
+        for env in ({"MJPL_SPEC": 0}, {"MJPL_SPEC": 0, "MJPL_FUSED_POOL": 320}, {"MJPL_SPEC": 0, "MJPL_FUSED_SINGLE": 100000000},
+                    {"MJPL_FILTER": 0}):
+            e = _engine(m, qidx, base, allowed, MJPL_FUSED_MBOX=1, **env)
+            if "MJPL_FILTER" in env:  # the float64 checks through the pool, the general build of models with moving boxes included
+                got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+                np.testing.assert_array_equal(got, want, err_msg=f"{seed} {env}")
+                np.testing.assert_array_equal(gfb, wfb, err_msg=f"{seed} {env}")
+                e.close()
+                continue
             info = e.info()
             if info["filter_interpreter"] == 2 or not info["filter_enabled"]:
                 e.close()

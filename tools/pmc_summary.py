@@ -17,7 +17,7 @@ def main():
         acc = defaultdict(list)
         with open(path) as f:
             for row in csv.DictReader(f):
-                if kern in row["Kernel_Name"]:
+                if kern in row["Kernel_Name"] and (kern + "_f64" not in row["Kernel_Name"] or kern.endswith("_f64")):
                     acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in acc.items():
             res[k] = sum(v) / len(v)
@@ -26,7 +26,7 @@ def main():
             continue
         with open(path) as f:
             for row in csv.DictReader(f):
-                if kern in row["Name"]:
+                if kern in row["Name"] and (kern + "_f64" not in row["Name"] or kern.endswith("_f64")):
                     res["avg_ns"] = float(row["AverageNs"])
                     res["calls"] = int(row["Calls"])
     if "FETCH_SIZE" in res or "WRITE_SIZE" in res:

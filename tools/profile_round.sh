@@ -20,7 +20,7 @@ done
 for k in k_edges_fused k_tail; do
   python3 tools/pmc_summary.py gpurun_out/prof_${TAG} $k gpurun_out/${TAG}_pmc_$k.json > /dev/null
 done
-python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_f64 k_check_edges gpurun_out/${TAG}f64_pmc_k_check_edges.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_f64 k_edges_fused_f64 gpurun_out/${TAG}f64_pmc_k_edges_fused_f64.json > /dev/null
 for k in k_edges_fused k_tail; do
   python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_interp $k gpurun_out/${TAG}interp_pmc_$k.json > /dev/null
 done

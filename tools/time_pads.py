@@ -24,4 +24,4 @@ for tag, m in (("franka_p+16obs", scenes.franka_p(True)), ("franka_p+16obs+10pad
                                                           nslots=info["nslots"], undecided=e.last_undecided(), valid=float(dv.download(np.uint8, E).mean()))
         print(tag, filt, out[f"{tag} filter={'on' if filt else 'off'}"], flush=True)
         e.close()
-json.dump(out, open("gpurun_out/r02d_pads.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r04_pads.json", "w"), indent=1)
