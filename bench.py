@@ -735,7 +735,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="edges workload: skip the float64-only and interpreter engines timed beside the headline")
-    ap.add_argument("--variant", choices=["headline", "f64", "interpreter", "generic"], default="headline",
+    ap.add_argument("--variant", choices=["headline", "f64", "interpreter", "generic", "pads"], default="headline",
                     help="edges workload: which engine configuration the TIMED steps run (profiling passes of the "
                          "variants: tools/profile_gpu.sh); the default line carries all three")
     ap.add_argument("--lanes", type=int, default=131072, help="rrt workload: lanes per rank per round")
@@ -768,11 +768,13 @@ def main():
     from mjpl_amd import engine, scenes
 
     rank = world.rank
-    model = scenes.franka_p(obstacles=True)
+    # (--variant pads: the same workload on Franka-P with the reference Panda's ten finger-pad boxes -- moving boxes --
+    #  for the profiling passes of that model's kernels; never the line the driver reads)
+    model = scenes.franka_p(obstacles=True, pads=args.variant == "pads")
     qidx = scenes.planning_index(model, scenes.FRANKA_ARM_JOINTS)
     base = model.keyframe("home").qpos.copy()
 
-    def make_engine(filt=True, spec=True):
+    def make_engine(filt=True, spec=True, model=model):
         e = engine.Engine(model, device=world.device)
         if spec is not True:
             e.set_spec(int(spec))  # (0: interpreter; 2: the robot's scene-generic library)
@@ -781,7 +783,8 @@ def main():
             e.set_filter(False)
         return e
 
-    timed = {"headline": (True, True), "f64": (False, True), "interpreter": (True, False), "generic": (True, 2)}[args.variant]
+    timed = {"headline": (True, True), "f64": (False, True), "interpreter": (True, False), "generic": (True, 2),
+             "pads": (True, True)}[args.variant]
     eng = make_engine(*timed)
     world.attach(eng)
     info = eng.info()
@@ -908,8 +911,10 @@ def main():
         kernel_ms = alone_ms[kernel]
         units, unit_bytes, unit_name = per_stage[kernel]
         achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9
-        prof = profile_record(kernel, E, args.layout, filt, spec)
-        workload = (f"configs[2]: Franka-P 7-DoF + 16 box/sphere obstacles + floor, {E} edges/GPU, "
+        ksuffix = "_pads" if args.variant == "pads" else ""  # (counter records are per model as well)
+        prof = profile_record(kernel + ksuffix, E, args.layout, filt, spec)
+        workload = (f"configs[2]: Franka-P 7-DoF + 16 box/sphere obstacles + floor"
+                    f"{' + the Panda finger pads, ten MOVING boxes (--variant pads: not the headline model)' if args.variant == 'pads' else ''}, {E} edges/GPU, "
                     f"eps {EPS}, step {STEP} (endpoint + interior waypoints per edge)")
         # what binds: vector-ALU issue (not HBM, not MFMA) -- SQ_INSTS_VALU wave-instructions of the committed
         # counter pass of this kernel / (its duration alone x the chip's issue slots per second)
@@ -975,7 +980,7 @@ def main():
                     "achieved_per_s": iv / (ms * 1e-3), "peak_per_s": VALU_ISSUE_PEAK,
                     "frac": iv / (ms * 1e-3) / VALU_ISSUE_PEAK, "source": rec.get("source")}
         # the vector-issue rate of the chip over a whole step: the vector instructions of all its kernels / the time a step takes
-        recs = [profile_record(k, E, args.layout, filt, spec) for k in stage_ms]
+        recs = [profile_record(k + ksuffix, E, args.layout, filt, spec) for k in stage_ms]
         if all(r.get("SQ_INSTS_VALU") for r, k in zip(recs, stage_ms) if stage_ms[k] > 0.01):
             iv = sum(float(r.get("SQ_INSTS_VALU", 0.0)) for r in recs)
             out["valu_issue_whole_step"] = {"wave_insts_valu_per_step": iv, "ms_per_step": elapsed / args.steps * 1e3,
@@ -1070,6 +1075,37 @@ def main():
                 for b in (va, vb, vv):
                     b.free()
                 ve.close()
+            # ... and a model with MOVING boxes: Franka-P with the reference Panda's ten finger-pad boxes (panda.xml:134-241),
+            # 488 pairs instead of 213 -- its own generated library (whole frames in registers, two waves per SIMD) against
+            # the interpreting kernels, which also give the verdicts to compare with
+            pm = scenes.franka_p(obstacles=True, pads=True)
+            pe, pi = make_engine(True, True, pm), make_engine(True, False, pm)
+            if pe.spec_kind() != 1:
+                sys.exit("bench.py: the moving-boxes variant found no library of its own under mjpl_amd/csrc/spec "
+                         "(__graft_entry__.build() makes it)")
+            pa, pb, pv, pw = pe.alloc(ha.nbytes).upload(ha), pe.alloc(hb.nbytes).upload(hb), pe.alloc(E), pi.alloc(E)
+            dt, p_launch, p_stage, _ = time_variant(pe, engine, pa, pb, E, layout, pv, vsteps, 5)
+            dti, i_launch, _, _ = time_variant(pi, engine, pa, pb, E, layout, pw, max(10, vsteps // 5), 2)
+            same = bool(np.array_equal(pv.download(np.uint8, E), pw.download(np.uint8, E)))
+            if not same:
+                sys.exit("bench.py: the moving-boxes library's verdicts differ from the interpreting kernels'")
+            pinfo = pe.info()
+            pnames = stage_names(pinfo, True)
+            p_stage = {pnames.get(k, k): v for k, v in p_stage.items()}
+            pk = max(p_stage, key=lambda k: p_stage[k])
+            variants["moving_boxes"] = {"value": E * vsteps / dt, "unit": "edges/s", "steps": vsteps, "ms_per_step": dt / vsteps * 1e3,
+                                        "streams": 1, "model": "Franka-P + 16 obstacles + the Panda's 10 finger-pad boxes (moving boxes)",
+                                        "enabled_pairs": int(pinfo["npairs"]), "step_ms_all_kernels": p_launch, "kernels_ms": p_stage,
+                                        "dtype": "f32-filter+f64-exact", "library": "this program's own", "fused_edges": bool(pinfo.get("fused_edges")),
+                                        "waves_per_workgroup": int(pinfo.get("fused_waves", 0)),
+                                        "interpreting_kernels_ms_per_step": i_launch,
+                                        "verdicts_equal_interpreting_kernels": same, "edges_compared": E,
+                                        "valu_issue": valu_issue(pk, p_stage[pk], profile_record(pk + "_pads", E, args.layout, True, 1))}
+            for b_ in (pa, pb, pv):
+                b_.free()
+            pw.free()
+            pe.close()
+            pi.close()
             out["variants"] = variants
         if flops.get("flops_per_edge"):
             # the float32 filter does the same geometry in binary32: the float64-equivalent rate is reported for scale

@@ -159,6 +159,9 @@ int mjpl_get_info(const mjpl_engine *e, mjpl_info *out);
 int mjpl_set_filter(mjpl_engine *e, int32_t enable, double tol);
 /* how many items of the most recent launch went to the float64 kernel (synchronises) */
 int64_t mjpl_filter_last_undecided(mjpl_engine *e);
+/* diagnostic: the (edge, check index, geom a, geom b) records the last filter launch handed to the exact pair kernel;
+ * returns how many there were (the arrays, each of `cap` entries or NULL, receive up to cap of them), or -1 */
+int64_t mjpl_filter_undecided_pairs(mjpl_engine *e, int32_t *edge, int32_t *idx, int32_t *ga, int32_t *gb, int64_t cap);
 /* The filter validates edges in two passes: the endpoints of all edges, then the interior
  * waypoints of the edges whose endpoint passed (MJPL_TWO_PASS=0 at create: one pass).  Returns how
  * many edges the interior pass of the most recent mjpl_check_edges* took (synchronises); 0 for a

@@ -1447,7 +1447,9 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
     code = (cur.pos[0] + par.pos[0] + psize[0] + gsize[0] + margin == T(12345.0)) ? V_CONTACT : V_NONE;
 #endif
     if (on && code == V_CONTACT) atomicOr(&wq.flags[owner], 1);
-    if (on && code == V_UNSURE) {
+    // (an owner known to be in contact -- from this batch, the line above, or an earlier one -- needs no exact check
+    //  of another pair: on uniformly random configurations half of the hand-offs were of this kind)
+    if (on && code == V_UNSURE && !(wq.flags[owner] & 1)) {
       // hand this one pair of the owner's configuration to the exact kernel; the owner walks on
       // as if it were free (the patch pass clears valid / lowers first_bad if it is not)
       bool handed = false;
@@ -1480,11 +1482,14 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
 // Append the lanes of `pm` (each with its own cur pose cur6 = pos + z axis; a slot partner's pose in
 // t6) to a wave's candidate queue, first draining one batch if they would not fit.  The interpreter
 // below carries this as a lambda; generated per-model code (mjpl_amd/specialise.py) calls it.
-template <class T, bool BOXQ>
-__device__ __forceinline__ void queue_push(const WaveQueue<T> &wq, int &fill, T &dead, int &fl, bool active, bool far,
+// MBOX builds (models with moving boxes): a candidate of the box queue carries full frames -- cur6b = the
+// moving geom's x and y axes, t6b = a slot partner's (zeros where that geom is no box).
+template <class T, bool BOXQ, bool MBOX = false>
+__device__ __forceinline__ void queue_push(const WaveQueue<T, MBOX> &wq, int &fill, T &dead, int &fl, bool active, bool far,
                                            const T *ltab, const T *lwcull, const T *lwnarrow, int nwpad, T tol,
                                            const PatchSink &ps, unsigned long long pm, int kind, int index, int gtype,
-                                           int ptype, bool pfirst, int gdoff, const T *cur6, const T *t6) {
+                                           int ptype, bool pfirst, int gdoff, const T *cur6, const T *t6,
+                                           const T *cur6b = nullptr, const T *t6b = nullptr) {
   constexpr int CAP = BOXQ ? QB_CAP : QN_CAP;
   const int lane = threadIdx.x & 63;
 #ifdef MJPL_X_NOPUSH  // timing-only build: the item kernel culls, but queues nothing (the masks stay live through fl)
@@ -1495,7 +1500,7 @@ __device__ __forceinline__ void queue_push(const WaveQueue<T> &wq, int &fill, T 
 #endif
   const int cnt = (int)__builtin_popcountll(pm);
   if (fill + cnt > CAP) {  // make room: one batch leaves the top of the queue
-    queue_drain<T, BOXQ, false>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps);
+    queue_drain<T, BOXQ, false, MBOX>(wq, fill, ltab, lwcull, lwnarrow, nwpad, tol, ps);
     fl = wq.flags[lane] & 3;
     dead = (fl != 0 || !active || far) ? T(__builtin_inff()) : T(0);
   }
@@ -1509,6 +1514,16 @@ __device__ __forceinline__ void queue_push(const WaveQueue<T> &wq, int &fill, T 
     if (!BOXQ && kind == EK_SLOT) {  // a static partner's pose is read from the world tables at the drain
 #pragma unroll
       for (int k = 0; k < 6; k++) qf[(6 + k) * CAP + off] = t6[k];
+    }
+    if constexpr (BOXQ && MBOX) {  // (the record layout of run_config_queued's own push)
+#pragma unroll
+      for (int k = 0; k < 6; k++) qf[(6 + k) * CAP + off] = cur6b ? cur6b[k] : T(0);
+      if (kind == EK_SLOT) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) qf[(12 + k) * CAP + off] = t6[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) qf[(18 + k) * CAP + off] = t6b ? t6b[k] : T(0);
+      }
     }
     qi0[off] = lane | (gtype << 6) | (ptype << 10) | ((pfirst ? 1 : 0) << 14) | (kind << 15) | (index << 17);
     qi1[off] = gdoff;
@@ -1814,7 +1829,9 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
           const unsigned long long pm = k == 0 ? m0 : (k == 1 ? m1 : (k == 2 ? m2 : m3));
-          if (pm == 0ull) continue;
+          // (a row that is no partner of this geom was culled with the chunk all the same, and a PLANE's row holds the
+          //  bound of the plane test: near the plane's origin it passed, and the pair was examined a second time)
+          if (pm == 0ull || !((bits >> k) & 1u)) continue;
           const int wc = base + k;
           // the row's info word came with the chunk (first 4 bytes of its 4th scalar)
           const T iw = k == 0 ? rcv[12] : (k == 1 ? rcv[13] : (k == 2 ? rcv[14] : rcv[15]));

@@ -527,6 +527,7 @@ struct SpecLib {
   typedef int (*TailFn)(hipStream_t, size_t, TailArgs);
   typedef int (*FusedFn)(hipStream_t, int, size_t, FusedArgs);  // (waves per workgroup, LDS bytes, arguments)
   FusedFn fused = nullptr;
+  int fused_waves = kFusedWaves;  // what its fused kernel was built for (mjpl_spec_fused_waves)
   EndpointsPwFn endpoints_pw = nullptr;
   ItemsPwFn items_pw = nullptr;
   TailFn tail = nullptr;
@@ -718,6 +719,7 @@ const SpecLib *find_spec(uint64_t hash, bool generic) {
     sl.items_pw = (SpecLib::ItemsPwFn)dlsym(lib, "mjpl_spec_launch_items_pw");
     sl.tail = (SpecLib::TailFn)dlsym(lib, "mjpl_spec_launch_tail");
     sl.fused = (SpecLib::FusedFn)dlsym(lib, "mjpl_spec_launch_fused");
+    if (auto fw = (int (*)())dlsym(lib, "mjpl_spec_fused_waves")) sl.fused_waves = fw();
     // (the stamp: both libraries built from the same mjpl_filter.h / mjpl_device.h / mjpl_trig.h -- the
     // structs that cross this boundary by value and the table layouts live there)
     const int g = gen ? gen() : 0;
@@ -740,7 +742,7 @@ void load_spec(mjpl_engine *e, bool generic_ok = false, int nstage = 0) {
   e->spec_generic = false;
   if (const char *s = getenv("MJPL_SPEC"))
     if (atoi(s) == 0) return;
-  if (e->spec_off || e->exact_general() || !e->filter_usable) return;  // (the generator covers the small queued builds)
+  if (e->spec_off || e->immediate() || (e->exact_general() && !e->filter_mbox()) || !e->filter_usable) return;  // (the generator covers the queued builds)
   if (!e->spec_generic_only) e->spec = find_spec(e->program_hash, false);
   if (e->spec || !generic_ok) return;
   const SpecLib *g = find_spec(e->robot_hash, true);
@@ -1507,9 +1509,9 @@ bool fused_plan(const mjpl_engine *e, int *nwaves, size_t *lds, int *ring = null
   const bool mbox = e->filter_mbox();
   // (models with moving boxes run one wave per SIMD: four waves per workgroup, and measured 5 % SLOWER fused than as the
   // two kernels -- 1.63 vs 1.55 ms on Franka-P with the ten pad boxes; MJPL_FUSED_MBOX=1 runs them fused all the same)
-  if (mbox && !e->fused_mbox) return false;
+  if (mbox && !e->fused_mbox && !e->spec) return false;
   if (!fused_fits(nplan, e->nsave, mbox)) return false;
-  const int nw = mbox ? 4 : kFusedWaves;
+  const int nw = e->spec ? e->spec->fused_waves : (mbox ? 4 : kFusedWaves);
   const size_t budget = (size_t)160 * 1024;
   const size_t base = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, 0);
   if (base + (size_t)(64 * nw + 64) * kFusedEntryBytes > budget) return false;
@@ -2233,7 +2235,10 @@ int mjpl_program_dump(const mjpl_model_desc *d, const int32_t *allowed_bodies, i
   if ((rc = compile_program(e.get())) != MJPL_OK) return rc;
   memset(info, 0, sizeof(*info));
   info->hash = e->program_hash;
-  info->maxs = e->maxs; info->wbox = e->wbox; info->mbox = e->mbox; info->immediate = e->exact_general();  // ("general builds only": nothing to specialise)
+  // (maxs: the slot-file width of the FILTER kernels a library is built around -- 24 for the queued build of models with
+  // moving boxes; immediate: only the immediate interpreter serves this program, nothing to specialise)
+  info->maxs = e->filter_mbox() ? kQueuedMaxSlots : e->maxs; info->wbox = e->wbox; info->mbox = e->mbox || e->filter_mbox();
+  info->immediate = e->immediate() || (e->exact_general() && !e->filter_mbox());
   info->filter_usable = e->filter_usable; info->filter_tol = e->filter_tol; info->nslots = e->nslots; info->nsave = e->nsave;
   info->spec_abi = MJPL_SPEC_ABI;
   info->robot_hash = e->robot_hash;
@@ -2304,6 +2309,23 @@ int64_t mjpl_filter_last_undecided(mjpl_engine *e) {
   if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
   if (hipMemcpy(n, e->d_ucount, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int64_t)n[0] + n[kCtr];
+}
+
+// Diagnostic: the (edge, check index, geom a, geom b) records the last filter launch handed to the exact pair
+// kernel -- which pairs the float32 filter could not decide.  Returns how many there were (the arrays receive up to
+// `cap` of them), or -1.
+int64_t mjpl_filter_undecided_pairs(mjpl_engine *e, int32_t *edge, int32_t *idx, int32_t *ga, int32_t *gb, int64_t cap) {
+  if (!e || !e->filter || !e->filter_usable || !e->d_ucount || !e->d_ucedge) return 0;
+  if (hipSetDevice(e->device) != hipSuccess) return -1;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+  int n = 0;
+  if (hipMemcpy(&n, e->d_ucount + kCtr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const size_t m = (size_t)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>(n, cap), (int64_t)e->uc_cap));
+  int32_t *dst[4] = {edge, idx, ga, gb};
+  const int *src[4] = {e->d_ucedge, e->d_ucidx, e->d_ucga, e->d_ucgb};
+  for (int k = 0; k < 4; k++)
+    if (dst[k] && m && hipMemcpy(dst[k], src[k], m * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
 }
 
 namespace {

@@ -105,6 +105,7 @@ ABI = {
     "mjpl_get_info": (C.c_int, [_VP, C.POINTER(Info)]),
     "mjpl_set_filter": (C.c_int, [_VP, C.c_int32, C.c_double]),
     "mjpl_filter_last_undecided": (C.c_int64, [_VP]),
+    "mjpl_filter_undecided_pairs": (C.c_int64, [_VP, _I32P, _I32P, _I32P, _I32P, C.c_int64]),
     "mjpl_filter_last_interior_edges": (C.c_int64, [_VP]),
     "mjpl_filter_last_items": (C.c_int64, [_VP]),
     "mjpl_check_configs": (C.c_int, [_VP, _F64P, C.c_int64, C.c_int32, _U8P]),
@@ -313,6 +314,16 @@ class Engine:
 
     def last_undecided(self) -> int:
         return int(self.lib.mjpl_filter_last_undecided(self.h))
+
+    def undecided_pairs(self, cap: int = 1 << 20):
+        """Diagnostic: the pairs the last filter launch handed to the exact pair kernel
+        -> (total, edge [m], check index [m], geom a [m], geom b [m]), m = min(total, cap)."""
+        arrs = [np.zeros(cap, np.int32) for _ in range(4)]
+        n = int(self.lib.mjpl_filter_undecided_pairs(self.h, *[a.ctypes.data_as(_I32P) for a in arrs], cap))
+        if n < 0:
+            raise RuntimeError("mjpl_filter_undecided_pairs failed")
+        m = min(n, cap)
+        return (n, *[a[:m] for a in arrs])
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

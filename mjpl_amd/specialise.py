@@ -220,6 +220,9 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
     cull_form = cull_form or os.environ.get("MJPL_SPEC_CULL", "expanded")
     if info.immediate or not info.filter_usable:
         raise ValueError("this model runs the immediate interpreter / has no usable filter: nothing to specialise")
+    mbox = bool(info.mbox)  # moving boxes: full frames in the box queue, two register slots per stored box
+    if mbox and generic:
+        raise ValueError("scene-generic libraries serve robots without moving boxes")
     g = _Gen(ip, fp, dp, info)
     w = g.w
     nbody = int(ip[H_NBODYOPS])
@@ -252,6 +255,11 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
     box_reach = math.sqrt(3.0) * maxcoord
     body_reach_cur = 0.0      # of the body the walk is at (PARENT_CUR refers to it)
     saved_reach: dict[int, float] = {}
+    # Moving boxes: boxes of one body with one orientation (the Panda's five pads per finger) have ONE frame --
+    # the x and y axes are kept once, in the second slot of the first of them; `axes_of` maps each box's own second
+    # slot to the slot that holds the values, `axes_key` says whose axes a slot holds right now.
+    axes_of: dict[int, int] = {}
+    axes_key: dict[int, tuple] = {}
 
     for b in range(nbody):
         parent, bdoff, njnt, save_slot, ngeom = (int(ip[pc + k]) for k in (B_PARENT, B_DOFF, B_NJNT, B_SAVE, B_NGEOM))
@@ -373,12 +381,19 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
             else:
                 for r, nm in enumerate(("cx", "cy", "cz")):
                     w(f"{nm} = p{r} + {lin([(lpos[0], f'R{3 * r}'), (lpos[1], f'R{3 * r + 1}'), (lpos[2], f'R{3 * r + 2}')])};")
+            curbox = mbox and gtype == GT_BOX
             if gflags & GF_SAMEROT:
                 w("zx = R2; zy = R5; zz = R8;")
+                if curbox:
+                    w("xx = R0; xy = R3; xz = R6; yx = R1; yy = R4; yz = R7;")
             else:
                 e = quat_mul_const_right(["q0", "q1", "q2", "q3"], lquat)
                 w(f"{{ const float g0 = {e[0]}, g1 = {e[1]}, g2 = {e[2]}, g3 = {e[3]};")
-                w("  zx = 2.0f * (g1 * g3 + g0 * g2); zy = 2.0f * (g2 * g3 - g0 * g1); zz = g0 * g0 - g1 * g1 - g2 * g2 + g3 * g3; }")
+                if curbox:  # the whole frame, by the interpreter's own routine (same binary32 values)
+                    w("  const float gq_[4] = {g0, g1, g2, g3}; float mm_[9]; mjpl::quat2mat(mm_, gq_);")
+                    w("  zx = mm_[2]; zy = mm_[5]; zz = mm_[8]; xx = mm_[0]; xy = mm_[3]; xz = mm_[6]; yx = mm_[1]; yy = mm_[4]; yz = mm_[7]; }")
+                else:
+                    w("  zx = 2.0f * (g1 * g3 + g0 * g2); zy = 2.0f * (g2 * g3 - g0 * g1); zz = g0 * g0 - g1 * g1 - g2 * g2 + g3 * g3; }")
             partners = []
             if generic:
                 pmask = wmask = 0  # (static partners: rows of the scene table, tested after the switch)
@@ -393,7 +408,7 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
                 k = len(partners)
                 dot = lin([(pz[0], "cx"), (pz[1], "cy"), (pz[2], "cz")], -(np.float32(pz[0]) * np.float32(ppos[0]) + np.float32(pz[1]) * np.float32(ppos[1]) + np.float32(pz[2]) * np.float32(ppos[2])))
                 w(f"MJPL_SPEC_HIT({k}, !({dot} + dead > {lit(wbound[wrow])}));")
-                partners.append((EK_PLANE, wrow, GT_PLANE, 1, 0))
+                partners.append((EK_PLANE, wrow, GT_PLANE, 1, 1 if curbox else 0, 63))
             # other static geoms
             w("const float ux = cx + dead;")
             if cull_form == "expanded" and not generic:
@@ -407,7 +422,7 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
                 pfirst = 1 if (ptype < gtype or (ptype == gtype and pgid < geom_id)) else 0
                 X, Y, Z = (float(fp[wc_at(wrow, f)]) for f in range(3))
                 statics.append((len(partners), X, Y, Z, wbound[wrow]))
-                partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if ptype == GT_BOX else 0))
+                partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if (ptype == GT_BOX or curbox) else 0, 63))
             if cull_form == "expanded" and statics:
                 reach = geom_reach + float(np.linalg.norm(np.asarray(lpos, dtype=np.float64)))
                 for a, b in zip(statics[0::2], statics[1::2]):
@@ -431,16 +446,38 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
                 pw = swords[n]
                 if generic:  # (lanes 0 .. 31 belong to the scene rows)
                     while len(partners) < SCENE_SLOT_LANE0:
-                        partners.append((0, 0, 0, 0, 0))
+                        partners.append((0, 0, 0, 0, 0, 0))
                 k = len(partners)
                 w(f"MJPL_SPEC_SLOTCULL({k}, {n}, {lit(sbound[n])});")
-                partners.append((EK_SLOT, n, (pw >> 12) & 15, 1 if (pw & P_FIRST) else 0, 0))
+                sptype = (pw >> 12) & 15
+                # (a stored box keeps its x and y axes in a second slot, pw & 63; with a box on either side the pair
+                # takes the box queue, whose records carry full frames)
+                n2 = (pw & 63) if mbox else 63
+                if n2 != 63:
+                    n2 = axes_of[n2]
+                partners.append((EK_SLOT, n, sptype, 1 if (pw & P_FIRST) else 0, 1 if (mbox and (curbox or sptype == GT_BOX)) else 0, n2))
             if len(partners) > 64:
                 raise ValueError("a geom with more than 64 enabled partners cannot be specialised")
-            stages.append((pending_fk + g.lines, gtype, gdoff, store & 63 if store >= 0 else -1))
+            store2 = ((store >> 6) & 63) if (store >= 0 and mbox) else 63
+            if store >= 0 and (store & 63) in axes_key:  # (a slot that held shared axes is written again: nobody may still read them)
+                if any(v == (store & 63) and k != v for k, v in axes_of.items()):
+                    raise ValueError("a shared axes slot is reused while boxes still refer to it")
+                del axes_key[store & 63]
+            if store2 != 63:
+                key = (b, bool(gflags & GF_SAMEROT), tuple(np.float32(lquat).tolist()))
+                held = [sl for sl, k_ in axes_key.items() if k_ == key]
+                if held:           # the frame is in the slot file already
+                    axes_of[store2] = held[0]
+                    store2 = 63
+                else:
+                    if any(v == store2 and k != v for k, v in axes_of.items()):
+                        raise ValueError("a shared axes slot is reused while boxes still refer to it")
+                    axes_of[store2] = store2
+                    axes_key[store2] = key
+            stages.append((pending_fk + g.lines, gtype, gdoff, store & 63 if store >= 0 else -1, store2))
             pending_fk = []
-            desc.append([(kind << 0) | (index << 2) | (ptype << 10) | (pfirst << 14) | (boxq << 15)
-                         for kind, index, ptype, pfirst, boxq in partners])
+            desc.append([(kind << 0) | (index << 2) | (ptype << 10) | (pfirst << 14) | (boxq << 15) | (index2 << 16)
+                         for kind, index, ptype, pfirst, boxq, index2 in partners])
     if pending_fk:  # trailing bodies without geoms influence nothing: drop them
         pending_fk = []
     nstage = len(stages)
@@ -492,14 +529,29 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
         o("  " + ", ".join(str(x) for x in (d + [0] * (64 - len(d)))) + ",")
     o("};")
     o("")
+    if mbox:
+        # Whole frames, up to 24 slots: as SlotFile's vectors (<24 x float>, widened to 32 lanes of registers each, six of
+        # them) the file alone asks for 192 registers and every access for a contiguous tuple -- 2 KB of scratch per lane
+        # at any occupancy.  Every slot number in this code is a literal, so plain scalars serve: the compiler keeps one
+        # register per value that is in use (scalar replacement), live from the stage that stores it.
+        o(f"struct SpecSlots {{ float f[6][{maxs}]; }};")
+        o("static __device__ __forceinline__ void spec_put6(SpecSlots &sf, int slot, const float *t6) {")
+        o("#pragma unroll")
+        o("  for (int k = 0; k < 6; k++) sf.f[k][slot] = t6[k];")
+        o("}")
+        o("static __device__ __forceinline__ void spec_get6(const SpecSlots &sf, int slot, float *t6) {")
+        o("#pragma unroll")
+        o("  for (int k = 0; k < 6; k++) t6[k] = sf.f[k][slot];")
+        o("}")
+        o("")
     o("struct Spec {")
     o(f"  static constexpr int kNplan = {int(ip[H_NPLAN])};")
     o("  template <class QT>")
     o("  static __device__ __forceinline__ int run(mjpl::FP tp, const float *ltab, const QT *q, int qstride, float *save,")
-    o("                                            int sstride, bool active, float tol, const mjpl::WaveQueue<float> &wq,")
+    o(f"                                            int sstride, bool active, float tol, const mjpl::WaveQueue<float, {'true' if mbox else 'false'}> &wq,")
     o("                                            int item, const mjpl::PatchSink &ps) {")
     o("    using namespace mjpl;")
-    o(f"    SlotFile<float, {maxs}> sf;")
+    o("    SpecSlots sf;" if mbox else f"    SlotFile<float, {maxs}> sf;")
     o("    float p0 = 0, p1 = 0, p2 = 0, q0 = 1, q1 = 0, q2 = 0, q3 = 0;")
     o("    float R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1;")
     o("    const int lane = threadIdx.x & 63;")
@@ -524,6 +576,8 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
     o(f"    for (int g = 0; g < {nstage}; g++) {{")
     o("      if (__builtin_amdgcn_ballot_w64(dead == 0.0f) == 0ull && qn == 0 && qb == 0) break;  // every lane decided")
     o("      float cx = 0, cy = 0, cz = 0, zx = 0, zy = 0, zz = 0;")
+    if mbox:
+        o("      float xx = 0, xy = 0, xz = 0, yx = 0, yy = 0, yz = 0;  // a moving box: its x and y axes")
     o("      int mlo = 0, mhi = 0;  // lane k holds the hit mask of this geom's partner k")
     o("      // ... and the descriptor of partner k: one vector load per stage, issued ahead of the stage's")
     o("      // arithmetic (a scalar load per hit stalls the wave for its whole latency)")
@@ -533,7 +587,7 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
         o("      const int dv = kSpecDesc[64 * g + lane];")
     o("      int gtype = 0, gdoff = 0;")
     o("      switch (g) {")
-    for si, (lines, gtype, gdoff, store) in enumerate(stages):
+    for si, (lines, gtype, gdoff, store, store2) in enumerate(stages):
         o(f"        case {si}: {{")
         for ln in lines:
             o("      " + ln)
@@ -603,6 +657,8 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
         o("#undef MJPL_SCENE_PAIR")
         o("      }")
     o("      const float cur6[6] = {cx, cy, cz, zx, zy, zz};")
+    if mbox:
+        o("      const float cur6b[6] = {xx, xy, xz, yx, yy, yz};")
     o("      // partners some lane passed: bit k of the ballot <=> lane k's stored mask is non-zero")
     o("      for (unsigned long long ab = __builtin_amdgcn_ballot_w64((mlo | mhi) != 0); ab; ab &= ab - 1) {")
     o("        const int k = (int)__builtin_ctzll(ab);")
@@ -612,23 +668,58 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
     o("        const int kind = d & 3, index = (d >> 2) & 255, ptype = (d >> 10) & 15;")
     o("        const bool pfirst = (d >> 14) & 1;")
     o("        float t6[6] = {0, 0, 0, 0, 0, 0};")
-    o("        if (kind == EK_SLOT) slot_get6(sf, index, t6);")
-    o("        if ((d >> 15) & 1)")
-    o("          queue_push<float, true>(wq, qb, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
-    o("                                  gtype, ptype, pfirst, gdoff, cur6, t6);")
-    o("        else")
-    o("          queue_push<float, false>(wq, qn, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
-    o("                                   gtype, ptype, pfirst, gdoff, cur6, t6);")
+    if mbox:
+        # (a switch over the slots in use keeps every access to the slot file a literal one)
+        used1 = sorted({(x >> 2) & 255 for d_ in desc for x in d_ if (x & 3) == EK_SLOT})
+        used2 = sorted({(x >> 16) & 63 for d_ in desc for x in d_ if (x & 3) == EK_SLOT} - {63})
+        o("        float t6b[6] = {0, 0, 0, 0, 0, 0};")
+        o("        const int index2 = (d >> 16) & 63;  // a stored box: the slot of its x and y axes")
+        o("        if (kind == EK_SLOT) {")
+        o("          switch (index) {")
+        for n in used1:
+            o(f"            case {n}: spec_get6(sf, {n}, t6); break;")
+        o("            default: break;")
+        o("          }")
+        o("          switch (index2) {")
+        for n in used2:
+            o(f"            case {n}: spec_get6(sf, {n}, t6b); break;")
+        o("            default: break;")
+        o("          }")
+        o("        }")
+    else:
+        o("        if (kind == EK_SLOT) slot_get6(sf, index, t6);")
+    if mbox:
+        o("        if ((d >> 15) & 1)")
+        o("          queue_push<float, true, true>(wq, qb, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
+        o("                                        gtype, ptype, pfirst, gdoff, cur6, t6, cur6b, t6b);")
+        o("        else")
+        o("          queue_push<float, false, true>(wq, qn, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
+        o("                                         gtype, ptype, pfirst, gdoff, cur6, t6);")
+    else:
+        o("        if ((d >> 15) & 1)")
+        o("          queue_push<float, true>(wq, qb, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
+        o("                                  gtype, ptype, pfirst, gdoff, cur6, t6);")
+        o("        else")
+        o("          queue_push<float, false>(wq, qn, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
+        o("                                   gtype, ptype, pfirst, gdoff, cur6, t6);")
     o("      }")
     o("      switch (g) {  // (a literal slot index keeps the slot file in registers)")
-    for si, (_, _, _, store) in enumerate(stages):
+    put = "spec_put6" if mbox else "slot_put6"
+    for si, (_, _, _, store, store2) in enumerate(stages):
         if store >= 0:
-            o(f"        case {si}: slot_put6(sf, {store}, cur6); break;")
+            if mbox and store2 != 63:
+                o(f"        case {si}: {put}(sf, {store}, cur6); {put}(sf, {store2}, cur6b); break;")
+            else:
+                o(f"        case {si}: {put}(sf, {store}, cur6); break;")
     o("        default: break;")
     o("      }")
     o("    }")
-    o("    if (qn > 0) queue_drain<float, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
-    if info.wbox or generic:  # (a scene-generic library serves scenes with static boxes whatever scene it was generated from)
+    if mbox:
+        o("    if (qn > 0) queue_drain<float, false, true, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
+        o("    if (qb > 0) queue_drain<float, true, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
+    else:
+        o("    if (qn > 0) queue_drain<float, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
+    if (info.wbox or generic) and not mbox:  # (a scene-generic library serves scenes with static boxes whatever scene it was generated from)
         o("    if (qb > 0) queue_drain<float, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
     o("    fl = wq.flags[lane] & 3;")
     o("    if (active && far) return V_UNSURE;  // nothing this lane's candidates said can be trusted")
@@ -760,7 +851,7 @@ _TU = """// GENERATED translation unit: the float32 filter kernels of mjpl_filte
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
-#include "mjpl_filter.h"
+%(waves_define)s#include "mjpl_filter.h"
 
 namespace {
 %(spec)s
@@ -791,27 +882,27 @@ unsigned long long mjpl_spec_hash(void) { return 0x%(hash)016xull; }
 int mjpl_spec_launch_configs(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
                              int nfp, const double *Q, int64_t N, int layout, float tol, uint8_t *valid, int *ulist, int *ucount,
                              UndecidedConfigs uc, int *zero_next) {
-  SPEC_LAUNCH((k_filter_configs<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, Q, N, layout, tol, valid, ulist, ucount, uc,
+  SPEC_LAUNCH((k_filter_configs<Spec, %(maxs)d, %(wbox)s, %(mbox)s>), ip, nip, fp, nfp, Q, N, layout, tol, valid, ulist, ucount, uc,
               zero_next);
 }
 int mjpl_spec_launch_endpoints(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
                                int nfp, const double *QA, const double *QB, int64_t E, int layout, float tol, uint8_t *valid,
                                int32_t *first_bad, int *status, int *ulist, int *ucount, UndecidedConfigs uc, int *slist,
                                int *scount, ItemBuffers ib, double step, int *zero_next) {
-  SPEC_LAUNCH((k_filter_endpoints<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, QA, QB, E, layout, tol, valid, first_bad, status,
+  SPEC_LAUNCH((k_filter_endpoints<Spec, %(maxs)d, %(wbox)s, %(mbox)s>), ip, nip, fp, nfp, QA, QB, E, layout, tol, valid, first_bad, status,
               ulist, ucount, uc, slist, scount, ib, step, zero_next);
 }
 int mjpl_spec_launch_items(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const float *fp,
                            int nfp, ItemBuffers ib, EdgeSource src, float tol, uint8_t *valid, int32_t *first_bad, int *ulist, int *ucount,
                            UndecidedConfigs uc) {
-  SPEC_LAUNCH((k_filter_items<Spec, %(maxs)d, %(wbox)s, false>), ip, nip, fp, nfp, ib, src, tol, valid, first_bad, ulist, ucount, uc);
+  SPEC_LAUNCH((k_filter_items<Spec, %(maxs)d, %(wbox)s, %(mbox)s>), ip, nip, fp, nfp, ib, src, tol, valid, first_bad, ulist, ucount, uc);
 }
 // persistent kernels (one wave per tile of 64, tiles from a device counter): the launcher sizes the grid
 int mjpl_spec_launch_endpoints_pw(hipStream_t st, size_t lds, const int *ip, int nip, const float *fp, int nfp, const double *QA,
                                   const double *QB, int64_t E, int layout, float tol, uint8_t *valid, int32_t *first_bad,
                                   int *status, int *ulist, int *ucount, UndecidedConfigs uc, ItemBuffers ib, double step,
                                   int *zero_next, int *tiles) {
-  auto kern = k_filter_endpoints_pw<Spec, %(maxs)d, %(wbox)s, false>;
+  auto kern = k_filter_endpoints_pw<Spec, %(maxs)d, %(wbox)s, %(mbox)s>;
   SPEC_GRANT(kern);
   const unsigned grid = persistent_grid(kern, lds, (E + 63) / 64);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, ip, nip, fp, nfp, QA, QB, E, layout, tol, valid, first_bad, status, ulist,
@@ -821,22 +912,25 @@ int mjpl_spec_launch_endpoints_pw(hipStream_t st, size_t lds, const int *ip, int
 int mjpl_spec_launch_items_pw(hipStream_t st, size_t lds, const int *ip, int nip, const float *fp, int nfp, ItemBuffers ib,
                               EdgeSource src, float tol, uint8_t *valid, int32_t *first_bad, int *ulist, int *ucount,
                               UndecidedConfigs uc, int *tiles) {
-  auto kern = k_filter_items_pw<Spec, %(maxs)d, %(wbox)s, false>;
+  auto kern = k_filter_items_pw<Spec, %(maxs)d, %(wbox)s, %(mbox)s>;
   SPEC_GRANT(kern);
   const unsigned grid = persistent_grid(kern, lds, (long long)ib.cap / 64);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, ip, nip, fp, nfp, ib, src, tol, valid, first_bad, ulist, ucount, uc, tiles);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int mjpl_spec_launch_tail(hipStream_t st, size_t lds, TailArgs a) {
-  auto kern = k_tail<ExactSpec, %(maxs)d, %(maxs)d, %(wbox)s, false>;
+  auto kern = k_tail<ExactSpec, %(maxs)d, %(maxsd)d, %(wbox)s, %(mbox)s>;
   SPEC_GRANT(kern);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.nw + a.np + a.nx)), dim3(kBlock), lds, st, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-// the whole float32 filter of an edge launch as one kernel (mjpl_fused.h); nwaves: wavefronts per workgroup
+// the whole float32 filter of an edge launch as one kernel (mjpl_fused.h); nwaves: wavefronts per workgroup, which
+// must be what mjpl_spec_fused_waves reports (twelve at three waves per SIMD; eight for a model with moving boxes,
+// whose code is built for two)
+int mjpl_spec_fused_waves(void) { return %(fwaves)d; }
 int mjpl_spec_launch_fused(hipStream_t st, int nwaves, size_t lds, FusedArgs a) {
-  if (nwaves != kFusedWaves) return -1;
-  auto kern = k_edges_fused<Spec, %(maxs)d, %(wbox)s, false, kFusedWaves>;
+  if (nwaves != %(fwaves)d) return -1;
+  auto kern = k_edges_fused<Spec, %(maxs)d, %(wbox)s, %(mbox)s, %(fwaves)d>;
   SPEC_GRANT(kern);
   return fused_launch(kern, nwaves, lds, a, st) == hipSuccess ? 0 : -1;
 }
@@ -846,6 +940,25 @@ int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t
 }
 }
 """
+
+
+def _mbox_waves() -> int:
+    """Waves per SIMD the kernels of a model with moving boxes are built for (MJPL_SPEC_MBOX_WAVES: A/B builds)."""
+    return max(1, min(3, int(os.environ.get("MJPL_SPEC_MBOX_WAVES", "2"))))
+
+
+def translation_unit(spec: str, exact: str, key: int, info, generic_word: int = 0) -> str:
+    """The source of a library: the kernels of mjpl_filter.h / mjpl_fused.h instantiated around `spec` / `exact`."""
+    mbox = bool(info.mbox)
+    return _TU % dict(spec=spec, exact=exact, hash=key, maxs=info.maxs,
+                      wbox="true" if (info.wbox or generic_word or mbox) else "false", mbox="true" if mbox else "false",
+                      maxsd=32 if mbox else info.maxs,  # (the exact kernels of a model with moving boxes: the general build)
+                      # a model with moving boxes keeps whole frames in its slot file and in the box queue's records: built for
+                      # two waves per SIMD (256 VGPRs), eight waves per workgroup of the fused kernel -- at three the kernels
+                      # spill 60 .. 90 registers and the fused kernel's LDS no longer fits: 0.56 against 0.42 ms on Franka-P
+                      # with the ten pad boxes (profiles/r04_pads.json)
+                      fwaves=(4 * _mbox_waves()) if mbox else 12, waves_define=f"#define MJPL_SPEC_WAVES {_mbox_waves()}\n" if mbox else "",
+                      generic=generic_word)
 
 
 def spec_path(hash_: int, generic: bool = False) -> str:
@@ -874,9 +987,8 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
             nj, ng = int(ip[pc + B_NJNT]), int(ip[pc + B_NGEOM])
             pc += B_SIZE + nj * J_SIZE + ng * (G_SIZE + MAX_SLOTS)
             nstage += ng
-    src = _TU % dict(spec=generate(ip, fp, dp, info, generic=generic), exact=generate_exact(ip, dp, info, generic=generic), hash=key,
-                     maxs=info.maxs, wbox="true" if (info.wbox or generic) else "false",
-                     generic=(SCENE_ROWS << 8 | nstage) if generic else 0)  # (kSceneRows, moving geoms)
+    src = translation_unit(generate(ip, fp, dp, info, generic=generic), generate_exact(ip, dp, info, generic=generic), key, info,
+                           (SCENE_ROWS << 8 | nstage) if generic else 0)  # (kSceneRows, moving geoms)
     # Source and library appear under their final names complete or not at all (os.replace): an engine created
     # while a rebuild is running finds the old library or the new one, never half a file -- a failed dlopen would
     # be remembered as "no library" for the life of that process -- and two builds of one hash cannot interleave.

@@ -17,12 +17,21 @@ def spec_models():
     m0 = scenes.franka_p(obstacles=False)
     out.append(("franka_p self-collision (BASELINE configs[1])", m0, (), np.arange(m0.nq, dtype=np.int32),
                 np.asarray(m0.qpos0, float).copy()))
+    # ... with the reference Panda's ten finger-pad boxes (panda.xml:134-241): moving boxes -- whole frames in the slot file
+    # and in the box queue's records, kernels built for two waves per SIMD (the five pads of a finger share frames)
+    mp = scenes.franka_p(True, True)
+    out.append(("franka_p+16obs+10 pad boxes (moving boxes)", mp, (), scenes.planning_index(mp, scenes.FRANKA_ARM_JOINTS),
+                mp.keyframe("home").qpos.copy()))
     u = scenes.ur5e()
     out.append(("ur5e_c", u, (), np.arange(u.nq, dtype=np.int32), np.asarray(u.qpos0, float).copy()))
     from test_gpu_models import random_model
     for seed in (1002, 1005):  # seeded random trees with slides, off-centre hinges, branching, static boxes
         rm, allowed = random_model(seed, moving_boxes=False)
         out.append((f"random_model({seed})", rm, tuple(allowed), np.arange(rm.nq, dtype=np.int32), np.asarray(rm.qpos0, float).copy()))
+    for seed in (1003, 1004):  # ... and with boxes of any orientation on the moving bodies (seeds whose configurations are neither all free nor all in contact)
+        rm, allowed = random_model(seed, moving_boxes=True)
+        out.append((f"random_model({seed}, moving boxes)", rm, tuple(allowed), np.arange(rm.nq, dtype=np.int32),
+                    np.asarray(rm.qpos0, float).copy()))
     return out
 
 

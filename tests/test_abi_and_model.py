@@ -165,9 +165,18 @@ def test_program_dump_and_code_generation_need_no_gpu():
                  2 * src.count("MJPL_SPEC_CULL2(") + src.count("MJPL_SPEC_SLOTCULL(") + src.count("MJPL_SPEC_HIT("))
         assert culls >= 10
         assert "struct Spec" in src and f"{info.hash:016x}" in src
-    m = scenes.franka_p(True, True)  # moving boxes: immediate interpreter, nothing to specialise
+    # sixteen moving boxes in a chain, 28 slots to hold at once: beyond the 24 of the queued kernels -- the immediate
+    # interpreter, nothing to specialise
+    from mjpl_amd.model import ModelBuilder
+    mb = ModelBuilder()
+    mb.add_geom("world", "plane", (1, 1, 0.1), pos=(0, 0, -0.4))
+    for b in range(16):
+        mb.add_body(f"b{b}", f"b{b - 1}" if b else "world", pos=(0.12, 0, 0))
+        mb.add_joint(f"b{b}", f"j{b}", "hinge", axis=(0, 0, 1) if b % 2 else (0, 1, 0), range=(-2.5, 2.5))
+        mb.add_geom(f"b{b}", "box", (0.04, 0.03, 0.02))
+    m = mb.compile()
     _, _, _, info = specialise.dump_program(m)
-    assert info.immediate
+    assert info.immediate and info.nslots == 28
     with pytest.raises(ValueError, match="immediate"):
         specialise.generate(*specialise.dump_program(m))
     assert specialise.build(m) is None
@@ -193,7 +202,7 @@ def test_program_hash_covers_the_float64_constants_and_the_shared_headers():
     # the stamp: a digest of the three shared headers, passed to both compilations
     stamp = build.src_stamp()
     assert stamp != 0 and f"-DMJPL_SRC_STAMP=0x{stamp:016x}ull" in build.hipcc_flags()
-    src = specialise._TU % dict(spec="", exact="", hash=info.hash, maxs=info.maxs, wbox="true", generic=0)
+    src = specialise.translation_unit("", "", info.hash, info)
     assert "mjpl_spec_src_stamp" in src and "MJPL_SRC_STAMP" in src
 
 

@@ -56,10 +56,12 @@ def test_specialised_kernels_equal_interpreter_and_oracle(oracle_mod, case):
         np.testing.assert_array_equal(e.check_configs(qb), wantc, err_msg=name)
         np.testing.assert_array_equal(e.check_configs(np.ascontiguousarray(qb.T), layout=eng_mod.SOA), wantc, err_msg=name)
     assert 0.02 < want.mean() < 0.98, name
-    # the filter decides about as much with either code (same culls, same narrowphase)
-    spec.check_edges(qa, qb, 0.01)
+    # the filter decides about as much with either code (same culls, same narrowphase).  Counted on a configuration
+    # launch: on edges the count also holds pairs of waypoints behind an edge's first bad one, and how many of those are
+    # looked at depends on the order the waves take waypoints in (waves per workgroup differ between the two).
+    spec.check_configs(qb)
     u_spec = spec.last_undecided()
-    interp.check_edges(qa, qb, 0.01)
+    interp.check_configs(qb)
     u_int = interp.last_undecided()
     assert abs(u_spec - u_int) <= 0.1 * max(u_spec, u_int) + 20, (u_spec, u_int)
     # changing the planning set changes the program: the engine falls back to the interpreter

@@ -41,7 +41,7 @@ def main():
             rec["hbm_bytes_per_launch"] = (2 * r.get("FETCH_SIZE", 0.0) + r.get("WRITE_SIZE", 0.0)) * 1024
             rec["correction"] = ("gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); "
                                  "FETCH_SIZE and WRITE_SIZE from separate --pmc passes")
-        rec["source"] = f"profiles/{os.path.basename(p)} (tools/profile_gpu.sh {tag})"
+        rec["source"] = f"profiles/{os.path.basename(p)} (tools/{'profile_pads.sh' if kernel.endswith('_pads') else 'profile_gpu.sh'} {tag})"
         # the kernel's floating-point instruction mix, from its own counter pass (tools/profile_next_rows.sh <flops tag>)
         fl = os.path.join(ROOT, "profiles", f"{flops_tag}_pmc_flops_{kernel}.json") if flops_tag else None
         if fl and os.path.exists(fl):
