@@ -299,6 +299,15 @@ typedef struct mjpl_pose mjpl_pose;
 
 /* PoseConstraint.__init__ (pose_constraint.py:18-70); ValueError cases -> MJPL_E_ARG */
 int mjpl_pose_create(mjpl_engine *e, const mjpl_pose_desc *desc, mjpl_pose **out);
+/* 1: a generated projection of the engine's per-model library serves this handle (the chain from the world to the
+ * site's body as straight-line code: mjpl_amd/specialise.py); 0: the interpreting kernels.
+ * Same results either way, bit for bit.  MJPL_POSE_SPEC=0 at creation keeps a handle on the interpreting kernels. */
+int mjpl_pose_spec_loaded(mjpl_pose *p);
+/* Host only, no device needed: the chain program of (model, site body) that mjpl_pose_create compiles -- int words
+ * [header | per chain body {njnt}, per joint {type, qadr, joint id}], doubles [per body pos[3] quat[4]; per joint
+ * axis[3] pos[3] qpos0] -- and the hash a generated projection is looked up by.  pi = pd = NULL returns the sizes. */
+int mjpl_pose_chain_dump(const mjpl_model_desc *model, int32_t site_body, int32_t *pi, int32_t *npi, double *pd, int32_t *npd,
+                         uint64_t *hash);
 void mjpl_pose_destroy(mjpl_pose *p);
 /* `pose_constraint.q_step = ...` (examples/franka_constrained_move_to_pose.py:72-75) */
 int mjpl_pose_set_q_step(mjpl_pose *p, double q_step);

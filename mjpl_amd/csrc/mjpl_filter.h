@@ -20,7 +20,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 12
+#define MJPL_SPEC_ABI 13
 // scene-generic specialised libraries: cull rows per moving geom, moving geoms at most,
 // floats of the scene header in front of the rows
 // Table: [header | per moving geom: kSceneRows cull rows of 4 floats, then kSceneRows descriptor words | one

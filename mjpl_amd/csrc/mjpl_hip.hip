@@ -28,6 +28,7 @@
 #include "mjpl_device.h"
 #include "mjpl_filter.h"
 #include "mjpl_pose.h"
+#include "mjpl_project.h"
 #include "mjpl_nearest.h"
 
 namespace {
@@ -149,146 +150,7 @@ k_filter_edges(const int *__restrict__ gip, int nip, const float *__restrict__ g
                                      first_bad, status, ulist, ucount, rlist, rcount, uc);
 }
 
-// ---- row f1: batched PoseConstraint (pose_constraint.py:72-171), one lane per configuration ----
-// LDS per lane: the working qpos [nq] and a [6][njoint] store that holds the chain joints'
-// world axis/anchor after FK and is overwritten in place by the RPY-Jacobian columns.
-constexpr int kPoseBlock = 64;
-
-constexpr double kPoseMaxCond = 1e6;  // (see k_pose_apply: fast path of the 6x6 pseudo-inverse)
-
-// One lane's PoseConstraint.apply (pose_constraint.py:78-91): qw ([nq] at a stride of kPoseBlock, LDS) holds the
-// configuration to project on entry and what the projection made of it on return; qo[k * qos] is q_old; jst the
-// lane's [6 * njoint] store.  Every lane of the wave calls it (`active` false: the lane only keeps company).
-// Returns 1: within tolerance, 0: left the joint limits or went farther than 2 q_step from q_old, 2: iteration
-// bound; *iters counts the Newton steps taken.
-__device__ __forceinline__ int pose_project_lane(const int *__restrict__ pi, const double *__restrict__ pd, double *qw,
-                                                 double *jst, const double *qo, int qos, bool active, int *iters) {
-  constexpr int B = kPoseBlock;
-  const int nq = pi[PH_NQ], nj = pi[PH_NJOINT], maxit = pi[PH_MAXIT];
-  const double *tail = pd + pi[PH_OFF_TAIL];
-  const double *jrange = pd + pi[PH_OFF_JRANGE];
-  const double tol = tail[PT_TOL], far_at = 2 * tail[PT_QSTEP];
-  // joint ids / types of the chain, in chain order, follow the per-body counts in `pi`
-  bool done = !active;
-  int result = 0, it = 0;
-  while (__ballot(!done) != 0ull) {
-    if (!done) {
-      PoseChainOut o;
-      pose_chain(pi, pd, qw, B, jst, B, o);
-      double dx[6], qs[4];
-      pose_displacement(tail, o, dx, qs);
-      if (norm6(dx) <= tol) {
-        done = true; result = 1;
-      } else if (it >= maxit) {
-        done = true; result = 2;
-      } else {
-        // _get_jacobian: E_rpy(world rpy of the site) @ [jacp; jacr]
-        double rpy[3];
-        quat2rpy(rpy, qs);
-        const double c_p = cos(rpy[1]), c_y = cos(rpy[2]), s_p = sin(rpy[1]), s_y = sin(rpy[2]);
-        const double e33 = c_y / c_p, e34 = s_y / c_p, e43 = -s_y, e44 = c_p;
-        const double e53 = c_y * (s_p / c_p), e54 = s_y * (s_p / c_p);
-        double A[6][6];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-          for (int c = 0; c < 6; c++) A[r][c] = 0;
-        int ic = PH_SIZE, jk = 0;
-        for (int b = 0; b < pi[PH_NBODY]; b++) {
-          const int njnt = pi[ic++];
-          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
-            const int jtype = pi[ic];
-            const double ax[3] = {jst[(0 * nj + jk) * B], jst[(1 * nj + jk) * B], jst[(2 * nj + jk) * B]};
-            double col[6];
-            if (jtype == JT_HINGE) {
-              const double r[3] = {o.site_xpos[0] - jst[(3 * nj + jk) * B], o.site_xpos[1] - jst[(4 * nj + jk) * B],
-                                   o.site_xpos[2] - jst[(5 * nj + jk) * B]};
-              col[0] = ax[1] * r[2] - ax[2] * r[1];
-              col[1] = ax[2] * r[0] - ax[0] * r[2];
-              col[2] = ax[0] * r[1] - ax[1] * r[0];
-              col[3] = e33 * ax[0] + e34 * ax[1];
-              col[4] = e43 * ax[0] + e44 * ax[1];
-              col[5] = e53 * ax[0] + e54 * ax[1] + ax[2];
-            } else {
-              col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2];
-              col[3] = e33 * 0.0 + e34 * 0.0;
-              col[4] = e43 * 0.0 + e44 * 0.0;
-              col[5] = e53 * 0.0 + e54 * 0.0 + 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 6; r++) jst[(r * nj + jk) * B] = col[r];
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-              for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
-          }
-        }
-        // pinv(J J^T) dx (pose_constraint.py:164-171).  Away from kinematic singularities J J^T is
-        // positive definite and modestly conditioned: its inverse by a certified Cholesky solve is
-        // pinv's result to ~cond * 2^-53 (<= 1e-10 relative here) at a hundredth of the
-        // eigen-decomposition's latency; anything the certificate refuses takes the eigen path,
-        // where pinv's singular-value cut-off decides.
-        double y[6];
-        const bool fast = spd6_solve_certified(A, dx, y, kPoseMaxCond);
-        if (__ballot(!fast) != 0ull) {
-          if (!fast) {  // (a copy: only this branch needs the matrix in memory, for the call)
-            double Ae[6][6];
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-              for (int c = 0; c < 6; c++) Ae[r][c] = A[r][c];
-            pinv_sym6_apply(Ae, dx, y);
-          }
-        }
-        ic = PH_SIZE; jk = 0;
-        for (int b = 0; b < pi[PH_NBODY]; b++) {
-          const int njnt = pi[ic++];
-          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
-            const int qadr = pi[ic + 1];
-            double acc = 0;
-#pragma unroll
-            for (int r = 0; r < 6; r++) acc = acc + jst[(r * nj + jk) * B] * y[r];
-            qw[qadr * B] -= acc;
-          }
-        }
-        bool viol = false;
-        double s = 0;
-        for (int k = 0; k < nq; k++) {
-          const double v = qw[k * B];
-          viol = viol || !(v >= jrange[2 * k] && v <= jrange[2 * k + 1]);
-          const double d = v - qo[k * qos];
-          s = s + d * d;
-        }
-        it++;
-        if (viol || sqrt(s) > far_at) { done = true; result = 0; }
-      }
-    }
-  }
-  *iters = it;
-  return result;
-}
-
-__global__ void __launch_bounds__(kPoseBlock)
-k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
-             const double *__restrict__ Q, int64_t N, double *__restrict__ Qout,
-             uint8_t *__restrict__ ok, int32_t *__restrict__ iters) {
-  extern __shared__ double smem[];
-  constexpr int B = kPoseBlock;
-  const int lane = threadIdx.x;
-  const int nq = pi[PH_NQ];
-  double *qw = smem + lane;                    // [nq][B]
-  double *jst = smem + (size_t)nq * B + lane;  // [6 * nj][B]
-  const int64_t i = (int64_t)blockIdx.x * B + lane;
-  const bool active = i < N;
-  for (int k = 0; k < nq; k++) qw[k * B] = active ? Q[i * nq + k] : 0.0;
-  int it = 0;
-  const int result = pose_project_lane(pi, pd, qw, jst, Qold + (active ? i : 0) * nq, 1, active, &it);
-  if (active) {
-    for (int k = 0; k < nq; k++) Qout[i * nq + k] = qw[k * B];
-    ok[i] = result == 1 ? 1 : 0;
-    if (iters) iters[i] = result == 2 ? -it : it;
-  }
-}
+// (pose_project_lane, k_pose_apply, k_rrt_gen_project: mjpl_project.h -- per-model libraries instantiate them, too)
 
 __global__ void __launch_bounds__(kPoseBlock)
 k_pose_valid(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Q,
@@ -528,6 +390,15 @@ struct SpecLib {
   typedef int (*FusedFn)(hipStream_t, int, size_t, FusedArgs);  // (waves per workgroup, LDS bytes, arguments)
   FusedFn fused = nullptr;
   int fused_waves = kFusedWaves;  // what its fused kernel was built for (mjpl_spec_fused_waves)
+  // generated PoseConstraint projections, one per site body of the model (mjpl_project.h): chain hashes and launchers
+  typedef int (*PoseApplyFn)(int, hipStream_t, unsigned, size_t, const int *, const double *, const double *, const double *, int64_t,
+                             double *, uint8_t *, int32_t *);
+  typedef int (*GenProjectFn)(int, hipStream_t, unsigned, size_t, int, int, int, double, const int *, const double *, const int *,
+                              const double *, const uint8_t *, const double *, const double *, const double *, RrtLanes, RrtCand, int *);
+  int pose_count = 0;
+  unsigned long long (*pose_hash)(int) = nullptr;
+  PoseApplyFn pose_apply = nullptr;
+  GenProjectFn gen_project = nullptr;
   EndpointsPwFn endpoints_pw = nullptr;
   ItemsPwFn items_pw = nullptr;
   TailFn tail = nullptr;
@@ -720,6 +591,11 @@ const SpecLib *find_spec(uint64_t hash, bool generic) {
     sl.tail = (SpecLib::TailFn)dlsym(lib, "mjpl_spec_launch_tail");
     sl.fused = (SpecLib::FusedFn)dlsym(lib, "mjpl_spec_launch_fused");
     if (auto fw = (int (*)())dlsym(lib, "mjpl_spec_fused_waves")) sl.fused_waves = fw();
+    sl.pose_hash = (unsigned long long (*)(int))dlsym(lib, "mjpl_spec_pose_hash");
+    sl.pose_apply = (SpecLib::PoseApplyFn)dlsym(lib, "mjpl_spec_launch_pose_apply");
+    sl.gen_project = (SpecLib::GenProjectFn)dlsym(lib, "mjpl_spec_launch_gen_project");
+    if (auto pc = (int (*)())dlsym(lib, "mjpl_spec_pose_count"))
+      sl.pose_count = (sl.pose_hash && sl.pose_apply && sl.gen_project) ? pc() : 0;
     // (the stamp: both libraries built from the same mjpl_filter.h / mjpl_device.h / mjpl_trig.h -- the
     // structs that cross this boundary by value and the table layouts live there)
     const int g = gen ? gen() : 0;
@@ -2917,6 +2793,8 @@ struct mjpl_pose {
   int *d_pi = nullptr;
   double *d_pd = nullptr;
   int nq = 0, nj = 0;
+  uint64_t chain_hash = 0;  // of the chain program (bodies, joints, their constants): names a generated projection
+  bool spec_off = false;    // MJPL_POSE_SPEC=0 at creation: the interpreting kernels whatever the engine has loaded
 };
 
 namespace {
@@ -2962,6 +2840,66 @@ int build_chain(const HostModel &m, int site_body, std::vector<int> &pi, std::ve
 }
 }  // namespace
 
+namespace {
+// what a generated projection carries as literals: the chain program without its run-time tail (site offset,
+// constraint, tolerances, iteration bound), the library ABI and the digest of the shared headers
+uint64_t chain_hash_of(const std::vector<int> &pi, const std::vector<double> &pd, size_t chain_doubles) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  auto mix = [&](const void *ptr, size_t n) {
+    const unsigned char *b = (const unsigned char *)ptr;
+    for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 0x100000001b3ull; }
+  };
+  const int head[3] = {pi[PH_NBODY], pi[PH_NJOINT], pi[PH_NQ]};
+  mix(head, sizeof(head));
+  mix(pi.data() + PH_SIZE, (pi.size() - PH_SIZE) * sizeof(int));
+  mix(pd.data(), chain_doubles * sizeof(double));
+  const int abi = MJPL_SPEC_ABI;
+  mix(&abi, sizeof(abi));
+  const unsigned long long stamp = MJPL_SRC_STAMP;
+  mix(&stamp, sizeof(stamp));
+  return h;
+}
+
+// the generated projection of this handle's chain in the library its engine has loaded NOW (set_planning may have
+// changed it since the handle was made), or -1
+int pose_spec_index(const mjpl_pose *p) {
+  const SpecLib *sl = p->e->spec;
+  if (!sl || p->spec_off) return -1;
+  for (int k = 0; k < sl->pose_count; k++)
+    if (sl->pose_hash(k) == p->chain_hash) return k;
+  return -1;
+}
+}  // namespace
+
+// Host only, no device needed: the chain program of (model, site body) -- what mjpl_pose_create compiles and
+// mjpl_amd/specialise.py turns into straight-line code -- and its hash.  Call with pi = pd = NULL for the sizes.
+int mjpl_pose_chain_dump(const mjpl_model_desc *d, int32_t site_body, int32_t *pi, int32_t *npi, double *pd, int32_t *npd,
+                         uint64_t *hash) {
+  if (!d || !npi || !npd || !hash) return fail(MJPL_E_ARG, "mjpl_pose_chain_dump: NULL argument");
+  if (d->nq != d->njnt) return fail(MJPL_E_JOINT, "nq != njnt: only 1-DoF joints are supported");
+  std::unique_ptr<mjpl_engine> e(new mjpl_engine());
+  e->device = -1;
+  int rc = engine_from_desc(e.get(), d, nullptr, 0);
+  if (rc != MJPL_OK) return rc;
+  if (site_body < 0 || site_body >= e->m.nbody) return fail(MJPL_E_ARG, "site body %d out of range", site_body);
+  std::vector<int> vi;
+  std::vector<double> vd;
+  int nj = 0;
+  if ((rc = build_chain(e->m, site_body, vi, vd, &nj)) != MJPL_OK) return rc;
+  *hash = chain_hash_of(vi, vd, vd.size());
+  const bool fits = pi && pd && *npi >= (int32_t)vi.size() && *npd >= (int32_t)vd.size();
+  *npi = (int32_t)vi.size();
+  *npd = (int32_t)vd.size();
+  if (fits) {
+    memcpy(pi, vi.data(), vi.size() * sizeof(int));
+    memcpy(pd, vd.data(), vd.size() * sizeof(double));
+  }
+  return MJPL_OK;
+}
+
+// 0: the interpreting kernels serve this handle; 1: a generated projection of the engine's library does
+int mjpl_pose_spec_loaded(mjpl_pose *p) { return (p && pose_spec_index(p) >= 0) ? 1 : 0; }
+
 int mjpl_pose_create(mjpl_engine *e, const mjpl_pose_desc *d, mjpl_pose **out) {
   if (!e || !d || !out) return fail(MJPL_E_ARG, "mjpl_pose_create: NULL argument");
   const HostModel &m = e->m;
@@ -2975,6 +2913,8 @@ int mjpl_pose_create(mjpl_engine *e, const mjpl_pose_desc *d, mjpl_pose **out) {
   p->nq = m.nq;
   int rc = build_chain(m, d->site_body, p->pi, p->pd, &p->nj);
   if (rc != MJPL_OK) return rc;
+  p->chain_hash = chain_hash_of(p->pi, p->pd, p->pd.size());
+  if (const char *f = getenv("MJPL_POSE_SPEC")) p->spec_off = atoi(f) == 0;
   p->pi[PH_MAXIT] = d->max_iters > 0 ? d->max_iters : 1000;
   p->pi[PH_OFF_TAIL] = (int)p->pd.size();
   p->pd.resize(p->pd.size() + PT_SIZE);
@@ -3024,7 +2964,13 @@ int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQold, const double *dQ, int
   if (!dQold || !dQout || !dok) return fail(MJPL_E_ARG, "NULL pointer");
   HIP_TRY(hipSetDevice(p->e->device));
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
-  hipLaunchKernelGGL(k_pose_apply, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd,
+  const int k = pose_spec_index(p);
+  if (k >= 0) {
+    if (p->e->spec->pose_apply(k, p->e->stream, grid, pose_lds(p), p->d_pi, p->d_pd, dQold, dQ, N, dQout, dok, diters) != 0)
+      return fail(MJPL_E_HIP, "generated projection kernel failed to launch");
+    return MJPL_OK;
+  }
+  hipLaunchKernelGGL(k_pose_apply<void>, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd,
                      dQold, dQ, N, dQout, dok, diters);
   HIP_TRY(hipGetLastError());
   return MJPL_OK;

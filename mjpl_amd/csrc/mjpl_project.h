@@ -1,0 +1,424 @@
+// mjpl_project.h -- the PoseConstraint projection (pose_constraint.py:72-171) as device code shared by libmjpl_hip.so
+// and the per-model libraries: one lane's Newton iteration, the batched kernel around it (row f1) and the planner's
+// chunk of projected extension steps (row e).  Everything is a template over a pose spec `PS`: void = the
+// interpreting statement (the chain program of mjpl_pose.h read from memory), else a generated struct whose `chain`
+// is the same statements for ONE (model, site body) as straight-line code (mjpl_amd/specialise.py: generate_pose).
+// Structs that cross the library boundary by value live here: this header is part of the source stamp.
+#pragma once
+
+#include <type_traits>
+
+#include "mjpl_device.h"
+#include "mjpl_pose.h"
+
+namespace mjpl {
+
+// counters shared with the host (one 64-byte block, read back per chunk / per exchange)
+enum : int { RC_EDGES = 0, RC_ACC, RC_ACTIVE, RC_CONN, RC_CONN_REFA, RC_CONN_REFB, RC_NEWA, RC_NEWB,
+             RC_OVERFLOW, RC_SIZE = 16 };
+
+struct RrtLanes {
+  double *T, *C, *RA;          // [nplan][L] SoA: target, current end of the lane's chain, reach of extend A
+  int32_t *near, *refA, *refB; // nearest node; final reference of the lane in tree A / B
+  uint8_t *on, *act;           // takes part this round; still extending
+  int32_t *cnt, *off;          // accepted nodes of the lane in this extension; exclusive scan
+  int32_t *gfirst, *gcount;    // candidates of the lane in this chunk: first slot, how many
+  uint8_t *gend;               // the lane ends after this chunk's candidates whatever their verdicts
+  int32_t *goal;               // biased lanes: goal index (-1: not biased)
+};
+
+struct RrtCand {               // candidates of one chunk, AoS rows of nplan
+  double *A, *B;
+  int32_t *lane, *level;
+  uint8_t *valid, *rule, *reach;
+  int cap;
+};
+
+__device__ __forceinline__ double seqnorm(const double *d, int n) {  // the sum order of the whole path
+  double s = 0;
+  for (int k = 0; k < n; k++) s = s + d[k] * d[k];
+  return sqrt(s);
+}
+
+constexpr int kRrtMaxPlan = 16;
+
+// ---- row f1: batched PoseConstraint (pose_constraint.py:72-171), one lane per configuration ----
+// LDS per lane: the working qpos [nq] and a [6][njoint] store that holds the chain joints'
+// world axis/anchor after FK and is overwritten in place by the RPY-Jacobian columns.
+constexpr int kPoseBlock = 64;
+
+constexpr double kPoseMaxCond = 1e6;  // (see k_pose_apply: fast path of the 6x6 pseudo-inverse)
+
+// One lane's PoseConstraint.apply (pose_constraint.py:78-91): qw ([nq] at a stride of kPoseBlock, LDS) holds the
+// configuration to project on entry and what the projection made of it on return; qo[k * qos] is q_old; jst the
+// lane's [6 * njoint] store.  Every lane of the wave calls it (`active` false: the lane only keeps company).
+// Returns 1: within tolerance, 0: left the joint limits or went farther than 2 q_step from q_old, 2: iteration
+// bound; *iters counts the Newton steps taken.
+// PS: void = the chain program in (pi, pd) is interpreted; else PS::chain is that chain as straight-line code
+// (pose_project_static below: the same statements in the same order, so the same float64 values).
+template <class PS> struct PoseStatic;
+
+template <class PS = void>
+__device__ __forceinline__ int pose_project_lane(const int *__restrict__ pi, const double *__restrict__ pd, double *qw,
+                                                 double *jst, const double *qo, int qos, bool active, int *iters) {
+  if constexpr (!std::is_void<PS>::value) return PoseStatic<PS>::project(pi, pd, qw, qo, qos, active, iters);
+  constexpr int B = kPoseBlock;
+  const int nq = pi[PH_NQ], nj = pi[PH_NJOINT], maxit = pi[PH_MAXIT];
+  const double *tail = pd + pi[PH_OFF_TAIL];
+  const double *jrange = pd + pi[PH_OFF_JRANGE];
+  const double tol = tail[PT_TOL], far_at = 2 * tail[PT_QSTEP];
+  // joint ids / types of the chain, in chain order, follow the per-body counts in `pi`
+  bool done = !active;
+  int result = 0, it = 0;
+  while (__ballot(!done) != 0ull) {
+    if (!done) {
+      PoseChainOut o;
+      pose_chain(pi, pd, qw, B, jst, B, o);
+      double dx[6], qs[4];
+      pose_displacement(tail, o, dx, qs);
+      if (norm6(dx) <= tol) {
+        done = true; result = 1;
+      } else if (it >= maxit) {
+        done = true; result = 2;
+      } else {
+        // _get_jacobian: E_rpy(world rpy of the site) @ [jacp; jacr]
+        double rpy[3];
+        quat2rpy(rpy, qs);
+        const double c_p = cos(rpy[1]), c_y = cos(rpy[2]), s_p = sin(rpy[1]), s_y = sin(rpy[2]);
+        const double e33 = c_y / c_p, e34 = s_y / c_p, e43 = -s_y, e44 = c_p;
+        const double e53 = c_y * (s_p / c_p), e54 = s_y * (s_p / c_p);
+        double A[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) A[r][c] = 0;
+        int ic = PH_SIZE, jk = 0;
+        for (int b = 0; b < pi[PH_NBODY]; b++) {
+          const int njnt = pi[ic++];
+          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
+            const int jtype = pi[ic];
+            const double ax[3] = {jst[(0 * nj + jk) * B], jst[(1 * nj + jk) * B], jst[(2 * nj + jk) * B]};
+            double col[6];
+            if (jtype == JT_HINGE) {
+              const double r[3] = {o.site_xpos[0] - jst[(3 * nj + jk) * B], o.site_xpos[1] - jst[(4 * nj + jk) * B],
+                                   o.site_xpos[2] - jst[(5 * nj + jk) * B]};
+              col[0] = ax[1] * r[2] - ax[2] * r[1];
+              col[1] = ax[2] * r[0] - ax[0] * r[2];
+              col[2] = ax[0] * r[1] - ax[1] * r[0];
+              col[3] = e33 * ax[0] + e34 * ax[1];
+              col[4] = e43 * ax[0] + e44 * ax[1];
+              col[5] = e53 * ax[0] + e54 * ax[1] + ax[2];
+            } else {
+              col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2];
+              col[3] = e33 * 0.0 + e34 * 0.0;
+              col[4] = e43 * 0.0 + e44 * 0.0;
+              col[5] = e53 * 0.0 + e54 * 0.0 + 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) jst[(r * nj + jk) * B] = col[r];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+              for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
+          }
+        }
+        // pinv(J J^T) dx (pose_constraint.py:164-171).  Away from kinematic singularities J J^T is
+        // positive definite and modestly conditioned: its inverse by a certified Cholesky solve is
+        // pinv's result to ~cond * 2^-53 (<= 1e-10 relative here) at a hundredth of the
+        // eigen-decomposition's latency; anything the certificate refuses takes the eigen path,
+        // where pinv's singular-value cut-off decides.
+        double y[6];
+        const bool fast = spd6_solve_certified(A, dx, y, kPoseMaxCond);
+        if (__ballot(!fast) != 0ull) {
+          if (!fast) {  // (a copy: only this branch needs the matrix in memory, for the call)
+            double Ae[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+              for (int c = 0; c < 6; c++) Ae[r][c] = A[r][c];
+            pinv_sym6_apply(Ae, dx, y);
+          }
+        }
+        ic = PH_SIZE; jk = 0;
+        for (int b = 0; b < pi[PH_NBODY]; b++) {
+          const int njnt = pi[ic++];
+          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
+            const int qadr = pi[ic + 1];
+            double acc = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc = acc + jst[(r * nj + jk) * B] * y[r];
+            qw[qadr * B] -= acc;
+          }
+        }
+        bool viol = false;
+        double s = 0;
+        for (int k = 0; k < nq; k++) {
+          const double v = qw[k * B];
+          viol = viol || !(v >= jrange[2 * k] && v <= jrange[2 * k + 1]);
+          const double d = v - qo[k * qos];
+          s = s + d * d;
+        }
+        it++;
+        if (viol || sqrt(s) > far_at) { done = true; result = 0; }
+      }
+    }
+  }
+  *iters = it;
+  return result;
+}
+
+// The projection around a generated chain.  PS provides: kNQ, kNJ, jtype(k), qadr(k) (constexpr) and
+// chain(q, jx, out, tail): mj_kinematics along the chain from the configuration in registers, jx[k] = world axis
+// (0..2) and anchor (3..5) of chain joint k.  The working configuration, the joints' columns and the 6x6 live in
+// registers (every index is a literal after unrolling); nothing is read from the chain program, no LDS but the
+// caller's qw / qo.  Statement for statement pose_project_lane above.
+template <class PS>
+struct PoseStatic {
+  static __device__ __forceinline__ int project(const int *__restrict__ pi, const double *__restrict__ pd, double *qw,
+                                                const double *qo, int qos, bool active, int *iters) {
+    constexpr int B = kPoseBlock, NQ = PS::kNQ, NJ = PS::kNJ;
+    const int maxit = pi[PH_MAXIT];
+    const double *tail = pd + pi[PH_OFF_TAIL];
+    const double *jrange = pd + pi[PH_OFF_JRANGE];
+    const double tol = tail[PT_TOL], far_at = 2 * tail[PT_QSTEP];
+    double qv[NQ], qold[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; k++) { qv[k] = qw[k * B]; qold[k] = qo[k * qos]; }
+    bool done = !active;
+    int result = 0, it = 0;
+    while (__ballot(!done) != 0ull) {
+      if (!done) {
+        PoseChainOut o;
+        double jx[NJ][6];
+        PS::chain(qv, jx, o, tail);
+        double dx[6], qs[4];
+        pose_displacement(tail, o, dx, qs);
+        if (norm6(dx) <= tol) {
+          done = true; result = 1;
+        } else if (it >= maxit) {
+          done = true; result = 2;
+        } else {
+          double rpy[3];
+          quat2rpy(rpy, qs);
+          const double c_p = cos(rpy[1]), c_y = cos(rpy[2]), s_p = sin(rpy[1]), s_y = sin(rpy[2]);
+          const double e33 = c_y / c_p, e34 = s_y / c_p, e43 = -s_y, e44 = c_p;
+          const double e53 = c_y * (s_p / c_p), e54 = s_y * (s_p / c_p);
+          double A[6][6];
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) A[r][c] = 0;
+#pragma unroll
+          for (int jk = 0; jk < NJ; jk++) {
+            const double ax[3] = {jx[jk][0], jx[jk][1], jx[jk][2]};
+            double col[6];
+            if (PS::jtype(jk) == JT_HINGE) {
+              const double r[3] = {o.site_xpos[0] - jx[jk][3], o.site_xpos[1] - jx[jk][4], o.site_xpos[2] - jx[jk][5]};
+              col[0] = ax[1] * r[2] - ax[2] * r[1];
+              col[1] = ax[2] * r[0] - ax[0] * r[2];
+              col[2] = ax[0] * r[1] - ax[1] * r[0];
+              col[3] = e33 * ax[0] + e34 * ax[1];
+              col[4] = e43 * ax[0] + e44 * ax[1];
+              col[5] = e53 * ax[0] + e54 * ax[1] + ax[2];
+            } else {
+              col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2];
+              col[3] = e33 * 0.0 + e34 * 0.0;
+              col[4] = e43 * 0.0 + e44 * 0.0;
+              col[5] = e53 * 0.0 + e54 * 0.0 + 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) jx[jk][r] = col[r];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+              for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
+          }
+          double y[6];
+          const bool fast = spd6_solve_certified(A, dx, y, kPoseMaxCond);
+          if (__ballot(!fast) != 0ull) {
+            if (!fast) {
+              double Ae[6][6];
+#pragma unroll
+              for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) Ae[r][c] = A[r][c];
+              pinv_sym6_apply(Ae, dx, y);
+            }
+          }
+#pragma unroll
+          for (int jk = 0; jk < NJ; jk++) {
+            double acc = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc = acc + jx[jk][r] * y[r];
+            qv[PS::qadr(jk)] -= acc;
+          }
+          bool viol = false;
+          double s = 0;
+#pragma unroll
+          for (int k = 0; k < NQ; k++) {
+            const double v = qv[k];
+            viol = viol || !(v >= jrange[2 * k] && v <= jrange[2 * k + 1]);
+            const double d = v - qold[k];
+            s = s + d * d;
+          }
+          it++;
+          if (viol || sqrt(s) > far_at) { done = true; result = 0; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NQ; k++) qw[k * B] = qv[k];
+    *iters = it;
+    return result;
+  }
+};
+
+template <class PS = void>
+__global__ void __launch_bounds__(kPoseBlock)
+k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
+             const double *__restrict__ Q, int64_t N, double *__restrict__ Qout,
+             uint8_t *__restrict__ ok, int32_t *__restrict__ iters) {
+  extern __shared__ double smem[];
+  constexpr int B = kPoseBlock;
+  const int lane = threadIdx.x;
+  const int nq = pi[PH_NQ];
+  double *qw = smem + lane;                    // [nq][B]
+  double *jst = smem + (size_t)nq * B + lane;  // [6 * nj][B]
+  const int64_t i = (int64_t)blockIdx.x * B + lane;
+  const bool active = i < N;
+  for (int k = 0; k < nq; k++) qw[k * B] = active ? Q[i * nq + k] : 0.0;
+  int it = 0;
+  const int result = pose_project_lane<PS>(pi, pd, qw, jst, Qold + (active ? i : 0) * nq, 1, active, &it);
+  if (active) {
+    for (int k = 0; k < nq; k++) Qout[i * nq + k] = qw[k * B];
+    ok[i] = result == 1 ? 1 : 0;
+    if (iters) iters[i] = result == 2 ? -it : it;
+  }
+}
+
+
+// One chunk of an extension under a projecting constraint (PoseConstraint): every active lane takes up to
+// S steps -- _step towards the target, the projection of that step (pose_project_lane: PoseConstraint.apply),
+// the rules of _constrained_extend on what comes back (planning/utils.py:139-164: joint limits, moved >= 1e-8,
+// not farther from the target; a projection that moves a joint outside the planning set is rejected) -- each from
+// where the step before ended.  The projection depends on the previous step's result, not on its collision
+// verdict, so a lane's S candidates are generated on the spot and validated together; k_rrt_accept keeps the
+// leading valid ones, which are exactly what S chunks of one step would have kept.  The host takes S > 1 when
+// few lanes are left and a chunk costs the latency of its kernels whatever it holds.
+// Every emitting lane owns S slots: those behind its last candidate carry a zero-length edge nobody reads.
+// One workgroup of 64 lanes; LDS per lane: qw[nq] | jst[6 * njoint] | qo[nq].
+template <class PS = void>
+__global__ void __launch_bounds__(kPoseBlock)
+k_rrt_gen_project(int L, int nplan, int S, double eps, const int *__restrict__ pi, const double *__restrict__ pd,
+                  const int *__restrict__ qidx, const double *__restrict__ qbase, const uint8_t *__restrict__ isplan,
+                  const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln,
+                  RrtCand cd, int *__restrict__ ctr) {
+  extern __shared__ double smem[];
+  constexpr int B = kPoseBlock;
+  const int lane = threadIdx.x;
+  const int l = blockIdx.x * B + lane;
+  const int nq = pi[PH_NQ], nj = pi[PH_NJOINT];
+  const bool act = l < L && ln.act[l] != 0;
+  const unsigned long long am = __ballot(act);
+  if (am == 0ull) return;
+  double *qw = smem + lane;
+  double *jst = smem + (size_t)nq * B + lane;
+  double *qo = smem + ((size_t)nq + 6 * (size_t)nj) * B + lane;
+  // S slots per active lane, one reservation per wave
+  int base = 0;
+  if (lane == 0) {
+    const int nact = __popcll(am);
+    base = atomicAdd(&ctr[RC_EDGES], nact * S);
+    atomicAdd(&ctr[RC_ACTIVE], nact);
+  }
+  base = __builtin_amdgcn_readfirstlane(base);
+  int first = base + __popcll(am & ((1ull << lane) - 1ull)) * S;
+  bool going = act;
+  if (going && first + S > cd.cap) {  // (the host sizes S for the space there is: a lane refused here waits for the next chunk)
+    atomicOr(&ctr[RC_OVERFLOW], 1);
+    for (int slot = first; slot < cd.cap; slot++) {
+      for (int c = 0; c < nplan; c++) {
+        const double v = ln.C[(int64_t)c * L + l];
+        cd.A[(int64_t)slot * nplan + c] = v;
+        cd.B[(int64_t)slot * nplan + c] = v;
+      }
+      cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
+    }
+    ln.gfirst[l] = 0; ln.gcount[l] = 0; ln.gend[l] = 0;
+    going = false;
+  }
+  const bool mine = going;
+  double T[kRrtMaxPlan], w[kRrtMaxPlan], q[kRrtMaxPlan], d[kRrtMaxPlan];
+  if (going)
+    for (int c = 0; c < nplan; c++) { T[c] = Tgt[(int64_t)c * L + l]; w[c] = ln.C[(int64_t)c * L + l]; }
+  const int lvl0 = mine ? ln.cnt[l] : 0;
+  int count = 0, end = 0;
+  for (int s = 0; s < S && __ballot(going) != 0ull; s++) {
+    if (going) {
+      // _step(w, T, eps) (planning/utils.py:167-186)
+      for (int c = 0; c < nplan; c++) d[c] = T[c] - w[c];
+      const double mag = seqnorm(d, nplan);
+      const double sm = eps < mag ? eps : mag;
+      bool reach = true;
+      for (int c = 0; c < nplan; c++) {
+        q[c] = w[c] + (d[c] / mag) * sm;
+        reach = reach && (q[c] == T[c]);
+      }
+      reach = reach || (mag <= eps);
+      if (reach)
+        for (int c = 0; c < nplan; c++) q[c] = T[c];  // a step of at most eps lands on the target
+      for (int k = 0; k < nq; k++) { qo[k * B] = qbase[k]; qw[k * B] = qbase[k]; }
+      for (int c = 0; c < nplan; c++) { qo[qidx[c] * B] = w[c]; qw[qidx[c] * B] = q[c]; }
+    }
+    int it = 0;
+    const int result = pose_project_lane<PS>(pi, pd, qw, jst, qo, B, going, &it);
+    if (going) {
+      bool good = result == 1;
+      for (int k = 0; k < nq; k++)  // a projection that moves a joint outside the planning set is rejected
+        if (!isplan[k]) good = good && (qw[k * B] == qbase[k]);
+      bool reach = true;
+      for (int c = 0; c < nplan; c++) {
+        q[c] = qw[qidx[c] * B];
+        reach = reach && (q[c] == T[c]);
+        good = good && (q[c] >= lo[c] && q[c] <= hi[c]);
+      }
+      for (int c = 0; c < nplan; c++) d[c] = q[c] - w[c];
+      good = good && !(seqnorm(d, nplan) < 1e-8);
+      for (int c = 0; c < nplan; c++) d[c] = T[c] - q[c];
+      const double after = seqnorm(d, nplan);
+      for (int c = 0; c < nplan; c++) d[c] = T[c] - w[c];
+      good = good && !(after > seqnorm(d, nplan));
+      const int slot = first + s;
+      for (int c = 0; c < nplan; c++) {
+        cd.A[(int64_t)slot * nplan + c] = w[c];
+        cd.B[(int64_t)slot * nplan + c] = good ? q[c] : w[c];  // (refused: a harmless edge for the validation launch)
+      }
+      cd.lane[slot] = l;
+      cd.level[slot] = lvl0 + s;
+      cd.rule[slot] = good ? 1 : 0;
+      cd.reach[slot] = (good && reach) ? 1 : 0;
+      count++;
+      if (good) {
+        for (int c = 0; c < nplan; c++) w[c] = q[c];
+        if (reach) { end = 1; going = false; }
+      } else {
+        end = 1; going = false;
+      }
+    }
+  }
+  if (mine) {
+    for (int slot = first + count; slot < first + S; slot++) {
+      for (int c = 0; c < nplan; c++) {
+        cd.A[(int64_t)slot * nplan + c] = w[c];
+        cd.B[(int64_t)slot * nplan + c] = w[c];
+      }
+      cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
+    }
+    ln.gfirst[l] = first;
+    ln.gcount[l] = count;
+    ln.gend[l] = (uint8_t)end;
+  }
+}
+
+
+}  // namespace mjpl

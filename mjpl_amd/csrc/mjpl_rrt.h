@@ -33,27 +33,6 @@ using namespace mjpl;
 
 // (the counter-based generator -- sm64 / rrt_key / rrt_u01 -- lives in mjpl_device.h)
 
-// counters shared with the host (one 64-byte block, read back per chunk / per exchange)
-enum : int { RC_EDGES = 0, RC_ACC, RC_ACTIVE, RC_CONN, RC_CONN_REFA, RC_CONN_REFB, RC_NEWA, RC_NEWB,
-             RC_OVERFLOW, RC_SIZE = 16 };
-
-struct RrtLanes {
-  double *T, *C, *RA;          // [nplan][L] SoA: target, current end of the lane's chain, reach of extend A
-  int32_t *near, *refA, *refB; // nearest node; final reference of the lane in tree A / B
-  uint8_t *on, *act;           // takes part this round; still extending
-  int32_t *cnt, *off;          // accepted nodes of the lane in this extension; exclusive scan
-  int32_t *gfirst, *gcount;    // candidates of the lane in this chunk: first slot, how many
-  uint8_t *gend;               // the lane ends after this chunk's candidates whatever their verdicts
-  int32_t *goal;               // biased lanes: goal index (-1: not biased)
-};
-
-struct RrtCand {               // candidates of one chunk, AoS rows of nplan
-  double *A, *B;
-  int32_t *lane, *level;
-  uint8_t *valid, *rule, *reach;
-  int cap;
-};
-
 struct RrtAcc {                // nodes accepted during the current extension, any order
   double *Q;                   // [cap][nplan]
   int32_t *lane, *level;
@@ -61,13 +40,6 @@ struct RrtAcc {                // nodes accepted during the current extension, a
 };
 
 // ----------------------------------------------------------------------------- kernels
-__device__ __forceinline__ double seqnorm(const double *d, int n) {  // the sum order of the whole path
-  double s = 0;
-  for (int k = 0; k < n; k++) s = s + d[k] * d[k];
-  return sqrt(s);
-}
-
-constexpr int kRrtMaxPlan = 16;
 constexpr int kRingStride = 32;  // ints per slot of the pinned counter ring
 
 __global__ void __launch_bounds__(256)
@@ -222,127 +194,7 @@ k_rrt_gen(int L, int nplan, int S, double eps, const double *__restrict__ lo,
   }
 }
 
-// One chunk of an extension under a projecting constraint (PoseConstraint): every active lane takes up to
-// S steps -- _step towards the target, the projection of that step (pose_project_lane: PoseConstraint.apply),
-// the rules of _constrained_extend on what comes back (planning/utils.py:139-164: joint limits, moved >= 1e-8,
-// not farther from the target; a projection that moves a joint outside the planning set is rejected) -- each from
-// where the step before ended.  The projection depends on the previous step's result, not on its collision
-// verdict, so a lane's S candidates are generated on the spot and validated together; k_rrt_accept keeps the
-// leading valid ones, which are exactly what S chunks of one step would have kept.  The host takes S > 1 when
-// few lanes are left and a chunk costs the latency of its kernels whatever it holds.
-// Every emitting lane owns S slots: those behind its last candidate carry a zero-length edge nobody reads.
-// One workgroup of 64 lanes; LDS per lane: qw[nq] | jst[6 * njoint] | qo[nq].
-__global__ void __launch_bounds__(kPoseBlock)
-k_rrt_gen_project(int L, int nplan, int S, double eps, const int *__restrict__ pi, const double *__restrict__ pd,
-                  const int *__restrict__ qidx, const double *__restrict__ qbase, const uint8_t *__restrict__ isplan,
-                  const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln,
-                  RrtCand cd, int *__restrict__ ctr) {
-  extern __shared__ double smem[];
-  constexpr int B = kPoseBlock;
-  const int lane = threadIdx.x;
-  const int l = blockIdx.x * B + lane;
-  const int nq = pi[PH_NQ], nj = pi[PH_NJOINT];
-  const bool act = l < L && ln.act[l] != 0;
-  const unsigned long long am = __ballot(act);
-  if (am == 0ull) return;
-  double *qw = smem + lane;
-  double *jst = smem + (size_t)nq * B + lane;
-  double *qo = smem + ((size_t)nq + 6 * (size_t)nj) * B + lane;
-  // S slots per active lane, one reservation per wave
-  int base = 0;
-  if (lane == 0) {
-    const int nact = __popcll(am);
-    base = atomicAdd(&ctr[RC_EDGES], nact * S);
-    atomicAdd(&ctr[RC_ACTIVE], nact);
-  }
-  base = __builtin_amdgcn_readfirstlane(base);
-  int first = base + __popcll(am & ((1ull << lane) - 1ull)) * S;
-  bool going = act;
-  if (going && first + S > cd.cap) {  // (the host sizes S for the space there is: a lane refused here waits for the next chunk)
-    atomicOr(&ctr[RC_OVERFLOW], 1);
-    for (int slot = first; slot < cd.cap; slot++) {
-      for (int c = 0; c < nplan; c++) {
-        const double v = ln.C[(int64_t)c * L + l];
-        cd.A[(int64_t)slot * nplan + c] = v;
-        cd.B[(int64_t)slot * nplan + c] = v;
-      }
-      cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
-    }
-    ln.gfirst[l] = 0; ln.gcount[l] = 0; ln.gend[l] = 0;
-    going = false;
-  }
-  const bool mine = going;
-  double T[kRrtMaxPlan], w[kRrtMaxPlan], q[kRrtMaxPlan], d[kRrtMaxPlan];
-  if (going)
-    for (int c = 0; c < nplan; c++) { T[c] = Tgt[(int64_t)c * L + l]; w[c] = ln.C[(int64_t)c * L + l]; }
-  const int lvl0 = mine ? ln.cnt[l] : 0;
-  int count = 0, end = 0;
-  for (int s = 0; s < S && __ballot(going) != 0ull; s++) {
-    if (going) {
-      // _step(w, T, eps) (planning/utils.py:167-186)
-      for (int c = 0; c < nplan; c++) d[c] = T[c] - w[c];
-      const double mag = seqnorm(d, nplan);
-      const double sm = eps < mag ? eps : mag;
-      bool reach = true;
-      for (int c = 0; c < nplan; c++) {
-        q[c] = w[c] + (d[c] / mag) * sm;
-        reach = reach && (q[c] == T[c]);
-      }
-      reach = reach || (mag <= eps);
-      if (reach)
-        for (int c = 0; c < nplan; c++) q[c] = T[c];  // a step of at most eps lands on the target
-      for (int k = 0; k < nq; k++) { qo[k * B] = qbase[k]; qw[k * B] = qbase[k]; }
-      for (int c = 0; c < nplan; c++) { qo[qidx[c] * B] = w[c]; qw[qidx[c] * B] = q[c]; }
-    }
-    int it = 0;
-    const int result = pose_project_lane(pi, pd, qw, jst, qo, B, going, &it);
-    if (going) {
-      bool good = result == 1;
-      for (int k = 0; k < nq; k++)  // a projection that moves a joint outside the planning set is rejected
-        if (!isplan[k]) good = good && (qw[k * B] == qbase[k]);
-      bool reach = true;
-      for (int c = 0; c < nplan; c++) {
-        q[c] = qw[qidx[c] * B];
-        reach = reach && (q[c] == T[c]);
-        good = good && (q[c] >= lo[c] && q[c] <= hi[c]);
-      }
-      for (int c = 0; c < nplan; c++) d[c] = q[c] - w[c];
-      good = good && !(seqnorm(d, nplan) < 1e-8);
-      for (int c = 0; c < nplan; c++) d[c] = T[c] - q[c];
-      const double after = seqnorm(d, nplan);
-      for (int c = 0; c < nplan; c++) d[c] = T[c] - w[c];
-      good = good && !(after > seqnorm(d, nplan));
-      const int slot = first + s;
-      for (int c = 0; c < nplan; c++) {
-        cd.A[(int64_t)slot * nplan + c] = w[c];
-        cd.B[(int64_t)slot * nplan + c] = good ? q[c] : w[c];  // (refused: a harmless edge for the validation launch)
-      }
-      cd.lane[slot] = l;
-      cd.level[slot] = lvl0 + s;
-      cd.rule[slot] = good ? 1 : 0;
-      cd.reach[slot] = (good && reach) ? 1 : 0;
-      count++;
-      if (good) {
-        for (int c = 0; c < nplan; c++) w[c] = q[c];
-        if (reach) { end = 1; going = false; }
-      } else {
-        end = 1; going = false;
-      }
-    }
-  }
-  if (mine) {
-    for (int slot = first + count; slot < first + S; slot++) {
-      for (int c = 0; c < nplan; c++) {
-        cd.A[(int64_t)slot * nplan + c] = w[c];
-        cd.B[(int64_t)slot * nplan + c] = w[c];
-      }
-      cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
-    }
-    ln.gfirst[l] = first;
-    ln.gcount[l] = count;
-    ln.gend[l] = (uint8_t)end;
-  }
-}
+// (k_rrt_gen_project: mjpl_project.h)
 
 // accept the leading valid candidates of every lane
 __global__ void __launch_bounds__(256)
@@ -699,9 +551,19 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
       // speculation costs slots (S per lane) and nothing else: a lane that stops early stops generating.
       S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(r->proj_steps_max, r->proj_slots / std::max(1, active_bound)),
                                                       (int64_t)r->cd.cap / std::max(1, active_bound)));
-      hipLaunchKernelGGL(k_rrt_gen_project, dim3((unsigned)((L + kPoseBlock - 1) / kPoseBlock)), dim3(kPoseBlock),
-                         pose_lds(r->pose) + (size_t)kPoseBlock * sizeof(double) * (size_t)r->nq, st, L, nplan, S, r->eps,
-                         r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase, r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+      {
+        const unsigned pgrid = (unsigned)((L + kPoseBlock - 1) / kPoseBlock);
+        const size_t plds = pose_lds(r->pose) + (size_t)kPoseBlock * sizeof(double) * (size_t)r->nq;
+        const int pk = pose_spec_index(r->pose);  // (the chain as straight-line code, if the engine's library has it)
+        if (pk >= 0) {
+          if (e->spec->gen_project(pk, st, pgrid, plds, L, nplan, S, r->eps, r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase,
+                                   r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr) != 0)
+            return fail(MJPL_E_HIP, "generated projection kernel failed to launch");
+        } else {
+          hipLaunchKernelGGL(k_rrt_gen_project<void>, dim3(pgrid), dim3(kPoseBlock), plds, st, L, nplan, S, r->eps, r->pose->d_pi,
+                             r->pose->d_pd, r->d_qidx, r->d_qbase, r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+        }
+      }
       if (chunk < 2) {  // (the first two chunks: their own counts)
         if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
         if (r->h_ctr[RC_OVERFLOW] & 3) return fail(MJPL_E_CAPACITY, "rrt: buffer overrun in a projecting extension");

@@ -133,6 +133,8 @@ ABI = {
                                         C.POINTER(C.c_float)]),
     "mjpl_pose_create": (C.c_int, [_VP, C.POINTER(PoseDesc), C.POINTER(_VP)]),
     "mjpl_pose_destroy": (None, [_VP]),
+    "mjpl_pose_spec_loaded": (C.c_int, [_VP]),
+    "mjpl_pose_chain_dump": (C.c_int, [C.POINTER(_ModelDesc), C.c_int32, _I32P, _I32P, _F64P, _I32P, C.POINTER(C.c_uint64)]),
     "mjpl_pose_set_q_step": (C.c_int, [_VP, C.c_double]),
     "mjpl_pose_apply": (C.c_int, [_VP, _F64P, _F64P, C.c_int64, _F64P, _U8P, _I32P]),
     "mjpl_pose_valid": (C.c_int, [_VP, _F64P, C.c_int64, _U8P, _F64P, _F64P]),
@@ -507,6 +509,10 @@ class PoseProjector:
         self.h = h
         self.nq = model.nq
         eng._projectors.add(self)
+
+    def spec_loaded(self) -> bool:
+        """True: a generated projection of the engine's per-model library serves this handle (same results)."""
+        return bool(self.eng.lib.mjpl_pose_spec_loaded(self.h))
 
     def close(self):
         if self.h and self.eng.h:

@@ -852,6 +852,7 @@ _TU = """// GENERATED translation unit: the float32 filter kernels of mjpl_filte
 #include <stdint.h>
 #include <atomic>
 %(waves_define)s#include "mjpl_filter.h"
+#include "mjpl_project.h"
 
 namespace {
 %(spec)s
@@ -939,7 +940,151 @@ int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t
   SPEC_LAUNCH((k_patch_pairs<ExactSpec>), ip, nip, dp, ndp, gt, uc, valid, first_bad);
 }
 }
+// ---- PoseConstraint projections of this model's site bodies (mjpl_project.h)
+%(pose)s
 """
+
+
+# ---- the PoseConstraint projection as straight-line code (mjpl_project.h: PoseStatic<PS>) ----------------------
+PH_NBODY, PH_NJOINT, PH_NQ, PH_SIZE = 0, 1, 2, 6  # (mjpl_pose.h)
+
+
+def _model_desc(model):
+    d = _engine._ModelDesc()
+    d.nq, d.njnt, d.nbody, d.ngeom = model.nq, model.njnt, model.nbody, model.ngeom
+    keep = []
+    for name, typ in _engine._ModelDesc._fields_[4:]:
+        arr = getattr(model, name)
+        arr = _engine._i32(arr) if typ is _engine._I32P else _engine._f64(arr)
+        keep.append(arr)
+        setattr(d, name, arr.ctypes.data_as(typ))
+    return d, keep
+
+
+def dump_pose_chain(model, site_body: int):
+    """The chain program mjpl_pose_create compiles for (model, site body), on the host (no GPU)
+    -> (pi int32[], pd float64[], hash)."""
+    lib = _engine.load_library()
+    d, keep = _model_desc(model)
+    npi, npd, h = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+
+    def call(pi, pd):
+        rc = lib.mjpl_pose_chain_dump(C.byref(d), int(site_body), None if pi is None else pi.ctypes.data_as(_engine._I32P), C.byref(npi),
+                                      None if pd is None else pd.ctypes.data_as(_engine._F64P), C.byref(npd), C.byref(h))
+        if rc != 0:
+            raise _engine.MjplError(rc, lib.mjpl_last_error().decode())
+
+    call(None, None)
+    pi, pd = np.zeros(npi.value, np.int32), np.zeros(npd.value, np.float64)
+    call(pi, pd)
+    return pi, pd, int(h.value)
+
+
+def pose_site_bodies(model) -> list[int]:
+    """The bodies a generated projection is made for: every body that carries a site (a PoseConstraint names a site)."""
+    return sorted({int(b) for b in np.asarray(model.site_bodyid).reshape(-1) if int(b) > 0})
+
+
+def generate_pose(pi, pd, hash_: int, index: int) -> str:
+    """`struct PoseSpec<index>`: mj_kinematics along one chain with the model's constants as literals -- the
+    statements of pose_chain (mjpl_pose.h) in the same order, calling the same routines, so the same float64 values;
+    what goes away is the reading of the chain program (scalar loads in a dependent chain, loop control) and the
+    trip through LDS of the joints' axes and anchors."""
+    nb, nj, nq = int(pi[PH_NBODY]), int(pi[PH_NJOINT]), int(pi[PH_NQ])
+    out = []
+    o = out.append
+
+    def arr(v):
+        return "{" + ", ".join(dlit(x) for x in v) + "}"
+    jtypes, qadrs = [], []
+    body = []
+    b_ = body.append
+    ic, dc, jk = PH_SIZE, 0, 0
+    for b in range(nb):
+        njnt = int(pi[ic]); ic += 1
+        b_(f"    {{  // chain body {b}")
+        b_("      double np[3], nq[4];")
+        b_(f"      {{ const double bpos[3] = {arr(pd[dc:dc + 3])}, bquat[4] = {arr(pd[dc + 3:dc + 7])};")
+        dc += 7
+        b_("        mul_mat_vec3(np, R, bpos);")
+        b_("        np[0] += p[0]; np[1] += p[1]; np[2] += p[2];")
+        b_("        mul_quat(nq, qt, bquat); }")
+        for j in range(njnt):
+            jtype, qadr = int(pi[ic]), int(pi[ic + 1]); ic += 3
+            jtypes.append(jtype); qadrs.append(qadr)
+            b_(f"      {{ const double jaxis[3] = {arr(pd[dc:dc + 3])}, jpos[3] = {arr(pd[dc + 3:dc + 6])};")
+            b_(f"        const double dq = q[{qadr}] - {dlit(pd[dc + 6])};")
+            dc += 7
+            b_("        double xaxis[3], xanchor[3];")
+            b_("        rot_vec_quat(xaxis, jaxis, nq);")
+            b_("        rot_vec_quat(xanchor, jpos, nq);")
+            b_("        xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];")
+            b_(f"        jx[{jk}][0] = xaxis[0]; jx[{jk}][1] = xaxis[1]; jx[{jk}][2] = xaxis[2];")
+            b_(f"        jx[{jk}][3] = xanchor[0]; jx[{jk}][4] = xanchor[1]; jx[{jk}][5] = xanchor[2];")
+            if jtype == JT_SLIDE:
+                b_("        np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq; }")
+            else:
+                b_("        double sn, cs, vec[3];")
+                b_("        sincos_half(dq * 0.5, &sn, &cs);")
+                b_("        const double qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};")
+                b_("        mul_quat(nq, nq, qloc);")
+                b_("        rot_vec_quat(vec, jpos, nq);")
+                b_("        np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2]; }")
+            jk += 1
+        b_("      normalize4(nq);")
+        b_("      p[0] = np[0]; p[1] = np[1]; p[2] = np[2];")
+        b_("      qt[0] = nq[0]; qt[1] = nq[1]; qt[2] = nq[2]; qt[3] = nq[3];")
+        b_("      quat2mat(R, qt);")
+        b_("    }")
+    assert jk == nj
+    o(f"// GENERATED: chain program {hash_:016x} -- {nb} bodies, {nj} joints, nq {nq}")
+    o(f"struct PoseSpec{index} {{")
+    o(f"  static constexpr int kNQ = {nq}, kNJ = {nj};")
+    o(f"  static constexpr unsigned long long kHash = 0x{hash_:016x}ull;")
+    o(f"  static __device__ __forceinline__ constexpr int jtype(int k) {{ constexpr int t[{max(nj, 1)}] = {{{', '.join(str(x) for x in jtypes) or '0'}}}; return t[k]; }}")
+    o(f"  static __device__ __forceinline__ constexpr int qadr(int k) {{ constexpr int t[{max(nj, 1)}] = {{{', '.join(str(x) for x in qadrs) or '0'}}}; return t[k]; }}")
+    o(f"  static __device__ __forceinline__ void chain(const double (&q)[{nq}], double (&jx)[{max(nj, 1)}][6], mjpl::PoseChainOut &out,")
+    o("                                               const double *tail) {")
+    o("    using namespace mjpl;")
+    o("    double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};")
+    out.extend(body)
+    o("    const double spos[3] = {tail[PT_SITE_POS], tail[PT_SITE_POS + 1], tail[PT_SITE_POS + 2]};")
+    o("    const double squat[4] = {tail[PT_SITE_QUAT], tail[PT_SITE_QUAT + 1], tail[PT_SITE_QUAT + 2], tail[PT_SITE_QUAT + 3]};")
+    o("    double sp[3], sq[4];")
+    o("    mul_mat_vec3(sp, R, spos);")
+    o("    out.site_xpos[0] = sp[0] + p[0]; out.site_xpos[1] = sp[1] + p[1]; out.site_xpos[2] = sp[2] + p[2];")
+    o("    mul_quat(sq, qt, squat);")
+    o("    quat2mat(out.site_xmat, sq);")
+    o("  }")
+    o("};")
+    return "\n".join(out) + "\n"
+
+
+def generate_pose_section(model) -> str:
+    """All generated projections of a model and the entry points a library exports for them."""
+    specs = []
+    for k, b in enumerate(pose_site_bodies(model)):
+        pi, pd, h = dump_pose_chain(model, b)
+        if int(pi[PH_NJOINT]) == 0 or int(pi[PH_NJOINT]) > 12 or int(pi[PH_NQ]) > 16:
+            continue  # (nothing to project / registers: the interpreting kernels serve such a chain)
+        specs.append((len(specs), h, generate_pose(pi, pd, h, len(specs))))
+    n = len(specs)
+    src = ["namespace {"] + [s for _, _, s in specs] + ["}  // namespace", "", 'extern "C" {', f"int mjpl_spec_pose_count(void) {{ return {n}; }}",
+           "unsigned long long mjpl_spec_pose_hash(int k) {", "  switch (k) {"]
+    src += [f"    case {k}: return PoseSpec{k}::kHash;" for k, _, _ in specs]
+    src += ["    default: return 0ull;", "  }", "}"]
+    src += ["int mjpl_spec_launch_pose_apply(int k, hipStream_t st, unsigned grid, size_t lds, const int *pi, const double *pd, const double *Qold,",
+            "                                const double *Q, int64_t N, double *Qout, uint8_t *ok, int32_t *iters) {", "  switch (k) {"]
+    src += [f"    case {k}: hipLaunchKernelGGL(mjpl::k_pose_apply<PoseSpec{k}>, dim3(grid), dim3(mjpl::kPoseBlock), lds, st, pi, pd, Qold, Q, N, Qout, ok, iters); break;"
+            for k, _, _ in specs]
+    src += ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -1;", "}"]
+    src += ["int mjpl_spec_launch_gen_project(int k, hipStream_t st, unsigned grid, size_t lds, int L, int nplan, int S, double eps, const int *pi,",
+            "                                 const double *pd, const int *qidx, const double *qbase, const uint8_t *isplan, const double *lo,",
+            "                                 const double *hi, const double *Tgt, mjpl::RrtLanes ln, mjpl::RrtCand cd, int *ctr) {", "  switch (k) {"]
+    src += [f"    case {k}: hipLaunchKernelGGL(mjpl::k_rrt_gen_project<PoseSpec{k}>, dim3(grid), dim3(mjpl::kPoseBlock), lds, st, L, nplan, S, eps, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr); break;"
+            for k, _, _ in specs]
+    src += ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -1;", "}", "}"]
+    return "\n".join(src) + "\n"
 
 
 def _mbox_waves() -> int:
@@ -947,10 +1092,13 @@ def _mbox_waves() -> int:
     return max(1, min(3, int(os.environ.get("MJPL_SPEC_MBOX_WAVES", "2"))))
 
 
-def translation_unit(spec: str, exact: str, key: int, info, generic_word: int = 0) -> str:
-    """The source of a library: the kernels of mjpl_filter.h / mjpl_fused.h instantiated around `spec` / `exact`."""
+def translation_unit(spec: str, exact: str, key: int, info, generic_word: int = 0, pose: str | None = None) -> str:
+    """The source of a library: the kernels of mjpl_filter.h / mjpl_fused.h instantiated around `spec` / `exact`,
+    and the projections of `pose` (generate_pose_section; None: a library without any)."""
     mbox = bool(info.mbox)
-    return _TU % dict(spec=spec, exact=exact, hash=key, maxs=info.maxs,
+    if pose is None:
+        pose = 'extern "C" int mjpl_spec_pose_count(void) { return 0; }\n'
+    return _TU % dict(spec=spec, exact=exact, hash=key, maxs=info.maxs, pose=pose,
                       wbox="true" if (info.wbox or generic_word or mbox) else "false", mbox="true" if mbox else "false",
                       maxsd=32 if mbox else info.maxs,  # (the exact kernels of a model with moving boxes: the general build)
                       # a model with moving boxes keeps whole frames in its slot file and in the box queue's records: built for
@@ -988,7 +1136,8 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
             pc += B_SIZE + nj * J_SIZE + ng * (G_SIZE + MAX_SLOTS)
             nstage += ng
     src = translation_unit(generate(ip, fp, dp, info, generic=generic), generate_exact(ip, dp, info, generic=generic), key, info,
-                           (SCENE_ROWS << 8 | nstage) if generic else 0)  # (kSceneRows, moving geoms)
+                           (SCENE_ROWS << 8 | nstage) if generic else 0,  # (kSceneRows, moving geoms)
+                           pose=generate_pose_section(model))
     # Source and library appear under their final names complete or not at all (os.replace): an engine created
     # while a rebuild is running finds the old library or the new one, never half a file -- a failed dlopen would
     # be remembered as "no library" for the life of that process -- and two builds of one hash cannot interleave.

@@ -158,7 +158,7 @@ def test_program_dump_and_code_generation_need_no_gpu():
         assert info.hash == info2.hash and np.array_equal(ip, ip2) and np.array_equal(fp.view(np.uint32), fp2.view(np.uint32))
         assert info.hash not in seen, name
         seen.add(info.hash)
-        assert not info.immediate and info.filter_usable and info.spec_abi == 12
+        assert not info.immediate and info.filter_usable and info.spec_abi == 13
         np.testing.assert_allclose(fp[np.isfinite(fp)], dp[np.isfinite(fp)].astype(np.float32), rtol=2e-5, atol=2e-4)
         src = specialise.generate(ip, fp, dp, info)
         culls = (src.count("MJPL_SPEC_CULLX(") + 2 * src.count("MJPL_SPEC_CULLX2(") + src.count("MJPL_SPEC_CULL(") +

@@ -88,6 +88,45 @@ def test_batched_projection_matches_the_oracle(oracle_mod, scene):
     assert (iters[both] > 0).any()
 
 
+def test_generated_projection_is_the_interpreting_one_bit_for_bit(oracle_mod, monkeypatch):
+    """Franka-P's libraries carry the chain to the site's body as straight-line code (mjpl_project.h: PoseStatic,
+    specialise.generate_pose): the same statements in the same order -- every projected configuration, verdict and
+    iteration count equals the interpreting kernel's bit for bit.  A handle made under MJPL_POSE_SPEC=0, and one on
+    an engine without a library (MJPL_SPEC=0), run the interpreting kernel."""
+    m = scenes.franka_p(obstacles=False)
+    q_home = m.keyframe("home").qpos.copy()
+    rng = np.random.default_rng(21)
+    n = 30000
+    lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+    Q_old = np.clip(q_home + rng.normal(scale=0.08, size=(n, m.nq)), lo, hi)
+    Q_old[:, 7:] = q_home[7:]
+    d = rng.normal(size=(n, m.nq))
+    d[:, 7:] = 0
+    Q = np.clip(Q_old + rng.choice([0.02, 0.05, 0.2], size=(n, 1)) * d / np.linalg.norm(d, axis=1, keepdims=True), lo, hi)
+    kw = dict(z_translation=(-0.05, 0.05), roll=(-0.1, 0.1), pitch=(-0.1, 0.1), q_step=0.5)
+    results = {}
+    for tag, env in (("generated", {}), ("interpreting", {"MJPL_POSE_SPEC": "0"}), ("no library", {"MJPL_SPEC": "0"})):
+        for k in ("MJPL_POSE_SPEC", "MJPL_SPEC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = mjpl.engine.Engine(m)
+        frame = mjpl.site_pose(m, q_home, "ee_site", engine=eng)
+        pc = mjpl.PoseConstraint(m, "ee_site", frame, engine=eng, **kw)
+        assert pc._proj.spec_loaded() == (tag == "generated"), tag
+        results[tag] = pc.apply_batch(Q_old, Q)
+        eng.close()
+    for k in ("MJPL_POSE_SPEC", "MJPL_SPEC"):
+        monkeypatch.delenv(k, raising=False)
+    q0, ok0, it0 = results["generated"]
+    assert 0.05 < ok0.mean() < 1.0 and it0.max() >= 3, (ok0.mean(), it0.max())
+    for tag in ("interpreting", "no library"):
+        q1, ok1, it1 = results[tag]
+        np.testing.assert_array_equal(ok0, ok1, err_msg=tag)
+        np.testing.assert_array_equal(it0, it1, err_msg=tag)
+        np.testing.assert_array_equal(np.ascontiguousarray(q0).view(np.uint64), np.ascontiguousarray(q1).view(np.uint64), err_msg=tag)
+
+
 def test_projection_properties_at_config4_size():
     """131 072 rows (config 4's 1 048 576 samples / 8 GPUs): every accepted row satisfies the
     constraint, the joint limits and the 2*q_step bound; projecting a projected row is a no-op."""

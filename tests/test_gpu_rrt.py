@@ -209,12 +209,14 @@ def test_projecting_extension_makes_the_same_trees_whatever_the_steps_per_launch
     joints = scenes.FRANKA_ARM_JOINTS
     qidx = scenes.planning_index(m, joints)
     q_init = m.keyframe("home").qpos.copy()
-    cc, pc, q_goal = _constrained(m, q_init, 7)
     trees = []
-    for steps, slots in (("1", "1"), policy):
-        old = {k: os.environ.get(k) for k in ("MJPL_RRT_PROJ_STEPS", "MJPL_RRT_PROJ_SLOTS")}
-        os.environ.update(MJPL_RRT_PROJ_STEPS=steps, MJPL_RRT_PROJ_SLOTS=slots)
+    # (the S = 1 run also keeps its projection on the INTERPRETING kernel, MJPL_POSE_SPEC=0; the other run takes the
+    #  chain as straight-line code from the model's library, mjpl_project.h: the same trees, bit for bit)
+    for (steps, slots), pose_spec in zip((("1", "1"), policy), ("0", "1")):
+        old = {k: os.environ.get(k) for k in ("MJPL_RRT_PROJ_STEPS", "MJPL_RRT_PROJ_SLOTS", "MJPL_POSE_SPEC")}
+        os.environ.update(MJPL_RRT_PROJ_STEPS=steps, MJPL_RRT_PROJ_SLOTS=slots, MJPL_POSE_SPEC=pose_spec)
         try:
+            cc, pc, q_goal = _constrained(m, q_init, 7)
             dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=11, goal_biasing_probability=0.05,
                                    batch=4096, capacity=1 << 21, pose=pc)
         finally:
@@ -222,6 +224,7 @@ def test_projecting_extension_makes_the_same_trees_whatever_the_steps_per_launch
                 os.environ.pop(k, None)
                 if v is not None:
                     os.environ[k] = v
+        assert pc._proj.spec_loaded() == (pose_spec == "1")
         dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 11)
         infos = [dev.rrt.round() for _ in range(3)]
         assert infos[-1].nodes[0] > 5000 and infos[-1].nodes[1] > 5000
