@@ -1053,7 +1053,7 @@ def main():
                                   # (with the filter off no kernel of a per-model library runs, whatever the engine has loaded)
                                   "specialised_kernels": bool(ve.spec_loaded()) and vf,
                                   "library": ({0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[ve.spec_kind()]
-                                              if vf else "none: the interpreting float64 kernels of libmjpl_hip.so (k_edges_fused_f64, then k_check_edges over the edges too long for its pool)"),
+                                              if vf else "none: the interpreting float64 kernels of libmjpl_hip.so (k_edges_fused_f64 -- the exact check through the candidate queues, narrowphase with full lanes -- then k_check_edges over the edges too long for its pool)"),
                                   "fused_edges": bool(vf and vinfo.get("fused_edges")),
                                   "verdicts_equal_headline": same, "edges_compared": E,
                                   "valu_issue": valu_issue(vk, v_stage[vk], rec)}

@@ -1564,9 +1564,10 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
   const T *lwcull = ltab + uni(ip[H_OFF_WCULL]);
   const T *lwnarrow = ltab + uni(ip[H_OFF_WNARROW]);
   int pc = uni(ip[H_OFF_BODYOPS]);
-  // the per-model limits inside which binary32 poses are within tol / 2 of the binary64 ones
-  const T maxcoord = tp[uni(ip[H_OFF_FCONST]) + FC_MAXCOORD];
-  const T maxangle = tp[uni(ip[H_OFF_FCONST]) + FC_MAXANGLE];
+  // the per-model limits inside which binary32 poses are within tol / 2 of the binary64 ones (T = double: the EXACT
+  // check through the same queues -- k_edges_fused_f64 -- has no such limits, no tolerance and never an UNSURE)
+  const T maxcoord = Real<T>::exact ? T(0) : tp[uni(ip[H_OFF_FCONST]) + FC_MAXCOORD];
+  const T maxangle = Real<T>::exact ? T(0) : tp[uni(ip[H_OFF_FCONST]) + FC_MAXANGLE];
 
   for (int b = 0; b < nbodyops; b++) {
     if (__builtin_amdgcn_ballot_w64(dead == T(0)) == 0ull && qn == 0 && qb == 0) break;  // every lane decided
@@ -1629,7 +1630,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
           rot_vec_quat(xanchor, jpos, nq);
           xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];
         }
-        far = far || !(fabs(dq) <= maxangle);  // binary32(q) is off by eps |q|
+        if constexpr (!Real<T>::exact) far = far || !(fabs(dq) <= maxangle);  // binary32(q) is off by eps |q|
         T sn, cs;
         sincos_half(dq * T(0.5), &sn, &cs);
         T qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};
@@ -1650,8 +1651,10 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
     // float32 positions lose absolute accuracy with distance from the origin: beyond the model's
     // limit (FC_MAXCOORD) the tolerance band no longer covers the rounding error, so the whole
     // configuration goes to the exact path (this also catches NaN)
-    far = far || !(fmax(fabs(p[0]), fmax(fabs(p[1]), fabs(p[2]))) <= maxcoord);
-    if (far) dead = kInf;
+    if constexpr (!Real<T>::exact) {
+      far = far || !(fmax(fabs(p[0]), fmax(fabs(p[1]), fabs(p[2]))) <= maxcoord);
+      if (far) dead = kInf;
+    }
     if (save_slot >= 0) {
       T *sv = save + (size_t)save_slot * 7 * sstride;
 #pragma unroll

@@ -507,24 +507,30 @@ k_edges_fused(FusedArgs a) {
 // the waypoint along.  Verdicts are those of k_check_edges bit for bit: same statements on the same values.
 constexpr int kFusedF64Waves = 8;   // 186 .. 256 VGPRs: two waves per SIMD
 constexpr int kFusedF64Kmax = 31;
-__host__ __device__ constexpr size_t fused_f64_wave_bytes(int nplan, int nsave) {
+// QUEUED: the float64 check through the candidate queues (run_config_queued<double>: culls lane per configuration,
+// narrowphase with full lanes) instead of the immediate interpreter; a wave's queues follow its rows.
+__host__ __device__ constexpr size_t fused_f64_wave_bytes(int nplan, int nsave, bool queued = false) {
   const size_t rows = (size_t)nplan * 64 * sizeof(double), saves = (size_t)nsave * 7 * 64 * sizeof(double);
-  return rows + (saves > rows ? saves : rows);  // [columns / end row | pose saves / walking row]
+  return rows + (saves > rows ? saves : rows) + (queued ? WaveQueue<double, false>::bytes() : 0);  // [columns / end row | pose saves / walking row | queues]
 }
-inline size_t fused_f64_lds_bytes(int nwaves, int nplan, int nsave, int pool) {
-  return (size_t)nwaves * fused_f64_wave_bytes(nplan, nsave) + WorkPool::bytes(pool);
+inline size_t fused_f64_lds_bytes(int nwaves, int nplan, int nsave, int pool, bool queued = false) {
+  return (size_t)nwaves * fused_f64_wave_bytes(nplan, nsave, queued) + WorkPool::bytes(pool);
 }
 
-template <int MAXS, bool WBOX, bool MBOX, int NW>
+template <int MAXS, bool WBOX, bool MBOX, int NW, bool QUEUED = false>
 __global__ void __launch_bounds__(NW * 64)
 k_edges_fused_f64(FusedArgs a) {
+  static_assert(!QUEUED || (!MBOX && MAXS <= 16), "the queued float64 check serves the slot files of 4 / 8 / 16, no moving boxes");
   extern __shared__ double smem[];
   zero_counters(a.zero_next);
   const int nplan = a.ip[H_NPLAN], nsave = a.ip[H_NSAVE];
   const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-  const size_t wbytes = fused_f64_wave_bytes(nplan, nsave);
+  const size_t wbytes = fused_f64_wave_bytes(nplan, nsave, QUEUED);
   double *col = reinterpret_cast<double *>(reinterpret_cast<char *>(smem) + (size_t)wv * wbytes) + lane;  // [nplan][64]
   double *aux = col + (size_t)nplan * 64;  // pose saves during a check, the walking / end row between checks
+  WaveQueue<double, false> wq;
+  if constexpr (QUEUED) wq.carve(reinterpret_cast<char *>(smem) + (size_t)(wv + 1) * wbytes - WaveQueue<double, false>::bytes());
+  PatchSink sink = {};  // (nothing is handed on: the exact check decides everything itself)
   WorkPool pool;
   pool.init(reinterpret_cast<char *>(smem) + (size_t)NW * wbytes, a.pool, a.tile0, a.tile1, NW);
   __syncthreads();
@@ -598,7 +604,11 @@ k_edges_fused_f64(FusedArgs a) {
       }
     }
     wave_lds_fence();
-    const bool hit = run_config<double, MAXS, false, WBOX, MBOX>((IP)a.ip, (DP)a.dp, col, 64, aux, 64, active, 0.0, none, i) == V_CONTACT;
+    bool hit;
+    if constexpr (QUEUED)  // (the tables the drains gather from: the float64 tables in global memory, 23 KB, cache resident)
+      hit = run_config_queued<double, MAXS, WBOX, false>((IP)a.ip, (DP)a.dp, a.dp, col, 64, aux, 64, active, 0.0, wq, (int)i, sink) == V_CONTACT;
+    else
+      hit = run_config<double, MAXS, false, WBOX, MBOX>((IP)a.ip, (DP)a.dp, col, 64, aux, 64, active, 0.0, none, i) == V_CONTACT;
     wave_lds_fence();
     if (!ep) {
       if (active && hit) {

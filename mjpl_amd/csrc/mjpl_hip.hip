@@ -484,6 +484,7 @@ struct mjpl_engine {
   bool fused = true;
   int fused_policy = 0, fused_kmax = 4096, fused_pool_cap = 0;  // (MJPL_FUSED_POOL: at most that many ring slots)
   bool fused_mbox = false;
+  bool f64_queued = true;  // MJPL_F64_QUEUED: the float64 pool kernel checks through the candidate queues (A/B switch)
   int fused_single_max = 32768;  // MJPL_FUSED_SINGLE: batches up to this many edges check every configuration of an edge in one round (measured: 0.068 vs 0.087 ms at 1 024 edges, 0.090 vs 0.102 at 32 768, 0.116 vs 0.106 at 65 536)
   bool fused_skip_once = false;  // mjpl_check_edges: this launch holds a few long edges -> the kernels with checkpoints
   const char *fused_dbg_path = nullptr;  // MJPL_FUSED_DEBUG=<file> (with a -DMJPL_FUSED_DEBUG build of the kernels)
@@ -1859,10 +1860,14 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     int *zero_next = next_counters(e);
     CounterGuard guard{e, true};
     const int nplan = (int)e->qidx.size();
-    const size_t base = fused_f64_lds_bytes(kFusedF64Waves, nplan, e->nsave, 0);
+    // the check through the candidate queues (narrowphase with full lanes) where the model has the queued build's
+    // shape and eight waves' queues fit beside the rows and a pool; else the immediate interpreter (MJPL_F64_QUEUED=0)
+    const bool queued = e->f64_queued && !e->exact_general() &&
+                        fused_f64_lds_bytes(kFusedF64Waves, nplan, e->nsave, 64 * kFusedF64Waves + 64, true) <= (size_t)160 * 1024;
+    const size_t base = fused_f64_lds_bytes(kFusedF64Waves, nplan, e->nsave, 0, queued);
     int pool = (int)std::min<size_t>(kFusedMaxPool, ((size_t)160 * 1024 - base) / kFusedEntryBytes / 64 * 64);
     if (e->fused_pool_cap > 0) pool = std::max(64 * kFusedF64Waves + 64, std::min(pool, e->fused_pool_cap / 64 * 64));
-    const size_t flds = fused_f64_lds_bytes(kFusedF64Waves, nplan, e->nsave, pool);
+    const size_t flds = fused_f64_lds_bytes(kFusedF64Waves, nplan, e->nsave, pool, queued);
     FusedArgs fa = {};
     fa.ip = e->d_ip; fa.nip = (int)e->ip.size();
     fa.dp = e->d_dp; fa.ndp = (int)e->dp.size();
@@ -1877,11 +1882,16 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     fa.kmax = kFusedF64Kmax; fa.pool = pool; fa.policy = e->fused_policy;
     MJPL_MARK(0);
     rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
-      auto kern = k_edges_fused_f64<decltype(S)::value, decltype(W)::value, decltype(M)::value, kFusedF64Waves>;
-      int r = allow_lds(kern, flds);
-      if (r != MJPL_OK) return r;
-      if (fused_launch(kern, kFusedF64Waves, flds, fa, e->stream) != hipSuccess) return fail(MJPL_E_HIP, "the float64 pool kernel failed to launch");
-      return MJPL_OK;
+      auto go = [&](auto kern) -> int {
+        int r = allow_lds(kern, flds);
+        if (r != MJPL_OK) return r;
+        if (fused_launch(kern, kFusedF64Waves, flds, fa, e->stream) != hipSuccess) return fail(MJPL_E_HIP, "the float64 pool kernel failed to launch");
+        return MJPL_OK;
+      };
+      if constexpr (!decltype(M)::value && decltype(S)::value <= 16) {
+        if (queued) return go(k_edges_fused_f64<decltype(S)::value, decltype(W)::value, false, kFusedF64Waves, true>);
+      }
+      return go(k_edges_fused_f64<decltype(S)::value, decltype(W)::value, decltype(M)::value, kFusedF64Waves, false>);
     });
     if (rc != MJPL_OK) return rc;
     guard.armed = false;
@@ -2006,6 +2016,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   e->fused_dbg_path = getenv("MJPL_FUSED_DEBUG");
   if (const char *f = getenv("MJPL_FUSED_POOL")) e->fused_pool_cap = atoi(f);
   if (const char *f = getenv("MJPL_FUSED_MBOX")) e->fused_mbox = atoi(f) != 0;
+  if (const char *f = getenv("MJPL_F64_QUEUED")) e->f64_queued = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FUSED_SINGLE")) e->fused_single_max = std::max(0, atoi(f));
   if (const char *f = getenv("MJPL_FUSED_KMAX")) e->fused_kmax = std::max(2, std::min(atoi(f), 1 << 16));
   if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));

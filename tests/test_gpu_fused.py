@@ -18,7 +18,7 @@ from helpers import random_edges  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-KEYS = ("MJPL_FUSED", "MJPL_FUSED_MBOX", "MJPL_FUSED_POOL", "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX", "MJPL_SPEC", "MJPL_UC_CAP", "MJPL_FILTER")
+KEYS = ("MJPL_FUSED", "MJPL_FUSED_MBOX", "MJPL_FUSED_POOL", "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX", "MJPL_SPEC", "MJPL_UC_CAP", "MJPL_FILTER", "MJPL_F64_QUEUED")
 
 
 def _engine(m, qidx=None, base=None, allowed=(), **env):
@@ -61,7 +61,9 @@ def test_ring_that_wraps_and_every_policy_at_full_size(oracle_mod):
                 {"MJPL_FUSED_POOL": 832, "MJPL_UC_CAP": 64}, {"MJPL_FUSED_SINGLE": 100000000, "MJPL_FUSED_POOL": 832},
                 {"MJPL_FUSED_POOL": 832, "MJPL_SPEC": 0},
                 # the float64 checks through the same pool (filter off): eight waves per workgroup, a ring that wraps
-                {"MJPL_FILTER": 0}, {"MJPL_FILTER": 0, "MJPL_FUSED_POOL": 576}, {"MJPL_FILTER": 0, "MJPL_FUSED_POOL": 576, "MJPL_FUSED_POLICY": 1}):
+                {"MJPL_FILTER": 0}, {"MJPL_FILTER": 0, "MJPL_FUSED_POOL": 576}, {"MJPL_FILTER": 0, "MJPL_FUSED_POOL": 576, "MJPL_FUSED_POLICY": 1},
+                # ... and with the immediate float64 interpreter as the check instead of the candidate queues
+                {"MJPL_FILTER": 0, "MJPL_F64_QUEUED": 0}):
         e = _engine(m, qidx, base, **env)
         f64 = "MJPL_FILTER" in env
         assert bool(e.info()["filter_enabled"]) != f64
@@ -109,7 +111,8 @@ def test_long_short_and_broken_edges_in_one_batch(oracle_mod, single):
     qa, qb = np.array(starts), np.array(ends)
     want, wfb, ncheck = orc.valid_edges(qa, qb, step, nthreads=8, info=True)
     assert ncheck.max() > 800 and 0 < want.sum() < len(want)
-    for env in ({"MJPL_FUSED_KMAX": 200}, {}, {"MJPL_FUSED_KMAX": 200, "MJPL_FUSED_POOL": 832}, {"MJPL_FILTER": 0}):
+    for env in ({"MJPL_FUSED_KMAX": 200}, {}, {"MJPL_FUSED_KMAX": 200, "MJPL_FUSED_POOL": 832}, {"MJPL_FILTER": 0},
+                {"MJPL_FILTER": 0, "MJPL_F64_QUEUED": 0}):
         e = _engine(m, MJPL_FUSED_SINGLE=single, **env)
         assert e.info()["fused_edges"] or "MJPL_FILTER" in env
         got, gfb = e.check_edges(qa, qb, step, first_bad=True)
