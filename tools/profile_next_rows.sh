@@ -22,12 +22,12 @@ python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_pose k_pose_apply gpurun_out
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_nearest_mfma gpurun_out/${TAG}_pmc_k_nearest_mfma.json > /dev/null
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_rrt_gen_project gpurun_out/${TAG}_pmc_k_rrt_gen_project.json > /dev/null
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_ik k_ik_solve gpurun_out/${TAG}_pmc_k_ik_solve.json > /dev/null
-# the float64 edge kernel's issued floating-point instruction mix (bench --variant f64)
+# the float64 pool kernel's issued floating-point instruction mix (bench --variant f64: k_edges_fused_f64)
 OUT=$R/gpurun_out/prof_${TAG}_f64flops
 cd /tmp
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-variants --variant f64 > $OUT.log 2>&1
 cd $R
-python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_f64flops k_check_edges gpurun_out/${TAG}_pmc_flops_k_check_edges.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_f64flops k_edges_fused_f64 gpurun_out/${TAG}_pmc_flops_k_edges_fused_f64.json > /dev/null
 ls gpurun_out/${TAG}_*
 # (the raw rocprofv3 output is bulky and gpurun_out/ travels back only below 64 MiB: the summaries are what is kept)
 rm -rf gpurun_out/prof_${TAG}_pose gpurun_out/prof_${TAG}_rrt gpurun_out/prof_${TAG}_ik gpurun_out/prof_${TAG}_f64flops
