@@ -206,7 +206,21 @@ SCENE_ROWS, SCENE_HEADER, SCENE_SLOT_LANE0 = 32, 32, 40  # (mjpl_filter.h: kScen
 SCENE_PLANE_ROWS, SCENE_STAGE = 2, 32 * 4 + 32              # (kScenePlaneRows, kSceneStageFloats)
 
 
+class _SharedAxesReused(ValueError):
+    """Boxes share an axes slot that the program's slot allocation reuses while they still refer to it."""
+
+
 def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = False) -> str:
+    """Straight-line filter code of one program (see _generate).  Moving boxes of one body with one orientation share
+    the slot of their x and y axes; where the program's own slot allocation gets in the way of that, every box keeps
+    its own."""
+    try:
+        return _generate(ip, fp, dp, info, cull_form, generic, share_axes=True)
+    except _SharedAxesReused:
+        return _generate(ip, fp, dp, info, cull_form, generic, share_axes=False)
+
+
+def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = False, share_axes: bool = True) -> str:
     """HIP source of `struct Spec` for one compiled program.
     generic: the ROBOT's code only -- forward kinematics, geom poses, the culls against earlier moving geoms --
     as literals; every static partner (floor, obstacles, the robot's own world-welded base) is a row of the
@@ -461,17 +475,17 @@ def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fal
             store2 = ((store >> 6) & 63) if (store >= 0 and mbox) else 63
             if store >= 0 and (store & 63) in axes_key:  # (a slot that held shared axes is written again: nobody may still read them)
                 if any(v == (store & 63) and k != v for k, v in axes_of.items()):
-                    raise ValueError("a shared axes slot is reused while boxes still refer to it")
+                    raise _SharedAxesReused("a shared axes slot is reused while boxes still refer to it")
                 del axes_key[store & 63]
             if store2 != 63:
                 key = (b, bool(gflags & GF_SAMEROT), tuple(np.float32(lquat).tolist()))
-                held = [sl for sl, k_ in axes_key.items() if k_ == key]
+                held = [sl for sl, k_ in axes_key.items() if k_ == key] if share_axes else []
                 if held:           # the frame is in the slot file already
                     axes_of[store2] = held[0]
                     store2 = 63
                 else:
                     if any(v == store2 and k != v for k, v in axes_of.items()):
-                        raise ValueError("a shared axes slot is reused while boxes still refer to it")
+                        raise _SharedAxesReused("a shared axes slot is reused while boxes still refer to it")
                     axes_of[store2] = store2
                     axes_key[store2] = key
             stages.append((pending_fk + g.lines, gtype, gdoff, store & 63 if store >= 0 else -1, store2))
