@@ -182,6 +182,32 @@ def test_program_dump_and_code_generation_need_no_gpu():
     assert specialise.build(m) is None
 
 
+def test_pose_chain_dump_and_generated_projection_need_no_gpu():
+    """mjpl_pose_chain_dump compiles the chain program of a (model, site body) on the host; specialise.generate_pose
+    turns it into straight-line code: one block per chain body, one sincos per hinge, the hash a handle looks its
+    projection up by -- which depends on the chain's constants and not on anything else of the model."""
+    from mjpl_amd import scenes, specialise
+    m = scenes.franka_p(obstacles=True)
+    bodies = specialise.pose_site_bodies(m)
+    assert bodies == [int(m.site_bodyid[m.site("ee_site").id])]
+    pi, pd, h = specialise.dump_pose_chain(m, bodies[0])
+    pi2, pd2, h2 = specialise.dump_pose_chain(scenes.franka_p(obstacles=False), bodies[0])
+    assert h == h2 and np.array_equal(pi, pi2) and np.array_equal(pd, pd2)  # (obstacles are no part of the chain)
+    nb, nj, nq = (int(pi[k]) for k in (specialise.PH_NBODY, specialise.PH_NJOINT, specialise.PH_NQ))
+    assert (nj, nq) == (7, 9) and nb >= 8 and len(pd) == 7 * (nb + nj)
+    src = specialise.generate_pose(pi, pd, h, 0)
+    assert "struct PoseSpec0" in src and f"kNQ = {nq}, kNJ = {nj}" in src and f"{h:016x}" in src
+    assert src.count("// chain body") == nb and src.count("sincos_half(") == nj
+    m2 = scenes.franka_p(obstacles=True)
+    m2.body_pos[3, 2] += 1e-9  # one constant of the chain, far below anything a test would notice
+    assert specialise.dump_pose_chain(m2, bodies[0])[2] != h
+    u = scenes.ur5e()
+    assert specialise.dump_pose_chain(u, specialise.pose_site_bodies(u)[0])[2] != h
+    sec = specialise.generate_pose_section(m)
+    for sym in ("mjpl_spec_pose_count", "mjpl_spec_pose_hash", "mjpl_spec_launch_pose_apply", "mjpl_spec_launch_gen_project"):
+        assert sym in sec
+
+
 def test_program_hash_covers_the_float64_constants_and_the_shared_headers():
     """A specialised library carries its program's float64 constants as literals (the exact pair
     re-check, ExactSpec::fk_pair) and is built from the same headers as libmjpl_hip.so.  Two programs
