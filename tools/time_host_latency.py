@@ -11,8 +11,9 @@ e = engine.Engine(m); e.set_planning(qidx, m.keyframe("home").qpos.copy())
 out = {}
 for E in (1, 16, 64, 256, 1024, 4096, 65536, 262144):
     qa, qb = bench.make_edges(m, qidx, E, 2)
-    for _ in range(20):
+    for _ in range(20):  # (both entry points warmed: the first call of either allocates)
         e.check_edges(qa, qb, 0.01)
+        e.check_configs(qb)
     n = 300 if E <= 4096 else 30
     t0 = time.perf_counter()
     for _ in range(n):
