@@ -380,7 +380,7 @@ typedef struct mjpl_program_info {
    * such a library carries as literals -- moving bodies, their geoms and self pairs, planning set,
    * tolerance -- the number of cull rows per moving geom it reads from the engine's scene table, and
    * whether this program can run on one (<= scene_rows static geoms, <= 24 moving geoms numbered
-   * consecutively, no moving boxes) */
+   * consecutively; not the immediate interpreter's programs) */
   uint64_t robot_hash;
   int32_t scene_rows;
   int32_t scene_ok;

@@ -1134,7 +1134,8 @@ int compile_program(mjpl_engine *e) {
   e->moving_base = nm > 0 ? mgeoms[0] : 0;
   int nplanes = 0;
   for (int w = 0; w < nworld; w++) nplanes += (winfo[w] & 255) == GT_PLANE ? 1 : 0;
-  bool generic_ok = !e->exact_general() && e->filter_usable && nplanes <= kScenePlaneRows && nworld - nplanes <= kSceneRows - kScenePlaneRows &&
+  // (a robot with moving boxes, or 17 .. 24 stored geoms: the 24-slot queued build has generated code, too)
+  bool generic_ok = !e->immediate() && e->filter_usable && nplanes <= kScenePlaneRows && nworld - nplanes <= kSceneRows - kScenePlaneRows &&
                     nstage <= kSceneMaxStages && nstage > 0;
   for (int k = 1; k < nm && generic_ok; k++) generic_ok = mgeoms[k] == mgeoms[0] + k;  // (the pair re-check counts geoms from the first moving one)
   {
@@ -1246,7 +1247,9 @@ int compile_program(mjpl_engine *e) {
               // three fused multiply-adds on a centre within `reach`: each rounds by at most u (reach + |n . p0| + |bound|)
               row[3] = std::isfinite(reach) ? round_up(bound + off + 4.0 * u24 * (1.01 * reach + std::fabs(off) + std::fabs(bound)))
                                             : std::numeric_limits<float>::infinity();
-              desc = EK_PLANE | (w << 2) | (GT_PLANE << 10) | (1 << 14);
+              // (bit 15: the candidate goes to the box queue -- a static box, or ANY partner of a moving box, whose
+              //  records carry whole frames)
+              desc = EK_PLANE | (w << 2) | (GT_PLANE << 10) | (1 << 14) | ((gtype == GT_BOX && e->filter_mbox() ? 1 : 0) << 15);
             } else {
               const double nx = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
               for (int c = 0; c < 3; c++) row[c] = (float)(-2.0 * X[c]);
@@ -1257,7 +1260,8 @@ int compile_program(mjpl_engine *e) {
               if (!std::isfinite(bound)) row[3] = (float)bound;
               const int pgid = winfo[w] >> 8;
               const int pfirst = (ptype < gtype || (ptype == gtype && pgid < g)) ? 1 : 0;
-              desc = EK_STATIC | (w << 2) | (ptype << 10) | (pfirst << 14) | ((ptype == GT_BOX ? 1 : 0) << 15);
+              desc = EK_STATIC | (w << 2) | (ptype << 10) | (pfirst << 14) |
+                     (((ptype == GT_BOX || (gtype == GT_BOX && e->filter_mbox())) ? 1 : 0) << 15);
             }
             memcpy(dword, &desc, sizeof(float));
           }

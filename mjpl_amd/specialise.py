@@ -235,8 +235,6 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
     if info.immediate or not info.filter_usable:
         raise ValueError("this model runs the immediate interpreter / has no usable filter: nothing to specialise")
     mbox = bool(info.mbox)  # moving boxes: full frames in the box queue, two register slots per stored box
-    if mbox and generic:
-        raise ValueError("scene-generic libraries serve robots without moving boxes")
     g = _Gen(ip, fp, dp, info)
     w = g.w
     nbody = int(ip[H_NBODYOPS])

@@ -45,7 +45,13 @@ def generic_scenes():
             ("franka_p + 3 boxes + 3 spheres + 5 capsules, seed 2", scenes.franka_p_scene(3, 3, 2, n_capsules=5), 2),
             ("franka_p + 14 boxes + 12 spheres, seed 3 (30 static geoms)", scenes.franka_p_scene(14, 12, 3), 2),
             ("franka_p + a wall (two planes) + 4 boxes + 3 spheres, seed 5", _with_wall(scenes.random_obstacles(4, 3, 5)), 2),
-            ("franka_p + a wall (two planes) + 3 boxes, seed 6 (odd number of bounded rows)", _with_wall(scenes.random_obstacles(3, 0, 6)), 2)]
+            ("franka_p + a wall (two planes) + 3 boxes, seed 6 (odd number of bounded rows)", _with_wall(scenes.random_obstacles(3, 0, 6)), 2),
+            # ... and the robot WITH the Panda's ten finger-pad boxes (moving boxes): a second generic library
+            ("franka_p with pads + the 16 committed obstacles (has its own library)", scenes.franka_p(True, True), 1),
+            ("franka_p with pads alone (floor + base)", scenes.franka_p(False, True), 2),
+            ("franka_p with pads + 6 boxes + 4 spheres, seed 1", scenes.franka_p_builder(scenes.random_obstacles(6, 4, 1), pads=True).compile(), 2),
+            ("franka_p with pads + 2 boxes + 3 spheres + 4 capsules, seed 7",
+             scenes.franka_p_builder(scenes.random_obstacles(2, 3, 7, n_capsules=4), pads=True).compile(), 2)]
 
 
 def _with_wall(obstacles):
@@ -59,3 +65,9 @@ def generic_robot():
     """(model, allowed, planning indices, base) the generic library is generated from."""
     m = scenes.franka_p(obstacles=True)
     return m, (), scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos.copy()
+
+
+def generic_robots():
+    """Every robot __graft_entry__.build() makes a scene-generic library for: Franka-P, and Franka-P with the finger pads."""
+    mp = scenes.franka_p(True, True)
+    return [generic_robot(), (mp, (), scenes.planning_index(mp, scenes.FRANKA_ARM_JOINTS), mp.keyframe("home").qpos.copy())]
