@@ -844,10 +844,13 @@ def main():
     def start_of_timed_region():
         world.barrier()
         return time.perf_counter()
-    # EXACTLY args.steps launches, back to back on their engines' streams; every 16th one of an engine also carries
-    # one HIP event after each of its kernels (the per-kernel durations roofline.achieved uses; bracketing every 4th
-    # launch cost the one-stream line 2 % of its rate)
-    t0, timed_res = run_all(share, 16, start_of_timed_region)  # every call synchronises its stream
+    # EXACTLY args.steps launches, back to back on their engines' streams; one launch in `sample` of an engine also
+    # carries one HIP event after each of its kernels (the per-kernel durations roofline.achieved uses).  A bracketed
+    # launch costs ~56 us more than a plain one -- the events break the back-to-back submission: every 4th launch cost
+    # the one-stream line 2 % of its rate, every 16th still 1.8 % (0.1966 against 0.1931 ms per step without any,
+    # tools/time_fused.py) -- so about 32 launches of the region are bracketed, never more than one in 16.
+    sample = max(16, args.steps // 32)
+    t0, timed_res = run_all(share, sample, start_of_timed_region)  # every call synchronises its stream
     world.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = float(world.gather(elapsed).max())
@@ -928,7 +931,7 @@ def main():
                        "against ~22 600 flop"}
         roof = {"kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms if S == 1 else one_stream["step_ms_all_kernels"],
                 "kernels_ms": alone_ms, "kernel_samples": nsamp, "streams_of_these_durations": 1,
-                "kernel_ms_source": "HIP events on the engine's own stream around every kernel of every 16th launch, nothing else on the chip"
+                "kernel_ms_source": f"HIP events on the engine's own stream around every kernel of every {sample}th launch of the timed region, nothing else on the chip"
                                     + ("" if S == 1 else " (the one_stream run of this line; the timed region overlaps kernels of several engines)"),
                 "hbm": hbm}
         if prof.get("SQ_INSTS_VALU"):
