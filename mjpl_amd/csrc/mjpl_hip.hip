@@ -182,177 +182,7 @@ k_pose_valid(const int *__restrict__ pi, const double *__restrict__ pd, const do
 }
 
 
-// ---- row f3: batched IK seeds (the role of MinkIKSolver.solve_ik, mink_ik_solver.py:72-116) ----
-// One lane per seed: damped least squares on the 6-D world-frame pose error of the site,
-//   dq = J^T (J J^T + (damp + lm |e|^2) I)^-1 e,   |dq|_inf <= max_step,   q clamped to jnt_range,
-// joints outside the solver's joint set are held (their Jacobian columns are zero).  A seed is
-// solved when |e_pos| <= pos_tol and |e_ori| <= ori_tol (:100-102).
-__global__ void __launch_bounds__(kPoseBlock)
-k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Q,
-           int64_t N, double *__restrict__ Qout, uint8_t *__restrict__ ok, int32_t *__restrict__ iters,
-           double *__restrict__ err, int max_restarts, uint64_t restart_seed) {
-  extern __shared__ double smem[];
-  constexpr int B = kPoseBlock;
-  const int lane = threadIdx.x;
-  const int nq = pi[PH_NQ], nj = pi[PH_NJOINT], maxit = pi[PH_MAXIT];
-  const double *tail = pd + pi[PH_OFF_TAIL];
-  const double *jrange = pd + pi[PH_OFF_JRANGE];
-  const double *movable = jrange + 2 * nq;
-  double *qw = smem + lane;
-  double *jst = smem + (size_t)nq * B + lane;
-  const int64_t i = (int64_t)blockIdx.x * B + lane;
-  const bool active = i < N;
-  for (int k = 0; k < nq; k++) qw[k * B] = active ? Q[i * nq + k] : 0.0;
-  const double pos_tol = tail[IT_POS_TOL], ori_tol = tail[IT_ORI_TOL];
-  const double damp = tail[IT_DAMP], lm = tail[IT_LM], max_step = tail[IT_MAX_STEP];
-  bool done = !active, solved = false;
-  int it = 0;
-  double epos = 0, eori = 0;
-  // Levenberg-Marquardt flavour of the damping: the error-proportional term is scaled up when an
-  // iteration made the error grow and relaxed when it shrank; joints that sit on a limit and are
-  // pushed further out are taken out of the step (one re-solve), otherwise a clamped joint keeps
-  // absorbing the step every iteration and the seed stalls on the boundary.
-  double lam_scale = 1.0, prev_err2 = 1.0e300;
-  // A seed that has not improved its best error by 1 % for 12 iterations sits in a local minimum
-  // (in practice: on joint limits) and more iterations do not move it.  Like the reference, which
-  // re-draws the start with random_config when an attempt fails (mink_ik_solver.py:108-115), the
-  // row then restarts from a fresh uniform draw of the solver's joints -- inside its iteration
-  // budget, up to max_restarts times.
-  double best_err2 = 1.0e300;
-  int best_it = 0, restarts = 0;
-  const uint64_t rkey = rrt_key(restart_seed, (uint64_t)i, 0x494bull);
-  while (__ballot(!done) != 0ull) {
-    if (!done) {
-      PoseChainOut o;
-      pose_chain(pi, pd, qw, B, jst, B, o);
-      double e[6];
-      ik_error(tail, o, e);
-      epos = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-      eori = sqrt(e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
-      if (epos <= pos_tol && eori <= ori_tol) {
-        done = true; solved = true;
-      } else if (it >= maxit) {
-        done = true;
-      } else {
-        const double err2 = epos * epos + eori * eori;
-        if (err2 < 0.98 * best_err2) { best_err2 = err2; best_it = it; }
-        if (it - best_it >= 12 && restarts < max_restarts) {
-          restarts++;
-          int ic2 = PH_SIZE;
-          for (int b = 0; b < pi[PH_NBODY]; b++) {
-            const int njnt = pi[ic2++];
-            for (int j = 0; j < njnt; j++, ic2 += 3) {
-              const int qadr = pi[ic2 + 1], jid = pi[ic2 + 2];
-              if (movable[jid] != 0.0) {
-                const double u = rrt_u01(rkey, (uint64_t)restarts * 64u + (uint64_t)(jid & 63));
-                qw[qadr * B] = jrange[2 * jid] + u * (jrange[2 * jid + 1] - jrange[2 * jid]);
-              }
-            }
-          }
-          lam_scale = 1.0; prev_err2 = 1.0e300; best_err2 = 1.0e300; best_it = it;
-          it++;
-          continue;
-        }
-        lam_scale = err2 > prev_err2 ? fmin(lam_scale * 4.0, 1.0e4) : fmax(lam_scale * 0.5, 1.0 / 64.0);
-        prev_err2 = err2;
-        const double lam = (damp + lm * err2) * lam_scale;
-        // Jacobian columns of the chain joints -> rows 0..5 of the store (held joints: zero)
-        int ic = PH_SIZE, jk = 0;
-        for (int b = 0; b < pi[PH_NBODY]; b++) {
-          const int njnt = pi[ic++];
-          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
-            const int jtype = pi[ic], jid = pi[ic + 2];
-            const double mv = movable[jid];
-            const double ax[3] = {jst[(0 * nj + jk) * B], jst[(1 * nj + jk) * B], jst[(2 * nj + jk) * B]};
-            double col[6];
-            if (jtype == JT_HINGE) {
-              const double r[3] = {o.site_xpos[0] - jst[(3 * nj + jk) * B], o.site_xpos[1] - jst[(4 * nj + jk) * B],
-                                   o.site_xpos[2] - jst[(5 * nj + jk) * B]};
-              col[0] = mv * (ax[1] * r[2] - ax[2] * r[1]);
-              col[1] = mv * (ax[2] * r[0] - ax[0] * r[2]);
-              col[2] = mv * (ax[0] * r[1] - ax[1] * r[0]);
-              col[3] = mv * ax[0]; col[4] = mv * ax[1]; col[5] = mv * ax[2];
-            } else {
-              col[0] = mv * ax[0]; col[1] = mv * ax[1]; col[2] = mv * ax[2];
-              col[3] = 0; col[4] = 0; col[5] = 0;
-            }
-#pragma unroll
-            for (int r = 0; r < 6; r++) jst[(r * nj + jk) * B] = col[r];
-          }
-        }
-        unsigned locked = 0;
-        double scale = 1.0;
-        for (int pass = 0; pass < 2; pass++) {
-          double A[6][6];
-#pragma unroll
-          for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 6; c++) A[r][c] = (r == c) ? lam : 0.0;
-          for (int k = 0; k < nj; k++) {
-            if ((locked >> (k & 31)) & 1u) continue;
-            double col[6];
-#pragma unroll
-            for (int r = 0; r < 6; r++) col[r] = jst[(r * nj + k) * B];
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-              for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
-          }
-          double y[6];
-          chol6_solve(A, e, y);
-          // dq of chain joint k -> row 6 of the store; step length limit over the whole update
-          double big = 0;
-          for (int k = 0; k < nj; k++) {
-            double acc = 0;
-            if (!((locked >> (k & 31)) & 1u)) {
-#pragma unroll
-              for (int r = 0; r < 6; r++) acc = acc + jst[(r * nj + k) * B] * y[r];
-            }
-            jst[(6 * nj + k) * B] = acc;
-            big = fabs(acc) > big ? fabs(acc) : big;
-          }
-          scale = big > max_step ? max_step / big : 1.0;
-          if (pass == 1 || nj > 32) break;
-          unsigned out = 0;
-          ic = PH_SIZE; jk = 0;
-          for (int b = 0; b < pi[PH_NBODY]; b++) {
-            const int njnt = pi[ic++];
-            for (int j = 0; j < njnt; j++, jk++, ic += 3) {
-              const int qadr = pi[ic + 1], jid = pi[ic + 2];
-              const double dq = jst[(6 * nj + jk) * B], v = qw[qadr * B];
-              const double span = jrange[2 * jid + 1] - jrange[2 * jid];
-              const bool at_lo = v <= jrange[2 * jid] + 1e-9 * span, at_hi = v >= jrange[2 * jid + 1] - 1e-9 * span;
-              if (movable[jid] != 0.0 && ((at_lo && dq < 0) || (at_hi && dq > 0))) out |= 1u << (jk & 31);
-            }
-          }
-          if (out == 0) break;
-          locked = out;
-        }
-        ic = PH_SIZE; jk = 0;
-        for (int b = 0; b < pi[PH_NBODY]; b++) {
-          const int njnt = pi[ic++];
-          for (int j = 0; j < njnt; j++, jk++, ic += 3) {
-            const int qadr = pi[ic + 1], jid = pi[ic + 2];
-            double v = qw[qadr * B] + scale * jst[(6 * nj + jk) * B];
-            if (movable[jid] != 0.0) {
-              v = v < jrange[2 * jid] ? jrange[2 * jid] : v;
-              v = v > jrange[2 * jid + 1] ? jrange[2 * jid + 1] : v;
-              qw[qadr * B] = v;
-            }
-          }
-        }
-        it++;
-      }
-    }
-  }
-  if (active) {
-    for (int k = 0; k < nq; k++) Qout[i * nq + k] = qw[k * B];
-    ok[i] = solved ? 1 : 0;
-    if (iters) iters[i] = it;
-    if (err) { err[2 * i] = epos; err[2 * i + 1] = eori; }
-  }
-}
-
+// (k_ik_solve: mjpl_project.h -- interpreting, or around a model's generated chain)
 
 // ------------------------------------------------------------------------------- host model
 
@@ -395,10 +225,13 @@ struct SpecLib {
                              double *, uint8_t *, int32_t *);
   typedef int (*GenProjectFn)(int, hipStream_t, unsigned, size_t, int, int, int, double, const int *, const double *, const int *,
                               const double *, const uint8_t *, const double *, const double *, const double *, RrtLanes, RrtCand, int *);
+  typedef int (*IkSolveFn)(int, hipStream_t, unsigned, size_t, const int *, const double *, const double *, int64_t, double *, uint8_t *,
+                           int32_t *, double *, int, unsigned long long);
   int pose_count = 0;
   unsigned long long (*pose_hash)(int) = nullptr;
   PoseApplyFn pose_apply = nullptr;
   GenProjectFn gen_project = nullptr;
+  IkSolveFn ik_solve = nullptr;
   EndpointsPwFn endpoints_pw = nullptr;
   ItemsPwFn items_pw = nullptr;
   TailFn tail = nullptr;
@@ -595,8 +428,9 @@ const SpecLib *find_spec(uint64_t hash, bool generic) {
     sl.pose_hash = (unsigned long long (*)(int))dlsym(lib, "mjpl_spec_pose_hash");
     sl.pose_apply = (SpecLib::PoseApplyFn)dlsym(lib, "mjpl_spec_launch_pose_apply");
     sl.gen_project = (SpecLib::GenProjectFn)dlsym(lib, "mjpl_spec_launch_gen_project");
+    sl.ik_solve = (SpecLib::IkSolveFn)dlsym(lib, "mjpl_spec_launch_ik_solve");
     if (auto pc = (int (*)())dlsym(lib, "mjpl_spec_pose_count"))
-      sl.pose_count = (sl.pose_hash && sl.pose_apply && sl.gen_project) ? pc() : 0;
+      sl.pose_count = (sl.pose_hash && sl.pose_apply && sl.gen_project && sl.ik_solve) ? pc() : 0;
     // (the stamp: both libraries built from the same mjpl_filter.h / mjpl_device.h / mjpl_trig.h -- the
     // structs that cross this boundary by value and the table layouts live there)
     const int g = gen ? gen() : 0;
@@ -3070,6 +2904,16 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, i
   int nj = 0;
   int rc = build_chain(m, d->site_body, pi, pd, &nj);
   if (rc != MJPL_OK) return rc;
+  // the chain as straight-line code, if the engine's library has it (same results; MJPL_POSE_SPEC=0: interpreted)
+  int spec_k = -1;
+  {
+    const char *f = getenv("MJPL_POSE_SPEC");
+    if (e->spec && e->spec->pose_count > 0 && !(f && atoi(f) == 0)) {
+      const uint64_t h = chain_hash_of(pi, pd, pd.size());
+      for (int k = 0; k < e->spec->pose_count && spec_k < 0; k++)
+        if (e->spec->pose_hash(k) == h) spec_k = k;
+    }
+  }
   pi[PH_MAXIT] = d->iterations;
   pi[PH_OFF_TAIL] = (int)pd.size();
   pd.resize(pd.size() + IT_SIZE);
@@ -3096,7 +2940,13 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, i
   HIP_TRY(hipMemcpy(d_pi, pi.data(), ib, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_pd, pd.data(), db, hipMemcpyHostToDevice));
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
-  hipLaunchKernelGGL(k_ik_solve, dim3(grid), dim3(kPoseBlock), lds, e->stream, d_pi, d_pd, dQ, N, dQout, dok,
+  if (spec_k >= 0) {
+    if (e->spec->ik_solve(spec_k, e->stream, grid, lds, d_pi, d_pd, dQ, N, dQout, dok, diters, derr, d->restarts > 0 ? d->restarts : 0,
+                          (unsigned long long)d->restart_seed) != 0)
+      return fail(MJPL_E_HIP, "generated IK kernel failed to launch");
+    return MJPL_OK;
+  }
+  hipLaunchKernelGGL(k_ik_solve<void>, dim3(grid), dim3(kPoseBlock), lds, e->stream, d_pi, d_pd, dQ, N, dQout, dok,
                      diters, derr, d->restarts > 0 ? d->restarts : 0, (uint64_t)d->restart_seed);
   HIP_TRY(hipGetLastError());
   return MJPL_OK;

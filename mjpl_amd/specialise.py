@@ -1008,7 +1008,7 @@ def generate_pose(pi, pd, hash_: int, index: int) -> str:
 
     def arr(v):
         return "{" + ", ".join(dlit(x) for x in v) + "}"
-    jtypes, qadrs = [], []
+    jtypes, qadrs, jids = [], [], []
     body = []
     b_ = body.append
     ic, dc, jk = PH_SIZE, 0, 0
@@ -1022,8 +1022,8 @@ def generate_pose(pi, pd, hash_: int, index: int) -> str:
         b_("        np[0] += p[0]; np[1] += p[1]; np[2] += p[2];")
         b_("        mul_quat(nq, qt, bquat); }")
         for j in range(njnt):
-            jtype, qadr = int(pi[ic]), int(pi[ic + 1]); ic += 3
-            jtypes.append(jtype); qadrs.append(qadr)
+            jtype, qadr, jid = int(pi[ic]), int(pi[ic + 1]), int(pi[ic + 2]); ic += 3
+            jtypes.append(jtype); qadrs.append(qadr); jids.append(jid)
             b_(f"      {{ const double jaxis[3] = {arr(pd[dc:dc + 3])}, jpos[3] = {arr(pd[dc + 3:dc + 6])};")
             b_(f"        const double dq = q[{qadr}] - {dlit(pd[dc + 6])};")
             dc += 7
@@ -1055,6 +1055,7 @@ def generate_pose(pi, pd, hash_: int, index: int) -> str:
     o(f"  static constexpr unsigned long long kHash = 0x{hash_:016x}ull;")
     o(f"  static __device__ __forceinline__ constexpr int jtype(int k) {{ constexpr int t[{max(nj, 1)}] = {{{', '.join(str(x) for x in jtypes) or '0'}}}; return t[k]; }}")
     o(f"  static __device__ __forceinline__ constexpr int qadr(int k) {{ constexpr int t[{max(nj, 1)}] = {{{', '.join(str(x) for x in qadrs) or '0'}}}; return t[k]; }}")
+    o(f"  static __device__ __forceinline__ constexpr int jid(int k) {{ constexpr int t[{max(nj, 1)}] = {{{', '.join(str(x) for x in jids) or '0'}}}; return t[k]; }}")
     o(f"  static __device__ __forceinline__ void chain(const double (&q)[{nq}], double (&jx)[{max(nj, 1)}][6], mjpl::PoseChainOut &out,")
     o("                                               const double *tail) {")
     o("    using namespace mjpl;")
@@ -1094,6 +1095,11 @@ def generate_pose_section(model) -> str:
             "                                 const double *pd, const int *qidx, const double *qbase, const uint8_t *isplan, const double *lo,",
             "                                 const double *hi, const double *Tgt, mjpl::RrtLanes ln, mjpl::RrtCand cd, int *ctr) {", "  switch (k) {"]
     src += [f"    case {k}: hipLaunchKernelGGL(mjpl::k_rrt_gen_project<PoseSpec{k}>, dim3(grid), dim3(mjpl::kPoseBlock), lds, st, L, nplan, S, eps, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr); break;"
+            for k, _, _ in specs]
+    src += ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -1;", "}"]
+    src += ["int mjpl_spec_launch_ik_solve(int k, hipStream_t st, unsigned grid, size_t lds, const int *pi, const double *pd, const double *Q, int64_t N,",
+            "                               double *Qout, uint8_t *ok, int32_t *iters, double *err, int max_restarts, unsigned long long restart_seed) {", "  switch (k) {"]
+    src += [f"    case {k}: hipLaunchKernelGGL(mjpl::k_ik_solve<PoseSpec{k}>, dim3(grid), dim3(mjpl::kPoseBlock), lds, st, pi, pd, Q, N, Qout, ok, iters, err, max_restarts, (uint64_t)restart_seed); break;"
             for k, _, _ in specs]
     src += ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -1;", "}", "}"]
     return "\n".join(src) + "\n"

@@ -201,3 +201,35 @@ def test_restarts_lift_convergence_and_match_the_cpu_statement(oracle_mod):
     _, okc, _, errc = oracle_mod.ik_solve_batch(m, *args, iterations=200, restarts=8, restart_seed=11, nthreads=8)
     assert abs(okc.mean() - ok8.mean()) < 0.03
     assert (okc == ok8).mean() > 0.9  # row by row they mostly agree (not bit for bit: another sin/cos)
+
+
+def test_generated_chain_gives_the_interpreting_kernels_iterates_bit_for_bit(monkeypatch):
+    """Franka-P's library carries the chain to the site's body as straight-line code (mjpl_project.h: IkStatic):
+    the same iteration statement for statement -- every seed's final configuration, verdict, iteration count and
+    error norms equal those of the interpreting kernel (MJPL_POSE_SPEC=0) bit for bit, restarts included."""
+    import mjpl_amd as mjpl
+    from mjpl_amd import scenes
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    q_home = m.keyframe("home").qpos.copy()
+    results = {}
+    for tag, env in (("generated", None), ("interpreting", "0")):
+        monkeypatch.delenv("MJPL_POSE_SPEC", raising=False)
+        if env is not None:
+            monkeypatch.setenv("MJPL_POSE_SPEC", env)
+        cc = mjpl.CollisionConstraint(m)
+        assert cc.engine.spec_kind() == 1  # (all nine joints planned from qpos0: tests/spec_models.py has that library, chain included)
+        solver = mjpl.HipIKSolver(m, joints, [], seed=3, num_seeds=4096, iterations=200, engine=cc.engine)
+        q_t = mjpl.random_config(m, q_home, joints, 5, [mjpl.JointLimitConstraint(m), cc])
+        target = mjpl.site_pose(m, q_t, "ee_site", engine=cc.engine)
+        Q0 = solver._seeds(q_home, np.random.default_rng(3))
+        args = ("ee_site", target.translation(), target.rotation().wxyz, Q0, solver.movable)
+        results[tag] = cc.engine.ik_solve(*args, iterations=200, restarts=8, restart_seed=11)
+        cc.engine.close()
+    monkeypatch.delenv("MJPL_POSE_SPEC", raising=False)
+    (q0, ok0, it0, e0), (q1, ok1, it1, e1) = results["generated"], results["interpreting"]
+    assert ok0.mean() > 0.9 and it0.max() > 50
+    np.testing.assert_array_equal(ok0, ok1)
+    np.testing.assert_array_equal(it0, it1)
+    np.testing.assert_array_equal(np.ascontiguousarray(q0).view(np.uint64), np.ascontiguousarray(q1).view(np.uint64))
+    np.testing.assert_array_equal(np.ascontiguousarray(e0).view(np.uint64), np.ascontiguousarray(e1).view(np.uint64))
