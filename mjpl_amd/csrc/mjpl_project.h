@@ -307,14 +307,17 @@ k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const do
 // few lanes are left and a chunk costs the latency of its kernels whatever it holds.
 // Every emitting lane owns S slots: those behind its last candidate carry a zero-length edge nobody reads.
 // One workgroup of 64 lanes; LDS per lane: qw[nq] | jst[6 * njoint] | qo[nq].
-template <class PS = void>
+// NP > 0: the number of planning joints is a constant of the instantiation (a per-model library knows its program's):
+// the target / current / candidate rows of a lane are registers then, not scratch.
+template <class PS = void, int NP = 0>
 __global__ void __launch_bounds__(kPoseBlock)
-k_rrt_gen_project(int L, int nplan, int S, double eps, const int *__restrict__ pi, const double *__restrict__ pd,
+k_rrt_gen_project(int L, int nplan_arg, int S, double eps, const int *__restrict__ pi, const double *__restrict__ pd,
                   const int *__restrict__ qidx, const double *__restrict__ qbase, const uint8_t *__restrict__ isplan,
                   const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln,
                   RrtCand cd, int *__restrict__ ctr) {
   extern __shared__ double smem[];
   constexpr int B = kPoseBlock;
+  const int nplan = NP > 0 ? NP : nplan_arg;
   const int lane = threadIdx.x;
   const int l = blockIdx.x * B + lane;
   const int nq = pi[PH_NQ], nj = pi[PH_NJOINT];

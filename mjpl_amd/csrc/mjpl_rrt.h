@@ -438,8 +438,11 @@ struct mjpl_rrt {
   int pendcap = 0;
   // projecting extensions: most steps a lane takes per chunk, and the candidate slots a chunk is sized for
   // (S = min(proj_steps_max, proj_slots / active lanes); MJPL_RRT_PROJ_STEPS / MJPL_RRT_PROJ_SLOTS)
-  int proj_steps_max = 64;
-  int64_t proj_slots = 65536;
+  // (round 4, with the chain as generated code a step is cheap enough for the chunk's fixed cost to show: 64 / 65 536 ->
+  //  65.2 ms per 131 072-lane round, 256 / 262 144 -> 62.6, 1 024 / 1 048 576 -> 59.8; the slots are bounded by the
+  //  candidate buffer, 4 L, all the same)
+  int proj_steps_max = 1024;
+  int64_t proj_slots = 1 << 20;
   int *d_ctr = nullptr, *h_ctr = nullptr;
   // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned copies
   int *h_ring = nullptr;      // 4 slots of kRingStride ints: RC_SIZE counters, then the sequence word
@@ -555,11 +558,9 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
         const unsigned pgrid = (unsigned)((L + kPoseBlock - 1) / kPoseBlock);
         const size_t plds = pose_lds(r->pose) + (size_t)kPoseBlock * sizeof(double) * (size_t)r->nq;
         const int pk = pose_spec_index(r->pose);  // (the chain as straight-line code, if the engine's library has it)
-        if (pk >= 0) {
-          if (e->spec->gen_project(pk, st, pgrid, plds, L, nplan, S, r->eps, r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase,
-                                   r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr) != 0)
-            return fail(MJPL_E_HIP, "generated projection kernel failed to launch");
-        } else {
+        // (a library refuses -- nothing launched -- when it was built for another number of planning joints)
+        if (pk < 0 || e->spec->gen_project(pk, st, pgrid, plds, L, nplan, S, r->eps, r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase,
+                                           r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr) != 0) {
           hipLaunchKernelGGL(k_rrt_gen_project<void>, dim3(pgrid), dim3(kPoseBlock), plds, st, L, nplan, S, r->eps, r->pose->d_pi,
                              r->pose->d_pd, r->d_qidx, r->d_qbase, r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
         }

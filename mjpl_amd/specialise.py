@@ -1073,8 +1073,10 @@ def generate_pose(pi, pd, hash_: int, index: int) -> str:
     return "\n".join(out) + "\n"
 
 
-def generate_pose_section(model) -> str:
-    """All generated projections of a model and the entry points a library exports for them."""
+def generate_pose_section(model, nplan: int = 0) -> str:
+    """All generated projections of a model and the entry points a library exports for them.  nplan: the number of
+    planning joints of the program the library is built for (the planner's chunk kernel keeps a lane's rows in
+    registers when it is a constant; 0: unknown)."""
     specs = []
     for k, b in enumerate(pose_site_bodies(model)):
         pi, pd, h = dump_pose_chain(model, b)
@@ -1094,7 +1096,11 @@ def generate_pose_section(model) -> str:
     src += ["int mjpl_spec_launch_gen_project(int k, hipStream_t st, unsigned grid, size_t lds, int L, int nplan, int S, double eps, const int *pi,",
             "                                 const double *pd, const int *qidx, const double *qbase, const uint8_t *isplan, const double *lo,",
             "                                 const double *hi, const double *Tgt, mjpl::RrtLanes ln, mjpl::RrtCand cd, int *ctr) {", "  switch (k) {"]
-    src += [f"    case {k}: hipLaunchKernelGGL(mjpl::k_rrt_gen_project<PoseSpec{k}>, dim3(grid), dim3(mjpl::kPoseBlock), lds, st, L, nplan, S, eps, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr); break;"
+    np_ = int(nplan) if 0 < int(nplan) <= 16 else 0
+    if np_:
+        src += [f"  if (nplan != {np_}) return -1;  // (the library's program plans {np_} joints)"]
+        src[-1], src[-2] = src[-2], src[-1]  # (the check goes in front of the switch)
+    src += [f"    case {k}: hipLaunchKernelGGL((mjpl::k_rrt_gen_project<PoseSpec{k}, {np_}>), dim3(grid), dim3(mjpl::kPoseBlock), lds, st, L, nplan, S, eps, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr); break;"
             for k, _, _ in specs]
     src += ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -1;", "}"]
     src += ["int mjpl_spec_launch_ik_solve(int k, hipStream_t st, unsigned grid, size_t lds, const int *pi, const double *pd, const double *Q, int64_t N,",
@@ -1155,7 +1161,7 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
             nstage += ng
     src = translation_unit(generate(ip, fp, dp, info, generic=generic), generate_exact(ip, dp, info, generic=generic), key, info,
                            (SCENE_ROWS << 8 | nstage) if generic else 0,  # (kSceneRows, moving geoms)
-                           pose=generate_pose_section(model))
+                           pose=generate_pose_section(model, int(ip[H_NPLAN])))
     # Source and library appear under their final names complete or not at all (os.replace): an engine created
     # while a rebuild is running finds the old library or the new one, never half a file -- a failed dlopen would
     # be remembered as "no library" for the life of that process -- and two builds of one hash cannot interleave.
