@@ -100,9 +100,13 @@ k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLane
 // from C towards its target and emits the candidate edges (w -> q) it would like validated.  The
 // candidates do not depend on the verdicts, so S may exceed 1; the rule checks (joint limits, moved,
 // not farther) are made here.  (k_rrt_gen_project below: the same with a PoseConstraint.)
+template <int NP>
 __global__ void __launch_bounds__(256)
-k_rrt_gen(int L, int nplan, int S, double eps, const double *__restrict__ lo,
+k_rrt_gen(int L, int nplan_arg, int S, double eps, const double *__restrict__ lo,
           const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln, RrtCand cd, int *__restrict__ ctr) {
+  // (NP: the number of planning joints as a constant of the instantiation -- the rows below are registers then; with a
+  //  run-time count they live in scratch, and a chunk of 512 lanes took 125 us instead of 50)
+  const int nplan = NP > 0 ? NP : nplan_arg;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool act = l < L && ln.act[l] != 0;
@@ -572,7 +576,17 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
         active_bound = r->h_ctr[RC_ACTIVE];
       }
     } else {
-      hipLaunchKernelGGL(k_rrt_gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+      {
+        auto gen = k_rrt_gen<0>;
+        switch (nplan) {  // (the usual planning sets: their rows in registers)
+#define MJPL_GEN_CASE(n) case n: gen = k_rrt_gen<n>; break;
+          MJPL_GEN_CASE(1) MJPL_GEN_CASE(2) MJPL_GEN_CASE(3) MJPL_GEN_CASE(4) MJPL_GEN_CASE(5) MJPL_GEN_CASE(6) MJPL_GEN_CASE(7)
+          MJPL_GEN_CASE(8) MJPL_GEN_CASE(9) MJPL_GEN_CASE(10) MJPL_GEN_CASE(12)
+#undef MJPL_GEN_CASE
+          default: break;
+        }
+        hipLaunchKernelGGL(gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+      }
       if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
       if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
       if (r->h_ctr[RC_ACTIVE] == 0) {
