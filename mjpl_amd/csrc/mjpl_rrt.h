@@ -213,32 +213,61 @@ k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restr
   }
   // ... and clear them for the next chunk instead of two fills
   if (l == 0) { ctr[RC_EDGES] = 0; ctr[RC_ACTIVE] = 0; }
-  if (l >= L || !ln.act[l]) return;
-  const int n = ln.gcount[l];
-  if (n == 0) return;  // waiting for candidate space
-  const int f = ln.gfirst[l];
+  // (every lane of the wave stays to the end: the accepted rows are copied by the whole wave)
+  const bool live = l < L && ln.act[l] != 0;
+  const int n = live ? ln.gcount[l] : 0;  // (0: waiting for candidate space, or not in this extension)
+  const int f = n > 0 ? ln.gfirst[l] : 0;
+  // the leading candidates that are valid and passed the rules -- their flags fetched sixteen at a time: a chunk may
+  // hold a thousand steps of a lane
   int a = 0;
   bool arrived = false;
-  while (a < n && cd.valid[f + a] && cd.rule[f + a]) {
-    arrived = cd.reach[f + a] != 0;
-    a++;
+  for (bool more = true; more && a < n;) {
+    const int m = n - a < 16 ? n - a : 16;
+    uint8_t fv[16], fr[16], fc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int at = f + a + (k < m ? k : 0);
+      fv[k] = cd.valid[at]; fr[k] = cd.rule[at]; fc[k] = cd.reach[at];
+    }
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const bool good = j < m && fv[j] && fr[j];
+      if (more && good) { arrived = fc[j] != 0; k++; }
+      else more = more && good;  // (the first that is not: everything behind it is ignored)
+    }
+    a += k;
+    more = more && k == m;
   }
-  if (a > 0) {
-    const int at = atomicAdd(&ctr[RC_ACC], a);
+  int at = 0, lvl0 = 0;
+  bool keep = a > 0;
+  if (keep) {
+    at = atomicAdd(&ctr[RC_ACC], a);
     if (at + a > acc.cap) {
       atomicOr(&ctr[RC_OVERFLOW], 2);
       ln.act[l] = 0;
-      return;
+      keep = false;
+    } else {
+      lvl0 = ln.cnt[l];
     }
-    const int lvl0 = ln.cnt[l];
-    for (int s = 0; s < a; s++) {
-      for (int c = 0; c < nplan; c++) acc.Q[(int64_t)(at + s) * nplan + c] = cd.B[(int64_t)(f + s) * nplan + c];
-      acc.lane[at + s] = l;
-      acc.level[at + s] = lvl0 + s;
-    }
+  }
+  // The accepted rows of a lane are contiguous on both sides (slots f .. f + a of the candidates, at .. at + a of the
+  // accepted nodes): the wave copies them lane by lane, 64 elements at a time -- one lane copying a thousand rows of its
+  // own, element after element, was a millisecond.
+  const int wl = (int)(threadIdx.x & 63);
+  for (unsigned long long todo = __ballot(keep); todo; todo &= todo - 1) {
+    const int j = (int)__builtin_ctzll(todo);
+    const int fj = __shfl(f, j), atj = __shfl(at, j), aj = __shfl(a, j), lj = __shfl(l, j), vj = __shfl(lvl0, j);
+    const long long src = (long long)fj * nplan, dst = (long long)atj * nplan;
+    for (int k = wl; k < aj * nplan; k += 64) acc.Q[dst + k] = cd.B[src + k];
+    for (int k = wl; k < aj; k += 64) { acc.lane[atj + k] = lj; acc.level[atj + k] = vj + k; }
+  }
+  if (!live || n == 0) return;
+  if (keep) {
     for (int c = 0; c < nplan; c++) ln.C[(int64_t)c * L + l] = cd.B[(int64_t)(f + a - 1) * nplan + c];
     ln.cnt[l] = lvl0 + a;
   }
+  if (a > 0 && !keep) return;  // (out of room for accepted nodes: the lane was stopped above)
   if (a < n || ln.gend[l] || arrived) ln.act[l] = 0;
 }
 
