@@ -579,7 +579,7 @@ def bench_rrt(args, world):
         round_s = slowest / done
         roofline = {"bound": "hbm", "achieved": round_bytes / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round_bytes / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "whole round (k_rrt_gen_project holds ~80 % of its GPU time)",
+                    "kernel": "whole round (k_rrt_gen_project holds ~70 % of its GPU time: profiles/r04h_rrt_kernel_stats.csv)",
                     "kernel_ms": round_s * 1e3, "algorithmic_bytes_per_round": round_bytes,
                     "of_which_nearest_neighbour_scans": nn_bytes,
                     "note": "latency bound: one lane's float64 Newton chain per projection step (DESIGN.md section 7); the HBM figure is "
