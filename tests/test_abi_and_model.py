@@ -165,6 +165,18 @@ def test_program_dump_and_code_generation_need_no_gpu():
                  2 * src.count("MJPL_SPEC_CULL2(") + src.count("MJPL_SPEC_SLOTCULL(") + src.count("MJPL_SPEC_HIT("))
         assert culls >= 10
         assert "struct Spec" in src and f"{info.hash:016x}" in src
+        if info.mbox:
+            # moving boxes: the slot file is plain scalars (a literal index everywhere), whole frames go through the box
+            # queue, and boxes of one body with one orientation keep their x / y axes once
+            assert "struct SpecSlots" in src and "SlotFile<float" not in src
+            assert "queue_push<float, true, true>" in src and "cur6b, t6b" in src
+            nbox = int(((m.geom_type == 6) & (m.geom_bodyid > 0)).sum())
+            stored_axes = src.count(", cur6b); break;")
+            assert 0 < stored_axes <= nbox
+            if "pad" in name:
+                assert stored_axes == 3  # (five pads per finger, three distinct orientations among the stored finger's)
+            gsrc = specialise.generate(ip, fp, dp, info, generic=True) if info.scene_ok else None
+            assert gsrc is None or ("struct SpecSlots" in gsrc and "MJPL_SCENE_PAIR" in gsrc)
     # sixteen moving boxes in a chain, 28 slots to hold at once: beyond the 24 of the queued kernels -- the immediate
     # interpreter, nothing to specialise
     from mjpl_amd.model import ModelBuilder
