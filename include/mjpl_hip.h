@@ -108,9 +108,9 @@ typedef struct mjpl_info {
   float   filter_err_b;
   int32_t filter_poisoned_geoms; /* static geoms too large / far for binary32: always re-checked */
   /* which float32 interpreter this model runs: 0 = queued narrowphase, small builds (no moving
-   * boxes, <= 16 stored geoms; the only one a specialised library can replace); 1 = queued, the
-   * general 24-slot build with moving boxes in the box queue; 2 = immediate narrowphase (more
-   * than 24 stored geoms, or MJPL_FORCE_IMMEDIATE=1 at creation: tests) */
+   * boxes, <= 16 stored geoms); 1 = queued, the general 24-slot build with moving boxes in the
+   * box queue; 2 = immediate narrowphase (more than 24 stored geoms, or MJPL_FORCE_IMMEDIATE=1
+   * at creation: tests).  A specialised library can replace 0 and 1 (mjpl_spec_loaded), not 2. */
   int32_t filter_interpreter;
   /* how an edge launch is laid out on the device (defaults; MJPL_PERSIST / MJPL_TAIL at creation):
    * persistent_kernels = 1: endpoint and item kernels run as persistent grids of waves with tile queues;
@@ -249,7 +249,7 @@ void *mjpl_stream(mjpl_engine *e);
                                   * k_edges_fused, the whole float32 filter of the launch (stage 1 is then empty) */
 #define MJPL_STAGE_ITEMS     1  /* k_filter_items                                          */
 #define MJPL_STAGE_WALK      2  /* k_filter_edges                                          */
-#define MJPL_STAGE_PATCH     3  /* k_patch_pairs (moving boxes: k_check_configs, patch mode); with mjpl_info.fused_tail:
+#define MJPL_STAGE_PATCH     3  /* k_patch_pairs (immediate interpreter: k_check_configs, patch mode); with mjpl_info.fused_tail:
                                   * k_tail, the one launch that holds the walking, pair and exact-edge roles (stages
                                   * 2 and 4 are then empty) */
 #define MJPL_STAGE_EXACT     4  /* k_check_edges                                           */
@@ -371,7 +371,7 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *desc, const double *dQ
 typedef struct mjpl_program_info {
   uint64_t hash;            /* FNV-1a of (ip, fp, dp, kernel variant, MJPL_SPEC_ABI, digest of the shared headers) */
   int32_t maxs, wbox, mbox; /* kernel variant: slot-file width, static / moving boxes present */
-  int32_t immediate;        /* 1: the model runs the immediate interpreter (not specialisable yet) */
+  int32_t immediate;        /* 1: the model runs the immediate interpreter (more than 24 stored geoms: not specialisable) */
   int32_t filter_usable;
   float   filter_tol;
   int32_t nslots, nsave;
