@@ -24,6 +24,10 @@ def spec_models():
                 mp.keyframe("home").qpos.copy()))
     u = scenes.ur5e()
     out.append(("ur5e_c", u, (), np.arange(u.nq, dtype=np.int32), np.asarray(u.qpos0, float).copy()))
+    # the reference's KAT model (test/models/two_dof_ball.xml): two SLIDE joints under a site -- the slide branch of the
+    # generated PoseConstraint chain (tests/test_gpu_pose.py: test_translation_limit_kat_on_gpu)
+    tb = scenes.two_dof_ball()
+    out.append(("two_dof_ball", tb, (), np.arange(tb.nq, dtype=np.int32), np.asarray(tb.qpos0, float).copy()))
     from test_gpu_models import random_model
     for seed in (1002, 1005):  # seeded random trees with slides, off-centre hinges, branching, static boxes
         rm, allowed = random_model(seed, moving_boxes=False)

@@ -11,10 +11,23 @@ pytestmark = pytest.mark.gpu
 INF = (-np.inf, np.inf)
 
 
-def test_translation_limit_kat_on_gpu():
+def test_translation_limit_kat_on_gpu(monkeypatch):
     m = scenes.two_dof_ball()
     home = mjpl.site_pose(m, np.zeros(2), "ball_site")
     pc = mjpl.PoseConstraint(m, "ball_site", home, x_translation=(-0.1, 0.1), q_step=np.inf)
+    # (the model's library carries its chain -- two slide joints -- as straight-line code; the interpreting kernel
+    #  must give the same projection bit for bit)
+    assert pc._proj.spec_loaded()
+    monkeypatch.setenv("MJPL_POSE_SPEC", "0")
+    pi = mjpl.PoseConstraint(m, "ball_site", home, x_translation=(-0.1, 0.1), q_step=np.inf, engine=pc.engine)
+    monkeypatch.delenv("MJPL_POSE_SPEC")
+    assert not pi._proj.spec_loaded()
+    rng = np.random.default_rng(2)
+    Q = rng.uniform(-0.5, 0.5, size=(4096, 2))
+    a, b = pc.apply_batch(np.zeros_like(Q), Q), pi.apply_batch(np.zeros_like(Q), Q)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
+    assert a[1].all() and (np.abs(a[0][:, 0]) <= 0.1 + 1e-3).all()
     q = np.array([0.2, 0.0])
     assert not pc.valid_config(q)
     qc = pc.apply(np.array([0.0, 0.0]), q)
