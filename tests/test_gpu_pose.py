@@ -28,6 +28,16 @@ def test_translation_limit_kat_on_gpu(monkeypatch):
     for x, y in zip(a, b):
         np.testing.assert_array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
     assert a[1].all() and (np.abs(a[0][:, 0]) <= 0.1 + 1e-3).all()
+    # ... and the IK iteration around the same chain (IkStatic, slide columns)
+    movable = np.ones(m.njnt, np.uint8)
+    args = ("ball_site", home.translation() + np.array([0.15, -0.2, 0.0]), home.rotation().wxyz, Q[:1024], movable)
+    ik_gen = pc.engine.ik_solve(*args, iterations=100)
+    monkeypatch.setenv("MJPL_POSE_SPEC", "0")
+    ik_int = pc.engine.ik_solve(*args, iterations=100)
+    monkeypatch.delenv("MJPL_POSE_SPEC")
+    for x, y in zip(ik_gen, ik_int):
+        np.testing.assert_array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
+    assert ik_gen[1].mean() > 0.9
     q = np.array([0.2, 0.0])
     assert not pc.valid_config(q)
     qc = pc.apply(np.array([0.0, 0.0]), q)
