@@ -1,6 +1,6 @@
 // mjpl_project.h -- the PoseConstraint projection (pose_constraint.py:72-171) as device code shared by libmjpl_hip.so
-// and the per-model libraries: one lane's Newton iteration, the batched kernel around it (row f1) and the planner's
-// chunk of projected extension steps (row e).  Everything is a template over a pose spec `PS`: void = the
+// and the per-model libraries: one lane's Newton iteration, the batched kernel around it (row f1), the planner's
+// chunk of projected extension steps (row e) and the batched IK seeds (row f3).  Everything is a template over a pose spec `PS`: void = the
 // interpreting statement (the chain program of mjpl_pose.h read from memory), else a generated struct whose `chain`
 // is the same statements for ONE (model, site body) as straight-line code (mjpl_amd/specialise.py: generate_pose).
 // Structs that cross the library boundary by value live here: this header is part of the source stamp.
@@ -55,7 +55,7 @@ constexpr double kPoseMaxCond = 1e6;  // (see k_pose_apply: fast path of the 6x6
 // Returns 1: within tolerance, 0: left the joint limits or went farther than 2 q_step from q_old, 2: iteration
 // bound; *iters counts the Newton steps taken.
 // PS: void = the chain program in (pi, pd) is interpreted; else PS::chain is that chain as straight-line code
-// (pose_project_static below: the same statements in the same order, so the same float64 values).
+// (PoseStatic<PS>::project below: the same statements in the same order, so the same float64 values).
 template <class PS> struct PoseStatic;
 
 template <class PS = void>
