@@ -233,3 +233,29 @@ def test_generated_chain_gives_the_interpreting_kernels_iterates_bit_for_bit(mon
     np.testing.assert_array_equal(it0, it1)
     np.testing.assert_array_equal(np.ascontiguousarray(q0).view(np.uint64), np.ascontiguousarray(q1).view(np.uint64))
     np.testing.assert_array_equal(np.ascontiguousarray(e0).view(np.uint64), np.ascontiguousarray(e1).view(np.uint64))
+
+
+def test_quick_first_pass_returns_valid_solutions_and_falls_back(oracle_mod):
+    """An attempt first runs its seeds for `quick_iterations` and spends the whole budget only if none came back valid
+    (a launch lasts as long as its slowest seed).  Both ways the solutions meet the pose tolerances and the
+    constraints; with a first pass too short for any seed to converge the whole budget still finds them."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    q_home = m.keyframe("home").qpos.copy()
+    cc = mjpl.CollisionConstraint(m)
+    cons = [mjpl.JointLimitConstraint(m), cc]
+    q_t = mjpl.random_config(m, q_home, joints, 5, cons)
+    target = mjpl.site_pose(m, q_t, "ee_site", engine=cc.engine)
+    got = {}
+    for quick in (64, 0, 2):
+        solver = mjpl.HipIKSolver(m, joints, cons, seed=3, max_attempts=2, iterations=300, engine=cc.engine, quick_iterations=quick)
+        sols = solver.solve_ik(target, "ee_site", q_init_guess=q_home)
+        assert sols, quick
+        for q in sols[:8]:
+            assert mjpl.obeys_constraints(q, cons)
+            e_pos, e_ori = _pose_error(oracle_mod, m, "ee_site", q, target)
+            assert e_pos <= 1e-3 and e_ori <= 1e-3
+        got[quick] = (len(sols), solver.stats["mean_iters"])
+    # (two iterations converge nothing: that attempt went on to the whole budget and found what quick = 0 finds)
+    assert got[2][0] == got[0][0]
+    assert got[64][0] >= 1 and got[64][1] <= 64
