@@ -41,6 +41,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles on a SIMD-32,
 # 4 SIMDs per CU, 256 CUs, 2.4 GHz max clock -> wave-instructions per second the chip can issue
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+CLOCK_WARM_STEPS = 300       # untimed launches before anything is measured (~60 ms: the clocks)
+SHORT_REGION_STEPS = 64      # a timed region shorter than this carries no HIP events (they come from untimed launches)
+IN_TURNS_MIN_STEPS = 600     # the three-engine `in_turns` figure is only taken in runs at least this long
 FP64_VECTOR_PEAK = 78.6e12   # MI355X_MICROARCH.md: FP64 vector 78.6 TFLOP/s
 
 
@@ -312,6 +315,40 @@ def profile_record(kernel, E, layout, filt=True, spec=True):
         return {}
 
 
+def issue_roofline(key, kernel, hbm, step_ms, launches_per_step=1.0):
+    """`roofline` of a line whose dominant kernel is bound by vector-instruction issue, from the committed counter pass of
+    this same command (profiles/pmc.json[key], written by tools/pmc_collect.py from profiles/<tag>_pmc_<kernel>.json and
+    profiles/<tag>_<workload>_kernel_stats.csv): achieved = SQ_INSTS_VALU per launch / the kernel's average duration in
+    that trace, both from the same profiling round, so that dividing one committed file by the other reproduces `frac`.
+    The HBM figure north_star asks for rides along as `hbm` (algorithmic bytes / this run's step time).  No record: the HBM
+    object alone, saying so."""
+    rec = profile_key(key)
+    if not rec.get("SQ_INSTS_VALU") or not rec.get("avg_ns"):
+        return dict(hbm, note=f"no committed counter pass for {kernel} ({key} in profiles/pmc.json): the HBM figure only; the path is "
+                              "issue / latency bound (SURVEY.md 8d)")
+    iv, ms = float(rec["SQ_INSTS_VALU"]), float(rec["avg_ns"]) * 1e-6
+    out = {"bound": "valu_issue", "kernel": kernel, "achieved": iv / (ms * 1e-3), "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
+           "frac": iv / (ms * 1e-3) / VALU_ISSUE_PEAK, "traffic": rec.get("hbm_bytes_per_launch"),
+           "wave_insts_valu_per_launch": iv, "kernel_ms": ms, "kernel_ms_source": "average duration of the kernel in the committed kernel trace (the counters' own profiling round), not this run",
+           "launches_per_step": launches_per_step, "kernel_ms_per_step": ms * launches_per_step, "step_ms_this_run": step_ms,
+           "waves_per_launch": rec.get("SQ_WAVES"), "counters_source": rec.get("source"), "hbm": hbm}
+    if rec.get("SQ_THREAD_CYCLES_VALU") and rec.get("SQ_ACTIVE_INST_VALU"):
+        out["live_lanes_per_valu_instruction"] = float(rec["SQ_THREAD_CYCLES_VALU"]) / float(rec["SQ_ACTIVE_INST_VALU"])
+    if rec.get("SQ_WAIT_ANY") and rec.get("SQ_WAVE_CYCLES"):
+        out["waiting_fraction_of_wave_cycles"] = float(rec["SQ_WAIT_ANY"]) / float(rec["SQ_WAVE_CYCLES"])
+    out["note"] = ("peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md, Wave scheduling); "
+                   "float64 Newton chains: what binds is the issue rate and the latency of one wave's dependent instructions, not HBM")
+    return out
+
+
+def profile_key(key):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
+            return json.load(f).get(key, {})
+    except (OSError, ValueError):
+        return {}
+
+
 def flop_record():
     """The oracle's static operation count of one step of the headline workload (profiles/flops.json,
     written by tools/count_flops.py from oracle/libmjpl_oracle_count.so); {} if absent."""
@@ -360,9 +397,12 @@ def bench_configs(args, world):
                "config": {"workload": f"configs[1]: Franka-P 7-DoF, self-collision + floor, {N} configurations/launch/GPU",
                           "valid_fraction": float(valid.mean()), "step_ms_hip_events": float(np.mean(ms)),
                           "parallelism": f"configuration-sharded x{world.world}, no data-path collective"},
-               "roofline": {"bound": "hbm", "achieved": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None, "note": "57 algorithmic bytes per configuration; ALU/issue bound"}}
+               "roofline": issue_roofline(
+                   f"k_filter_configs_configs{N}", "k_filter_configs",
+                   {"bound": "hbm", "achieved": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_configuration": 57},
+                   float(np.mean(ms)))}
         if not args.no_cpu_baseline:
             from oracle import pyoracle
             orc = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
@@ -437,10 +477,12 @@ def bench_next_rows(args, world):
                        value=value, unit="rows/s", ms_per_step=slowest / args.steps * 1e3,
                        config={"workload": f"{n} rows per launch per GPU, {np.abs(iters).mean():.1f} projection steps per row on average",
                                "accepted_fraction": float(ok.mean()), "parallelism": "row-" + sharded},
-                       roofline={"bound": "hbm", "achieved": n * row_bytes * args.steps / elapsed / 1e9,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": n * row_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                 "note": "FP64 issue / latency bound (FK + Jacobian + a certified 6x6 Cholesky solve per projection step; eigen-decomposition only near singularities)"},
+                       roofline=issue_roofline(
+                           f"k_pose_apply_rows_pose{n}", "k_pose_apply_rows",
+                           {"bound": "hbm", "achieved": n * row_bytes * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": n * row_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes_per_row": row_bytes},
+                           slowest / args.steps * 1e3),
                        cpu_baseline={"value": k / dtc, "unit": "rows/s", "cores": cores, "kind": "port",
                                      "sample": f"first {k} rows of rank 0, {cores} pthreads"})
     else:
@@ -487,10 +529,12 @@ def bench_next_rows(args, world):
                        config={"workload": f"{len(Q0)} seeds per launch per GPU, <= 200 iterations, host buffers (PCIe included)",
                                "converged_fraction": float(ok.mean()), "collision_free_of_converged": float(free.mean()),
                                "mean_iterations": float(its.mean()), "parallelism": "seed-" + sharded},
-                       roofline={"bound": "hbm", "achieved": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                 "note": "latency of the iteration chain (256 waves on 1 024 SIMDs)"},
+                       roofline=issue_roofline(
+                           f"k_ik_solve_rows_ik{len(Q0)}", "k_ik_solve_rows",
+                           {"bound": "hbm", "achieved": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes_per_seed": 2 * 8 * model.nq},
+                           slowest / args.steps * 1e3),
                        cpu_baseline=cpu_ik)
     if out is not None:
         _flush_c_stdio()
@@ -569,21 +613,22 @@ def bench_rrt(args, world):
             path_ok = bool(ok_edges.all() and np.all(pc.valid_configs(full)))
             if not path_ok:
                 raise SystemExit("bench: the planner's path fails the oracle's collision check / the pose constraint")
-        # ---- roofline of a round.  A round is ~60 launches of a dozen kernels; 80 % of its GPU time is k_rrt_gen_project, a
-        # float64 chain per lane (profiles/r03u_rrt_kernel_stats.csv, r04*_rrt_kernel_stats.csv): latency of that chain binds,
-        # not HBM.  Algorithmic bytes of a round: per sample its target read and what it reached written
-        # (2 x 8 nplan + 11 B), per new node its row and parent written (8 nplan + 4 B), and the two nearest-neighbour scans
-        # (row f2: 8 nplan B per node per 512-query tile).
-        nn_bytes = sum(int(n) for n in info.nodes) * 8 * nplan * ((L + 511) // 512)
+        # ---- roofline of a round.  A round is ~60 launches of a dozen kernels; most of its GPU time is the projecting
+        # extension's generating kernel, float64 Newton chains (profiles/*_rrt_kernel_stats.csv): its issue rate and the latency of
+        # one wave's chain bind, not HBM.  Algorithmic bytes of a round: per sample its target read and what
+        # it reached written (2 x 8 nplan + 11 B), per new node its row and parent written (8 nplan + 4 B), and the two
+        # nearest-neighbour scans (row f2: N x nq x 8 B per query batch -- the node matrix ONCE per scan; that the kernel walks it
+        # once per 512-query tile is implementation traffic served by L2, not algorithmic bytes) plus their queries and answers.
+        nn_bytes = sum(int(n) for n in info.nodes) * 8 * nplan + 2 * L * (8 * nplan + 4)
         round_bytes = L * (2 * 8 * nplan + 11) + (new_nodes / max(done, 1)) * (8 * nplan + 4) + nn_bytes
         round_s = slowest / done
-        roofline = {"bound": "hbm", "achieved": round_bytes / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round_bytes / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "whole round (k_rrt_gen_project holds ~70 % of its GPU time: profiles/r04h_rrt_kernel_stats.csv)",
-                    "kernel_ms": round_s * 1e3, "algorithmic_bytes_per_round": round_bytes,
-                    "of_which_nearest_neighbour_scans": nn_bytes,
-                    "note": "latency bound: one lane's float64 Newton chain per projection step (DESIGN.md section 7); the HBM figure is "
-                            "what north_star asks for, over the whole round because its kernels are not bracketed by events one by one"}
+        rec = profile_key(f"k_rrt_gen_project_rows_rrt{L}")
+        roofline = issue_roofline(
+            f"k_rrt_gen_project_rows_rrt{L}", "k_rrt_gen_project_rows",
+            {"bound": "hbm", "achieved": round_bytes / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round_bytes / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_round": round_bytes,
+             "of_which_nearest_neighbour_scans": nn_bytes, "over": "the whole round (its kernels are not bracketed one by one)"},
+            round_s * 1e3, launches_per_step=float(rec.get("calls_per_round", 0.0)) or 1.0)
         cpu = None
         if not args.no_cpu_baseline:
             # the same algorithm stated in NumPy (mjpl_amd.planning.parallel_rrt.ParallelBiRRT: what the GPU planner's trees are
@@ -837,9 +882,17 @@ def main():
             raise errs[0]
         return stamp, res
 
-    # warmup (untimed)
+    # Untimed: the clocks first -- at least ~60 ms of launches whatever --warmup is (a 20-step region is 4 ms: started
+    # cold the chip runs it 5 % below the rate it holds a second later) --, then the W warmup steps of the contract.
+    run_all([CLOCK_WARM_STEPS] * S, 1 << 30)
     if args.warmup > 0:
         run_all([args.warmup] * S, 1 << 30)
+    # A short region carries no events at all: a bracketed launch costs ~56 us more than a plain one (below), 3 % of a
+    # 20-step region for one sample.  The per-kernel durations of such a line come from 32 launches taken here, every
+    # one bracketed, on engine 0 alone -- the same kernels on the same batch, outside the clock.
+    pre_res = None
+    if args.steps < SHORT_REGION_STEPS:
+        _, pre_res = run_all([32] + [0] * (S - 1), 1)
 
     def start_of_timed_region():
         world.barrier()
@@ -849,15 +902,20 @@ def main():
     # launch costs ~56 us more than a plain one -- the events break the back-to-back submission: every 4th launch cost
     # the one-stream line 2 % of its rate, every 16th still 1.8 % (0.1966 against 0.1931 ms per step without any,
     # tools/time_fused.py) -- so about 32 launches of the region are bracketed, never more than one in 16.
-    sample = max(16, args.steps // 32)
+    sample = (1 << 30) if pre_res is not None else max(16, args.steps // 32)
     t0, timed_res = run_all(share, sample, start_of_timed_region)  # every call synchronises its stream
     world.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = float(world.gather(elapsed).max())
     wsum = float(sum(share))
-    launch_ms = sum(r[0] * n for r, n in zip(timed_res, share) if r) / wsum
-    stage_ms = {k: sum(r[1][k] * n for r, n in zip(timed_res, share) if r) / wsum for k in timed_res[0][1]}
-    nsamp = sum(r[2] for r in timed_res if r)
+    if pre_res is not None:
+        launch_ms, stage_ms, nsamp = pre_res[0]
+        sample_note = "HIP events on the engine's own stream around every kernel of 32 untimed launches just before the timed region (a region of fewer than %d steps carries no events), nothing else on the chip" % SHORT_REGION_STEPS
+    else:
+        launch_ms = sum(r[0] * n for r, n in zip(timed_res, share) if r) / wsum
+        stage_ms = {k: sum(r[1][k] * n for r, n in zip(timed_res, share) if r) / wsum for k in timed_res[0][1]}
+        nsamp = sum(r[2] for r in timed_res if r)
+        sample_note = f"HIP events on the engine's own stream around every kernel of every {sample}th launch of the timed region, nothing else on the chip"
 
     valid = dvalid.download(np.uint8, E)
     for k in range(1, S):
@@ -931,7 +989,7 @@ def main():
                        "against ~22 600 flop"}
         roof = {"kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms if S == 1 else one_stream["step_ms_all_kernels"],
                 "kernels_ms": alone_ms, "kernel_samples": nsamp, "streams_of_these_durations": 1,
-                "kernel_ms_source": f"HIP events on the engine's own stream around every kernel of every {sample}th launch of the timed region, nothing else on the chip"
+                "kernel_ms_source": sample_note
                                     + ("" if S == 1 else " (the one_stream run of this line; the timed region overlaps kernels of several engines)"),
                 "hbm": hbm}
         if prof.get("SQ_INSTS_VALU"):
@@ -990,15 +1048,17 @@ def main():
                                             "frac": iv / (elapsed / args.steps) / VALU_ISSUE_PEAK, "peak_per_s": VALU_ISSUE_PEAK,
                                             "kernels": [k for k in stage_ms if stage_ms[k] > 0.01]}
         out["one_stream"] = one_stream
-        if S == 1 and world.world == 1 and not args.no_variants and args.variant == "headline":
+        if S == 1 and world.world == 1 and not args.no_variants and args.variant == "headline" and args.steps >= IN_TURNS_MIN_STEPS:
+            # (only in a long run: three freshly created engines sharing 20 steps measure their own start-up, and the figure
+            #  printed BELOW the one-stream value in round 4's driver line)
             # ... and the same steps taken in turns by three engines (three HIP streams: batches in flight): what a caller
             # with several batches to validate can add on top (mjpl_amd.engine.EngineRing); never the line's value
             T = 3
-            tsteps = max(60, min(args.steps, 600))
+            tsteps = min(args.steps, 1200)
             tengs = [eng] + [make_engine(*timed) for _ in range(T - 1)]
             touts = [dvalid] + [x.alloc(E) for x in tengs[1:]]
             tshare = [tsteps // T + (1 if k < tsteps % T else 0) for k in range(T)]
-            run_all([5] * T, 1 << 30, None, tengs, touts)
+            run_all([100] * T, 1 << 30, None, tengs, touts)
             tv, _ = run_all(tshare, 1 << 30, time.perf_counter, tengs, touts)
             dtv = time.perf_counter() - tv
             if not all(np.array_equal(o.download(np.uint8, E), valid) for o in touts):

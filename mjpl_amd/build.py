@@ -23,7 +23,7 @@ _BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-m
 # the per-model specialised libraries (mjpl_amd/specialise.py).  Their digest is compiled into both
 # (MJPL_SRC_STAMP) and mixed into the program hash a specialised library is named by, so a library
 # built from other headers is neither found nor accepted (load_spec compares the stamps).
-STAMPED_HEADERS = ("mjpl_filter.h", "mjpl_fused.h", "mjpl_device.h", "mjpl_trig.h", "mjpl_pose.h", "mjpl_project.h")
+STAMPED_HEADERS = ("mjpl_filter.h", "mjpl_fused.h", "mjpl_device.h", "mjpl_trig.h", "mjpl_pose.h", "mjpl_project.h", "mjpl_rows.h")
 
 
 def src_stamp() -> int:

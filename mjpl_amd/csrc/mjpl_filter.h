@@ -20,7 +20,7 @@ constexpr int kFilterBlock = 256;     // queued filter kernels: four wavefronts 
 constexpr int kStatusNonFinite = 1;
 // version of the contract between libmjpl_hip.so and a per-model specialised library
 // (kernel signatures of this header + table layouts of mjpl_device.h)
-#define MJPL_SPEC_ABI 13
+#define MJPL_SPEC_ABI 14
 // scene-generic specialised libraries: cull rows per moving geom, moving geoms at most,
 // floats of the scene header in front of the rows
 // Table: [header | per moving geom: kSceneRows cull rows of 4 floats, then kSceneRows descriptor words | one
@@ -1428,22 +1428,31 @@ k_tail(TailArgs a) {
   }
   // (the walking list was closed by the endpoint kernel: when it is empty -- the usual case -- the walking
   // workgroups add nothing to anybody's list and nobody waits for them)
-  if (*a.lcount > 0 && threadIdx.x == 0) {
-    int spins = 0;
-    while (__hip_atomic_load(a.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.nw) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1 << 24)) {  // (seconds: no W pass takes that long -- report, do not hang)
-        atomicOr(a.status, kStatusTailTimeout);
-        break;
+  // Thread 0 waits and decides for the workgroup; the decision travels through one LDS word, so every thread
+  // takes the same side of the branch below (the bodies behind it hold __syncthreads: threads that each read the
+  // status word themselves could see another workgroup's time-out between two of their loads and part ways).
+  __shared__ int give_up;
+  if (threadIdx.x == 0) {
+    int gave = 0;
+    if (*a.lcount > 0) {
+      int spins = 0;
+      while (__hip_atomic_load(a.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.nw) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 24)) {  // (seconds: no W pass takes that long -- report, do not hang)
+          atomicOr(a.status, kStatusTailTimeout);
+          break;
+        }
       }
+      __threadfence();
+      gave = (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusTailTimeout) ? 1 : 0;
     }
-    __threadfence();
+    give_up = gave;
   }
   __syncthreads();
   // (a wait that gave up: the lists may still be growing under a walking workgroup, so nothing read from them
   // now can be trusted -- leave the batch alone; the status bit is sticky and every synchronising entry point,
   // mjpl_take_status and the planner's rounds report it as MJPL_E_HIP)
-  if (*a.lcount > 0 && (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusTailTimeout)) return;
+  if (give_up) return;
   if (b < a.nw + a.np)
     patch_pairs_body<ESpec>(a.ip, a.nip, a.dp, a.ndp, a.gt, a.uc, a.valid, a.first_bad, b - a.nw, a.np);
   else

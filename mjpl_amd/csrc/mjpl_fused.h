@@ -404,7 +404,7 @@ k_edges_fused(FusedArgs a) {
         });
         double tsw;
         K = count_waypoints_walk(a.ip, a.step, active && finite, at_end, qe, 64, qx, 64, a.kmax, nplan, tsw);
-        if (K > 0 || a.single) a.tstep[i] = tsw;  // (parked in memory across the check: two registers less to keep alive)
+        if (active && (K > 0 || a.single)) a.tstep[i] = tsw;  // (parked in memory across the check: two registers less to keep alive; lanes past E own no element)
         wave_lds_fence();
         for (int k0 = 0; k0 < nplan; k0 += 8) {
           double v[8];
@@ -421,6 +421,7 @@ k_edges_fused(FusedArgs a) {
           finite = finite && (fabs(x) <= 1.79769313486231570815e+308) && (fabs(y) <= 1.79769313486231570815e+308);
         });
         K = -1;
+        if (active && a.single) a.tstep[i] = 0.0;  // (the walking list redoes the edge; its one item here is check 0, the endpoint, whatever the step)
         load_columns(qw, 64, a.QB, a.E, i, nplan, a.layout, active && finite);
       }
       active = active && finite;

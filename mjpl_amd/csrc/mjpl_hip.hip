@@ -221,11 +221,12 @@ struct SpecLib {
   FusedFn fused = nullptr;
   int fused_waves = kFusedWaves;  // what its fused kernel was built for (mjpl_spec_fused_waves)
   // generated PoseConstraint projections, one per site body of the model (mjpl_project.h): chain hashes and launchers
-  typedef int (*PoseApplyFn)(int, hipStream_t, unsigned, size_t, const int *, const double *, const double *, const double *, int64_t,
+  // (row kernels of mjpl_rows.h: projection index, lanes per row, stream, waves, ...; 0 launched, -1 refused, -2 HIP error)
+  typedef int (*PoseApplyFn)(int, int, hipStream_t, unsigned, const int *, const double *, const double *, const double *, int64_t, int64_t,
                              double *, uint8_t *, int32_t *);
-  typedef int (*GenProjectFn)(int, hipStream_t, unsigned, size_t, int, int, int, double, const int *, const double *, const int *,
+  typedef int (*GenProjectFn)(int, int, hipStream_t, unsigned, int, int, int, double, int, const int *, const double *, const int *,
                               const double *, const uint8_t *, const double *, const double *, const double *, RrtLanes, RrtCand, int *);
-  typedef int (*IkSolveFn)(int, hipStream_t, unsigned, size_t, const int *, const double *, const double *, int64_t, double *, uint8_t *,
+  typedef int (*IkSolveFn)(int, int, hipStream_t, unsigned, const int *, const double *, const double *, int64_t, int64_t, double *, uint8_t *,
                            int32_t *, double *, int, unsigned long long);
   int pose_count = 0;
   unsigned long long (*pose_hash)(int) = nullptr;
@@ -2709,6 +2710,26 @@ uint64_t chain_hash_of(const std::vector<int> &pi, const std::vector<double> &pd
   return h;
 }
 
+// How a batch of N rows (projections, IK seeds, active planner lanes) goes to the row kernels of mjpl_rows.h.  The
+// kernels hold one wave per SIMD (their registers), 1 024 waves on the chip.  While ALL rows can be resident at once
+// a row gets as many lanes as that allows -- eight up to 8 192 rows, four up to 16 384 (the lanes split a third of a
+// Newton step's instructions) -- and every row starts with the launch: such batches are bound by their slowest row,
+// which must not wait for a free lane first.  Beyond that one lane per row, and a wave owns ceil(N / 1 024) >= 64 rows:
+// it refills as rows end.  MJPL_ROWS_G: force the lanes per row (A/B timing).
+struct RowsShape { int G; unsigned grid; int64_t per; };
+RowsShape rows_shape(int64_t N) {
+  static const int forced = [] { const char *v = getenv("MJPL_ROWS_G"); return v ? atoi(v) : 0; }();
+  const int64_t max_waves = 1024;  // one per SIMD: what the row kernels' registers allow (mjpl_rows.h)
+  RowsShape r;
+  r.G = N <= 8 * max_waves ? 8 : (N <= 16 * max_waves ? 4 : 1);
+  if (forced == 1 || forced == 4 || forced == 8) r.G = forced;
+  const int64_t rows_per_wave = 64 / r.G;
+  const int64_t waves = std::min<int64_t>(max_waves, (N + rows_per_wave - 1) / rows_per_wave);
+  r.per = (N + waves - 1) / waves;
+  r.grid = (unsigned)((N + r.per - 1) / r.per);
+  return r;
+}
+
 // the generated projection of this handle's chain in the library its engine has loaded NOW (set_planning may have
 // changed it since the handle was made), or -1
 int pose_spec_index(const mjpl_pose *p) {
@@ -2815,11 +2836,12 @@ int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQold, const double *dQ, int
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
   const int k = pose_spec_index(p);
   if (k >= 0) {
-    if (p->e->spec->pose_apply(k, p->e->stream, grid, pose_lds(p), p->d_pi, p->d_pd, dQold, dQ, N, dQout, dok, diters) != 0)
-      return fail(MJPL_E_HIP, "generated projection kernel failed to launch");
-    return MJPL_OK;
+    const RowsShape rs = rows_shape(N);
+    const int rc2 = p->e->spec->pose_apply(k, rs.G, p->e->stream, rs.grid, p->d_pi, p->d_pd, dQold, dQ, N, rs.per, dQout, dok, diters);
+    if (rc2 == 0) return MJPL_OK;
+    if (rc2 != -1) return fail(MJPL_E_HIP, "generated projection kernel failed to launch");
   }
-  hipLaunchKernelGGL(k_pose_apply<void>, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd,
+  hipLaunchKernelGGL(k_pose_apply, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd,
                      dQold, dQ, N, dQout, dok, diters);
   HIP_TRY(hipGetLastError());
   return MJPL_OK;
@@ -2941,12 +2963,13 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, i
   HIP_TRY(hipMemcpy(d_pd, pd.data(), db, hipMemcpyHostToDevice));
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
   if (spec_k >= 0) {
-    if (e->spec->ik_solve(spec_k, e->stream, grid, lds, d_pi, d_pd, dQ, N, dQout, dok, diters, derr, d->restarts > 0 ? d->restarts : 0,
-                          (unsigned long long)d->restart_seed) != 0)
-      return fail(MJPL_E_HIP, "generated IK kernel failed to launch");
-    return MJPL_OK;
+    const RowsShape rs = rows_shape(N);
+    const int rc2 = e->spec->ik_solve(spec_k, rs.G, e->stream, rs.grid, d_pi, d_pd, dQ, N, rs.per, dQout, dok, diters, derr,
+                                      d->restarts > 0 ? d->restarts : 0, (unsigned long long)d->restart_seed);
+    if (rc2 == 0) return MJPL_OK;
+    if (rc2 != -1) return fail(MJPL_E_HIP, "generated IK kernel failed to launch");
   }
-  hipLaunchKernelGGL(k_ik_solve<void>, dim3(grid), dim3(kPoseBlock), lds, e->stream, d_pi, d_pd, dQ, N, dQout, dok,
+  hipLaunchKernelGGL(k_ik_solve, dim3(grid), dim3(kPoseBlock), lds, e->stream, d_pi, d_pd, dQ, N, dQout, dok,
                      diters, derr, d->restarts > 0 ? d->restarts : 0, (uint64_t)d->restart_seed);
   HIP_TRY(hipGetLastError());
   return MJPL_OK;

@@ -14,8 +14,10 @@
 namespace mjpl {
 
 // counters shared with the host (one 64-byte block, read back per chunk / per exchange)
+// RC_LISTN + p: entries of active-lane list p of a projecting extension (chunk c reads list c & 1, its acceptance
+// kernel writes list (c + 1) & 1: the lanes still extending, packed -- the generating kernel's waves hold live rows only)
 enum : int { RC_EDGES = 0, RC_ACC, RC_ACTIVE, RC_CONN, RC_CONN_REFA, RC_CONN_REFB, RC_NEWA, RC_NEWB,
-             RC_OVERFLOW, RC_SIZE = 16 };
+             RC_OVERFLOW, RC_LISTN, RC_LISTN1, RC_SIZE = 16 };
 
 struct RrtLanes {
   double *T, *C, *RA;          // [nplan][L] SoA: target, current end of the lane's chain, reach of extend A
@@ -25,6 +27,7 @@ struct RrtLanes {
   int32_t *gfirst, *gcount;    // candidates of the lane in this chunk: first slot, how many
   uint8_t *gend;               // the lane ends after this chunk's candidates whatever their verdicts
   int32_t *goal;               // biased lanes: goal index (-1: not biased)
+  int32_t *list[2];            // projecting extensions: the active lanes of a chunk, packed (RC_LISTN + parity entries)
 };
 
 struct RrtCand {               // candidates of one chunk, AoS rows of nplan
@@ -54,14 +57,10 @@ constexpr double kPoseMaxCond = 1e6;  // (see k_pose_apply: fast path of the 6x6
 // lane's [6 * njoint] store.  Every lane of the wave calls it (`active` false: the lane only keeps company).
 // Returns 1: within tolerance, 0: left the joint limits or went farther than 2 q_step from q_old, 2: iteration
 // bound; *iters counts the Newton steps taken.
-// PS: void = the chain program in (pi, pd) is interpreted; else PS::chain is that chain as straight-line code
-// (PoseStatic<PS>::project below: the same statements in the same order, so the same float64 values).
-template <class PS> struct PoseStatic;
-
-template <class PS = void>
+// The chain program in (pi, pd) is interpreted.  (A model's library runs the same iteration around its generated chain
+// -- the same statements in the same order, the same float64 values -- in the row kernels of mjpl_rows.h.)
 __device__ __forceinline__ int pose_project_lane(const int *__restrict__ pi, const double *__restrict__ pd, double *qw,
                                                  double *jst, const double *qo, int qos, bool active, int *iters) {
-  if constexpr (!std::is_void<PS>::value) return PoseStatic<PS>::project(pi, pd, qw, qo, qos, active, iters);
   constexpr int B = kPoseBlock;
   const int nq = pi[PH_NQ], nj = pi[PH_NJOINT], maxit = pi[PH_MAXIT];
   const double *tail = pd + pi[PH_OFF_TAIL];
@@ -167,113 +166,6 @@ __device__ __forceinline__ int pose_project_lane(const int *__restrict__ pi, con
   return result;
 }
 
-// The projection around a generated chain.  PS provides: kNQ, kNJ, jtype(k), qadr(k) (constexpr) and
-// chain(q, jx, out, tail): mj_kinematics along the chain from the configuration in registers, jx[k] = world axis
-// (0..2) and anchor (3..5) of chain joint k.  The working configuration, the joints' columns and the 6x6 live in
-// registers (every index is a literal after unrolling); nothing is read from the chain program, no LDS but the
-// caller's qw / qo.  Statement for statement pose_project_lane above.
-template <class PS>
-struct PoseStatic {
-  static __device__ __forceinline__ int project(const int *__restrict__ pi, const double *__restrict__ pd, double *qw,
-                                                const double *qo, int qos, bool active, int *iters) {
-    constexpr int B = kPoseBlock, NQ = PS::kNQ, NJ = PS::kNJ;
-    const int maxit = pi[PH_MAXIT];
-    const double *tail = pd + pi[PH_OFF_TAIL];
-    const double *jrange = pd + pi[PH_OFF_JRANGE];
-    const double tol = tail[PT_TOL], far_at = 2 * tail[PT_QSTEP];
-    double qv[NQ], qold[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; k++) { qv[k] = qw[k * B]; qold[k] = qo[k * qos]; }
-    bool done = !active;
-    int result = 0, it = 0;
-    while (__ballot(!done) != 0ull) {
-      if (!done) {
-        PoseChainOut o;
-        double jx[NJ][6];
-        PS::chain(qv, jx, o, tail);
-        double dx[6], qs[4];
-        pose_displacement(tail, o, dx, qs);
-        if (norm6(dx) <= tol) {
-          done = true; result = 1;
-        } else if (it >= maxit) {
-          done = true; result = 2;
-        } else {
-          double rpy[3];
-          quat2rpy(rpy, qs);
-          const double c_p = cos(rpy[1]), c_y = cos(rpy[2]), s_p = sin(rpy[1]), s_y = sin(rpy[2]);
-          const double e33 = c_y / c_p, e34 = s_y / c_p, e43 = -s_y, e44 = c_p;
-          const double e53 = c_y * (s_p / c_p), e54 = s_y * (s_p / c_p);
-          double A[6][6];
-#pragma unroll
-          for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 6; c++) A[r][c] = 0;
-#pragma unroll
-          for (int jk = 0; jk < NJ; jk++) {
-            const double ax[3] = {jx[jk][0], jx[jk][1], jx[jk][2]};
-            double col[6];
-            if (PS::jtype(jk) == JT_HINGE) {
-              const double r[3] = {o.site_xpos[0] - jx[jk][3], o.site_xpos[1] - jx[jk][4], o.site_xpos[2] - jx[jk][5]};
-              col[0] = ax[1] * r[2] - ax[2] * r[1];
-              col[1] = ax[2] * r[0] - ax[0] * r[2];
-              col[2] = ax[0] * r[1] - ax[1] * r[0];
-              col[3] = e33 * ax[0] + e34 * ax[1];
-              col[4] = e43 * ax[0] + e44 * ax[1];
-              col[5] = e53 * ax[0] + e54 * ax[1] + ax[2];
-            } else {
-              col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2];
-              col[3] = e33 * 0.0 + e34 * 0.0;
-              col[4] = e43 * 0.0 + e44 * 0.0;
-              col[5] = e53 * 0.0 + e54 * 0.0 + 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 6; r++) jx[jk][r] = col[r];
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-              for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + col[r] * col[c];
-          }
-          double y[6];
-          const bool fast = spd6_solve_certified(A, dx, y, kPoseMaxCond);
-          if (__ballot(!fast) != 0ull) {
-            if (!fast) {
-              double Ae[6][6];
-#pragma unroll
-              for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c < 6; c++) Ae[r][c] = A[r][c];
-              pinv_sym6_apply(Ae, dx, y);
-            }
-          }
-#pragma unroll
-          for (int jk = 0; jk < NJ; jk++) {
-            double acc = 0;
-#pragma unroll
-            for (int r = 0; r < 6; r++) acc = acc + jx[jk][r] * y[r];
-            qv[PS::qadr(jk)] -= acc;
-          }
-          bool viol = false;
-          double s = 0;
-#pragma unroll
-          for (int k = 0; k < NQ; k++) {
-            const double v = qv[k];
-            viol = viol || !(v >= jrange[2 * k] && v <= jrange[2 * k + 1]);
-            const double d = v - qold[k];
-            s = s + d * d;
-          }
-          it++;
-          if (viol || sqrt(s) > far_at) { done = true; result = 0; }
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NQ; k++) qw[k * B] = qv[k];
-    *iters = it;
-    return result;
-  }
-};
-
-template <class PS = void>
 __global__ void __launch_bounds__(kPoseBlock)
 k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
              const double *__restrict__ Q, int64_t N, double *__restrict__ Qout,
@@ -288,7 +180,7 @@ k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const do
   const bool active = i < N;
   for (int k = 0; k < nq; k++) qw[k * B] = active ? Q[i * nq + k] : 0.0;
   int it = 0;
-  const int result = pose_project_lane<PS>(pi, pd, qw, jst, Qold + (active ? i : 0) * nq, 1, active, &it);
+  const int result = pose_project_lane(pi, pd, qw, jst, Qold + (active ? i : 0) * nq, 1, active, &it);
   if (active) {
     for (int k = 0; k < nq; k++) Qout[i * nq + k] = qw[k * B];
     ok[i] = result == 1 ? 1 : 0;
@@ -307,21 +199,24 @@ k_pose_apply(const int *__restrict__ pi, const double *__restrict__ pd, const do
 // few lanes are left and a chunk costs the latency of its kernels whatever it holds.
 // Every emitting lane owns S slots: those behind its last candidate carry a zero-length edge nobody reads.
 // One workgroup of 64 lanes; LDS per lane: qw[nq] | jst[6 * njoint] | qo[nq].
-// NP > 0: the number of planning joints is a constant of the instantiation (a per-model library knows its program's):
-// the target / current / candidate rows of a lane are registers then, not scratch.
-template <class PS = void, int NP = 0>
+// The lanes of a chunk come from the packed list `par` of the extension (RC_LISTN + par entries, written by k_rrt_begin
+// for chunk 0 and by the acceptance kernel of the chunk before otherwise): lane i of the grid takes entry i.
+// This is the interpreting statement (the chain program read from memory, one lane per row); a model's library runs the
+// same chunk around its generated chain in k_rrt_gen_project_rows (mjpl_rows.h).
 __global__ void __launch_bounds__(kPoseBlock)
-k_rrt_gen_project(int L, int nplan_arg, int S, double eps, const int *__restrict__ pi, const double *__restrict__ pd,
+k_rrt_gen_project(int L, int nplan, int S, double eps, int par, const int *__restrict__ pi, const double *__restrict__ pd,
                   const int *__restrict__ qidx, const double *__restrict__ qbase, const uint8_t *__restrict__ isplan,
                   const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln,
                   RrtCand cd, int *__restrict__ ctr) {
   extern __shared__ double smem[];
   constexpr int B = kPoseBlock;
-  const int nplan = NP > 0 ? NP : nplan_arg;
   const int lane = threadIdx.x;
-  const int l = blockIdx.x * B + lane;
+  const int at = blockIdx.x * B + lane;
+  const int nlist = ctr[RC_LISTN + par];
+  if (blockIdx.x == 0 && lane == 0) ctr[RC_LISTN + (par ^ 1)] = 0;  // (the acceptance kernel of this chunk fills it)
   const int nq = pi[PH_NQ], nj = pi[PH_NJOINT];
-  const bool act = l < L && ln.act[l] != 0;
+  const bool act = at < nlist;
+  const int l = act ? ln.list[par][at] : 0;
   const unsigned long long am = __ballot(act);
   if (am == 0ull) return;
   double *qw = smem + lane;
@@ -374,7 +269,7 @@ k_rrt_gen_project(int L, int nplan_arg, int S, double eps, const int *__restrict
       for (int c = 0; c < nplan; c++) { qo[qidx[c] * B] = w[c]; qw[qidx[c] * B] = q[c]; }
     }
     int it = 0;
-    const int result = pose_project_lane<PS>(pi, pd, qw, jst, qo, B, going, &it);
+    const int result = pose_project_lane(pi, pd, qw, jst, qo, B, going, &it);
     if (going) {
       bool good = result == 1;
       for (int k = 0; k < nq; k++)  // a projection that moves a joint outside the planning set is rejected
@@ -429,19 +324,12 @@ k_rrt_gen_project(int L, int nplan_arg, int S, double eps, const int *__restrict
 //   dq = J^T (J J^T + (damp + lm |e|^2) I)^-1 e,   |dq|_inf <= max_step,   q clamped to jnt_range,
 // joints outside the solver's joint set are held (their Jacobian columns are zero).  A seed is
 // solved when |e_pos| <= pos_tol and |e_ori| <= ori_tol (:100-102).
-// PS: void = the chain program is interpreted; else IkStatic<PS> below: the same iteration around the model's
-// generated chain, configuration / columns / step in registers (statement for statement: the same results).
-template <class PS> struct IkStatic;
-
-template <class PS = void>
+// The chain program is interpreted here; IkRows (mjpl_rows.h): the same iteration around a model's generated chain,
+// configuration / columns / step in registers (statement for statement: the same results).
 __global__ void __launch_bounds__(kPoseBlock)
 k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Q,
            int64_t N, double *__restrict__ Qout, uint8_t *__restrict__ ok, int32_t *__restrict__ iters,
            double *__restrict__ err, int max_restarts, uint64_t restart_seed) {
-  if constexpr (!std::is_void<PS>::value) {
-    IkStatic<PS>::solve(pi, pd, Q, N, Qout, ok, iters, err, max_restarts, restart_seed);
-    return;
-  }
   extern __shared__ double smem[];
   constexpr int B = kPoseBlock;
   const int lane = threadIdx.x;
@@ -604,150 +492,6 @@ k_ik_solve(const int *__restrict__ pi, const double *__restrict__ pd, const doub
   }
 }
 
-
-
-template <class PS>
-struct IkStatic {
-  static __device__ __forceinline__ void solve(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Q,
-                                               int64_t N, double *__restrict__ Qout, uint8_t *__restrict__ ok, int32_t *__restrict__ iters,
-                                               double *__restrict__ err, int max_restarts, uint64_t restart_seed) {
-    constexpr int B = kPoseBlock, NQ = PS::kNQ, NJ = PS::kNJ;
-    const int lane = threadIdx.x;
-    const int maxit = pi[PH_MAXIT];
-    const double *tail = pd + pi[PH_OFF_TAIL];
-    const double *jrange = pd + pi[PH_OFF_JRANGE];
-    const double *movable = jrange + 2 * NQ;
-    const int64_t i = (int64_t)blockIdx.x * B + lane;
-    const bool active = i < N;
-    double qv[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; k++) qv[k] = active ? Q[i * NQ + k] : 0.0;
-    const double pos_tol = tail[IT_POS_TOL], ori_tol = tail[IT_ORI_TOL];
-    const double damp = tail[IT_DAMP], lm = tail[IT_LM], max_step = tail[IT_MAX_STEP];
-    bool done = !active, solved = false;
-    int it = 0;
-    double epos = 0, eori = 0;
-    double lam_scale = 1.0, prev_err2 = 1.0e300;
-    double best_err2 = 1.0e300;
-    int best_it = 0, restarts = 0;
-    const uint64_t rkey = rrt_key(restart_seed, (uint64_t)i, 0x494bull);
-    while (__ballot(!done) != 0ull) {
-      if (!done) {
-        PoseChainOut o;
-        double jx[NJ][6];
-        PS::chain(qv, jx, o, tail);  // (the site offset sits at the same place of the IK tail: IT_SITE_* == PT_SITE_*)
-        double e[6];
-        ik_error(tail, o, e);
-        epos = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-        eori = sqrt(e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
-        if (epos <= pos_tol && eori <= ori_tol) {
-          done = true; solved = true;
-        } else if (it >= maxit) {
-          done = true;
-        } else {
-          const double err2 = epos * epos + eori * eori;
-          if (err2 < 0.98 * best_err2) { best_err2 = err2; best_it = it; }
-          if (it - best_it >= 12 && restarts < max_restarts) {
-            restarts++;
-#pragma unroll
-            for (int jk = 0; jk < NJ; jk++) {
-              const int jid = PS::jid(jk);
-              if (movable[jid] != 0.0) {
-                const double u = rrt_u01(rkey, (uint64_t)restarts * 64u + (uint64_t)(jid & 63));
-                qv[PS::qadr(jk)] = jrange[2 * jid] + u * (jrange[2 * jid + 1] - jrange[2 * jid]);
-              }
-            }
-            lam_scale = 1.0; prev_err2 = 1.0e300; best_err2 = 1.0e300; best_it = it;
-            it++;
-            continue;
-          }
-          lam_scale = err2 > prev_err2 ? fmin(lam_scale * 4.0, 1.0e4) : fmax(lam_scale * 0.5, 1.0 / 64.0);
-          prev_err2 = err2;
-          const double lam = (damp + lm * err2) * lam_scale;
-#pragma unroll
-          for (int jk = 0; jk < NJ; jk++) {
-            const double mv = movable[PS::jid(jk)];
-            const double ax[3] = {jx[jk][0], jx[jk][1], jx[jk][2]};
-            double col[6];
-            if (PS::jtype(jk) == JT_HINGE) {
-              const double r[3] = {o.site_xpos[0] - jx[jk][3], o.site_xpos[1] - jx[jk][4], o.site_xpos[2] - jx[jk][5]};
-              col[0] = mv * (ax[1] * r[2] - ax[2] * r[1]);
-              col[1] = mv * (ax[2] * r[0] - ax[0] * r[2]);
-              col[2] = mv * (ax[0] * r[1] - ax[1] * r[0]);
-              col[3] = mv * ax[0]; col[4] = mv * ax[1]; col[5] = mv * ax[2];
-            } else {
-              col[0] = mv * ax[0]; col[1] = mv * ax[1]; col[2] = mv * ax[2];
-              col[3] = 0; col[4] = 0; col[5] = 0;
-            }
-#pragma unroll
-            for (int r = 0; r < 6; r++) jx[jk][r] = col[r];
-          }
-          unsigned locked = 0;
-          double scale = 1.0;
-          double dqv[NJ];
-          for (int pass = 0; pass < 2; pass++) {
-            double A[6][6];
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-              for (int c = 0; c < 6; c++) A[r][c] = (r == c) ? lam : 0.0;
-#pragma unroll
-            for (int k = 0; k < NJ; k++) {
-              if ((locked >> (k & 31)) & 1u) continue;
-#pragma unroll
-              for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c < 6; c++) A[r][c] = A[r][c] + jx[k][r] * jx[k][c];
-            }
-            double y[6];
-            chol6_solve(A, e, y);
-            double big = 0;
-#pragma unroll
-            for (int k = 0; k < NJ; k++) {
-              double acc = 0;
-              if (!((locked >> (k & 31)) & 1u)) {
-#pragma unroll
-                for (int r = 0; r < 6; r++) acc = acc + jx[k][r] * y[r];
-              }
-              dqv[k] = acc;
-              big = fabs(acc) > big ? fabs(acc) : big;
-            }
-            scale = big > max_step ? max_step / big : 1.0;
-            if (pass == 1) break;
-            unsigned out = 0;
-#pragma unroll
-            for (int jk = 0; jk < NJ; jk++) {
-              const int jid = PS::jid(jk);
-              const double dq = dqv[jk], v = qv[PS::qadr(jk)];
-              const double span = jrange[2 * jid + 1] - jrange[2 * jid];
-              const bool at_lo = v <= jrange[2 * jid] + 1e-9 * span, at_hi = v >= jrange[2 * jid + 1] - 1e-9 * span;
-              if (movable[jid] != 0.0 && ((at_lo && dq < 0) || (at_hi && dq > 0))) out |= 1u << (jk & 31);
-            }
-            if (out == 0) break;
-            locked = out;
-          }
-#pragma unroll
-          for (int jk = 0; jk < NJ; jk++) {
-            const int jid = PS::jid(jk);
-            double v = qv[PS::qadr(jk)] + scale * dqv[jk];
-            if (movable[jid] != 0.0) {
-              v = v < jrange[2 * jid] ? jrange[2 * jid] : v;
-              v = v > jrange[2 * jid + 1] ? jrange[2 * jid + 1] : v;
-              qv[PS::qadr(jk)] = v;
-            }
-          }
-          it++;
-        }
-      }
-    }
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < NQ; k++) Qout[i * NQ + k] = qv[k];
-      ok[i] = solved ? 1 : 0;
-      if (iters) iters[i] = it;
-      if (err) { err[2 * i] = epos; err[2 * i + 1] = eori; }
-    }
-  }
-};
-
 }  // namespace mjpl
+
+#include "mjpl_rows.h"

@@ -96,6 +96,20 @@ k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLane
   ln.cnt[l] = 0;
 }
 
+// a projecting extension works from packed lists of its active lanes (mjpl_project.h: RC_LISTN): list 0 for chunk 0
+__global__ void __launch_bounds__(256)
+k_rrt_list_begin(int L, RrtLanes ln, int *__restrict__ ctr) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = l < L && ln.act[l] != 0;
+  const unsigned long long m = __ballot(act);
+  if (m == 0ull) return;
+  const int lane = (int)(threadIdx.x & 63);
+  int base = 0;
+  if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&ctr[RC_LISTN], __popcll(m));
+  base = __shfl(base, (int)__builtin_ctzll(m));
+  if (act) ln.list[0][base + __popcll(m & ((1ull << lane) - 1ull))] = l;
+}
+
 // One chunk of an extension without a projecting constraint: every active lane walks up to S steps
 // from C towards its target and emits the candidate edges (w -> q) it would like validated.  The
 // candidates do not depend on the verdicts, so S may exceed 1; the rule checks (joint limits, moved,
@@ -202,7 +216,8 @@ k_rrt_gen(int L, int nplan_arg, int S, double eps, const double *__restrict__ lo
 
 // accept the leading valid candidates of every lane
 __global__ void __launch_bounds__(256)
-k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restrict__ ctr, int *__restrict__ host_slot, int seq) {
+k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restrict__ ctr, int *__restrict__ host_slot, int seq,
+             int next_list) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   // The chunk's counts are closed (the generating kernel is through): leave them in the pinned block the host
   // will look at two chunks from now (RC_SIZE ints and a sequence word written last) ...
@@ -262,13 +277,27 @@ k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restr
     for (int k = wl; k < aj * nplan; k += 64) acc.Q[dst + k] = cd.B[src + k];
     for (int k = wl; k < aj; k += 64) { acc.lane[atj + k] = lj; acc.level[atj + k] = vj + k; }
   }
-  if (!live || n == 0) return;
-  if (keep) {
-    for (int c = 0; c < nplan; c++) ln.C[(int64_t)c * L + l] = cd.B[(int64_t)(f + a - 1) * nplan + c];
-    ln.cnt[l] = lvl0 + a;
+  bool still = live && n == 0;  // (waiting for candidate space: still in the extension)
+  if (live && n > 0) {
+    if (keep) {
+      for (int c = 0; c < nplan; c++) ln.C[(int64_t)c * L + l] = cd.B[(int64_t)(f + a - 1) * nplan + c];
+      ln.cnt[l] = lvl0 + a;
+    }
+    if (!(a > 0 && !keep)) {  // (else: out of room for accepted nodes, the lane was stopped above)
+      if (a < n || ln.gend[l] || arrived) ln.act[l] = 0;
+      else still = true;
+    }
   }
-  if (a > 0 && !keep) return;  // (out of room for accepted nodes: the lane was stopped above)
-  if (a < n || ln.gend[l] || arrived) ln.act[l] = 0;
+  // projecting extensions: the lanes still extending, packed, are the next chunk's rows (next_list: 0 / 1; -1: none kept)
+  if (next_list >= 0) {
+    const unsigned long long m = __ballot(still);
+    if (m != 0ull) {
+      int base = 0;
+      if (wl == (int)__builtin_ctzll(m)) base = atomicAdd(&ctr[RC_LISTN + next_list], __popcll(m));
+      base = __shfl(base, (int)__builtin_ctzll(m));
+      if (still) ln.list[next_list][base + __popcll(m & ((1ull << wl) - 1ull))] = l;
+    }
+  }
 }
 
 // exclusive scan of cnt[L] (deterministic node order: lanes ascending) in three small launches: sums of blocks of
@@ -476,6 +505,10 @@ struct mjpl_rrt {
   //  candidate buffer, 4 L, all the same)
   int proj_steps_max = 1024;
   int64_t proj_slots = 1 << 20;
+  // ... and the shape of the generating launch (mjpl_rows.h; mjpl_hip.hip: rows_shape): lanes per row, waves per launch
+  // (one per SIMD: the kernels' registers) -- MJPL_RRT_PROJ_G / MJPL_RRT_PROJ_WAVES for A/B timing
+  int proj_g = 0;            // 0: lanes per row by the number of active lanes (rows_shape)
+  int proj_waves_max = 1024;
   int *d_ctr = nullptr, *h_ctr = nullptr;
   // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned copies
   int *h_ring = nullptr;      // 4 slots of kRingStride ints: RC_SIZE counters, then the sequence word
@@ -512,6 +545,15 @@ inline unsigned rgrid(int64_t n) { return (unsigned)((n + 255) / 256); }
 // MJPL_RRT_TRACE=1: where a round's wall time goes (stderr; synchronises the stream at every mark)
 struct RrtTrace {
   bool on = getenv("MJPL_RRT_TRACE") != nullptr;
+  bool chunks = on && atoi(getenv("MJPL_RRT_TRACE")) >= 2;  // (2: a line per extension chunk -- the stream is synchronised after every chunk)
+  void chunk(hipStream_t st, int index, int active, int S, int G, unsigned grid) {
+    if (!chunks) return;
+    (void)hipStreamSynchronize(st);
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rrt]   chunk %3d  active <= %7d  S %5d  G %d  waves %5u  %9.3f ms\n", index, active, S, G, grid,
+            std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = std::chrono::steady_clock::now();
+  }
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void mark(hipStream_t st, const char *what, long n = -1) {
     if (!on) return;
@@ -540,9 +582,11 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   int rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, Tgt, L, r->ln.near, nullptr);
   if (rc != MJPL_OK) return rc;
   tr.mark(st, "nearest neighbour", r->n[t]);
+  const bool projecting = r->pose != nullptr;
+  if (projecting) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_LISTN, 0, 2 * sizeof(int), st));  // (both lists of the extension: empty)
   hipLaunchKernelGGL(k_rrt_begin, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->d_Q[t], r->cap, r->ln, r->d_first, Tgt,
                      second, r->d_ctr);
-  const bool projecting = r->pose != nullptr;
+  if (projecting) hipLaunchKernelGGL(k_rrt_list_begin, dim3(rgrid(L)), dim3(256), 0, st, L, r->ln, r->d_ctr);
   int S = projecting ? 1 : 4;
   // With a projecting constraint an extension is hundreds of chunks, the late ones with a handful of lanes:
   // waiting for every chunk's counters before sizing its launches would leave the GPU idle while the host
@@ -565,6 +609,8 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     }
   } ring_guard{r, &chunks_done, st, false};
   int active_bound = L;  // (projecting) no more lanes than this are active in the chunk about to be launched
+  int trace_G = 0;
+  unsigned trace_grid = 0;
   for (int chunk = 0;; chunk++) {
     chunks_done = chunk + 1;
     if (projecting) {
@@ -588,13 +634,28 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
       S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(r->proj_steps_max, r->proj_slots / std::max(1, active_bound)),
                                                       (int64_t)r->cd.cap / std::max(1, active_bound)));
       {
-        const unsigned pgrid = (unsigned)((L + kPoseBlock - 1) / kPoseBlock);
+        // The chunk's rows are the packed list chunk & 1 (at most active_bound entries).  A model's library walks them
+        // with waves that refill (mjpl_rows.h): one lane per row while there are many, four or eight lanes per row once
+        // all of them fit the chip at once (rows_shape) -- the tail of an extension, which is most of its time.
+        const int par = chunk & 1;
         const size_t plds = pose_lds(r->pose) + (size_t)kPoseBlock * sizeof(double) * (size_t)r->nq;
         const int pk = pose_spec_index(r->pose);  // (the chain as straight-line code, if the engine's library has it)
-        // (a library refuses -- nothing launched -- when it was built for another number of planning joints)
-        if (pk < 0 || e->spec->gen_project(pk, st, pgrid, plds, L, nplan, S, r->eps, r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase,
-                                           r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr) != 0) {
-          hipLaunchKernelGGL(k_rrt_gen_project<void>, dim3(pgrid), dim3(kPoseBlock), plds, st, L, nplan, S, r->eps, r->pose->d_pi,
+        int launched = -1;
+        trace_G = 1; trace_grid = (unsigned)((active_bound + kPoseBlock - 1) / kPoseBlock);
+        if (pk >= 0) {
+          const RowsShape rs = r->proj_g > 0 ? RowsShape{r->proj_g, 0u, 0} : rows_shape(active_bound);
+          const int G = rs.G;
+          const int64_t rows_per_wave = 64 / G;
+          const unsigned rgridw = (unsigned)std::max<int64_t>(1, std::min<int64_t>(r->proj_waves_max, (active_bound + rows_per_wave - 1) / rows_per_wave));
+          // (a library refuses -- nothing launched, -1 -- when it was built for another number of planning joints)
+          trace_G = G; trace_grid = rgridw;
+          launched = e->spec->gen_project(pk, G, st, rgridw, L, nplan, S, r->eps, par, r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase,
+                                          r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+          if (launched != 0 && launched != -1) return fail(MJPL_E_HIP, "rrt: the generated extension kernel failed to launch");
+        }
+        if (launched != 0) {
+          const unsigned pgrid = (unsigned)((active_bound + kPoseBlock - 1) / kPoseBlock);
+          hipLaunchKernelGGL(k_rrt_gen_project, dim3(std::max(1u, pgrid)), dim3(kPoseBlock), plds, st, L, nplan, S, r->eps, par, r->pose->d_pi,
                              r->pose->d_pd, r->d_qidx, r->d_qbase, r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
         }
       }
@@ -639,7 +700,9 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
       rc = launch_configs(e, r->cd.B, E, MJPL_AOS, r->cd.valid, nullptr);
     if (rc != MJPL_OK) return rc;
     hipLaunchKernelGGL(k_rrt_accept, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->cd, r->acc, r->d_ctr,
-                       projecting ? r->h_ring + (chunk % 4) * kRingStride : (int *)nullptr, r->ring_seq0 + chunk);
+                       projecting ? r->h_ring + (chunk % 4) * kRingStride : (int *)nullptr, r->ring_seq0 + chunk,
+                       projecting ? ((chunk + 1) & 1) : -1);
+    if (projecting) tr.chunk(st, chunk, active_bound, S, trace_G, trace_grid);
     // chunk sizes double: a chain of n steps costs O(log n) chunks and at most 2x its own checks
     if (!projecting && S < 64) {
       const int64_t room = (int64_t)r->cd.cap / std::max(1, r->h_ctr[RC_ACTIVE]);
@@ -778,6 +841,7 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   RA(r->ln.T, (size_t)nplan * L); RA(r->ln.C, (size_t)nplan * L); RA(r->ln.RA, (size_t)nplan * L);
   RA(r->ln.near, L); RA(r->ln.refA, L); RA(r->ln.refB, L); RA(r->ln.on, L); RA(r->ln.act, L); RA(r->ln.cnt, L); RA(r->ln.off, L);
   RA(r->ln.gfirst, L); RA(r->ln.gcount, L); RA(r->ln.gend, L); RA(r->ln.goal, L);
+  RA(r->ln.list[0], L); RA(r->ln.list[1], L);
   r->cd.cap = (int)std::min<int64_t>(std::max<int64_t>(4 * (int64_t)L, 1 << 16), (int64_t)1 << 27);
   RA(r->cd.A, (size_t)r->cd.cap * nplan); RA(r->cd.B, (size_t)r->cd.cap * nplan); RA(r->cd.lane, r->cd.cap); RA(r->cd.level, r->cd.cap);
   RA(r->cd.valid, r->cd.cap); RA(r->cd.rule, r->cd.cap); RA(r->cd.reach, r->cd.cap);
@@ -794,6 +858,8 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   memset(r->h_ring, 0, 4 * kRingStride * sizeof(int));
   if (const char *v = getenv("MJPL_RRT_PROJ_STEPS")) r->proj_steps_max = std::max(1, atoi(v));
   if (const char *v = getenv("MJPL_RRT_PROJ_SLOTS")) r->proj_slots = std::max(1, atoi(v));
+  if (const char *v = getenv("MJPL_RRT_PROJ_G")) { const int g = atoi(v); r->proj_g = (g == 1 || g == 4 || g == 8) ? g : 0; }
+  if (const char *v = getenv("MJPL_RRT_PROJ_WAVES")) r->proj_waves_max = std::max(1, atoi(v));
   HIP_TRY(hipHostMalloc((void **)&r->h_heads, 8 * 1024 * sizeof(int)));
   HIP_TRY(hipHostMalloc((void **)&r->h_myhead, 8 * sizeof(int)));
   std::vector<uint8_t> isplan(r->nq, 0);

@@ -997,77 +997,87 @@ def pose_site_bodies(model) -> list[int]:
     return sorted({int(b) for b in np.asarray(model.site_bodyid).reshape(-1) if int(b) > 0})
 
 
-def generate_pose(pi, pd, hash_: int, index: int) -> str:
-    """`struct PoseSpec<index>`: mj_kinematics along one chain with the model's constants as literals -- the
-    statements of pose_chain (mjpl_pose.h) in the same order, calling the same routines, so the same float64 values;
-    what goes away is the reading of the chain program (scalar loads in a dependent chain, loop control) and the
-    trip through LDS of the joints' axes and anchors."""
+def generate_pose(pi, pd, hash_: int, index: int, qualifier: str = "static __device__ __forceinline__", fold: bool = True) -> str:
+    """`struct PoseSpec<index>`: mj_kinematics along one chain with the model's constants folded in (mjpl_amd/fold.py):
+    the operations of pose_chain (mjpl_pose.h) in the same order, minus those whose result the constants decide
+    (products with an exact 0 or 1, sums with an exact 0) -- the same float64 values up to the sign of exact zeros.
+    The half-angle sines and cosines of the hinges are arguments: the caller computes them, one joint after the other
+    or one joint per lane of a row's group (mjpl_project.h).  What goes away against the interpreting kernel: the
+    reading of the chain program, the loop control, the trip through LDS of the joints' axes and anchors, and about
+    half of the chain's arithmetic.  qualifier: how the member functions are declared (tests compile a chain for the host)."""
+    from .fold import Fold
     nb, nj, nq = int(pi[PH_NBODY]), int(pi[PH_NJOINT]), int(pi[PH_NQ])
-    out = []
-    o = out.append
-
-    def arr(v):
-        return "{" + ", ".join(dlit(x) for x in v) + "}"
-    jtypes, qadrs, jids = [], [], []
-    body = []
-    b_ = body.append
+    f = Fold(indent="    ", fold=fold)  # (fold=False: every operation of the statement, for tests)
+    c, v = f.c, f.v
+    jtypes, qadrs, jids, q0s = [], [], [], []
+    p, qt = [c(0), c(0), c(0)], [c(1), c(0), c(0), c(0)]
+    R = [c(x) for x in (1, 0, 0, 0, 1, 0, 0, 0, 1)]
     ic, dc, jk = PH_SIZE, 0, 0
     for b in range(nb):
         njnt = int(pi[ic]); ic += 1
-        b_(f"    {{  // chain body {b}")
-        b_("      double np[3], nq[4];")
-        b_(f"      {{ const double bpos[3] = {arr(pd[dc:dc + 3])}, bquat[4] = {arr(pd[dc + 3:dc + 7])};")
+        f.emit(f"// chain body {b}")
+        bpos, bquat = [c(x) for x in pd[dc:dc + 3]], [c(x) for x in pd[dc + 3:dc + 7]]
         dc += 7
-        b_("        mul_mat_vec3(np, R, bpos);")
-        b_("        np[0] += p[0]; np[1] += p[1]; np[2] += p[2];")
-        b_("        mul_quat(nq, qt, bquat); }")
+        np_ = [f.add(x, y) for x, y in zip(f.mul_mat_vec3(R, bpos), p)]
+        nq_ = f.mul_quat(qt, bquat)
         for j in range(njnt):
             jtype, qadr, jid = int(pi[ic]), int(pi[ic + 1]), int(pi[ic + 2]); ic += 3
-            jtypes.append(jtype); qadrs.append(qadr); jids.append(jid)
-            b_(f"      {{ const double jaxis[3] = {arr(pd[dc:dc + 3])}, jpos[3] = {arr(pd[dc + 3:dc + 6])};")
-            b_(f"        const double dq = q[{qadr}] - {dlit(pd[dc + 6])};")
+            jtypes.append(jtype); qadrs.append(qadr); jids.append(jid); q0s.append(float(pd[dc + 6]))
+            jaxis, jpos = [c(x) for x in pd[dc:dc + 3]], [c(x) for x in pd[dc + 3:dc + 6]]
+            dq = f.sub(v(f"q[{qadr}]"), c(pd[dc + 6]))
             dc += 7
-            b_("        double xaxis[3], xanchor[3];")
-            b_("        rot_vec_quat(xaxis, jaxis, nq);")
-            b_("        rot_vec_quat(xanchor, jpos, nq);")
-            b_("        xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];")
-            b_(f"        jx[{jk}][0] = xaxis[0]; jx[{jk}][1] = xaxis[1]; jx[{jk}][2] = xaxis[2];")
-            b_(f"        jx[{jk}][3] = xanchor[0]; jx[{jk}][4] = xanchor[1]; jx[{jk}][5] = xanchor[2];")
+            xaxis = f.rot_vec_quat(jaxis, nq_)
+            xanchor = [f.add(x, y) for x, y in zip(f.rot_vec_quat(jpos, nq_), np_)]
+            for r in range(3):
+                f.emit(f"jx[{jk}][{r}] = {f.text(xaxis[r])}; jx[{jk}][{3 + r}] = {f.text(xanchor[r])};")
             if jtype == JT_SLIDE:
-                b_("        np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq; }")
+                np_ = [f.add(np_[r], f.mul(xaxis[r], dq)) for r in range(3)]
             else:
-                b_("        double sn, cs, vec[3];")
-                b_("        sincos_half(dq * 0.5, &sn, &cs);")
-                b_("        const double qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};")
-                b_("        mul_quat(nq, nq, qloc);")
-                b_("        rot_vec_quat(vec, jpos, nq);")
-                b_("        np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2]; }")
+                sn, cs = v(f"sn[{jk}]"), v(f"cs[{jk}]")
+                qloc = [cs, f.mul(jaxis[0], sn), f.mul(jaxis[1], sn), f.mul(jaxis[2], sn)]
+                nq_ = f.mul_quat(nq_, qloc)
+                vec = f.rot_vec_quat(jpos, nq_)
+                np_ = [f.sub(xanchor[r], vec[r]) for r in range(3)]
             jk += 1
-        b_("      normalize4(nq);")
-        b_("      p[0] = np[0]; p[1] = np[1]; p[2] = np[2];")
-        b_("      qt[0] = nq[0]; qt[1] = nq[1]; qt[2] = nq[2]; qt[3] = nq[3];")
-        b_("      quat2mat(R, qt);")
-        b_("    }")
+        nq_ = f.normalize4(nq_)
+        p, qt = np_, nq_
+        R = f.quat2mat(qt)
     assert jk == nj
-    o(f"// GENERATED: chain program {hash_:016x} -- {nb} bodies, {nj} joints, nq {nq}")
+    f.emit("// the site (mj_local2Global)")
+    spos = [v(f"tail[mjpl::PT_SITE_POS + {k}]") for k in range(3)]
+    squat = [v(f"tail[mjpl::PT_SITE_QUAT + {k}]") for k in range(4)]
+    sp = f.mul_mat_vec3(R, spos)
+    for k in range(3):
+        f.emit(f"out.site_xpos[{k}] = {f.text(f.add(sp[k], p[k]))};")
+    sm = f.quat2mat(f.mul_quat(qt, squat))
+    for k in range(9):
+        f.emit(f"out.site_xmat[{k}] = {f.text(sm[k])};")
+    out = []
+    o = out.append
+    njx = max(nj, 1)
+    tab = lambda vals: ", ".join(str(x) for x in vals) or "0"  # noqa: E731
+    o(f"// GENERATED: chain program {hash_:016x} -- {nb} bodies, {nj} joints, nq {nq}; "
+      f"{f.ops['mul']} products, {f.ops['add']} sums, {f.ops['sqrt']} square roots after folding")
     o(f"struct PoseSpec{index} {{")
     o(f"  static constexpr int kNQ = {nq}, kNJ = {nj};")
     o(f"  static constexpr unsigned long long kHash = 0x{hash_:016x}ull;")
-    o(f"  static __device__ __forceinline__ constexpr int jtype(int k) {{ constexpr int t[{max(nj, 1)}] = {{{', '.join(str(x) for x in jtypes) or '0'}}}; return t[k]; }}")
-    o(f"  static __device__ __forceinline__ constexpr int qadr(int k) {{ constexpr int t[{max(nj, 1)}] = {{{', '.join(str(x) for x in qadrs) or '0'}}}; return t[k]; }}")
-    o(f"  static __device__ __forceinline__ constexpr int jid(int k) {{ constexpr int t[{max(nj, 1)}] = {{{', '.join(str(x) for x in jids) or '0'}}}; return t[k]; }}")
-    o(f"  static __device__ __forceinline__ void chain(const double (&q)[{nq}], double (&jx)[{max(nj, 1)}][6], mjpl::PoseChainOut &out,")
-    o("                                               const double *tail) {")
-    o("    using namespace mjpl;")
-    o("    double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};")
-    out.extend(body)
-    o("    const double spos[3] = {tail[PT_SITE_POS], tail[PT_SITE_POS + 1], tail[PT_SITE_POS + 2]};")
-    o("    const double squat[4] = {tail[PT_SITE_QUAT], tail[PT_SITE_QUAT + 1], tail[PT_SITE_QUAT + 2], tail[PT_SITE_QUAT + 3]};")
-    o("    double sp[3], sq[4];")
-    o("    mul_mat_vec3(sp, R, spos);")
-    o("    out.site_xpos[0] = sp[0] + p[0]; out.site_xpos[1] = sp[1] + p[1]; out.site_xpos[2] = sp[2] + p[2];")
-    o("    mul_quat(sq, qt, squat);")
-    o("    quat2mat(out.site_xmat, sq);")
+    o(f"  {qualifier} constexpr int jtype(int k) {{ constexpr int t[{njx}] = {{{tab(jtypes)}}}; return t[k]; }}")
+    o(f"  {qualifier} constexpr int qadr(int k) {{ constexpr int t[{njx}] = {{{tab(qadrs)}}}; return t[k]; }}")
+    o(f"  {qualifier} constexpr int jid(int k) {{ constexpr int t[{njx}] = {{{tab(jids)}}}; return t[k]; }}")
+    o("  // half the angle of chain joint k (a hinge's: what its sine and cosine are taken of; 0 for a slide joint)")
+    o(f"  {qualifier} double half_angle(int k, const double (&q)[{nq}]) {{")
+    o("    switch (k) {")
+    for k in range(nj):
+        if jtypes[k] == JT_HINGE:
+            h = Fold(indent="")
+            o(f"      case {k}: return {h.text(h.sub(h.v(f'q[{qadrs[k]}]'), h.c(q0s[k])))} * 0.5;" if q0s[k] == 0.0 else
+              f"      case {k}: return (q[{qadrs[k]}] - {dlit(q0s[k])}) * 0.5;")
+    o("      default: return 0.0;")
+    o("    }")
+    o("  }")
+    o(f"  {qualifier} void chain(const double (&q)[{nq}], const double (&sn)[{njx}], const double (&cs)[{njx}], double (&jx)[{njx}][6],")
+    o("                                               mjpl::PoseChainOut &out, const double *tail) {")
+    out.extend(f.lines)
     o("  }")
     o("};")
     return "\n".join(out) + "\n"
@@ -1088,26 +1098,35 @@ def generate_pose_section(model, nplan: int = 0) -> str:
            "unsigned long long mjpl_spec_pose_hash(int k) {", "  switch (k) {"]
     src += [f"    case {k}: return PoseSpec{k}::kHash;" for k, _, _ in specs]
     src += ["    default: return 0ull;", "  }", "}"]
-    src += ["int mjpl_spec_launch_pose_apply(int k, hipStream_t st, unsigned grid, size_t lds, const int *pi, const double *pd, const double *Qold,",
-            "                                const double *Q, int64_t N, double *Qout, uint8_t *ok, int32_t *iters) {", "  switch (k) {"]
-    src += [f"    case {k}: hipLaunchKernelGGL(mjpl::k_pose_apply<PoseSpec{k}>, dim3(grid), dim3(mjpl::kPoseBlock), lds, st, pi, pd, Qold, Q, N, Qout, ok, iters); break;"
-            for k, _, _ in specs]
-    src += ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -1;", "}"]
-    src += ["int mjpl_spec_launch_gen_project(int k, hipStream_t st, unsigned grid, size_t lds, int L, int nplan, int S, double eps, const int *pi,",
+    # Launchers of the row kernels (mjpl_rows.h).  G: lanes per row (1, 4 or 8); return 0 = launched, -1 = refused with
+    # nothing launched (no such projection / lane count / number of planning joints: the caller takes the interpreting
+    # kernel), -2 = the launch failed (a HIP error the caller reports; hipGetLastError has cleared it).
+    done = ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -2;", "}"]
+
+    def cases(fmt):
+        out = []
+        for k, _, _ in specs:
+            out += [f"    case {3 * k + i}: " + fmt.format(k=k, g=g) + " break;" for i, g in enumerate((1, 4, 8))]
+        return out
+    pick = ["  if (G != 1 && G != 4 && G != 8) return -1;", "  switch (3 * k + (G == 8 ? 2 : (G == 4 ? 1 : 0))) {"]
+    src += ["int mjpl_spec_launch_pose_apply(int k, int G, hipStream_t st, unsigned grid, const int *pi, const double *pd, const double *Qold,",
+            "                                const double *Q, int64_t N, int64_t per, double *Qout, uint8_t *ok, int32_t *iters) {"] + pick
+    src += cases("hipLaunchKernelGGL((mjpl::k_pose_apply_rows<PoseSpec{k}, {g}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, pi, pd, Qold, Q, N, per, Qout, ok, iters);")
+    src += done
+    src += ["int mjpl_spec_launch_gen_project(int k, int G, hipStream_t st, unsigned grid, int L, int nplan, int S, double eps, int par, const int *pi,",
             "                                 const double *pd, const int *qidx, const double *qbase, const uint8_t *isplan, const double *lo,",
-            "                                 const double *hi, const double *Tgt, mjpl::RrtLanes ln, mjpl::RrtCand cd, int *ctr) {", "  switch (k) {"]
+            "                                 const double *hi, const double *Tgt, mjpl::RrtLanes ln, mjpl::RrtCand cd, int *ctr) {"]
     np_ = int(nplan) if 0 < int(nplan) <= 16 else 0
     if np_:
-        src += [f"  if (nplan != {np_}) return -1;  // (the library's program plans {np_} joints)"]
-        src[-1], src[-2] = src[-2], src[-1]  # (the check goes in front of the switch)
-    src += [f"    case {k}: hipLaunchKernelGGL((mjpl::k_rrt_gen_project<PoseSpec{k}, {np_}>), dim3(grid), dim3(mjpl::kPoseBlock), lds, st, L, nplan, S, eps, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr); break;"
-            for k, _, _ in specs]
-    src += ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -1;", "}"]
-    src += ["int mjpl_spec_launch_ik_solve(int k, hipStream_t st, unsigned grid, size_t lds, const int *pi, const double *pd, const double *Q, int64_t N,",
-            "                               double *Qout, uint8_t *ok, int32_t *iters, double *err, int max_restarts, unsigned long long restart_seed) {", "  switch (k) {"]
-    src += [f"    case {k}: hipLaunchKernelGGL(mjpl::k_ik_solve<PoseSpec{k}>, dim3(grid), dim3(mjpl::kPoseBlock), lds, st, pi, pd, Q, N, Qout, ok, iters, err, max_restarts, (uint64_t)restart_seed); break;"
-            for k, _, _ in specs]
-    src += ["    default: return -1;", "  }", "  return hipGetLastError() == hipSuccess ? 0 : -1;", "}", "}"]
+        src += [f"  if (nplan != {np_}) return -1;  // (the library's program plans {np_} joints)"] + pick
+        src += cases("hipLaunchKernelGGL((mjpl::k_rrt_gen_project_rows<PoseSpec{k}, " + str(np_) + ", {g}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, L, S, eps, par, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr);")
+        src += done
+    else:
+        src += ["  return -1;  // (the number of planning joints is not a constant of this library)", "}"]
+    src += ["int mjpl_spec_launch_ik_solve(int k, int G, hipStream_t st, unsigned grid, const int *pi, const double *pd, const double *Q, int64_t N, int64_t per,",
+            "                               double *Qout, uint8_t *ok, int32_t *iters, double *err, int max_restarts, unsigned long long restart_seed) {"] + pick
+    src += cases("hipLaunchKernelGGL((mjpl::k_ik_solve_rows<PoseSpec{k}, {g}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, pi, pd, Q, N, per, Qout, ok, iters, err, max_restarts, (uint64_t)restart_seed);")
+    src += done + ["}"]
     return "\n".join(src) + "\n"
 
 
@@ -1149,7 +1168,7 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
     os.makedirs(SPEC_DIR, exist_ok=True)
     key = info.robot_hash if generic else info.hash
     target = output or spec_path(key, generic)  # (output, extra_flags: timing-only variants, tools/time_variants.sh)
-    deps = [os.path.join(_build.CSRC, f) for f in _build.STAMPED_HEADERS] + [__file__]
+    deps = [os.path.join(_build.CSRC, f) for f in _build.STAMPED_HEADERS] + [__file__, os.path.join(os.path.dirname(__file__), "fold.py")]
     if not force and os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
         return target
     nstage = 0

@@ -158,7 +158,7 @@ def test_program_dump_and_code_generation_need_no_gpu():
         assert info.hash == info2.hash and np.array_equal(ip, ip2) and np.array_equal(fp.view(np.uint32), fp2.view(np.uint32))
         assert info.hash not in seen, name
         seen.add(info.hash)
-        assert not info.immediate and info.filter_usable and info.spec_abi == 13
+        assert not info.immediate and info.filter_usable and info.spec_abi == 14
         np.testing.assert_allclose(fp[np.isfinite(fp)], dp[np.isfinite(fp)].astype(np.float32), rtol=2e-5, atol=2e-4)
         src = specialise.generate(ip, fp, dp, info)
         culls = (src.count("MJPL_SPEC_CULLX(") + 2 * src.count("MJPL_SPEC_CULLX2(") + src.count("MJPL_SPEC_CULL(") +
@@ -196,8 +196,10 @@ def test_program_dump_and_code_generation_need_no_gpu():
 
 def test_pose_chain_dump_and_generated_projection_need_no_gpu():
     """mjpl_pose_chain_dump compiles the chain program of a (model, site body) on the host; specialise.generate_pose
-    turns it into straight-line code: one block per chain body, one sincos per hinge, the hash a handle looks its
-    projection up by -- which depends on the chain's constants and not on anything else of the model."""
+    turns it into straight-line code (constants folded, mjpl_amd/fold.py): one block per chain body, the hinges' half-angle
+    sines and cosines as ARGUMENTS (the row kernels compute them, one joint per lane of a row's group or one after the
+    other), the hash a handle looks its projection up by -- which depends on the chain's constants and not on anything
+    else of the model."""
     from mjpl_amd import scenes, specialise
     m = scenes.franka_p(obstacles=True)
     bodies = specialise.pose_site_bodies(m)
@@ -209,7 +211,10 @@ def test_pose_chain_dump_and_generated_projection_need_no_gpu():
     assert (nj, nq) == (7, 9) and nb >= 8 and len(pd) == 7 * (nb + nj)
     src = specialise.generate_pose(pi, pd, h, 0)
     assert "struct PoseSpec0" in src and f"kNQ = {nq}, kNJ = {nj}" in src and f"{h:016x}" in src
-    assert src.count("// chain body") == nb and src.count("sincos_half(") == nj
+    assert src.count("// chain body") == nb and "sincos" not in src and src.count(": return q[") == nj  # (half_angle: one case per hinge)
+    assert "const double (&sn)[7], const double (&cs)[7]" in src and "pd[" not in src and "pi[" not in src
+    folded, plain = (specialise.generate_pose(pi, pd, h, 0, fold=f).count(" * ") for f in (True, False))
+    assert folded < 0.5 * plain  # (more than half of the statement's products have a factor the constants decide)
     m2 = scenes.franka_p(obstacles=True)
     m2.body_pos[3, 2] += 1e-9  # one constant of the chain, far below anything a test would notice
     assert specialise.dump_pose_chain(m2, bodies[0])[2] != h

@@ -1,0 +1,144 @@
+"""The generated chain (mjpl_amd/fold.py, specialise.generate_pose) on the CPU: the folded straight-line code, compiled
+for the host with the library's floating-point flags, against (1) the same generator with folding off -- every operation
+of pose_chain's statement executed -- and (2) the oracle's chain (oracle/mjpl_oracle_pose.c: chain_kinematics).
+Equality is by value (`==`): folding products with an exact zero may change the sign of an exact zero, nothing else."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mjpl_amd as mjpl
+from mjpl_amd import build as _build
+from mjpl_amd import scenes
+from mjpl_amd import specialise as sp
+from mjpl_amd.fold import Fold, unit_interval
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+_HARNESS = r"""
+#include <cmath>
+#include <cstdint>
+#include "mjpl_trig.h"
+namespace mjpl {
+struct PoseChainOut { double site_xpos[3], site_xmat[9]; };
+enum : int { PT_SITE_POS = 0, PT_SITE_QUAT = 3 };
+}
+namespace folded {
+%(folded)s
+}
+namespace plain {
+%(plain)s
+}
+template <class PS>
+static void run(const double *q_, const double *tail, double *xpos, double *xmat, double *jx_) {
+  double q[PS::kNQ], sn[PS::kNJ > 0 ? PS::kNJ : 1], cs[PS::kNJ > 0 ? PS::kNJ : 1], jx[PS::kNJ > 0 ? PS::kNJ : 1][6];
+  for (int k = 0; k < PS::kNQ; k++) q[k] = q_[k];
+  for (int k = 0; k < PS::kNJ; k++) {
+    sn[k] = 0; cs[k] = 1;
+    if (PS::jtype(k) == 3) mjpl::sincos_pi2(PS::half_angle(k, q), &sn[k], &cs[k]);
+  }
+  mjpl::PoseChainOut o;
+  PS::chain(q, sn, cs, jx, o, tail);
+  for (int k = 0; k < 3; k++) xpos[k] = o.site_xpos[k];
+  for (int k = 0; k < 9; k++) xmat[k] = o.site_xmat[k];
+  for (int k = 0; k < PS::kNJ; k++) for (int r = 0; r < 6; r++) jx_[6 * k + r] = jx[k][r];
+}
+extern "C" void chain_folded(const double *q, const double *tail, double *xpos, double *xmat, double *jx) { run<folded::PoseSpec0>(q, tail, xpos, xmat, jx); }
+extern "C" void chain_plain(const double *q, const double *tail, double *xpos, double *xmat, double *jx) { run<plain::PoseSpec0>(q, tail, xpos, xmat, jx); }
+"""
+
+
+def _compile(model, site_body, tmp_path, tag):
+    pi, pd, h = sp.dump_pose_chain(model, site_body)
+    kw = dict(qualifier="static inline")
+    src = _HARNESS % dict(folded=sp.generate_pose(pi, pd, h, 0, **kw), plain=sp.generate_pose(pi, pd, h, 0, fold=False, **kw))
+    cpp, so = tmp_path / f"chain_{tag}.cpp", tmp_path / f"chain_{tag}.so"
+    cpp.write_text(src)
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-shared", "-fPIC", f"-I{_build.CSRC}", "-o", str(so), str(cpp)],
+                   check=True)
+    lib = C.CDLL(str(so))
+    nj = int(pi[sp.PH_NJOINT])
+    P = C.POINTER(C.c_double)
+
+    def call(fn, q, tail):
+        q, tail = np.ascontiguousarray(q, np.float64), np.ascontiguousarray(tail, np.float64)
+        xpos, xmat, jx = np.zeros(3), np.zeros(9), np.zeros((max(nj, 1), 6))
+        getattr(lib, fn)(q.ctypes.data_as(P), tail.ctypes.data_as(P), xpos.ctypes.data_as(P), xmat.ctypes.data_as(P), jx.ctypes.data_as(P))
+        return xpos, xmat, jx[:nj]
+    return call, nj
+
+
+def _cases():
+    from test_gpu_models import random_model  # (no GPU needed to build a model)
+    yield "franka", scenes.franka_p(obstacles=False), "ee_site"
+    yield "ur5e", scenes.ur5e(), "attachment_site"
+    yield "ball", scenes.two_dof_ball(), "ball_site"
+    import dataclasses
+    for seed in (3, 8):
+        model, _ = random_model(seed, moving_boxes=False)
+        q = np.array([0.5, 0.5, -0.5, 0.5])
+        model = dataclasses.replace(model, nsite=1, site_bodyid=np.array([model.nbody - 1], np.int32),
+                                    site_pos=np.array([[0.05, -0.02, 0.08]]), site_quat=q[None] / np.linalg.norm(q), site_names=["tip"])
+        yield f"random{seed}", model, "tip"
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_folded_chain_equals_the_statement_and_the_oracle(case, oracle_mod, tmp_path):
+    tag, model, site = case
+    sid = model.site_names.index(site) if hasattr(model, "site_names") else model.site(site).id
+    body = int(np.asarray(model.site_bodyid).reshape(-1)[sid])
+    call, nj = _compile(model, body, tmp_path, tag)
+    tail = np.concatenate([np.asarray(model.site_pos, np.float64).reshape(-1, 3)[sid], np.asarray(model.site_quat, np.float64).reshape(-1, 4)[sid]])
+    ident = (np.array([1.0, 0, 0, 0]), np.zeros(3))
+    po = oracle_mod.PoseOracle(model, site, ident, [(-np.inf, np.inf)] * 6)
+    rng = np.random.default_rng(5)
+    lo, hi = np.asarray(model.jnt_range)[:, 0], np.asarray(model.jnt_range)[:, 1]
+    Q = rng.uniform(lo, hi, size=(400, model.nq))
+    Q[0] = np.asarray(model.qpos0, np.float64)
+    Q[1] = 0.0
+    Q[2], Q[3] = lo, hi
+    Q[4:40] = np.asarray(model.qpos0, np.float64) + rng.normal(scale=1e-3, size=(36, model.nq))
+    with oracle_mod.portable_trig():
+        for q in Q:
+            a, b = call("chain_folded", q, tail), call("chain_plain", q, tail)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (tag, q)
+            p, R = po.site_pose(q)
+            assert np.array_equal(a[0], np.asarray(p)) and np.array_equal(a[1], np.asarray(R).reshape(-1)), (tag, q)
+
+
+def test_unit_interval_is_the_statements_condition():
+    import math
+    lo, hi = unit_interval(1e-15)
+
+    def inside(s):
+        n = math.sqrt(s)
+        return not (n < 1e-15) and not (abs(n - 1.0) > 1e-15)
+    x = lo
+    while x <= hi:
+        assert inside(x)
+        x = math.nextafter(x, math.inf)
+    for edge, d in ((lo, -math.inf), (hi, math.inf)):
+        x = edge
+        for _ in range(500):
+            x = math.nextafter(x, d)
+            assert not inside(x)
+    for s in (0.0, 1e-31, 0.5, 2.0, math.inf):
+        assert not inside(s) and not (lo <= s <= hi)
+
+
+def test_fold_rules():
+    f = Fold()
+    a, b = f.v("a"), f.v("b")
+    assert f.mul(a, f.c(0.0)) == ("c", 0.0) and f.mul(f.c(-0.0), b) == ("c", 0.0)
+    assert f.mul(a, f.c(1.0)) == a and f.mul(f.c(-1.0), a) == f.neg(a)
+    assert f.add(a, f.c(0.0)) == a and f.sub(a, f.c(0.0)) == a and f.sub(f.c(0.0), a) == f.neg(a)
+    assert f.mul(f.c(3.0), f.c(0.1)) == ("c", 3.0 * 0.1)
+    assert not f.lines
+    t = f.sub(f.mul(f.neg(a), b), f.mul(a, f.c(-2.5)))  # -(a b) + 2.5 a
+    assert f.text(t) == "t2"
+    assert f.lines == ["    const double t0 = a * b;", "    const double t1 = a * 0x1.4000000000000p+1;", "    const double t2 = t1 - t0;"]

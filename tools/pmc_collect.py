@@ -52,6 +52,24 @@ def main():
                     rec[k] = fr[k]
             rec["flops_source"] = f"profiles/{os.path.basename(fl)} (tools/profile_next_rows.sh {flops_tag})"
         out[f"{kernel}_{E}_{layout}_f{filt}_s{spec}"] = rec
+    # the next rows' lines (bench.py --workload pose / ik / rrt / configs): keyed by kernel and workload size; the
+    # duration is the kernel's average in the SAME profiling round's kernel trace (pmc_summary.py: avg_ns, calls)
+    next_rows = {"k_pose_apply_rows": ("pose", 131072, 1), "k_ik_solve_rows": ("ik", 16384, 1),
+                 "k_rrt_gen_project_rows": ("rrt", 131072, 1), "k_nearest_mfma": ("rrt", 131072, 1), "k_filter_configs": ("configs", 65536, 1)}
+    for kernel, (workload, size, timed_steps) in next_rows.items():
+        p = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kernel}.json")
+        if not os.path.exists(p):
+            continue
+        with open(p) as f:
+            r = json.load(f)
+        rec = {k: r[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES",
+                                 "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE", "avg_ns", "calls") if k in r}
+        if workload == "rrt" and "calls" in r:
+            # (the profiled command runs one timed round after the warm-up round of single-node trees, whose launches are
+            #  counted with it: a handful of microsecond-long ones)
+            rec["calls_per_round"] = r["calls"] / float(timed_steps)
+        rec["source"] = f"profiles/{os.path.basename(p)} + profiles/{tag}_{workload}_kernel_stats.csv (tools/profile_next_rows.sh {tag})"
+        out[f"{kernel}_{workload}{size}"] = rec
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v.get("source") for k, v in out.items()}, indent=1))

@@ -24,11 +24,15 @@ def main():
     for path in glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True):
         if "trace_streams" in path:  # (the bench line's own mode, kernels of several streams overlapping: not a kernel alone)
             continue
+        total_ns, calls = 0.0, 0
         with open(path) as f:
-            for row in csv.DictReader(f):
+            for row in csv.DictReader(f):  # (a template's instantiations are rows of their own: one kernel to this summary)
                 if kern in row["Name"] and (kern + "_f64" not in row["Name"] or kern.endswith("_f64")):
-                    res["avg_ns"] = float(row["AverageNs"])
-                    res["calls"] = int(row["Calls"])
+                    total_ns += float(row["TotalDurationNs"])
+                    calls += int(row["Calls"])
+        if calls:
+            res["avg_ns"] = total_ns / calls
+            res["calls"] = calls
     if "FETCH_SIZE" in res or "WRITE_SIZE" in res:
         # rocprofv3 reports KiB; FETCH_SIZE x2 per the gfx950 correction
         res["hbm_bytes_per_launch"] = (2 * res.get("FETCH_SIZE", 0.0) + res.get("WRITE_SIZE", 0.0)) * 1024

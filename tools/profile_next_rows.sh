@@ -6,7 +6,7 @@ set -u
 TAG=${1:-run}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for W in "pose:--steps 5 --warmup 1" "rrt:--steps 1" "ik:--steps 2 --warmup 1"; do
+for W in "pose:--steps 5 --warmup 1" "rrt:--steps 1" "ik:--steps 2 --warmup 1" "configs:--steps 5 --warmup 1"; do
   NAME=${W%%:*}; ARGS=${W#*:}
   OUT=$R/gpurun_out/prof_${TAG}_$NAME
   mkdir -p $OUT
@@ -18,10 +18,11 @@ for W in "pose:--steps 5 --warmup 1" "rrt:--steps 1" "ik:--steps 2 --warmup 1"; 
   cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv
 done
 cd $R
-python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_pose k_pose_apply gpurun_out/${TAG}_pmc_k_pose_apply.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_pose k_pose_apply_rows gpurun_out/${TAG}_pmc_k_pose_apply_rows.json > /dev/null
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_nearest_mfma gpurun_out/${TAG}_pmc_k_nearest_mfma.json > /dev/null
-python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_rrt_gen_project gpurun_out/${TAG}_pmc_k_rrt_gen_project.json > /dev/null
-python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_ik k_ik_solve gpurun_out/${TAG}_pmc_k_ik_solve.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_rrt_gen_project_rows gpurun_out/${TAG}_pmc_k_rrt_gen_project_rows.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_ik k_ik_solve_rows gpurun_out/${TAG}_pmc_k_ik_solve_rows.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_configs k_filter_configs gpurun_out/${TAG}_pmc_k_filter_configs.json > /dev/null
 # the float64 pool kernel's issued floating-point instruction mix (bench --variant f64: k_edges_fused_f64)
 OUT=$R/gpurun_out/prof_${TAG}_f64flops
 cd /tmp
@@ -30,4 +31,4 @@ cd $R
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_f64flops k_edges_fused_f64 gpurun_out/${TAG}_pmc_flops_k_edges_fused_f64.json > /dev/null
 ls gpurun_out/${TAG}_*
 # (the raw rocprofv3 output is bulky and gpurun_out/ travels back only below 64 MiB: the summaries are what is kept)
-rm -rf gpurun_out/prof_${TAG}_pose gpurun_out/prof_${TAG}_rrt gpurun_out/prof_${TAG}_ik gpurun_out/prof_${TAG}_f64flops
+rm -rf gpurun_out/prof_${TAG}_pose gpurun_out/prof_${TAG}_rrt gpurun_out/prof_${TAG}_ik gpurun_out/prof_${TAG}_configs gpurun_out/prof_${TAG}_f64flops
