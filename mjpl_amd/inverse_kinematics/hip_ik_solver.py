@@ -46,6 +46,8 @@ class HipIKSolver(IKSolver):
         # A launch lasts as long as its slowest seed -- the full iteration budget whenever one seed does not converge,
         # 23 us per iteration -- while most seeds that converge at all do so within ~50 iterations: an attempt first runs
         # with this many iterations and only if NO seed came back valid with the whole budget (0: always the whole budget).
+        # The caller's guess (row 0 of the first attempt) is the exception: if the quick pass did not solve IT, it alone
+        # runs again with the whole budget, so which solution is closest to the guess does not depend on this number.
         self.quick_iterations = quick_iterations
         self._owns_engine = engine is None
         self.engine = engine if engine is not None else _engine.Engine(model, device=device)
@@ -106,6 +108,16 @@ class HipIKSolver(IKSolver):
             good = np.zeros(0, bool)
             if 0 < self.quick_iterations < self.iterations:
                 Q, good, _ = self.solve_batch(pose, site, seeds, iterations=self.quick_iterations)
+                if good.any() and q_init_guess is not None and attempt == 0 and not good[0]:
+                    # The guess itself (row 0) gets the WHOLE budget whatever the quick pass found: the Cartesian planner
+                    # takes the solution closest to the guess (cartesian_planner.py:101-102), and a guess that needs more
+                    # than quick_iterations must not lose to a far-away re-draw that converged quickly.  One seed, one launch.
+                    quick_stats = self.stats
+                    Q0, g0, _ = self.solve_batch(pose, site, seeds[:1])
+                    self.stats = dict(quick_stats, guess_with_whole_budget=bool(g0[0]), guess_iters=self.stats["mean_iters"])
+                    if g0[0]:
+                        Q, good = Q.copy(), good.copy()
+                        Q[0], good[0] = Q0[0], True
             if not good.any():
                 Q, good, _ = self.solve_batch(pose, site, seeds)
             if good.any():

@@ -10,6 +10,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# kernels of the next rows' lines: (bench.py --workload, rows per launch, timed steps of the profiled command)
+NEXT_ROWS = {"k_pose_apply_rows": ("pose", 131072, 1), "k_ik_solve_rows": ("ik", 16384, 1),
+             "k_rrt_gen_project_rows": ("rrt", 131072, 1), "k_nearest_mfma": ("rrt", 131072, 1), "k_filter_configs": ("configs", 65536, 1)}
 
 
 def main():
@@ -28,7 +31,7 @@ def main():
     edge_kernels = ("k_edges_fused", "k_filter_", "k_tail", "k_check_edges", "k_patch_pairs")  # (the headline workload's; the next rows' are not keyed here)
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_pmc_*.json"))):
         kernel = os.path.basename(p)[len(tag) + 5:-5]
-        if not kernel.startswith(edge_kernels):
+        if not kernel.startswith(edge_kernels) or kernel in NEXT_ROWS:
             continue
         with open(p) as f:
             r = json.load(f)
@@ -54,9 +57,7 @@ def main():
         out[f"{kernel}_{E}_{layout}_f{filt}_s{spec}"] = rec
     # the next rows' lines (bench.py --workload pose / ik / rrt / configs): keyed by kernel and workload size; the
     # duration is the kernel's average in the SAME profiling round's kernel trace (pmc_summary.py: avg_ns, calls)
-    next_rows = {"k_pose_apply_rows": ("pose", 131072, 1), "k_ik_solve_rows": ("ik", 16384, 1),
-                 "k_rrt_gen_project_rows": ("rrt", 131072, 1), "k_nearest_mfma": ("rrt", 131072, 1), "k_filter_configs": ("configs", 65536, 1)}
-    for kernel, (workload, size, timed_steps) in next_rows.items():
+    for kernel, (workload, size, timed_steps) in NEXT_ROWS.items():
         p = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kernel}.json")
         if not os.path.exists(p):
             continue
