@@ -987,6 +987,16 @@ def main():
                               "frac": BYTES_PER_EDGE * E * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
                "note": "the figure north_star asks for; the path is not HBM bound (SURVEY.md 8d): 113 algorithmic bytes per edge "
                        "against ~22 600 flop"}
+        if prof.get("hbm_bytes_per_launch") and units:
+            # counter traffic against the algorithmic bytes, and where the excess comes from (profiles/README.md, round 5):
+            # reads = the two column sets once per endpoint tile + once more per waypoint tile of their edges (L2 misses of
+            # 8-byte gathers, doubled by the gfx950 FETCH_SIZE correction, which may not apply to them); writes = almost all
+            # SCRATCH write-backs -- the kernel sits at the 168-register bound of three waves per SIMD and keeps 68 B per lane in
+            # scratch (16 vector + 83 scalar registers spilled): 3 072 waves x 64 lanes x 68 B = 13.4 MB -- not verdict stores (0.26 MB)
+            hbm["traffic_over_algorithmic"] = float(prof["hbm_bytes_per_launch"]) / float(unit_bytes * units)
+            hbm["traffic_breakdown"] = {"FETCH_SIZE_x2_bytes": 2 * 1024 * float(prof.get("FETCH_SIZE_KiB") or 0.0),
+                                        "WRITE_SIZE_bytes": 1024 * float(prof.get("WRITE_SIZE_KiB") or 0.0),
+                                        "of_the_writes": "scratch write-backs (68 B per lane x 196 608 lanes = 13.4 MB); verdict bytes 0.26 MB"}
         roof = {"kernel": kernel, "kernel_ms": kernel_ms, "step_ms_all_kernels": launch_ms if S == 1 else one_stream["step_ms_all_kernels"],
                 "kernels_ms": alone_ms, "kernel_samples": nsamp, "streams_of_these_durations": 1,
                 "kernel_ms_source": sample_note

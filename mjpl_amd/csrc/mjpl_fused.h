@@ -344,6 +344,7 @@ k_edges_fused(FusedArgs a) {
   w.save = reinterpret_cast<float *>(w.base + (((size_t)nplan * 64 * sizeof(float) + 7) & ~(size_t)7));
   w.qmem = reinterpret_cast<char *>(w.save) + (((size_t)nsave * 7 * 64 * sizeof(float) + 7) & ~(size_t)7);
   int *w_edge = reinterpret_cast<int *>(w.base + w.bytes), *w_idx = w_edge + 64;
+  double *wts = reinterpret_cast<double *>(w_edge);  // an endpoint tile's step fractions: the same 512 bytes (8-byte aligned: the slice is)
   char *shared = reinterpret_cast<char *>(smem) + (size_t)NW * wbytes;
   w.ltab = reinterpret_cast<float *>(shared);
   for (int k = threadIdx.x; k < a.nfp; k += blockDim.x) w.ltab[k] = a.fp[k];
@@ -404,7 +405,7 @@ k_edges_fused(FusedArgs a) {
         });
         double tsw;
         K = count_waypoints_walk(a.ip, a.step, active && finite, at_end, qe, 64, qx, 64, a.kmax, nplan, tsw);
-        if (active && (K > 0 || a.single)) a.tstep[i] = tsw;  // (parked in memory across the check: two registers less to keep alive; lanes past E own no element)
+        wts[lane] = tsw;  // (parked across the check -- two registers less to keep alive -- in the wave's item table, which an endpoint tile does not use; round 4 parked it in HBM: 2 MB written and read per launch)
         wave_lds_fence();
         for (int k0 = 0; k0 < nplan; k0 += 8) {
           double v[8];
@@ -421,7 +422,7 @@ k_edges_fused(FusedArgs a) {
           finite = finite && (fabs(x) <= 1.79769313486231570815e+308) && (fabs(y) <= 1.79769313486231570815e+308);
         });
         K = -1;
-        if (active && a.single) a.tstep[i] = 0.0;  // (the walking list redoes the edge; its one item here is check 0, the endpoint, whatever the step)
+        wts[lane] = 0.0;  // (the walking list redoes the edge; its one item here is check 0, the endpoint, whatever the step)
         load_columns(qw, 64, a.QB, a.E, i, nplan, a.layout, active && finite);
       }
       active = active && finite;
@@ -481,7 +482,7 @@ k_edges_fused(FusedArgs a) {
     if (survive && K < 0) a.llist[atomicAdd(a.lcount, 1)] = (int)i;  // too long (or too many columns): walking kernel
     if (a.single) K = K < 0 ? 1 : K + 1;  // (the endpoint is check 0 of the edge's items; of a walking edge the only one)
     const bool entry = survive && K > 0;
-    const double tse = entry ? a.tstep[i] : 0.0;
+    const double tse = entry ? wts[lane] : 0.0;
     stat_surv += (int)__builtin_popcountll(__ballot(survive));
     pool.commit(entry, K, i, tse);
     MJPL_DG(0, 1);

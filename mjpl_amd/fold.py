@@ -88,6 +88,18 @@ class Fold:
         self.memo[expr] = ("v", name, False)
         return self.memo[expr]
 
+    def scope(self):
+        """`with f.scope():` -- registers defined inside a C++ block are forgotten when it closes (the memo is restored)."""
+        fold = self
+
+        class _Scope:
+            def __enter__(self):
+                self.saved = dict(fold.memo)
+
+            def __exit__(self, *exc):
+                fold.memo = self.saved
+        return _Scope()
+
     def named(self, name: str, a) -> tuple:
         """Bind a value to a declared variable (an output or a loop-carried register)."""
         self.emit(f"{name} = {self.text(a)};")

@@ -747,87 +747,80 @@ def dlit(x) -> str:
     return float(x).hex()
 
 
-def generate_exact(ip, dp, info, generic: bool = False) -> str:
-    """HIP source of `struct ExactSpec`: the float64 FK of k_patch_pairs (mjpl_filter.h) for one compiled
-    program -- the interpreter's own statements, body by body, with every table read replaced by the
-    value it would read (exact hexadecimal literals).  Same operations on the same values: the kernel's
-    verdicts are the interpreter's, bit for bit; what goes away is ~700 scalar loads per wave."""
+def generate_exact(ip, dp, info, generic: bool = False, fold: bool = True) -> str:
+    """HIP source of `struct ExactSpec`: the float64 FK of k_patch_pairs (mjpl_filter.h) for one compiled program -- the
+    interpreter's own statements, body by body, with the program's constants folded in (mjpl_amd/fold.py: products with
+    an exact 0 or 1 and sums with an exact 0 are not executed, the unit-length test of mju_normalize4 is an interval
+    test; every other operation in the interpreter's order).  Same values (up to the sign of exact zeros): the kernel's
+    verdicts are the interpreter's, bit for bit; what goes away is ~700 scalar loads per wave and more than half of the
+    chain's float64 instructions -- the latency of this chain is what a launch's tail kernel costs.
+    fold=False: every operation of the statement (tests)."""
+    from .fold import Fold
     out = []
     o = out.append
     nbody = int(ip[H_NBODYOPS])
     pc = int(ip[H_OFF_BODYOPS])
-
-    def arr(vals):
-        return "{" + ", ".join(dlit(v) for v in vals) + "}"
-
+    f = Fold(indent="    ", fold=fold)
+    c, v = f.c, f.v
     o("struct ExactSpec {")
     o("  // 1: geoms are numbered from the first moving one (a scene-generic library: model ids shift with the scene)")
     o(f"  static constexpr int kRelative = {1 if generic else 0};")
     o("  static __device__ __forceinline__ void fk_pair(const double *q, int qstride, double *save, int sstride, bool active,")
     o("                                                 int ga, int gb, mjpl::GeomT<double> &A, mjpl::GeomT<double> &Bg) {")
     o("    using namespace mjpl;")
-    o("    typedef GeomT<double> Geom;")
-    o("    double p[3] = {0, 0, 0}, qt[4] = {1, 0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};")
+    p, qt = [c(0), c(0), c(0)], [c(1), c(0), c(0), c(0)]
+    R = [c(x) for x in (1, 0, 0, 0, 1, 0, 0, 0, 1)]
     stage = 0
+    nsin = 0
     for b in range(nbody):
         parent, bdoff, njnt, save_slot, ngeom = (int(ip[pc + k]) for k in (B_PARENT, B_DOFF, B_NJNT, B_SAVE, B_NGEOM))
         pc += B_SIZE
         bd = dp[bdoff:]
-        o(f"    {{  // body op {b}")
-        o("      double pp[3], pq[4], pR[9];")
+        f.emit(f"// body op {b}")
         if parent == PARENT_CUR:
-            o("      for (int k = 0; k < 3; k++) pp[k] = p[k];")
-            o("      for (int k = 0; k < 4; k++) pq[k] = qt[k];")
-            o("      for (int k = 0; k < 9; k++) pR[k] = R[k];")
+            pp, pq, pR = p, qt, R
         elif parent == PARENT_STATIC:
-            o(f"      {{ const double a_[3] = {arr(bd[7:10])}, b_[4] = {arr(bd[10:14])}, c_[9] = {arr(bd[14:23])};")
-            o("        for (int k = 0; k < 3; k++) pp[k] = a_[k];")
-            o("        for (int k = 0; k < 4; k++) pq[k] = b_[k];")
-            o("        for (int k = 0; k < 9; k++) pR[k] = c_[k]; }")
+            pp, pq, pR = [c(x) for x in bd[7:10]], [c(x) for x in bd[10:14]], [c(x) for x in bd[14:23]]
         else:
-            o(f"      {{ const double *sv = save + (size_t){parent - 1} * 7 * sstride;")
-            o("        for (int k = 0; k < 3; k++) pp[k] = sv[k * sstride];")
-            o("        for (int k = 0; k < 4; k++) pq[k] = sv[(3 + k) * sstride];")
-            o("        quat2mat(pR, pq); }")
-        o("      double np[3], nq[4];")
-        o(f"      {{ const double bpos[3] = {arr(bd[0:3])}, bquat[4] = {arr(bd[3:7])};")
-        o("        mul_mat_vec3(np, pR, bpos);")
-        o("        np[0] += pp[0]; np[1] += pp[1]; np[2] += pp[2];")
-        o("        mul_quat(nq, pq, bquat); }")
+            k0 = f.n
+            f.n += 1
+            f.emit(f"const double *sv{k0} = save + (size_t){parent - 1} * 7 * sstride;")
+            names = [f"sv{k0}_{k}" for k in range(7)]
+            f.emit("const double " + ", ".join(f"{names[k]} = sv{k0}[{k} * sstride]" for k in range(7)) + ";")
+            pp, pq = [v(n) for n in names[:3]], [v(n) for n in names[3:]]
+            pR = f.quat2mat(pq)
+        np_ = [f.add(x, y) for x, y in zip(f.mul_mat_vec3(pR, [c(x) for x in bd[0:3]]), pp)]
+        nq_ = f.mul_quat(pq, [c(x) for x in bd[3:7]])
         for j in range(njnt):
             jtype, qsrc, jflags, jdoff = (int(ip[pc + k]) for k in (J_TYPE, J_QSRC, J_FLAGS, J_DOFF))
             pc += J_SIZE
             jd = dp[jdoff:]
-            qv = f"q[{qsrc} * qstride]" if qsrc >= 0 else dlit(jd[7])
-            o(f"      {{ const double qv = {qv};")
-            o(f"        const double dq = qv - {dlit(jd[6])};")
-            o(f"        const double jaxis[3] = {arr(jd[0:3])}, jpos[3] = {arr(jd[3:6])};")
+            qv = v(f"q[{qsrc} * qstride]") if qsrc >= 0 else c(jd[7])
+            dq = f.sub(qv, c(jd[6]))
+            jaxis, jpos = [c(x) for x in jd[0:3]], [c(x) for x in jd[3:6]]
             if jtype == JT_SLIDE:
-                o("        double xaxis[3];")
-                o("        rot_vec_quat(xaxis, jaxis, nq);")
-                o("        np[0] += xaxis[0] * dq; np[1] += xaxis[1] * dq; np[2] += xaxis[2] * dq; }")
+                xaxis = f.rot_vec_quat(jaxis, nq_)
+                np_ = [f.add(np_[r], f.mul(xaxis[r], dq)) for r in range(3)]
             else:
-                o("        double xanchor[3] = {np[0], np[1], np[2]};")
+                xanchor = np_
                 if jflags & JF_POS_NONZERO:
-                    o("        rot_vec_quat(xanchor, jpos, nq);")
-                    o("        xanchor[0] += np[0]; xanchor[1] += np[1]; xanchor[2] += np[2];")
-                o("        double sn, cs;")
-                o("        sincos_half(dq * 0.5, &sn, &cs);")
-                o("        double qloc[4] = {cs, jaxis[0] * sn, jaxis[1] * sn, jaxis[2] * sn};")
-                o("        mul_quat(nq, nq, qloc);")
+                    xanchor = [f.add(x, y) for x, y in zip(f.rot_vec_quat(jpos, nq_), np_)]
+                half = f.mul(dq, c(0.5))
+                f.emit(f"double sn{nsin}, cs{nsin};")
+                f.emit(f"sincos_half({f.text(half)}, &sn{nsin}, &cs{nsin});")
+                sn, cs = v(f"sn{nsin}"), v(f"cs{nsin}")
+                nsin += 1
+                nq_ = f.mul_quat(nq_, [cs, f.mul(jaxis[0], sn), f.mul(jaxis[1], sn), f.mul(jaxis[2], sn)])
                 if jflags & JF_POS_NONZERO:
-                    o("        double vec[3];")
-                    o("        rot_vec_quat(vec, jpos, nq);")
-                    o("        np[0] = xanchor[0] - vec[0]; np[1] = xanchor[1] - vec[1]; np[2] = xanchor[2] - vec[2];")
-                o("        (void)jpos; (void)xanchor; }")
-        o("      normalize4(nq);")
-        o("      for (int k = 0; k < 3; k++) p[k] = np[k];")
-        o("      for (int k = 0; k < 4; k++) qt[k] = nq[k];")
-        o("      quat2mat(R, qt);")
+                    vec = f.rot_vec_quat(jpos, nq_)
+                    np_ = [f.sub(xanchor[r], vec[r]) for r in range(3)]
+        nq_ = f.normalize4(nq_)
+        p, qt = np_, nq_
+        R = f.quat2mat(qt)
         if save_slot >= 0:
-            o(f"      {{ double *sv = save + (size_t){save_slot} * 7 * sstride;")
-            o("        for (int k = 0; k < 3; k++) sv[k * sstride] = p[k];")
-            o("        for (int k = 0; k < 4; k++) sv[(3 + k) * sstride] = qt[k]; }")
+            f.emit(f"{{ double *sv = save + (size_t){save_slot} * 7 * sstride;")
+            f.emit("  " + " ".join(f"sv[{k} * sstride] = {f.text(p[k])};" for k in range(3)))
+            f.emit("  " + " ".join(f"sv[{3 + k} * sstride] = {f.text(qt[k])};" for k in range(4)) + " }")
         for gi in range(ngeom):
             gflags, gdoff, geom_id = (int(ip[pc + k]) for k in (G_FLAGS, G_DOFF, G_GEOMID))
             pc += G_SIZE + MAX_SLOTS
@@ -835,26 +828,24 @@ def generate_exact(ip, dp, info, generic: bool = False) -> str:
             if generic:
                 geom_id = stage
             stage += 1
-            o(f"      if (__ballot(active && (ga == {geom_id} || gb == {geom_id})) != 0ull) {{")
-            o("        Geom cur;")
-            if gflags & GF_SAMEPOS:
-                o("        cur.pos[0] = p[0]; cur.pos[1] = p[1]; cur.pos[2] = p[2];")
-            else:
-                o(f"        {{ const double lpos[3] = {arr(gd[0:3])};")
-                o("          mul_mat_vec3(cur.pos, R, lpos);")
-                o("          cur.pos[0] += p[0]; cur.pos[1] += p[1]; cur.pos[2] += p[2]; }")
-            if gflags & GF_SAMEROT:
-                o("        for (int k = 0; k < 9; k++) cur.m[k] = R[k];")
-            else:
-                o(f"        {{ const double lq[4] = {arr(gd[3:7])};")
-                o("          double gq[4];")
-                o("          mul_quat(gq, qt, lq);")
-                o("          quat2mat(cur.m, gq); }")
-            o(f"        const bool isa = ga == {geom_id}, isb = gb == {geom_id};")
-            o("        for (int k = 0; k < 3; k++) { A.pos[k] = isa ? cur.pos[k] : A.pos[k]; Bg.pos[k] = isb ? cur.pos[k] : Bg.pos[k]; }")
-            o("        for (int k = 0; k < 9; k++) { A.m[k] = isa ? cur.m[k] : A.m[k]; Bg.m[k] = isb ? cur.m[k] : Bg.m[k]; }")
-            o("      }")
-        o("    }")
+            f.emit(f"if (__ballot(active && (ga == {geom_id} || gb == {geom_id})) != 0ull) {{")
+            with f.scope():
+                ind, f.ind = f.ind, f.ind + "  "
+                if gflags & GF_SAMEPOS:
+                    cpos = p
+                else:
+                    cpos = [f.add(x, y) for x, y in zip(f.mul_mat_vec3(R, [c(x) for x in gd[0:3]]), p)]
+                cm = R if gflags & GF_SAMEROT else f.quat2mat(f.mul_quat(qt, [c(x) for x in gd[3:7]]))
+                f.emit(f"const bool isa = ga == {geom_id}, isb = gb == {geom_id};")
+                for k in range(3):
+                    t = f.text(cpos[k])
+                    f.emit(f"A.pos[{k}] = isa ? {t} : A.pos[{k}]; Bg.pos[{k}] = isb ? {t} : Bg.pos[{k}];")
+                for k in range(9):
+                    t = f.text(cm[k])
+                    f.emit(f"A.m[{k}] = isa ? {t} : A.m[{k}]; Bg.m[{k}] = isb ? {t} : Bg.m[{k}];")
+                f.ind = ind
+            f.emit("}")
+    out.extend(f.lines)
     o("  }")
     o("};")
     return "\n".join(out) + "\n"

@@ -142,3 +142,72 @@ def test_fold_rules():
     t = f.sub(f.mul(f.neg(a), b), f.mul(a, f.c(-2.5)))  # -(a b) + 2.5 a
     assert f.text(t) == "t2"
     assert f.lines == ["    const double t0 = a * b;", "    const double t1 = a * 0x1.4000000000000p+1;", "    const double t2 = t1 - t0;"]
+
+
+_EXACT_HARNESS = r"""
+#include <cmath>
+#include <cstdint>
+#include <cstddef>
+#include "mjpl_trig.h"
+#define __device__
+#define __forceinline__ inline
+#define __ballot(x) ((x) ? 1ull : 0ull)
+namespace mjpl {
+template <class T> struct GeomT { T pos[3], m[9]; };
+static inline void sincos_half(double x, double *s, double *c) { sincos_pi2(x, s, c); }
+}
+namespace folded {
+%(folded)s
+}
+namespace plain {
+%(plain)s
+}
+template <class ES>
+static void run(const double *q, double *save, int ga, int gb, double *out) {
+  mjpl::GeomT<double> A = {}, B = {};
+  ES::fk_pair(q, 1, save, 1, true, ga, gb, A, B);
+  for (int k = 0; k < 3; k++) { out[k] = A.pos[k]; out[12 + k] = B.pos[k]; }
+  for (int k = 0; k < 9; k++) { out[3 + k] = A.m[k]; out[15 + k] = B.m[k]; }
+}
+extern "C" void pair_folded(const double *q, double *save, int ga, int gb, double *out) { run<folded::ExactSpec>(q, save, ga, gb, out); }
+extern "C" void pair_plain(const double *q, double *save, int ga, int gb, double *out) { run<plain::ExactSpec>(q, save, ga, gb, out); }
+"""
+
+
+@pytest.mark.parametrize("name", ["franka_p", "pads", "ur5e"])
+def test_folded_exact_fk_equals_the_statement_and_the_oracle(name, oracle_mod, tmp_path):
+    """ExactSpec::fk_pair (the float64 FK of the pair re-check) with the constants folded in, against the same generator
+    with folding off and against the oracle's FK: geom positions and frames of random pairs, equal value by value."""
+    model = {"franka_p": lambda: scenes.franka_p(True), "pads": lambda: scenes.franka_p(True, True), "ur5e": scenes.ur5e}[name]()
+    if name == "ur5e":
+        qidx, base = None, None
+    else:
+        qidx, base = scenes.planning_index(model, scenes.FRANKA_ARM_JOINTS), model.keyframe("home").qpos.copy()
+    ip, fp, dp, info = sp.dump_program(model, (), qidx, base)
+    src = _EXACT_HARNESS % dict(folded=sp.generate_exact(ip, dp, info), plain=sp.generate_exact(ip, dp, info, fold=False))
+    cpp, so = tmp_path / f"exact_{name}.cpp", tmp_path / f"exact_{name}.so"
+    cpp.write_text(src)
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-shared", "-fPIC", "-Wno-attributes", f"-I{_build.CSRC}",
+                    "-o", str(so), str(cpp)], check=True)
+    lib = C.CDLL(str(so))
+    P = C.POINTER(C.c_double)
+    moving = [g for g in range(model.ngeom) if int(model.body_weldid[model.geom_bodyid[g]]) != 0]
+    rng = np.random.default_rng(9)
+    nplan = model.nq if qidx is None else len(qidx)
+    lo = model.jnt_range[:, 0] if qidx is None else model.jnt_range[qidx, 0]
+    hi = model.jnt_range[:, 1] if qidx is None else model.jnt_range[qidx, 1]
+    orc = oracle_mod.Oracle(model, planning_qidx=qidx, qpos_base=base)
+    save = np.zeros(7 * 64)
+    with oracle_mod.portable_trig():
+        for trial in range(120):
+            q = rng.uniform(lo, hi) if trial > 1 else (np.zeros(nplan) if trial else 0.5 * (lo + hi))
+            q = np.ascontiguousarray(q, np.float64)
+            ga, gb = (int(x) for x in rng.choice(moving, 2, replace=False))
+            a, b = np.zeros(24), np.zeros(24)
+            lib.pair_folded(q.ctypes.data_as(P), save.ctypes.data_as(P), ga, gb, a.ctypes.data_as(P))
+            lib.pair_plain(q.ctypes.data_as(P), save.ctypes.data_as(P), ga, gb, b.ctypes.data_as(P))
+            assert np.array_equal(a, b), (name, trial, ga, gb)
+            fk = orc.fk(q[None])
+            gx, gm = np.asarray(fk["geom_xpos"]).reshape(-1, 3), np.asarray(fk["geom_xmat"]).reshape(-1, 9)
+            assert np.array_equal(a[0:3], gx[ga]) and np.array_equal(a[12:15], gx[gb]), (name, trial)
+            assert np.array_equal(a[3:12], gm[ga]) and np.array_equal(a[15:24], gm[gb]), (name, trial)
