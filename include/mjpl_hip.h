@@ -172,6 +172,11 @@ int64_t mjpl_filter_last_interior_edges(mjpl_engine *e);
  * one lane per edge walks them; edges too long for the item space always do).  Returns how many
  * waypoint items the most recent mjpl_check_edges* checked (synchronises); -1 if never used. */
 int64_t mjpl_filter_last_items(mjpl_engine *e);
+/* The fused filter kernel spares an edge its waypoint checks when the END configuration keeps every enabled pair
+ * farther apart than the pair can move while the planning joints travel the edge (a certificate that only ever says
+ * "free": the verdict _valid_collision_interval, planning/utils.py:188-216, would reach by checking every waypoint).
+ * Returns how many surviving edges of the most recent mjpl_check_edges* were spared (synchronises); -1 if the filter is off. */
+int64_t mjpl_filter_last_certified(mjpl_engine *e);
 
 /* ---- host-buffer entry points (stage H2D, run, copy back, synchronise) ---------- */
 

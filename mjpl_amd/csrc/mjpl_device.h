@@ -52,7 +52,8 @@ template <> struct Real<double> { static constexpr bool exact = true; typedef DP
 template <> struct Real<float> { static constexpr bool exact = false; typedef FP Tab; };
 
 // verdict codes of the narrowphase (the exact path only produces 0 and 1)
-enum : int { V_NONE = 0, V_CONTACT = 1, V_UNSURE = 2 };
+enum : int { V_NONE = 0, V_CONTACT = 1, V_UNSURE = 2,
+              V_CLEAR = 3 };  // (a generated check asked for the edge certificate: no contact, and clear of it by the edge's motion)
 // The float32 filter decides a configuration only while its float32 world poses are provably
 // within tol/2 of the float64 ones (DESIGN.md section 5.1b derives the bound E = A + B * C per
 // model): every moving body origin within FC_MAXCOORD metres of the world origin (C), every
@@ -321,6 +322,20 @@ MJPL_HD int classify(T s, T tol) {
   if constexpr (Real<T>::exact) return !(s > 0) ? V_CONTACT : V_NONE;
   return s > tol ? V_NONE : (s < -tol ? V_CONTACT : V_UNSURE);
 }
+// The edge certificate of the fused filter kernel (mjpl_fused.h: an edge whose END configuration keeps every enabled pair
+// farther apart than the pair can move along the edge needs no waypoint checks): a narrowphase routine called with an
+// accumulator also says whether its pair is clear of contact by `extra` metres MORE than the verdict V_NONE needs -- the
+// same quantities, one more compare.  `clear` only ever goes from true to false; a routine that cannot tell leaves it false.
+template <class T>
+struct CertAcc {
+  T extra;
+  bool clear;
+};
+template <class T>
+MJPL_HD int classify_c(T s, T tol, CertAcc<T> *ca) {
+  if (ca) ca->clear = ca->clear && (s - ca->extra > tol);
+  return classify(s, tol);
+}
 MJPL_HD int v_or(int a, int b) {  // "any contact" over several tests
   return (a == V_CONTACT || b == V_CONTACT) ? V_CONTACT : ((a == V_UNSURE || b == V_UNSURE) ? V_UNSURE : V_NONE);
 }
@@ -339,33 +354,33 @@ struct GeomT {
 };
 
 template <class T>
-MJPL_HD int sphere_sphere(T margin, const T *pos1, T r1, const T *pos2, T r2, T tol) {
+MJPL_HD int sphere_sphere(T margin, const T *pos1, T r1, const T *pos2, T r2, T tol, CertAcc<T> *ca = nullptr) {
   T dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
   T cdist_sqr = dot3(dif, dif);
   T min_dist = margin + r1 + r2;
   if constexpr (Real<T>::exact) return !(cdist_sqr > min_dist * min_dist) ? V_CONTACT : V_NONE;
-  return classify(rsqrt_val(cdist_sqr) - min_dist, tol);
+  return classify_c(rsqrt_val(cdist_sqr) - min_dist, tol, ca);
 }
 
 template <class T>
-MJPL_HD int plane_sphere(T margin, const GeomT<T> &pl, const T *pos2, T r2, T tol) {
+MJPL_HD int plane_sphere(T margin, const GeomT<T> &pl, const T *pos2, T r2, T tol, CertAcc<T> *ca = nullptr) {
   T n[3] = {pl.m[2], pl.m[5], pl.m[8]};
   T tmp[3] = {pos2[0] - pl.pos[0], pos2[1] - pl.pos[1], pos2[2] - pl.pos[2]};
   T cdist = dot3(tmp, n);
   if constexpr (Real<T>::exact) return !(cdist > margin + r2) ? V_CONTACT : V_NONE;
-  return classify(cdist - (margin + r2), tol);
+  return classify_c(cdist - (margin + r2), tol, ca);
 }
 
 template <class T>
-MJPL_HD int plane_capsule(T margin, const GeomT<T> &pl, const GeomT<T> &cap, const T *size2, T tol) {
+MJPL_HD int plane_capsule(T margin, const GeomT<T> &pl, const GeomT<T> &cap, const T *size2, T tol, CertAcc<T> *ca = nullptr) {
   T seg[3] = {size2[1] * cap.m[2], size2[1] * cap.m[5], size2[1] * cap.m[8]};
   T e1[3] = {cap.pos[0] + seg[0], cap.pos[1] + seg[1], cap.pos[2] + seg[2]};
   T e2[3] = {cap.pos[0] - seg[0], cap.pos[1] - seg[1], cap.pos[2] - seg[2]};
-  return v_or(plane_sphere(margin, pl, e1, size2[0], tol), plane_sphere(margin, pl, e2, size2[0], tol));
+  return v_or(plane_sphere(margin, pl, e1, size2[0], tol, ca), plane_sphere(margin, pl, e2, size2[0], tol, ca));
 }
 
 template <class T>
-MJPL_HD int plane_box(T margin, const GeomT<T> &pl, const GeomT<T> &box, const T *size2, T tol) {
+MJPL_HD int plane_box(T margin, const GeomT<T> &pl, const GeomT<T> &box, const T *size2, T tol, CertAcc<T> *ca = nullptr) {
   T norm[3] = {pl.m[2], pl.m[5], pl.m[8]};
   T dif[3] = {box.pos[0] - pl.pos[0], box.pos[1] - pl.pos[1], box.pos[2] - pl.pos[2]};
   T dist = dot3(dif, norm);
@@ -383,6 +398,7 @@ MJPL_HD int plane_box(T margin, const GeomT<T> &pl, const GeomT<T> &box, const T
       res = (res == V_CONTACT || !(dist + ldist > margin || ldist > 0)) ? V_CONTACT : V_NONE;
     } else {
       // a corner counts iff it is below the centre (ldist <= 0) and within the margin
+      if (ca) ca->clear = ca->clear && (dist + ldist - margin - ca->extra > tol);  // (every corner that far above the plane)
       const bool sure_out = (dist + ldist - margin > tol) || (ldist > tol);
       const bool sure_in = (dist + ldist - margin < -tol) && (ldist < -tol);
       res = v_or(res, sure_in ? V_CONTACT : (sure_out ? V_NONE : V_UNSURE));
@@ -392,7 +408,7 @@ MJPL_HD int plane_box(T margin, const GeomT<T> &pl, const GeomT<T> &box, const T
 }
 
 template <class T>
-MJPL_HD int sphere_capsule(T margin, const T *pos1, T r1, const GeomT<T> &cap, const T *size2, T tol) {
+MJPL_HD int sphere_capsule(T margin, const T *pos1, T r1, const GeomT<T> &cap, const T *size2, T tol, CertAcc<T> *ca = nullptr) {
   T len = size2[1];
   T axis[3] = {cap.m[2], cap.m[5], cap.m[8]};
   T vec[3] = {pos1[0] - cap.pos[0], pos1[1] - cap.pos[1], pos1[2] - cap.pos[2]};
@@ -400,12 +416,12 @@ MJPL_HD int sphere_capsule(T margin, const T *pos1, T r1, const GeomT<T> &cap, c
   vec[0] = axis[0] * x + cap.pos[0];
   vec[1] = axis[1] * x + cap.pos[1];
   vec[2] = axis[2] * x + cap.pos[2];
-  return sphere_sphere(margin, pos1, r1, vec, size2[0], tol);
+  return sphere_sphere(margin, pos1, r1, vec, size2[0], tol, ca);
 }
 
 template <class T>
 __device__ __forceinline__ int capsule_capsule(T margin, const GeomT<T> &c1, const T *size1,
-                                               const GeomT<T> &c2, const T *size2, T tol) {
+                                               const GeomT<T> &c2, const T *size2, T tol, CertAcc<T> *ca = nullptr) {
   T axis1[3] = {c1.m[2] * size1[1], c1.m[5] * size1[1], c1.m[8] * size1[1]};
   T axis2[3] = {c2.m[2] * size2[1], c2.m[5] * size2[1], c2.m[8] * size2[1]};
   T dif[3] = {c1.pos[0] - c2.pos[0], c1.pos[1] - c2.pos[1], c1.pos[2] - c2.pos[2]};
@@ -423,7 +439,10 @@ __device__ __forceinline__ int capsule_capsule(T margin, const GeomT<T> &c1, con
     // the float64 routine switches to its parallel branch at the ABSOLUTE threshold |det| < 1e-15,
     // which tiny capsules reach at any angle -- ma * mc itself is below it for half-lengths under
     // ~2e-4 m), and degenerate capsules.  NaN fails both tests.
-    if (!(det > T(1e-4) * ma * mc) || !(det > T(4e-15))) return V_UNSURE;
+    if (!(det > T(1e-4) * ma * mc) || !(det > T(4e-15))) {
+      if (ca) ca->clear = false;
+      return V_UNSURE;
+    }
   }
   const bool general = Real<T>::exact ? (fabs(det) >= T(MJPL_MINVAL)) : true;
   if (general) {
@@ -465,6 +484,7 @@ __device__ __forceinline__ int capsule_capsule(T margin, const GeomT<T> &c1, con
       const T e2 = x2 >= 1 ? fmax(g2, T(0)) : (x2 <= -1 ? fmax(-g2, T(0)) : fabs(g2));
       const T alen = T(1.001) * (size1[1] + size2[1]);  // |a1| + |a2| (the axes are unit vectors)
       const T lo2 = D2 - T(4) * (e1 + e2) - alen * (T(0.5) * tol + T(2e-6) * D) - T(1e-6) * D2;
+      if (ca) ca->clear = ca->clear && (lo2 > (rs + ca->extra + tol) * (rs + ca->extra + tol));
       res = (D - rs < -tol) ? V_CONTACT : ((lo2 > (rs + tol) * (rs + tol)) ? V_NONE : V_UNSURE);
     }
   } else {
@@ -491,21 +511,21 @@ __device__ __forceinline__ int capsule_capsule(T margin, const GeomT<T> &c1, con
 }
 
 template <class T>
-MJPL_HD int sphere_box_local(T margin, const T *c, T r, const T *size2, T tol) {
+MJPL_HD int sphere_box_local(T margin, const T *c, T r, const T *size2, T tol, CertAcc<T> *ca = nullptr) {
   T d[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) d[k] = clipd(c[k], -size2[k], size2[k]) - c[k];
   T dist = rsqrt_val(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   if constexpr (Real<T>::exact) return !(dist - r > margin) ? V_CONTACT : V_NONE;
-  return classify(dist - r - margin, tol);
+  return classify_c(dist - r - margin, tol, ca);
 }
 
 template <class T>
-MJPL_HD int sphere_box(T margin, const T *pos1, T r1, const GeomT<T> &box, const T *size2, T tol) {
+MJPL_HD int sphere_box(T margin, const T *pos1, T r1, const GeomT<T> &box, const T *size2, T tol, CertAcc<T> *ca = nullptr) {
   T tmp[3] = {pos1[0] - box.pos[0], pos1[1] - box.pos[1], pos1[2] - box.pos[2]};
   T center[3];
   mul_matT_vec3(center, box.m, tmp);
-  return sphere_box_local(margin, center, r1, size2, tol);
+  return sphere_box_local(margin, center, r1, size2, tol, ca);
 }
 
 template <class T>
@@ -523,7 +543,7 @@ MJPL_HD T capbox_g(const T *p, const T *h, const T *s, T t) {
 // exact 1-D convex minimisation of dist^2(segment point, box); see oracle/mjpl_oracle.c
 template <class T>
 __device__ __forceinline__ int capsule_box(T margin, const GeomT<T> &cap, const T *size1,
-                                           const GeomT<T> &box, const T *size2, T tol) {
+                                           const GeomT<T> &box, const T *size2, T tol, CertAcc<T> *ca = nullptr) {
   T tmp[3] = {cap.pos[0] - box.pos[0], cap.pos[1] - box.pos[1], cap.pos[2] - box.pos[2]};
   T axis[3] = {cap.m[2], cap.m[5], cap.m[8]};
   T p[3], a[3], h[3], inv[3];
@@ -579,6 +599,7 @@ __device__ __forceinline__ int capsule_box(T margin, const GeomT<T> &cap, const 
     const T ge = t >= 1 ? fmax(gt, T(0)) : (t <= -1 ? fmax(-gt, T(0)) : fabs(gt));
     const T hl = T(1.001) * size1[1];
     const T lo2 = D2 - T(4) * ge - hl * (T(0.5) * tol + T(2e-6) * D) - T(1e-6) * D2;
+    if (ca) ca->clear = ca->clear && (lo2 > (rs + ca->extra + tol) * (rs + ca->extra + tol));
     return (D - rs < -tol) ? V_CONTACT : ((lo2 > (rs + tol) * (rs + tol)) ? V_NONE : V_UNSURE);
   }
 }
@@ -651,28 +672,28 @@ __device__ __forceinline__ int box_box(T margin, const GeomT<T> &b1, const T *si
 template <class T, bool WBOX, bool MBOX>
 __device__ __forceinline__ int pair_contact(int tcur, const GeomT<T> &cur, const T *scur, int tpar,
                                             const GeomT<T> &par, const T *spar, bool pfirst, T margin,
-                                            T tol) {
+                                            T tol, CertAcc<T> *ca = nullptr) {
   constexpr bool PBOX = WBOX || MBOX;  // the partner may be a box
   int r = V_NONE;
   if (tpar == GT_PLANE) {
-    if (tcur == GT_SPHERE) r = plane_sphere(margin, par, cur.pos, scur[0], tol);
-    else if (tcur == GT_CAPSULE) r = plane_capsule(margin, par, cur, scur, tol);
-    else if (MBOX) r = plane_box(margin, par, cur, scur, tol);
+    if (tcur == GT_SPHERE) r = plane_sphere(margin, par, cur.pos, scur[0], tol, ca);
+    else if (tcur == GT_CAPSULE) r = plane_capsule(margin, par, cur, scur, tol, ca);
+    else if (MBOX) r = plane_box(margin, par, cur, scur, tol, ca);
   } else if (tcur == GT_SPHERE && tpar == GT_SPHERE) {
     const T r1 = pfirst ? spar[0] : scur[0], r2 = pfirst ? scur[0] : spar[0];
-    r = sphere_sphere(margin, cur.pos, r1, par.pos, r2, tol);  // (a-b)^2 == (b-a)^2 exactly
+    r = sphere_sphere(margin, cur.pos, r1, par.pos, r2, tol, ca);  // (a-b)^2 == (b-a)^2 exactly
   } else if (tcur == GT_SPHERE && tpar == GT_CAPSULE) {
-    r = sphere_capsule(margin, cur.pos, scur[0], par, spar, tol);
+    r = sphere_capsule(margin, cur.pos, scur[0], par, spar, tol, ca);
   } else if (tcur == GT_CAPSULE && tpar == GT_SPHERE) {
-    r = sphere_capsule(margin, par.pos, spar[0], cur, scur, tol);
+    r = sphere_capsule(margin, par.pos, spar[0], cur, scur, tol, ca);
   } else if (PBOX && tcur == GT_SPHERE && tpar == GT_BOX) {
-    r = sphere_box(margin, cur.pos, scur[0], par, spar, tol);
+    r = sphere_box(margin, cur.pos, scur[0], par, spar, tol, ca);
   } else if (MBOX && tcur == GT_BOX && tpar == GT_SPHERE) {
-    r = sphere_box(margin, par.pos, spar[0], cur, scur, tol);
+    r = sphere_box(margin, par.pos, spar[0], cur, scur, tol, ca);
   } else if (PBOX && tcur == GT_CAPSULE && tpar == GT_BOX) {
-    r = capsule_box(margin, cur, scur, par, spar, tol);
+    r = capsule_box(margin, cur, scur, par, spar, tol, ca);
   } else if (MBOX && tcur == GT_BOX && tpar == GT_CAPSULE) {
-    r = capsule_box(margin, par, spar, cur, scur, tol);
+    r = capsule_box(margin, par, spar, cur, scur, tol, ca);
   } else if (tcur == GT_CAPSULE && tpar == GT_CAPSULE) {
     GeomT<T> c1, c2;
     T s1[2], s2[2];
@@ -688,7 +709,7 @@ __device__ __forceinline__ int pair_contact(int tcur, const GeomT<T> &cur, const
       s1[k] = pfirst ? spar[k] : scur[k];
       s2[k] = pfirst ? scur[k] : spar[k];
     }
-    r = capsule_capsule(margin, c1, s1, c2, s2, tol);
+    r = capsule_capsule(margin, c1, s1, c2, s2, tol, ca);
   } else if (MBOX) {
     GeomT<T> b1, b2;
     T s1[3], s2[3];
@@ -704,6 +725,7 @@ __device__ __forceinline__ int pair_contact(int tcur, const GeomT<T> &cur, const
       b1.m[k] = pfirst ? par.m[k] : cur.m[k];
       b2.m[k] = pfirst ? cur.m[k] : par.m[k];
     }
+    if (ca) ca->clear = false;  // (the separating-axis verdict carries no distance: such a pair never certifies)
     r = box_box(margin, b1, s1, b2, s2, tol);
   }
   return r;
@@ -883,6 +905,7 @@ __device__ inline void exact_waypoint(const EdgeSource &src, Perm perm, int npla
 
 struct PatchSink {
   UndecidedConfigs uc;
+  const _Float16 *adq = nullptr;  // edge certificate (generated checks): this lane's |dq| per planning column at adq[k * 64]; null: none
   const double *qcol;  // configurations of this wave's lanes: q[k] of lane l at qcol[k * B + l * L]
   int B, L, nplan;     // (LDS columns: B = block size, L = 1)
   int idx;             // check index of the configurations under test (wave-uniform) ...
@@ -1309,7 +1332,7 @@ struct WaveQueue {
   int *ni0, *ni1; // [QN_CAP] each: packed pair id, constant-table offset of the cur geom's block
   T *bf;          // [kBFields][QB_CAP]
   int *bi0, *bi1; // [QB_CAP]
-  int *flags;     // [64] : bit0 contact, bit1 unsure, per owning lane
+  int *flags;     // [64] : bit0 contact, bit1 unsure, bit2 a candidate closer than its certificate margin; bits 3..: the owner's item
   static __host__ __device__ constexpr size_t bytes() {
     return (size_t)QN_FIELDS * QN_CAP * sizeof(T) + 2 * QN_CAP * sizeof(int) +
            (size_t)kBFields * QB_CAP * sizeof(T) + 2 * QB_CAP * sizeof(int) + 64 * sizeof(int);
@@ -1356,7 +1379,15 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
     qn -= n;
     const int jj = on ? j : 0;
     const int i0 = qi0[jj];
-    Tab gd = tp + qi1[jj];
+    const int i1 = qi1[jj];
+    Tab gd = tp + (i1 & 0xffff);
+    // the certificate margin of the candidate (metres; 0: none asked for) -- float32 filter builds only
+    CertAcc<T> cacc = {T(0), true};
+    CertAcc<T> *ca = nullptr;
+    if constexpr (!Real<T>::exact) {
+      cacc.extra = (T)__builtin_bit_cast(_Float16, (unsigned short)((unsigned)i1 >> 16));
+      ca = &cacc;
+    }
     const int owner = i0 & 63, gtype = (i0 >> 6) & 15, ptype = (i0 >> 10) & 15;
     const bool pfirst = (i0 >> 14) & 1;
     const int kind = (i0 >> 15) & 3, index = (i0 >> 17) & 255;
@@ -1394,7 +1425,7 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
         psize[2] = plane ? T(0) : rw[WN_SIZE + 2];
         margin = gd[GD_WBOUND + nwpad + index];
       }
-      if (on) code = pair_contact<T, true, true>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
+      if (on) code = pair_contact<T, true, true>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol, ca);
     } else if constexpr (BOXQ) {
       Tab rw = wnarrow + index * WN_LEN;
       par.pos[0] = wcull[wc_at(index, 0)]; par.pos[1] = wcull[wc_at(index, 1)]; par.pos[2] = wcull[wc_at(index, 2)];
@@ -1408,7 +1439,7 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
       unsigned long long ts1 = stamp();
 #endif
 #ifndef MJPL_X_DRAIN_NONARROW
-      if (on) code = pair_contact<T, true, false>(gtype, cur, gsize, GT_BOX, par, psize, pfirst, margin, tol);
+      if (on) code = pair_contact<T, true, false>(gtype, cur, gsize, GT_BOX, par, psize, pfirst, margin, tol, ca);
 #endif
 #ifdef MJPL_STAMPS
       pin(code);
@@ -1435,7 +1466,7 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
       unsigned long long ts1 = stamp();
 #endif
 #ifndef MJPL_X_DRAIN_NONARROW
-      if (on) code = pair_contact<T, false, false>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol);
+      if (on) code = pair_contact<T, false, false>(gtype, cur, gsize, ptype, par, psize, pfirst, margin, tol, ca);
 #endif
 #ifdef MJPL_STAMPS
       pin(code);
@@ -1447,6 +1478,9 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
     code = (cur.pos[0] + par.pos[0] + psize[0] + gsize[0] + margin == T(12345.0)) ? V_CONTACT : V_NONE;
 #endif
     if (on && code == V_CONTACT) atomicOr(&wq.flags[owner], 1);
+    if constexpr (!Real<T>::exact) {  // (a candidate that is not clear by its margin: its owner's edge is not certified)
+      if (on && cacc.extra > T(0) && !(code == V_NONE && cacc.clear)) atomicOr(&wq.flags[owner], 4);
+    }
     // (an owner known to be in contact -- from this batch, the line above, or an earlier one -- needs no exact check
     //  of another pair: on uniformly random configurations half of the hand-offs were of this kind)
     if (on && code == V_UNSURE && !(wq.flags[owner] & 1)) {
@@ -1456,7 +1490,7 @@ __device__ __forceinline__ void queue_drain(const WaveQueue<T, MBOX> &wq, int &q
       if (ps.uc.count) {
         const int u = atomicAdd(ps.uc.count, 1);
         if (u < ps.uc.cap) {
-          const int item = (int)((unsigned)wq.flags[owner] >> 2);
+          const int item = (int)((unsigned)wq.flags[owner] >> 3);
           const int ed = ps.item_edge ? ps.item_edge[item] : item;
           const int ix = ps.item_idx ? ps.item_idx[item] : ps.idx;
           if (ps.src.QA)  // row `ed` of the caller's configurations (ix = 0), or waypoint ix of edge `ed`
@@ -1489,7 +1523,7 @@ __device__ __forceinline__ void queue_push(const WaveQueue<T, MBOX> &wq, int &fi
                                            const T *ltab, const T *lwcull, const T *lwnarrow, int nwpad, T tol,
                                            const PatchSink &ps, unsigned long long pm, int kind, int index, int gtype,
                                            int ptype, bool pfirst, int gdoff, const T *cur6, const T *t6,
-                                           const T *cur6b = nullptr, const T *t6b = nullptr) {
+                                           const T *cur6b = nullptr, const T *t6b = nullptr, T mcert = T(0)) {
   constexpr int CAP = BOXQ ? QB_CAP : QN_CAP;
   const int lane = threadIdx.x & 63;
 #ifdef MJPL_X_NOPUSH  // timing-only build: the item kernel culls, but queues nothing (the masks stay live through fl)
@@ -1526,7 +1560,9 @@ __device__ __forceinline__ void queue_push(const WaveQueue<T, MBOX> &wq, int &fi
       }
     }
     qi0[off] = lane | (gtype << 6) | (ptype << 10) | ((pfirst ? 1 : 0) << 14) | (kind << 15) | (index << 17);
-    qi1[off] = gdoff;
+    // the candidate's certificate margin (0: none) as a binary16 in the high half, rounded UP: x (1 + 2^-9) rounds to no less than x
+    const unsigned short mh = __builtin_bit_cast(unsigned short, (_Float16)((float)mcert * 1.001953125f));
+    qi1[off] = gdoff | ((int)mh << 16);
   }
   fill += cnt;
 }
@@ -1557,7 +1593,7 @@ __device__ __forceinline__ int run_config_queued(IP ip, typename Real<T>::Tab tp
 #ifdef MJPL_X_Q_NOPUSH
   unsigned long long sink = 0;
 #endif
-  wq.flags[lane] = (int)((unsigned)item << 2);  // bits 0..1 verdict flags, the rest: whose item this is
+  wq.flags[lane] = (int)((unsigned)item << 3);  // bits 0..2 flags, the rest: whose item this is
   const int nbodyops = uni(ip[H_NBODYOPS]);
   Tab wcull = tp + uni(ip[H_OFF_WCULL]);
   const int nwpad = uni(ip[H_NWPAD]);

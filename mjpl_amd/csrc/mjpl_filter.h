@@ -225,8 +225,9 @@ constexpr int kItemRegions = 32;
 // endpoint passed, unused, edges left to the walking kernel), the per-region item fills, the per-region
 // survivor counts.  The engine keeps two such sets and alternates: the first kernel of a launch clears
 // the set the NEXT launch will use (nobody touches it meanwhile), which saves a fill kernel per launch.
-constexpr int kNumCounters = 5 + 4 * kItemRegions + 1;
+constexpr int kNumCounters = 5 + 4 * kItemRegions + 2;
 constexpr int kCtrTailDone = 5 + 4 * kItemRegions;  // k_tail: walking workgroups that are through
+constexpr int kCtrCertified = 5 + 4 * kItemRegions + 1;  // fused kernel: surviving edges its certificate spared the waypoint checks
 // tile queues of the persistent kernels (k_filter_endpoints_pw / k_filter_items_pw), one per region:
 // the next tile of that region to hand out
 constexpr int kCtrEndpointTiles = 5 + 2 * kItemRegions;
@@ -862,10 +863,12 @@ __device__ __forceinline__ WaveLds<T, MBOX> carve_wave(double *smem, const T *__
 template <int MAXS, bool WBOX, bool MBOX, class Spec>
 __device__ __forceinline__ int check_wave(const int *__restrict__ gip, const float *__restrict__ gfp, const WaveLds<float, MBOX> &w,
                                           bool active, float tol, int64_t row, const UndecidedConfigs &uc,
-                                          const int *item_edge, const int *item_idx, const EdgeSource &src) {
+                                          const int *item_edge, const int *item_idx, const EdgeSource &src,
+                                          const _Float16 *adq = nullptr) {
   const int lane = threadIdx.x & 63;
   PatchSink ps;
   ps.uc = uc;
+  ps.adq = adq;  // (the edge certificate of the fused kernel's endpoint tiles; null: an ordinary check)
   ps.qcol = nullptr;  // (src is always set here: what goes to the exact re-check is read / rebuilt from the caller's rows)
   ps.B = 64;
   ps.L = 1;

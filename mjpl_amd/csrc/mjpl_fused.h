@@ -44,6 +44,8 @@ struct FusedArgs {
   int *claim; int gen;           // per-edge claim words of the undecided-edge list (see k_filter_items)
   double *tstep;                 // [E] scratch: an edge's step fraction between its count and its pool entry
   int *item_count, *surv_count;  // statistics: kItemRegions counters each, kCounterStride apart
+  int *cert_count;               // ... and one: surviving edges the certificate spared the waypoint checks
+  int cert;                      // 1: endpoint tiles of a two-round launch try the edge certificate (generated checks with kCert)
   int *zero_next;
   long long tile0, tile1;        // this launch serves endpoint tiles [tile0, tile1) of the batch (64 edges each)
   int kmax;                      // edges with more interior waypoints take the walking list
@@ -64,15 +66,20 @@ struct FusedArgs {
 enum : int { RG_HEAD = 0, RG_LOCK = 2, RG_ENT, RG_COMMIT, RG_NEXT, RG_PRODUCED, RG_RESERVED, RG_NEED = 8, RG_WORDS = 8 + 16 };
 constexpr int kFusedIdle = 0x7fffffff;
 
-__host__ __device__ constexpr size_t fused_wave_bytes(int nplan, int nsave, size_t qbytes) {
-  return wave_slice_bytes(nplan, nsave, sizeof(float), qbytes) + 2 * 64 * sizeof(int);  // + (edge, index) of the wave's items
+__host__ __device__ constexpr size_t fused_wave_bytes(int nplan, int nsave, size_t qbytes, bool cert = false) {
+  // + (edge, index) of the wave's items; cert (a library built with the edge certificate): + |QB - QA| per planning
+  // column of an endpoint tile's lanes, as binary16
+  return wave_slice_bytes(nplan, nsave, sizeof(float), qbytes) + 2 * 64 * sizeof(int) +
+         (cert ? (((size_t)nplan * 64 * sizeof(_Float16) + 7) & ~(size_t)7) : 0);
 }
 constexpr size_t kFusedEntryBytes = sizeof(double) + 2 * sizeof(int);  // step fraction, edge, first waypoint number
-inline size_t fused_lds_bytes(int nwaves, int nplan, int nsave, size_t ntab, bool mbox, int pool) {
+inline size_t fused_lds_bytes(int nwaves, int nplan, int nsave, size_t ntab, bool mbox, int pool, bool cert = false) {
   const size_t q = mbox ? WaveQueue<float, true>::bytes() : WaveQueue<float, false>::bytes();
-  return (size_t)nwaves * fused_wave_bytes(nplan, nsave, q) + ((ntab * sizeof(float) + 7) & ~(size_t)7) +
+  return (size_t)nwaves * fused_wave_bytes(nplan, nsave, q, cert) + ((ntab * sizeof(float) + 7) & ~(size_t)7) +
          (size_t)pool * kFusedEntryBytes + RG_WORDS * sizeof(int);
 }
+template <class Spec> struct SpecCert { static constexpr bool value = Spec::kCert; };
+template <> struct SpecCert<void> { static constexpr bool value = false; };
 // the float64 walking rows of the waypoint count lie over a wave's slice
 inline bool fused_fits(int nplan, int nsave, bool mbox) {
   const size_t q = mbox ? WaveQueue<float, true>::bytes() : WaveQueue<float, false>::bytes();
@@ -338,13 +345,22 @@ k_edges_fused(FusedArgs a) {
   const size_t qbytes = WaveQueue<float, MBOX>::bytes();
   WaveLds<float, MBOX> w;
   w.bytes = wave_slice_bytes(nplan, nsave, sizeof(float), qbytes);
-  const size_t wbytes = w.bytes + 2 * 64 * sizeof(int);
+  constexpr bool kCertBuild = SpecCert<Spec>::value;
+  const size_t wbytes = fused_wave_bytes(nplan, nsave, qbytes, kCertBuild);
   w.base = reinterpret_cast<char *>(smem) + (size_t)wv * wbytes;
   w.col = reinterpret_cast<float *>(w.base);
   w.save = reinterpret_cast<float *>(w.base + (((size_t)nplan * 64 * sizeof(float) + 7) & ~(size_t)7));
   w.qmem = reinterpret_cast<char *>(w.save) + (((size_t)nsave * 7 * 64 * sizeof(float) + 7) & ~(size_t)7);
   int *w_edge = reinterpret_cast<int *>(w.base + w.bytes), *w_idx = w_edge + 64;
   double *wts = reinterpret_cast<double *>(w_edge);  // an endpoint tile's step fractions: the same 512 bytes (8-byte aligned: the slice is)
+  _Float16 *wadq = reinterpret_cast<_Float16 *>(w_idx + 64) + lane;  // [nplan][64]: |QB - QA| of the lane's edge, rounded UP to binary16 (the certificate; as binary32 the twelve waves' rows no longer fit the LDS beside the pool)
+  // The edge certificate.  An endpoint tile of a two-round launch checks QB with every bounding cull widened
+  // by what the pair can move while the planning joints go from QB back to QA, and every candidate's narrowphase routine
+  // also says whether the pair is clear by that much: an edge all of whose pairs are never enters the pool -- none of its
+  // waypoints can be in contact (planning/utils.py:188-216 would find them all free).  A certificate only ever says
+  // "free"; verdicts and first-bad indices are what they were.
+  const bool cert_tile = kCertBuild && a.cert != 0 && !a.single;
+  int stat_cert = 0;
   char *shared = reinterpret_cast<char *>(smem) + (size_t)NW * wbytes;
   w.ltab = reinterpret_cast<float *>(shared);
   for (int k = threadIdx.x; k < a.nfp; k += blockDim.x) w.ltab[k] = a.fp[k];
@@ -402,6 +418,7 @@ k_edges_fused(FusedArgs a) {
           qx[k * 64] = x;
           qe[k * 64] = y;
           at_end = at_end && (x == y);
+          if constexpr (kCertBuild) wadq[k * 64] = (_Float16)((float)fabs(y - x) * 1.002f);  // (no less than |y - x|: the conversions round by 2^-24 and 2^-11; beyond 65 504: +inf, never certified)
         });
         double tsw;
         K = count_waypoints_walk(a.ip, a.step, active && finite, at_end, qe, 64, qx, 64, a.kmax, nplan, tsw);
@@ -445,7 +462,8 @@ k_edges_fused(FusedArgs a) {
     int code = V_NONE;
     if (!(ep && a.single))  // (an endpoint tile of a single-round launch only counts)
       code = check_wave<MAXS, WBOX, MBOX, Spec>(a.ip, a.fp, w, active, a.tol, ep ? i : (long long)lane, a.uc,
-                                                ep ? (const int *)nullptr : w_edge, ep ? (const int *)nullptr : w_idx, src);
+                                                ep ? (const int *)nullptr : w_edge, ep ? (const int *)nullptr : w_idx, src,
+                                                (ep && fits && cert_tile) ? wadq : (const _Float16 *)nullptr);
     wave_lds_fence();
     if (!ep) {
       if (active && code != V_NONE) {
@@ -462,6 +480,8 @@ k_edges_fused(FusedArgs a) {
       continue;
     }
     // ---- endpoint tile: verdicts, then the survivors' entries
+    const bool certified = active && code == V_CLEAR;  // (free, and every pair clear of contact by what it can move along the edge)
+    if (code == V_CLEAR) code = V_NONE;
     bool survive = active && code != V_CONTACT;
     if (i < a.E) {
       if (!finite) {
@@ -479,9 +499,10 @@ k_edges_fused(FusedArgs a) {
         if (a.first_bad) a.first_bad[i] = -1;
       }
     }
-    if (survive && K < 0) a.llist[atomicAdd(a.lcount, 1)] = (int)i;  // too long (or too many columns): walking kernel
+    if (survive && K < 0 && !certified) a.llist[atomicAdd(a.lcount, 1)] = (int)i;  // too long (or too many columns): walking kernel
     if (a.single) K = K < 0 ? 1 : K + 1;  // (the endpoint is check 0 of the edge's items; of a walking edge the only one)
-    const bool entry = survive && K > 0;
+    const bool entry = survive && K > 0 && !certified;
+    stat_cert += (int)__builtin_popcountll(__ballot(certified && survive && K != 0));
     const double tse = entry ? wts[lane] : 0.0;
     stat_surv += (int)__builtin_popcountll(__ballot(survive));
     pool.commit(entry, K, i, tse);
@@ -494,6 +515,7 @@ k_edges_fused(FusedArgs a) {
     const int region = (int)(blockIdx.x % kItemRegions);
     if (stat_items) atomicAdd(a.item_count + region * kCounterStride, stat_items);
     if (stat_surv) atomicAdd(a.surv_count + region * kCounterStride, stat_surv);
+    if (stat_cert) atomicAdd(a.cert_count, stat_cert);
   }
 }
 

@@ -220,6 +220,7 @@ struct SpecLib {
   typedef int (*FusedFn)(hipStream_t, int, size_t, FusedArgs);  // (waves per workgroup, LDS bytes, arguments)
   FusedFn fused = nullptr;
   int fused_waves = kFusedWaves;  // what its fused kernel was built for (mjpl_spec_fused_waves)
+  bool fused_cert = false;        // ... and whether with the edge certificate (mjpl_spec_fused_cert): LDS rows of |QB - QA|
   // generated PoseConstraint projections, one per site body of the model (mjpl_project.h): chain hashes and launchers
   // (row kernels of mjpl_rows.h: projection index, lanes per row, stream, waves, ...; 0 launched, -1 refused, -2 HIP error)
   typedef int (*PoseApplyFn)(int, int, hipStream_t, unsigned, const int *, const double *, const double *, const double *, int64_t, int64_t,
@@ -317,6 +318,7 @@ struct mjpl_engine {
   // MJPL_FUSED_POLICY (bit 0: item tiles first), MJPL_FUSED_KMAX: A/B measurements
   bool fused = true;
   int fused_policy = 0, fused_kmax = 4096, fused_pool_cap = 0;  // (MJPL_FUSED_POOL: at most that many ring slots)
+  int fused_cert = 1;  // the fused kernel's edge certificate (mjpl_fused.h; MJPL_FUSED_CERT=0: every surviving edge's waypoints are checked)
   bool fused_mbox = false;
   bool f64_queued = true;  // MJPL_F64_QUEUED: the float64 pool kernel checks through the candidate queues (A/B switch)
   int fused_single_max = 32768;  // MJPL_FUSED_SINGLE: batches up to this many edges check every configuration of an edge in one round (measured: 0.068 vs 0.087 ms at 1 024 edges, 0.090 vs 0.102 at 32 768, 0.116 vs 0.106 at 65 536)
@@ -394,13 +396,16 @@ std::mutex &spec_mutex() {
 const SpecLib *find_spec(uint64_t hash, bool generic) {
   std::lock_guard<std::mutex> lock(spec_mutex());
   auto &cache = spec_cache();
-  const uint64_t key = hash ^ (generic ? 0x9e3779b97f4a7c15ull : 0ull);
+  uint64_t key = hash ^ (generic ? 0x9e3779b97f4a7c15ull : 0ull);
+  const char *env_dir = getenv("MJPL_SPEC_DIR");
+  if (env_dir)  // (libraries of another directory are other libraries: e.g. the certificate builds under spec/cert)
+    for (const char *c = env_dir; *c; c++) key = (key ^ (uint64_t)(unsigned char)*c) * 0x100000001b3ull;
   auto it = cache.find(key);
   if (it != cache.end()) return it->second.lib ? &it->second : nullptr;
   SpecLib sl;
   std::string dir;
-  if (const char *d = getenv("MJPL_SPEC_DIR")) {
-    dir = d;
+  if (env_dir) {
+    dir = env_dir;
   } else {
     Dl_info info;
     if (dladdr((const void *)&mjpl_version, &info) && info.dli_fname) {
@@ -426,6 +431,7 @@ const SpecLib *find_spec(uint64_t hash, bool generic) {
     sl.tail = (SpecLib::TailFn)dlsym(lib, "mjpl_spec_launch_tail");
     sl.fused = (SpecLib::FusedFn)dlsym(lib, "mjpl_spec_launch_fused");
     if (auto fw = (int (*)())dlsym(lib, "mjpl_spec_fused_waves")) sl.fused_waves = fw();
+    if (auto fc = (int (*)())dlsym(lib, "mjpl_spec_fused_cert")) sl.fused_cert = fc() != 0;
     sl.pose_hash = (unsigned long long (*)(int))dlsym(lib, "mjpl_spec_pose_hash");
     sl.pose_apply = (SpecLib::PoseApplyFn)dlsym(lib, "mjpl_spec_launch_pose_apply");
     sl.gen_project = (SpecLib::GenProjectFn)dlsym(lib, "mjpl_spec_launch_gen_project");
@@ -896,6 +902,10 @@ int compile_program(mjpl_engine *e) {
       if (!(tol < 1e-2)) e->filter_usable = false;  // a band of centimetres decides nothing useful
     }
     e->filter_tol = (float)tol;
+    // (a candidate record of the filter's queues carries its geom's table offset in 16 bits -- the other half of the word
+    //  is the candidate's certificate margin, mjpl_device.h: queue_drain --: a table of 64 K entries or more, far beyond
+    //  any model the slot file holds, takes the exact path)
+    if (dp.size() + 64 >= 65536) e->filter_usable = false;
     double maxc = (B > 0) ? (0.5 * tol - A) / B : 1e6;
     maxc = std::fmin(std::fmax(maxc, 0.0), 1e6);
     e->fmax_coord = e->filter_usable ? maxc : 0.0;
@@ -1229,12 +1239,13 @@ bool fused_plan(const mjpl_engine *e, int *nwaves, size_t *lds, int *ring = null
   if (!fused_fits(nplan, e->nsave, mbox)) return false;
   const int nw = e->spec ? e->spec->fused_waves : (mbox ? 4 : kFusedWaves);
   const size_t budget = (size_t)160 * 1024;
-  const size_t base = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, 0);
+  const bool cert = e->spec && e->spec->fused_cert;
+  const size_t base = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, 0, cert);
   if (base + (size_t)(64 * nw + 64) * kFusedEntryBytes > budget) return false;
   int r = (int)std::min<size_t>(kFusedMaxPool, (budget - base) / kFusedEntryBytes / 64 * 64);
   if (e->fused_pool_cap > 0) r = std::max(64 * nw + 64, std::min(r, e->fused_pool_cap / 64 * 64));  // (tests: a ring that wraps)
   if (nwaves) *nwaves = nw;
-  if (lds) *lds = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, r);
+  if (lds) *lds = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, r, cert);
   if (ring) *ring = r;
   return true;
 }
@@ -1305,7 +1316,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
                    unsigned long long *dbits) {
   if (N == 0) return MJPL_OK;
   const unsigned grid = (unsigned)((N + kBlock - 1) / kBlock);
-  const bool filter = e->filter && e->filter_usable && dvalid && !dbits && N < (int64_t)1 << 30;
+  const bool filter = e->filter && e->filter_usable && dvalid && !dbits && N < (int64_t)1 << 29;
   if (filter) {
     int rc = ulist_reserve(e, N);
     if (rc != MJPL_OK) return rc;
@@ -1372,7 +1383,7 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
                  int layout, int flags, uint8_t *dvalid, int32_t *dfb) {
   if (E == 0) return MJPL_OK;
   const unsigned grid = (unsigned)((E + kBlock - 1) / kBlock);
-  const bool filter = e->filter && e->filter_usable && E < (int64_t)1 << 30;  // item ids travel in 30 bits of the per-lane flag words
+  const bool filter = e->filter && e->filter_usable && E < (int64_t)1 << 29;  // item ids travel in 29 bits of the per-lane flag words
   UndecidedConfigs uc = {};
   if (filter) {
     int rc = ulist_reserve(e, E);
@@ -1473,6 +1484,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
       fa.tstep = e->d_tstep;
       fa.item_count = e->d_ucount + 5 * kCtr;
       fa.surv_count = e->d_ucount + (5 + kItemRegions) * kCtr;
+      fa.cert_count = e->d_ucount + (size_t)kCtrCertified * kCtr;
+      fa.cert = e->fused_cert;
       fa.zero_next = zero_next;
       fa.kmax = e->fused_kmax; fa.pool = fring; fa.policy = e->fused_policy;
       // a batch that leaves most of the chip idle: one round of checks instead of two (the endpoint as an item)
@@ -1717,6 +1730,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     fa.llist = e->d_llist; fa.lcount = e->d_icount + kCtr;
     fa.item_count = e->d_ucount + 5 * kCtr;
     fa.surv_count = e->d_ucount + (5 + kItemRegions) * kCtr;
+    fa.cert_count = e->d_ucount + (size_t)kCtrCertified * kCtr;
+    fa.cert = 0;
     fa.zero_next = zero_next;
     fa.kmax = kFusedF64Kmax; fa.pool = pool; fa.policy = e->fused_policy;
     MJPL_MARK(0);
@@ -1852,6 +1867,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_TAIL")) e->fused_tail = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FUSED")) e->fused = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FUSED_POLICY")) e->fused_policy = atoi(f);
+  if (const char *f = getenv("MJPL_FUSED_CERT")) e->fused_cert = atoi(f) != 0 ? 1 : 0;
   e->fused_dbg_path = getenv("MJPL_FUSED_DEBUG");
   if (const char *f = getenv("MJPL_FUSED_POOL")) e->fused_pool_cap = atoi(f);
   if (const char *f = getenv("MJPL_FUSED_MBOX")) e->fused_mbox = atoi(f) != 0;
@@ -2080,6 +2096,13 @@ int64_t mjpl_filter_last_items(mjpl_engine *e) {
   int64_t total = 0;  // (reserved slots, as before: a region's surplus went to the walking kernel)
   for (int r = 0; r < kItemRegions; r++) total += n[(size_t)(5 + r) * kCtr];
   return total;
+}
+
+int64_t mjpl_filter_last_certified(mjpl_engine *e) {
+  if (!e || !e->filter || !e->d_ucount) return -1;
+  std::vector<int> n;
+  if (!read_counters(e, n)) return -1;
+  return n[(size_t)kCtrCertified * kCtr];
 }
 
 int mjpl_get_info(const mjpl_engine *e, mjpl_info *out) {

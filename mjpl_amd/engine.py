@@ -108,6 +108,7 @@ ABI = {
     "mjpl_filter_undecided_pairs": (C.c_int64, [_VP, _I32P, _I32P, _I32P, _I32P, C.c_int64]),
     "mjpl_filter_last_interior_edges": (C.c_int64, [_VP]),
     "mjpl_filter_last_items": (C.c_int64, [_VP]),
+    "mjpl_filter_last_certified": (C.c_int64, [_VP]),
     "mjpl_check_configs": (C.c_int, [_VP, _F64P, C.c_int64, C.c_int32, _U8P]),
     "mjpl_check_edges": (C.c_int, [_VP, _F64P, _F64P, C.c_int64, C.c_double, C.c_int32, C.c_int32, _U8P,
                                    _I32P]),
@@ -310,6 +311,10 @@ class Engine:
 
     def last_items(self) -> int:
         return int(self.lib.mjpl_filter_last_items(self.h))
+
+    def last_certified(self) -> int:
+        """Surviving edges of the last launch whose waypoint checks the fused kernel's edge certificate spared."""
+        return int(self.lib.mjpl_filter_last_certified(self.h))
 
     def last_interior_edges(self) -> int:
         return int(self.lib.mjpl_filter_last_interior_edges(self.h))

@@ -210,17 +210,17 @@ class _SharedAxesReused(ValueError):
     """Boxes share an axes slot that the program's slot allocation reuses while they still refer to it."""
 
 
-def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = False) -> str:
+def generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = False, report: dict | None = None) -> str:
     """Straight-line filter code of one program (see _generate).  Moving boxes of one body with one orientation share
     the slot of their x and y axes; where the program's own slot allocation gets in the way of that, every box keeps
     its own."""
     try:
-        return _generate(ip, fp, dp, info, cull_form, generic, share_axes=True)
+        return _generate(ip, fp, dp, info, cull_form, generic, share_axes=True, report=report)
     except _SharedAxesReused:
-        return _generate(ip, fp, dp, info, cull_form, generic, share_axes=False)
+        return _generate(ip, fp, dp, info, cull_form, generic, share_axes=False, report=report)
 
 
-def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = False, share_axes: bool = True) -> str:
+def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = False, share_axes: bool = True, report: dict | None = None) -> str:
     """HIP source of `struct Spec` for one compiled program.
     generic: the ROBOT's code only -- forward kinematics, geom poses, the culls against earlier moving geoms --
     as literals; every static partner (floor, obstacles, the robot's own world-welded base) is a row of the
@@ -272,6 +272,18 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
     # slot to the slot that holds the values, `axes_key` says whose axes a slot holds right now.
     axes_of: dict[int, int] = {}
     axes_key: dict[int, tuple] = {}
+    # The edge certificate (mjpl_fused.h): how far can any point of a moving geom travel while the
+    # planning joints go from one end of an edge to the other?  At most  sum_j |dq_j| rho_j  over the planning hinges j
+    # above it, rho_j = the longest the chain can stretch from joint j's anchor to the geom's centre + the geom's
+    # bounding radius (hinges keep lengths: a triangle inequality along the chain, as `geom_reach` above).  `anc` of a
+    # body: [(planning column, that length up to the body's origin)] root first.  A planning SLIDE joint, or a moving
+    # pair whose earlier geom does not hang on a prefix of the later one's joints, and the library is built without.
+    cert_ok = not generic
+    anc_cur: list = []
+    saved_anc: dict[int, list] = {}
+    slot_anc: dict[int, list] = {}   # slot -> planning columns above the geom stored there
+    cert_stage: list = []            # per stage: the lines of its certificate block
+    cert_levers: list = []           # per stage: (geom id, [(planning column, rho)], bounding radius) -- report["cert_levers"]
 
     for b in range(nbody):
         parent, bdoff, njnt, save_slot, ngeom = (int(ip[pc + k]) for k in (B_PARENT, B_DOFF, B_NJNT, B_SAVE, B_NGEOM))
@@ -293,6 +305,26 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
                 geom_reach += 2.0 * float(np.linalg.norm(dp[jdoff_ + 3: jdoff_ + 6]))
         geom_reach = min(geom_reach, box_reach)
         body_reach_cur = geom_reach
+        # ... and the planning joints above this body with their lever arms
+        anc_parent = [] if parent == PARENT_STATIC else (anc_cur if parent == PARENT_CUR else saved_anc[parent - 1])
+        blen = float(np.linalg.norm(bd[0:3]))
+        anc_body = [(qs, d + blen) for qs, d in anc_parent]
+        for j in range(njnt):
+            jt_, qs_, jd_ = (int(ip[pc + j * J_SIZE + k]) for k in (J_TYPE, J_QSRC, J_DOFF))
+            jp_ = float(np.linalg.norm(dp[jd_ + 3: jd_ + 6]))
+            if jt_ == JT_SLIDE:
+                if qs_ >= 0:
+                    cert_ok = False
+                else:  # a slide joint held at its constant: a fixed offset along its axis
+                    off_ = abs(float(dp[jd_ + 7]) - float(dp[jd_ + 6]))
+                    anc_body = [(qs, d + off_) for qs, d in anc_body]
+            else:
+                anc_body = [(qs, d + 2.0 * jp_) for qs, d in anc_body]
+                if qs_ >= 0:
+                    anc_body.append((qs_, jp_))
+        anc_cur = anc_body
+        if save_slot >= 0:
+            saved_anc[save_slot] = anc_body
         if save_slot >= 0:
             saved_reach[save_slot] = geom_reach
         # ---- parent pose
@@ -406,7 +438,10 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
                     w("  zx = mm_[2]; zy = mm_[5]; zz = mm_[8]; xx = mm_[0]; xy = mm_[3]; xz = mm_[6]; yx = mm_[1]; yy = mm_[4]; yz = mm_[7]; }")
                 else:
                     w("  zx = 2.0f * (g1 * g3 + g0 * g2); zy = 2.0f * (g2 * g3 - g0 * g1); zz = g0 * g0 - g1 * g1 - g2 * g2 + g3 * g3; }")
+            w("/*CERT*/")  # (the stage's certificate block goes here once its partners are known)
             partners = []
+            slot_levels: set = set()
+            slot_k2 = 0.0
             if generic:
                 pmask = wmask = 0  # (static partners: rows of the scene table, tested after the switch)
             wbound = fgd[GD_WBOUND: GD_WBOUND + nwpad]
@@ -419,12 +454,12 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
                 pz = [float(x) for x in fp[off_wnarrow + wrow * WN_LEN + WN_ZAXIS: off_wnarrow + wrow * WN_LEN + WN_ZAXIS + 3]]
                 k = len(partners)
                 dot = lin([(pz[0], "cx"), (pz[1], "cy"), (pz[2], "cz")], -(np.float32(pz[0]) * np.float32(ppos[0]) + np.float32(pz[1]) * np.float32(ppos[1]) + np.float32(pz[2]) * np.float32(ppos[2])))
-                w(f"MJPL_SPEC_HIT({k}, !({dot} + dead > {lit(wbound[wrow])}));")
-                partners.append((EK_PLANE, wrow, GT_PLANE, 1, 1 if curbox else 0, 63))
+                w(f"MJPL_SPEC_HIT({k}, !({dot} + deadp > {lit(wbound[wrow])}));")
+                partners.append((EK_PLANE, wrow, GT_PLANE, 1, 1 if curbox else 0, 63, 0))
             # other static geoms
             w("const float ux = cx + dead;")
             if cull_form == "expanded" and not generic:
-                w("const float cc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, ux * ux));")
+                w("const float cc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, ux * ux)) - wc0;  // (wc0: the certificate's widening, 0 without)")
             statics = []
             for wrow in range(64):
                 if not (wmask >> wrow) & 1:
@@ -434,7 +469,7 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
                 pfirst = 1 if (ptype < gtype or (ptype == gtype and pgid < geom_id)) else 0
                 X, Y, Z = (float(fp[wc_at(wrow, f)]) for f in range(3))
                 statics.append((len(partners), X, Y, Z, wbound[wrow]))
-                partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if (ptype == GT_BOX or curbox) else 0, 63))
+                partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if (ptype == GT_BOX or curbox) else 0, 63, 0))
             if cull_form == "expanded" and statics:
                 reach = geom_reach + float(np.linalg.norm(np.asarray(lpos, dtype=np.float64)))
                 for a, b in zip(statics[0::2], statics[1::2]):
@@ -458,16 +493,25 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
                 pw = swords[n]
                 if generic:  # (lanes 0 .. 31 belong to the scene rows)
                     while len(partners) < SCENE_SLOT_LANE0:
-                        partners.append((0, 0, 0, 0, 0, 0))
+                        partners.append((0, 0, 0, 0, 0, 0, 0))
                 k = len(partners)
-                w(f"MJPL_SPEC_SLOTCULL({k}, {n}, {lit(sbound[n])});")
+                # the planning joints above the stored geom must be a prefix of those above this one (else: no certificate)
+                mine_, theirs_ = [qs for qs, _ in anc_cur], slot_anc.get(n, None)
+                if theirs_ is None or mine_[:len(theirs_)] != theirs_ or len(theirs_) > 7:
+                    cert_ok = False
+                    lvl = 0
+                else:
+                    lvl = len(theirs_)
+                slot_levels.add(lvl)
+                slot_k2 = max(slot_k2, 2.0 * math.sqrt(max(float(sbound[n]), 0.0)))
+                w(f"MJPL_SPEC_SLOTCULL({k}, {n}, {lit(sbound[n])} + ws{lvl});")
                 sptype = (pw >> 12) & 15
                 # (a stored box keeps its x and y axes in a second slot, pw & 63; with a box on either side the pair
                 # takes the box queue, whose records carry full frames)
                 n2 = (pw & 63) if mbox else 63
                 if n2 != 63:
                     n2 = axes_of[n2]
-                partners.append((EK_SLOT, n, sptype, 1 if (pw & P_FIRST) else 0, 1 if (mbox and (curbox or sptype == GT_BOX)) else 0, n2))
+                partners.append((EK_SLOT, n, sptype, 1 if (pw & P_FIRST) else 0, 1 if (mbox and (curbox or sptype == GT_BOX)) else 0, n2, lvl))
             if len(partners) > 64:
                 raise ValueError("a geom with more than 64 enabled partners cannot be specialised")
             store2 = ((store >> 6) & 63) if (store >= 0 and mbox) else 63
@@ -486,12 +530,46 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
                         raise _SharedAxesReused("a shared axes slot is reused while boxes still refer to it")
                     axes_of[store2] = store2
                     axes_key[store2] = key
+            # the certificate block of the stage: suffix sums of |dq_j| rho_j from the deepest planning joint up; level c =
+            # the motion relative to a geom that hangs on the first c of them (0: to the world)
+            sizes_ = [float(x) for x in gd[GD_SIZE: GD_SIZE + 3]]
+            rbound_ = {GT_SPHERE: sizes_[0], GT_CAPSULE: sizes_[0] + sizes_[1], GT_BOX: math.sqrt(sum(x * x for x in sizes_))}.get(gtype, math.inf)
+            lp_ = float(np.linalg.norm(np.asarray(lpos, dtype=np.float64)))
+            k2w = max([2.0 * math.sqrt(max(float(st_[4]), 0.0)) for st_ in statics] + [0.0])
+            if not math.isfinite(rbound_) or len(anc_cur) > 7:
+                cert_ok = False
+            cb = ["float s_ = 0.0f;"]
+            need = sorted(slot_levels | {0})
+            for lv in range(len(anc_cur), -1, -1):
+                if lv < len(anc_cur):
+                    qs_, d_ = anc_cur[lv]
+                    rho_ = (d_ + lp_ + (rbound_ if math.isfinite(rbound_) else 0.0)) * (1.0 + 1e-6)
+                    cb.append(f"s_ = __builtin_fmaf((float)adq[{qs_} * 64], {lit(rho_)}, s_);")
+                if lv in need:
+                    cb.append(f"dm{lv} = __builtin_fmaf(s_, 1.001f, 2.0f * tol);")
+            cb.append(f"wc0 = __builtin_fmaf({lit(k2w * (1.0 + 1e-6))}, dm0, dm0 * dm0); deadp = dead - dm0;")
+            for lv in sorted(slot_levels):
+                cb.append(f"ws{lv} = __builtin_fmaf({lit(slot_k2 * (1.0 + 1e-6))}, dm{lv}, dm{lv} * dm{lv});")
+            cert_stage.append(cb)
+            cert_levers.append((geom_id, [(qs_, d_ + lp_ + (rbound_ if math.isfinite(rbound_) else 0.0)) for qs_, d_ in anc_cur], rbound_))
+            if store >= 0:
+                slot_anc[store & 63] = [qs for qs, _ in anc_cur]
             stages.append((pending_fk + g.lines, gtype, gdoff, store & 63 if store >= 0 else -1, store2))
             pending_fk = []
-            desc.append([(kind << 0) | (index << 2) | (ptype << 10) | (pfirst << 14) | (boxq << 15) | (index2 << 16)
-                         for kind, index, ptype, pfirst, boxq, index2 in partners])
+            desc.append([(kind << 0) | (index << 2) | (ptype << 10) | (pfirst << 14) | (boxq << 15) | (index2 << 16) | (lvl << 22)
+                         for kind, index, ptype, pfirst, boxq, index2, lvl in partners])
     if pending_fk:  # trailing bodies without geoms influence nothing: drop them
         pending_fk = []
+    # The certificate is an opt-in build (MJPL_SPEC_CERT=1): measured on the headline batch it halves the waypoint checks and
+    # gains 3 % -- a workgroup's two rounds of endpoint tiles bound the launch -- while the lines it adds to the code every
+    # tile runs cost 8 % without it (profiles/README.md, round 5).  Without it the generated code carries none of it.
+    cert_ok = cert_ok and cull_form == "expanded" and os.environ.get("MJPL_SPEC_CERT", "0") == "1"
+    if report is not None:
+        report["cert_ok"], report["cert_levers"] = bool(cert_ok), cert_levers
+    if not cert_ok:
+        import re
+        stages = [([re.sub(r" \+ ws\d\)", ")", ln).replace(") - wc0;", ");").replace("deadp", "dead") for ln in lines], gt_, gd_, st_, st2_)
+                  for lines, gt_, gd_, st_, st2_ in stages]
     nstage = len(stages)
     out = []
     o = out.append
@@ -558,6 +636,10 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
         o("")
     o("struct Spec {")
     o(f"  static constexpr int kNplan = {int(ip[H_NPLAN])};")
+    o("  // the edge certificate: with ps.adq = this lane's |dq| per planning column, run() widens every bounding cull by what")
+    o("  // the pair can move along the edge, every candidate carries that margin to its narrowphase routine, and a lane")
+    o("  // none of whose candidates came closer returns V_CLEAR instead of V_NONE (mjpl_fused.h)")
+    o(f"  static constexpr bool kCert = {'true' if cert_ok else 'false'};")
     o("  template <class QT>")
     o("  static __device__ __forceinline__ int run(mjpl::FP tp, const float *ltab, const QT *q, int qstride, float *save,")
     o(f"                                            int sstride, bool active, float tol, const mjpl::WaveQueue<float, {'true' if mbox else 'false'}> &wq,")
@@ -571,7 +653,9 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
     o("    float dead = active ? 0.0f : kInf;")
     o("    bool far = false;")
     o("    int fl = 0, qn = 0, qb = 0;")
-    o("    wq.flags[lane] = (int)((unsigned)item << 2);")
+    o("    wq.flags[lane] = (int)((unsigned)item << 3);")
+    o("    const _Float16 *adq = kCert ? ps.adq : nullptr;")
+    o("    const bool cert = adq != nullptr;  // (wave-uniform)")
     if generic:
         o(f"    // the scene table in front of the float32 tables: header, then per moving geom {SCENE_ROWS} cull rows and {SCENE_ROWS} descriptors")
         o(f"    const FP sc = tp + ({SC});")
@@ -591,6 +675,10 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
     if mbox:
         o("      float xx = 0, xy = 0, xz = 0, yx = 0, yy = 0, yz = 0;  // a moving box: its x and y axes")
     o("      int mlo = 0, mhi = 0;  // lane k holds the hit mask of this geom's partner k")
+    if cert_ok:
+        o("      // the certificate's margins of this geom by level (metres; all zero without) and what they widen the culls by")
+        o("      float dm0 = 0, dm1 = 0, dm2 = 0, dm3 = 0, dm4 = 0, dm5 = 0, dm6 = 0, dm7 = 0;")
+        o("      float wc0 = 0, ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, ws4 = 0, ws5 = 0, ws6 = 0, ws7 = 0, deadp = dead;")
     o("      // ... and the descriptor of partner k: one vector load per stage, issued ahead of the stage's")
     o("      // arithmetic (a scalar load per hit stalls the wave for its whole latency)")
     if generic:
@@ -602,6 +690,14 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
     for si, (lines, gtype, gdoff, store, store2) in enumerate(stages):
         o(f"        case {si}: {{")
         for ln in lines:
+            if ln.strip() == "/*CERT*/":
+                if cert_ok:
+                    o("          deadp = dead;")
+                    o("          if (cert) {")
+                    for cl in cert_stage[si]:
+                        o("            " + cl)
+                    o("          }")
+                continue
             o("      " + ln)
         if generic:
             o(f"          gtype = {gtype}; gdoff = info_bits(sc[8 + {si}]);")
@@ -679,6 +775,12 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
     o("        const int d = __builtin_amdgcn_readlane(dv, k);")
     o("        const int kind = d & 3, index = (d >> 2) & 255, ptype = (d >> 10) & 15;")
     o("        const bool pfirst = (d >> 14) & 1;")
+    o("        // the candidates' certificate margin: this geom's motion relative to the partner (level 0: to the world; 0 without)")
+    if cert_ok:
+        o("        const int lv_ = (d >> 22) & 7;")
+        o("        const float mc_ = lv_ == 0 ? dm0 : (lv_ == 1 ? dm1 : (lv_ == 2 ? dm2 : (lv_ == 3 ? dm3 : (lv_ == 4 ? dm4 : (lv_ == 5 ? dm5 : (lv_ == 6 ? dm6 : dm7))))));")
+    else:
+        o("        const float mc_ = 0.0f;")
     o("        float t6[6] = {0, 0, 0, 0, 0, 0};")
     if mbox:
         # (a switch over the slots in use keeps every access to the slot file a literal one)
@@ -703,17 +805,17 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
     if mbox:
         o("        if ((d >> 15) & 1)")
         o("          queue_push<float, true, true>(wq, qb, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
-        o("                                        gtype, ptype, pfirst, gdoff, cur6, t6, cur6b, t6b);")
+        o("                                        gtype, ptype, pfirst, gdoff, cur6, t6, cur6b, t6b, mc_);")
         o("        else")
         o("          queue_push<float, false, true>(wq, qn, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
-        o("                                         gtype, ptype, pfirst, gdoff, cur6, t6);")
+        o("                                         gtype, ptype, pfirst, gdoff, cur6, t6, nullptr, nullptr, mc_);")
     else:
         o("        if ((d >> 15) & 1)")
         o("          queue_push<float, true>(wq, qb, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
-        o("                                  gtype, ptype, pfirst, gdoff, cur6, t6);")
+        o("                                  gtype, ptype, pfirst, gdoff, cur6, t6, nullptr, nullptr, mc_);")
         o("        else")
         o("          queue_push<float, false>(wq, qn, dead, fl, active, far, ltab, lwcull, lwnarrow, nwpad, tol, ps, pm, kind, index,")
-        o("                                   gtype, ptype, pfirst, gdoff, cur6, t6);")
+        o("                                   gtype, ptype, pfirst, gdoff, cur6, t6, nullptr, nullptr, mc_);")
     o("      }")
     o("      switch (g) {  // (a literal slot index keeps the slot file in registers)")
     put = "spec_put6" if mbox else "slot_put6"
@@ -733,9 +835,9 @@ def _generate(ip, fp, dp, info, cull_form: str | None = None, generic: bool = Fa
         o("    if (qn > 0) queue_drain<float, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
     if (info.wbox or generic) and not mbox:  # (a scene-generic library serves scenes with static boxes whatever scene it was generated from)
         o("    if (qb > 0) queue_drain<float, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, tol, ps);")
-    o("    fl = wq.flags[lane] & 3;")
+    o("    fl = wq.flags[lane] & 7;")
     o("    if (active && far) return V_UNSURE;  // nothing this lane's candidates said can be trusted")
-    o("    return !active ? V_NONE : ((fl & 1) ? V_CONTACT : ((fl & 2) ? V_UNSURE : V_NONE));")
+    o("    return !active ? V_NONE : ((fl & 1) ? V_CONTACT : ((fl & 2) ? V_UNSURE : ((cert && !(fl & 4)) ? V_CLEAR : V_NONE)));")
     o("  }")
     o("};")
     return "\n".join(out) + "\n"
@@ -932,6 +1034,8 @@ int mjpl_spec_launch_tail(hipStream_t st, size_t lds, TailArgs a) {
 // must be what mjpl_spec_fused_waves reports (twelve at three waves per SIMD; eight for a model with moving boxes,
 // whose code is built for two)
 int mjpl_spec_fused_waves(void) { return %(fwaves)d; }
+// 1: the library's check was generated with the edge certificate (MJPL_SPEC_CERT=1): its fused kernel keeps |QB - QA| rows in LDS
+int mjpl_spec_fused_cert(void) { return Spec::kCert ? 1 : 0; }
 int mjpl_spec_launch_fused(hipStream_t st, int nwaves, size_t lds, FusedArgs a) {
   if (nwaves != %(fwaves)d) return -1;
   auto kern = k_edges_fused<Spec, %(maxs)d, %(wbox)s, %(mbox)s, %(fwaves)d>;

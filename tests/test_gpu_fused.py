@@ -18,7 +18,8 @@ from helpers import random_edges  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-KEYS = ("MJPL_FUSED", "MJPL_FUSED_MBOX", "MJPL_FUSED_POOL", "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX", "MJPL_SPEC", "MJPL_UC_CAP", "MJPL_FILTER", "MJPL_F64_QUEUED")
+KEYS = ("MJPL_FUSED", "MJPL_FUSED_MBOX", "MJPL_FUSED_POOL", "MJPL_FUSED_POLICY", "MJPL_FUSED_SINGLE", "MJPL_FUSED_KMAX", "MJPL_SPEC", "MJPL_UC_CAP", "MJPL_FILTER", "MJPL_F64_QUEUED",
+        "MJPL_SPEC_DIR", "MJPL_FUSED_CERT")
 
 
 def _engine(m, qidx=None, base=None, allowed=(), **env):
@@ -163,3 +164,55 @@ def test_models_with_moving_boxes_and_the_interpreter(oracle_mod):
             np.testing.assert_array_equal(got, want, err_msg=f"{seed} {env}")
             np.testing.assert_array_equal(gfb, wfb, err_msg=f"{seed} {env}")
             e.close()
+
+
+def test_edge_certificate_build_returns_the_same_verdicts_with_half_the_waypoint_checks(oracle_mod):
+    """A library generated with the edge certificate (MJPL_SPEC_CERT=1 -- __graft_entry__.build() puts the benchmark model's
+    under spec/cert/): an endpoint tile of a two-round launch widens every bounding cull by what the pair can move along
+    the edge, and an edge none of whose candidates comes closer never enters the pool.  Verdicts and first-bad indices are
+    those of the default library on all edges and of the oracle on a sample; about half of the surviving edges are
+    certified; MJPL_FUSED_CERT=0 turns it off at run time."""
+    from mjpl_amd import specialise
+    cert_dir = os.path.join(specialise.SPEC_DIR, "cert")
+    m, qidx, base = _franka()
+    key = int(specialise.dump_program(m, (), qidx, base)[3].hash)
+    if not os.path.exists(os.path.join(cert_dir, os.path.basename(specialise.spec_path(key)))):
+        pytest.skip("no certificate build of the benchmark model under spec/cert (python __graft_entry__.py makes it)")
+    E = 300000
+    qa, qb = random_edges(m, qidx, E, seed=23)
+    ref = _engine(m, qidx, base)
+    want, wfb = ref.check_edges(qa, qb, 0.01, first_bad=True)
+    assert ref.last_certified() == 0
+    items_plain, surv = ref.last_items(), ref.last_interior_edges()
+    ref.close()
+    orc = oracle_mod.Oracle(m, planning_qidx=qidx, qpos_base=base)
+    n = 20000
+    ov, ofb, _ = orc.valid_edges(qa[:n], qb[:n], 0.01, nthreads=8, info=True)
+    np.testing.assert_array_equal(want[:n], ov)
+    np.testing.assert_array_equal(wfb[:n], ofb)
+    for env, expect_cert in (({"MJPL_SPEC_DIR": cert_dir}, True), ({"MJPL_SPEC_DIR": cert_dir, "MJPL_FUSED_POOL": 832}, True),
+                             ({"MJPL_SPEC_DIR": cert_dir, "MJPL_FUSED_CERT": 0}, False),
+                             ({"MJPL_SPEC_DIR": cert_dir, "MJPL_FUSED_SINGLE": 100000000}, False)):  # (one round of checks: nothing to spare)
+        e = _engine(m, qidx, base, **env)
+        assert e.spec_kind() == 1 and e.info()["fused_edges"]
+        for rep in range(2):
+            got, gfb = e.check_edges(qa, qb, 0.01, first_bad=True)
+            np.testing.assert_array_equal(got, want, err_msg=f"{env} launch {rep}")
+            np.testing.assert_array_equal(gfb, wfb, err_msg=f"{env} launch {rep}")
+        c = e.last_certified()
+        if expect_cert:
+            assert 0.3 * surv < c < 0.7 * surv, (c, surv)
+            assert e.last_items() < 0.7 * items_plain
+        else:
+            assert c == 0
+        e.close()
+    # long edges (a path shortcut): the certificate fails for them -- their joints move too far -- and they are checked in full
+    qa2, qb2 = random_edges(m, qidx, 70000, seed=5)
+    qb2 = np.clip(qa2 + 8.0 * (qb2 - qa2), m.jnt_range[qidx, 0], m.jnt_range[qidx, 1])
+    e = _engine(m, qidx, base, MJPL_SPEC_DIR=cert_dir)
+    r = _engine(m, qidx, base)
+    for x, y in zip(e.check_edges(qa2, qb2, 0.01, first_bad=True), r.check_edges(qa2, qb2, 0.01, first_bad=True)):
+        np.testing.assert_array_equal(x, y)
+    assert e.last_certified() < 0.05 * 70000
+    e.close()
+    r.close()

@@ -211,3 +211,43 @@ def test_folded_exact_fk_equals_the_statement_and_the_oracle(name, oracle_mod, t
             gx, gm = np.asarray(fk["geom_xpos"]).reshape(-1, 3), np.asarray(fk["geom_xmat"]).reshape(-1, 9)
             assert np.array_equal(a[0:3], gx[ga]) and np.array_equal(a[12:15], gx[gb]), (name, trial)
             assert np.array_equal(a[3:12], gm[ga]) and np.array_equal(a[15:24], gm[gb]), (name, trial)
+
+
+def test_certificate_levers_bound_every_geoms_motion(oracle_mod, monkeypatch):
+    """The edge certificate of the fused kernel (mjpl_fused.h; specialise._generate: cert_levers) rests on one claim: while
+    the planning joints travel from QA to QB in a straight line, no point of moving geom g moves farther than
+    sum_j |dq_j| rho_j(g).  Checked against the oracle's FK along densely sampled edges: the path length of every geom's
+    centre plus what its orientation can add (bounding radius x the rotation its frame turned by), and the lever arms
+    themselves (no joint anchor is ever farther from a geom's centre than rho - bounding radius)."""
+    monkeypatch.setenv("MJPL_SPEC_CERT", "1")
+    model = scenes.franka_p(True)
+    qidx, base = scenes.planning_index(model, scenes.FRANKA_ARM_JOINTS), model.keyframe("home").qpos.copy()
+    ip, fp, dp, info = sp.dump_program(model, (), qidx, base)
+    rep = {}
+    sp.generate(ip, fp, dp, info, report=rep)
+    assert rep["cert_ok"] and len(rep["cert_levers"]) == 10
+    orc = oracle_mod.Oracle(model, planning_qidx=qidx, qpos_base=base)
+    rng = np.random.default_rng(17)
+    lo, hi = model.jnt_range[qidx, 0], model.jnt_range[qidx, 1]
+    jbody = [int(model.jnt_bodyid[j]) for j in range(len(qidx))]
+    T = 65
+    for trial in range(60):
+        qa = rng.uniform(lo, hi)
+        d = rng.normal(size=len(qidx))
+        qb = np.clip(qa + rng.choice([0.05, 0.3, 1.0]) * d / np.linalg.norm(d), lo, hi)
+        path = qa[None] + np.linspace(0.0, 1.0, T)[:, None] * (qb - qa)[None]
+        fk = orc.fk(path)
+        gx = np.asarray(fk["geom_xpos"]).reshape(T, -1, 3)
+        gm = np.asarray(fk["geom_xmat"]).reshape(T, -1, 3, 3)
+        xpos = np.asarray(fk["xpos"]).reshape(T, -1, 3)
+        adq = np.abs(qb - qa)
+        for geom_id, levers, rbound in rep["cert_levers"]:
+            bound = sum(adq[qs] * rho for qs, rho in levers)
+            centre = np.linalg.norm(np.diff(gx[:, geom_id], axis=0), axis=1).sum()
+            # the frame's total turning angle along the path: no point of the geom is farther than rbound from its centre
+            rel = np.einsum("tij,tkj->tik", gm[1:, geom_id], gm[:-1, geom_id])
+            ang = np.arccos(np.clip((np.trace(rel, axis1=1, axis2=2) - 1.0) / 2.0, -1.0, 1.0)).sum()
+            assert centre + rbound * ang <= bound * (1 + 1e-9) + 1e-12, (trial, geom_id, centre, ang, bound)
+            for qs, rho in levers:
+                arm = np.linalg.norm(gx[:, geom_id] - xpos[:, jbody[qs]], axis=1).max()
+                assert arm + rbound <= rho * (1 + 1e-9), (trial, geom_id, qs, arm, rho)

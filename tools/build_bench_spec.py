@@ -28,12 +28,16 @@ def main():
         name, _, opts = arg.partition(":")
         flags = [f"-DMJPL_X_{name}"] if not opts else [o for o in opts.split(",") if o.startswith("-")]
         os.environ.pop("MJPL_SPEC_CULL", None)
+        os.environ.pop("MJPL_SPEC_CERT", None)
         for o in opts.split(","):
             if o.startswith("cull="):
                 os.environ["MJPL_SPEC_CULL"] = o[5:]
+            if o.startswith("cert="):  # (CERT:cert=1 -- the check generated with the edge certificate, mjpl_fused.h)
+                os.environ["MJPL_SPEC_CERT"] = o[5:]
         print(specialise.build(m, (), arm, base, force=True, extra_flags=flags,
                                output=os.path.join(ROOT, "variants", f"spec_{name}.so")))
         os.environ.pop("MJPL_SPEC_CULL", None)
+        os.environ.pop("MJPL_SPEC_CERT", None)
 
 
 if __name__ == "__main__":
