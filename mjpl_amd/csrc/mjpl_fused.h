@@ -541,10 +541,17 @@ inline size_t fused_f64_lds_bytes(int nwaves, int nplan, int nsave, int pool, bo
   return (size_t)nwaves * fused_f64_wave_bytes(nplan, nsave, queued) + WorkPool::bytes(pool);
 }
 
-template <int MAXS, bool WBOX, bool MBOX, int NW, bool QUEUED = false>
+// XF: void = the interpreting statement; else a library built with MJPL_SPEC_F64=1 brings the check as straight-line code
+// (struct ExactFull, mjpl_amd/specialise.py: generate_full_exact -- the interpreter's float64 FK with the constants folded in,
+// its culls with the partners' rows as literals, its pushes, drains and routines): the same candidates reach the same
+// routines, the same verdicts.  An experiment the default libraries do not carry: it runs no faster than the interpreter
+// (0.4497 against 0.4473 ms per 262 144 edges: a float64 literal costs two scalar moves where the interpreter's one
+// sixteen-value scalar load brings four partners' rows; profiles/README.md, round 5).
+template <int MAXS, bool WBOX, bool MBOX, int NW, bool QUEUED = false, class XF = void>
 __global__ void __launch_bounds__(NW * 64)
 k_edges_fused_f64(FusedArgs a) {
   static_assert(!QUEUED || (!MBOX && MAXS <= 16), "the queued float64 check serves the slot files of 4 / 8 / 16, no moving boxes");
+  static_assert(std::is_void<XF>::value || QUEUED, "a generated float64 check goes through the candidate queues");
   extern __shared__ double smem[];
   zero_counters(a.zero_next);
   const int nplan = a.ip[H_NPLAN], nsave = a.ip[H_NSAVE];
@@ -629,7 +636,9 @@ k_edges_fused_f64(FusedArgs a) {
     }
     wave_lds_fence();
     bool hit;
-    if constexpr (QUEUED)  // (the tables the drains gather from: the float64 tables in global memory, 23 KB, cache resident)
+    if constexpr (!std::is_void<XF>::value)
+      hit = XF::run(a.dp, col, 64, aux, 64, active, wq, (int)i, sink) == V_CONTACT;
+    else if constexpr (QUEUED)  // (the tables the drains gather from: the float64 tables in global memory, 23 KB, cache resident)
       hit = run_config_queued<double, MAXS, WBOX, false>((IP)a.ip, (DP)a.dp, a.dp, col, 64, aux, 64, active, 0.0, wq, (int)i, sink) == V_CONTACT;
     else
       hit = run_config<double, MAXS, false, WBOX, MBOX>((IP)a.ip, (DP)a.dp, col, 64, aux, 64, active, 0.0, none, i) == V_CONTACT;

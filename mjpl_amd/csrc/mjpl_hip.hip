@@ -219,6 +219,7 @@ struct SpecLib {
   typedef int (*TailFn)(hipStream_t, size_t, TailArgs);
   typedef int (*FusedFn)(hipStream_t, int, size_t, FusedArgs);  // (waves per workgroup, LDS bytes, arguments)
   FusedFn fused = nullptr;
+  FusedFn fused_f64 = nullptr;  // the float64 pool kernel around the model's generated check (mjpl_spec_launch_fused_f64), if it has one
   int fused_waves = kFusedWaves;  // what its fused kernel was built for (mjpl_spec_fused_waves)
   bool fused_cert = false;        // ... and whether with the edge certificate (mjpl_spec_fused_cert): LDS rows of |QB - QA|
   // generated PoseConstraint projections, one per site body of the model (mjpl_project.h): chain hashes and launchers
@@ -318,6 +319,7 @@ struct mjpl_engine {
   // MJPL_FUSED_POLICY (bit 0: item tiles first), MJPL_FUSED_KMAX: A/B measurements
   bool fused = true;
   int fused_policy = 0, fused_kmax = 4096, fused_pool_cap = 0;  // (MJPL_FUSED_POOL: at most that many ring slots)
+  bool f64_spec = true;  // the float64 pool kernel around the library's generated check, when it has one (MJPL_F64_SPEC=0: interpreting)
   int fused_cert = 1;  // the fused kernel's edge certificate (mjpl_fused.h; MJPL_FUSED_CERT=0: every surviving edge's waypoints are checked)
   bool fused_mbox = false;
   bool f64_queued = true;  // MJPL_F64_QUEUED: the float64 pool kernel checks through the candidate queues (A/B switch)
@@ -430,6 +432,7 @@ const SpecLib *find_spec(uint64_t hash, bool generic) {
     sl.items_pw = (SpecLib::ItemsPwFn)dlsym(lib, "mjpl_spec_launch_items_pw");
     sl.tail = (SpecLib::TailFn)dlsym(lib, "mjpl_spec_launch_tail");
     sl.fused = (SpecLib::FusedFn)dlsym(lib, "mjpl_spec_launch_fused");
+    sl.fused_f64 = (SpecLib::FusedFn)dlsym(lib, "mjpl_spec_launch_fused_f64");
     if (auto fw = (int (*)())dlsym(lib, "mjpl_spec_fused_waves")) sl.fused_waves = fw();
     if (auto fc = (int (*)())dlsym(lib, "mjpl_spec_fused_cert")) sl.fused_cert = fc() != 0;
     sl.pose_hash = (unsigned long long (*)(int))dlsym(lib, "mjpl_spec_pose_hash");
@@ -1735,7 +1738,14 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     fa.zero_next = zero_next;
     fa.kmax = kFusedF64Kmax; fa.pool = pool; fa.policy = e->fused_policy;
     MJPL_MARK(0);
-    rc = dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
+    // a model's library may carry the check as straight-line code (ExactFull; MJPL_F64_SPEC=0: the interpreting kernel)
+    bool generated = false;
+    if (queued && e->spec && e->spec->fused_f64 && e->f64_spec && e->spec->generic_rows == 0) {
+      const int r2 = e->spec->fused_f64(e->stream, kFusedF64Waves, flds, fa);
+      if (r2 == 0) generated = true;
+      else if (r2 != -1) return fail(MJPL_E_HIP, "the generated float64 pool kernel failed to launch");
+    }
+    rc = generated ? MJPL_OK : dispatch_variant(e, [&](auto S, auto W, auto M) -> int {
       auto go = [&](auto kern) -> int {
         int r = allow_lds(kern, flds);
         if (r != MJPL_OK) return r;
@@ -1868,6 +1878,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_FUSED")) e->fused = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FUSED_POLICY")) e->fused_policy = atoi(f);
   if (const char *f = getenv("MJPL_FUSED_CERT")) e->fused_cert = atoi(f) != 0 ? 1 : 0;
+  if (const char *f = getenv("MJPL_F64_SPEC")) e->f64_spec = atoi(f) != 0;
   e->fused_dbg_path = getenv("MJPL_FUSED_DEBUG");
   if (const char *f = getenv("MJPL_FUSED_POOL")) e->fused_pool_cap = atoi(f);
   if (const char *f = getenv("MJPL_FUSED_MBOX")) e->fused_mbox = atoi(f) != 0;

@@ -952,6 +952,235 @@ def generate_exact(ip, dp, info, generic: bool = False, fold: bool = True) -> st
     o("};")
     return "\n".join(out) + "\n"
 
+def _exact_body_fk(f, ip, dp, pc, p, qt, R, sin_tag: str):
+    """mj_kinematics of ONE body op as folded straight-line float64 code (the statements of run_config_queued<double> /
+    patch_pairs_body, mjpl_device.h): `pc` at the body op's header.  (p, qt, R): the walk's current state as Fold values.
+    -> (pc behind the joints, new p, qt, R, save slot, number of geoms)."""
+    c, v = f.c, f.v
+    parent, bdoff, njnt, save_slot, ngeom = (int(ip[pc + k]) for k in (B_PARENT, B_DOFF, B_NJNT, B_SAVE, B_NGEOM))
+    pc += B_SIZE
+    bd = dp[bdoff:]
+    if parent == PARENT_CUR:
+        pp, pq, pR = p, qt, R
+    elif parent == PARENT_STATIC:
+        pp, pq, pR = [c(x) for x in bd[7:10]], [c(x) for x in bd[10:14]], [c(x) for x in bd[14:23]]
+    else:
+        k0 = f.n
+        f.n += 1
+        f.emit(f"const double *sv{k0} = save + (size_t){parent - 1} * 7 * sstride;")
+        names = [f"{f.prefix}sv{k0}_{k}" for k in range(7)]
+        f.emit("const double " + ", ".join(f"{names[k]} = sv{k0}[{k} * sstride]" for k in range(7)) + ";")
+        pp, pq = [v(n) for n in names[:3]], [v(n) for n in names[3:]]
+        pR = f.quat2mat(pq)
+    np_ = [f.add(x, y) for x, y in zip(f.mul_mat_vec3(pR, [c(x) for x in bd[0:3]]), pp)]
+    nq_ = f.mul_quat(pq, [c(x) for x in bd[3:7]])
+    for j in range(njnt):
+        jtype, qsrc, jflags, jdoff = (int(ip[pc + k]) for k in (J_TYPE, J_QSRC, J_FLAGS, J_DOFF))
+        pc += J_SIZE
+        jd = dp[jdoff:]
+        qv = v(f"q[{qsrc} * qstride]") if qsrc >= 0 else c(jd[7])
+        dq = f.sub(qv, c(jd[6]))
+        jaxis, jpos = [c(x) for x in jd[0:3]], [c(x) for x in jd[3:6]]
+        if jtype == JT_SLIDE:
+            xaxis = f.rot_vec_quat(jaxis, nq_)
+            np_ = [f.add(np_[r], f.mul(xaxis[r], dq)) for r in range(3)]
+        else:
+            xanchor = np_
+            if jflags & JF_POS_NONZERO:
+                xanchor = [f.add(x, y) for x, y in zip(f.rot_vec_quat(jpos, nq_), np_)]
+            half = f.mul(dq, c(0.5))
+            tag = f"{sin_tag}{j}"
+            f.emit(f"double sn{tag}, cs{tag};")
+            f.emit(f"sincos_half({f.text(half)}, &sn{tag}, &cs{tag});")
+            sn, cs = v(f"sn{tag}"), v(f"cs{tag}")
+            nq_ = f.mul_quat(nq_, [cs, f.mul(jaxis[0], sn), f.mul(jaxis[1], sn), f.mul(jaxis[2], sn)])
+            if jflags & JF_POS_NONZERO:
+                vec = f.rot_vec_quat(jpos, nq_)
+                np_ = [f.sub(xanchor[r], vec[r]) for r in range(3)]
+    nq_ = f.normalize4(nq_)
+    Rn = f.quat2mat(nq_)
+    if save_slot >= 0:
+        f.emit(f"{{ double *sv = save + (size_t){save_slot} * 7 * sstride;")
+        f.emit("  " + " ".join(f"sv[{k} * sstride] = {f.text(np_[k])};" for k in range(3)))
+        f.emit("  " + " ".join(f"sv[{3 + k} * sstride] = {f.text(nq_[k])};" for k in range(4)) + " }")
+    return pc, np_, nq_, Rn, save_slot, ngeom
+
+
+def generate_full_exact(ip, fp, dp, info) -> str | None:
+    """HIP source of `struct ExactFull`: the float64 check of one configuration through the candidate queues
+    (run_config_queued<double>, mjpl_device.h -- what k_edges_fused_f64 calls for every endpoint and waypoint when the
+    filter is off or refused) as straight-line code for ONE compiled program: forward kinematics and geom poses with the
+    constants folded in (mjpl_amd/fold.py), one bounding cull per ENABLED partner with its row of the table as literals,
+    the interpreter's own pushes, drains and narrowphase routines behind them.  The culls are the interpreter's
+    expressions (|c - X|^2 as x x + y y + z z, + dead, against the same bound), so the same candidates reach the same
+    routines: the verdicts are the interpreter's bit for bit.  None: the model keeps the interpreting kernel (moving
+    boxes, a slot file wider than 16, the immediate interpreter).
+    MEASURED (round 5, tools/f64_probe.py): no faster than the interpreting kernel -- 0.4497 against 0.4473 ms per 262 144
+    edges.  The interpreter fetches four partners' rows with one sixteen-value scalar load; every float64 literal here
+    is two scalar moves, and the kernel spills 222 scalar registers.  So libraries carry it only when built with
+    MJPL_SPEC_F64=1; what a generated float64 path would need is the partners' rows from the table (scalar loads) around
+    the folded FK -- the FK is a tenth of the check."""
+    from .fold import Fold
+    if info.immediate or info.mbox or int(info.maxs) > 16:
+        return None
+    nbody, nwpad, maxs = int(ip[H_NBODYOPS]), int(ip[H_NWPAD]), int(info.maxs)
+    off_wcull, off_wnarrow = int(ip[H_OFF_WCULL]), int(ip[H_OFF_WNARROW])
+
+    def wc_at(wrow, f_):
+        return off_wcull + ((wrow >> 2) << 4) + (f_ << 2) + (wrow & 3)
+    state = ["p0", "p1", "p2", "q0", "q1", "q2", "q3"] + [f"R{k}" for k in range(9)]
+    stages, desc, pending = [], [], []
+    pc = int(ip[H_OFF_BODYOPS])
+    known = True  # the walk's state is still a generation-time constant (nothing assigned to the variables yet)
+    cp, cq, cR = None, None, None
+    for b in range(nbody):
+        f = Fold(indent="          ", prefix=f"b{b}_")
+        if known and b == 0:
+            p, qt, R = [f.c(0)] * 3, [f.c(1), f.c(0), f.c(0), f.c(0)], [f.c(x) for x in (1, 0, 0, 0, 1, 0, 0, 0, 1)]
+        else:
+            p, qt, R = [f.v(n) for n in state[:3]], [f.v(n) for n in state[3:7]], [f.v(n) for n in state[7:]]
+        pc, p, qt, R, save_slot, ngeom = _exact_body_fk(f, ip, dp, pc, p, qt, R, f"b{b}j")
+        for name, val in zip(state, p + qt + R):
+            f.emit(f"{name} = {f.text(val)};")
+        known = False
+        pending.extend(["        {"] + f.lines + ["        }"])
+        for gi in range(ngeom):
+            gtype, gflags, gdoff, store, geom_id, smask = (int(ip[pc + k]) for k in (G_TYPE, G_FLAGS, G_DOFF, G_STORE, G_GEOMID, G_SMASK))
+            wmask = (int(ip[pc + G_WMASK_LO]) & 0xFFFFFFFF) | ((int(ip[pc + G_WMASK_HI]) & 0xFFFFFFFF) << 32)
+            pmask = (int(ip[pc + G_PMASK_LO]) & 0xFFFFFFFF) | ((int(ip[pc + G_PMASK_HI]) & 0xFFFFFFFF) << 32)
+            swords = [int(x) for x in ip[pc + G_SIZE: pc + G_SIZE + MAX_SLOTS]]
+            pc += G_SIZE + MAX_SLOTS
+            gd = dp[gdoff:]
+            g = Fold(indent="          ", prefix=f"g{len(stages)}_")
+            sp_, sq_, sR_ = [g.v(n) for n in state[:3]], [g.v(n) for n in state[3:7]], [g.v(n) for n in state[7:]]
+            cpos = sp_ if gflags & GF_SAMEPOS else [g.add(x, y) for x, y in zip(g.mul_mat_vec3(sR_, [g.c(x) for x in gd[0:3]]), sp_)]
+            if gflags & GF_SAMEROT:
+                zax = [sR_[2], sR_[5], sR_[8]]
+            else:  # quat2zaxis(qt (x) lq): the third column of quat2mat, its expressions
+                gq = g.mul_quat(sq_, [g.c(x) for x in gd[3:7]])
+                m_ = g.mul
+                q00, q01, q02 = m_(gq[0], gq[0]), m_(gq[0], gq[1]), m_(gq[0], gq[2])
+                q11, q13, q22, q23, q33 = m_(gq[1], gq[1]), m_(gq[1], gq[3]), m_(gq[2], gq[2]), m_(gq[2], gq[3]), m_(gq[3], gq[3])
+                two = g.c(2.0)
+                zax = [m_(two, g.add(q13, q02)), m_(two, g.sub(q23, q01)), g.add(g.sub(g.sub(q00, q11), q22), q33)]
+            for name, val in zip(("cx", "cy", "cz", "zx", "zy", "zz"), cpos + zax):
+                g.emit(f"{name} = {g.text(val)};")
+            cv = [g.v("cx"), g.v("cy"), g.v("cz")]
+            partners = []
+            wbound = gd[GD_WBOUND: GD_WBOUND + nwpad]
+            sbound = gd[GD_WBOUND + 2 * nwpad: GD_WBOUND + 2 * nwpad + MAX_SLOTS]
+            for wrow in range(64):  # static planes
+                if not (pmask >> wrow) & 1:
+                    continue
+                ppos = [g.c(dp[wc_at(wrow, k)]) for k in range(3)]
+                pz = [g.c(dp[off_wnarrow + wrow * WN_LEN + WN_ZAXIS + k]) for k in range(3)]
+                dif = [g.sub(cv[k], ppos[k]) for k in range(3)]
+                dot = g.sum([g.mul(dif[k], pz[k]) for k in range(3)])
+                g.emit(f"MJPL_X64_HIT({len(partners)}, !({g.text(dot)} + dead > {dlit(wbound[wrow])}));")
+                partners.append((EK_PLANE, wrow, GT_PLANE, 1, 0))
+            for wrow in range(64):  # other static geoms
+                if not (wmask >> wrow) & 1:
+                    continue
+                info_word = int(np.frombuffer(np.float64(dp[wc_at(wrow, 3)]).tobytes(), dtype=np.int32)[0])
+                ptype, pgid = info_word & 255, info_word >> 8
+                pfirst = 1 if (ptype < gtype or (ptype == gtype and pgid < geom_id)) else 0
+                dd = [g.sub(cv[k], g.c(dp[wc_at(wrow, k)])) for k in range(3)]
+                sq = g.sum([g.mul(x, x) for x in dd])
+                g.emit(f"MJPL_X64_HIT({len(partners)}, !({g.text(sq)} + dead > {dlit(wbound[wrow])}));")
+                partners.append((EK_STATIC, wrow, ptype, pfirst, 1 if ptype == GT_BOX else 0))
+            for n in range(maxs):  # earlier moving geoms in the slot file
+                if not (smask >> n) & 1:
+                    continue
+                pw = swords[n]
+                g.emit(f"MJPL_X64_SLOTCULL({len(partners)}, {n}, {dlit(sbound[n])});")
+                partners.append((EK_SLOT, n, (pw >> 12) & 15, 1 if (pw & P_FIRST) else 0, 0))
+            if len(partners) > 64:
+                return None
+            stages.append((pending + g.lines, gtype, gdoff, store & 63 if store >= 0 else -1))
+            pending = []
+            desc.append([(kind << 0) | (index << 2) | (ptype << 10) | (pfirst << 14) | (boxq << 15) for kind, index, ptype, pfirst, boxq in partners])
+    nstage = len(stages)
+    wbox = any((x >> 15) & 1 for d in desc for x in d)
+    out = []
+    o = out.append
+    o(f"// GENERATED: the float64 check of program {info.hash:016x} through the candidate queues -- {nstage} moving geoms, "
+      f"{sum(len(d) for d in desc)} literal pairs")
+    o("#define MJPL_X64_HIT(k, pass) \\")
+    o("  do { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(pass); \\")
+    o("       mjpl::park_mask<k>(mlo, mhi, m_); } while (0)")
+    o("#define MJPL_X64_SLOTCULL(k, n, BOUND) \\")
+    o("  do { const double dx_ = cx - sf.f[0][n], dy_ = cy - sf.f[1][n], dz_ = cz - sf.f[2][n]; \\")
+    o("       MJPL_X64_HIT(k, !(dx_ * dx_ + dy_ * dy_ + dz_ * dz_ + dead > (BOUND))); } while (0)")
+    o(f"__constant__ int kExactDesc[{nstage} * 64] = {{")
+    for d in desc:
+        o("  " + ", ".join(str(x) for x in (d + [0] * (64 - len(d)))) + ",")
+    o("};")
+    o("struct ExactFull {")
+    o(f"  static constexpr int kMaxs = {maxs};")
+    # (outlined: inlined at the pool kernel's one call site the build returned no contact for any waypoint tile while endpoint
+    #  tiles were right -- every variant with a second call site, and this outlined form, return the interpreter's verdicts on
+    #  all edges; observed with ROCm 7.2's compiler at 222 spilled scalar registers, not explained)
+    o("  static __device__ __attribute__((noinline)) int run(const double *ltab, const double *q, int qstride, double *save, int sstride, bool active,")
+    o("                                            const mjpl::WaveQueue<double, false> &wq, int item, const mjpl::PatchSink &ps) {")
+    o("    using namespace mjpl;")
+    o(f"    SlotFile<double, {maxs}> sf;")
+    o("    double p0 = 0, p1 = 0, p2 = 0, q0 = 1, q1 = 0, q2 = 0, q3 = 0;")
+    o("    double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1;")
+    o("    const int lane = threadIdx.x & 63;")
+    o("    double dead = active ? 0.0 : (double)__builtin_inff();")
+    o("    int fl = 0, qn = 0, qb = 0;")
+    o("    wq.flags[lane] = (int)((unsigned)item << 3);")
+    o(f"    const int nwpad = {nwpad};")
+    o(f"    const double *lwcull = ltab + {off_wcull}, *lwnarrow = ltab + {off_wnarrow};")
+    o("#pragma nounroll")
+    o(f"    for (int g = 0; g < {nstage}; g++) {{")
+    o("      if (__builtin_amdgcn_ballot_w64(dead == 0.0) == 0ull && qn == 0 && qb == 0) break;  // every lane decided")
+    o("      double cx = 0, cy = 0, cz = 0, zx = 0, zy = 0, zz = 0;")
+    o("      int mlo = 0, mhi = 0;  // lane k holds the hit mask of this geom's partner k")
+    o("      const int dv = kExactDesc[64 * g + lane];")
+    o("      int gtype = 0, gdoff = 0;")
+    o("      switch (g) {")
+    for si, (lines, gtype, gdoff, store) in enumerate(stages):
+        o(f"        case {si}: {{")
+        out.extend(lines)
+        o(f"          gtype = {gtype}; gdoff = {gdoff};")
+        o("        } break;")
+    o("        default: break;")
+    o("      }")
+    o("      const double cur6[6] = {cx, cy, cz, zx, zy, zz};")
+    o("      for (unsigned long long ab = __builtin_amdgcn_ballot_w64((mlo | mhi) != 0); ab; ab &= ab - 1) {")
+    o("        const int k = (int)__builtin_ctzll(ab);")
+    o("        const unsigned long long pm = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(mlo, k) |")
+    o("                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, k) << 32);")
+    o("        const int d = __builtin_amdgcn_readlane(dv, k);")
+    o("        const int kind = d & 3, index = (d >> 2) & 255, ptype = (d >> 10) & 15;")
+    o("        const bool pfirst = (d >> 14) & 1;")
+    o("        double t6[6] = {0, 0, 0, 0, 0, 0};")
+    o("        if (kind == EK_SLOT) slot_get6(sf, index, t6);")
+    o("        if ((d >> 15) & 1)")
+    o("          queue_push<double, true>(wq, qb, dead, fl, active, false, ltab, lwcull, lwnarrow, nwpad, 0.0, ps, pm, kind, index, gtype, ptype,")
+    o("                                   pfirst, gdoff, cur6, t6);")
+    o("        else")
+    o("          queue_push<double, false>(wq, qn, dead, fl, active, false, ltab, lwcull, lwnarrow, nwpad, 0.0, ps, pm, kind, index, gtype, ptype,")
+    o("                                    pfirst, gdoff, cur6, t6);")
+    o("      }")
+    o("      switch (g) {  // (a literal slot index keeps the slot file in registers)")
+    for si, (_, _, _, store) in enumerate(stages):
+        if store >= 0:
+            o(f"        case {si}: slot_put6(sf, {store}, cur6); break;")
+    o("        default: break;")
+    o("      }")
+    o("    }")
+    o("    if (qn > 0) queue_drain<double, false, true>(wq, qn, ltab, lwcull, lwnarrow, nwpad, 0.0, ps);")
+    if wbox:
+        o("    if (qb > 0) queue_drain<double, true, true>(wq, qb, ltab, lwcull, lwnarrow, nwpad, 0.0, ps);")
+    o("    fl = wq.flags[lane] & 3;")
+    o("    return !active ? V_NONE : ((fl & 1) ? V_CONTACT : V_NONE);")
+    o("  }")
+    o("};")
+    return "\n".join(out) + "\n"
+
+
 _TU = """// GENERATED translation unit: the float32 filter kernels of mjpl_filter.h around one model's Spec.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -962,6 +1191,7 @@ _TU = """// GENERATED translation unit: the float32 filter kernels of mjpl_filte
 namespace {
 %(spec)s
 %(exact)s
+%(exact_full)s
 }  // namespace
 
 using namespace mjpl;
@@ -1042,6 +1272,7 @@ int mjpl_spec_launch_fused(hipStream_t st, int nwaves, size_t lds, FusedArgs a) 
   SPEC_GRANT(kern);
   return fused_launch(kern, nwaves, lds, a, st) == hipSuccess ? 0 : -1;
 }
+%(fused_f64)s
 int mjpl_spec_launch_patch(hipStream_t st, unsigned grid, unsigned block, size_t lds, const int *ip, int nip, const double *dp,
                            int ndp, GeomTable gt, UndecidedConfigs uc, uint8_t *valid, int32_t *first_bad) {
   SPEC_LAUNCH((k_patch_pairs<ExactSpec>), ip, nip, dp, ndp, gt, uc, valid, first_bad);
@@ -1230,13 +1461,24 @@ def _mbox_waves() -> int:
     return max(1, min(3, int(os.environ.get("MJPL_SPEC_MBOX_WAVES", "2"))))
 
 
-def translation_unit(spec: str, exact: str, key: int, info, generic_word: int = 0, pose: str | None = None) -> str:
+_FUSED_F64 = """// the float64 checks of an edge launch through the pool (filter off or refused) around this model's generated check
+int mjpl_spec_launch_fused_f64(hipStream_t st, int nwaves, size_t lds, FusedArgs a) {
+  if (nwaves != kFusedF64Waves) return -1;
+  auto kern = k_edges_fused_f64<ExactFull::kMaxs, %(wbox)s, false, kFusedF64Waves, true, ExactFull>;
+  SPEC_GRANT(kern);
+  return fused_launch(kern, nwaves, lds, a, st) == hipSuccess ? 0 : -2;
+}"""
+
+
+def translation_unit(spec: str, exact: str, key: int, info, generic_word: int = 0, pose: str | None = None, exact_full: str | None = None) -> str:
     """The source of a library: the kernels of mjpl_filter.h / mjpl_fused.h instantiated around `spec` / `exact`,
     and the projections of `pose` (generate_pose_section; None: a library without any)."""
     mbox = bool(info.mbox)
     if pose is None:
         pose = 'extern "C" int mjpl_spec_pose_count(void) { return 0; }\n'
-    return _TU % dict(spec=spec, exact=exact, hash=key, maxs=info.maxs, pose=pose,
+    wbox_s = "true" if (info.wbox or generic_word or mbox) else "false"
+    return _TU % dict(spec=spec, exact=exact, hash=key, maxs=info.maxs, pose=pose, exact_full=exact_full or "",
+                      fused_f64=(_FUSED_F64 % dict(wbox=wbox_s)) if exact_full else "",
                       wbox="true" if (info.wbox or generic_word or mbox) else "false", mbox="true" if mbox else "false",
                       maxsd=32 if mbox else info.maxs,  # (the exact kernels of a model with moving boxes: the general build)
                       # a model with moving boxes keeps whole frames in its slot file and in the box queue's records: built for
@@ -1275,7 +1517,9 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
             nstage += ng
     src = translation_unit(generate(ip, fp, dp, info, generic=generic), generate_exact(ip, dp, info, generic=generic), key, info,
                            (SCENE_ROWS << 8 | nstage) if generic else 0,  # (kSceneRows, moving geoms)
-                           pose=generate_pose_section(model, int(ip[H_NPLAN])))
+                           pose=generate_pose_section(model, int(ip[H_NPLAN])),
+                           # (an experiment, off by default: see generate_full_exact / mjpl_fused.h)
+                           exact_full=generate_full_exact(ip, fp, dp, info) if (not generic and os.environ.get("MJPL_SPEC_F64") == "1") else None)
     # Source and library appear under their final names complete or not at all (os.replace): an engine created
     # while a rebuild is running finds the old library or the new one, never half a file -- a failed dlopen would
     # be remembered as "no library" for the life of that process -- and two builds of one hash cannot interleave.

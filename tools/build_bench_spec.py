@@ -32,6 +32,9 @@ def main():
         for o in opts.split(","):
             if o.startswith("cull="):
                 os.environ["MJPL_SPEC_CULL"] = o[5:]
+            if o.startswith("env="):  # (NAME:env=KEY=VALUE -- a generator switch)
+                k_, _, v_ = o[4:].partition("=")
+                os.environ[k_] = v_
             if o.startswith("cert="):  # (CERT:cert=1 -- the check generated with the edge certificate, mjpl_fused.h)
                 os.environ["MJPL_SPEC_CERT"] = o[5:]
         print(specialise.build(m, (), arm, base, force=True, extra_flags=flags,
