@@ -2752,7 +2752,8 @@ uint64_t chain_hash_of(const std::vector<int> &pi, const std::vector<double> &pd
 // it refills as rows end.  MJPL_ROWS_G: force the lanes per row (A/B timing).
 struct RowsShape { int G; unsigned grid; int64_t per; };
 RowsShape rows_shape(int64_t N) {
-  static const int forced = [] { const char *v = getenv("MJPL_ROWS_G"); return v ? atoi(v) : 0; }();
+  const char *fv = getenv("MJPL_ROWS_G");  // (read per call: tests compare the three kernels on one batch)
+  const int forced = fv ? atoi(fv) : 0;
   const int64_t max_waves = 1024;  // one per SIMD: what the row kernels' registers allow (mjpl_rows.h)
   RowsShape r;
   r.G = N <= 8 * max_waves ? 8 : (N <= 16 * max_waves ? 4 : 1);

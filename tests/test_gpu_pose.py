@@ -278,3 +278,47 @@ def test_constrained_move_to_pose_example(monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, "argv", [path, "-s", "5"])
     assert mod.main()
+
+
+def test_row_kernels_give_the_same_bytes_with_one_four_and_eight_lanes_per_row(monkeypatch):
+    """mjpl_rows.h: the projection and the IK seeds around a generated chain give a row 1, 4 or 8 lanes (by the batch
+    size; MJPL_ROWS_G forces one).  The lanes of a row share out the statements -- which lane computes a sine changes,
+    not the sine -- so projected configurations, verdicts, iteration counts, IK solutions and errors are the same bytes,
+    and equal to the interpreting kernel's (MJPL_POSE_SPEC=0)."""
+    m = scenes.franka_p(obstacles=False)
+    q_home = m.keyframe("home").qpos.copy()
+    rng = np.random.default_rng(33)
+    n = 5000
+    lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+    Q_old = np.clip(q_home + rng.normal(scale=0.08, size=(n, m.nq)), lo, hi)
+    Q_old[:, 7:] = q_home[7:]
+    d = rng.normal(size=(n, m.nq))
+    d[:, 7:] = 0
+    Q = np.clip(Q_old + rng.choice([0.02, 0.05, 0.2], size=(n, 1)) * d / np.linalg.norm(d, axis=1, keepdims=True), lo, hi)
+    kw = dict(z_translation=(-0.05, 0.05), roll=(-0.1, 0.1), pitch=(-0.1, 0.1), q_step=0.5)
+    eng = mjpl.engine.Engine(m)
+    frame = mjpl.site_pose(m, q_home, "ee_site", engine=eng)
+    pc = mjpl.PoseConstraint(m, "ee_site", frame, engine=eng, **kw)
+    assert pc._proj.spec_loaded()
+    movable = np.zeros(m.njnt, np.uint8)
+    movable[:7] = 1
+    target = mjpl.site_pose(m, np.clip(q_home + 0.3, lo, hi), "ee_site", engine=eng)
+    seeds = np.repeat(q_home[None], 1024, axis=0)
+    seeds[:, :7] = rng.uniform(lo[:7], hi[:7], size=(1024, 7))
+    out = {}
+    for g in ("1", "4", "8"):
+        monkeypatch.setenv("MJPL_ROWS_G", g)
+        out[g] = list(pc.apply_batch(Q_old, Q)) + list(eng.ik_solve("ee_site", target.translation(), target.rotation().wxyz, seeds, movable,
+                                                                     iterations=120, restarts=4, restart_seed=5))
+    monkeypatch.delenv("MJPL_ROWS_G")
+    monkeypatch.setenv("MJPL_POSE_SPEC", "0")
+    pi = mjpl.PoseConstraint(m, "ee_site", frame, engine=eng, **kw)
+    assert not pi._proj.spec_loaded()
+    out["interpreting"] = list(pi.apply_batch(Q_old, Q)) + list(eng.ik_solve("ee_site", target.translation(), target.rotation().wxyz, seeds, movable,
+                                                                               iterations=120, restarts=4, restart_seed=5))
+    monkeypatch.delenv("MJPL_POSE_SPEC")
+    assert 0.05 < out["1"][1].mean() < 1.0 and out["1"][4].mean() > 0.5
+    for tag in ("4", "8", "interpreting"):
+        for x, y in zip(out["1"], out[tag]):
+            np.testing.assert_array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8), err_msg=tag)
+    eng.close()

@@ -266,3 +266,37 @@ def test_first_round_of_131072_lanes_equals_the_host_planner_on_a_lane_prefix(or
         np.testing.assert_array_equal(Q[:k], hq)
         np.testing.assert_array_equal(par[:k], hp)
         assert par[k] == 0  # the next chain starts at the root, too: lane 4096 (or later) begins
+
+
+@pytest.mark.parametrize("lanes_per_row", ["1", "4", "8"])
+def test_projecting_extension_makes_the_same_trees_whatever_the_lanes_per_row(lanes_per_row):
+    """The generated chunk kernel (mjpl_rows.h: k_rrt_gen_project_rows) gives a row -- an active lane's chain of steps --
+    one lane, four or eight; by default the host picks by the number of active lanes (rows_shape).  Forced to one value
+    for every chunk (MJPL_RRT_PROJ_G), the trees of three rounds must be, bit for bit, those of the interpreting kernel
+    at one step per launch: the lanes of a row only share out the statements."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    trees = []
+    keys = ("MJPL_RRT_PROJ_STEPS", "MJPL_RRT_PROJ_SLOTS", "MJPL_POSE_SPEC", "MJPL_RRT_PROJ_G")
+    for env in (dict(MJPL_RRT_PROJ_STEPS="1", MJPL_RRT_PROJ_SLOTS="1", MJPL_POSE_SPEC="0"), dict(MJPL_RRT_PROJ_G=lanes_per_row)):
+        old = {k: os.environ.pop(k, None) for k in keys}
+        os.environ.update(env)
+        try:
+            cc, pc, q_goal = _constrained(m, q_init, 7)
+            dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=13, goal_biasing_probability=0.05,
+                                   batch=2048, capacity=1 << 21, pose=pc)
+        finally:
+            for k in keys:
+                os.environ.pop(k, None)
+                if old[k] is not None:
+                    os.environ[k] = old[k]
+        dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 13)
+        infos = [dev.rrt.round() for _ in range(3)]
+        assert infos[-1].nodes[0] > 2000 and infos[-1].nodes[1] > 2000
+        trees.append([dev.rrt.tree(t) for t in (0, 1)])
+        dev.rrt.close()
+    for t in (0, 1):
+        np.testing.assert_array_equal(trees[0][t][0], trees[1][t][0])
+        np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
