@@ -225,7 +225,7 @@ struct SpecLib {
   // generated PoseConstraint projections, one per site body of the model (mjpl_project.h): chain hashes and launchers
   // (row kernels of mjpl_rows.h: projection index, lanes per row, stream, waves, ...; 0 launched, -1 refused, -2 HIP error)
   typedef int (*PoseApplyFn)(int, int, hipStream_t, unsigned, const int *, const double *, const double *, const double *, int64_t, int64_t,
-                             double *, uint8_t *, int32_t *);
+                             double *, uint8_t *, int32_t *, PosePhase);
   typedef int (*GenProjectFn)(int, int, hipStream_t, unsigned, int, int, int, double, int, const int *, const double *, const int *,
                               const double *, const uint8_t *, const double *, const double *, const double *, RrtLanes, RrtCand, int *);
   typedef int (*IkSolveFn)(int, int, hipStream_t, unsigned, const int *, const double *, const double *, int64_t, int64_t, double *, uint8_t *,
@@ -355,8 +355,8 @@ struct mjpl_engine {
   void *comm = nullptr;
   int comm_rank = 0, comm_world = 1;
   // grow-only staging buffers for the host-pointer entry points
-  void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+  void *stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ([6]: the parked-row list of a two-launch projection)
+  size_t stage_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
   // pinned, grow-only host block of the fused small-batch path of the host-pointer entry points
   // (one H2D and one D2H per call instead of five copies from / to pageable memory)
   void *h_pin = nullptr;
@@ -1940,7 +1940,7 @@ void mjpl_destroy(mjpl_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->comm) (void)mjpl_comm_destroy(e);
-  for (int k = 0; k < 6; k++)
+  for (int k = 0; k < 7; k++)
     if (e->stage[k]) (void)hipFree(e->stage[k]);
   if (e->h_pin) (void)hipHostFree(e->h_pin);
   if (e->d_ip) (void)hipFree(e->d_ip);
@@ -2872,9 +2872,34 @@ int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQold, const double *dQ, int
   const int k = pose_spec_index(p);
   if (k >= 0) {
     const RowsShape rs = rows_shape(N);
-    const int rc2 = p->e->spec->pose_apply(k, rs.G, p->e->stream, rs.grid, p->d_pi, p->d_pd, dQold, dQ, N, rs.per, dQout, dok, diters);
-    if (rc2 == 0) return MJPL_OK;
-    if (rc2 != -1) return fail(MJPL_E_HIP, "generated projection kernel failed to launch");
+    mjpl_engine *e = p->e;
+    // MJPL_POSE_PHASE_STEPS=k (an experiment, off by default): a batch too large for several lanes per row in two
+    // launches (mjpl_rows.h: PosePhase) -- every row's first k Newton steps with one lane per row, then the rows that
+    // want more, a list the first launch packs, with eight.  Same bytes; measured SLOWER at 131 072 rows (0.198 ms in
+    // one launch; k = 2 / 3 / 4 / 6: 0.352 / 0.283 / 0.247 / 0.206 -- profiles/r05h_pose_phase.json): eight lanes per row
+    // cost eight times the lanes for 1.6 times the speed, and 40 % of the rows want more than three steps.
+    static const int phase_steps = [] { const char *v = getenv("MJPL_POSE_PHASE_STEPS"); return v ? atoi(v) : 0; }();
+    if (rs.G == 1 && phase_steps > 0) {
+      const size_t need = ((size_t)N * 2 + 16) * sizeof(int32_t);
+      if ((rc = stage_reserve(e, 6, need)) != MJPL_OK) return rc;
+      int32_t *list = (int32_t *)e->stage[6], *itst = list + N;
+      int *count = (int *)(itst + N);
+      HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), e->stream));
+      const PosePhase first = {phase_steps, nullptr, nullptr, list, count, itst};
+      int rc2 = e->spec->pose_apply(k, 1, e->stream, rs.grid, p->d_pi, p->d_pd, dQold, dQ, N, rs.per, dQout, dok, diters, first);
+      if (rc2 == 0) {
+        const PosePhase second = {0, list, count, nullptr, nullptr, itst};
+        rc2 = e->spec->pose_apply(k, 8, e->stream, 1024u, p->d_pi, p->d_pd, dQold, dQ, N, 0, dQout, dok, diters, second);
+        if (rc2 == 0) return MJPL_OK;
+        return fail(MJPL_E_HIP, "generated projection kernel (second launch) failed to launch");
+      }
+      if (rc2 != -1) return fail(MJPL_E_HIP, "generated projection kernel failed to launch");
+    } else {
+      const PosePhase whole = {0, nullptr, nullptr, nullptr, nullptr, nullptr};
+      const int rc2 = e->spec->pose_apply(k, rs.G, e->stream, rs.grid, p->d_pi, p->d_pd, dQold, dQ, N, rs.per, dQout, dok, diters, whole);
+      if (rc2 == 0) return MJPL_OK;
+      if (rc2 != -1) return fail(MJPL_E_HIP, "generated projection kernel failed to launch");
+    }
   }
   hipLaunchKernelGGL(k_pose_apply, dim3(grid), dim3(kPoseBlock), pose_lds(p), p->e->stream, p->d_pi, p->d_pd,
                      dQold, dQ, N, dQout, dok, diters);

@@ -223,17 +223,37 @@ struct PoseRows {
 
 // PoseConstraint.apply for N rows: wave w owns rows [w * per, (w + 1) * per) and refills (header comment).
 // Launch: ceil(N / per) workgroups of one wave; per >= 64 / G.
+// Two launches for a large batch (mjpl_hip.hip: mjpl_pose_apply_dev): the rows' iteration counts differ -- 2.9 Newton
+// steps on average, twenty for a few -- and a wave whose range is used up idles most of its lanes through its slowest
+// rows' tail.  So the first launch (one lane per row) lets a row take `phase_steps` Newton steps at most; a row that
+// wants more parks its working configuration in Qout and its step count in `it_store` and enters `out_list`; the second
+// launch (eight lanes per row: few rows, latency matters) takes its rows from that list (`in_list`, `in_count` on the
+// device: per = ceil(count / waves)) and finishes them.  The same iteration on the same values: the same results.
+struct PosePhase {
+  int phase_steps;           // > 0: a row is parked after that many Newton steps; 0: rows run to their end
+  const int32_t *in_list;    // rows of this launch (null: 0 .. N - 1, read from Q)
+  const int *in_count;
+  int32_t *out_list;         // parked rows
+  int *out_count;
+  int32_t *it_store;         // [N] Newton steps taken by a parked row
+};
+
 template <class PS, int G>
 __global__ void __launch_bounds__(kPoseBlock)
 k_pose_apply_rows(const int *__restrict__ pi, const double *__restrict__ pd, const double *__restrict__ Qold,
                   const double *__restrict__ Q, int64_t N, int64_t per, double *__restrict__ Qout,
-                  uint8_t *__restrict__ ok, int32_t *__restrict__ iters) {
+                  uint8_t *__restrict__ ok, int32_t *__restrict__ iters, PosePhase ph) {
   typedef PoseRows<PS, G> P;
   constexpr int NQ = PS::kNQ;
   __shared__ double xch[G == 1 ? 1 : RowId<G>::kRows * kXchStride];
   const RowId<G> id;
   double *x = xch + (G == 1 ? 0 : id.row * kXchStride);
   const typename P::Consts c(pi, pd);
+  const bool resumed = ph.in_list != nullptr;
+  if (resumed) {  // (the list's length is known on the device only)
+    N = *ph.in_count;
+    per = (N + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
+  }
   int64_t next = (int64_t)blockIdx.x * per;
   const int64_t end = next + per < N ? next + per : N;
   typename P::Row r;
@@ -243,11 +263,13 @@ k_pose_apply_rows(const int *__restrict__ pi, const double *__restrict__ pd, con
     const unsigned long long free_rows = id.rows(!busy);
     if (free_rows != 0ull && next < end) {
       if (!busy) {
-        i = next + id.rank(free_rows);
-        if (i < end) {
+        const int64_t at = next + id.rank(free_rows);
+        if (at < end) {
+          i = resumed ? (int64_t)ph.in_list[at] : at;
+          const double *src = resumed ? Qout : Q;
 #pragma unroll
-          for (int k = 0; k < NQ; k++) { r.qv[k] = Q[i * NQ + k]; r.qold[k] = Qold[i * NQ + k]; }
-          r.it = 0;
+          for (int k = 0; k < NQ; k++) { r.qv[k] = src[i * NQ + k]; r.qold[k] = Qold[i * NQ + k]; }
+          r.it = resumed ? ph.it_store[i] : 0;
           busy = true;
         }
       }
@@ -265,6 +287,21 @@ k_pose_apply_rows(const int *__restrict__ pi, const double *__restrict__ pd, con
         }
         busy = false;
       }
+    }
+    // rows that have had their share of this launch: parked for the next one
+    const bool park = busy && ph.phase_steps > 0 && r.it >= ph.phase_steps;
+    const unsigned long long pm = id.rows(park);
+    if (pm != 0ull) {
+      int base = 0;
+      if (id.lane == (int)__builtin_ctzll(pm)) base = atomicAdd(ph.out_count, __popcll(pm));
+      base = __shfl(base, (int)__builtin_ctzll(pm));
+      if (park && id.g == 0) {
+#pragma unroll
+        for (int k = 0; k < NQ; k++) Qout[i * NQ + k] = r.qv[k];
+        ph.it_store[i] = r.it;
+        ph.out_list[base + id.rank(pm)] = (int32_t)i;
+      }
+      if (park) busy = false;
     }
   }
 }

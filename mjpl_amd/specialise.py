@@ -1436,8 +1436,8 @@ def generate_pose_section(model, nplan: int = 0) -> str:
         return out
     pick = ["  if (G != 1 && G != 4 && G != 8) return -1;", "  switch (3 * k + (G == 8 ? 2 : (G == 4 ? 1 : 0))) {"]
     src += ["int mjpl_spec_launch_pose_apply(int k, int G, hipStream_t st, unsigned grid, const int *pi, const double *pd, const double *Qold,",
-            "                                const double *Q, int64_t N, int64_t per, double *Qout, uint8_t *ok, int32_t *iters) {"] + pick
-    src += cases("hipLaunchKernelGGL((mjpl::k_pose_apply_rows<PoseSpec{k}, {g}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, pi, pd, Qold, Q, N, per, Qout, ok, iters);")
+            "                                const double *Q, int64_t N, int64_t per, double *Qout, uint8_t *ok, int32_t *iters, mjpl::PosePhase ph) {"] + pick
+    src += cases("hipLaunchKernelGGL((mjpl::k_pose_apply_rows<PoseSpec{k}, {g}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, pi, pd, Qold, Q, N, per, Qout, ok, iters, ph);")
     src += done
     src += ["int mjpl_spec_launch_gen_project(int k, int G, hipStream_t st, unsigned grid, int L, int nplan, int S, double eps, int par, const int *pi,",
             "                                 const double *pd, const int *qidx, const double *qbase, const uint8_t *isplan, const double *lo,",
