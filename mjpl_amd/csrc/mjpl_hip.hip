@@ -333,6 +333,7 @@ struct mjpl_engine {
   void *d_nn16 = nullptr;       // ... the matrix-core screen's operands (binary16 rows) and partial results
   size_t nn16_bytes = 0;
   int nn_mfma = 1;              // MJPL_NN_MFMA=0: binary32 screen only
+  int64_t nn_sample = 65536;    // MJPL_NN_SAMPLE: nodes of the strided sample the matrix cores take every query's bound from
   int nn_last = 0;              // what the last mjpl_nearest_dev launched: 0 float64 scan, 1 binary32 screen, 2 matrix-core screen (or 1: see its flag)
   size_t uc_cap = 0, uc_cap_limit = 0;
   int nslots = 0, nsave = 0, maxs = 4;
@@ -1874,6 +1875,7 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   if (const char *f = getenv("MJPL_EXPAND")) e->expand = atoi(f) != 0;
   if (const char *f = getenv("MJPL_PERSIST")) e->persist = atoi(f) != 0 ? 1 : 0;
   if (const char *f = getenv("MJPL_NN_MFMA")) e->nn_mfma = atoi(f) != 0 ? 1 : 0;
+  if (const char *f = getenv("MJPL_NN_SAMPLE")) e->nn_sample = std::max<int64_t>(1024, atoll(f)) / 32 * 32;
   if (const char *f = getenv("MJPL_TAIL")) e->fused_tail = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FUSED")) e->fused = atoi(f) != 0;
   if (const char *f = getenv("MJPL_FUSED_POLICY")) e->fused_policy = atoi(f);
@@ -2264,18 +2266,21 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
       const int64_t stride = n / kSampleNodes;
       const int64_t nc0 = std::min<int64_t>(maxchunks, kSampleNodes / kNNThreads);
       const int64_t ch0 = kSampleNodes / nc0;
-      scan64(kSampleNodes, ch0, nc0, stride);
-      hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc0, seed_idx, seed_d2,
-                         (const int32_t *)nullptr, (const double *)nullptr);
       // the screened scan on the matrix cores (nplan <= 7), unless some coordinate is too large for binary16 -- which the
-      // device finds out while it packs the operands: then that kernel returns at once and the binary32 one runs
-      const bool mfma = e->nn_mfma && nplan <= kNNMMaxPlan;
+      // device finds out while it packs the operands: then those kernels return at once and the float64 sample scan and
+      // the binary32 screen run (which in turn return at once when the matrix cores serve the call)
+      // (the matrix-core kernel reads its node tiles through a buffer descriptor with 32-bit offsets: 2^26 nodes at most)
+      const bool mfma = e->nn_mfma && nplan <= kNNMMaxPlan && n < ((int64_t)1 << 26);
       e->nn_last = mfma ? 2 : 1;
       unsigned *xbits = nullptr;
       int32_t *mp_idx = nullptr;
       double *mp_d2 = nullptr;
       int mparts = 0;
-      if (mfma) {
+      if (!mfma) {
+        scan64(kSampleNodes, ch0, nc0, stride);
+        hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc0, seed_idx, seed_d2,
+                           (const int32_t *)nullptr, (const double *)nullptr, (const unsigned *)nullptr);
+      } else {
         const int64_t npad = (n + 31) / 32 * 32, Mpad = (M + kNNMQueries - 1) / kNNMQueries * kNNMQueries;
         const int64_t qblocks = Mpad / kNNMQueries;
         int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((2048 + qblocks - 1) / qblocks, n / 4096));
@@ -2305,12 +2310,40 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
                            nodes16, (float *)nullptr, xbits);
         hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16,
                            qn, xbits);
-        const dim3 gm((unsigned)qblocks, (unsigned)nsplit);
+        // every query's bound: the sample node the screen likes best, its distance exactly (wild coordinates: the
+        // float64 scan of the sample as before; either pair of kernels leaves at once when the other serves the call)
+        const int64_t msample = std::min<int64_t>(e->nn_sample, n / 16 / 32 * 32);
+        const int64_t mstride = n / msample;
+        const dim3 gm((unsigned)qblocks, (unsigned)nsplit), gs((unsigned)qblocks, 1u);
+#define MJPL_NNM_CASE(NPV)                                                                                                       \
+        case NPV:                                                                                                                \
+          hipLaunchKernelGGL((k_nearest_mfma<NPV, true>), gs, dim3(kNNMWaves * 64), 0, e->stream, dnodes, msample, cap, dqueries, M, \
+                             (const uint4 *)nodes16, (const uint4 *)q16, (const float *)qn, (const unsigned *)xbits, msample,    \
+                             mstride, seed_d2, (int32_t *)nullptr, (double *)nullptr);                                           \
+          break;
+        switch (nplan) {
+          MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7)
+        }
+#undef MJPL_NNM_CASE
+        {
+          const dim3 grid((unsigned)qtiles, (unsigned)nc0);
+#define MJPL_NN_CASE(NPV)                                                                                    \
+          case NPV:                                                                                          \
+            hipLaunchKernelGGL(k_nearest_part<NPV>, grid, dim3(kNNThreads), 0, e->stream, dnodes, kSampleNodes, cap, dqueries, \
+                               M, nplan, ch0, pidx, pd2, stride, (const unsigned *)xbits);                   \
+            break;
+          switch (nplan) {
+            MJPL_NN_CASE(2) MJPL_NN_CASE(3) MJPL_NN_CASE(4) MJPL_NN_CASE(5) MJPL_NN_CASE(6) MJPL_NN_CASE(7)
+          }
+#undef MJPL_NN_CASE
+        }
+        hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc0, seed_idx, seed_d2,
+                           (const int32_t *)nullptr, (const double *)nullptr, (const unsigned *)xbits);
 #define MJPL_NNM_CASE(NPV)                                                                                                \
         case NPV:                                                                                                         \
-          hipLaunchKernelGGL(k_nearest_mfma<NPV>, gm, dim3(kNNMWaves * 64), 0, e->stream, dnodes, n, cap, dqueries, M,    \
+          hipLaunchKernelGGL((k_nearest_mfma<NPV, false>), gm, dim3(kNNMWaves * 64), 0, e->stream, dnodes, n, cap, dqueries, M,    \
                              (const uint4 *)nodes16, (const uint4 *)q16, (const float *)qn, (const unsigned *)xbits, chm, \
-                             (const double *)seed_d2, mp_idx, mp_d2);                                                     \
+                             (int64_t)1, seed_d2, mp_idx, mp_d2, getenv("MJPL_NN_PROBE") ? 1 : 0);                          \
           break;
         switch (nplan) {
           MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7)

@@ -60,7 +60,9 @@ template <int NP>
 __global__ void __launch_bounds__(kNNThreads)
 k_nearest_part(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries,
                int64_t M, int nplan_rt, int64_t chunk, int32_t *__restrict__ pidx, double *__restrict__ pd2,
-               int64_t stride = 1) {  // (stride > 1: every stride-th node only -- a sample; indices are sample indices)
+               int64_t stride = 1,  // (stride > 1: every stride-th node only -- a sample; indices are sample indices)
+               const unsigned *__restrict__ only_if_wild = nullptr) {
+  if (only_if_wild && only_if_wild[1] == 0u) return;  // (the matrix cores found the sample's bounds: k_nearest_mfma<NP, true>)
   constexpr int W = NP ? NP : kNNMaxPlan;
   const int nplan = NP ? NP : nplan_rt;
   __shared__ double tile[W * kNNThreads];
@@ -362,100 +364,231 @@ __device__ __forceinline__ float nn_mfma_threshold(double ref2, double ref, doub
   return f;
 }
 
-template <int NP>
+// The scan's loop, round 5 (profiles/README.md): (1) a wave keeps kNNMAhead node tiles in flight -- with one, every
+// iteration waited for a trip to L2 that the 0.1 us of arithmetic of a tile does not cover; (2) a pair that passes
+// the screen is PARKED -- (node, set) in the lane's own list in LDS, kNNMPark entries -- and the lists are worked off
+// together when one fills up and at the end of the chunk: the exact distance wants fourteen loads from HBM, and
+// taken on the spot a wave waited ~1.5 us for them at one or two live lanes, a hundred and fifty times per chunk.
+// A lane works its list off in the order it was filled, which is scan order per query, with a strict <: the same
+// winner.  Between two passes over the lists the thresholds stand still (they only ever fall), so a few more pairs
+// are parked than the immediate evaluation would have looked at; every one of them is compared exactly.
+// SAMPLE: the pass in front of the scan that gives every query its bound (bound2: the exact squared distance to SOME
+// node).  Round 4 found it with a float64 scan of a strided sample of 16 384 nodes (1.7 ms at planner size, 40 % of
+// the scan behind it); here the same instructions pick the sample node with the smallest screened value -- no
+// threshold, no exact arithmetic in the loop -- and ONE exact distance per lane at the end is the bound: any node's
+// distance is a valid one, and the screen's argmin is within its error of the sample's best.
+constexpr int kNNMAhead = 4, kNNMPark = 32;
+
+template <int NP, bool SAMPLE>
 __global__ void __launch_bounds__(kNNMWaves * 64, 2)
 k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries, int64_t M,
                const uint4 *__restrict__ nodes16, const uint4 *__restrict__ queries16, const float *__restrict__ qnorm,
-               const unsigned *__restrict__ xbits, int64_t chunk, const double *__restrict__ bound2,
-               int32_t *__restrict__ pidx, double *__restrict__ pd2) {
+               const unsigned *__restrict__ xbits, int64_t chunk, int64_t stride, double *__restrict__ bound2,
+               int32_t *__restrict__ pidx, double *__restrict__ pd2, int probe = 0) {
   static_assert(NP <= kNNMMaxPlan, "seven coordinate slots per half of the operand");
-  if (xbits[1] != 0u) return;  // wild coordinates: the binary32 screen serves this call
+  if (xbits[1] != 0u) return;  // wild coordinates: the binary32 screen (and the float64 sample scan) serve this call
+  // a lane's state that the loop itself does not touch lives in LDS (the two accumulator sets, the queries' operands and
+  // the tiles in flight leave ~50 registers): the parked pairs, and per set the best exact distance, its node, the bound
+  constexpr int kThreads = kNNMWaves * 64;
+  __shared__ int32_t park[SAMPLE ? 1 : kNNMPark * kThreads];
+  __shared__ double best_l[SAMPLE ? 1 : kNNMSets * kThreads], ref2_l[SAMPLE ? 1 : kNNMSets * kThreads];
+  __shared__ int32_t bi_l[kNNMSets * kThreads];
   const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, w = threadIdx.x >> 6;
   const int64_t q0 = ((int64_t)blockIdx.x * kNNMWaves + w) * (kNNMSets * 32) + r;
   const double kInf = std::numeric_limits<double>::infinity();
   const double X = (double)__uint_as_float(xbits[0]);
   const double e = 1.5 * 0x1p-22 * X + 0x1p-24, a = 0x1p-16 * NP * X * X;
   nn_h8 bh[kNNMSets], bl[kNNMSets];
-  float nq[kNNMSets], T[kNNMSets];
-  double best[kNNMSets], ref2[kNNMSets];
-  int32_t bi[kNNMSets];
+  float T[kNNMSets];
+  double *best = best_l + (SAMPLE ? 0 : threadIdx.x), *ref2 = ref2_l + (SAMPLE ? 0 : threadIdx.x);  // [set * kThreads]
+  int32_t *bi = bi_l + threadIdx.x;
 #pragma unroll
   for (int s = 0; s < kNNMSets; s++) {
     const int64_t q = q0 + 32 * s;  // (the packed queries are padded to whole workgroups)
     const uint4 u = queries16[4 * q + h], v = queries16[4 * q + 2 + h];
     __builtin_memcpy(&bh[s], &u, 16);
     __builtin_memcpy(&bl[s], &v, 16);
-    nq[s] = qnorm[q];
-    best[s] = kInf;
-    bi[s] = -1;
-    ref2[s] = (q < M) ? bound2[q] : 0.0;
-    T[s] = ref2[s] < kInf ? nn_mfma_threshold<NP>(ref2[s], sqrt(ref2[s]), e, a, nq[s]) : std::numeric_limits<float>::infinity();
-    if (q >= M) T[s] = -std::numeric_limits<float>::infinity();
+    bi[s * kThreads] = -1;
+    if constexpr (SAMPLE) {
+      T[s] = std::numeric_limits<float>::infinity();  // (the smallest screened value so far: a strict < below)
+    } else {
+      const double b2 = (q < M) ? bound2[q] : 0.0;
+      best[s * kThreads] = kInf;
+      ref2[s * kThreads] = b2;
+      T[s] = b2 < kInf ? nn_mfma_threshold<NP>(b2, sqrt(b2), e, a, qnorm[q]) : std::numeric_limits<float>::infinity();
+      if (q >= M || probe) T[s] = -std::numeric_limits<float>::infinity();  // (probe: a timing run in which nothing passes the screen -- wrong answers, the loop alone)
+    }
   }
   const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
   const nn_f16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint4 ua = (lo < hi) ? nodes16[2 * (lo + r) + h] : uint4{0, 0, 0, 0};
-  for (int64_t base = lo; base < hi; base += 32) {
-    nn_h8 av;
-    __builtin_memcpy(&av, &ua, 16);
-    if (base + 32 < hi) ua = nodes16[2 * (base + 32 + r) + h];  // (the next tile travels during this one's arithmetic)
+  int32_t *mypark = park + (SAMPLE ? 0 : threadIdx.x);
+  int parked = 0;
+
+  // exact distance of node `node` from query q: k_nearest_part's statements
+  auto exact = [&](int64_t node, int64_t q) {
+    double ex = 0;
+#pragma unroll
+    for (int c = 0; c < NP; c++) {
+      const double d = nodes[(int64_t)c * cap + node] - queries[(int64_t)c * M + q];
+      ex = ex + d * d;
+    }
+    return ex;
+  };
+  // the lanes' lists, entry j of every lane at a time (the loads of a pass travel together)
+  auto work_off = [&]() {
+    int most = parked;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int other = __shfl_xor(most, o);
+      most = other > most ? other : most;
+    }
+    unsigned touched = 0;
+    for (int j = 0; j < most; j++) {
+      if (j < parked) {
+        const int32_t ent = mypark[j * kThreads];
+        const int s = ent & 3;
+        const int64_t node = lo + (int64_t)(ent >> 2);
+        const double ex = exact(node, q0 + 32 * s);
+        if (ex < best[s * kThreads]) {
+          best[s * kThreads] = ex;
+          bi[s * kThreads] = (int32_t)node;
+          if (ex < ref2[s * kThreads]) { ref2[s * kThreads] = ex; touched |= 1u << s; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kNNMSets; k++)
+      if ((touched >> k) & 1u) {  // (a set's lower bound: its threshold falls; q < M, or nothing of it was ever parked)
+        const double b2 = ref2[k * kThreads];
+        T[k] = nn_mfma_threshold<NP>(b2, sqrt(b2), e, a, qnorm[q0 + 32 * k]);
+      }
+    parked = 0;
+  };
+
+  // One step: the eight instructions of tile `base` into `cur`, and -- issued between them, so that the vector pipe
+  // works while the matrix pipe does (a wave issues in order: with the folds BEHIND its own eight instructions it
+  // waited through them, then left the matrix pipe idle through its folds, and two waves per SIMD only partly fill
+  // each other's gaps: 900 cycles per pair of tiles where the instructions alone are 512) -- the folds of the tile
+  // before it, whose accumulators `prev` are complete.  Then that tile's passes, if any.
+  auto step = [&](nn_f16 (&cur)[kNNMSets], const nn_f16 (&prev)[kNNMSets], const nn_h8 &av, int64_t pbase, bool have_prev) {
+    static_assert(kNNMSets == 4, "eight matrix instructions, half a set's fold behind each");
+    float mins[kNNMSets];
+#pragma unroll
+    for (int j = 0; j < 2 * kNNMSets; j++) {
+      const int s = j & 3;
+      cur[s] = j < kNNMSets ? __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], zero, 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], cur[s], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // (the order written here IS the schedule: nothing moves across)
+      const nn_f16 &t = prev[j >> 1];
+      float m;
+      if ((j & 1) == 0) {
+        m = __builtin_fminf(__builtin_fminf(t[0], t[1]), t[2]);
+        m = __builtin_fminf(__builtin_fminf(m, t[3]), t[4]);
+        m = __builtin_fminf(__builtin_fminf(m, t[5]), t[6]);
+        m = __builtin_fminf(__builtin_fminf(m, t[7]), t[8]);
+      } else {
+        m = mins[j >> 1];
+        m = __builtin_fminf(__builtin_fminf(m, t[9]), t[10]);
+        m = __builtin_fminf(__builtin_fminf(m, t[11]), t[12]);
+        m = __builtin_fminf(__builtin_fminf(m, t[13]), t[14]);
+        m = __builtin_fminf(m, t[15]);
+      }
+      mins[j >> 1] = m;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     bool hit[kNNMSets];
     bool any = false;
-    // (all eight instructions first, four accumulators: the matrix pipe runs back to back while the folds of the
-    //  sets that are through occupy the vector pipe)
-    nn_f16 tt[kNNMSets];
-#pragma unroll
-    for (int s = 0; s < kNNMSets; s++) tt[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], zero, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < kNNMSets; s++) tt[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], tt[s], 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < kNNMSets; s++) {
-      const nn_f16 t = tt[s];
-      float m = __builtin_fminf(__builtin_fminf(t[0], t[1]), t[2]);
-#pragma unroll
-      for (int i = 3; i < 15; i += 2) m = __builtin_fminf(__builtin_fminf(m, t[i]), t[i + 1]);
-      m = __builtin_fminf(m, t[15]);
-      hit[s] = m <= T[s];
+      hit[s] = have_prev && (SAMPLE ? mins[s] < T[s] : mins[s] <= T[s]);
       any = any || hit[s];
     }
-    if (__ballot(any) != 0ull) {
+    if (__ballot(any) == 0ull) return;
+    if constexpr (SAMPLE) {
+#pragma unroll
+      for (int s = 0; s < kNNMSets; s++) {
+        if (!hit[s]) continue;
+        const nn_f16 &t = prev[s];
+        int at = 15;
+#pragma unroll
+        for (int i = 14; i >= 0; i--) at = t[i] == mins[s] ? i : at;
+        T[s] = mins[s];
+        bi[s * kThreads] = (int32_t)(pbase + (at & 3) + 8 * (at >> 2) + 4 * h);
+      }
+    } else {
 #pragma unroll
       for (int s = 0; s < kNNMSets; s++) {
         if (__ballot(hit[s]) == 0ull) continue;
-        const nn_f16 t = tt[s];
-        const int64_t q = q0 + 32 * s;
+        if (__ballot(parked + 16 > kNNMPark) != 0ull) {  // (room for a set's sixteen on every lane, or the lists are worked off first)
+          work_off();
+          if (__ballot(mins[s] <= T[s]) == 0ull) continue;
+        }
+        const nn_f16 &t = prev[s];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-          if (t[i] <= T[s]) {
-            const int64_t node = base + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (node < hi) {
-              double ex = 0;
-#pragma unroll
-              for (int c = 0; c < NP; c++) {
-                const double d = nodes[(int64_t)c * cap + node] - queries[(int64_t)c * M + q];
-                ex = ex + d * d;
-              }
-              if (ex < best[s]) {
-                best[s] = ex;
-                bi[s] = (int32_t)node;
-                if (ex < ref2[s]) {
-                  ref2[s] = ex;
-                  T[s] = nn_mfma_threshold<NP>(ex, sqrt(ex), e, a, nq[s]);
-                }
-              }
-            }
+          const int64_t node = pbase + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (t[i] <= T[s] && node < hi) {
+            mypark[parked * (kNNMWaves * 64)] = (int32_t)(((node - lo) << 2) | s);
+            parked++;
           }
         }
       }
     }
-  }
+  };
+  static_assert(kNNMAhead == 4, "four named registers hold the tiles in flight (an indexed array would live in scratch)");
+  const int ntile = __builtin_amdgcn_readfirstlane((int)((hi - lo + 31) >> 5));  // (wave-uniform, and told so: a scalar register)
+  // tile k of this lane through a buffer descriptor: the chunk's first row in scalar registers, the lane's 32-bit byte
+  // offset in ONE vector register, the tile's offset in a scalar one (a 64-bit address per lane was two registers more
+  // than there are, and its reload from scratch -- a vector-memory operation like the tiles -- waited for every tile in flight)
+  typedef unsigned nn_u4 __attribute__((ext_vector_type(4)));
+  const int64_t rstride = SAMPLE ? stride : 1;  // rows of the packed nodes between two rows of a tile
+  const __amdgpu_buffer_rsrc_t tiles =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(nodes16 + 2 * lo * rstride), 0, 0x7fffffff, 0x00020000);
+  const unsigned loff = (unsigned)((2 * (int64_t)r * rstride + h) * 16);
+  const unsigned tbytes = (unsigned)(64 * rstride * 16);  // (a chunk's tiles span less than 2^31 bytes: mjpl_nearest_dev sizes them so)
+  auto fetch = [&](int k) -> uint4 {
+    if (k >= ntile) return uint4{0, 0, 0, 0};
+    const nn_u4 v = __builtin_amdgcn_raw_buffer_load_b128(tiles, loff, (unsigned)k * tbytes, 0);
+    return uint4{v[0], v[1], v[2], v[3]};
+  };
+  uint4 a0 = fetch(0), a1 = fetch(1), a2 = fetch(2), a3 = fetch(3);
+  nn_f16 ta[kNNMSets], tb[kNNMSets];
 #pragma unroll
-  for (int s = 0; s < kNNMSets; s++) {
-    const int64_t q = q0 + 32 * s;
-    if (q < M) {
-      const int64_t at = ((int64_t)blockIdx.y * 2 + h) * M + q;
-      pidx[at] = bi[s];
-      pd2[at] = best[s];  // (+inf, -1: nothing within the bound among this lane's rows)
+  for (int s = 0; s < kNNMSets; s++) ta[s] = tb[s] = zero;
+  // step k: the instructions of tile k (of a tile of zeros behind the last one) and the folds of tile k - 1
+  auto turn = [&](nn_f16 (&cur)[kNNMSets], const nn_f16 (&prev)[kNNMSets], int k) {
+    nn_h8 av;
+    __builtin_memcpy(&av, &a0, 16);
+    a0 = a1; a1 = a2; a2 = a3;
+    a3 = fetch(k + kNNMAhead);
+    step(cur, prev, av, lo + 32 * (int64_t)(k - 1), k > 0);
+  };
+  for (int k = 0; k <= ntile; k += 2) {  // (<=: one step more, which folds the last tile)
+    turn(tb, ta, k);
+    if (k + 1 <= ntile) turn(ta, tb, k + 1);
+  }
+  if constexpr (SAMPLE) {
+    // one exact distance per lane and set: the bound of its query (the better of the two lanes that share it)
+#pragma unroll
+    for (int s = 0; s < kNNMSets; s++) {
+      const int64_t q = q0 + 32 * s;
+      double ex = kInf;
+      const int32_t liked = bi[s * kThreads];
+      if (q < M && liked >= 0) ex = exact((int64_t)liked * stride, q);
+      const double other = __shfl_xor(ex, 32);
+      ex = other < ex ? other : ex;
+      if (q < M && h == 0) bound2[q] = ex;
+    }
+  } else {
+    work_off();
+#pragma unroll
+    for (int s = 0; s < kNNMSets; s++) {
+      const int64_t q = q0 + 32 * s;
+      if (q < M) {
+        const int64_t at = ((int64_t)blockIdx.y * 2 + h) * M + q;
+        pidx[at] = bi[s * kThreads];
+        pd2[at] = best[s * kThreads];  // (+inf, -1: nothing within the bound among this lane's rows)
+      }
     }
   }
 }
@@ -482,9 +615,11 @@ k_nearest_reduce_ties(const int32_t *__restrict__ pidx, const double *__restrict
 __global__ void __launch_bounds__(kBlock)
 k_nearest_reduce(const int32_t *__restrict__ pidx, const double *__restrict__ pd2, int64_t M, int nchunks,
                  int32_t *__restrict__ out_idx, double *__restrict__ out_d2,
-                 const int32_t *__restrict__ seed_idx = nullptr, const double *__restrict__ seed_d2 = nullptr) {
+                 const int32_t *__restrict__ seed_idx = nullptr, const double *__restrict__ seed_d2 = nullptr,
+                 const unsigned *__restrict__ only_if_wild = nullptr) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= M) return;
+  if (only_if_wild && only_if_wild[1] == 0u) return;
   // (seed: the result over the nodes below the chunks' range -- lower indices, so it goes first)
   double best = seed_d2 ? seed_d2[j] : std::numeric_limits<double>::infinity();
   int32_t bi = seed_idx ? seed_idx[j] : -1;
