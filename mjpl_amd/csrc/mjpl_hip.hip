@@ -2259,7 +2259,7 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
     };
     const unsigned rgridM = (unsigned)((M + kBlock - 1) / kBlock);
     constexpr int64_t kSampleNodes = 16384;
-    if (M >= 16384 && n >= 16 * kSampleNodes && nplan >= 2 && nplan <= 9) {
+    if (M >= 4096 && n >= 16 * kSampleNodes && nplan >= 2 && nplan <= 9) {  // (4 096: the planner's look-up of its tail lanes)
       // Large trees and query sets.  First a strided sample of the nodes, exactly: every query gets a
       // bound close to its answer.  Then the binary32-screened scan of all nodes, eight queries per
       // lane, which evaluates exactly only what lies within that bound.

@@ -384,6 +384,53 @@ k_rrt_finish(int L, int nplan, RrtLanes ln, int32_t *__restrict__ ref, double *_
     for (int c = 0; c < nplan; c++) reached[(int64_t)c * L + l] = ln.C[(int64_t)c * L + l];
 }
 
+// the early look-up of the connect phase's nearest nodes (mjpl_rrt: early_nn): what every lane has reached so far, and
+// whether that is final -- a lane with act == 0 is through, nothing writes its C again in this extension
+__global__ void __launch_bounds__(256)
+k_rrt_early(int L, int nplan, RrtLanes ln, uint8_t *__restrict__ early, double *__restrict__ reached) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  early[l] = ln.act[l] == 0 ? 1 : 0;  // (one read: the lanes still extending may change under this kernel, their rows here are never used)
+  for (int c = 0; c < nplan; c++) reached[(int64_t)c * L + l] = ln.C[(int64_t)c * L + l];
+}
+
+// ... the lanes that were still under way then, packed ([0] of ctr2: how many), with their final targets as queries;
+// the rows behind them repeat the first (the look-up is sized for `room` queries whatever the count)
+__global__ void __launch_bounds__(256)
+k_rrt_late_list(int L, const uint8_t *__restrict__ early, int32_t *__restrict__ pos, int *__restrict__ count) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool late = l < L && early[l] == 0;
+  const unsigned long long m = __ballot(late);
+  if (m == 0ull) return;
+  const int lane = (int)(threadIdx.x & 63);
+  int base = 0;
+  if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, (int)__builtin_ctzll(m));
+  if (late) pos[l] = base + __popcll(m & ((1ull << lane) - 1ull));
+}
+__global__ void __launch_bounds__(256)
+k_rrt_late_fill(int L, int nplan, int room, const double *__restrict__ Tgt, double *__restrict__ q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= room) return;
+  for (int c = 0; c < nplan; c++) q[(int64_t)c * room + i] = Tgt[(int64_t)c * L];  // (lane 0's target: a query like any other)
+}
+__global__ void __launch_bounds__(256)
+k_rrt_late_queries(int L, int nplan, int room, const uint8_t *__restrict__ early, const int32_t *__restrict__ pos,
+                   const double *__restrict__ Tgt, double *__restrict__ q, int *__restrict__ ctr) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L || early[l]) return;
+  const int at = pos[l];
+  if (at >= room) { atomicOr(&ctr[RC_OVERFLOW], 4); return; }  // (cannot happen: lanes only ever leave an extension)
+  for (int c = 0; c < nplan; c++) q[(int64_t)c * room + at] = Tgt[(int64_t)c * L + l];
+}
+__global__ void __launch_bounds__(256)
+k_rrt_near_merge(int L, int room, const uint8_t *__restrict__ early, const int32_t *__restrict__ pos, const int32_t *__restrict__ near_e,
+                 const int32_t *__restrict__ near_late, int32_t *__restrict__ near) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  near[l] = early[l] ? near_e[l] : near_late[pos[l] < room ? pos[l] : 0];
+}
+
 __global__ void __launch_bounds__(256)
 k_rrt_connect(int L, int nplan, RrtLanes ln, int *__restrict__ ctr) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -509,6 +556,22 @@ struct mjpl_rrt {
   // (one per SIMD: the kernels' registers) -- MJPL_RRT_PROJ_G / MJPL_RRT_PROJ_WAVES for A/B timing
   int proj_g = 0;            // 0: lanes per row by the number of active lanes (rows_shape)
   int proj_waves_max = 1024;
+  // The connect phase's nearest neighbours, early (round 5).  A lane's round does not depend on any other lane's (both trees
+  // are the round's snapshot), and the tail of the first extension is a handful of lanes taking a thousand sequential steps
+  // on an otherwise idle chip: once no more than `early_lanes` lanes are still extending, the lanes that are through get
+  // their nearest node of the OTHER tree on a second stream (what they reached is final: ln.C of a lane with act == 0);
+  // the second extension then looks up only the lanes that were still under way, and waits for the early answers.  The
+  // same queries against the same nodes: the same nodes.  MJPL_RRT_EARLY_NN=0 turns it off; MJPL_RRT_EARLY_LANES /
+  // MJPL_RRT_EARLY_MIN_NODES move the thresholds (tests set them low).
+  int early_nn = 1, early_lanes = 4096;
+  int64_t early_min_nodes = 65536;
+  bool early_on = false;      // this round's first extension started the early look-up
+  hipStream_t side = nullptr;
+  hipEvent_t ev_tail = nullptr, ev_near = nullptr;
+  double *d_RAe = nullptr;    // [nplan][L] what the lanes had reached when the early look-up started
+  int32_t *d_near_e = nullptr, *d_late_pos = nullptr, *d_late_near = nullptr;
+  uint8_t *d_early = nullptr; // the lane's answer is the early one
+  double *d_late_q = nullptr; // [nplan][early_lanes] the other lanes' queries, packed (padded with the first of them)
   int *d_ctr = nullptr, *h_ctr = nullptr;
   // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned copies
   int *h_ring = nullptr;      // 4 slots of kRingStride ints: RC_SIZE counters, then the sequence word
@@ -579,9 +642,28 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   const int L = r->L, nplan = r->nplan;
   RrtTrace tr;
   tr.mark(st, "(before the extension)");
-  int rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, Tgt, L, r->ln.near, nullptr);
-  if (rc != MJPL_OK) return rc;
-  tr.mark(st, "nearest neighbour", r->n[t]);
+  int rc = MJPL_OK;
+  if (second && r->early_on) {
+    // the lanes that were through when the first extension's tail began have their answers (or will have: ev_near);
+    // the others -- early_lanes at most -- are looked up now
+    r->early_on = false;
+    const int room = r->early_lanes;
+    HIP_TRY(hipMemsetAsync(r->d_late_near, 0, sizeof(int), st));  // ([0] doubles as the list's counter until the look-up writes it)
+    hipLaunchKernelGGL(k_rrt_late_list, dim3(rgrid(L)), dim3(256), 0, st, L, r->d_early, r->d_late_pos, (int *)r->d_late_near);
+    hipLaunchKernelGGL(k_rrt_late_fill, dim3(rgrid(room)), dim3(256), 0, st, L, nplan, room, Tgt, r->d_late_q);
+    hipLaunchKernelGGL(k_rrt_late_queries, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, room, r->d_early, r->d_late_pos, Tgt, r->d_late_q,
+                       r->d_ctr);
+    HIP_TRY(hipStreamWaitEvent(st, r->ev_near, 0));  // (the look-ups share the engine's scratch: one after the other)
+    rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, r->d_late_q, room, r->d_late_near, nullptr);
+    if (rc != MJPL_OK) return rc;
+    hipLaunchKernelGGL(k_rrt_near_merge, dim3(rgrid(L)), dim3(256), 0, st, L, room, r->d_early, r->d_late_pos, r->d_near_e, r->d_late_near,
+                       r->ln.near);
+    tr.mark(st, "nearest neighbour (the lanes of the tail; the others were looked up early)", r->n[t]);
+  } else {
+    rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, Tgt, L, r->ln.near, nullptr);
+    if (rc != MJPL_OK) return rc;
+    tr.mark(st, "nearest neighbour", r->n[t]);
+  }
   const bool projecting = r->pose != nullptr;
   if (projecting) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_LISTN, 0, 2 * sizeof(int), st));  // (both lists of the extension: empty)
   hipLaunchKernelGGL(k_rrt_begin, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->d_Q[t], r->cap, r->ln, r->d_first, Tgt,
@@ -627,6 +709,18 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
         if (r->h_ctr[RC_OVERFLOW] & 1) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer overrun in a projecting extension");
         if (r->h_ctr[RC_ACTIVE] == 0) break;
         active_bound = r->h_ctr[RC_ACTIVE];
+        if (!second && r->early_nn && !r->early_on && active_bound <= r->early_lanes && r->n[1 - t] >= r->early_min_nodes) {
+          // the tail begins: everything enqueued so far (the acceptance of chunk - 1 last) decides which lanes are through
+          HIP_TRY(hipEventRecord(r->ev_tail, st));
+          HIP_TRY(hipStreamWaitEvent(r->side, r->ev_tail, 0));
+          hipLaunchKernelGGL(k_rrt_early, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan, r->ln, r->d_early, r->d_RAe);
+          e->stream = r->side;  // (the look-up's launches go where the engine's stream points)
+          const int nrc = mjpl_nearest_dev(e, r->d_Q[1 - t], r->n[1 - t], r->cap, r->d_RAe, L, r->d_near_e, nullptr);
+          e->stream = st;
+          if (nrc != MJPL_OK) return nrc;
+          HIP_TRY(hipEventRecord(r->ev_near, r->side));
+          r->early_on = true;
+        }
       }
       // Steps per chunk: one while the chunk's kernels are busy with the lanes there are; more when they are
       // not -- a chunk then costs the latency of its launches whatever it holds, and S steps share it.  The
@@ -801,6 +895,9 @@ void mjpl_rrt_destroy(mjpl_rrt *r) {
   if (!r) return;
   (void)hipSetDevice(r->e->device);
   (void)hipStreamSynchronize(r->e->stream);
+  if (r->side) { (void)hipStreamSynchronize(r->side); (void)hipStreamDestroy(r->side); }
+  if (r->ev_tail) (void)hipEventDestroy(r->ev_tail);
+  if (r->ev_near) (void)hipEventDestroy(r->ev_near);
   for (void *p : r->owned) (void)hipFree(p);
   if (r->h_ctr) (void)hipHostFree(r->h_ctr);
   if (r->h_ring) (void)hipHostFree(r->h_ring);
@@ -852,6 +949,17 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   RA(r->d_ctr, RC_SIZE); RA(r->d_heads, 8 * 1024); RA(r->d_path, (size_t)nplan * 65536);
   RA(r->d_first, 1);  // re-allocated by reset for the number of goals
   RA(r->d_scan, (size_t)(L + kScanBlock - 1) / kScanBlock);
+  if (const char *v = getenv("MJPL_RRT_EARLY_NN")) r->early_nn = atoi(v) != 0 ? 1 : 0;
+  if (const char *v = getenv("MJPL_RRT_EARLY_LANES")) r->early_lanes = std::max(1, atoi(v));
+  if (const char *v = getenv("MJPL_RRT_EARLY_MIN_NODES")) r->early_min_nodes = std::max<int64_t>(1, atoll(v));
+  if (!d->pose) r->early_nn = 0;  // (extensions without a projecting constraint have no such tail)
+  if (r->early_nn) {
+    RA(r->d_RAe, (size_t)nplan * L); RA(r->d_near_e, L); RA(r->d_late_pos, L); RA(r->d_early, L);
+    RA(r->d_late_near, std::max(r->early_lanes, 1)); RA(r->d_late_q, (size_t)nplan * r->early_lanes);
+    HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&r->ev_tail, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&r->ev_near, hipEventDisableTiming));
+  }
 #undef RA
   HIP_TRY(hipHostMalloc((void **)&r->h_ctr, RC_SIZE * sizeof(int)));
   HIP_TRY(hipHostMalloc((void **)&r->h_ring, 4 * kRingStride * sizeof(int)));
@@ -927,6 +1035,7 @@ int rrt_begin(mjpl_rrt *r, int32_t request_stop) {
   const int world = rrt_world(r), rank = rrt_rank(r);
   if (world > 1024) return fail(MJPL_E_CAPACITY, "rrt: world size %d not supported", world);  // (the same on every rank)
   r->round++;
+  r->early_on = false;
   const int grow = (r->round - 1) % 2, other = 1 - grow;  // tree swap every round (rrt.py:234-235)
   {
     const int nf = std::max(r->ngoal, 1);

@@ -300,3 +300,37 @@ def test_projecting_extension_makes_the_same_trees_whatever_the_lanes_per_row(la
     for t in (0, 1):
         np.testing.assert_array_equal(trees[0][t][0], trees[1][t][0])
         np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
+
+
+@pytest.mark.parametrize("early_lanes", ["64", "3000"])
+def test_connect_phase_neighbours_looked_up_early_make_the_same_trees(early_lanes):
+    """Round 5: once no more than MJPL_RRT_EARLY_LANES lanes of the first extension are still under way, the lanes that are
+    through get their nearest node of the other tree on a second stream while the tail runs; the second extension looks up
+    the rest and merges (mjpl_rrt.h: early_nn).  The same queries against the same snapshot: the trees of four rounds must
+    be, bit for bit, those of a planner that looks all lanes up after the first extension (MJPL_RRT_EARLY_NN=0)."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    trees = []
+    keys = ("MJPL_RRT_EARLY_NN", "MJPL_RRT_EARLY_LANES", "MJPL_RRT_EARLY_MIN_NODES")
+    for env in (dict(MJPL_RRT_EARLY_NN="0"), dict(MJPL_RRT_EARLY_NN="1", MJPL_RRT_EARLY_LANES=early_lanes, MJPL_RRT_EARLY_MIN_NODES="1")):
+        old = {k: os.environ.pop(k, None) for k in keys}
+        os.environ.update(env)
+        try:
+            cc, pc, q_goal = _constrained(m, q_init, 7)
+            dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=17, goal_biasing_probability=0.05,
+                                   batch=4096, capacity=1 << 21, pose=pc)
+        finally:
+            for k in keys:
+                os.environ.pop(k, None)
+                if old[k] is not None:
+                    os.environ[k] = old[k]
+        dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 17)
+        infos = [dev.rrt.round() for _ in range(4)]
+        assert infos[-1].nodes[0] > 5000 and infos[-1].nodes[1] > 5000
+        trees.append([dev.rrt.tree(t) for t in (0, 1)])
+        dev.rrt.close()
+    for t in (0, 1):
+        np.testing.assert_array_equal(trees[0][t][0], trees[1][t][0])
+        np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
