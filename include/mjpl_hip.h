@@ -227,6 +227,14 @@ int mjpl_check_configs_bits_dev(mjpl_engine *e, const double *dQ, int64_t N, int
 int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap,
                      const double *dqueries, int64_t M, int32_t *dout_idx, double *dout_dist2);
 
+/* The same over the node range [n0, n) only, behind an answer for the nodes below n0 (dprev_idx, dprev_dist2: what an
+ * earlier mjpl_nearest_dev over the first n0 nodes returned for these queries; NULL, NULL: none): the result is the
+ * whole scan's -- a node of the range wins only if it is strictly nearer, so ties still go to the lowest index
+ * (Tree.nearest_neighbor, planning/tree.py:57-66, over a tree that has grown since it was last scanned). */
+int mjpl_nearest_range_dev(mjpl_engine *e, const double *dnodes, int64_t n0, int64_t n, int64_t cap,
+                           const double *dqueries, int64_t M, int32_t *dout_idx, double *dout_dist2,
+                           const int32_t *dprev_idx, const double *dprev_dist2);
+
 /* Which screen the last mjpl_nearest_dev ran in front of its float64 distances: 0 none (plain float64 scan),
  * 1 binary32 on the vector units, 2 binary16 operands on the matrix cores (large trees and query sets whose
  * coordinates are all below 256 in magnitude and whose nodes' squared norms are below 65504, the range of

@@ -333,6 +333,7 @@ struct mjpl_engine {
   void *d_nn16 = nullptr;       // ... the matrix-core screen's operands (binary16 rows) and partial results
   size_t nn16_bytes = 0;
   int nn_mfma = 1;              // MJPL_NN_MFMA=0: binary32 screen only
+  void *d_nn_tmp = nullptr; size_t nn_tmp_bytes = 0;  // distances of a ranged look-up whose caller wants none
   int64_t nn_sample = 65536;    // MJPL_NN_SAMPLE: nodes of the strided sample the matrix cores take every query's bound from
   int nn_last = 0;              // what the last mjpl_nearest_dev launched: 0 float64 scan, 1 binary32 screen, 2 matrix-core screen (or 1: see its flag)
   size_t uc_cap = 0, uc_cap_limit = 0;
@@ -1956,6 +1957,7 @@ void mjpl_destroy(mjpl_engine *e) {
   if (e->d_geomtab) (void)hipFree(e->d_geomtab);
   if (e->d_nn) (void)hipFree(e->d_nn);
   if (e->d_nn16) (void)hipFree(e->d_nn16);
+  if (e->d_nn_tmp) (void)hipFree(e->d_nn_tmp);
   if (e->d_tstep) (void)hipFree(e->d_tstep);
   if (e->d_itemck) (void)hipFree(e->d_itemck);
   if (e->d_itemedge) (void)hipFree(e->d_itemedge);
@@ -2207,11 +2209,62 @@ int32_t mjpl_nearest_last_screen(mjpl_engine *e) {
   return x[1] ? 1 : 2;  // (coordinates too large for binary16: the binary32 screen ran)
 }
 
+}  // extern "C"
+
+// the look-up over nodes [0, n) of the slab at `dnodes` (column stride `cap`); outer_d2 (or NULL): a distance every query
+// already has an answer at -- nothing farther is of interest
+static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap, const double *dqueries, int64_t M,
+                        int32_t *dout_idx, double *dout_dist2, const double *outer_d2);
+
+// mjpl_nearest_dev over the node range [n0, n) behind an answer (outer_idx, outer_d2: NULL = none) for the nodes below n0
+int nearest_range(mjpl_engine *e, const double *dnodes, int64_t n0, int64_t n, int64_t cap, const double *dqueries, int64_t M,
+                  int32_t *dout_idx, double *dout_dist2, const int32_t *outer_idx, const double *outer_d2) {
+  if (n0 == 0 && !outer_idx) return nearest_core(e, dnodes, n, cap, dqueries, M, dout_idx, dout_dist2, nullptr);
+  if (n0 < 0 || n0 > n || (outer_idx && !outer_d2)) return fail(MJPL_E_ARG, "nearest_range: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  double *d2 = dout_dist2;
+  if (!d2) {
+    if ((size_t)M * sizeof(double) > e->nn_tmp_bytes) {
+      if (e->d_nn_tmp) HIP_TRY(hipFree(e->d_nn_tmp));
+      e->d_nn_tmp = nullptr; e->nn_tmp_bytes = 0;
+      HIP_TRY(hipMalloc(&e->d_nn_tmp, (size_t)M * sizeof(double)));
+      e->nn_tmp_bytes = (size_t)M * sizeof(double);
+    }
+    d2 = (double *)e->d_nn_tmp;
+  }
+  if (n > n0) {
+    const int rc = nearest_core(e, dnodes + n0, n - n0, cap, dqueries, M, dout_idx, d2, outer_idx ? outer_d2 : nullptr);
+    if (rc != MJPL_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_nearest_rebase, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, M, n0, n > n0 ? 1 : 0, dout_idx,
+                     d2, dout_dist2, outer_idx, outer_d2);
+  HIP_TRY(hipGetLastError());
+  return MJPL_OK;
+}
+
+extern "C" {
+
 int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap, const double *dqueries,
                      int64_t M, int32_t *dout_idx, double *dout_dist2) {
   if (!e || n < 0 || M < 0 || cap < n) return fail(MJPL_E_ARG, "mjpl_nearest_dev: bad sizes");
   if (M == 0) return MJPL_OK;
   if (!dnodes || !dqueries || !dout_idx) return fail(MJPL_E_ARG, "mjpl_nearest_dev: NULL pointer");
+  return nearest_core(e, dnodes, n, cap, dqueries, M, dout_idx, dout_dist2, nullptr);
+}
+
+int mjpl_nearest_range_dev(mjpl_engine *e, const double *dnodes, int64_t n0, int64_t n, int64_t cap, const double *dqueries,
+                           int64_t M, int32_t *dout_idx, double *dout_dist2, const int32_t *dprev_idx, const double *dprev_dist2) {
+  if (!e || n < 0 || n0 < 0 || n0 > n || M < 0 || cap < n) return fail(MJPL_E_ARG, "mjpl_nearest_range_dev: bad sizes");
+  if (M == 0) return MJPL_OK;
+  if (!dnodes || !dqueries || !dout_idx || ((dprev_idx == nullptr) != (dprev_dist2 == nullptr)))
+    return fail(MJPL_E_ARG, "mjpl_nearest_range_dev: NULL pointer");
+  return nearest_range(e, dnodes, n0, n, cap, dqueries, M, dout_idx, dout_dist2, dprev_idx, dprev_dist2);
+}
+
+}  // extern "C"
+
+static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t cap, const double *dqueries, int64_t M,
+                        int32_t *dout_idx, double *dout_dist2, const double *outer_d2) {
   HIP_TRY(hipSetDevice(e->device));
   const int nplan = (int)e->qidx.size();
   if (nplan <= kNNMaxPlan && n > 0) {
@@ -2259,11 +2312,15 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
     };
     const unsigned rgridM = (unsigned)((M + kBlock - 1) / kBlock);
     constexpr int64_t kSampleNodes = 16384;
-    if (M >= 4096 && n >= 16 * kSampleNodes && nplan >= 2 && nplan <= 9) {  // (4 096: the planner's look-up of its tail lanes)
+    // (4 096 queries: the planner's look-up of its tail lanes.  A ranged look-up brings a bound for every query with it -- the
+    //  distance already found below the range: screened from 8 192 nodes on.  It still takes the sample of its range: the
+    //  nodes a round adds reach into places the tree was far from, and a query there would otherwise park every one of them)
+    const bool have_bound = outer_d2 != nullptr;
+    if (M >= 4096 && (n >= 16 * kSampleNodes || (have_bound && n >= 8192)) && nplan >= 2 && nplan <= 9) {
       // Large trees and query sets.  First a strided sample of the nodes, exactly: every query gets a
       // bound close to its answer.  Then the binary32-screened scan of all nodes, eight queries per
       // lane, which evaluates exactly only what lies within that bound.
-      const int64_t stride = n / kSampleNodes;
+      const int64_t stride = std::max<int64_t>(1, n / kSampleNodes);
       const int64_t nc0 = std::min<int64_t>(maxchunks, kSampleNodes / kNNThreads);
       const int64_t ch0 = kSampleNodes / nc0;
       // the screened scan on the matrix cores (nplan <= 7), unless some coordinate is too large for binary16 -- which the
@@ -2276,10 +2333,12 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
       int32_t *mp_idx = nullptr;
       double *mp_d2 = nullptr;
       int mparts = 0;
+      const int64_t nsamp64 = std::min<int64_t>(kSampleNodes, n / kNNThreads * kNNThreads);  // (a short range: all of it)
       if (!mfma) {
-        scan64(kSampleNodes, ch0, nc0, stride);
-        hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc0, seed_idx, seed_d2,
-                           (const int32_t *)nullptr, (const double *)nullptr, (const unsigned *)nullptr);
+        scan64(nsamp64, ch0, (nsamp64 + ch0 - 1) / ch0, stride);
+        hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)((nsamp64 + ch0 - 1) / ch0), seed_idx,
+                           seed_d2, (const int32_t *)nullptr, (const double *)nullptr, (const unsigned *)nullptr);
+        if (have_bound) hipLaunchKernelGGL(k_nearest_bound_min, dim3(rgridM), dim3(kBlock), 0, e->stream, seed_d2, outer_d2, M);
       } else {
         const int64_t npad = (n + 31) / 32 * 32, Mpad = (M + kNNMQueries - 1) / kNNMQueries * kNNMQueries;
         const int64_t qblocks = Mpad / kNNMQueries;
@@ -2312,8 +2371,8 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
                            qn, xbits);
         // every query's bound: the sample node the screen likes best, its distance exactly (wild coordinates: the
         // float64 scan of the sample as before; either pair of kernels leaves at once when the other serves the call)
-        const int64_t msample = std::min<int64_t>(e->nn_sample, n / 16 / 32 * 32);
-        const int64_t mstride = n / msample;
+        const int64_t msample = std::max<int64_t>(32, std::min<int64_t>(e->nn_sample, n / 16 / 32 * 32));
+        const int64_t mstride = std::max<int64_t>(1, n / msample);
         const dim3 gm((unsigned)qblocks, (unsigned)nsplit), gs((unsigned)qblocks, 1u);
 #define MJPL_NNM_CASE(NPV)                                                                                                       \
         case NPV:                                                                                                                \
@@ -2326,10 +2385,10 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
         }
 #undef MJPL_NNM_CASE
         {
-          const dim3 grid((unsigned)qtiles, (unsigned)nc0);
+          const dim3 grid((unsigned)qtiles, (unsigned)((nsamp64 + ch0 - 1) / ch0));
 #define MJPL_NN_CASE(NPV)                                                                                    \
           case NPV:                                                                                          \
-            hipLaunchKernelGGL(k_nearest_part<NPV>, grid, dim3(kNNThreads), 0, e->stream, dnodes, kSampleNodes, cap, dqueries, \
+            hipLaunchKernelGGL(k_nearest_part<NPV>, grid, dim3(kNNThreads), 0, e->stream, dnodes, nsamp64, cap, dqueries, \
                                M, nplan, ch0, pidx, pd2, stride, (const unsigned *)xbits);                   \
             break;
           switch (nplan) {
@@ -2337,8 +2396,9 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
           }
 #undef MJPL_NN_CASE
         }
-        hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)nc0, seed_idx, seed_d2,
-                           (const int32_t *)nullptr, (const double *)nullptr, (const unsigned *)xbits);
+        hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)((nsamp64 + ch0 - 1) / ch0), seed_idx,
+                           seed_d2, (const int32_t *)nullptr, (const double *)nullptr, (const unsigned *)xbits);
+        if (have_bound) hipLaunchKernelGGL(k_nearest_bound_min, dim3(rgridM), dim3(kBlock), 0, e->stream, seed_d2, outer_d2, M);
 #define MJPL_NNM_CASE(NPV)                                                                                                \
         case NPV:                                                                                                         \
           hipLaunchKernelGGL((k_nearest_mfma<NPV, false>), gm, dim3(kNNMWaves * 64), 0, e->stream, dnodes, n, cap, dqueries, M,    \
@@ -2393,6 +2453,8 @@ int mjpl_nearest_dev(mjpl_engine *e, const double *dnodes, int64_t n, int64_t ca
   HIP_TRY(hipGetLastError());
   return MJPL_OK;
 }
+
+extern "C" {
 
 // ---- host-buffer
 

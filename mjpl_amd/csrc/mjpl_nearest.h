@@ -612,6 +612,28 @@ k_nearest_reduce_ties(const int32_t *__restrict__ pidx, const double *__restrict
   if (out_d2) out_d2[j] = best;
 }
 
+// A look-up over the node range [index0, n) only, behind an answer for the nodes below it (the planner looks a round's
+// targets up in the nodes a tree had a round ago while that round's tail runs, and in the nodes the round added afterwards):
+// k_nearest_bound_min lowers every query's bound (from the range's own sample) to the distance already found;
+// k_nearest_rebase turns the range's indices into node ids and keeps the earlier answer unless the range holds a strictly nearer node (lower indices win ties).
+__global__ void __launch_bounds__(kBlock)
+k_nearest_bound_min(double *__restrict__ bound2, const double *__restrict__ outer_d2, int64_t M) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < M && outer_d2[j] < bound2[j]) bound2[j] = outer_d2[j];
+}
+__global__ void __launch_bounds__(kBlock)
+k_nearest_rebase(int64_t M, int64_t index0, int have_range, int32_t *__restrict__ idx, double *__restrict__ d2, double *__restrict__ d2_out,
+                 const int32_t *__restrict__ outer_idx, const double *__restrict__ outer_d2) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  int32_t k = have_range ? idx[j] : -1;
+  double d = have_range ? d2[j] : std::numeric_limits<double>::infinity();
+  if (k >= 0) k += (int32_t)index0;
+  if (outer_idx && outer_idx[j] >= 0 && !(k >= 0 && d < outer_d2[j])) { k = outer_idx[j]; d = outer_d2[j]; }
+  idx[j] = k;
+  if (d2_out) d2_out[j] = d;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_nearest_reduce(const int32_t *__restrict__ pidx, const double *__restrict__ pd2, int64_t M, int nchunks,
                  int32_t *__restrict__ out_idx, double *__restrict__ out_d2,

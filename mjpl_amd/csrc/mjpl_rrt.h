@@ -384,6 +384,11 @@ k_rrt_finish(int L, int nplan, RrtLanes ln, int32_t *__restrict__ ref, double *_
     for (int c = 0; c < nplan; c++) reached[(int64_t)c * L + l] = ln.C[(int64_t)c * L + l];
 }
 
+__global__ void k_rrt_first_init(int32_t *__restrict__ first, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) first[i] = 0x7fffffff;
+}
+
 // the early look-up of the connect phase's nearest nodes (mjpl_rrt: early_nn): what every lane has reached so far, and
 // whether that is final -- a lane with act == 0 is through, nothing writes its C again in this extension
 __global__ void __launch_bounds__(256)
@@ -563,7 +568,7 @@ struct mjpl_rrt {
   // the second extension then looks up only the lanes that were still under way, and waits for the early answers.  The
   // same queries against the same nodes: the same nodes.  MJPL_RRT_EARLY_NN=0 turns it off; MJPL_RRT_EARLY_LANES /
   // MJPL_RRT_EARLY_MIN_NODES move the thresholds (tests set them low).
-  int early_nn = 1, early_lanes = 4096;
+  int early_nn = 1, early_lanes = 4096, early_next = 1;  // (early_next: the next round's look-up as well, MJPL_RRT_EARLY_NEXT=0: not)
   int64_t early_min_nodes = 65536;
   bool early_on = false;      // this round's first extension started the early look-up
   hipStream_t side = nullptr;
@@ -572,6 +577,18 @@ struct mjpl_rrt {
   int32_t *d_near_e = nullptr, *d_late_pos = nullptr, *d_late_near = nullptr;
   uint8_t *d_early = nullptr; // the lane's answer is the early one
   double *d_late_q = nullptr; // [nplan][early_lanes] the other lanes' queries, packed (padded with the first of them)
+  // ... and, behind that look-up on the same stream, the NEXT round's targets (counter-based draws: they depend on the seed,
+  // the rank and the round number only) against the nodes its growing tree holds NOW -- the tree this round's connect phase
+  // extends; what that adds is appended at the round's end, behind them, and is all the next round still has to scan
+  // (nearest_range: lower indices win ties, as in one scan).  pre_round: the round the draws are for (0: none).
+  int pre_round = 0;
+  int pre_n0 = 0;             // nodes of that tree covered by the early answers
+  double *d_Tn = nullptr;     // [nplan][L] the next round's targets
+  int32_t *d_goal_n = nullptr, *d_first_n = nullptr, *d_pre_idx = nullptr;
+  double *d_pre_d2 = nullptr;
+  hipEvent_t ev_pre = nullptr;
+  // the look-ups on the second stream use their own scratch (the engine's may be in use by a look-up on the first)
+  struct NnScratch { void *nn = nullptr; size_t nn_bytes = 0; void *nn16 = nullptr; size_t nn16_bytes = 0; void *tmp = nullptr; size_t tmp_bytes = 0; } side_nn;
   int *d_ctr = nullptr, *h_ctr = nullptr;
   // projecting extensions read their chunk counters two chunks late (rrt_extend): a ring of pinned copies
   int *h_ring = nullptr;      // 4 slots of kRingStride ints: RC_SIZE counters, then the sequence word
@@ -635,6 +652,27 @@ int rrt_read_ctr(mjpl_rrt *r) {
   return MJPL_OK;
 }
 
+int rrt_rank(const mjpl_rrt *r);
+
+// a look-up enqueued on the planner's second stream, with its scratch
+int rrt_side_nearest(mjpl_rrt *r, const double *nodes, int64_t n, const double *queries, int64_t M, int32_t *idx, double *d2) {
+  mjpl_engine *e = r->e;
+  auto swap_scratch = [&]() {
+    std::swap(e->d_nn, r->side_nn.nn); std::swap(e->nn_bytes, r->side_nn.nn_bytes);
+    std::swap(e->d_nn16, r->side_nn.nn16); std::swap(e->nn16_bytes, r->side_nn.nn16_bytes);
+    std::swap(e->d_nn_tmp, r->side_nn.tmp); std::swap(e->nn_tmp_bytes, r->side_nn.tmp_bytes);
+  };
+  hipStream_t keep = e->stream;
+  const int last = e->nn_last;
+  swap_scratch();
+  e->stream = r->side;  // (the look-up's launches go where the engine's stream points)
+  const int rc = mjpl_nearest_dev(e, nodes, n, r->cap, queries, M, idx, d2);
+  e->stream = keep;
+  swap_scratch();
+  e->nn_last = last;    // (mjpl_nearest_last_screen speaks of the engine's own scratch)
+  return rc;
+}
+
 // one extension of tree `t` towards the targets Tgt ([nplan][L]); `second`: the connect phase
 int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   mjpl_engine *e = r->e;
@@ -659,6 +697,13 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     hipLaunchKernelGGL(k_rrt_near_merge, dim3(rgrid(L)), dim3(256), 0, st, L, room, r->d_early, r->d_late_pos, r->d_near_e, r->d_late_near,
                        r->ln.near);
     tr.mark(st, "nearest neighbour (the lanes of the tail; the others were looked up early)", r->n[t]);
+  } else if (!second && r->pre_round == r->round && r->pre_n0 <= r->n[t]) {
+    // this round's targets were looked up in the tree's first pre_n0 nodes while the round before ran its tail
+    r->pre_round = 0;
+    HIP_TRY(hipStreamWaitEvent(st, r->ev_pre, 0));
+    rc = nearest_range(e, r->d_Q[t], r->pre_n0, r->n[t], r->cap, Tgt, L, r->ln.near, nullptr, r->d_pre_idx, r->d_pre_d2);
+    if (rc != MJPL_OK) return rc;
+    tr.mark(st, "nearest neighbour (the nodes of the last round; the others were scanned early)", r->n[t] - r->pre_n0);
   } else {
     rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, Tgt, L, r->ln.near, nullptr);
     if (rc != MJPL_OK) return rc;
@@ -714,11 +759,24 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
           HIP_TRY(hipEventRecord(r->ev_tail, st));
           HIP_TRY(hipStreamWaitEvent(r->side, r->ev_tail, 0));
           hipLaunchKernelGGL(k_rrt_early, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan, r->ln, r->d_early, r->d_RAe);
-          e->stream = r->side;  // (the look-up's launches go where the engine's stream points)
-          const int nrc = mjpl_nearest_dev(e, r->d_Q[1 - t], r->n[1 - t], r->cap, r->d_RAe, L, r->d_near_e, nullptr);
-          e->stream = st;
+          int nrc = rrt_side_nearest(r, r->d_Q[1 - t], r->n[1 - t], r->d_RAe, L, r->d_near_e, nullptr);
           if (nrc != MJPL_OK) return nrc;
           HIP_TRY(hipEventRecord(r->ev_near, r->side));
+          if (r->early_next) {
+            // the next round: its growing tree is 1 - t, its draws are keyed by the round number
+            RrtLanes lnn = r->ln;
+            lnn.T = r->d_Tn; lnn.goal = r->d_goal_n;
+            const int nf = std::max(r->ngoal, 1);
+            hipLaunchKernelGGL(k_rrt_first_init, dim3(rgrid(nf)), dim3(256), 0, r->side, r->d_first_n, nf);
+            hipLaunchKernelGGL(k_rrt_sample, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan,
+                               rrt_key(r->seed, (uint64_t)rrt_rank(r), (uint64_t)(r->round + 1)), r->pgoal, 1 - t, r->ngoal, r->d_lo, r->d_hi,
+                               r->d_qinit, r->d_Q[1], r->cap, lnn, r->d_first_n);
+            nrc = rrt_side_nearest(r, r->d_Q[1 - t], r->n[1 - t], r->d_Tn, L, r->d_pre_idx, r->d_pre_d2);
+            if (nrc != MJPL_OK) return nrc;
+            HIP_TRY(hipEventRecord(r->ev_pre, r->side));
+            r->pre_round = r->round + 1;
+            r->pre_n0 = r->n[1 - t];
+          }
           r->early_on = true;
         }
       }
@@ -898,6 +956,10 @@ void mjpl_rrt_destroy(mjpl_rrt *r) {
   if (r->side) { (void)hipStreamSynchronize(r->side); (void)hipStreamDestroy(r->side); }
   if (r->ev_tail) (void)hipEventDestroy(r->ev_tail);
   if (r->ev_near) (void)hipEventDestroy(r->ev_near);
+  if (r->ev_pre) (void)hipEventDestroy(r->ev_pre);
+  if (r->side_nn.nn) (void)hipFree(r->side_nn.nn);
+  if (r->side_nn.nn16) (void)hipFree(r->side_nn.nn16);
+  if (r->side_nn.tmp) (void)hipFree(r->side_nn.tmp);
   for (void *p : r->owned) (void)hipFree(p);
   if (r->h_ctr) (void)hipHostFree(r->h_ctr);
   if (r->h_ring) (void)hipHostFree(r->h_ring);
@@ -959,6 +1021,11 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
     HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&r->ev_tail, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&r->ev_near, hipEventDisableTiming));
+    if (const char *v = getenv("MJPL_RRT_EARLY_NEXT")) r->early_next = atoi(v) != 0 ? 1 : 0;
+    if (r->early_next) {
+      RA(r->d_Tn, (size_t)nplan * L); RA(r->d_goal_n, L); RA(r->d_first_n, 1); RA(r->d_pre_idx, L); RA(r->d_pre_d2, L);
+      HIP_TRY(hipEventCreateWithFlags(&r->ev_pre, hipEventDisableTiming));
+    }
   }
 #undef RA
   HIP_TRY(hipHostMalloc((void **)&r->h_ctr, RC_SIZE * sizeof(int)));
@@ -1000,9 +1067,13 @@ int mjpl_rrt_reset(mjpl_rrt *r, const double *q_init, const double *q_goals, int
   HIP_TRY(hipMemcpy(r->d_parent[0], minus.data(), sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(r->d_parent[1], minus.data(), ngoal * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(r->d_qinit, q_init, nplan * sizeof(double), hipMemcpyHostToDevice));
+  if (r->side) HIP_TRY(hipStreamSynchronize(r->side));
+  r->pre_round = 0;
+  r->early_on = false;
   if (ngoal > r->first_cap) {
     int rc = rrt_alloc(r, &r->d_first, (size_t)ngoal);
     if (rc != MJPL_OK) return rc;
+    if (r->early_next && r->early_nn && (rc = rrt_alloc(r, &r->d_first_n, (size_t)ngoal)) != MJPL_OK) return rc;
     r->first_cap = ngoal;
   }
   r->n[0] = 1;
@@ -1037,12 +1108,20 @@ int rrt_begin(mjpl_rrt *r, int32_t request_stop) {
   r->round++;
   r->early_on = false;
   const int grow = (r->round - 1) % 2, other = 1 - grow;  // tree swap every round (rrt.py:234-235)
-  {
+  if (r->pre_round == r->round) {
+    // the round before drew this round's targets (and looked them up in the nodes there were): its buffers become the round's
+    HIP_TRY(hipStreamWaitEvent(st, r->ev_pre, 0));
+    std::swap(r->ln.T, r->d_Tn);
+    std::swap(r->ln.goal, r->d_goal_n);
+    std::swap(r->d_first, r->d_first_n);
+    hipLaunchKernelGGL(k_rrt_round_init, dim3(rgrid((int)RC_SIZE)), dim3(256), 0, st, r->d_ctr, r->d_first, 0);
+  } else {
+    r->pre_round = 0;
     const int nf = std::max(r->ngoal, 1);
     hipLaunchKernelGGL(k_rrt_round_init, dim3(rgrid(std::max(nf, (int)RC_SIZE))), dim3(256), 0, st, r->d_ctr, r->d_first, nf);
+    hipLaunchKernelGGL(k_rrt_sample, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, rrt_key(r->seed, (uint64_t)rank, (uint64_t)r->round), r->pgoal,
+                       grow, r->ngoal, r->d_lo, r->d_hi, r->d_qinit, r->d_Q[1], r->cap, r->ln, r->d_first);
   }
-  hipLaunchKernelGGL(k_rrt_sample, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, rrt_key(r->seed, (uint64_t)rank, (uint64_t)r->round), r->pgoal,
-                     grow, r->ngoal, r->d_lo, r->d_hi, r->d_qinit, r->d_Q[1], r->cap, r->ln, r->d_first);
   int newA = 0, newB = 0;
   int rc = rrt_extend(r, grow, r->ln.T, 0, &newA);
   if (rc == MJPL_OK) rc = rrt_extend(r, other, r->ln.RA, 1, &newB);
@@ -1053,6 +1132,7 @@ int rrt_begin(mjpl_rrt *r, int32_t request_stop) {
   }
   r->local_err.clear();
   if (rc != MJPL_OK) {
+    r->pre_round = 0;
     r->local_err = g_err;
     const int h[8] = {0, 0, 0x7fffffff, 0, 0, request_stop ? 1 : 0, rc, 0};
     memcpy(r->h_myhead, h, sizeof(h));
@@ -1137,6 +1217,7 @@ int mjpl_rrt_set_world(mjpl_rrt *r, int32_t rank, int32_t world) {
   r->rank = rank;
   r->world = world;
   r->world_set = true;
+  r->pre_round = 0;  // (draws made ahead for the next round were keyed by the rank there was)
   return MJPL_OK;
 }
 

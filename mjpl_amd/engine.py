@@ -119,6 +119,7 @@ ABI = {
     "mjpl_take_status": (C.c_int, [_VP, _I32P]),
     "mjpl_check_configs_bits_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP]),
     "mjpl_nearest_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, _VP, _VP]),
+    "mjpl_nearest_range_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     "mjpl_nearest_last_screen": (C.c_int32, [_VP]),
     "mjpl_dev_alloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "mjpl_dev_free": (C.c_int, [_VP, _VP]),
@@ -415,6 +416,10 @@ class Engine:
 
     def nearest_dev(self, dnodes, n, cap, dqueries, m, dout_idx, dout_d2=None):
         self._ok(self.lib.mjpl_nearest_dev(self.h, dnodes, n, cap, dqueries, m, dout_idx, dout_d2))
+
+    def nearest_range_dev(self, dnodes, n0, n, cap, dqueries, m, dout_idx, dout_d2=None, dprev_idx=None, dprev_d2=None):
+        """nearest_dev over nodes [n0, n) behind the answer (dprev_idx, dprev_d2) for the nodes below n0."""
+        self._ok(self.lib.mjpl_nearest_range_dev(self.h, dnodes, n0, n, cap, dqueries, m, dout_idx, dout_d2, dprev_idx, dprev_d2))
 
     def nearest_last_screen(self) -> int:
         """0: plain float64 scan, 1: binary32 screen, 2: matrix-core (binary16) screen -- of the last nearest_dev."""

@@ -442,3 +442,47 @@ def test_far_from_the_origin_the_filter_steps_aside(oracle_mod, moving_boxes):
     e0 = eng_mod.Engine(model, allowed)
     e0.check_configs(Q)
     assert e0.last_undecided() < len(Q) // 4
+
+
+@pytest.mark.parametrize("n0,n,M", [(200000, 300000, 16500), (290000, 300100, 4200), (300000, 300000, 4100), (0, 270000, 5000), (1000, 9000, 700)])
+def test_nearest_neighbour_over_a_node_range_behind_an_earlier_answer(n0, n, M):
+    """mjpl_nearest_range_dev: a tree that was scanned when it had n0 nodes has n now; scanning [n0, n) behind the earlier
+    answer must give the whole scan's winners and distances -- also where a new node ties an old one exactly (the old, lower
+    index wins) and where an old node ties a new one (ditto), with the earlier distances as every query's screen bound (no
+    sample), through the matrix-core screen, the plain scan (few new nodes / few queries) and an empty range."""
+    m = scenes.franka_p()
+    e = eng_mod.Engine(m)
+    e.set_planning(scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos)
+    rng = np.random.default_rng(n0 + n + M)
+    cap = n + 77
+    nodes = np.zeros((7, cap))
+    nodes[:, :n] = rng.uniform(-2.9, 2.9, size=(7, n))
+    qs = rng.uniform(-2.9, 2.9, size=(7, M))
+    if n > n0 > 0:
+        nodes[:, n - 5] = nodes[:, 17]          # a new node equal to an old one: the old one wins
+        qs[:, 3] = nodes[:, 17] + 1e-9
+        nodes[:, n0 + 1] = qs[:, 4]             # a new node ON a query
+        qs[:, 5] = nodes[:, min(n0 - 1, 40)]    # an old node on a query
+    dn, dq = e.alloc(nodes.nbytes).upload(nodes), e.alloc(qs.nbytes).upload(qs)
+    di0, dd0, di, dd = e.alloc(4 * M), e.alloc(8 * M), e.alloc(4 * M), e.alloc(8 * M)
+    if n0 > 0:
+        e.nearest_dev(dn.ptr, n0, cap, dq.ptr, M, di0.ptr, dd0.ptr)
+        e.nearest_range_dev(dn.ptr, n0, n, cap, dq.ptr, M, di.ptr, dd.ptr, di0.ptr, dd0.ptr)
+    else:
+        e.nearest_range_dev(dn.ptr, 0, n, cap, dq.ptr, M, di.ptr, dd.ptr)
+    got, gd = di.download(np.int32, M), dd.download(np.float64, M)
+    sel = np.concatenate([np.arange(0, min(M, 64)), rng.integers(0, M, 150)])
+    s = np.zeros((len(sel), n))
+    for c in range(7):  # the kernel's sum order
+        d = nodes[c][None, :n] - qs[c][sel][:, None]
+        s = s + d * d
+    np.testing.assert_array_equal(got[sel], s.argmin(1))
+    np.testing.assert_array_equal(gd[sel], s.min(1))
+    if n > n0 > 0:
+        assert got[3] == 17 and got[4] == n0 + 1 and gd[4] == 0.0 and got[5] == min(n0 - 1, 40)
+    # ... and without the distances (the planner's call): the same winners
+    di2 = e.alloc(4 * M)
+    if n0 > 0:
+        e.nearest_range_dev(dn.ptr, n0, n, cap, dq.ptr, M, di2.ptr, None, di0.ptr, dd0.ptr)
+        np.testing.assert_array_equal(di2.download(np.int32, M), got)
+    e.close()

@@ -302,19 +302,22 @@ def test_projecting_extension_makes_the_same_trees_whatever_the_lanes_per_row(la
         np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
 
 
-@pytest.mark.parametrize("early_lanes", ["64", "3000"])
-def test_connect_phase_neighbours_looked_up_early_make_the_same_trees(early_lanes):
+@pytest.mark.parametrize("early_lanes,early_next", [("64", "1"), ("3000", "1"), ("3000", "0")])
+def test_connect_phase_neighbours_looked_up_early_make_the_same_trees(early_lanes, early_next):
     """Round 5: once no more than MJPL_RRT_EARLY_LANES lanes of the first extension are still under way, the lanes that are
     through get their nearest node of the other tree on a second stream while the tail runs; the second extension looks up
-    the rest and merges (mjpl_rrt.h: early_nn).  The same queries against the same snapshot: the trees of four rounds must
-    be, bit for bit, those of a planner that looks all lanes up after the first extension (MJPL_RRT_EARLY_NN=0)."""
+    the rest and merges (mjpl_rrt.h: early_nn).  Behind that look-up, on the same stream, the NEXT round's targets are drawn
+    and looked up in the nodes its growing tree holds now; the next round scans only what this round adds behind them
+    (MJPL_RRT_EARLY_NEXT).  The same queries against the same snapshots: the trees of four rounds must be, bit for bit,
+    those of a planner that looks every lane up when its extension begins (MJPL_RRT_EARLY_NN=0)."""
     m = scenes.franka_p(obstacles=True)
     joints = scenes.FRANKA_ARM_JOINTS
     qidx = scenes.planning_index(m, joints)
     q_init = m.keyframe("home").qpos.copy()
     trees = []
-    keys = ("MJPL_RRT_EARLY_NN", "MJPL_RRT_EARLY_LANES", "MJPL_RRT_EARLY_MIN_NODES")
-    for env in (dict(MJPL_RRT_EARLY_NN="0"), dict(MJPL_RRT_EARLY_NN="1", MJPL_RRT_EARLY_LANES=early_lanes, MJPL_RRT_EARLY_MIN_NODES="1")):
+    keys = ("MJPL_RRT_EARLY_NN", "MJPL_RRT_EARLY_LANES", "MJPL_RRT_EARLY_MIN_NODES", "MJPL_RRT_EARLY_NEXT")
+    for env in (dict(MJPL_RRT_EARLY_NN="0"),
+                dict(MJPL_RRT_EARLY_NN="1", MJPL_RRT_EARLY_LANES=early_lanes, MJPL_RRT_EARLY_MIN_NODES="1", MJPL_RRT_EARLY_NEXT=early_next)):
         old = {k: os.environ.pop(k, None) for k in keys}
         os.environ.update(env)
         try:
