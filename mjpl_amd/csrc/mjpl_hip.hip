@@ -2373,11 +2373,16 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         // float64 scan of the sample as before; either pair of kernels leaves at once when the other serves the call)
         const int64_t msample = std::max<int64_t>(32, std::min<int64_t>(e->nn_sample, n / 16 / 32 * 32));
         const int64_t mstride = std::max<int64_t>(1, n / msample);
-        const dim3 gm((unsigned)qblocks, (unsigned)nsplit), gs((unsigned)qblocks, 1u);
+        // (the sample in as many chunks as give the chip ~1 024 workgroups: a look-up of few queries -- the planner's tail lanes --
+        //  would otherwise scan it with eight)
+        const int64_t ssplit = std::max<int64_t>(1, std::min<int64_t>((1024 + qblocks - 1) / qblocks, msample / 256));
+        const int64_t schunk = ((msample + ssplit - 1) / ssplit + 31) / 32 * 32;
+        const dim3 gm((unsigned)qblocks, (unsigned)nsplit), gs((unsigned)qblocks, (unsigned)((msample + schunk - 1) / schunk));
+        hipLaunchKernelGGL(k_nn_fill_inf, dim3(rgridM), dim3(kBlock), 0, e->stream, seed_d2, M, (const unsigned *)xbits);
 #define MJPL_NNM_CASE(NPV)                                                                                                       \
         case NPV:                                                                                                                \
           hipLaunchKernelGGL((k_nearest_mfma<NPV, true>), gs, dim3(kNNMWaves * 64), 0, e->stream, dnodes, msample, cap, dqueries, M, \
-                             (const uint4 *)nodes16, (const uint4 *)q16, (const float *)qn, (const unsigned *)xbits, msample,    \
+                             (const uint4 *)nodes16, (const uint4 *)q16, (const float *)qn, (const unsigned *)xbits, schunk,     \
                              mstride, seed_d2, (int32_t *)nullptr, (double *)nullptr);                                           \
           break;
         switch (nplan) {

@@ -356,6 +356,12 @@ k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int
   if (__ballot(wild) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&xbits[1], 1u);
 }
 
+__global__ void __launch_bounds__(256)
+k_nn_fill_inf(double *__restrict__ x, int64_t M, const unsigned *__restrict__ xbits) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < M && xbits[1] == 0u) x[j] = std::numeric_limits<double>::infinity();
+}
+
 template <int NP>
 __device__ __forceinline__ float nn_mfma_threshold(double ref2, double ref, double e, double a, float nq) {
   const double th = (ref2 + 2.0 * (4.0 * sqrt((double)NP) * e * ref + 4.0 * NP * e * e + a)) * (1.0 + 1e-6) - (double)nq;
@@ -577,7 +583,9 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
       if (q < M && liked >= 0) ex = exact((int64_t)liked * stride, q);
       const double other = __shfl_xor(ex, 32);
       ex = other < ex ? other : ex;
-      if (q < M && h == 0) bound2[q] = ex;
+      // (the sample may be cut into chunks, blockIdx.y: the smallest of their bounds -- non-negative doubles order like their bits;
+      //  k_nn_fill_inf set every bound to +inf before the launch)
+      if (q < M && h == 0) atomicMin(reinterpret_cast<unsigned long long *>(bound2 + q), (unsigned long long)__double_as_longlong(ex));
     }
   } else {
     work_off();
