@@ -272,7 +272,8 @@ void *mjpl_stream(mjpl_engine *e);
  * events recorded on that stream: two around the whole run (*ms_mean = mean duration of a call,
  * all kernels) and, on every `sample_every`-th call, one after each stage, so that
  * stage_ms[MJPL_NSTAGES] (nullable) receives each stage's mean duration over *nsamples (nullable)
- * sampled calls.  Sampling keeps the instrumentation below one percent of the run it measures.
+ * sampled calls.  Sampling keeps the instrumentation below one percent of the run it measures;
+ * sample_every > iters: no call is sampled (stage_ms untouched, *nsamples = 0).
  * Inputs and outputs are device-resident.  Used by bench.py for roofline.achieved. */
 int mjpl_time_edges_stages_dev(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E,
                                double step_dist, int32_t layout, uint8_t *dvalid, int32_t iters,

@@ -2700,7 +2700,10 @@ int mjpl_time_edges_stages_dev(mjpl_engine *e, const double *dQA, const double *
   // Two events around the whole run (the mean step) and, on every `sample_every`-th step, one
   // event after each stage of the launch: bracketing every kernel of every step would cost a few
   // percent of the throughput the run is there to measure.
-  const int nsamp = iters > 0 ? (iters + sample_every - 1) / sample_every : 0;
+  // (sample_every > iters: NO launch is bracketed -- a bracketed launch costs ~56 us more than a plain one, 1.4 % of a
+  //  20-step region: bench.py takes the per-kernel durations of such a region from launches outside it)
+  const bool none = sample_every > iters;
+  const int nsamp = (iters > 0 && !none) ? (iters + sample_every - 1) / sample_every : 0;
   constexpr int NM = MJPL_NSTAGES + 1;
   std::vector<hipEvent_t> ev((size_t)nsamp * NM + 2);
   for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
@@ -2708,7 +2711,7 @@ int mjpl_time_edges_stages_dev(mjpl_engine *e, const double *dQA, const double *
   int rc = MJPL_OK;
   HIP_TRY(hipEventRecord(region_start, e->stream));
   for (int k = 0; k < iters && rc == MJPL_OK; k++) {
-    e->marks = (k % sample_every == 0) ? &ev[(size_t)(k / sample_every) * NM] : nullptr;
+    e->marks = (!none && k % sample_every == 0) ? &ev[(size_t)(k / sample_every) * NM] : nullptr;
     rc = mjpl_check_edges_dev(e, dQA, dQB, E, step_dist, layout, 0, dvalid, nullptr);
     e->marks = nullptr;
   }
@@ -2718,7 +2721,7 @@ int mjpl_time_edges_stages_dev(mjpl_engine *e, const double *dQA, const double *
     float total = 0;
     HIP_TRY(hipEventElapsedTime(&total, region_start, region_end));
     *ms_mean = total / (float)iters;
-    if (stage_ms) {
+    if (stage_ms && nsamp > 0) {
       for (int st = 0; st < MJPL_NSTAGES; st++) {
         double acc = 0;
         for (int sidx = 0; sidx < nsamp; sidx++) {
