@@ -568,6 +568,7 @@ struct mjpl_rrt {
   // the second extension then looks up only the lanes that were still under way, and waits for the early answers.  The
   // same queries against the same nodes: the same nodes.  MJPL_RRT_EARLY_NN=0 turns it off; MJPL_RRT_EARLY_LANES /
   // MJPL_RRT_EARLY_MIN_NODES move the thresholds (tests set them low).
+  int exact_counts = 1;  // a projecting extension reads every chunk's lane count before it sizes the chunk (MJPL_RRT_EXACT_COUNTS=0: two chunks late, from the pinned ring)
   int early_nn = 1, early_lanes = 4096, early_next = 1;  // (early_next: the next round's look-up as well, MJPL_RRT_EARLY_NEXT=0: not)
   int64_t early_min_nodes = 65536;
   bool early_on = false;      // this round's first extension started the early look-up
@@ -735,13 +736,53 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
       r->ring_seq0 += *chunks + 8;
     }
   } ring_guard{r, &chunks_done, st, false};
+  // the look-ups that run beside the tail of the first extension (mjpl_rrt: early_nn), started once, when no more than
+  // early_lanes lanes are still extending: everything enqueued so far (the acceptance of the chunk before last) decides
+  // which lanes are through
+  auto start_tail_lookups = [&](int active) -> int {
+    if (second || !r->early_nn || r->early_on || active > r->early_lanes || r->n[1 - t] < r->early_min_nodes) return MJPL_OK;
+    HIP_TRY(hipEventRecord(r->ev_tail, st));
+    HIP_TRY(hipStreamWaitEvent(r->side, r->ev_tail, 0));
+    hipLaunchKernelGGL(k_rrt_early, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan, r->ln, r->d_early, r->d_RAe);
+    int nrc = rrt_side_nearest(r, r->d_Q[1 - t], r->n[1 - t], r->d_RAe, L, r->d_near_e, nullptr);
+    if (nrc != MJPL_OK) return nrc;
+    HIP_TRY(hipEventRecord(r->ev_near, r->side));
+    if (r->early_next) {
+      // the next round: its growing tree is 1 - t, its draws are keyed by the round number
+      RrtLanes lnn = r->ln;
+      lnn.T = r->d_Tn; lnn.goal = r->d_goal_n;
+      const int nf = std::max(r->ngoal, 1);
+      hipLaunchKernelGGL(k_rrt_first_init, dim3(rgrid(nf)), dim3(256), 0, r->side, r->d_first_n, nf);
+      hipLaunchKernelGGL(k_rrt_sample, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan,
+                         rrt_key(r->seed, (uint64_t)rrt_rank(r), (uint64_t)(r->round + 1)), r->pgoal, 1 - t, r->ngoal, r->d_lo, r->d_hi,
+                         r->d_qinit, r->d_Q[1], r->cap, lnn, r->d_first_n);
+      nrc = rrt_side_nearest(r, r->d_Q[1 - t], r->n[1 - t], r->d_Tn, L, r->d_pre_idx, r->d_pre_d2);
+      if (nrc != MJPL_OK) return nrc;
+      HIP_TRY(hipEventRecord(r->ev_pre, r->side));
+      r->pre_round = r->round + 1;
+      r->pre_n0 = r->n[1 - t];
+    }
+    r->early_on = true;
+    return MJPL_OK;
+  };
   int active_bound = L;  // (projecting) no more lanes than this are active in the chunk about to be launched
   int trace_G = 0;
   unsigned trace_grid = 0;
   for (int chunk = 0;; chunk++) {
     chunks_done = chunk + 1;
     if (projecting) {
-      if (chunk >= 2) {
+      if (r->exact_counts) {
+        // Round 5: the chunk's list has been closed by the acceptance kernel before it (chunk 0: by k_rrt_list_begin); its
+        // length IS the number of active lanes.  Reading it costs a trip to the host with the chip idle (~30 us) and buys
+        // the right number of steps for the chunk: sized by the count of two chunks ago (below) an extension's first three
+        // chunks all took four steps and it needed eight to ten chunks where five or six do (profiles/README.md).
+        if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
+        if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
+        if (r->h_ctr[RC_OVERFLOW] & 1) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer overrun in a projecting extension");
+        if (r->h_ctr[RC_LISTN + (chunk & 1)] == 0) break;
+        active_bound = r->h_ctr[RC_LISTN + (chunk & 1)];
+        if (chunk >= 1 && (rc = start_tail_lookups(active_bound)) != MJPL_OK) return rc;
+      } else if (chunk >= 2) {
         const int look = (chunk - 2) % 4;
         volatile int *slot = r->h_ring + look * kRingStride;
         const int want = r->ring_seq0 + chunk - 2;
@@ -754,31 +795,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
         if (r->h_ctr[RC_OVERFLOW] & 1) return fail(MJPL_E_CAPACITY, "rrt: candidate buffer overrun in a projecting extension");
         if (r->h_ctr[RC_ACTIVE] == 0) break;
         active_bound = r->h_ctr[RC_ACTIVE];
-        if (!second && r->early_nn && !r->early_on && active_bound <= r->early_lanes && r->n[1 - t] >= r->early_min_nodes) {
-          // the tail begins: everything enqueued so far (the acceptance of chunk - 1 last) decides which lanes are through
-          HIP_TRY(hipEventRecord(r->ev_tail, st));
-          HIP_TRY(hipStreamWaitEvent(r->side, r->ev_tail, 0));
-          hipLaunchKernelGGL(k_rrt_early, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan, r->ln, r->d_early, r->d_RAe);
-          int nrc = rrt_side_nearest(r, r->d_Q[1 - t], r->n[1 - t], r->d_RAe, L, r->d_near_e, nullptr);
-          if (nrc != MJPL_OK) return nrc;
-          HIP_TRY(hipEventRecord(r->ev_near, r->side));
-          if (r->early_next) {
-            // the next round: its growing tree is 1 - t, its draws are keyed by the round number
-            RrtLanes lnn = r->ln;
-            lnn.T = r->d_Tn; lnn.goal = r->d_goal_n;
-            const int nf = std::max(r->ngoal, 1);
-            hipLaunchKernelGGL(k_rrt_first_init, dim3(rgrid(nf)), dim3(256), 0, r->side, r->d_first_n, nf);
-            hipLaunchKernelGGL(k_rrt_sample, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan,
-                               rrt_key(r->seed, (uint64_t)rrt_rank(r), (uint64_t)(r->round + 1)), r->pgoal, 1 - t, r->ngoal, r->d_lo, r->d_hi,
-                               r->d_qinit, r->d_Q[1], r->cap, lnn, r->d_first_n);
-            nrc = rrt_side_nearest(r, r->d_Q[1 - t], r->n[1 - t], r->d_Tn, L, r->d_pre_idx, r->d_pre_d2);
-            if (nrc != MJPL_OK) return nrc;
-            HIP_TRY(hipEventRecord(r->ev_pre, r->side));
-            r->pre_round = r->round + 1;
-            r->pre_n0 = r->n[1 - t];
-          }
-          r->early_on = true;
-        }
+        if ((rc = start_tail_lookups(active_bound)) != MJPL_OK) return rc;
       }
       // Steps per chunk: one while the chunk's kernels are busy with the lanes there are; more when they are
       // not -- a chunk then costs the latency of its launches whatever it holds, and S steps share it.  The
@@ -811,7 +828,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
                              r->pose->d_pd, r->d_qidx, r->d_qbase, r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
         }
       }
-      if (chunk < 2) {  // (the first two chunks: their own counts)
+      if (!r->exact_counts && chunk < 2) {  // (the first two chunks: their own counts)
         if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
         if (r->h_ctr[RC_OVERFLOW] & 3) return fail(MJPL_E_CAPACITY, "rrt: buffer overrun in a projecting extension");
         if (r->h_ctr[RC_ACTIVE] == 0) break;
@@ -1011,6 +1028,7 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   RA(r->d_ctr, RC_SIZE); RA(r->d_heads, 8 * 1024); RA(r->d_path, (size_t)nplan * 65536);
   RA(r->d_first, 1);  // re-allocated by reset for the number of goals
   RA(r->d_scan, (size_t)(L + kScanBlock - 1) / kScanBlock);
+  if (const char *v = getenv("MJPL_RRT_EXACT_COUNTS")) r->exact_counts = atoi(v) != 0 ? 1 : 0;
   if (const char *v = getenv("MJPL_RRT_EARLY_NN")) r->early_nn = atoi(v) != 0 ? 1 : 0;
   if (const char *v = getenv("MJPL_RRT_EARLY_LANES")) r->early_lanes = std::max(1, atoi(v));
   if (const char *v = getenv("MJPL_RRT_EARLY_MIN_NODES")) r->early_min_nodes = std::max<int64_t>(1, atoll(v));
