@@ -715,7 +715,10 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   hipLaunchKernelGGL(k_rrt_begin, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->d_Q[t], r->cap, r->ln, r->d_first, Tgt,
                      second, r->d_ctr);
   if (projecting) hipLaunchKernelGGL(k_rrt_list_begin, dim3(rgrid(L)), dim3(256), 0, st, L, r->ln, r->d_ctr);
-  int S = projecting ? 1 : 4;
+  // (without a projection: four steps per lane in the first chunk of a big batch, doubling; a small batch -- a planner of
+  //  a few hundred lanes -- starts with as many as 2^16 candidate slots allow, up to 64: its chunks cost their launches'
+  //  latency whatever they hold, and an extension of six chunks becomes one of two)
+  int S = projecting ? 1 : (int)std::max<int64_t>(4, std::min<int64_t>(std::min<int64_t>(64, ((int64_t)1 << 16) / std::max(1, L)), (int64_t)r->cd.cap / std::max(1, L)));
   // With a projecting constraint an extension is hundreds of chunks, the late ones with a handful of lanes:
   // waiting for every chunk's counters before sizing its launches would leave the GPU idle while the host
   // enqueues the next kernels.  Lanes only ever leave an extension, and every active lane owns S slots of the

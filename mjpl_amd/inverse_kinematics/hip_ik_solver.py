@@ -23,6 +23,29 @@ from ..lie import SE3
 from .ik_solver_interface import IKSolver
 
 
+def distinct_solutions(sols: np.ndarray, q0: np.ndarray, tol: float = 1e-6) -> list[np.ndarray]:
+    """The rows of `sols` closest to `q0` first (cartesian_planner.py:101-102 picks that one), a row dropped when an earlier
+    KEPT one is within `tol` of it.  Two rows that close are as close in their distance to q0: only runs of neighbours
+    whose distances differ by less than `tol` can hold such a pair -- none, as a rule -- and only those are looked at
+    pair by pair (one call per pair of a couple of hundred solutions was a third of a planning call's time)."""
+    dist = np.linalg.norm(sols - q0, axis=1)
+    order = np.argsort(dist, kind="stable")
+    sols, dist = sols[order], dist[order]
+    kept = np.ones(len(sols), dtype=bool)
+    tight = np.flatnonzero(np.diff(dist) < tol)
+    k = 0
+    while k < len(tight):
+        lo = hi = int(tight[k])
+        while k < len(tight) and int(tight[k]) == hi:  # the run lo .. hi + 1 of neighbours
+            hi += 1
+            k += 1
+        for j in range(lo + 1, hi + 1):
+            prev = np.flatnonzero(kept[lo:j]) + lo
+            if len(prev) and np.linalg.norm(sols[prev] - sols[j], axis=1).min() < tol:
+                kept[j] = False
+    return [q.copy() for q in sols[kept]]
+
+
 class HipIKSolver(IKSolver):
     def __init__(self, model, joints: list[str], constraints: list[Constraint] = [],
                  pos_tolerance: float = 1e-3, ori_tolerance: float = 1e-3, seed: int | None = None,
@@ -123,16 +146,8 @@ class HipIKSolver(IKSolver):
             if good.any():
                 sols = Q[good]
                 # distinct solutions, closest to the guess first (cartesian_planner.py:101-102 picks that one)
-                order = np.argsort(np.linalg.norm(sols - q0, axis=1), kind="stable")
-                sols = sols[order]
-                # greedy in that order: keep a solution unless an earlier KEPT one is within 1e-6
-                # (row-wise distances to the kept set, not one Python call per pair)
-                kept = np.zeros(len(sols), dtype=bool)
-                for k in range(len(sols)):
-                    if not kept[:k].any() or np.linalg.norm(sols[:k][kept[:k]] - sols[k], axis=1).min() >= 1e-6:
-                        kept[k] = True
-                return [q.copy() for q in sols[kept]]
+                return distinct_solutions(sols, q0)
         return []
 
 
-__all__ = ("HipIKSolver", "obeys_constraints")
+__all__ = ("HipIKSolver", "distinct_solutions", "obeys_constraints")

@@ -358,18 +358,18 @@ class _PlannerBase:
         # searched for another robot configuration than it starts in
         if not np.array_equal(q_init[fixed], self.q_template[fixed]):
             raise ValueError("q_init differs from the planner's `q_template` outside of the planning joints")
-        for q in q_goals:
-            if not np.allclose(q_init[fixed], q[fixed], rtol=0, atol=1e-12):
-                raise ValueError("goal config differs from q_init outside of the planning joints")
+        G = np.stack(q_goals)  # (one call for all goals: an IK solver hands a planner a couple of hundred)
+        if not np.isclose(G[:, fixed], q_init[fixed][None, :], rtol=0, atol=1e-12).all():
+            raise ValueError("goal config differs from q_init outside of the planning joints")
         a = q_init[self.qidx]
-        goals = np.stack([q[self.qidx] for q in q_goals])
+        goals = G[:, self.qidx]
         ends = np.concatenate([a[None], goals])
         in_lim = np.all((ends >= self.lo) & (ends <= self.hi), axis=1)
         if not (in_lim.all() and self._valid_ends(ends).all()):
             raise ValueError("q_init or a goal config is not a valid configuration")
-        for q in q_goals:  # a direct connection (rrt.py:174-176)
-            if np.linalg.norm(q - q_init) <= self.eps:
-                return [q_init, q]
+        near = np.flatnonzero(np.linalg.norm(G - q_init[None, :], axis=1) <= self.eps)  # a direct connection (rrt.py:174-176)
+        if len(near):
+            return [q_init, q_goals[int(near[0])]]
         rows = self._search(a, goals)
         if rows is None:
             return []

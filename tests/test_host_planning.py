@@ -337,3 +337,30 @@ def test_batched_extension_equals_stepwise_extension(oracle_mod):
         for a, b in zip(plans["stepwise"][k], plans["batched"][k]):
             np.testing.assert_array_equal(a, b)
     assert plans["batched"][2] < plans["stepwise"][2] / 3  # far fewer constraint calls
+
+
+def test_distinct_ik_solutions_equal_the_pairwise_greedy():
+    """HipIKSolver's de-duplication looks only at runs of solutions whose distances to the guess differ by less than the
+    tolerance; the result must be the pairwise greedy's (keep a row unless an earlier kept one is within 1e-6), also with
+    planted duplicates, chains of near-duplicates and rows equidistant from the guess."""
+    from mjpl_amd.inverse_kinematics.hip_ik_solver import distinct_solutions
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        n = int(rng.integers(1, 120))
+        q0 = rng.normal(size=7)
+        sols = rng.uniform(-2, 2, size=(n, 7))
+        for _ in range(int(rng.integers(0, 12))):  # duplicates and chains of them, 2e-7 .. 8e-7 apart
+            a, b = rng.integers(0, n, 2)
+            step = rng.normal(size=7)
+            sols[b] = sols[a] + step / np.linalg.norm(step) * rng.uniform(2e-7, 8e-7)
+        if n > 4:  # equidistant from the guess, far from each other
+            d = sols[1] - q0
+            sols[2] = q0 - d
+        want_order = np.argsort(np.linalg.norm(sols - q0, axis=1), kind="stable")
+        s = sols[want_order]
+        kept = np.zeros(n, bool)
+        for k in range(n):
+            if not kept[:k].any() or np.linalg.norm(s[:k][kept[:k]] - s[k], axis=1).min() >= 1e-6:
+                kept[k] = True
+        got = distinct_solutions(sols, q0)
+        np.testing.assert_array_equal(np.stack(got), s[kept])
