@@ -475,6 +475,252 @@ k_rrt_gen_project_rows(int L, int S, double eps, int par, const int *__restrict_
   }
 }
 
+// ---- row e, a step ahead ----------------------------------------------------------------------------------------------
+// The tail of an extension is a few hundred lanes taking a thousand steps each, and a step is two passes of the loop
+// above: the Newton update of the stepped configuration, then the evaluation that finds the result within tolerance.
+// That second pass decides nothing the next step's first pass needs -- IF it comes back within tolerance, the candidate
+// is the configuration it was given.  So a row takes SIXTEEN lanes, two halves of eight: the half that holds the row's
+// projection runs its pass; the other half, in the same instructions, takes the step after -- _step from the candidate
+// the closing evaluation is about to confirm, and the first Newton pass of its projection.  When the evaluation does
+// come back within tolerance (and the rules of _constrained_extend accept the candidate), the half that ran ahead
+// holds the row's projection from then on and the halves change roles; when it does not, what ran ahead is dropped.
+// A step then costs one pass, not two.  Every value is computed by the statements of the kernel above from the same
+// inputs -- running ahead only changes WHEN -- so the candidates are the same bit for bit
+// (tests/test_gpu_rrt.py::..._whatever_the_lanes_per_row, 16 and 64).  Launch: ceil(entries / ROWS) waves at most 1 024.
+template <class PS, int NP, int ROWS>
+__global__ void __launch_bounds__(kPoseBlock)
+k_rrt_gen_project_ahead(int L, int S, double eps, int par, const int *__restrict__ pi, const double *__restrict__ pd,
+                        const int *__restrict__ qidx, const double *__restrict__ qbase, const uint8_t *__restrict__ isplan,
+                        const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln,
+                        RrtCand cd, int *__restrict__ ctr) {
+  static_assert(NP > 0, "the planning joints of the library's program");
+  typedef PoseRows<PS, 8> P;
+  constexpr int NQ = PS::kNQ;
+  // ROWS rows of a wave, 4 or 1: a row runs ahead only in the pass it expects to close its step in, and the statements of
+  // running ahead (the rules, _step: seven float64 divisions) are executed by the whole wave whenever one of its rows
+  // does -- with four rows at four different points of their steps that is nearly every pass.  With no more rows than
+  // SIMDs a row has its wave to itself (sixteen of its lanes) and pays for them once per step.
+  static_assert(ROWS == 4 || ROWS == 1, "four rows of sixteen lanes, or one");
+  constexpr int kRows = ROWS;
+  // A row's target, the end of its chain, the candidate under judgement and the configuration its projection stands at live
+  // in LDS, one copy for both halves: across the Newton pass only the projection itself stays in registers (the kernel
+  // above keeps them all there and spills ~1 500 moves' worth into the accumulation registers; here they would be more)
+  __shared__ double xch[2 * kRows * kXchStride];  // a half's exchange area (the sines and cosines its eight lanes share out)
+  __shared__ double rowmem[kRows * (3 * NP + NQ)];
+  const int lane = (int)(threadIdx.x & 63), row = lane >> 4, half = (lane >> 3) & 1, g = lane & 7;
+  const bool leader = (lane & 15) == 0;
+  const unsigned long long kLeaders = ROWS == 4 ? 0x0001000100010001ull : 0x1ull;
+  const int lrow = row < kRows ? row : 0;  // (lanes beyond the wave's rows never hold one: they keep company)
+  double *x = xch + (lrow * 2 + half) * kXchStride;
+  double *Tl = rowmem + lrow * (3 * NP + NQ), *wl = Tl + NP, *qnl = wl + NP, *qrow = qnl + NP;
+  const typename P::Consts c(pi, pd);
+  const int n = ctr[RC_LISTN + par];
+  const int32_t *__restrict__ list = ln.list[par];
+  if (blockIdx.x == 0 && lane == 0) ctr[RC_LISTN + (par ^ 1)] = 0;  // (the acceptance kernel of this chunk fills it)
+  const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int begin = (int)blockIdx.x * per;
+  const int end = begin + per < n ? begin + per : n;
+  if (begin >= end) return;
+  int base = 0;
+  if (lane == 0) {
+    base = atomicAdd(&ctr[RC_EDGES], (end - begin) * S);
+    atomicAdd(&ctr[RC_ACTIVE], end - begin);
+  }
+  base = __builtin_amdgcn_readfirstlane(base);
+  int next = begin;
+  typename P::Row r;  // the row's projection on the half `chalf`; scratch on the other
+  bool busy = false;
+  int l = 0, first = 0, s = 0, count = 0, lvl0 = 0;
+  int chalf = 0;  // the half that holds the row's projection
+  int cit = 0;    // Newton updates that projection has had (its r.it)
+  int need = 1;   // updates the row's last step took before it closed: the pass this step is expected to close in
+
+  // _step(from, T, eps) (planning/utils.py:167-186) into rr: the statements of begin_step above
+  auto step_into = [&](typename P::Row &rr, const double *from) {
+    double d[NP], q[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) d[k] = Tl[k] - from[k];
+    const double mag = seqnorm(d, NP);
+    const double sm = eps < mag ? eps : mag;
+    bool reach = true;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      q[k] = from[k] + (d[k] / mag) * sm;
+      reach = reach && (q[k] == Tl[k]);
+    }
+    reach = reach || (mag <= eps);
+    if (reach) {
+#pragma unroll
+      for (int k = 0; k < NP; k++) q[k] = Tl[k];  // a step of at most eps lands on the target
+    }
+#pragma unroll
+    for (int k = 0; k < NQ; k++) { rr.qold[k] = qbase[k]; rr.qv[k] = qbase[k]; }
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const int at = qidx[k];
+      const double fk = from[k];
+#pragma unroll
+      for (int j = 0; j < NQ; j++)
+        if (j == at) { rr.qold[j] = fk; rr.qv[j] = q[k]; }
+    }
+    rr.it = 0;
+  };
+  // the rules of _constrained_extend on the configuration in `qrow`, were it what the projection returned within tolerance;
+  // the candidate (its planning coordinates) goes to `qnl`.  Called by all lanes of the wave; ends with the row's fence.
+  auto rules = [&](bool &good, bool &reach) {
+    double d[NP], qn[NP];
+    good = true;
+#pragma unroll
+    for (int k = 0; k < NQ; k++)  // a projection that moves a joint outside the planning set is rejected
+      if (!isplan[k]) good = good && (qrow[k] == qbase[k]);
+    reach = true;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      qn[k] = qrow[qidx[k]];
+      reach = reach && (qn[k] == Tl[k]);
+      good = good && (qn[k] >= lo[k] && qn[k] <= hi[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) d[k] = qn[k] - wl[k];
+    good = good && !(seqnorm(d, NP) < 1e-8);
+#pragma unroll
+    for (int k = 0; k < NP; k++) d[k] = Tl[k] - qn[k];
+    const double after = seqnorm(d, NP);
+#pragma unroll
+    for (int k = 0; k < NP; k++) d[k] = Tl[k] - wl[k];
+    good = good && !(after > seqnorm(d, NP));
+    if (leader && busy) {
+#pragma unroll
+      for (int k = 0; k < NP; k++) qnl[k] = qn[k];
+    }
+    row_fence();
+  };
+
+  for (;;) {
+    const unsigned long long free_rows = __ballot(!busy) & kLeaders;
+    if (free_rows != 0ull && next < end) {
+      bool took = false;
+      if (!busy && row < kRows) {
+        const int at = next + __popcll(free_rows & ((1ull << (row * 16)) - 1ull));
+        if (at < end) {
+          l = list[at];
+          first = base + (at - begin) * S;
+          s = 0; count = 0;
+          lvl0 = ln.cnt[l];
+          if (first + S > cd.cap) {  // (the host sizes S for the space there is: a lane refused here waits for the next chunk)
+            if (leader) {
+              atomicOr(&ctr[RC_OVERFLOW], 1);
+              for (int slot = first; slot < cd.cap; slot++) {
+                for (int k = 0; k < NP; k++) {
+                  const double wk = ln.C[(int64_t)k * L + l];
+                  cd.A[(int64_t)slot * NP + k] = wk; cd.B[(int64_t)slot * NP + k] = wk;
+                }
+                cd.lane[slot] = l; cd.level[slot] = 0; cd.rule[slot] = 0; cd.reach[slot] = 0;
+              }
+              ln.gfirst[l] = 0; ln.gcount[l] = 0; ln.gend[l] = 0;
+            }
+          } else {
+            busy = true;
+            took = true;
+            chalf = 0; cit = 0; need = 1;
+            if (leader) {
+#pragma unroll
+              for (int k = 0; k < NP; k++) { Tl[k] = Tgt[(int64_t)k * L + l]; wl[k] = ln.C[(int64_t)k * L + l]; }
+            }
+          }
+        }
+      }
+      next += __popcll(free_rows);
+      row_fence();
+      if (took && half == 0) step_into(r, wl);
+    }
+    if (__ballot(busy) == 0ull) {
+      if (next < end) continue;  // (every row of this pass was refused candidate space: on to the next entries)
+      break;
+    }
+    // ---- one pass.  The configuration the row's projection stands at, to both halves
+    const bool mine = busy && half == chalf;
+    if (mine && g == 0) {
+#pragma unroll
+      for (int k = 0; k < NQ; k++) qrow[k] = r.qv[k];
+    }
+    row_fence();
+    // Run ahead?  Only behind the evaluation that is expected to close its step (the projection has had as many updates as
+    // the step before took), with a step left in the chunk, and if the candidate it would confirm passes the rules and is
+    // not the target itself
+    bool good = false, reach = false, judged = false;
+    bool ahead = busy && cit >= need && s + 1 < S;
+    if (__ballot(ahead) != 0ull) {
+      rules(good, reach);
+      judged = true;
+      ahead = ahead && good && !reach;
+    }
+    const bool runs_ahead = ahead && !mine;
+    if (runs_ahead) step_into(r, qnl);
+    int res = -2;
+    if (mine || runs_ahead) res = P::iterate(c, r, x, g);
+    const int lead = lane & ~15;
+    const int res_row = __shfl(res, lead + 8 * chalf), res_ahead = __shfl(res, lead + 8 * (chalf ^ 1));
+    const bool done_step = busy && res_row != -1;
+    if (busy && res_row == -1) {
+      cit++;  // (another update: whatever ran ahead is dropped)
+      if (cit > need) need = cit;
+    }
+    if (__ballot(done_step) != 0ull) {
+      // a projection is through (1: within tolerance at `qrow`; 0 / 2: failed): the candidate and the rules
+      if (!judged) rules(good, reach);
+      bool restep = false;
+      if (done_step) {
+        good = good && res_row == 1;
+        const int slot = first + s;
+        if (leader) {
+#pragma unroll
+          for (int k = 0; k < NP; k++) {
+            cd.A[(int64_t)slot * NP + k] = wl[k];
+            cd.B[(int64_t)slot * NP + k] = good ? qnl[k] : wl[k];  // (refused: a harmless edge for the validation launch)
+          }
+          cd.lane[slot] = l;
+          cd.level[slot] = lvl0 + s;
+          cd.rule[slot] = good ? 1 : 0;
+          cd.reach[slot] = (good && reach) ? 1 : 0;
+        }
+        count++;
+        s++;
+        const bool over = !good || reach;  // the lane ends after this chunk's candidates whatever their verdicts
+        need = cit > 1 ? cit : 1;
+        if (good && leader) {
+#pragma unroll
+          for (int k = 0; k < NP; k++) wl[k] = qnl[k];
+        }
+        if (!over && s < S) {
+          if (ahead && res_ahead == -1) {
+            chalf ^= 1;  // the half that ran ahead holds the next step's projection, one update in
+            cit = 1;
+          } else {
+            cit = 0;
+            restep = true;
+          }
+        } else {
+          if (leader) {
+            const double *wend = good ? qnl : wl;  // (the chain's end: wl is being rewritten by this lane alone, read it as it will be)
+            for (int sl = first + count; sl < first + S; sl++) {  // slots behind the last candidate: a zero-length edge nobody reads
+#pragma unroll
+              for (int k = 0; k < NP; k++) { cd.A[(int64_t)sl * NP + k] = wend[k]; cd.B[(int64_t)sl * NP + k] = wend[k]; }
+              cd.lane[sl] = l; cd.level[sl] = 0; cd.rule[sl] = 0; cd.reach[sl] = 0;
+            }
+            ln.gfirst[l] = first;
+            ln.gcount[l] = count;
+            ln.gend[l] = (uint8_t)(over ? 1 : 0);
+          }
+          busy = false;
+        }
+      }
+      row_fence();  // (the chain's new end, before anybody steps from it)
+      if (restep && half == chalf) step_into(r, wl);
+    }
+  }
+}
+
 // ---- row f3: batched IK seeds ---------------------------------------------------------------------------------------
 // k_ik_solve (mjpl_project.h) around the generated chain: one seed per row, the Levenberg-Marquardt damping, the locking of
 // joints on a limit and the restarts statement for statement; G lanes share the hinges' sines and cosines.

@@ -559,7 +559,12 @@ struct mjpl_rrt {
   int64_t proj_slots = 1 << 20;
   // ... and the shape of the generating launch (mjpl_rows.h; mjpl_hip.hip: rows_shape): lanes per row, waves per launch
   // (one per SIMD: the kernels' registers) -- MJPL_RRT_PROJ_G / MJPL_RRT_PROJ_WAVES for A/B timing
-  int proj_g = 0;            // 0: lanes per row by the number of active lanes (rows_shape)
+  int proj_g = 0;            // 0: lanes per row by the number of active lanes (rows_shape); 1 / 4 / 8 / 16 forced
+  // rows of sixteen lanes that run a step ahead (mjpl_rows.h: k_rrt_gen_project_ahead), when no more lanes than this extend:
+  // one row per wave (measured: with four rows per wave, 1 536 lanes, 14.0 ms against 13.5 with eight lanes per row -- the
+  // statements of running ahead are paid by every row of the wave; one row per wave, 268 lanes x 1 024 steps: 20.5 ms
+  // against 23.9).  MJPL_RRT_AHEAD=0: never; MJPL_RRT_AHEAD_LANES
+  int ahead = 1, ahead_lanes = 1024;
   int proj_waves_max = 1024;
   // The connect phase's nearest neighbours, early (round 5).  A lane's round does not depend on any other lane's (both trees
   // are the round's snapshot), and the tail of the first extension is a handful of lanes taking a thousand sequential steps
@@ -816,13 +821,22 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
         trace_G = 1; trace_grid = (unsigned)((active_bound + kPoseBlock - 1) / kPoseBlock);
         if (pk >= 0) {
           const RowsShape rs = r->proj_g > 0 ? RowsShape{r->proj_g, 0u, 0} : rows_shape(active_bound);
-          const int G = rs.G;
-          const int64_t rows_per_wave = 64 / G;
+          // (few rows: sixteen lanes each, the next step's first Newton pass beside this step's closing evaluation -- mjpl_rows.h,
+          //  k_rrt_gen_project_ahead; a library without that kernel refuses and the chunk falls back below)
+          const int G = (r->proj_g == 0 && r->ahead && active_bound <= r->ahead_lanes) ? (active_bound <= r->proj_waves_max ? 64 : 16) : rs.G;
+          const int64_t rows_per_wave = G == 64 ? 1 : 64 / G;  // (64: sixteen lanes per row all the same, ONE row per wave)
           const unsigned rgridw = (unsigned)std::max<int64_t>(1, std::min<int64_t>(r->proj_waves_max, (active_bound + rows_per_wave - 1) / rows_per_wave));
           // (a library refuses -- nothing launched, -1 -- when it was built for another number of planning joints)
           trace_G = G; trace_grid = rgridw;
           launched = e->spec->gen_project(pk, G, st, rgridw, L, nplan, S, r->eps, par, r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase,
                                           r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+          if (launched == -1 && (G == 16 || G == 64) && r->proj_g == 0) {  // (no such kernel in this library: eight lanes per row)
+            const int64_t rpw = 64 / rs.G;
+            const unsigned gw = (unsigned)std::max<int64_t>(1, std::min<int64_t>(r->proj_waves_max, (active_bound + rpw - 1) / rpw));
+            trace_G = rs.G; trace_grid = gw;
+            launched = e->spec->gen_project(pk, rs.G, st, gw, L, nplan, S, r->eps, par, r->pose->d_pi, r->pose->d_pd, r->d_qidx, r->d_qbase,
+                                            r->d_isplan, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+          }
           if (launched != 0 && launched != -1) return fail(MJPL_E_HIP, "rrt: the generated extension kernel failed to launch");
         }
         if (launched != 0) {
@@ -1054,7 +1068,9 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   memset(r->h_ring, 0, 4 * kRingStride * sizeof(int));
   if (const char *v = getenv("MJPL_RRT_PROJ_STEPS")) r->proj_steps_max = std::max(1, atoi(v));
   if (const char *v = getenv("MJPL_RRT_PROJ_SLOTS")) r->proj_slots = std::max(1, atoi(v));
-  if (const char *v = getenv("MJPL_RRT_PROJ_G")) { const int g = atoi(v); r->proj_g = (g == 1 || g == 4 || g == 8) ? g : 0; }
+  if (const char *v = getenv("MJPL_RRT_PROJ_G")) { const int g = atoi(v); r->proj_g = (g == 1 || g == 4 || g == 8 || g == 16 || g == 64) ? g : 0; }
+  if (const char *v = getenv("MJPL_RRT_AHEAD")) r->ahead = atoi(v) != 0 ? 1 : 0;
+  if (const char *v = getenv("MJPL_RRT_AHEAD_LANES")) r->ahead_lanes = std::max(1, atoi(v));
   if (const char *v = getenv("MJPL_RRT_PROJ_WAVES")) r->proj_waves_max = std::max(1, atoi(v));
   HIP_TRY(hipHostMalloc((void **)&r->h_heads, 8 * 1024 * sizeof(int)));
   HIP_TRY(hipHostMalloc((void **)&r->h_myhead, 8 * sizeof(int)));

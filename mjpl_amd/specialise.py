@@ -1444,7 +1444,12 @@ def generate_pose_section(model, nplan: int = 0) -> str:
             "                                 const double *hi, const double *Tgt, mjpl::RrtLanes ln, mjpl::RrtCand cd, int *ctr) {"]
     np_ = int(nplan) if 0 < int(nplan) <= 16 else 0
     if np_:
-        src += [f"  if (nplan != {np_}) return -1;  // (the library's program plans {np_} joints)"] + pick
+        src += [f"  if (nplan != {np_}) return -1;  // (the library's program plans {np_} joints)",
+                "  if (G == 16 || G == 64) {  // sixteen lanes per row, four rows per wave or one: the next step's first Newton pass beside this step's closing evaluation (mjpl_rows.h)",
+                "    switch (2 * k + (G == 64 ? 1 : 0)) {"]
+        src += [f"      case {2 * k + i}: hipLaunchKernelGGL((mjpl::k_rrt_gen_project_ahead<PoseSpec{k}, {np_}, {rows}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, L, S, eps, par, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr); break;"
+                for k, _, _ in specs for i, rows in enumerate((4, 1))]
+        src += ["      default: return -1;", "    }", "    return hipGetLastError() == hipSuccess ? 0 : -2;", "  }"] + pick
         src += cases("hipLaunchKernelGGL((mjpl::k_rrt_gen_project_rows<PoseSpec{k}, " + str(np_) + ", {g}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, L, S, eps, par, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr);")
         src += done
     else:

@@ -268,10 +268,11 @@ def test_first_round_of_131072_lanes_equals_the_host_planner_on_a_lane_prefix(or
         assert par[k] == 0  # the next chain starts at the root, too: lane 4096 (or later) begins
 
 
-@pytest.mark.parametrize("lanes_per_row", ["1", "4", "8"])
+@pytest.mark.parametrize("lanes_per_row", ["1", "4", "8", "16", "64"])
 def test_projecting_extension_makes_the_same_trees_whatever_the_lanes_per_row(lanes_per_row):
     """The generated chunk kernel (mjpl_rows.h: k_rrt_gen_project_rows) gives a row -- an active lane's chain of steps --
-    one lane, four or eight; by default the host picks by the number of active lanes (rows_shape).  Forced to one value
+    one lane, four or eight -- or sixteen, two halves of eight of which one runs the next step's first Newton pass beside
+    this step's closing evaluation (k_rrt_gen_project_ahead); by default the host picks by the number of active lanes.  Forced to one value
     for every chunk (MJPL_RRT_PROJ_G), the trees of three rounds must be, bit for bit, those of the interpreting kernel
     at one step per launch: the lanes of a row only share out the statements."""
     m = scenes.franka_p(obstacles=True)
