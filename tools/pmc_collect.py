@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernels of the next rows' lines: (bench.py --workload, rows per launch, timed steps of the profiled command)
 NEXT_ROWS = {"k_pose_apply_rows": ("pose", 131072, 1), "k_ik_solve_rows": ("ik", 16384, 1),
-             "k_rrt_gen_project_rows": ("rrt", 131072, 1), "k_nearest_mfma": ("rrt", 131072, 1), "k_filter_configs": ("configs", 65536, 1)}
+             "k_rrt_gen_project_rows": ("rrt", 131072, 1), "k_rrt_gen_project_ahead": ("rrt", 131072, 1), "k_nearest_mfma": ("rrt", 131072, 1), "k_filter_configs": ("configs", 65536, 1)}
 
 
 def main():

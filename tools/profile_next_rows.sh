@@ -21,6 +21,7 @@ cd $R
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_pose k_pose_apply_rows gpurun_out/${TAG}_pmc_k_pose_apply_rows.json > /dev/null
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt "k_nearest_mfma<7, false>" gpurun_out/${TAG}_pmc_k_nearest_mfma.json > /dev/null  # (the scan; <7, true> is the sample pass)
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_rrt_gen_project_rows gpurun_out/${TAG}_pmc_k_rrt_gen_project_rows.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_rrt_gen_project_ahead gpurun_out/${TAG}_pmc_k_rrt_gen_project_ahead.json > /dev/null  # (the tail's rows a step ahead)
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_ik k_ik_solve_rows gpurun_out/${TAG}_pmc_k_ik_solve_rows.json > /dev/null
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_configs k_filter_configs gpurun_out/${TAG}_pmc_k_filter_configs.json > /dev/null
 # the float64 pool kernel's issued floating-point instruction mix (bench --variant f64: k_edges_fused_f64)
