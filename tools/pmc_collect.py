@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernels of the next rows' lines: (bench.py --workload, rows per launch, timed steps of the profiled command)
 NEXT_ROWS = {"k_pose_apply_rows": ("pose", 131072, 1), "k_ik_solve_rows": ("ik", 16384, 1),
-             "k_rrt_gen_project_rows": ("rrt", 131072, 1), "k_rrt_gen_project_ahead": ("rrt", 131072, 1), "k_nearest_mfma": ("rrt", 131072, 1), "k_filter_configs": ("configs", 65536, 1)}
+             "k_rrt_gen_project_rows": ("rrt", 131072, 2), "k_rrt_gen_project_ahead": ("rrt", 131072, 2), "k_nearest_mfma": ("rrt", 131072, 2), "k_filter_configs": ("configs", 65536, 1)}
 
 
 def main():
@@ -66,8 +66,8 @@ def main():
         rec = {k: r[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES",
                                  "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE", "avg_ns", "calls") if k in r}
         if workload == "rrt" and "calls" in r:
-            # (the profiled command runs one timed round after the warm-up round of single-node trees, whose launches are
-            #  counted with it: a handful of microsecond-long ones)
+            # (the profiled command runs one timed round after the warm-up round -- the first round of the search, from single-node
+            #  trees, 131 072 lanes all the same: two rounds' launches in the trace)
             rec["calls_per_round"] = r["calls"] / float(timed_steps)
         rec["source"] = f"profiles/{os.path.basename(p)} + profiles/{tag}_{workload}_kernel_stats.csv (tools/profile_next_rows.sh {tag})"
         out[f"{kernel}_{workload}{size}"] = rec
