@@ -338,3 +338,37 @@ def test_connect_phase_neighbours_looked_up_early_make_the_same_trees(early_lane
     for t in (0, 1):
         np.testing.assert_array_equal(trees[0][t][0], trees[1][t][0])
         np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
+
+
+def test_look_ups_ahead_at_planner_size_make_the_same_trees():
+    """The same comparison at a planner's size -- 65 536 lanes, three rounds, trees of several hundred thousand nodes --
+    with the defaults: the connect phase's and the next round's look-ups on the second stream, the next round's scan of
+    the appended nodes behind the early answer through the matrix-core screen (nearest_range), every chunk sized by its own
+    lane count, the tail's rows a step ahead -- against a planner with all of that off."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    trees = []
+    keys = ("MJPL_RRT_EARLY_NN", "MJPL_RRT_EXACT_COUNTS", "MJPL_RRT_AHEAD")
+    for env in (dict(MJPL_RRT_EARLY_NN="0", MJPL_RRT_EXACT_COUNTS="0", MJPL_RRT_AHEAD="0"), dict()):
+        old = {k: os.environ.pop(k, None) for k in keys}
+        os.environ.update(env)
+        try:
+            cc, pc, q_goal = _constrained(m, q_init, 7)
+            dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=23, goal_biasing_probability=0.05,
+                                   batch=65536, capacity=1 << 23, pose=pc)
+        finally:
+            for k in keys:
+                os.environ.pop(k, None)
+                if old[k] is not None:
+                    os.environ[k] = old[k]
+        dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 23)
+        infos = [dev.rrt.round() for _ in range(3)]
+        assert infos[-1].nodes[0] > 200000 and infos[-1].nodes[1] > 200000
+        trees.append([dev.rrt.tree(t) for t in (0, 1)])
+        dev.rrt.close()
+        cc.engine.close()
+    for t in (0, 1):
+        np.testing.assert_array_equal(trees[0][t][0], trees[1][t][0])
+        np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
