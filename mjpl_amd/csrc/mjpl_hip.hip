@@ -334,6 +334,7 @@ struct mjpl_engine {
   size_t nn16_bytes = 0;
   int nn_mfma = 1;              // MJPL_NN_MFMA=0: binary32 screen only
   void *d_nn_tmp = nullptr; size_t nn_tmp_bytes = 0;  // distances of a ranged look-up whose caller wants none
+  int64_t nn_reserve_nodes = 0; // packed-node rows the screened look-up's scratch is sized for at least (mjpl_rrt_create: the planner's capacity, 2^23 at most)
   int64_t nn_sample = 65536;    // MJPL_NN_SAMPLE: nodes of the strided sample the matrix cores take every query's bound from
   int nn_last = 0;              // what the last mjpl_nearest_dev launched: 0 float64 scan, 1 binary32 screen, 2 matrix-core screen (or 1: see its flag)
   size_t uc_cap = 0, uc_cap_limit = 0;
@@ -2351,7 +2352,8 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         const size_t need16 = 256 + b_nodes + b_q + b_qn + b_pd + b_pi + 32;
         if (need16 > e->nn16_bytes) {
           // (trees grow call by call, and a reallocation stalls the stream: room for four times the nodes, within the slab)
-          const size_t room = need16 - b_nodes + (size_t)std::min<int64_t>((cap + 31) / 32 * 32, 4 * npad) * 32;
+          // (a planner says how far its trees may grow: nn_reserve_nodes -- no reallocation in the middle of a search)
+          const size_t room = need16 - b_nodes + (size_t)std::min<int64_t>((cap + 31) / 32 * 32, std::max<int64_t>(4 * npad, e->nn_reserve_nodes)) * 32;
           if (e->d_nn16) HIP_TRY(hipFree(e->d_nn16));
           e->d_nn16 = nullptr; e->nn16_bytes = 0;
           HIP_TRY(hipMalloc(&e->d_nn16, room));

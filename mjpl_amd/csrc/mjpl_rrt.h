@@ -1022,6 +1022,7 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   r->nq = e->m.nq;
   r->L = d->lanes;
   r->cap = d->capacity;
+  e->nn_reserve_nodes = std::max<int64_t>(e->nn_reserve_nodes, std::min<int64_t>(d->capacity, (int64_t)1 << 23));
   r->eps = d->epsilon;
   r->istep = d->interval_step;
   r->pgoal = d->goal_bias;
