@@ -2366,7 +2366,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         float *qn = (float *)at; at += b_qn;
         mp_idx = (int32_t *)at; at += (b_pi + 31) / 32 * 32;
         uint4 *nodes16 = (uint4 *)at;
-        HIP_TRY(hipMemsetAsync(xbits, 0, 8, e->stream));
+        HIP_TRY(hipMemsetAsync(xbits, 0, 12, e->stream));  // [0] largest coordinate, [1] wild, [2] largest node norm
         hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, dnodes, n, cap, npad, nplan, 0,
                            nodes16, (float *)nullptr, xbits);
         hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16,

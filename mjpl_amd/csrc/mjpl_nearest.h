@@ -271,7 +271,7 @@ k_nearest_part32(const double *__restrict__ nodes, int64_t n, int64_t cap, const
 // per lane are folded with eight v_min3 and compared once; only a wave that sees a pass looks at the sixteen one
 // by one and evaluates the exact float64 distance of those -- k_nearest_part's statements, in scan order with a
 // strict <.
-//   thr >= (R2 + 2 (4 sqrt(NP) e r + 4 NP e^2 + a)) (1 + 1e-6),  e = 1.5 2^-22 X + 2^-24,  a = 2^-16 NP X^2,
+//   thr >= (R2 + 2 (4 sqrt(NP) e r + 4 NP e^2 + a)) (1 + 1e-6),  e = 1.5 2^-22 X + 2^-24,  a = 2^-18 (max |x~| + |q~|)^2,
 // R2 = min(best exact squared distance so far of this lane, bound2), r = sqrt(R2), X = the largest finite coordinate
 // magnitude among all nodes and queries (k_nn_pack).  (v -> binary32 loses 2^-24 |v|; v_h is within 2^-11 |v| of
 // that, v_l within 2^-11 of the rest or 2^-25 where it is subnormal -- the matrix cores keep binary16 subnormals,
@@ -279,7 +279,8 @@ k_nearest_part32(const double *__restrict__ nodes, int64_t n, int64_t cap, const
 // the true one by at most 2 sqrt(NP) e, and a node no farther than r has a represented squared distance of at most
 // R2 + 4 sqrt(NP) e r + 4 NP e^2.  Arithmetic: the products are exact in binary32; the seven-term sums of |x~|^2
 // and |q~|^2, the split of n (2^-22 n), the 32-term accumulation of the two instructions and the subtraction of
-// |q~|^2 lose at most 50 2^-24 (|x~| + |q~|)^2 <= 2^-16 NP X^2 together.  The factor two and the 1e-6 are margin.)
+// |q~|^2 lose at most 50 2^-24 (|x~| + |q~|)^2 together: a takes 64 2^-24 of that with the query's own |q~| and the largest
+// |x~| among the nodes (round 4: 2^-16 NP X^2 for all pairs, four to seven times as much).  The factor two and the 1e-6 are margin.)
 // With single binary16 coordinates -- one instruction, e = 2^-11 X -- the screen let through every node within
 // 0.02 rad of the bound: a quarter of a tree whose chains all start at one root.  A node at +inf gives +inf or NaN,
 // which v_min3 and the ordered compare ignore: never nearest, as in the other kernels.  Two lanes share a query
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(256)
 k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int64_t padded, int nplan, int is_query,
           uint4 *__restrict__ out16, float *__restrict__ nrm, unsigned *__restrict__ xbits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float mx = 0;
+  float mx = 0, n2max = 0;
   bool wild = false;
   if (i < padded) {
     union { _Float16 h[16]; uint4 u[2]; } hi, lo;
@@ -350,7 +351,11 @@ k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int
       out16[2 * i + 1] = hi.u[1];
     }
     if (nrm) nrm[i] = n2;
+    // (the largest finite |x~|^2 among the nodes: the screen's arithmetic allowance is taken per query against it, below)
+    if (!is_query && i < count && n2 < std::numeric_limits<float>::infinity()) n2max = n2;
   }
+  for (int o = 32; o > 0; o >>= 1) n2max = fmaxf(n2max, __shfl_xor(n2max, o));
+  if ((threadIdx.x & 63) == 0 && n2max > 0) atomicMax(&xbits[2], __float_as_uint(n2max));
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(&xbits[0], __float_as_uint(mx));
   if (__ballot(wild) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&xbits[1], 1u);
@@ -403,7 +408,17 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
   const int64_t q0 = ((int64_t)blockIdx.x * kNNMWaves + w) * (kNNMSets * 32) + r;
   const double kInf = std::numeric_limits<double>::infinity();
   const double X = (double)__uint_as_float(xbits[0]);
-  const double e = 1.5 * 0x1p-22 * X + 0x1p-24, a = 0x1p-16 * NP * X * X;
+  // The arithmetic allowance `a` of nn_mfma_threshold, per query: the sums lose at most 50 2^-24 (|x~| + |q~|)^2 (comment above);
+  // round 4 took the bound for ALL pairs, 2^-16 NP X^2.  With a query's own |q~| and the largest |x~| among the nodes
+  // (k_nn_pack) it is several times smaller -- and in a dense tree every node within sqrt(2 a) of a query's best passes the
+  // screen: at 2 10^6 nodes on a five-dimensional manifold a look-up of configurations ON the tree took 160 ms with
+  // sqrt(2 a) = 0.045 (profiles/README.md, round 5).
+  const double N2 = (double)__uint_as_float(xbits[2]) * (1.0 + 1e-5);
+  const double e = 1.5 * 0x1p-22 * X + 0x1p-24;
+  auto allowance = [&](float nqv) {
+    const double sxy = sqrt(N2) + sqrt((double)nqv * (1.0 + 1e-5));
+    return 0x1p-18 * sxy * sxy;
+  };
   nn_h8 bh[kNNMSets], bl[kNNMSets];
   float T[kNNMSets];
   double *best = best_l + (SAMPLE ? 0 : threadIdx.x), *ref2 = ref2_l + (SAMPLE ? 0 : threadIdx.x);  // [set * kThreads]
@@ -421,7 +436,7 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
       const double b2 = (q < M) ? bound2[q] : 0.0;
       best[s * kThreads] = kInf;
       ref2[s * kThreads] = b2;
-      T[s] = b2 < kInf ? nn_mfma_threshold<NP>(b2, sqrt(b2), e, a, qnorm[q]) : std::numeric_limits<float>::infinity();
+      T[s] = b2 < kInf ? nn_mfma_threshold<NP>(b2, sqrt(b2), e, allowance(qnorm[q]), qnorm[q]) : std::numeric_limits<float>::infinity();
       if (q >= M || probe) T[s] = -std::numeric_limits<float>::infinity();  // (probe: a timing run in which nothing passes the screen -- wrong answers, the loop alone)
     }
   }
@@ -466,7 +481,7 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     for (int k = 0; k < kNNMSets; k++)
       if ((touched >> k) & 1u) {  // (a set's lower bound: its threshold falls; q < M, or nothing of it was ever parked)
         const double b2 = ref2[k * kThreads];
-        T[k] = nn_mfma_threshold<NP>(b2, sqrt(b2), e, a, qnorm[q0 + 32 * k]);
+        T[k] = nn_mfma_threshold<NP>(b2, sqrt(b2), e, allowance(qnorm[q0 + 32 * k]), qnorm[q0 + 32 * k]);
       }
     parked = 0;
   };
