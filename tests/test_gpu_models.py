@@ -486,3 +486,37 @@ def test_nearest_neighbour_over_a_node_range_behind_an_earlier_answer(n0, n, M):
         e.nearest_range_dev(dn.ptr, n0, n, cap, dq.ptr, M, di2.ptr, None, di0.ptr, dd0.ptr)
         np.testing.assert_array_equal(di2.download(np.int32, M), got)
     e.close()
+
+
+def test_nearest_neighbour_in_a_dense_tree():
+    """Queries that lie ON a dense tree (the connect phase of a search that has filled its manifold): 300 000 nodes on a
+    two-dimensional sheet in the seven joints, a few thousandths of a radian apart, queries = nodes, nodes moved by 1e-4,
+    and points between them.  Thousands of nodes are within the screen's arithmetic allowance of every query's best -- the
+    allowance is per query (its own norm, the largest node norm) -- and the winners must be the float64 scan's all the same."""
+    m = scenes.franka_p()
+    e = eng_mod.Engine(m)
+    e.set_planning(scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos)
+    rng = np.random.default_rng(77)
+    n, M = 300000, 8192
+    u, v = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    base = np.array([0.3, -0.8, 1.1, -2.0, 0.4, 2.2, -0.6])
+    a1, a2 = rng.normal(size=7), rng.normal(size=7)
+    a1, a2 = a1 / np.linalg.norm(a1), a2 / np.linalg.norm(a2)
+    nodes = (base[:, None] + 0.9 * a1[:, None] * u[None, :] + 0.9 * a2[:, None] * v[None, :] + 0.05 * np.sin(3 * u * v)[None, :])
+    pick = rng.integers(0, n, M)
+    qs = nodes[:, pick].copy()
+    qs[:, M // 3: 2 * M // 3] += rng.normal(scale=1e-4, size=(7, 2 * M // 3 - M // 3))
+    qs[:, 2 * M // 3:] = 0.5 * (qs[:, 2 * M // 3:] + nodes[:, rng.integers(0, n, M - 2 * M // 3)])
+    dn, dq = e.alloc(nodes.nbytes).upload(nodes), e.alloc(qs.nbytes).upload(qs)
+    di, dd = e.alloc(4 * M), e.alloc(8 * M)
+    e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
+    assert e.nearest_last_screen() == 2
+    got, gd = di.download(np.int32, M), dd.download(np.float64, M)
+    sel = np.concatenate([np.arange(0, 40), M // 3 + np.arange(0, 40), 2 * M // 3 + np.arange(0, 40), rng.integers(0, M, 120)])
+    s = np.zeros((len(sel), n))
+    for c in range(7):  # the kernel's sum order
+        d = nodes[c][None, :] - qs[c][sel][:, None]
+        s = s + d * d
+    np.testing.assert_array_equal(got[sel], s.argmin(1))
+    np.testing.assert_array_equal(gd[sel], s.min(1))
+    e.close()
