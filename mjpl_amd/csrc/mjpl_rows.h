@@ -27,6 +27,14 @@
 
 namespace mjpl {
 
+// Where planning column k sits in qpos: read from the planner's table (PlanQRuntime), or -- a model's library knows its
+// program's planning joints -- a constant of the generated source (struct SpecPlanQ, mjpl_amd/specialise.py): the loops that
+// scatter a lane's planning coordinates into a configuration and gather them back are unrolled over constants then, and the
+// NP x NQ compare-and-select chains they were (~350 vector instructions per step of an extension) fold away.
+struct PlanQRuntime {
+  static __device__ __forceinline__ int at(int k, const int *__restrict__ qidx) { return qidx[k]; }
+};
+
 constexpr int kXchStride = 26;  // doubles per row of a wave's exchange area (rows land on disjoint LDS banks: 52 words apart)
 
 __device__ __forceinline__ void row_fence() {  // LDS written by some lanes of the wave, read by others
@@ -313,7 +321,7 @@ k_pose_apply_rows(const int *__restrict__ pi, const double *__restrict__ pd, con
 // iterations of its projection, the rules of _constrained_extend (planning/utils.py:139-164); a row whose chain ends
 // (rule failure, arrival, S steps) hands its lanes to the next entry.  What the chunk writes (candidates per lane,
 // gfirst / gcount / gend) is what k_rrt_gen_project<void> writes: slot NUMBERS differ (nothing reads them across lanes).
-template <class PS, int NP, int G>
+template <class PS, int NP, int G, class PQ = PlanQRuntime>
 __global__ void __launch_bounds__(kPoseBlock)
 k_rrt_gen_project_rows(int L, int S, double eps, int par, const int *__restrict__ pi, const double *__restrict__ pd,
                        const int *__restrict__ qidx, const double *__restrict__ qbase, const uint8_t *__restrict__ isplan,
@@ -366,7 +374,7 @@ k_rrt_gen_project_rows(int L, int S, double eps, int par, const int *__restrict_
     for (int k = 0; k < NQ; k++) { r.qold[k] = qbase[k]; r.qv[k] = qbase[k]; }
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-      const int at = qidx[k];
+      const int at = PQ::at(k, qidx);
 #pragma unroll
       for (int j = 0; j < NQ; j++)
         if (j == at) { r.qold[j] = w[k]; r.qv[j] = q[k]; }
@@ -418,7 +426,7 @@ k_rrt_gen_project_rows(int L, int S, double eps, int par, const int *__restrict_
         bool reach = true;
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-          const int at = qidx[k];
+          const int at = PQ::at(k, qidx);
           double v = 0;
 #pragma unroll
           for (int j = 0; j < NQ; j++)
@@ -487,7 +495,7 @@ k_rrt_gen_project_rows(int L, int S, double eps, int par, const int *__restrict_
 // A step then costs one pass, not two.  Every value is computed by the statements of the kernel above from the same
 // inputs -- running ahead only changes WHEN -- so the candidates are the same bit for bit
 // (tests/test_gpu_rrt.py::..._whatever_the_lanes_per_row, 16 and 64).  Launch: ceil(entries / ROWS) waves at most 1 024.
-template <class PS, int NP, int ROWS>
+template <class PS, int NP, int ROWS, class PQ = PlanQRuntime>
 __global__ void __launch_bounds__(kPoseBlock)
 k_rrt_gen_project_ahead(int L, int S, double eps, int par, const int *__restrict__ pi, const double *__restrict__ pd,
                         const int *__restrict__ qidx, const double *__restrict__ qbase, const uint8_t *__restrict__ isplan,
@@ -557,7 +565,7 @@ k_rrt_gen_project_ahead(int L, int S, double eps, int par, const int *__restrict
     for (int k = 0; k < NQ; k++) { rr.qold[k] = qbase[k]; rr.qv[k] = qbase[k]; }
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-      const int at = qidx[k];
+      const int at = PQ::at(k, qidx);
       const double fk = from[k];
 #pragma unroll
       for (int j = 0; j < NQ; j++)
@@ -576,7 +584,7 @@ k_rrt_gen_project_ahead(int L, int S, double eps, int par, const int *__restrict
     reach = true;
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-      qn[k] = qrow[qidx[k]];
+      qn[k] = qrow[PQ::at(k, qidx)];
       reach = reach && (qn[k] == Tl[k]);
       good = good && (qn[k] >= lo[k] && qn[k] <= hi[k]);
     }

@@ -1409,10 +1409,11 @@ def generate_pose(pi, pd, hash_: int, index: int, qualifier: str = "static __dev
     return "\n".join(out) + "\n"
 
 
-def generate_pose_section(model, nplan: int = 0) -> str:
+def generate_pose_section(model, nplan: int = 0, qidx=None) -> str:
     """All generated projections of a model and the entry points a library exports for them.  nplan: the number of
     planning joints of the program the library is built for (the planner's chunk kernel keeps a lane's rows in
-    registers when it is a constant; 0: unknown)."""
+    registers when it is a constant; 0: unknown); qidx: their qpos addresses (None: unknown -- the kernels read the
+    planner's table)."""
     specs = []
     for k, b in enumerate(pose_site_bodies(model)):
         pi, pd, h = dump_pose_chain(model, b)
@@ -1420,7 +1421,17 @@ def generate_pose_section(model, nplan: int = 0) -> str:
             continue  # (nothing to project / registers: the interpreting kernels serve such a chain)
         specs.append((len(specs), h, generate_pose(pi, pd, h, len(specs))))
     n = len(specs)
-    src = ["namespace {"] + [s for _, _, s in specs] + ["}  // namespace", "", 'extern "C" {', f"int mjpl_spec_pose_count(void) {{ return {n}; }}",
+    np_ = int(nplan) if 0 < int(nplan) <= 16 else 0
+    planq = "mjpl::PlanQRuntime"
+    plan_src = []
+    if np_ and qidx is not None and len(qidx) == np_:
+        planq = "SpecPlanQ"
+        plan_src = ["// where the program's planning columns sit in qpos (the library is named by the program's hash, which covers them)",
+                    "struct SpecPlanQ {",
+                    "  static __device__ __forceinline__ constexpr int at(int k, const int *) {",
+                    f"    constexpr int t[{np_}] = {{{', '.join(str(int(x)) for x in qidx)}}};",
+                    "    return t[k];", "  }", "};"]
+    src = ["namespace {"] + [s for _, _, s in specs] + plan_src + ["}  // namespace", "", 'extern "C" {', f"int mjpl_spec_pose_count(void) {{ return {n}; }}",
            "unsigned long long mjpl_spec_pose_hash(int k) {", "  switch (k) {"]
     src += [f"    case {k}: return PoseSpec{k}::kHash;" for k, _, _ in specs]
     src += ["    default: return 0ull;", "  }", "}"]
@@ -1442,15 +1453,14 @@ def generate_pose_section(model, nplan: int = 0) -> str:
     src += ["int mjpl_spec_launch_gen_project(int k, int G, hipStream_t st, unsigned grid, int L, int nplan, int S, double eps, int par, const int *pi,",
             "                                 const double *pd, const int *qidx, const double *qbase, const uint8_t *isplan, const double *lo,",
             "                                 const double *hi, const double *Tgt, mjpl::RrtLanes ln, mjpl::RrtCand cd, int *ctr) {"]
-    np_ = int(nplan) if 0 < int(nplan) <= 16 else 0
     if np_:
         src += [f"  if (nplan != {np_}) return -1;  // (the library's program plans {np_} joints)",
                 "  if (G == 16 || G == 64) {  // sixteen lanes per row, four rows per wave or one: the next step's first Newton pass beside this step's closing evaluation (mjpl_rows.h)",
                 "    switch (2 * k + (G == 64 ? 1 : 0)) {"]
-        src += [f"      case {2 * k + i}: hipLaunchKernelGGL((mjpl::k_rrt_gen_project_ahead<PoseSpec{k}, {np_}, {rows}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, L, S, eps, par, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr); break;"
+        src += [f"      case {2 * k + i}: hipLaunchKernelGGL((mjpl::k_rrt_gen_project_ahead<PoseSpec{k}, {np_}, {rows}, {planq}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, L, S, eps, par, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr); break;"
                 for k, _, _ in specs for i, rows in enumerate((4, 1))]
         src += ["      default: return -1;", "    }", "    return hipGetLastError() == hipSuccess ? 0 : -2;", "  }"] + pick
-        src += cases("hipLaunchKernelGGL((mjpl::k_rrt_gen_project_rows<PoseSpec{k}, " + str(np_) + ", {g}>), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, L, S, eps, par, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr);")
+        src += cases("hipLaunchKernelGGL((mjpl::k_rrt_gen_project_rows<PoseSpec{k}, " + str(np_) + ", {g}, " + planq + ">), dim3(grid), dim3(mjpl::kPoseBlock), 0, st, L, S, eps, par, pi, pd, qidx, qbase, isplan, lo, hi, Tgt, ln, cd, ctr);")
         src += done
     else:
         src += ["  return -1;  // (the number of planning joints is not a constant of this library)", "}"]
@@ -1522,7 +1532,7 @@ def build(model, allowed_collision_bodies=(), qidx=None, qpos_base=None, filter_
             nstage += ng
     src = translation_unit(generate(ip, fp, dp, info, generic=generic), generate_exact(ip, dp, info, generic=generic), key, info,
                            (SCENE_ROWS << 8 | nstage) if generic else 0,  # (kSceneRows, moving geoms)
-                           pose=generate_pose_section(model, int(ip[H_NPLAN])),
+                           pose=generate_pose_section(model, int(ip[H_NPLAN]), qidx=(None if qidx is None else [int(x) for x in qidx])),
                            # (an experiment, off by default: see generate_full_exact / mjpl_fused.h)
                            exact_full=generate_full_exact(ip, fp, dp, info) if (not generic and os.environ.get("MJPL_SPEC_F64") == "1") else None)
     # Source and library appear under their final names complete or not at all (os.replace): an engine created
