@@ -2410,7 +2410,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         case NPV:                                                                                                         \
           hipLaunchKernelGGL((k_nearest_mfma<NPV, false>), gm, dim3(kNNMWaves * 64), 0, e->stream, dnodes, n, cap, dqueries, M,    \
                              (const uint4 *)nodes16, (const uint4 *)q16, (const float *)qn, (const unsigned *)xbits, chm, \
-                             (int64_t)1, seed_d2, mp_idx, mp_d2, getenv("MJPL_NN_PROBE") ? 1 : 0);                          \
+                             (int64_t)1, seed_d2, mp_idx, mp_d2);                                                         \
           break;
         switch (nplan) {
           MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7)

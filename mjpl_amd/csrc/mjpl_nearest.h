@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(kNNMWaves * 64, 2)
 k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries, int64_t M,
                const uint4 *__restrict__ nodes16, const uint4 *__restrict__ queries16, const float *__restrict__ qnorm,
                const unsigned *__restrict__ xbits, int64_t chunk, int64_t stride, double *__restrict__ bound2,
-               int32_t *__restrict__ pidx, double *__restrict__ pd2, int probe = 0) {
+               int32_t *__restrict__ pidx, double *__restrict__ pd2) {
   static_assert(NP <= kNNMMaxPlan, "seven coordinate slots per half of the operand");
   if (xbits[1] != 0u) return;  // wild coordinates: the binary32 screen (and the float64 sample scan) serve this call
   // a lane's state that the loop itself does not touch lives in LDS (the two accumulator sets, the queries' operands and
@@ -437,7 +437,7 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
       best[s * kThreads] = kInf;
       ref2[s * kThreads] = b2;
       T[s] = b2 < kInf ? nn_mfma_threshold<NP>(b2, sqrt(b2), e, allowance(qnorm[q]), qnorm[q]) : std::numeric_limits<float>::infinity();
-      if (q >= M || probe) T[s] = -std::numeric_limits<float>::infinity();  // (probe: a timing run in which nothing passes the screen -- wrong answers, the loop alone)
+      if (q >= M) T[s] = -std::numeric_limits<float>::infinity();
     }
   }
   const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
