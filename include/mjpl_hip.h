@@ -241,6 +241,14 @@ int mjpl_nearest_range_dev(mjpl_engine *e, const double *dnodes, int64_t n0, int
  * binary16).  The result is the float64 scan's either way.  Synchronises. */
 int32_t mjpl_nearest_last_screen(mjpl_engine *e);
 
+/* ---- options: the switches tests and tools need, through the ABI instead of the caller's environment ----
+ * mjpl_set_option(e, name, value): MJPL_OK, or MJPL_E_ARG for an unknown name / a value out of range.  Options
+ * that shape the compiled model (e.g. "filter") take effect at the next mjpl_set_planning / first launch; the rest
+ * at the next call.  Names: the table in tools/README.md ("nn_cells", "nn_cells_min_nodes", "nn_mfma",
+ * "nn_sample", "filter", "fused", ...).  mjpl_get_option reads one back. */
+int mjpl_set_option(mjpl_engine *e, const char *name, double value);
+int mjpl_get_option(mjpl_engine *e, const char *name, double *value);
+
 /* ---- device memory and stream helpers (so that hosts need no other GPU runtime) -- */
 
 int mjpl_dev_alloc(mjpl_engine *e, size_t bytes, void **out);
@@ -441,6 +449,13 @@ typedef struct mjpl_rrt_desc {
   const double *lo, *hi;       /* [nplan] sampling box = JointLimitConstraint ranges            */
   mjpl_pose *pose;             /* nullable: PoseConstraint applied first                        */
   int64_t max_new_per_round;   /* slab rows per tree per rank per round; <= 0: max(128 lanes, 65536) */
+  int32_t max_steps_per_round; /* most nodes a lane adds per extension; 0: no cap (the reference's
+                                * _constrained_extend runs a chain to its end, planning/utils.py:139-164).
+                                * > 0: a lane of the growing tree still under way after that many nodes is
+                                * CARRIED -- it sits the connect phase out and, the next time its tree grows,
+                                * goes on from the node it reached towards the same target instead of drawing
+                                * a new one; a capped connect-phase lane just stops.  Deterministic per (lane,
+                                * round): all ranks still hold identical trees. */
 } mjpl_rrt_desc;
 
 typedef struct mjpl_rrt_round_info {

@@ -30,6 +30,7 @@
 #include "mjpl_pose.h"
 #include "mjpl_project.h"
 #include "mjpl_nearest.h"
+#include "mjpl_nearest_cells.h"
 
 namespace {
 
@@ -336,6 +337,9 @@ struct mjpl_engine {
   void *d_nn_tmp = nullptr; size_t nn_tmp_bytes = 0;  // distances of a ranged look-up whose caller wants none
   int64_t nn_reserve_nodes = 0; // packed-node rows the screened look-up's scratch is sized for at least (mjpl_rrt_create: the planner's capacity, 2^23 at most)
   int64_t nn_sample = 65536;    // MJPL_NN_SAMPLE: nodes of the strided sample the matrix cores take every query's bound from
+  int nn_cells = 1;             // the cell-ordered scan for big trees (mjpl_nearest_cells.h); option "nn_cells"
+  int64_t nn_cells_min = 131072; // ... from this many nodes on; option "nn_cells_min_nodes"
+  int nn_last_cells = 0;        // the last look-up took it
   int nn_last = 0;              // what the last mjpl_nearest_dev launched: 0 float64 scan, 1 binary32 screen, 2 matrix-core screen (or 1: see its flag)
   size_t uc_cap = 0, uc_cap_limit = 0;
   int nslots = 0, nsave = 0, maxs = 4;
@@ -2200,6 +2204,45 @@ int mjpl_take_status(mjpl_engine *e, int32_t *status) {
   return MJPL_OK;
 }
 
+// ---- options through the ABI (include/mjpl_hip.h).  One table: name -> how to read it, how to set it.
+namespace {
+struct EngineOption {
+  const char *name;
+  double (*get)(mjpl_engine *);
+  bool (*set)(mjpl_engine *, double);  // false: value out of range
+};
+#define MJPL_OPT_BOOL(NAME, FIELD) \
+  {NAME, [](mjpl_engine *e) { return (double)(e->FIELD ? 1 : 0); }, [](mjpl_engine *e, double v) { e->FIELD = v != 0.0; return true; }}
+const EngineOption kEngineOptions[] = {
+    MJPL_OPT_BOOL("nn_cells", nn_cells),
+    MJPL_OPT_BOOL("nn_mfma", nn_mfma),
+    {"nn_cells_min_nodes", [](mjpl_engine *e) { return (double)e->nn_cells_min; },
+     [](mjpl_engine *e, double v) { if (!(v >= 0 && v < 9e15)) return false; e->nn_cells_min = (int64_t)v; return true; }},
+    {"nn_sample", [](mjpl_engine *e) { return (double)e->nn_sample; },
+     [](mjpl_engine *e, double v) { if (!(v >= 32 && v < 9e15)) return false; e->nn_sample = std::max<int64_t>(1024, (int64_t)v) / 32 * 32; return true; }},
+    {"nn_last_cells", [](mjpl_engine *e) { return (double)e->nn_last_cells; }, nullptr},  // (read-only: the last look-up took the cell-ordered scan)
+};
+#undef MJPL_OPT_BOOL
+}  // namespace
+
+int mjpl_set_option(mjpl_engine *e, const char *name, double value) {
+  if (!e || !name) return fail(MJPL_E_ARG, "mjpl_set_option: NULL argument");
+  for (const EngineOption &o : kEngineOptions)
+    if (strcmp(o.name, name) == 0) {
+      if (!o.set) return fail(MJPL_E_ARG, "mjpl_set_option: \"%s\" is read-only", name);
+      if (!(value == value) || !o.set(e, value)) return fail(MJPL_E_ARG, "mjpl_set_option: value %g out of range for \"%s\"", value, name);
+      return MJPL_OK;
+    }
+  return fail(MJPL_E_ARG, "mjpl_set_option: unknown option \"%s\"", name);
+}
+
+int mjpl_get_option(mjpl_engine *e, const char *name, double *value) {
+  if (!e || !name || !value) return fail(MJPL_E_ARG, "mjpl_get_option: NULL argument");
+  for (const EngineOption &o : kEngineOptions)
+    if (strcmp(o.name, name) == 0) { *value = o.get(e); return MJPL_OK; }
+  return fail(MJPL_E_ARG, "mjpl_get_option: unknown option \"%s\"", name);
+}
+
 int32_t mjpl_nearest_last_screen(mjpl_engine *e) {
   if (!e) return -1;
   if (e->nn_last != 2) return e->nn_last;
@@ -2335,6 +2378,171 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
       double *mp_d2 = nullptr;
       int mparts = 0;
       const int64_t nsamp64 = std::min<int64_t>(kSampleNodes, n / kNNThreads * kNNThreads);  // (a short range: all of it)
+      e->nn_last_cells = 0;
+      if (mfma && e->nn_cells && n >= e->nn_cells_min && n >= 64 * kNNCellSub) {
+        // ---- the cell-ordered scan (mjpl_nearest_cells.h): nodes sorted along a space-filling curve, queries by where on it
+        // their bound was found, a wave scans the sub-chunks some query of it can have its answer in
+        e->nn_last_cells = 1;
+        const int64_t npad = (n + kNNCellSub - 1) / kNNCellSub * kNNCellSub, Mpad = (M + kNNMQueries - 1) / kNNMQueries * kNNMQueries;
+        const int64_t qblocks = Mpad / kNNMQueries;
+        const int nsub = (int)(npad / kNNCellSub), nwords = (nsub + 63) / 64, nsubp = nwords * 64;
+        // (sub-chunks per workgroup row: whole mask words, ~2 048 workgroups in all, no more rows than words)
+        const int64_t rows_want = std::max<int64_t>(1, std::min<int64_t>((2048 + qblocks - 1) / qblocks, nwords));
+        const int spg_words = (int)((nwords + rows_want - 1) / rows_want);
+        const int nsplit = (nwords + spg_words - 1) / spg_words;
+        mparts = 2 * nsplit;
+        // the arena: what grows with the tree last
+        auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+        size_t sort_tmp_n = 0, sort_tmp_q = 0;
+        const int64_t nres = std::max<int64_t>(npad, std::min<int64_t>((cap + kNNCellSub - 1) / kNNCellSub * kNNCellSub,
+                                                                       std::max<int64_t>(4 * npad, e->nn_reserve_nodes)));
+        (void)rocprim::radix_sort_pairs(nullptr, sort_tmp_n, (const unsigned *)nullptr, (unsigned *)nullptr, (const int32_t *)nullptr,
+                                        (int32_t *)nullptr, (size_t)nres, 0, kNNCKeyBits, e->stream);
+        (void)rocprim::radix_sort_pairs(nullptr, sort_tmp_q, (const unsigned *)nullptr, (unsigned *)nullptr, (const int32_t *)nullptr,
+                                        (int32_t *)nullptr, (size_t)M, 0, 16, e->stream);
+        const size_t b_q16 = al((size_t)Mpad * 64), b_qn = al((size_t)Mpad * 4), b_qs = al((size_t)nplan * M * 8), b_b2 = al((size_t)M * 8);
+        const size_t b_qf = al((size_t)Mpad * 32), b_k = al((size_t)M * 4), b_pd = al((size_t)mparts * M * 8), b_pi = al((size_t)mparts * M * 4);
+        const size_t b_masks = al((size_t)(Mpad / 128) * nwords * 8), b_tmpq = al(sort_tmp_q);
+        const size_t fixed = 1024 + 2 * b_q16 + 2 * b_qn + b_qs + b_b2 + b_qf + 4 * b_k + b_pd + b_pi + b_tmpq;
+        auto grows = [&](int64_t np) {  // masks, boxes, keys + permutation (in / out), sort space, sorted rows, packed rows
+          const size_t words = (size_t)((np / kNNCellSub + 63) / 64);
+          return al((size_t)(Mpad / 128) * words * 8) + al(16 * words * 64 * 4) + 4 * al((size_t)np * 4) + al(sort_tmp_n) +
+                 al((size_t)nplan * np * 8) + al((size_t)np * 32);
+        };
+        if (fixed + grows(npad) > e->nn16_bytes) {
+          const size_t room = fixed + grows(nres);
+          if (e->d_nn16) HIP_TRY(hipFree(e->d_nn16));
+          e->d_nn16 = nullptr; e->nn16_bytes = 0;
+          HIP_TRY(hipMalloc(&e->d_nn16, room));
+          e->nn16_bytes = room;
+        }
+        char *at = (char *)e->d_nn16;
+        auto take = [&](size_t b) { char *p = at; at += b; return p; };
+        xbits = (unsigned *)take(256);
+        unsigned *mm = (unsigned *)take(256);
+        NncPlan *plan = (NncPlan *)take(512);
+        uint4 *q16u = (uint4 *)take(b_q16), *q16 = (uint4 *)take(b_q16);
+        float *qnu = (float *)take(b_qn), *qn = (float *)take(b_qn);
+        double *queries_s = (double *)take(b_qs), *bound2_s = (double *)take(b_b2);
+        float *qf = (float *)take(b_qf);
+        unsigned *kq_in = (unsigned *)take(b_k), *kq_out = (unsigned *)take(b_k);
+        int32_t *pq_in = (int32_t *)take(b_k), *perm_q = (int32_t *)take(b_k);
+        mp_d2 = (double *)take(b_pd);
+        mp_idx = (int32_t *)take(b_pi);
+        void *tmpq = take(b_tmpq);
+        unsigned long long *masks = (unsigned long long *)take(b_masks);
+        float *nbox = (float *)take(al((size_t)16 * nsubp * 4));
+        unsigned *kn_in = (unsigned *)take(al((size_t)npad * 4)), *kn_out = (unsigned *)take(al((size_t)npad * 4));
+        int32_t *pn_in = (int32_t *)take(al((size_t)npad * 4)), *perm_n = (int32_t *)take(al((size_t)npad * 4));
+        void *tmpn = take(al(sort_tmp_n));
+        double *nodes_s = (double *)take(al((size_t)nplan * npad * 8));
+        uint4 *nodes16 = (uint4 *)take(al((size_t)npad * 32));
+        // 1. the nodes along the curve
+        HIP_TRY(hipMemsetAsync(xbits, 0, 12, e->stream));
+        HIP_TRY(hipMemsetAsync(mm, 0xff, 32, e->stream));
+        HIP_TRY(hipMemsetAsync(mm + 8, 0, 32, e->stream));
+        hipLaunchKernelGGL(k_nnc_minmax, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, e->stream, dnodes, n, cap, nplan, mm);
+        hipLaunchKernelGGL(k_nnc_plan, dim3(1), dim3(64), 0, e->stream, (const unsigned *)mm, nplan, plan);
+        hipLaunchKernelGGL(k_nnc_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, dnodes, n, cap, nplan, (const NncPlan *)plan,
+                           kn_in, pn_in);
+        size_t tn = sort_tmp_n;
+        if (rocprim::radix_sort_pairs(tmpn, tn, (const unsigned *)kn_in, kn_out, (const int32_t *)pn_in, perm_n, (size_t)n, 0, kNNCKeyBits,
+                                      e->stream) != hipSuccess)
+          return fail(MJPL_E_HIP, "nearest: sorting the nodes failed");
+        hipLaunchKernelGGL(k_nnc_gather, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, dnodes, cap, (const int32_t *)perm_n, n,
+                           npad, nplan, nodes_s, npad);
+        hipLaunchKernelGGL(k_nnc_boxes, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, e->stream, (const double *)nodes_s, n, npad, nplan, nsub,
+                           nsubp, nbox);
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, (const double *)nodes_s, n, npad, npad, nplan,
+                           0, nodes16, (float *)nullptr, xbits);
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16u, qnu,
+                           xbits);
+        // 2. every query's bound, and where on the curve it was found (wild coordinates: the float64 scan of a sample of the
+        //    callers' rows, as in the plain path; either pair of kernels leaves at once when the other serves the call)
+        const int64_t msample = std::max<int64_t>(32, std::min<int64_t>(e->nn_sample, n / 16 / 32 * 32));
+        const int64_t mstride = std::max<int64_t>(1, n / msample);
+        const int64_t ssplit = std::max<int64_t>(1, std::min<int64_t>((1024 + qblocks - 1) / qblocks, msample / 256));
+        const int64_t schunk = ((msample + ssplit - 1) / ssplit + 31) / 32 * 32;
+        const dim3 gs((unsigned)qblocks, (unsigned)((msample + schunk - 1) / schunk));
+        NnCells sc{};
+        sc.pack_idx = 1;
+        for (sc.idx_shift = 0; (msample >> sc.idx_shift) > 65536; sc.idx_shift++) {}
+        hipLaunchKernelGGL(k_nn_fill_inf, dim3(rgridM), dim3(kBlock), 0, e->stream, seed_d2, M, (const unsigned *)xbits);
+#define MJPL_NNM_CASE(NPV)                                                                                                           \
+        case NPV:                                                                                                                    \
+          hipLaunchKernelGGL((k_nearest_mfma<NPV, true>), gs, dim3(kNNMWaves * 64), 0, e->stream, (const double *)nodes_s, msample, npad,  \
+                             dqueries, M, (const uint4 *)nodes16, (const uint4 *)q16u, (const float *)qnu, (const unsigned *)xbits,  \
+                             schunk, mstride, seed_d2, (int32_t *)nullptr, (double *)nullptr, sc);                                   \
+          break;
+        switch (nplan) {
+          MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7)
+        }
+#undef MJPL_NNM_CASE
+        {
+          const dim3 grid((unsigned)qtiles, (unsigned)((nsamp64 + ch0 - 1) / ch0));
+#define MJPL_NN_CASE(NPV)                                                                                    \
+          case NPV:                                                                                          \
+            hipLaunchKernelGGL(k_nearest_part<NPV>, grid, dim3(kNNThreads), 0, e->stream, dnodes, nsamp64, cap, dqueries, \
+                               M, nplan, ch0, pidx, pd2, stride, (const unsigned *)xbits);                   \
+            break;
+          switch (nplan) {
+            MJPL_NN_CASE(2) MJPL_NN_CASE(3) MJPL_NN_CASE(4) MJPL_NN_CASE(5) MJPL_NN_CASE(6) MJPL_NN_CASE(7)
+          }
+#undef MJPL_NN_CASE
+        }
+        hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)((nsamp64 + ch0 - 1) / ch0), seed_idx,
+                           seed_d2, (const int32_t *)nullptr, (const double *)nullptr, (const unsigned *)xbits);
+        if (have_bound) hipLaunchKernelGGL(k_nnc_bound_min, dim3(rgridM), dim3(kBlock), 0, e->stream, seed_d2, outer_d2, M, (const unsigned *)xbits);
+        // 3. the queries in scan order
+        hipLaunchKernelGGL(k_nnc_query_keys, dim3(rgridM), dim3(kBlock), 0, e->stream, (const double *)seed_d2, M, kq_in, pq_in);
+        size_t tq = sort_tmp_q;
+        if (rocprim::radix_sort_pairs(tmpq, tq, (const unsigned *)kq_in, kq_out, (const int32_t *)pq_in, perm_q, (size_t)M, 0, 16, e->stream) !=
+            hipSuccess)
+          return fail(MJPL_E_HIP, "nearest: sorting the queries failed");
+        hipLaunchKernelGGL(k_nnc_gather_queries, dim3((unsigned)((Mpad + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, dqueries,
+                           (const double *)seed_d2, (const int32_t *)perm_q, M, Mpad, nplan, queries_s, bound2_s, qf);
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, e->stream, (const double *)queries_s, M, M, Mpad, nplan,
+                           1, q16, qn, xbits);
+        // 4. candidates, scan
+        hipLaunchKernelGGL(k_nn_candidates, dim3((unsigned)(Mpad / 128), (unsigned)((nwords + 3) / 4)), dim3(256), 0, e->stream, (const float *)qf,
+                           M, (const float *)nbox, nsub, nsubp, nwords, masks, (const unsigned *)xbits);
+        NnCells cs{};
+        cs.masks = masks; cs.perm_n = perm_n; cs.nsub = nsub; cs.nwords = nwords; cs.spg = spg_words * 64;
+        const dim3 gm((unsigned)qblocks, (unsigned)nsplit);
+#define MJPL_NNM_CASE(NPV)                                                                                                           \
+        case NPV:                                                                                                                    \
+          hipLaunchKernelGGL((k_nearest_mfma<NPV, false, true>), gm, dim3(kNNMWaves * 64), 0, e->stream, (const double *)nodes_s, n, npad, \
+                             (const double *)queries_s, M, (const uint4 *)nodes16, (const uint4 *)q16, (const float *)qn,            \
+                             (const unsigned *)xbits, (int64_t)0, (int64_t)1, bound2_s, mp_idx, mp_d2, cs);                          \
+          break;
+        switch (nplan) {
+          MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7)
+        }
+#undef MJPL_NNM_CASE
+        // 5. wild coordinates: the binary32 screen over the callers' rows; then the answers in the callers' order
+        const int qb32c = kNN32Queries * kNNThreads;
+        const int64_t qt32c = (M + qb32c - 1) / qb32c;
+        int64_t nc32c = std::max<int64_t>(1, (8192 + qt32c - 1) / qt32c);
+        nc32c = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nc32c, (int64_t)maxchunks), n / (8 * kNNThreads)));
+        int64_t ch32c = (n + nc32c - 1) / nc32c;
+        ch32c = (ch32c + kNNThreads - 1) / kNNThreads * kNNThreads;
+        nc32c = (n + ch32c - 1) / ch32c;
+        const dim3 g32c((unsigned)qt32c, (unsigned)nc32c);
+#define MJPL_NN32_CASE(NPV)                                                                                   \
+        case NPV:                                                                                             \
+          hipLaunchKernelGGL(k_nearest_part32<NPV>, g32c, dim3(kNNThreads), 0, e->stream, dnodes, n, cap, dqueries, \
+                             M, ch32c, (const double *)seed_d2, pidx, pd2, (const unsigned *)xbits);          \
+          break;
+        switch (nplan) {
+          MJPL_NN32_CASE(2) MJPL_NN32_CASE(3) MJPL_NN32_CASE(4) MJPL_NN32_CASE(5) MJPL_NN32_CASE(6) MJPL_NN32_CASE(7)
+        }
+#undef MJPL_NN32_CASE
+        hipLaunchKernelGGL(k_nnc_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, (const int32_t *)mp_idx, (const double *)mp_d2, M, mparts,
+                           (const int32_t *)perm_q, dout_idx, dout_dist2, (const unsigned *)xbits, (const int32_t *)pidx, (const double *)pd2,
+                           (int)nc32c);
+        HIP_TRY(hipGetLastError());
+        return MJPL_OK;
+      }
       if (!mfma) {
         scan64(nsamp64, ch0, (nsamp64 + ch0 - 1) / ch0, stride);
         hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)((nsamp64 + ch0 - 1) / ch0), seed_idx,

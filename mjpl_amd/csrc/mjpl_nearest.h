@@ -390,12 +390,29 @@ __device__ __forceinline__ float nn_mfma_threshold(double ref2, double ref, doub
 // distance is a valid one, and the screen's argmin is within its error of the sample's best.
 constexpr int kNNMAhead = 4, kNNMPark = 32;
 
-template <int NP, bool SAMPLE>
+// CELLS (round 6; mjpl_nearest_cells.h): the nodes arrive sorted along a space-filling curve of their
+// cells, so that the kNNCellSub nodes of a "sub-chunk" lie together in a small box; the queries arrive sorted by where on
+// that curve the sample pass found their bound, so that the 128 queries of a wave look at the same part of the tree.  A
+// pass in front of the scan (k_nn_candidates) marks, per wave, the sub-chunks whose box comes within SOME query's bound of
+// that query; the wave scans those and nothing else.  What is skipped holds no node within the bound of any of the wave's
+// queries, so the winners are those of the full scan; equal distances go to the lower node id through the permutation.
+constexpr int kNNCellSub = 256;    // nodes per sub-chunk (a multiple of 32)
+struct NnCells {
+  const unsigned long long *masks; // [waves of 128 sorted queries][nwords]: bit k of word j = sub-chunk 64 j + k is a candidate
+  const int32_t *perm_n;           // sorted position -> node id
+  int nsub, nwords;                // sub-chunks; mask words per wave
+  int spg;                         // sub-chunks per blockIdx.y (a multiple of 64)
+  int pack_idx;                    // (SAMPLE) the low 16 bits of a bound carry the sample position it was found at (scaled by idx_shift)
+  int idx_shift;
+};
+
+template <int NP, bool SAMPLE, bool CELLS = false>
 __global__ void __launch_bounds__(kNNMWaves * 64, 2)
 k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries, int64_t M,
                const uint4 *__restrict__ nodes16, const uint4 *__restrict__ queries16, const float *__restrict__ qnorm,
                const unsigned *__restrict__ xbits, int64_t chunk, int64_t stride, double *__restrict__ bound2,
-               int32_t *__restrict__ pidx, double *__restrict__ pd2) {
+               int32_t *__restrict__ pidx, double *__restrict__ pd2, NnCells cells = NnCells{}) {
+  static_assert(!(SAMPLE && CELLS), "the sample pass is a plain scan");
   static_assert(NP <= kNNMMaxPlan, "seven coordinate slots per half of the operand");
   if (xbits[1] != 0u) return;  // wild coordinates: the binary32 screen (and the float64 sample scan) serve this call
   // a lane's state that the loop itself does not touch lives in LDS (the two accumulator sets, the queries' operands and
@@ -440,7 +457,10 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
       if (q >= M) T[s] = -std::numeric_limits<float>::infinity();
     }
   }
-  const int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  // the node range under the loop: a chunk of the launch -- or (CELLS) one run of sub-chunks after another; parked pairs
+  // count their nodes from glo, the start of everything this workgroup may scan
+  int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  const int64_t glo = CELLS ? (int64_t)blockIdx.y * cells.spg * kNNCellSub : lo;
   const nn_f16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t *mypark = park + (SAMPLE ? 0 : threadIdx.x);
   int parked = 0;
@@ -468,9 +488,12 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
       if (j < parked) {
         const int32_t ent = mypark[j * kThreads];
         const int s = ent & 3;
-        const int64_t node = lo + (int64_t)(ent >> 2);
+        const int64_t node = glo + (int64_t)(ent >> 2);
         const double ex = exact(node, q0 + 32 * s);
-        if (ex < best[s * kThreads]) {
+        bool better = ex < best[s * kThreads];
+        if constexpr (CELLS)  // (sorted rows are not in id order: an equal distance goes to the lower node id)
+          if (ex == best[s * kThreads] && bi[s * kThreads] >= 0) better = cells.perm_n[node] < cells.perm_n[bi[s * kThreads]];
+        if (better) {
           best[s * kThreads] = ex;
           bi[s * kThreads] = (int32_t)node;
           if (ex < ref2[s * kThreads]) { ref2[s * kThreads] = ex; touched |= 1u << s; }
@@ -549,7 +572,7 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
         for (int i = 0; i < 16; i++) {
           const int64_t node = pbase + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (t[i] <= T[s] && node < hi) {
-            mypark[parked * (kNNMWaves * 64)] = (int32_t)(((node - lo) << 2) | s);
+            mypark[parked * (kNNMWaves * 64)] = (int32_t)(((node - glo) << 2) | s);
             parked++;
           }
         }
@@ -557,6 +580,8 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     }
   };
   static_assert(kNNMAhead == 4, "four named registers hold the tiles in flight (an indexed array would live in scratch)");
+  nn_f16 ta[kNNMSets], tb[kNNMSets];
+  auto scan_range = [&]() {  // the screened scan of nodes [lo, hi)
   const int ntile = __builtin_amdgcn_readfirstlane((int)((hi - lo + 31) >> 5));  // (wave-uniform, and told so: a scalar register)
   // tile k of this lane through a buffer descriptor: the chunk's first row in scalar registers, the lane's 32-bit byte
   // offset in ONE vector register, the tile's offset in a scalar one (a 64-bit address per lane was two registers more
@@ -573,7 +598,6 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     return uint4{v[0], v[1], v[2], v[3]};
   };
   uint4 a0 = fetch(0), a1 = fetch(1), a2 = fetch(2), a3 = fetch(3);
-  nn_f16 ta[kNNMSets], tb[kNNMSets];
 #pragma unroll
   for (int s = 0; s < kNNMSets; s++) ta[s] = tb[s] = zero;
   // step k: the instructions of tile k (of a tile of zeros behind the last one) and the folds of tile k - 1
@@ -588,6 +612,30 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     turn(tb, ta, k);
     if (k + 1 <= ntile) turn(ta, tb, k + 1);
   }
+  };  // scan_range
+  if constexpr (!CELLS) {
+    scan_range();
+  } else {
+    // the sub-chunks some query of this wave may have its answer in: one bit each, found beforehand (k_nn_candidates);
+    // runs of consecutive ones are scanned as one range
+    const int wq = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kNNMWaves + w));
+    const unsigned long long *mrow = cells.masks + (int64_t)wq * cells.nwords;
+    const int sc0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * cells.spg);  // (spg: a multiple of 64)
+    const int sc1 = __builtin_amdgcn_readfirstlane(sc0 + cells.spg < cells.nsub ? sc0 + cells.spg : cells.nsub);
+    for (int base = sc0; base < sc1; base += 64) {
+      unsigned long long mask = mrow[base >> 6];
+      while (mask != 0ull) {
+        const int first = (int)__builtin_ctzll(mask);
+        const unsigned long long rest = ~(mask >> first);
+        const int run = rest == 0ull ? 64 - first : (int)__builtin_ctzll(rest);
+        lo = (int64_t)(base + first) * kNNCellSub;
+        hi = (int64_t)(base + first + run) * kNNCellSub;
+        hi = hi < n ? hi : n;
+        scan_range();
+        mask &= (first + run >= 64) ? 0ull : ~((1ull << (first + run)) - 1ull);
+      }
+    }
+  }
   if constexpr (SAMPLE) {
     // one exact distance per lane and set: the bound of its query (the better of the two lanes that share it)
 #pragma unroll
@@ -596,11 +644,21 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
       double ex = kInf;
       const int32_t liked = bi[s * kThreads];
       if (q < M && liked >= 0) ex = exact((int64_t)liked * stride, q);
+      const double own = ex;
       const double other = __shfl_xor(ex, 32);
       ex = other < ex ? other : ex;
       // (the sample may be cut into chunks, blockIdx.y: the smallest of their bounds -- non-negative doubles order like their bits;
       //  k_nn_fill_inf set every bound to +inf before the launch)
-      if (q < M && h == 0) atomicMin(reinterpret_cast<unsigned long long *>(bound2 + q), (unsigned long long)__double_as_longlong(ex));
+      unsigned long long word = (unsigned long long)__double_as_longlong(ex);
+      if (cells.pack_idx) {
+        // (the scan sorts its queries by where along the curve their bound was found: the bound, rounded up to a multiple of
+        //  2^16 ulps -- still the distance to no node nearer than it says -- carries the sample position in its low bits)
+        const int32_t mine = liked >= 0 ? liked : 0;
+        const int32_t theirs = __shfl_xor(mine, 32);
+        const int32_t at = other < own ? theirs : mine;
+        if (ex < kInf) word = ((word + 0xffffull) & ~0xffffull) | (unsigned long long)((unsigned)(at >> cells.idx_shift) & 0xffffu);
+      }
+      if (q < M && h == 0) atomicMin(reinterpret_cast<unsigned long long *>(bound2 + q), word);
     }
   } else {
     work_off();
@@ -609,7 +667,9 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
       const int64_t q = q0 + 32 * s;
       if (q < M) {
         const int64_t at = ((int64_t)blockIdx.y * 2 + h) * M + q;
-        pidx[at] = bi[s * kThreads];
+        int32_t won = bi[s * kThreads];
+        if constexpr (CELLS) won = won >= 0 ? cells.perm_n[won] : won;
+        pidx[at] = won;
         pd2[at] = best[s * kThreads];  // (+inf, -1: nothing within the bound among this lane's rows)
       }
     }

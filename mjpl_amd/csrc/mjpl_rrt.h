@@ -39,15 +39,32 @@ struct RrtAcc {                // nodes accepted during the current extension, a
   int cap;
 };
 
+// Lanes whose chain was capped (mjpl_rrt_desc.max_steps_per_round), one record set per tree: the next time the tree grows
+// such a lane goes on from the node it had reached towards the same target instead of drawing a new one (DESIGN.md
+// section 7; mjpl_amd/planning/parallel_rrt.py: Carry).  flag == nullptr: no cap, nothing is ever carried.
+struct RrtCarry {
+  uint8_t *flag;               // [L] the lane's chain of this tree goes on
+  double *T;                   // [nplan][L] its target
+  int32_t *goal;               // [L] its goal pick (-1: an ordinary sample)
+  int32_t *node;               // [L] the node it had reached: pending index -1 - k until the round's exchange, a node id after
+};
+
 // ----------------------------------------------------------------------------- kernels
 constexpr int kRingStride = 32;  // ints per slot of the pinned counter ring
 
 __global__ void __launch_bounds__(256)
 k_rrt_sample(int L, int nplan, uint64_t key, double pgoal, int grow, int ngoal, const double *__restrict__ lo,
              const double *__restrict__ hi, const double *__restrict__ qinit, const double *__restrict__ goalQ,
-             int64_t goalcap, RrtLanes ln, int32_t *__restrict__ first) {
+             int64_t goalcap, RrtLanes ln, int32_t *__restrict__ first, RrtCarry cy) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= L) return;
+  if (cy.flag && cy.flag[l]) {  // a carried lane: the target and the goal pick of the round it was capped in
+    for (int c = 0; c < nplan; c++) ln.T[(int64_t)c * L + l] = cy.T[(int64_t)c * L + l];
+    const int g = cy.goal[l];
+    if (g >= 0) atomicMin(&first[g], l);  // (among the lanes of one goal it competes like any other)
+    ln.goal[l] = g;
+    return;
+  }
   const uint64_t base = (uint64_t)l * (uint64_t)(nplan + 2);
   const bool biased = rrt_u01(key, base + nplan) <= pgoal;  // rng.random() <= p  (rrt.py:197)
   int g = -1;
@@ -73,7 +90,7 @@ k_rrt_sample(int L, int nplan, uint64_t key, double pgoal, int grow, int ngoal, 
 // extension start: C = node nearest to the target, lane on unless it duplicates a lower biased lane
 __global__ void __launch_bounds__(256)
 k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLanes ln, const int32_t *__restrict__ first,
-            const double *__restrict__ Tgt, int second, int *__restrict__ ctr) {
+            const double *__restrict__ Tgt, int second, int *__restrict__ ctr, RrtCarry cy) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l == 0) { ctr[RC_EDGES] = 0; ctr[RC_ACTIVE] = 0; ctr[RC_ACC] = 0; }  // for the extension's first chunk
   if (l >= L) return;
@@ -83,9 +100,13 @@ k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLane
     on = g < 0 || first[g] == l;
     ln.on[l] = on ? 1 : 0;
   } else {
-    on = ln.on[l] != 0;
+    on = ln.on[l] != 0 && !(cy.flag && cy.flag[l]);  // (a lane carried by the first extension sits the connect phase out)
   }
-  const int nn = ln.near[l];
+  int nn = ln.near[l];
+  if (!second && cy.flag && cy.flag[l]) {  // a carried chain goes on from where it stopped (a lane that lost its goal to a lower one: dropped)
+    if (on) { nn = cy.node[l]; ln.near[l] = nn; }
+    cy.flag[l] = 0;  // (consumed: k_rrt_accept raises it again if the chain is capped again)
+  }
   bool same = true;
   for (int c = 0; c < nplan; c++) {
     const double v = Q[(int64_t)c * cap + nn];
@@ -116,7 +137,7 @@ k_rrt_list_begin(int L, RrtLanes ln, int *__restrict__ ctr) {
 // not farther) are made here.  (k_rrt_gen_project below: the same with a PoseConstraint.)
 template <int NP>
 __global__ void __launch_bounds__(256)
-k_rrt_gen(int L, int nplan_arg, int S, double eps, const double *__restrict__ lo,
+k_rrt_gen(int L, int nplan_arg, int S_arg, int max_steps, double eps, const double *__restrict__ lo,
           const double *__restrict__ hi, const double *__restrict__ Tgt, RrtLanes ln, RrtCand cd, int *__restrict__ ctr) {
   // (NP: the number of planning joints as a constant of the instantiation -- the rows below are registers then; with a
   //  run-time count they live in scratch, and a chunk of 512 lanes took 125 us instead of 50)
@@ -124,6 +145,8 @@ k_rrt_gen(int L, int nplan_arg, int S, double eps, const double *__restrict__ lo
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool act = l < L && ln.act[l] != 0;
+  // (the cap: no more steps than the lane may still add nodes this round -- at least one: a lane at its cap has been stopped)
+  const int S = (act && max_steps > 0 && max_steps - ln.cnt[l] < S_arg) ? max_steps - ln.cnt[l] : S_arg;
   double T[kRrtMaxPlan], w[kRrtMaxPlan], q[kRrtMaxPlan], d[kRrtMaxPlan];
   if (act)
     for (int c = 0; c < nplan; c++) { T[c] = Tgt[(int64_t)c * L + l]; w[c] = ln.C[(int64_t)c * L + l]; }
@@ -217,7 +240,7 @@ k_rrt_gen(int L, int nplan_arg, int S, double eps, const double *__restrict__ lo
 // accept the leading valid candidates of every lane
 __global__ void __launch_bounds__(256)
 k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restrict__ ctr, int *__restrict__ host_slot, int seq,
-             int next_list) {
+             int next_list, int max_steps, int second, const double *__restrict__ Tgt, RrtCarry cy) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   // The chunk's counts are closed (the generating kernel is through): leave them in the pinned block the host
   // will look at two chunks from now (RC_SIZE ints and a sequence word written last) ...
@@ -286,6 +309,17 @@ k_rrt_accept(int L, int nplan, RrtLanes ln, RrtCand cd, RrtAcc acc, int *__restr
     if (!(a > 0 && !keep)) {  // (else: out of room for accepted nodes, the lane was stopped above)
       if (a < n || ln.gend[l] || arrived) ln.act[l] = 0;
       else still = true;
+    }
+    // the cap: a lane that has added max_steps nodes and is still under way stops for this round.  In the first extension
+    // it is carried -- it sits the connect phase out, and goes on the next time its tree grows -- in the second it just stops
+    if (still && max_steps > 0 && lvl0 + a >= max_steps) {
+      still = false;
+      ln.act[l] = 0;
+      if (!second) {
+        cy.flag[l] = 1;
+        cy.goal[l] = ln.goal[l];
+        for (int c = 0; c < nplan; c++) cy.T[(int64_t)c * L + l] = Tgt[(int64_t)c * L + l];
+      }
     }
   }
   // projecting extensions: the lanes still extending, packed, are the next chunk's rows (next_list: 0 / 1; -1: none kept)
@@ -384,6 +418,14 @@ k_rrt_finish(int L, int nplan, RrtLanes ln, int32_t *__restrict__ ref, double *_
     for (int c = 0; c < nplan; c++) reached[(int64_t)c * L + l] = ln.C[(int64_t)c * L + l];
 }
 
+// the lanes capped in this round's first extension: their last node (a pending index of this rank's block) as a node id
+__global__ void __launch_bounds__(256)
+k_rrt_carry_node(int L, RrtCarry cy, const int32_t *__restrict__ ref, int base) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L || !cy.flag[l]) return;
+  cy.node[l] = base + (-1 - ref[l]);  // (a capped lane added max_steps >= 1 nodes: its reference is a pending one)
+}
+
 __global__ void k_rrt_first_init(int32_t *__restrict__ first, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) first[i] = 0x7fffffff;
@@ -395,7 +437,7 @@ __global__ void __launch_bounds__(256)
 k_rrt_early(int L, int nplan, RrtLanes ln, uint8_t *__restrict__ early, double *__restrict__ reached) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= L) return;
-  early[l] = ln.act[l] == 0 ? 1 : 0;  // (one read: the lanes still extending may change under this kernel, their rows here are never used)
+  early[l] = ln.act[l] == 0 ? 1 : 0;  // (on the extension's own stream, between two chunks: nothing else writes act or C meanwhile)
   for (int c = 0; c < nplan; c++) reached[(int64_t)c * L + l] = ln.C[(int64_t)c * L + l];
 }
 
@@ -437,9 +479,9 @@ k_rrt_near_merge(int L, int room, const uint8_t *__restrict__ early, const int32
 }
 
 __global__ void __launch_bounds__(256)
-k_rrt_connect(int L, int nplan, RrtLanes ln, int *__restrict__ ctr) {
+k_rrt_connect(int L, int nplan, RrtLanes ln, int *__restrict__ ctr, RrtCarry cy) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= L || !ln.on[l]) return;
+  if (l >= L || !ln.on[l] || (cy.flag && cy.flag[l])) return;  // (carried: no connect phase this round)
   bool eq = true;
   for (int c = 0; c < nplan; c++) eq = eq && (ln.RA[(int64_t)c * L + l] == ln.C[(int64_t)c * L + l]);
   if (eq) atomicMin(&ctr[RC_CONN], l);
@@ -535,6 +577,8 @@ struct mjpl_rrt {
   double eps = 0.05, istep = 0, pgoal = 0.05;
   uint64_t seed = 0;
   int ngoal = 0, round = 0;
+  int max_steps = 0;           // most nodes a lane adds per extension (0: no cap); the lanes capped in a tree's first extension are carried
+  RrtCarry carry[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // per tree
   int n[2] = {0, 0};
   double *d_Q[2] = {nullptr, nullptr};
   int32_t *d_parent[2] = {nullptr, nullptr};
@@ -697,7 +741,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     hipLaunchKernelGGL(k_rrt_late_fill, dim3(rgrid(room)), dim3(256), 0, st, L, nplan, room, Tgt, r->d_late_q);
     hipLaunchKernelGGL(k_rrt_late_queries, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, room, r->d_early, r->d_late_pos, Tgt, r->d_late_q,
                        r->d_ctr);
-    HIP_TRY(hipStreamWaitEvent(st, r->ev_near, 0));  // (the look-ups share the engine's scratch: one after the other)
+    HIP_TRY(hipStreamWaitEvent(st, r->ev_near, 0));  // (d_near_e: the early answers, written on the second stream)
     rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, r->d_late_q, room, r->d_late_near, nullptr);
     if (rc != MJPL_OK) return rc;
     hipLaunchKernelGGL(k_rrt_near_merge, dim3(rgrid(L)), dim3(256), 0, st, L, room, r->d_early, r->d_late_pos, r->d_near_e, r->d_late_near,
@@ -718,7 +762,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   const bool projecting = r->pose != nullptr;
   if (projecting) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_LISTN, 0, 2 * sizeof(int), st));  // (both lists of the extension: empty)
   hipLaunchKernelGGL(k_rrt_begin, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->d_Q[t], r->cap, r->ln, r->d_first, Tgt,
-                     second, r->d_ctr);
+                     second, r->d_ctr, r->carry[second ? 1 - t : t]);  // (the records of the tree that grows this round)
   if (projecting) hipLaunchKernelGGL(k_rrt_list_begin, dim3(rgrid(L)), dim3(256), 0, st, L, r->ln, r->d_ctr);
   // (without a projection: four steps per lane in the first chunk of a big batch, doubling; a small batch -- a planner of
   //  a few hundred lanes -- starts with as many as 2^16 candidate slots allow, up to 64: its chunks cost their launches'
@@ -749,9 +793,11 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   // which lanes are through
   auto start_tail_lookups = [&](int active) -> int {
     if (second || !r->early_nn || r->early_on || active > r->early_lanes || r->n[1 - t] < r->early_min_nodes) return MJPL_OK;
+    // (the snapshot of who is through, and of what they reached, is taken on the MAIN stream, between two chunks: on the
+    //  second stream it would read act / C while a later chunk's acceptance kernel writes them)
+    hipLaunchKernelGGL(k_rrt_early, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->d_early, r->d_RAe);
     HIP_TRY(hipEventRecord(r->ev_tail, st));
     HIP_TRY(hipStreamWaitEvent(r->side, r->ev_tail, 0));
-    hipLaunchKernelGGL(k_rrt_early, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan, r->ln, r->d_early, r->d_RAe);
     int nrc = rrt_side_nearest(r, r->d_Q[1 - t], r->n[1 - t], r->d_RAe, L, r->d_near_e, nullptr);
     if (nrc != MJPL_OK) return nrc;
     HIP_TRY(hipEventRecord(r->ev_near, r->side));
@@ -763,7 +809,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
       hipLaunchKernelGGL(k_rrt_first_init, dim3(rgrid(nf)), dim3(256), 0, r->side, r->d_first_n, nf);
       hipLaunchKernelGGL(k_rrt_sample, dim3(rgrid(L)), dim3(256), 0, r->side, L, nplan,
                          rrt_key(r->seed, (uint64_t)rrt_rank(r), (uint64_t)(r->round + 1)), r->pgoal, 1 - t, r->ngoal, r->d_lo, r->d_hi,
-                         r->d_qinit, r->d_Q[1], r->cap, lnn, r->d_first_n);
+                         r->d_qinit, r->d_Q[1], r->cap, lnn, r->d_first_n, r->carry[1 - t]);
       nrc = rrt_side_nearest(r, r->d_Q[1 - t], r->n[1 - t], r->d_Tn, L, r->d_pre_idx, r->d_pre_d2);
       if (nrc != MJPL_OK) return nrc;
       HIP_TRY(hipEventRecord(r->ev_pre, r->side));
@@ -774,6 +820,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     return MJPL_OK;
   };
   int active_bound = L;  // (projecting) no more lanes than this are active in the chunk about to be launched
+  int steps_done = 0;    // (projecting) steps per lane of the chunks launched so far
   int trace_G = 0;
   unsigned trace_grid = 0;
   for (int chunk = 0;; chunk++) {
@@ -810,6 +857,8 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
       // speculation costs slots (S per lane) and nothing else: a lane that stops early stops generating.
       S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(r->proj_steps_max, r->proj_slots / std::max(1, active_bound)),
                                                       (int64_t)r->cd.cap / std::max(1, active_bound)));
+      // the cap: a lane still extending has added every step of every chunk so far (any other outcome ended it)
+      if (r->max_steps > 0) S = std::min(S, std::max(1, r->max_steps - steps_done));
       {
         // The chunk's rows are the packed list chunk & 1 (at most active_bound entries).  A model's library walks them
         // with waves that refill (mjpl_rows.h): one lane per row while there are many, four or eight lanes per row once
@@ -861,7 +910,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
 #undef MJPL_GEN_CASE
           default: break;
         }
-        hipLaunchKernelGGL(gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->eps, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
+        hipLaunchKernelGGL(gen, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, S, r->max_steps, r->eps, r->d_lo, r->d_hi, Tgt, r->ln, r->cd, r->d_ctr);
       }
       if ((rc = rrt_read_ctr(r)) != MJPL_OK) return rc;
       if (r->h_ctr[RC_OVERFLOW] & 2) return fail(MJPL_E_CAPACITY, "rrt: more new nodes in one extension than the pending slab holds");
@@ -887,7 +936,8 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     if (rc != MJPL_OK) return rc;
     hipLaunchKernelGGL(k_rrt_accept, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->cd, r->acc, r->d_ctr,
                        projecting ? r->h_ring + (chunk % 4) * kRingStride : (int *)nullptr, r->ring_seq0 + chunk,
-                       projecting ? ((chunk + 1) & 1) : -1);
+                       projecting ? ((chunk + 1) & 1) : -1, r->max_steps, second, Tgt, r->carry[t]);
+    steps_done += S;
     if (projecting) tr.chunk(st, chunk, active_bound, S, trace_G, trace_grid);
     // chunk sizes double: a chain of n steps costs O(log n) chunks and at most 2x its own checks
     if (!projecting && S < 64) {
@@ -1046,6 +1096,12 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   RA(r->d_ctr, RC_SIZE); RA(r->d_heads, 8 * 1024); RA(r->d_path, (size_t)nplan * 65536);
   RA(r->d_first, 1);  // re-allocated by reset for the number of goals
   RA(r->d_scan, (size_t)(L + kScanBlock - 1) / kScanBlock);
+  if (d->max_steps_per_round < 0) return fail(MJPL_E_ARG, "`max_steps_per_round` must be >= 0 (0: no cap)");
+  r->max_steps = d->max_steps_per_round;
+  if (r->max_steps > 0)
+    for (int t = 0; t < 2; t++) {
+      RA(r->carry[t].flag, L); RA(r->carry[t].T, (size_t)nplan * L); RA(r->carry[t].goal, L); RA(r->carry[t].node, L);
+    }
   if (const char *v = getenv("MJPL_RRT_EXACT_COUNTS")) r->exact_counts = atoi(v) != 0 ? 1 : 0;
   if (const char *v = getenv("MJPL_RRT_EARLY_NN")) r->early_nn = atoi(v) != 0 ? 1 : 0;
   if (const char *v = getenv("MJPL_RRT_EARLY_LANES")) r->early_lanes = std::max(1, atoi(v));
@@ -1106,6 +1162,8 @@ int mjpl_rrt_reset(mjpl_rrt *r, const double *q_init, const double *q_goals, int
   HIP_TRY(hipMemcpy(r->d_parent[1], minus.data(), ngoal * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(r->d_qinit, q_init, nplan * sizeof(double), hipMemcpyHostToDevice));
   if (r->side) HIP_TRY(hipStreamSynchronize(r->side));
+  for (int t = 0; t < 2; t++)
+    if (r->carry[t].flag) HIP_TRY(hipMemset(r->carry[t].flag, 0, (size_t)r->L));
   r->pre_round = 0;
   r->early_on = false;
   if (ngoal > r->first_cap) {
@@ -1158,13 +1216,13 @@ int rrt_begin(mjpl_rrt *r, int32_t request_stop) {
     const int nf = std::max(r->ngoal, 1);
     hipLaunchKernelGGL(k_rrt_round_init, dim3(rgrid(std::max(nf, (int)RC_SIZE))), dim3(256), 0, st, r->d_ctr, r->d_first, nf);
     hipLaunchKernelGGL(k_rrt_sample, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, rrt_key(r->seed, (uint64_t)rank, (uint64_t)r->round), r->pgoal,
-                       grow, r->ngoal, r->d_lo, r->d_hi, r->d_qinit, r->d_Q[1], r->cap, r->ln, r->d_first);
+                       grow, r->ngoal, r->d_lo, r->d_hi, r->d_qinit, r->d_Q[1], r->cap, r->ln, r->d_first, r->carry[grow]);
   }
   int newA = 0, newB = 0;
   int rc = rrt_extend(r, grow, r->ln.T, 0, &newA);
   if (rc == MJPL_OK) rc = rrt_extend(r, other, r->ln.RA, 1, &newB);
   if (rc == MJPL_OK) {
-    hipLaunchKernelGGL(k_rrt_connect, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->d_ctr);
+    hipLaunchKernelGGL(k_rrt_connect, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->d_ctr, r->carry[grow]);
     hipLaunchKernelGGL(k_rrt_header, dim3(1), dim3(1), 0, st, r->ln, r->d_ctr, grow, request_stop ? 1 : 0, r->d_heads + 8 * rank);
     if (hipGetLastError() != hipSuccess) rc = fail(MJPL_E_HIP, "rrt: a kernel of the round failed to launch");
   }
@@ -1217,6 +1275,8 @@ int rrt_finish(mjpl_rrt *r, const int *heads, const char *const allQ[2], const c
     for (int k = 0; k < world; k++) {
       const int cnt = heads[8 * k + pass];
       if (k == win_rank) (pass == 0 ? baseA_of_winner : baseB_of_winner) = base;
+      if (k == rank && pass == 0 && r->max_steps > 0)
+        hipLaunchKernelGGL(k_rrt_carry_node, dim3(rgrid(r->L)), dim3(256), 0, st, r->L, r->carry[grow], r->ln.refA, base);
       if (cnt > 0) {
         if (!allQ[pass] || !allP[pass]) return fail(MJPL_E_ARG, "rrt: no gathered slab for pass %d", pass);
         hipLaunchKernelGGL(k_rrt_merge, dim3(rgrid(cnt)), dim3(256), 0, st, cnt, nplan, (const double *)(allQ[pass] + (size_t)k * rowb),

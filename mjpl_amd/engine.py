@@ -85,7 +85,7 @@ class RrtDesc(C.Structure):
     _fields_ = [
         ("lanes", C.c_int32), ("capacity", C.c_int64), ("epsilon", C.c_double), ("interval_step", C.c_double),
         ("goal_bias", C.c_double), ("seed", C.c_uint64), ("lo", _F64P), ("hi", _F64P), ("pose", C.c_void_p),
-        ("max_new_per_round", C.c_int64),
+        ("max_new_per_round", C.c_int64), ("max_steps_per_round", C.c_int32),
     ]
 
 
@@ -144,6 +144,8 @@ ABI = {
     "mjpl_pose_valid_dev": (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, _VP]),
     "mjpl_ik_solve": (C.c_int, [_VP, C.POINTER(IKDesc), _F64P, C.c_int64, _F64P, _U8P, _I32P, _F64P]),
     "mjpl_ik_solve_dev": (C.c_int, [_VP, C.POINTER(IKDesc), _VP, C.c_int64, _VP, _VP, _VP, _VP]),
+    "mjpl_set_option": (C.c_int, [_VP, C.c_char_p, C.c_double]),
+    "mjpl_get_option": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_double)]),
     "mjpl_rrt_create": (C.c_int, [_VP, C.POINTER(RrtDesc), C.POINTER(_VP)]),
     "mjpl_rrt_destroy": (None, [_VP]),
     "mjpl_rrt_reset": (C.c_int, [_VP, _F64P, _F64P, C.c_int32, C.c_uint64]),
@@ -421,6 +423,15 @@ class Engine:
         """nearest_dev over nodes [n0, n) behind the answer (dprev_idx, dprev_d2) for the nodes below n0."""
         self._ok(self.lib.mjpl_nearest_range_dev(self.h, dnodes, n0, n, cap, dqueries, m, dout_idx, dout_d2, dprev_idx, dprev_d2))
 
+    def set_option(self, name: str, value) -> None:
+        """A switch of the library by name (include/mjpl_hip.h: mjpl_set_option; the table is in tools/README.md)."""
+        self._ok(self.lib.mjpl_set_option(self.h, name.encode(), float(value)))
+
+    def get_option(self, name: str) -> float:
+        v = C.c_double(0.0)
+        self._ok(self.lib.mjpl_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def nearest_last_screen(self) -> int:
         """0: plain float64 scan, 1: binary32 screen, 2: matrix-core (binary16) screen -- of the last nearest_dev."""
         return int(self.lib.mjpl_nearest_last_screen(self.h))
@@ -581,7 +592,7 @@ class DeviceRRT:
     Batches are over the engine's planning columns, so call ``Engine.set_planning`` first."""
 
     def __init__(self, eng: Engine, lanes: int, capacity: int, lo, hi, epsilon=0.05, interval_step=None,
-                 goal_bias=0.05, seed=0, pose: PoseProjector | None = None, max_new_per_round=0):
+                 goal_bias=0.05, seed=0, pose: PoseProjector | None = None, max_new_per_round=0, max_steps_per_round=0):
         self.eng, self.nplan, self.lanes = eng, eng.nplan, int(lanes)
         lo, hi = _f64(lo), _f64(hi)
         if lo.shape != (self.nplan,) or hi.shape != (self.nplan,):
@@ -593,6 +604,7 @@ class DeviceRRT:
         d.lo, d.hi = lo.ctypes.data_as(_F64P), hi.ctypes.data_as(_F64P)
         d.pose = pose.h if pose is not None else None
         d.max_new_per_round = int(max_new_per_round)
+        d.max_steps_per_round = int(max_steps_per_round)
         self._pose = pose  # keep the handle alive
         self.h = None
         h = _VP()

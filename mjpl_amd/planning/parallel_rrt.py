@@ -57,28 +57,49 @@ def rrt_u01(key, ctr) -> np.ndarray:
     return (x >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
 
 
-def sample_targets(key, lanes: int, lo, hi, p_goal: float, grow: int, q_init, goals):
+def sample_targets(key, lanes: int, lo, hi, p_goal: float, grow: int, q_init, goals, carry=None):
     """Targets of one round: (T [L, n], on bool[L]).  Lane l uses counters l * (n + 2) + {0..n-1}
     for its columns, + n for the goal-bias draw (biased iff u <= p, rrt.py:197) and + n + 1 for the
-    goal pick (rrt.py:201-203).  Of the biased lanes that share a target only the lowest is on."""
+    goal pick (rrt.py:201-203).  Of the biased lanes that share a target only the lowest is on.
+    `carry` (or None): a :class:`Carry` of the tree that grows -- a carried lane keeps the target (and
+    the goal pick) of the round it was capped in instead of this round's draws; among the lanes of one
+    goal it competes like any other."""
     n = len(lo)
     base = np.arange(lanes, dtype=np.uint64) * np.uint64(n + 2)
     cols = rrt_u01(key, base[:, None] + np.arange(n, dtype=np.uint64)[None, :])
     T = lo[None, :] + cols * (hi - lo)[None, :]
     biased = rrt_u01(key, base + np.uint64(n)) <= p_goal
+    if grow == 0:
+        g = np.minimum((rrt_u01(key, base + np.uint64(n + 1)) * len(goals)).astype(np.int64), len(goals) - 1)
+        T[biased] = goals[g[biased]]
+    else:
+        g = np.zeros(lanes, np.int64)
+        T[biased] = q_init
+    g = np.where(biased, g, -1)
+    if carry is not None and carry.flag.any():
+        c = carry.flag
+        T[c] = carry.T[c]
+        g[c] = carry.goal[c]
     on = np.ones(lanes, bool)
-    if biased.any():
-        if grow == 0:
-            g = np.minimum((rrt_u01(key, base + np.uint64(n + 1)) * len(goals)).astype(np.int64), len(goals) - 1)
-            T[biased] = goals[g[biased]]
-        else:
-            g = np.zeros(lanes, np.int64)
-            T[biased] = q_init
-        idx = np.flatnonzero(biased)
+    idx = np.flatnonzero(g >= 0)
+    if len(idx):
         _, first = np.unique(g[idx], return_index=True)
         on[idx] = False
         on[idx[first]] = True
+    if carry is not None:
+        return T, on, g
     return T, on
+
+
+class Carry:
+    """Lanes of one tree whose chain was capped (`max_steps_per_round`): they go on, the next time their
+    tree grows, towards the same target from the node they had reached."""
+
+    def __init__(self, lanes: int, n: int):
+        self.flag = np.zeros(lanes, bool)
+        self.T = np.zeros((lanes, n))
+        self.goal = np.full(lanes, -1, np.int64)
+        self.node = np.zeros(lanes, np.int64)  # node id in the tree (global: the same on every rank)
 
 
 def row_norm(d: np.ndarray) -> np.ndarray:
@@ -390,9 +411,18 @@ class ParallelBiRRT(_PlannerBase):
     def __init__(self, model, planning_joints: list[str], validator: EdgeValidator, q_template: np.ndarray,
                  epsilon: float = 0.05, interval_step: float | None = None, seed: int = 0,
                  goal_biasing_probability: float = 0.05, batch: int = 256, max_rounds: int = 1000,
-                 max_planning_time: float = 10.0, max_new_per_round: int = 1 << 20, group=None):
+                 max_planning_time: float = 10.0, max_new_per_round: int = 1 << 20, group=None,
+                 max_steps_per_round: int = 64):
         super().__init__(model, planning_joints, q_template, epsilon, seed, goal_biasing_probability, batch,
                          max_rounds, max_planning_time)
+        if max_steps_per_round < 0:
+            raise ValueError("`max_steps_per_round` must be >= 0 (0: no cap)")
+        # A lane adds at most this many nodes to a tree per extension (0: as many as its chain has, the
+        # reference's _constrained_extend).  A lane of the growing tree that is still under way then is
+        # CARRIED: it sits out the connect phase, and the next time its tree grows it goes on from the node
+        # it had reached towards the same target instead of drawing a new one.  A connect-phase lane that
+        # is capped just stops.  No round waits for a chain of a thousand steps.
+        self.max_steps = int(max_steps_per_round)
         self.validator = validator
         self.interval_step = interval_step
         self.slab_rows = int(max_new_per_round)
@@ -408,18 +438,24 @@ class ParallelBiRRT(_PlannerBase):
         return np.asarray(self.validator.valid_edges(ends, ends, None), dtype=bool)
 
     # ------------------------------------------------------------------ one extension
-    def _extend(self, t: int, targets: np.ndarray, on: np.ndarray):
+    def _extend(self, t: int, targets: np.ndarray, on: np.ndarray, start=None):
         """Extend tree t towards `targets` on the lanes that are `on`.
-        -> (reached [L, n], ref [L], new rows, new parents): a reference >= 0 is a node id of tree t,
-        < 0 means pending entry -1 - ref of this extension; new nodes are ordered (lane, level)."""
+        -> (reached [L, n], ref [L], new rows, new parents, capped bool[L]): a reference >= 0 is a node id
+        of tree t, < 0 means pending entry -1 - ref of this extension; new nodes are ordered (lane, level).
+        `start` (or None): (mask, node ids) -- those lanes start at the given node instead of the nearest.
+        capped: the lane added `max_steps` nodes and was still under way."""
         nodes = self.trees.nodes(t)
         L = len(targets)
         near = nearest(nodes, targets)
+        if start is not None:
+            near = np.where(start[0], start[1], near)
         cur = nodes[near].copy()
         active = on & ~np.all(cur == targets, axis=1)
         project = getattr(self.validator, "project", None)
         acc_rows, acc_lane, acc_level = [], [], []
         cnt = np.zeros(L, np.int64)
+        capped = np.zeros(L, bool)
+        cap = self.max_steps if self.max_steps > 0 else None
 
         def gen(a, walk):
             d = targets[a] - walk
@@ -437,12 +473,13 @@ class ParallelBiRRT(_PlannerBase):
 
         if project is None:
             # nothing projects: a lane's candidates do not depend on the verdicts.  Generate every
-            # lane's whole chain, validate all edges in one launch, keep each lane's valid prefix.
+            # lane's whole chain (its first `max_steps` steps), validate all edges in one launch, keep
+            # each lane's valid prefix.
             walk = cur.copy()
             alive = active.copy()
             QA, QB, owner, level = [], [], [], []
             lv = 0
-            while alive.any():
+            while alive.any() and (cap is None or lv < cap):
                 a = np.flatnonzero(alive)
                 q_new, dist, reach = gen(a, walk[a])
                 ok = rules(a, walk[a], q_new, dist)
@@ -462,6 +499,8 @@ class ParallelBiRRT(_PlannerBase):
                 np.minimum.at(first_fail, owner[~valid], level[~valid])
                 keep = level < first_fail[owner]
                 acc_rows, acc_lane, acc_level = [QB[keep]], [owner[keep]], [level[keep]]
+                if cap is not None:  # still walking after `cap` steps, every one of them valid
+                    capped = alive & (first_fail >= cap)
         else:
             while active.any():
                 a = np.flatnonzero(active)
@@ -480,11 +519,16 @@ class ParallelBiRRT(_PlannerBase):
                 cur[a[sel]] = q_new[sel]
                 cnt[a[sel]] += 1
                 active[a[~ok | reach]] = False
+                if cap is not None:
+                    full = active & (cnt >= cap)
+                    capped |= full
+                    active &= ~full
 
         if acc_rows and sum(len(r) for r in acc_rows):
             rows, lane, level = np.concatenate(acc_rows), np.concatenate(acc_lane), np.concatenate(acc_level)
             order = np.lexsort((level, lane))  # lanes ascending, levels ascending within a lane
             rows, lane, level = rows[order], lane[order], level[order]
+            self.longest_chain = max(self.longest_chain, int(level.max()) + 1)  # (statistics: most nodes a lane added in one extension)
             pos = np.arange(len(rows))
             parents = np.where(level == 0, near[lane], -pos)  # -1 - (pos - 1)
             reached = cur.copy()
@@ -492,8 +536,8 @@ class ParallelBiRRT(_PlannerBase):
             last = np.flatnonzero(np.r_[lane[1:] != lane[:-1], True])
             reached[lane[last]] = rows[last]
             ref[lane[last]] = -1 - pos[last]
-            return reached, ref, rows, parents
-        return cur, near.copy(), np.empty((0, targets.shape[1])), np.empty(0, np.int64)
+            return reached, ref, rows, parents, capped
+        return cur, near.copy(), np.empty((0, targets.shape[1])), np.empty(0, np.int64), capped
 
     # ------------------------------------------------------------------ exchange
     def _allgather(self, arr: np.ndarray) -> np.ndarray:
@@ -509,13 +553,23 @@ class ParallelBiRRT(_PlannerBase):
         t0 = time.time()
         winner = None
         rounds = 0
+        carry = [Carry(self.batch, n), Carry(self.batch, n)]  # per tree: the lanes whose chains go on
+        self.carried = []  # (per round: how many lanes went on from a carried chain -- tests, statistics)
+        self.longest_chain = 0
         for rounds in range(1, self.max_rounds + 1):
             grow = (rounds - 1) % 2  # tree swap every round (rrt.py:234-235)
             other = 1 - grow
             key = rrt_key(self.seed, self.rank, rounds)
-            T, on = sample_targets(key, self.batch, self.lo, self.hi, self.p_goal, grow, a, goals)
-            RA, refA, rowsA, parA = self._extend(grow, T, on)
-            RB, refB, rowsB, parB = self._extend(other, RA, on)
+            cg = carry[grow]
+            T, on, goal = sample_targets(key, self.batch, self.lo, self.hi, self.p_goal, grow, a, goals, carry=cg)
+            took = cg.flag & on  # (a carried lane that lost its goal to a lower lane is dropped)
+            self.carried.append(int(took.sum()))
+            RA, refA, rowsA, parA, capped = self._extend(grow, T, on, start=(took, cg.node))
+            cg.flag = capped
+            cg.T[capped], cg.goal[capped] = T[capped], goal[capped]
+            cg.node[capped] = refA[capped]  # (pending: made a node id below, once this rank's block has its base)
+            on = on & ~capped               # carried lanes sit the connect phase out
+            RB, refB, rowsB, parB, _ = self._extend(other, RA, on)
             hit = np.flatnonzero(on & np.all(RA == RB, axis=1))
             head = np.zeros(8, np.int64)
             head[:3] = len(rowsA), len(rowsB), INT_MAX
@@ -544,6 +598,9 @@ class ParallelBiRRT(_PlannerBase):
                         bases[t] = base
                     p = slabs[k, :cnt, n].astype(np.int64)
                     self.trees.append(t, slabs[k, :cnt, :n], np.where(p >= 0, p, base + (-1 - p)))
+                    if k == self.rank and which == 0:  # this rank's capped lanes: their last nodes' ids
+                        c = carry[grow].flag
+                        carry[grow].node[c] = base + (-1 - carry[grow].node[c])
                 bases.setdefault(t, self.trees.n[t])
             if win_rank >= 0:
                 ra, rb = int(heads[win_rank, 3]), int(heads[win_rank, 4])
@@ -580,7 +637,7 @@ class DeviceBiRRT(_PlannerBase):
     def __init__(self, model, planning_joints: list[str], collision, q_template: np.ndarray, epsilon: float = 0.05,
                  interval_step: float | None = None, seed: int = 0, goal_biasing_probability: float = 0.05,
                  batch: int = 4096, max_rounds: int = 1000, max_planning_time: float = 10.0, capacity: int = 1 << 20,
-                 pose=None, comm=None, group=None, max_new_per_round: int = 0):
+                 pose=None, comm=None, group=None, max_new_per_round: int = 0, max_steps_per_round: int = 64):
         super().__init__(model, planning_joints, q_template, epsilon, seed, goal_biasing_probability, batch,
                          max_rounds, max_planning_time)
         from .. import engine as _engine
@@ -602,7 +659,8 @@ class DeviceBiRRT(_PlannerBase):
             eng.comm_init(uid, self.rank, self.world)
         self.rrt = _engine.DeviceRRT(eng, self.batch, capacity, self.lo, self.hi, epsilon=self.eps,
                                      interval_step=interval_step, goal_bias=self.p_goal, seed=self.seed,
-                                     pose=None if pose is None else pose._proj, max_new_per_round=max_new_per_round)
+                                     pose=None if pose is None else pose._proj, max_new_per_round=max_new_per_round,
+                                     max_steps_per_round=max_steps_per_round)
 
     def _valid_ends(self, ends):
         self.collision._ensure_planning()

@@ -124,9 +124,13 @@ def test_bits_output_matches_bytes():
     np.testing.assert_array_equal(bits.astype(np.uint8), want)
 
 
-def test_nearest_neighbour_kernel():
+@pytest.mark.parametrize("cells", [1, 0])
+def test_nearest_neighbour_kernel(cells):
+    """(cells: the cell-ordered scan of big trees, mjpl_nearest_cells.h -- on by default -- or the full scan; the answers
+    are the same, bit for bit)"""
     m = scenes.franka_p()
     e = eng_mod.Engine(m)
+    e.set_option("nn_cells", cells)
     qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
     e.set_planning(qidx, m.keyframe("home").qpos)
     rng = np.random.default_rng(4)
@@ -208,7 +212,7 @@ def test_nearest_neighbour_kernel():
     for env_on in (True, False):
         e.nearest_dev(dn3.ptr, n3, n3, dq3.ptr, M3, di3.ptr, dd3.ptr)
         got4, gd4 = di3.download(np.int32, M3), dd3.download(np.float64, M3)
-        assert e.nearest_last_screen() == 2
+        assert e.nearest_last_screen() == 2 and e.get_option("nn_last_cells") == cells
         for lo in range(0, len(sel), 100):
             js = sel[lo:lo + 100]
             s3 = np.zeros((len(js), n3))
@@ -226,8 +230,9 @@ def test_nearest_neighbour_kernel():
         dn3, dq3 = e.alloc(nodes3.nbytes).upload(nodes3), e.alloc(q3.nbytes).upload(q3)
 
 
+@pytest.mark.parametrize("cells", [1, 0])
 @pytest.mark.parametrize("scale,screen", [(30.0, 2), (96.0, 2), (110.0, 1), (250.0, 1)])
-def test_nearest_neighbour_large_coordinates(scale, screen):
+def test_nearest_neighbour_large_coordinates(scale, screen, cells):
     """Coordinates below the 256 limit of the matrix-core screen but whose squared norms leave binary16's range
     (65504: seven coordinates of 97, one of 256): the node norm travels as two binary16 numbers, and a node beyond
     that range would turn into inf - inf = NaN inside the instruction and never pass the screen.  Such a call
@@ -235,6 +240,7 @@ def test_nearest_neighbour_large_coordinates(scale, screen):
     m = scenes.franka_p()
     e = eng_mod.Engine(m)
     e.set_planning(scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos)
+    e.set_option("nn_cells", cells)
     rng = np.random.default_rng(int(scale))
     n, M = 270000, 16400
     nodes = rng.uniform(0.3 * scale, scale, size=(7, n)) * rng.choice([-1.0, 1.0], size=(7, n))
@@ -264,6 +270,7 @@ def test_nearest_neighbour_matrix_core_screen_for_other_planning_sets(nplan):
     e = eng_mod.Engine(m)
     qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)[:nplan]
     e.set_planning(qidx, m.keyframe("home").qpos)
+    assert e.get_option("nn_cells") == 1  # (the default: the cell-ordered scan)
     rng = np.random.default_rng(40 + nplan)
     n, M = 280000 + 17 * nplan, 16384 + 5 * nplan
     nodes = rng.uniform(-2.9, 2.9, size=(nplan, n))
@@ -274,7 +281,7 @@ def test_nearest_neighbour_matrix_core_screen_for_other_planning_sets(nplan):
     dn, dq = e.alloc(nodes.nbytes).upload(nodes), e.alloc(qs.nbytes).upload(qs)
     di, dd = e.alloc(4 * M), e.alloc(8 * M)
     e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
-    assert e.nearest_last_screen() == 2
+    assert e.nearest_last_screen() == 2 and e.get_option("nn_last_cells") == 1
     got, gd = di.download(np.int32, M), dd.download(np.float64, M)
     sel = np.concatenate([np.arange(0, 64), rng.integers(64, M, 200)])
     s = np.zeros((len(sel), n))
@@ -444,8 +451,9 @@ def test_far_from_the_origin_the_filter_steps_aside(oracle_mod, moving_boxes):
     assert e0.last_undecided() < len(Q) // 4
 
 
+@pytest.mark.parametrize("cells_min", [131072, 16384])
 @pytest.mark.parametrize("n0,n,M", [(200000, 300000, 16500), (290000, 300100, 4200), (300000, 300000, 4100), (0, 270000, 5000), (1000, 9000, 700)])
-def test_nearest_neighbour_over_a_node_range_behind_an_earlier_answer(n0, n, M):
+def test_nearest_neighbour_over_a_node_range_behind_an_earlier_answer(n0, n, M, cells_min):
     """mjpl_nearest_range_dev: a tree that was scanned when it had n0 nodes has n now; scanning [n0, n) behind the earlier
     answer must give the whole scan's winners and distances -- also where a new node ties an old one exactly (the old, lower
     index wins) and where an old node ties a new one (ditto), with the earlier distances as every query's screen bound (no
@@ -453,6 +461,7 @@ def test_nearest_neighbour_over_a_node_range_behind_an_earlier_answer(n0, n, M):
     m = scenes.franka_p()
     e = eng_mod.Engine(m)
     e.set_planning(scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos)
+    e.set_option("nn_cells_min_nodes", cells_min)  # (16 384: the range of 100 000 new nodes takes the cell-ordered scan as well)
     rng = np.random.default_rng(n0 + n + M)
     cap = n + 77
     nodes = np.zeros((7, cap))
@@ -488,7 +497,8 @@ def test_nearest_neighbour_over_a_node_range_behind_an_earlier_answer(n0, n, M):
     e.close()
 
 
-def test_nearest_neighbour_in_a_dense_tree():
+@pytest.mark.parametrize("cells", [1, 0])
+def test_nearest_neighbour_in_a_dense_tree(cells):
     """Queries that lie ON a dense tree (the connect phase of a search that has filled its manifold): 300 000 nodes on a
     two-dimensional sheet in the seven joints, a few thousandths of a radian apart, queries = nodes, nodes moved by 1e-4,
     and points between them.  Thousands of nodes are within the screen's arithmetic allowance of every query's best -- the
@@ -496,6 +506,7 @@ def test_nearest_neighbour_in_a_dense_tree():
     m = scenes.franka_p()
     e = eng_mod.Engine(m)
     e.set_planning(scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos)
+    e.set_option("nn_cells", cells)
     rng = np.random.default_rng(77)
     n, M = 300000, 8192
     u, v = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
@@ -510,7 +521,7 @@ def test_nearest_neighbour_in_a_dense_tree():
     dn, dq = e.alloc(nodes.nbytes).upload(nodes), e.alloc(qs.nbytes).upload(qs)
     di, dd = e.alloc(4 * M), e.alloc(8 * M)
     e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
-    assert e.nearest_last_screen() == 2
+    assert e.nearest_last_screen() == 2 and e.get_option("nn_last_cells") == cells
     got, gd = di.download(np.int32, M), dd.download(np.float64, M)
     sel = np.concatenate([np.arange(0, 40), M // 3 + np.arange(0, 40), 2 * M // 3 + np.arange(0, 40), rng.integers(0, M, 120)])
     s = np.zeros((len(sel), n))

@@ -85,6 +85,30 @@ def test_device_trees_equal_the_oracle_validated_planner(oracle_mod, seed, batch
     assert any(np.array_equal(got[-1], g) for g in goals)
 
 
+@pytest.mark.parametrize("cap,seed,batch", [(5, 2, 64), (12, 6, 200)])
+def test_capped_chains_carried_into_later_rounds_equal_the_host_planner(oracle_mod, cap, seed, batch):
+    """mjpl_rrt_desc.max_steps_per_round: a lane adds at most `cap` nodes per extension; a lane of
+    the growing tree still under way is carried -- it sits the connect phase out and, the next time its tree grows,
+    goes on from the node it reached towards the same target.  With caps this small most chains are cut and many lanes
+    are carried, over a dozen rounds: the device's trees must still be the NumPy statement's node for node, and the
+    statement must report carried lanes (else the test tests nothing)."""
+    m, joints, qidx, q_init, v, goals = _scene(oracle_mod, seed=seed + 40)
+    kw = dict(epsilon=0.05, interval_step=0.01, seed=seed, goal_biasing_probability=0.1, batch=batch, max_planning_time=300.0,
+              max_steps_per_round=cap)
+    host = pr.ParallelBiRRT(m, joints, v, q_init, **kw)
+    want = host.plan_to_configs(q_init, goals[:2])
+    assert len(want) > 2 and host.stats["rounds"] >= 3 and sum(host.carried) > 0 and host.longest_chain == cap
+    cc = mjpl.CollisionConstraint(m)
+    dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, capacity=1 << 20, **kw)
+    got = dev.plan_to_configs(q_init, goals[:2])
+    assert dev.stats["rounds"] == host.stats["rounds"] and dev.stats["nodes"] == host.stats["nodes"]
+    for t in (0, 1):
+        Q, par = dev.rrt.tree(t)
+        np.testing.assert_array_equal(Q, host.trees.nodes(t))
+        np.testing.assert_array_equal(par, host.trees.parent[t][: host.trees.n[t]])
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
 def test_endpoint_only_validation_and_argument_errors(oracle_mod):
     m, joints, qidx, q_init, v, goals = _scene(oracle_mod, seed=21)
     kw = dict(epsilon=0.07, interval_step=None, seed=4, goal_biasing_probability=0.05, batch=96, max_planning_time=300.0)

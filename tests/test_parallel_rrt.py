@@ -186,19 +186,44 @@ def test_thread_group_multi_round_and_rank_one_winner():
     """Lanes few enough that the search takes several rounds; seeds chosen so that rank 1 holds the
     connecting lane and that a rank contributes an empty slab to a round."""
     from mjpl_amd.planning.parallel_rrt import INT_MAX, ThreadGroup
-    seen = []
-    for seed, batch in ((1, 4), (11, 2)):
+    seen, carried = [], []
+    for seed, batch in ((26, 4), (26, 2)):
         def one(rank, member):
             m, qidx, v, p, q_init, g = _make(world_group=member, seed=seed, batch=batch)
             path = p.plan_to_config(q_init, g)
             _check_path(m, qidx, v, path, q_init, g)
-            return np.array(path).tobytes(), tuple(p.trees.n), p.stats["rounds"], p.stats["win_rank"], p.stats["last_heads"]
+            return (np.array(path).tobytes(), tuple(p.trees.n), p.stats["rounds"], p.stats["win_rank"], p.stats["last_heads"],
+                    sum(p.carried))
 
         a, b = ThreadGroup(2).run(one)
         assert a[:4] == b[:4] and np.array_equal(a[4], b[4])
         assert a[2] > 1 and a[3] == 1 and a[4][0, 2] == INT_MAX
         seen.append(a[4])
+        carried.append(a[5] + b[5])
     assert (seen[1][:, :2] == 0).any(), "a rank with an empty slab"
+    assert carried[0] > 0, "a search of ten rounds in which some lane's chain went on from the round before last"
+
+
+def test_capped_chains_are_carried_and_the_cap_binds():
+    """`max_steps_per_round`: a lane adds at most that many nodes per extension; a lane of
+    the growing tree still under way is carried -- no connect phase this round, the same target and the node it
+    reached the next time its tree grows.  With a cap of 6 no lane adds more than 6 nodes in
+    an extension; carried lanes appear; the path is valid; and a cap no chain reaches changes nothing."""
+    from mjpl_amd.planning.parallel_rrt import ParallelBiRRT
+    m, qidx, v, p, q_init, g = _make(seed=3, batch=16)
+    kw = dict(epsilon=0.05, interval_step=0.01, seed=3, batch=16, goal_biasing_probability=0.1, max_planning_time=120.0)
+    capped = ParallelBiRRT(m, p.planning_joints, v, q_init, max_steps_per_round=6, **kw)
+    path = capped.plan_to_config(q_init, g)
+    _check_path(m, qidx, v, path, q_init, g)
+    assert sum(capped.carried) > 0 and capped.carried[0] == 0 and capped.carried[1] == 0  # (round 3 is the first to take over lanes)
+    assert capped.longest_chain == 6  # (the cap binds: some chain was cut, none is longer)
+    free = ParallelBiRRT(m, p.planning_joints, v, q_init, max_steps_per_round=0, **kw)
+    loose = ParallelBiRRT(m, p.planning_joints, v, q_init, max_steps_per_round=100000, **kw)
+    pa, pb = free.plan_to_config(q_init, g), loose.plan_to_config(q_init, g)
+    assert sum(loose.carried) == 0 and free.longest_chain == loose.longest_chain > 6 and len(pa) == len(pb) and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    assert free.trees.n == loose.trees.n
+    with pytest.raises(ValueError, match="max_steps_per_round"):
+        ParallelBiRRT(m, p.planning_joints, v, q_init, max_steps_per_round=-1, **kw)
 
 
 def test_projecting_validator_on_the_cpu(oracle_mod):

@@ -6,6 +6,8 @@ cd $GRAFT_REPO_ROOT
 REAL=$(python tools/build_bench_spec.py --path)
 python tools/cert_probe.py 262144 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Lib" > gpurun_out/${TAG}_cert_default_262144.json
 cp $REAL /tmp/real_spec.so
+# (whatever happens below, the library under the production name is the production build again when this script ends)
+trap 'cp /tmp/real_spec.so $REAL' EXIT
 cp variants/spec_${2:-CERT}.so $REAL
 for E in 262144 1048576 4194304; do
   python tools/cert_probe.py $E 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Lib" > gpurun_out/${TAG}_cert_build_$E.json

@@ -4,6 +4,8 @@
 cd $GRAFT_REPO_ROOT
 REAL=$(python tools/build_bench_spec.py --path)
 cp $REAL /tmp/real_spec.so
+# (whatever happens below, the library under the production name is the production build again when this script ends)
+trap 'cp /tmp/real_spec.so $REAL' EXIT
 run() {
   python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-variants 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  edges', d['ms_per_step'], 'ms', d['value'])"
   python bench.py --workload pose --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  pose', d['ms_per_step'], 'ms')"
