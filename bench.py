@@ -584,6 +584,8 @@ def bench_rrt(args, world):
                            batch=L, capacity=args.capacity, pose=pc, comm=(uid, world.rank, world.world))
     world.rccl = True
     world.attach(cc.engine)
+    if os.environ.get("MJPL_RRT_TRACE"):  # (tracing: the look-ups count the pairs that reach their exact evaluation)
+        cc.engine.set_option("nn_probe", 2)
     dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 3)
     info = dev.rrt.round()  # warm-up: the first round grows from two single-node trees
     rows, new_nodes, exch = [], 0, []

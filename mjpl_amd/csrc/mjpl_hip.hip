@@ -340,6 +340,8 @@ struct mjpl_engine {
   int nn_cells = 1;             // the cell-ordered scan for big trees (mjpl_nearest_cells.h); option "nn_cells"
   int64_t nn_cells_min = 131072; // ... from this many nodes on; option "nn_cells_min_nodes"
   int nn_last_cells = 0;        // the last look-up took it
+  int nn_probe = 0;             // (timing only) option "nn_probe"
+  const int32_t *nn_last_count = nullptr; int nn_last_waves = 0, nn_last_nsub = 0;  // the last cell-ordered scan's candidate counts
   int nn_last = 0;              // what the last mjpl_nearest_dev launched: 0 float64 scan, 1 binary32 screen, 2 matrix-core screen (or 1: see its flag)
   size_t uc_cap = 0, uc_cap_limit = 0;
   int nslots = 0, nsave = 0, maxs = 4;
@@ -2221,6 +2223,28 @@ const EngineOption kEngineOptions[] = {
     {"nn_sample", [](mjpl_engine *e) { return (double)e->nn_sample; },
      [](mjpl_engine *e, double v) { if (!(v >= 32 && v < 9e15)) return false; e->nn_sample = std::max<int64_t>(1024, (int64_t)v) / 32 * 32; return true; }},
     {"nn_last_cells", [](mjpl_engine *e) { return (double)e->nn_last_cells; }, nullptr},  // (read-only: the last look-up took the cell-ordered scan)
+    {"nn_probe", [](mjpl_engine *e) { return (double)e->nn_probe; }, [](mjpl_engine *e, double v) { e->nn_probe = (int)v; return true; }},
+    {"nn_last_exact_pairs",  // (read-only; synchronises; counted only with "nn_probe" = 2)
+     [](mjpl_engine *e) {
+       unsigned x[4] = {0, 0, 0, 0};
+       if (!e->d_nn16 || hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(x, e->d_nn16, sizeof(x), hipMemcpyDeviceToHost) != hipSuccess)
+         return -1.0;
+       return (double)x[3];
+     },
+     nullptr},
+    // (read-only; synchronises: the share of the tree's sub-chunks a wave of the last cell-ordered scan had on its list, averaged)
+    {"nn_last_candidate_fraction",
+     [](mjpl_engine *e) {
+       if (!e->nn_last_cells || !e->nn_last_count || e->nn_last_waves < 1 || e->nn_last_nsub < 1) return -1.0;
+       std::vector<int32_t> c((size_t)e->nn_last_waves);
+       if (hipStreamSynchronize(e->stream) != hipSuccess ||
+           hipMemcpy(c.data(), e->nn_last_count, c.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+         return -1.0;
+       double sum = 0;
+       for (int32_t v : c) sum += v;
+       return sum / ((double)c.size() * e->nn_last_nsub);
+     },
+     nullptr},
 };
 #undef MJPL_OPT_BOOL
 }  // namespace
@@ -2379,7 +2403,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
       int mparts = 0;
       const int64_t nsamp64 = std::min<int64_t>(kSampleNodes, n / kNNThreads * kNNThreads);  // (a short range: all of it)
       e->nn_last_cells = 0;
-      if (mfma && e->nn_cells && n >= e->nn_cells_min && n >= 64 * kNNCellSub) {
+      if (mfma && e->nn_cells && n >= e->nn_cells_min && n >= 64 * kNNCellSub && n < ((int64_t)1 << 25)) {
         // ---- the cell-ordered scan (mjpl_nearest_cells.h): nodes sorted along a space-filling curve, queries by where on it
         // their bound was found, a wave scans the sub-chunks some query of it can have its answer in
         e->nn_last_cells = 1;
@@ -2387,9 +2411,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         const int64_t qblocks = Mpad / kNNMQueries;
         const int nsub = (int)(npad / kNNCellSub), nwords = (nsub + 63) / 64, nsubp = nwords * 64;
         // (sub-chunks per workgroup row: whole mask words, ~2 048 workgroups in all, no more rows than words)
-        const int64_t rows_want = std::max<int64_t>(1, std::min<int64_t>((2048 + qblocks - 1) / qblocks, nwords));
-        const int spg_words = (int)((nwords + rows_want - 1) / rows_want);
-        const int nsplit = (nwords + spg_words - 1) / spg_words;
+        const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((4096 + qblocks - 1) / qblocks, nwords));
         mparts = 2 * nsplit;
         // the arena: what grows with the tree last
         auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -2400,14 +2422,15 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
                                         (int32_t *)nullptr, (size_t)nres, 0, kNNCKeyBits, e->stream);
         (void)rocprim::radix_sort_pairs(nullptr, sort_tmp_q, (const unsigned *)nullptr, (unsigned *)nullptr, (const int32_t *)nullptr,
                                         (int32_t *)nullptr, (size_t)M, 0, 16, e->stream);
-        const size_t b_q16 = al((size_t)Mpad * 64), b_qn = al((size_t)Mpad * 4), b_qs = al((size_t)nplan * M * 8), b_b2 = al((size_t)M * 8);
+        const size_t b_q16 = al((size_t)Mpad * 64), b_qn = al((size_t)Mpad * 4), b_qs = al((size_t)8 * M * 8), b_b2 = al((size_t)M * 8);
         const size_t b_qf = al((size_t)Mpad * 32), b_k = al((size_t)M * 4), b_pd = al((size_t)mparts * M * 8), b_pi = al((size_t)mparts * M * 4);
         const size_t b_masks = al((size_t)(Mpad / 128) * nwords * 8), b_tmpq = al(sort_tmp_q);
-        const size_t fixed = 1024 + 2 * b_q16 + 2 * b_qn + b_qs + b_b2 + b_qf + 4 * b_k + b_pd + b_pi + b_tmpq;
-        auto grows = [&](int64_t np) {  // masks, boxes, keys + permutation (in / out), sort space, sorted rows, packed rows
+        const size_t b_cnt = al((size_t)(Mpad / 128) * 4);
+        const size_t fixed = 1024 + 2 * b_q16 + 2 * b_qn + b_qs + b_b2 + b_qf + 4 * b_k + b_pd + b_pi + b_tmpq + b_cnt;
+        auto grows = [&](int64_t np) {  // masks, lists, boxes, keys + permutation (in / out), sort space, sorted rows, packed rows
           const size_t words = (size_t)((np / kNNCellSub + 63) / 64);
-          return al((size_t)(Mpad / 128) * words * 8) + al(16 * words * 64 * 4) + 4 * al((size_t)np * 4) + al(sort_tmp_n) +
-                 al((size_t)nplan * np * 8) + al((size_t)np * 32);
+          return al((size_t)(Mpad / 128) * words * 8) + al((size_t)(Mpad / 128) * words * 64 * 4) + al(16 * words * 64 * 4) +
+                 4 * al((size_t)np * 4) + al(sort_tmp_n) + al((size_t)8 * np * 8) + al((size_t)np * 32);
         };
         if (fixed + grows(npad) > e->nn16_bytes) {
           const size_t room = fixed + grows(nres);
@@ -2430,18 +2453,20 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         mp_d2 = (double *)take(b_pd);
         mp_idx = (int32_t *)take(b_pi);
         void *tmpq = take(b_tmpq);
+        int32_t *ccount = (int32_t *)take(b_cnt);
         unsigned long long *masks = (unsigned long long *)take(b_masks);
+        int32_t *clist = (int32_t *)take(al((size_t)(Mpad / 128) * nsubp * 4));
         float *nbox = (float *)take(al((size_t)16 * nsubp * 4));
         unsigned *kn_in = (unsigned *)take(al((size_t)npad * 4)), *kn_out = (unsigned *)take(al((size_t)npad * 4));
         int32_t *pn_in = (int32_t *)take(al((size_t)npad * 4)), *perm_n = (int32_t *)take(al((size_t)npad * 4));
         void *tmpn = take(al(sort_tmp_n));
-        double *nodes_s = (double *)take(al((size_t)nplan * npad * 8));
+        double *nodes_s = (double *)take(al((size_t)8 * npad * 8));
         uint4 *nodes16 = (uint4 *)take(al((size_t)npad * 32));
         // 1. the nodes along the curve
-        HIP_TRY(hipMemsetAsync(xbits, 0, 12, e->stream));
+        HIP_TRY(hipMemsetAsync(xbits, 0, 16, e->stream));  // ([3]: option "nn_probe" = 2 counts the exact evaluations here)
         HIP_TRY(hipMemsetAsync(mm, 0xff, 32, e->stream));
         HIP_TRY(hipMemsetAsync(mm + 8, 0, 32, e->stream));
-        hipLaunchKernelGGL(k_nnc_minmax, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, e->stream, dnodes, n, cap, nplan, mm);
+        hipLaunchKernelGGL(k_nnc_minmax, dim3((unsigned)((n + 256 * kNNCMinmaxRows - 1) / (256 * kNNCMinmaxRows))), dim3(256), 0, e->stream, dnodes, n, cap, nplan, mm);
         hipLaunchKernelGGL(k_nnc_plan, dim3(1), dim3(64), 0, e->stream, (const unsigned *)mm, nplan, plan);
         hipLaunchKernelGGL(k_nnc_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, dnodes, n, cap, nplan, (const NncPlan *)plan,
                            kn_in, pn_in);
@@ -2450,12 +2475,12 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
                                       e->stream) != hipSuccess)
           return fail(MJPL_E_HIP, "nearest: sorting the nodes failed");
         hipLaunchKernelGGL(k_nnc_gather, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, dnodes, cap, (const int32_t *)perm_n, n,
-                           npad, nplan, nodes_s, npad);
-        hipLaunchKernelGGL(k_nnc_boxes, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, e->stream, (const double *)nodes_s, n, npad, nplan, nsub,
+                           npad, nplan, nodes_s);
+        hipLaunchKernelGGL(k_nnc_boxes, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, e->stream, (const double *)nodes_s, n, nplan, nsub,
                            nsubp, nbox);
-        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, (const double *)nodes_s, n, npad, npad, nplan,
-                           0, nodes16, (float *)nullptr, xbits);
-        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16u, qnu,
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((npad + 256 * kNNPackRows - 1) / (256 * kNNPackRows))), dim3(256), 0, e->stream, (const double *)nodes_s, n, (int64_t)1, npad, nplan,
+                           0, nodes16, (float *)nullptr, xbits, (int64_t)8);
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 256 * kNNPackRows - 1) / (256 * kNNPackRows))), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16u, qnu,
                            xbits);
         // 2. every query's bound, and where on the curve it was found (wild coordinates: the float64 scan of a sample of the
         //    callers' rows, as in the plain path; either pair of kernels leaves at once when the other serves the call)
@@ -2466,6 +2491,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         const dim3 gs((unsigned)qblocks, (unsigned)((msample + schunk - 1) / schunk));
         NnCells sc{};
         sc.pack_idx = 1;
+        sc.node_rows = 1;  // (the sorted nodes: rows of eight; the queries still the callers' columns)
         for (sc.idx_shift = 0; (msample >> sc.idx_shift) > 65536; sc.idx_shift++) {}
         hipLaunchKernelGGL(k_nn_fill_inf, dim3(rgridM), dim3(kBlock), 0, e->stream, seed_d2, M, (const unsigned *)xbits);
 #define MJPL_NNM_CASE(NPV)                                                                                                           \
@@ -2501,13 +2527,16 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
           return fail(MJPL_E_HIP, "nearest: sorting the queries failed");
         hipLaunchKernelGGL(k_nnc_gather_queries, dim3((unsigned)((Mpad + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, dqueries,
                            (const double *)seed_d2, (const int32_t *)perm_q, M, Mpad, nplan, queries_s, bound2_s, qf);
-        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, e->stream, (const double *)queries_s, M, M, Mpad, nplan,
-                           1, q16, qn, xbits);
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 256 * kNNPackRows - 1) / (256 * kNNPackRows))), dim3(256), 0, e->stream, (const double *)queries_s, M, (int64_t)1, Mpad, nplan,
+                           1, q16, qn, xbits, (int64_t)8);
         // 4. candidates, scan
         hipLaunchKernelGGL(k_nn_candidates, dim3((unsigned)(Mpad / 128), (unsigned)((nwords + 3) / 4)), dim3(256), 0, e->stream, (const float *)qf,
                            M, (const float *)nbox, nsub, nsubp, nwords, masks, (const unsigned *)xbits);
+        hipLaunchKernelGGL(k_nn_compact, dim3((unsigned)((Mpad / 128 + 3) / 4)), dim3(256), 0, e->stream, (const unsigned long long *)masks, nwords,
+                           (int)(Mpad / 128), clist, (int64_t)nsubp, ccount, (const unsigned *)xbits);
         NnCells cs{};
-        cs.masks = masks; cs.perm_n = perm_n; cs.nsub = nsub; cs.nwords = nwords; cs.spg = spg_words * 64;
+        cs.list = clist; cs.count = ccount; cs.perm_n = perm_n; cs.list_pitch = nsubp; cs.probe = e->nn_probe; cs.counter = xbits + 3; cs.node_rows = 1; cs.query_rows = 1;
+        e->nn_last_count = ccount; e->nn_last_waves = (int)((M + 127) / 128); e->nn_last_nsub = nsub;
         const dim3 gm((unsigned)qblocks, (unsigned)nsplit);
 #define MJPL_NNM_CASE(NPV)                                                                                                           \
         case NPV:                                                                                                                    \
@@ -2575,9 +2604,9 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         mp_idx = (int32_t *)at; at += (b_pi + 31) / 32 * 32;
         uint4 *nodes16 = (uint4 *)at;
         HIP_TRY(hipMemsetAsync(xbits, 0, 12, e->stream));  // [0] largest coordinate, [1] wild, [2] largest node norm
-        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, dnodes, n, cap, npad, nplan, 0,
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((npad + 256 * kNNPackRows - 1) / (256 * kNNPackRows))), dim3(256), 0, e->stream, dnodes, n, cap, npad, nplan, 0,
                            nodes16, (float *)nullptr, xbits);
-        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16,
+        hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 256 * kNNPackRows - 1) / (256 * kNNPackRows))), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16,
                            qn, xbits);
         // every query's bound: the sample node the screen likes best, its distance exactly (wild coordinates: the
         // float64 scan of the sample as before; either pair of kernels leaves at once when the other serves the call)

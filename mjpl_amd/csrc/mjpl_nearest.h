@@ -296,19 +296,24 @@ constexpr int kNNMMaxPlan = 7;
 constexpr float kNNMWild = 256.0f;
 
 // nodes / queries -> the operand rows, |x~|^2, and X.  Nodes: 32 bytes (k = 0..7 | 8..15); queries: 64 (two columns).
+constexpr int kNNPackRows = 8;  // rows per thread: a launch has ceil(padded / (256 kNNPackRows)) workgroups
 __global__ void __launch_bounds__(256)
 k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int64_t padded, int nplan, int is_query,
-          uint4 *__restrict__ out16, float *__restrict__ nrm, unsigned *__restrict__ xbits) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+          uint4 *__restrict__ out16, float *__restrict__ nrm, unsigned *__restrict__ xbits, int64_t row_stride = 1) {
+  // (coordinate c of row i: src[c * col_stride + i * row_stride] -- columns [nplan][count] by default, rows of eight with (1, 8))
   float mx = 0, n2max = 0;
   bool wild = false;
+  // (kNNPackRows rows per thread: the three atomics at the end are per wave, and with one row per thread a tree of two
+  //  million nodes sent sixty thousand of them to one cache line -- 0.6 ms of a 0.66 ms kernel)
+  for (int rep = 0; rep < kNNPackRows; rep++) {
+  const int64_t i = ((int64_t)blockIdx.x * kNNPackRows + rep) * blockDim.x + threadIdx.x;
   if (i < padded) {
     union { _Float16 h[16]; uint4 u[2]; } hi, lo;
     for (int k = 0; k < 16; k++) { hi.h[k] = (_Float16)0.0f; lo.h[k] = (_Float16)0.0f; }
     float n2 = 0;
     if (i < count) {
       for (int c = 0; c < nplan; c++) {
-        const double v = src[(int64_t)c * col_stride + i];
+        const double v = src[(int64_t)c * col_stride + i * row_stride];
         const float f = (float)v;
         if (v != v) wild = true;
         if (fabs(v) < std::numeric_limits<double>::infinity()) {
@@ -352,7 +357,8 @@ k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int
     }
     if (nrm) nrm[i] = n2;
     // (the largest finite |x~|^2 among the nodes: the screen's arithmetic allowance is taken per query against it, below)
-    if (!is_query && i < count && n2 < std::numeric_limits<float>::infinity()) n2max = n2;
+    if (!is_query && i < count && n2 < std::numeric_limits<float>::infinity()) n2max = fmaxf(n2max, n2);
+  }
   }
   for (int o = 32; o > 0; o >>= 1) n2max = fmaxf(n2max, __shfl_xor(n2max, o));
   if ((threadIdx.x & 63) == 0 && n2max > 0) atomicMax(&xbits[2], __float_as_uint(n2max));
@@ -398,10 +404,14 @@ constexpr int kNNMAhead = 4, kNNMPark = 32;
 // queries, so the winners are those of the full scan; equal distances go to the lower node id through the permutation.
 constexpr int kNNCellSub = 256;    // nodes per sub-chunk (a multiple of 32)
 struct NnCells {
-  const unsigned long long *masks; // [waves of 128 sorted queries][nwords]: bit k of word j = sub-chunk 64 j + k is a candidate
+  const int32_t *list;             // [waves of 128 sorted queries][list_pitch]: the wave's candidate sub-chunks, ascending
+  const int32_t *count;            // [waves]: how many
   const int32_t *perm_n;           // sorted position -> node id
-  int nsub, nwords;                // sub-chunks; mask words per wave
-  int spg;                         // sub-chunks per blockIdx.y (a multiple of 64)
+  int64_t list_pitch;
+  int node_rows, query_rows;       // the float64 nodes / queries are rows of eight ([count][8]) instead of columns
+  int probe;                       // (timing only, option "nn_probe": 1 = parked pairs are dropped unevaluated -- WRONG answers;
+                                   //  2 = the pairs that reach the exact evaluation are counted in counter[0])
+  unsigned *counter;
   int pack_idx;                    // (SAMPLE) the low 16 bits of a bound carry the sample position it was found at (scaled by idx_shift)
   int idx_shift;
 };
@@ -460,7 +470,7 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
   // the node range under the loop: a chunk of the launch -- or (CELLS) one run of sub-chunks after another; parked pairs
   // count their nodes from glo, the start of everything this workgroup may scan
   int64_t lo = (int64_t)blockIdx.y * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-  const int64_t glo = CELLS ? (int64_t)blockIdx.y * cells.spg * kNNCellSub : lo;
+  const int64_t glo = CELLS ? 0 : lo;  // (CELLS: a row of the grid takes sub-chunks from all over the tree; n < 2^26)
   const nn_f16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t *mypark = park + (SAMPLE ? 0 : threadIdx.x);
   int parked = 0;
@@ -468,9 +478,29 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
   // exact distance of node `node` from query q: k_nearest_part's statements
   auto exact = [&](int64_t node, int64_t q) {
     double ex = 0;
+    // (the cell-ordered scan hands over rows of eight doubles -- a node is ONE cache line, not seven: in a dense tree a
+    //  look-up evaluates hundreds of millions of these)
+    if constexpr (CELLS) {  // (both in rows: four 16-byte loads each)
+      double nv[8], qv[8];
+      const double2 *np2 = reinterpret_cast<const double2 *>(nodes + 8 * node), *qp2 = reinterpret_cast<const double2 *>(queries + 8 * q);
+#pragma unroll
+      for (int k = 0; k < (NP + 1) / 2; k++) {
+        const double2 a = np2[k], b = qp2[k];
+        nv[2 * k] = a.x; nv[2 * k + 1] = a.y; qv[2 * k] = b.x; qv[2 * k + 1] = b.y;
+      }
+#pragma unroll
+      for (int c = 0; c < NP; c++) {
+        const double d = nv[c] - qv[c];
+        ex = ex + d * d;
+      }
+      return ex;
+    }
+    const double *nrow = cells.node_rows ? nodes + 8 * node : nodes + node;
+    const double *qrow = cells.query_rows ? queries + 8 * q : queries + q;
+    const int64_t ncs = cells.node_rows ? 1 : cap, qcs = cells.query_rows ? 1 : M;
 #pragma unroll
     for (int c = 0; c < NP; c++) {
-      const double d = nodes[(int64_t)c * cap + node] - queries[(int64_t)c * M + q];
+      const double d = nrow[(int64_t)c * ncs] - qrow[(int64_t)c * qcs];
       ex = ex + d * d;
     }
     return ex;
@@ -484,6 +514,15 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
       most = other > most ? other : most;
     }
     unsigned touched = 0;
+    if constexpr (CELLS) {
+      if (cells.probe == 1) most = 0;
+      if (cells.probe == 2) {
+        int tot = parked;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (l == 0 && tot > 0) atomicAdd(cells.counter, (unsigned)tot);
+      }
+    }
     for (int j = 0; j < most; j++) {
       if (j < parked) {
         const int32_t ent = mypark[j * kThreads];
@@ -581,12 +620,15 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
   };
   static_assert(kNNMAhead == 4, "four named registers hold the tiles in flight (an indexed array would live in scratch)");
   nn_f16 ta[kNNMSets], tb[kNNMSets];
-  auto scan_range = [&]() {  // the screened scan of nodes [lo, hi)
+#pragma unroll
+  for (int s = 0; s < kNNMSets; s++) ta[s] = tb[s] = zero;
+  typedef unsigned nn_u4 __attribute__((ext_vector_type(4)));
+  if constexpr (!CELLS) {
+  // ---- the screened scan of nodes [lo, hi)
   const int ntile = __builtin_amdgcn_readfirstlane((int)((hi - lo + 31) >> 5));  // (wave-uniform, and told so: a scalar register)
   // tile k of this lane through a buffer descriptor: the chunk's first row in scalar registers, the lane's 32-bit byte
   // offset in ONE vector register, the tile's offset in a scalar one (a 64-bit address per lane was two registers more
   // than there are, and its reload from scratch -- a vector-memory operation like the tiles -- waited for every tile in flight)
-  typedef unsigned nn_u4 __attribute__((ext_vector_type(4)));
   const int64_t rstride = SAMPLE ? stride : 1;  // rows of the packed nodes between two rows of a tile
   const __amdgpu_buffer_rsrc_t tiles =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(nodes16 + 2 * lo * rstride), 0, 0x7fffffff, 0x00020000);
@@ -598,8 +640,6 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     return uint4{v[0], v[1], v[2], v[3]};
   };
   uint4 a0 = fetch(0), a1 = fetch(1), a2 = fetch(2), a3 = fetch(3);
-#pragma unroll
-  for (int s = 0; s < kNNMSets; s++) ta[s] = tb[s] = zero;
   // step k: the instructions of tile k (of a tile of zeros behind the last one) and the folds of tile k - 1
   auto turn = [&](nn_f16 (&cur)[kNNMSets], const nn_f16 (&prev)[kNNMSets], int k) {
     nn_h8 av;
@@ -612,28 +652,61 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     turn(tb, ta, k);
     if (k + 1 <= ntile) turn(ta, tb, k + 1);
   }
-  };  // scan_range
-  if constexpr (!CELLS) {
-    scan_range();
   } else {
-    // the sub-chunks some query of this wave may have its answer in: one bit each, found beforehand (k_nn_candidates);
-    // runs of consecutive ones are scanned as one range
+    // ---- the screened scan of this wave's candidate sub-chunks (k_nn_candidates / k_nn_compact: their numbers, ascending,
+    // cells.count of them): row y of the grid's rows takes the y-th slice of the list, and walks its tiles -- kNNCellSub / 32
+    // per sub-chunk -- as ONE stream through the same pipeline; the list comes through the scalar cache, an entry ahead.
+    // (Range by range -- every run of consecutive sub-chunks its own prologue and drain -- the loop spent two thirds of
+    //  its time filling and emptying the pipeline: 3.6 ms where the stream takes 1.3, profiles/README.md round 6.)
+    constexpr int kTiles = kNNCellSub / 32;
+    static_assert((kTiles & (kTiles - 1)) == 0, "a power of two");
     const int wq = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kNNMWaves + w));
-    const unsigned long long *mrow = cells.masks + (int64_t)wq * cells.nwords;
-    const int sc0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * cells.spg);  // (spg: a multiple of 64)
-    const int sc1 = __builtin_amdgcn_readfirstlane(sc0 + cells.spg < cells.nsub ? sc0 + cells.spg : cells.nsub);
-    for (int base = sc0; base < sc1; base += 64) {
-      unsigned long long mask = mrow[base >> 6];
-      while (mask != 0ull) {
-        const int first = (int)__builtin_ctzll(mask);
-        const unsigned long long rest = ~(mask >> first);
-        const int run = rest == 0ull ? 64 - first : (int)__builtin_ctzll(rest);
-        lo = (int64_t)(base + first) * kNNCellSub;
-        hi = (int64_t)(base + first + run) * kNNCellSub;
-        hi = hi < n ? hi : n;
-        scan_range();
-        mask &= (first + run >= 64) ? 0ull : ~((1ull << (first + run)) - 1ull);
+    const int32_t *list = cells.list + (int64_t)wq * cells.list_pitch;
+    const int cnt = __builtin_amdgcn_readfirstlane(cells.count[wq]);
+    const int e0 = __builtin_amdgcn_readfirstlane((int)((int64_t)cnt * blockIdx.y / gridDim.y));
+    const int e1 = __builtin_amdgcn_readfirstlane((int)((int64_t)cnt * (blockIdx.y + 1) / gridDim.y));
+    const int ntile = (e1 - e0) * kTiles;
+    hi = n;
+    const __amdgpu_buffer_rsrc_t tiles = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(nodes16), 0, 0x7fffffff, 0x00020000);
+    const unsigned loff = (unsigned)((2 * r + h) * 16);
+    // two cursors over the list: the tile to fetch next, the tile whose results are folded next
+    int fk = 0, f_sc = e0 < e1 ? list[e0] : 0, f_nx = e0 + 1 < e1 ? list[e0 + 1] : 0;
+    auto fetch = [&]() -> uint4 {
+      if (fk >= ntile) return uint4{0, 0, 0, 0};
+      const unsigned soff = ((unsigned)f_sc * (unsigned)kNNCellSub + (unsigned)(fk & (kTiles - 1)) * 32u) * 32u;  // (n < 2^25: below 2^30 bytes)
+      const nn_u4 v = __builtin_amdgcn_raw_buffer_load_b128(tiles, loff, soff, 0);
+      fk++;
+      if ((fk & (kTiles - 1)) == 0) {
+        f_sc = f_nx;
+        const int at = e0 + (fk / kTiles) + 1;
+        f_nx = at < e1 ? list[at] : 0;
       }
+      return uint4{v[0], v[1], v[2], v[3]};
+    };
+    uint4 a0 = fetch(), a1 = fetch(), a2 = fetch(), a3 = fetch();
+    int pk = 0, p_sc = f_sc, p_nx = 0;  // (set below, at the first fold)
+    p_sc = e0 < e1 ? list[e0] : 0;
+    p_nx = e0 + 1 < e1 ? list[e0 + 1] : 0;
+    auto turn = [&](nn_f16 (&cur)[kNNMSets], const nn_f16 (&prev)[kNNMSets], int k) {
+      nn_h8 av;
+      __builtin_memcpy(&av, &a0, 16);
+      a0 = a1; a1 = a2; a2 = a3;
+      a3 = fetch();
+      int64_t pbase = 0;
+      if (k > 0) {  // tile k - 1 = tile pk of the stream
+        pbase = (int64_t)p_sc * kNNCellSub + (int64_t)(pk & (kTiles - 1)) * 32;
+        pk++;
+        if ((pk & (kTiles - 1)) == 0) {
+          p_sc = p_nx;
+          const int at = e0 + (pk / kTiles) + 1;
+          p_nx = at < e1 ? list[at] : 0;
+        }
+      }
+      step(cur, prev, av, pbase, k > 0);
+    };
+    for (int k = 0; k <= ntile; k += 2) {
+      turn(tb, ta, k);
+      if (k + 1 <= ntile) turn(ta, tb, k + 1);
     }
   }
   if constexpr (SAMPLE) {

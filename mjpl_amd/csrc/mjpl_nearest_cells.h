@@ -47,12 +47,14 @@ __device__ __forceinline__ float nnc_up(double v) {
 }
 
 // mm[c] = ord(min), mm[8 + c] = ord(max) of column c over the finite coordinates (initialised to ~0 / 0)
+constexpr int kNNCMinmaxRows = 32;  // rows per thread
 __global__ void __launch_bounds__(256)
 k_nnc_minmax(const double *__restrict__ src, int64_t count, int64_t col_stride, int nplan, unsigned *__restrict__ mm) {
-  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x * 8 + threadIdx.x;
+  __shared__ float part[2][4];
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x * kNNCMinmaxRows + threadIdx.x;
   for (int c = 0; c < nplan; c++) {
     float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < kNNCMinmaxRows; k++) {
       const int64_t i = i0 + (int64_t)k * blockDim.x;
       if (i < count) {
         const double v = src[(int64_t)c * col_stride + i];
@@ -60,7 +62,15 @@ k_nnc_minmax(const double *__restrict__ src, int64_t count, int64_t col_stride, 
       }
     }
     for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
-    if ((threadIdx.x & 63) == 0 && lo <= hi) { atomicMin(&mm[c], nnc_ord(lo)); atomicMax(&mm[8 + c], nnc_ord(hi)); }
+    // (one pair of atomics per workgroup and column: per wave they were the kernel's whole time)
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = lo; part[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      lo = fminf(fminf(part[0][0], part[0][1]), fminf(part[0][2], part[0][3]));
+      hi = fmaxf(fmaxf(part[1][0], part[1][1]), fmaxf(part[1][2], part[1][3]));
+      if (lo <= hi) { atomicMin(&mm[c], nnc_ord(lo)); atomicMax(&mm[8 + c], nnc_ord(hi)); }
+    }
   }
 }
 
@@ -124,20 +134,24 @@ k_nnc_keys(const double *__restrict__ src, int64_t count, int64_t col_stride, in
   iota[i] = (int32_t)i;
 }
 
-// rows in sorted order: dst[c][j] = src[c][perm[j]] (columns beyond `count` up to `padded`: +inf -- a node that never wins)
+// rows in sorted order, eight doubles each -- one cache line per node for the exact distances: dst[j][c] = src[c][perm[j]]
+// (rows beyond `count` up to `padded`: +inf -- a node that never wins; slot 7: 0)
 __global__ void __launch_bounds__(256)
 k_nnc_gather(const double *__restrict__ src, int64_t col_stride, const int32_t *__restrict__ perm, int64_t count, int64_t padded,
-             int nplan, double *__restrict__ dst, int64_t dst_stride) {
+             int nplan, double *__restrict__ dst) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= padded) return;
   const int64_t i = j < count ? perm[j] : -1;
-  for (int c = 0; c < nplan; c++)
-    dst[(int64_t)c * dst_stride + j] = i >= 0 ? src[(int64_t)c * col_stride + i] : std::numeric_limits<double>::infinity();
+  double row[8];
+  for (int c = 0; c < 8; c++)
+    row[c] = c < nplan ? (i >= 0 ? src[(int64_t)c * col_stride + i] : std::numeric_limits<double>::infinity()) : 0.0;
+  double2 *out = reinterpret_cast<double2 *>(dst + 8 * j);
+  for (int k = 0; k < 4; k++) out[k] = double2{row[2 * k], row[2 * k + 1]};
 }
 
 // the box of every sub-chunk of the sorted nodes: nbox[c][s] = min, nbox[8 + c][s] = max (columns beyond nplan: -inf / +inf)
 __global__ void __launch_bounds__(256)
-k_nnc_boxes(const double *__restrict__ nodes_s, int64_t n, int64_t stride, int nplan, int nsub, int nsubp, float *__restrict__ nbox) {
+k_nnc_boxes(const double *__restrict__ nodes_s, int64_t n, int nplan, int nsub, int nsubp, float *__restrict__ nbox) {
   const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (s >= nsub) return;
@@ -147,7 +161,7 @@ k_nnc_boxes(const double *__restrict__ nodes_s, int64_t n, int64_t stride, int n
       for (int k = lane; k < kNNCellSub; k += 64) {
         const int64_t i = (int64_t)s * kNNCellSub + k;
         if (i < n) {
-          const double v = nodes_s[(int64_t)c * stride + i];
+          const double v = nodes_s[8 * i + c];  // (rows of eight)
           // (a NaN never wins and makes the call "wild" anyway; an infinite coordinate opens the box to that side)
           if (v == v) { lo = fminf(lo, nnc_down(v)); hi = fmaxf(hi, nnc_up(v)); }
         }
@@ -197,11 +211,13 @@ k_nnc_gather_queries(const double *__restrict__ src, const double *__restrict__ 
   if (j < M) {
     const int64_t i = perm[j];
     float amax = 0;
-    for (int c = 0; c < nplan; c++) {
-      const double v = src[(int64_t)c * M + i];
-      dst[(int64_t)c * M + j] = v;
-      row[c] = (float)v;
-      amax = fmaxf(amax, fabsf(row[c]));
+    for (int c = 0; c < 8; c++) {
+      const double v = c < nplan ? src[(int64_t)c * M + i] : 0.0;
+      dst[8 * j + c] = v;  // (rows of eight, as the nodes)
+      if (c < nplan) {
+        row[c] = (float)v;
+        amax = fmaxf(amax, fabsf(row[c]));
+      }
     }
     const double b2 = bound2[i];
     bound2_s[j] = b2;
@@ -251,6 +267,24 @@ k_nn_candidates(const float *__restrict__ qf, int64_t M, const float *__restrict
   }
   const unsigned long long m = __ballot(any && sc < nsub);
   if (lane == 0) masks[(int64_t)blockIdx.x * nwords + word] = m;
+}
+
+// the candidate bits of every wave as a list of sub-chunk numbers, ascending (what the scan walks): one wave per row of masks
+__global__ void __launch_bounds__(256)
+k_nn_compact(const unsigned long long *__restrict__ masks, int nwords, int nwaves, int32_t *__restrict__ list, int64_t list_pitch,
+             int32_t *__restrict__ count, const unsigned *__restrict__ xbits) {
+  if (xbits[1] != 0u) return;
+  const int wq = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (wq >= nwaves) return;
+  const int lane = threadIdx.x & 63;
+  int32_t *mine = list + (int64_t)wq * list_pitch;
+  int base = 0;
+  for (int word = 0; word < nwords; word++) {
+    const unsigned long long m = masks[(int64_t)wq * nwords + word];
+    if ((m >> lane) & 1ull) mine[base + __popcll(m & ((1ull << lane) - 1ull))] = word * 64 + lane;
+    base += __popcll(m);
+  }
+  if (lane == 0) count[wq] = base;
 }
 
 // the partial results of the scan (sorted query order, node ids already the callers') -> the callers' query order

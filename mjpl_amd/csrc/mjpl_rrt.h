@@ -90,7 +90,8 @@ k_rrt_sample(int L, int nplan, uint64_t key, double pgoal, int grow, int ngoal, 
 // extension start: C = node nearest to the target, lane on unless it duplicates a lower biased lane
 __global__ void __launch_bounds__(256)
 k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLanes ln, const int32_t *__restrict__ first,
-            const double *__restrict__ Tgt, int second, int *__restrict__ ctr, RrtCarry cy) {
+            const double *__restrict__ Tgt, int second, int *__restrict__ ctr, RrtCarry cy, const int32_t *__restrict__ cf,
+            uint8_t *__restrict__ coff) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l == 0) { ctr[RC_EDGES] = 0; ctr[RC_ACTIVE] = 0; ctr[RC_ACC] = 0; }  // for the extension's first chunk
   if (l >= L) return;
@@ -101,6 +102,12 @@ k_rrt_begin(int L, int nplan, const double *__restrict__ Q, int64_t cap, RrtLane
     ln.on[l] = on ? 1 : 0;
   } else {
     on = ln.on[l] != 0 && !(cy.flag && cy.flag[l]);  // (a lane carried by the first extension sits the connect phase out)
+    // ... and of the lanes whose first extension added nothing and that stand on the same node of the tree -- their connect
+    // phases would be the same chain towards the same configuration, node for node -- only the lowest takes part (k_rrt_conn_claim)
+    const int ra = ln.refA[l];
+    const bool dup = on && ra >= 0 && cf[ra] != l;
+    coff[l] = dup ? 1 : 0;
+    on = on && !dup;
   }
   int nn = ln.near[l];
   if (!second && cy.flag && cy.flag[l]) {  // a carried chain goes on from where it stopped (a lane that lost its goal to a lower one: dropped)
@@ -478,10 +485,24 @@ k_rrt_near_merge(int L, int room, const uint8_t *__restrict__ early, const int32
   near[l] = early[l] ? near_e[l] : near_late[pos[l] < room ? pos[l] : 0];
 }
 
+// between the two extensions: the lowest lane among those that stand on the same old node of the tree that grew
 __global__ void __launch_bounds__(256)
-k_rrt_connect(int L, int nplan, RrtLanes ln, int *__restrict__ ctr, RrtCarry cy) {
+k_rrt_conn_claim(int L, RrtLanes ln, RrtCarry cy, int32_t *__restrict__ cf) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L || !ln.on[l] || (cy.flag && cy.flag[l])) return;
+  const int ra = ln.refA[l];
+  if (ra >= 0) atomicMin(&cf[ra], l);
+}
+
+__global__ void __launch_bounds__(256)
+k_rrt_connect(int L, int nplan, RrtLanes ln, int *__restrict__ ctr, RrtCarry cy, int32_t *__restrict__ cf, const uint8_t *__restrict__ coff) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= L || !ln.on[l] || (cy.flag && cy.flag[l])) return;  // (carried: no connect phase this round)
+  {
+    const int ra = ln.refA[l];
+    if (ra >= 0) cf[ra] = 0x7f7f7f7f;  // (the claims of this round: cleared by the lanes that made them)
+  }
+  if (coff[l]) return;  // (another lane ran this lane's connect phase)
   bool eq = true;
   for (int c = 0; c < nplan; c++) eq = eq && (ln.RA[(int64_t)c * L + l] == ln.C[(int64_t)c * L + l]);
   if (eq) atomicMin(&ctr[RC_CONN], l);
@@ -577,6 +598,8 @@ struct mjpl_rrt {
   double eps = 0.05, istep = 0, pgoal = 0.05;
   uint64_t seed = 0;
   int ngoal = 0, round = 0;
+  int32_t *d_cf = nullptr;     // [cap] per node of the tree that grew: the lowest lane standing on it after the first extension (0x7f7f7f7f: none)
+  uint8_t *d_coff = nullptr;   // [L] the lane's connect phase is another lane's
   int max_steps = 0;           // most nodes a lane adds per extension (0: no cap); the lanes capped in a tree's first extension are carried
   RrtCarry carry[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // per tree
   int n[2] = {0, 0};
@@ -674,7 +697,7 @@ inline unsigned rgrid(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 // MJPL_RRT_TRACE=1: where a round's wall time goes (stderr; synchronises the stream at every mark)
 struct RrtTrace {
-  bool on = getenv("MJPL_RRT_TRACE") != nullptr;
+  bool on = getenv("MJPL_RRT_TRACE") != nullptr;  // (MJPL_DEBUG-class switch: tracing only)
   bool chunks = on && atoi(getenv("MJPL_RRT_TRACE")) >= 2;  // (2: a line per extension chunk -- the stream is synchronised after every chunk)
   void chunk(hipStream_t st, int index, int active, int S, int G, unsigned grid) {
     if (!chunks) return;
@@ -685,6 +708,14 @@ struct RrtTrace {
     t0 = std::chrono::steady_clock::now();
   }
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  // (after a look-up: what the cell-ordered scan had to do -- options "nn_last_candidate_fraction", "nn_last_exact_pairs")
+  void nn(mjpl_engine *e) {
+    if (!on) return;
+    double frac = -1, pairs = -1;
+    (void)mjpl_get_option(e, "nn_last_candidate_fraction", &frac);
+    (void)mjpl_get_option(e, "nn_last_exact_pairs", &pairs);
+    fprintf(stderr, "[rrt]   (look-up: %.4f of the tree's sub-chunks on a wave's list, %.0f exact distances)\n", frac, pairs);
+  }
   void mark(hipStream_t st, const char *what, long n = -1) {
     if (!on) return;
     (void)hipStreamSynchronize(st);
@@ -747,6 +778,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     hipLaunchKernelGGL(k_rrt_near_merge, dim3(rgrid(L)), dim3(256), 0, st, L, room, r->d_early, r->d_late_pos, r->d_near_e, r->d_late_near,
                        r->ln.near);
     tr.mark(st, "nearest neighbour (the lanes of the tail; the others were looked up early)", r->n[t]);
+    tr.nn(e);
   } else if (!second && r->pre_round == r->round && r->pre_n0 <= r->n[t]) {
     // this round's targets were looked up in the tree's first pre_n0 nodes while the round before ran its tail
     r->pre_round = 0;
@@ -758,11 +790,13 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
     rc = mjpl_nearest_dev(e, r->d_Q[t], r->n[t], r->cap, Tgt, L, r->ln.near, nullptr);
     if (rc != MJPL_OK) return rc;
     tr.mark(st, "nearest neighbour", r->n[t]);
+    tr.nn(e);
   }
   const bool projecting = r->pose != nullptr;
   if (projecting) HIP_TRY(hipMemsetAsync(r->d_ctr + RC_LISTN, 0, 2 * sizeof(int), st));  // (both lists of the extension: empty)
   hipLaunchKernelGGL(k_rrt_begin, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->d_Q[t], r->cap, r->ln, r->d_first, Tgt,
-                     second, r->d_ctr, r->carry[second ? 1 - t : t]);  // (the records of the tree that grows this round)
+                     second, r->d_ctr, r->carry[second ? 1 - t : t],  // (the records of the tree that grows this round)
+                     (const int32_t *)r->d_cf, r->d_coff);
   if (projecting) hipLaunchKernelGGL(k_rrt_list_begin, dim3(rgrid(L)), dim3(256), 0, st, L, r->ln, r->d_ctr);
   // (without a projection: four steps per lane in the first chunk of a big batch, doubling; a small batch -- a planner of
   //  a few hundred lanes -- starts with as many as 2^16 candidate slots allow, up to 64: its chunks cost their launches'
@@ -1096,6 +1130,9 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   RA(r->d_ctr, RC_SIZE); RA(r->d_heads, 8 * 1024); RA(r->d_path, (size_t)nplan * 65536);
   RA(r->d_first, 1);  // re-allocated by reset for the number of goals
   RA(r->d_scan, (size_t)(L + kScanBlock - 1) / kScanBlock);
+  RA(r->d_cf, r->cap); RA(r->d_coff, L);
+  HIP_TRY(hipMemset(r->d_cf, 0x7f, (size_t)r->cap * sizeof(int32_t)));
+  HIP_TRY(hipMemset(r->d_coff, 0, (size_t)L));
   if (d->max_steps_per_round < 0) return fail(MJPL_E_ARG, "`max_steps_per_round` must be >= 0 (0: no cap)");
   r->max_steps = d->max_steps_per_round;
   if (r->max_steps > 0)
@@ -1164,6 +1201,7 @@ int mjpl_rrt_reset(mjpl_rrt *r, const double *q_init, const double *q_goals, int
   if (r->side) HIP_TRY(hipStreamSynchronize(r->side));
   for (int t = 0; t < 2; t++)
     if (r->carry[t].flag) HIP_TRY(hipMemset(r->carry[t].flag, 0, (size_t)r->L));
+  HIP_TRY(hipMemset(r->d_cf, 0x7f, (size_t)r->cap * sizeof(int32_t)));  // (a round that failed half-way leaves its claims)
   r->pre_round = 0;
   r->early_on = false;
   if (ngoal > r->first_cap) {
@@ -1220,9 +1258,10 @@ int rrt_begin(mjpl_rrt *r, int32_t request_stop) {
   }
   int newA = 0, newB = 0;
   int rc = rrt_extend(r, grow, r->ln.T, 0, &newA);
+  if (rc == MJPL_OK) hipLaunchKernelGGL(k_rrt_conn_claim, dim3(rgrid(L)), dim3(256), 0, st, L, r->ln, r->carry[grow], r->d_cf);
   if (rc == MJPL_OK) rc = rrt_extend(r, other, r->ln.RA, 1, &newB);
   if (rc == MJPL_OK) {
-    hipLaunchKernelGGL(k_rrt_connect, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->d_ctr, r->carry[grow]);
+    hipLaunchKernelGGL(k_rrt_connect, dim3(rgrid(L)), dim3(256), 0, st, L, nplan, r->ln, r->d_ctr, r->carry[grow], r->d_cf, (const uint8_t *)r->d_coff);
     hipLaunchKernelGGL(k_rrt_header, dim3(1), dim3(1), 0, st, r->ln, r->d_ctr, grow, request_stop ? 1 : 0, r->d_heads + 8 * rank);
     if (hipGetLastError() != hipSuccess) rc = fail(MJPL_E_HIP, "rrt: a kernel of the round failed to launch");
   }

@@ -569,6 +569,14 @@ class ParallelBiRRT(_PlannerBase):
             cg.T[capped], cg.goal[capped] = T[capped], goal[capped]
             cg.node[capped] = refA[capped]  # (pending: made a node id below, once this rank's block has its base)
             on = on & ~capped               # carried lanes sit the connect phase out
+            # Lanes whose first extension added nothing stand on an old node of the tree; those on the SAME node would all
+            # run the same connect phase -- the same chain towards the same configuration, node for node (a sixth of
+            # a tree's rows were such copies): of them only the lowest lane takes part.
+            stuck = np.flatnonzero(on & (refA >= 0))
+            if len(stuck):
+                _, first = np.unique(refA[stuck], return_index=True)
+                on[stuck] = False
+                on[stuck[first]] = True
             RB, refB, rowsB, parB, _ = self._extend(other, RA, on)
             hit = np.flatnonzero(on & np.all(RA == RB, axis=1))
             head = np.zeros(8, np.int64)

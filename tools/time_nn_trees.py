@@ -48,6 +48,18 @@ def main():
             e.sync()
             res[cells] = ((time.perf_counter() - t0) / reps * 1e3, di.download(np.int32, M), dd.download(np.float64, M))
             assert e.get_option("nn_last_cells") == cells
+            if cells:
+                frac = e.get_option("nn_last_candidate_fraction")
+                if os.environ.get("NN_PROBE"):  # (timing only: the scan with its exact evaluations dropped)
+                    e.set_option("nn_probe", 1)
+                    e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
+                    e.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
+                    e.sync()
+                    print("   probe (no exact evaluations):", (time.perf_counter() - t0) / reps * 1e3, "ms")
+                    e.set_option("nn_probe", 0)
         same = bool(np.array_equal(res[1][1], res[0][1]) and np.array_equal(res[1][2], res[0][2]))
         for j in range(0, M, M // 32):  # ... and a sample against NumPy: sequential-sum squared norms, lowest index wins
             dif = nodes - qs[:, j:j + 1]
@@ -55,7 +67,7 @@ def main():
             for c in range(7):
                 s = s + dif[c] * dif[c]
             assert res[1][1][j] == int(np.argmin(s)), (label, j)
-        out[label] = {"nodes": n, "queries": M, "cells_ms": res[1][0], "full_ms": res[0][0], "answers_equal": same,
+        out[label] = {"nodes": n, "queries": M, "cells_ms": res[1][0], "full_ms": res[0][0], "answers_equal": same, "candidate_fraction": frac,
                       "median_distance": float(np.sqrt(np.median(res[0][2])))}
         print(label, out[label], flush=True)
         assert same
