@@ -315,23 +315,60 @@ def profile_record(kernel, E, layout, filt=True, spec=True):
         return {}
 
 
-def issue_roofline(key, kernel, hbm, step_ms, launches_per_step=1.0):
-    """`roofline` of a line whose dominant kernel is bound by vector-instruction issue, from the committed counter pass of
-    this same command (profiles/pmc.json[key], written by tools/pmc_collect.py from profiles/<tag>_pmc_<kernel>.json and
-    profiles/<tag>_<workload>_kernel_stats.csv): achieved = SQ_INSTS_VALU per launch / the kernel's average duration in
-    that trace, both from the same profiling round, so that dividing one committed file by the other reproduces `frac`.
-    The HBM figure north_star asks for rides along as `hbm` (algorithmic bytes / this run's step time).  No record: the HBM
-    object alone, saying so."""
+def kernel_time_this_run(eng, step, steps=32, mode=1):
+    """(ms of the dominant kernel per step, launches per step) of `steps` untimed steps of THIS run: option "kernel_timer"
+    (include/mjpl_hip.h) puts a HIP event on either side of every launch of the workload's dominant kernel, on the stream it
+    is launched on.  mode 1: the configuration filter / projection rows / IK rows / the planner's generating kernel; 2:
+    the nearest-neighbour scans."""
+    eng.set_option("kernel_timer", mode)
+    for _ in range(steps):
+        step()
+    ms, n = eng.get_option("kernel_timer_ms"), eng.get_option("kernel_timer_launches")
+    eng.set_option("kernel_timer", 0)
+    return (ms / steps, n / steps) if n > 0 and ms >= 0 else (None, None)
+
+
+def issue_roofline(key, kernel, hbm, step_ms, launches_per_step=1.0, this_run=None):
+    """`roofline` of a line whose dominant kernel is bound by vector-instruction issue: achieved = the kernel's wave-level
+    vector instructions per step (SQ_INSTS_VALU per launch of the committed counter pass of this same command,
+    profiles/pmc.json[key], x the launches per step) / the kernel's duration per step.  `this_run` = (ms per step, launches
+    per step) from kernel_time_this_run: the duration is THIS run's, between HIP events (round 6; before, the committed
+    trace's average -- a line could print a kernel longer than its step).  The record carries the digest of the kernel
+    sources it was captured under; another digest is said so (`counters_stale`).  The HBM figure north_star asks for rides
+    along as `hbm`.  No record: the HBM object alone, saying so."""
     rec = profile_key(key)
     if not rec.get("SQ_INSTS_VALU") or not rec.get("avg_ns"):
         return dict(hbm, note=f"no committed counter pass for {kernel} ({key} in profiles/pmc.json): the HBM figure only; the path is "
                               "issue / latency bound (SURVEY.md 8d)")
-    iv, ms = float(rec["SQ_INSTS_VALU"]), float(rec["avg_ns"]) * 1e-6
-    out = {"bound": "valu_issue", "kernel": kernel, "achieved": iv / (ms * 1e-3), "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
-           "frac": iv / (ms * 1e-3) / VALU_ISSUE_PEAK, "traffic": rec.get("hbm_bytes_per_launch"),
-           "wave_insts_valu_per_launch": iv, "kernel_ms": ms, "kernel_ms_source": "average duration of the kernel in the committed kernel trace (the counters' own profiling round), not this run",
-           "launches_per_step": launches_per_step, "kernel_ms_per_step": ms * launches_per_step, "step_ms_this_run": step_ms,
+    iv = float(rec["SQ_INSTS_VALU"])
+    if this_run and this_run[0]:
+        ms_step, launches_per_step = float(this_run[0]), float(this_run[1])
+        source = "HIP events around the kernel's launches in 32 untimed steps of THIS run (option kernel_timer)"
+    else:
+        ms_step = float(rec["avg_ns"]) * 1e-6 * launches_per_step
+        source = "average duration of the kernel in the committed kernel trace (the counters' own profiling round), not this run"
+    achieved = iv * launches_per_step / (ms_step * 1e-3)
+    out = {"bound": "valu_issue", "kernel": kernel, "achieved": achieved, "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
+           "frac": achieved / VALU_ISSUE_PEAK, "traffic": rec.get("hbm_bytes_per_launch"),
+           "wave_insts_valu_per_launch": iv, "kernel_ms_source": source,
+           "launches_per_step": launches_per_step, "kernel_ms_per_step": ms_step, "step_ms_this_run": step_ms,
            "waves_per_launch": rec.get("SQ_WAVES"), "counters_source": rec.get("source"), "hbm": hbm}
+    if step_ms < ms_step <= step_ms * 1.05:
+        # (a step that IS its one kernel: between events the kernel reads a few percent longer than the un-instrumented step
+        #  -- the events' own cost; the step's time is the kernel's)
+        out["kernel_ms_between_events"] = ms_step
+        ms_step = step_ms
+        achieved = iv * launches_per_step / (ms_step * 1e-3)
+        out.update(kernel_ms_per_step=ms_step, achieved=achieved, frac=achieved / VALU_ISSUE_PEAK)
+    elif ms_step > step_ms:  # (a kernel cannot outlast the step it is part of: the figure is withheld rather than printed)
+        out.update(frac=None, achieved=None, inconsistent=f"kernel {ms_step:.4f} ms per step > step {step_ms:.4f} ms")
+    try:
+        from mjpl_amd import build as _build
+        stamp = "%016x" % _build.src_stamp()
+        if rec.get("src_stamp") and rec["src_stamp"] != stamp:
+            out["counters_stale"] = f"the counters were captured under kernel sources {rec['src_stamp']}, this build is {stamp}"
+    except Exception:  # noqa: BLE001
+        pass
     if rec.get("SQ_THREAD_CYCLES_VALU") and rec.get("SQ_ACTIVE_INST_VALU"):
         out["live_lanes_per_valu_instruction"] = float(rec["SQ_THREAD_CYCLES_VALU"]) / float(rec["SQ_ACTIVE_INST_VALU"])
     if rec.get("SQ_WAIT_ANY") and rec.get("SQ_WAVE_CYCLES"):
@@ -381,6 +418,7 @@ def bench_configs(args, world):
     dq, dv = eng.alloc(h.nbytes).upload(h), eng.alloc(N)
     if args.warmup > 0:
         eng.time_configs_dev(dq.ptr, N, engine.SOA, dv.ptr, args.warmup)
+    this_run = kernel_time_this_run(eng, lambda: eng.time_configs_dev(dq.ptr, N, engine.SOA, dv.ptr, 1))
     world.barrier()
     t0 = time.perf_counter()
     ms = eng.time_configs_dev(dq.ptr, N, engine.SOA, dv.ptr, args.steps)
@@ -402,7 +440,7 @@ def bench_configs(args, world):
                    {"bound": "hbm", "achieved": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": 57 * N / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic": None, "algorithmic_bytes_per_configuration": 57},
-                   float(np.mean(ms)))}
+                   float(np.mean(ms)), this_run=this_run)}
         if not args.no_cpu_baseline:
             from oracle import pyoracle
             orc = pyoracle.Oracle(model, planning_qidx=qidx, qpos_base=base)
@@ -451,10 +489,13 @@ def bench_next_rows(args, world):
         dout, dok, dit = eng.alloc(Q.nbytes), eng.alloc(n), eng.alloc(4 * n)
         for _ in range(max(args.warmup, 1)):
             pc._proj.apply_dev(dqo.ptr, dq.ptr, n, dout.ptr, dok.ptr, dit.ptr)
+        this_run = kernel_time_this_run(eng, lambda: pc._proj.apply_dev(dqo.ptr, dq.ptr, n, dout.ptr, dok.ptr, dit.ptr))
+        eng.sync()
         world.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             pc._proj.apply_dev(dqo.ptr, dq.ptr, n, dout.ptr, dok.ptr, dit.ptr)
+        eng.sync()
         world.barrier()
         elapsed = time.perf_counter() - t0
         value, slowest = aggregate(world, n, args.steps, elapsed)
@@ -482,7 +523,7 @@ def bench_next_rows(args, world):
                            {"bound": "hbm", "achieved": n * row_bytes * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": n * row_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "algorithmic_bytes_per_row": row_bytes},
-                           slowest / args.steps * 1e3),
+                           slowest / args.steps * 1e3, this_run=this_run),
                        cpu_baseline={"value": k / dtc, "unit": "rows/s", "cores": cores, "kind": "port",
                                      "sample": f"first {k} rows of rank 0, {cores} pthreads"})
     else:
@@ -498,6 +539,8 @@ def bench_next_rows(args, world):
 
         for _ in range(max(args.warmup, 1)):
             once()
+        this_run = kernel_time_this_run(eng, lambda: eng.ik_solve("ee_site", target.translation(), target.rotation().wxyz, Q0, solver.movable,
+                                                                 iterations=200, restarts=8, restart_seed=11), steps=8)
         world.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -534,7 +577,7 @@ def bench_next_rows(args, world):
                            {"bound": "hbm", "achieved": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": len(Q0) * 2 * 8 * model.nq * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "algorithmic_bytes_per_seed": 2 * 8 * model.nq},
-                           slowest / args.steps * 1e3),
+                           slowest / args.steps * 1e3, this_run=this_run),
                        cpu_baseline=cpu_ik)
     if out is not None:
         _flush_c_stdio()
@@ -588,6 +631,9 @@ def bench_rrt(args, world):
         cc.engine.set_option("nn_probe", 2)
     dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 3)
     info = dev.rrt.round()  # warm-up: the first round grows from two single-node trees
+    # (the rounds cannot be repeated untimed -- the trees grow -- so the dominant kernels are bracketed in the timed rounds
+    #  themselves: two events per launch of the generating kernel and of the nearest-neighbour scans, ~40 launches per round)
+    cc.engine.set_option("kernel_timer", 3)
     rows, new_nodes, exch = [], 0, []
     nplan = len(qidx)
     world.barrier()
@@ -603,6 +649,9 @@ def bench_rrt(args, world):
     world.barrier()
     elapsed = time.perf_counter() - t0
     done = len(rows)
+    gen_ms, gen_n = cc.engine.get_option("kernel_timer_ms"), cc.engine.get_option("kernel_timer_launches")
+    nn_ms, nn_n = cc.engine.get_option("kernel_timer2_ms"), cc.engine.get_option("kernel_timer2_launches")
+    cc.engine.set_option("kernel_timer", 0)
     slowest = float(world.gather(elapsed).max())
     path_ok = None
     if world.rank == 0:
@@ -634,7 +683,17 @@ def bench_rrt(args, world):
             {"bound": "hbm", "achieved": round_bytes / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round_bytes / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_round": round_bytes,
              "of_which_nearest_neighbour_scans": nn_bytes, "over": "the whole round (its kernels are not bracketed one by one)"},
-            round_s * 1e3, launches_per_step=float(rec.get("calls_per_round", 0.0)) or 1.0)
+            round_s * 1e3, launches_per_step=float(rec.get("calls_per_round", 0.0)) or 1.0,
+            this_run=(gen_ms / done, gen_n / done) if gen_n > 0 else None)
+        if isinstance(roofline, dict) and roofline.get("bound") == "valu_issue":
+            roofline["kernel"] = "k_rrt_gen_project_rows / _ahead (every launch of the rounds' generating kernel)"
+            # (the committed counters are per launch of ONE of the two forms at the first rounds' sizes; this run's launches differ in
+            #  lanes and steps, so `achieved` here = the committed instructions per launch x this run's launches / this run's time)
+        roofline["nearest_neighbour_scans"] = {
+            "ms_per_round": nn_ms / done if nn_n > 0 else None, "launches_per_round": nn_n / done if nn_n > 0 else None,
+            "share_of_round": nn_ms / done / (round_s * 1e3) if nn_n > 0 else None,
+            "note": "k_nearest_mfma (cell-ordered scan, mjpl_nearest_cells.h) between HIP events in the timed rounds; beside the "
+                    "second stream's look-ups the shares may add up to more than the round"}
         cpu = None
         if not args.no_cpu_baseline:
             # the same algorithm stated in NumPy (mjpl_amd.planning.parallel_rrt.ParallelBiRRT: what the GPU planner's trees are

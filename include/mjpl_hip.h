@@ -248,6 +248,14 @@ int32_t mjpl_nearest_last_screen(mjpl_engine *e);
  * "nn_sample", "filter", "fused", ...).  mjpl_get_option reads one back. */
 int mjpl_set_option(mjpl_engine *e, const char *name, double value);
 int mjpl_get_option(mjpl_engine *e, const char *name, double *value);
+/* the table itself: how many options there are, and option `index`'s name (NULL beyond the table; *writable = 0 for a
+ * read-only one).  The library reads NO switch from the environment -- except that with MJPL_DEBUG=1 set when an engine
+ * is made, every writable option NAME is also taken from the variable MJPL_<NAME> (shell tools, A/B scripts). */
+int32_t mjpl_option_count(void);
+const char *mjpl_option_name(int32_t index, int32_t *writable);
+/* per-model libraries (mjpl_amd/specialise.py) are looked for in `dir` instead of the directory `spec` beside this
+ * library; NULL or "": the default again.  Process-wide; takes effect at the next mjpl_set_planning / mjpl_set_spec. */
+int mjpl_set_spec_dir(const char *dir);
 
 /* ---- device memory and stream helpers (so that hosts need no other GPU runtime) -- */
 

@@ -298,6 +298,11 @@ struct mjpl_engine {
   // timing runs (mjpl_time_edges_stages_dev): marks[k] is recorded after stage k - 1 of the launch
   // (marks[0] at its start); nullptr in ordinary launches
   hipEvent_t *marks = nullptr;
+  // option "kernel_timer" (bench.py: every line's roofline from THIS run), a bit mask: 1 = the dominant kernel of the configuration /
+  // projection / IK / planner-extension launches is bracketed with events, 2 = the nearest-neighbour scans; "kernel_timer_ms" /
+  // "kernel_timer2_ms" read the sums since the option was set, "kernel_timer[2]_launches" how many
+  int kt_mode = 0, kt_used[2] = {0, 0};  // (kt_mode: bit 0 = class 1, bit 1 = class 2)
+  std::vector<hipEvent_t> kt_ev[2];
   double *d_ucq = nullptr;  // undecided waypoints: rows of nplan float64
   int *d_ucedge = nullptr, *d_ucidx = nullptr, *d_ucga = nullptr, *d_ucgb = nullptr;
   double *d_geomtab = nullptr;  // GTB_LEN doubles per model geom (k_patch_pairs)
@@ -337,6 +342,16 @@ struct mjpl_engine {
   void *d_nn_tmp = nullptr; size_t nn_tmp_bytes = 0;  // distances of a ranged look-up whose caller wants none
   int64_t nn_reserve_nodes = 0; // packed-node rows the screened look-up's scratch is sized for at least (mjpl_rrt_create: the planner's capacity, 2^23 at most)
   int64_t nn_sample = 65536;    // MJPL_NN_SAMPLE: nodes of the strided sample the matrix cores take every query's bound from
+  // switches that used to be read from the environment wherever they were used (round 6: options, include/mjpl_hip.h)
+  size_t zero_copy_bytes = (size_t)256 << 10;  // "zero_copy_bytes"
+  int rows_g = 0;               // "rows_g": lanes per row of the projection / IK row kernels forced (0: by the batch size)
+  int pose_spec = 1;            // "pose_spec": 0 = projections and IK seeds on the interpreting kernels
+  int pose_phase_steps = 0;     // "pose_phase_steps"
+  int rrt_trace = 0;            // "rrt_trace": 1 = a planner round's phases on stderr, 2 = every extension chunk (synchronises)
+  // ... and the planner's (mjpl_rrt_create copies them into the handle it makes)
+  int rrt_exact_counts = 1, rrt_early_nn = 1, rrt_early_lanes = 4096, rrt_early_next = 1, rrt_proj_steps = 1024, rrt_proj_g = 0,
+      rrt_ahead = 1, rrt_ahead_lanes = 1024, rrt_proj_waves = 1024;
+  int64_t rrt_early_min_nodes = 65536, rrt_proj_slots = 1 << 20;
   int nn_cells = 1;             // the cell-ordered scan for big trees (mjpl_nearest_cells.h); option "nn_cells"
   int64_t nn_cells_min = 131072; // ... from this many nodes on; option "nn_cells_min_nodes"
   int nn_last_cells = 0;        // the last look-up took it
@@ -403,12 +418,23 @@ std::mutex &spec_mutex() {
   return m;
 }
 
+// mjpl_set_spec_dir: per-model libraries are looked for there instead of beside this library (process-wide)
+std::string &spec_dir_store() {
+  static std::string d;
+  return d;
+}
+std::string spec_dir_override() {
+  std::lock_guard<std::mutex> lock(spec_mutex());
+  return spec_dir_store();
+}
+
 // dlopen <dir>/<prefix><hash>.so and check that it was built for this hash from these headers
 const SpecLib *find_spec(uint64_t hash, bool generic) {
+  const std::string dir_override = spec_dir_override();
   std::lock_guard<std::mutex> lock(spec_mutex());
   auto &cache = spec_cache();
   uint64_t key = hash ^ (generic ? 0x9e3779b97f4a7c15ull : 0ull);
-  const char *env_dir = getenv("MJPL_SPEC_DIR");
+  const char *env_dir = dir_override.empty() ? nullptr : dir_override.c_str();
   if (env_dir)  // (libraries of another directory are other libraries: e.g. the certificate builds under spec/cert)
     for (const char *c = env_dir; *c; c++) key = (key ^ (uint64_t)(unsigned char)*c) * 0x100000001b3ull;
   auto it = cache.find(key);
@@ -470,8 +496,6 @@ const SpecLib *find_spec(uint64_t hash, bool generic) {
 void load_spec(mjpl_engine *e, bool generic_ok = false, int nstage = 0) {
   e->spec = nullptr;
   e->spec_generic = false;
-  if (const char *s = getenv("MJPL_SPEC"))
-    if (atoi(s) == 0) return;
   if (e->spec_off || e->immediate() || (e->exact_general() && !e->filter_mbox()) || !e->filter_usable) return;  // (the generator covers the queued builds)
   if (!e->spec_generic_only) e->spec = find_spec(e->program_hash, false);
   if (e->spec || !generic_ok) return;
@@ -495,10 +519,7 @@ int pin_reserve(mjpl_engine *e, size_t bytes) {
 constexpr size_t kFusedHostBytes = (size_t)256 << 10;  // batches up to this size take the fused path
 // ... and up to this size the kernels read the pinned block and write into it themselves, over the bus: no copy
 // operation on the stream at all (a scalar valid_config pays launches and one synchronisation; MJPL_ZERO_COPY_BYTES)
-size_t zero_copy_bytes() {
-  static const size_t v = [] { const char *s = getenv("MJPL_ZERO_COPY_BYTES"); return s ? (size_t)atoll(s) : (size_t)256 << 10; }();
-  return v;
-}
+size_t zero_copy_bytes(const mjpl_engine *e) { return e->zero_copy_bytes; }  // (option "zero_copy_bytes")
 
 // mj_collision pair filters [MJ-recalled: engine_collision_driver.c filterBitmask /
 // filterBodyPair] + the a6 ruleset folded in.  returns true if the pair is tested.
@@ -1305,6 +1326,25 @@ int dispatch_filter(const mjpl_engine *e, F &&f) {
   return dispatch_variant(e, f);
 }
 
+// option "kernel_timer": an event on either side of the launches of class `mode`
+void kt_mark(mjpl_engine *e, int mode, hipStream_t st) {
+  if (!(e->kt_mode & mode)) return;
+  const int c = mode == 2 ? 1 : 0;
+  if (e->kt_used[c] + 1 > (int)e->kt_ev[c].size()) {
+    if (e->kt_ev[c].size() >= 4096) return;  // (a run of more launches than that: the later ones go untimed)
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return;
+    e->kt_ev[c].push_back(ev);
+  }
+  (void)hipEventRecord(e->kt_ev[c][(size_t)e->kt_used[c]++], st);
+}
+
+struct KtScope {  // ... around everything a scope enqueues on the engine's stream
+  mjpl_engine *e; int mode;
+  KtScope(mjpl_engine *e_, int mode_) : e(e_), mode(mode_) { kt_mark(e, mode, e->stream); }
+  ~KtScope() { kt_mark(e, mode, e->stream); }
+};
+
 // exact re-check of the undecided pairs: the model's own straight-line float64 FK if it has a library
 int launch_patch(mjpl_engine *e, unsigned pgrid, size_t ldsc, const UndecidedConfigs &uc, uint8_t *dvalid, int32_t *dfb) {
   GeomTable gt = {e->d_geomtab, e->moving_base};
@@ -1347,6 +1387,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
     const unsigned fgrid = (unsigned)((N + fblock - 1) / fblock);
     // (queued interpreter: binary32 columns)
     const size_t ldsf = lds_bytes(e, 1, sizeof(float), fblock, !e->immediate(), e->immediate() ? sizeof(double) : sizeof(float));
+    kt_mark(e, 1, e->stream);
     if (e->spec)
       rc = e->spec->configs(e->stream, fgrid, (unsigned)fblock, ldsf, e->d_ip, (int)e->ip.size(), e->d_fp, (int)e->fp.size(), dQ, N,
                             layout, e->filter_tol, dvalid, e->d_ulist, e->d_ucount, uc, zero_next) == 0 ? MJPL_OK
@@ -1360,6 +1401,7 @@ int launch_configs(mjpl_engine *e, const double *dQ, int64_t N, int layout, uint
                          e->d_ucount, uc, zero_next);
       return MJPL_OK;
     });
+    kt_mark(e, 1, e->stream);
     if (rc != MJPL_OK) return rc;
     guard.armed = false;
     if (uc.count) {  // exact re-check of the undecided pairs; rows here are planning columns, AoS
@@ -1877,33 +1919,12 @@ int engine_from_desc(mjpl_engine *e, const mjpl_model_desc *d, const int32_t *al
   e->qidx.resize(m.nq);
   for (int k = 0; k < m.nq; k++) e->qidx[k] = k;
   e->qbase = m.qpos0;
-  if (const char *f = getenv("MJPL_FILTER")) e->filter = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_TWO_PASS")) e->two_pass = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_FORCE_IMMEDIATE")) e->force_immediate = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_EXPAND")) e->expand = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_PERSIST")) e->persist = atoi(f) != 0 ? 1 : 0;
-  if (const char *f = getenv("MJPL_NN_MFMA")) e->nn_mfma = atoi(f) != 0 ? 1 : 0;
-  if (const char *f = getenv("MJPL_NN_SAMPLE")) e->nn_sample = std::max<int64_t>(1024, atoll(f)) / 32 * 32;
-  if (const char *f = getenv("MJPL_TAIL")) e->fused_tail = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_FUSED")) e->fused = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_FUSED_POLICY")) e->fused_policy = atoi(f);
-  if (const char *f = getenv("MJPL_FUSED_CERT")) e->fused_cert = atoi(f) != 0 ? 1 : 0;
-  if (const char *f = getenv("MJPL_F64_SPEC")) e->f64_spec = atoi(f) != 0;
-  e->fused_dbg_path = getenv("MJPL_FUSED_DEBUG");
-  if (const char *f = getenv("MJPL_FUSED_POOL")) e->fused_pool_cap = atoi(f);
-  if (const char *f = getenv("MJPL_FUSED_MBOX")) e->fused_mbox = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_F64_QUEUED")) e->f64_queued = atoi(f) != 0;
-  if (const char *f = getenv("MJPL_FUSED_SINGLE")) e->fused_single_max = std::max(0, atoi(f));
-  if (const char *f = getenv("MJPL_FUSED_KMAX")) e->fused_kmax = std::max(2, std::min(atoi(f), 1 << 16));
-  if (const char *f = getenv("MJPL_ITEM_CAP")) e->item_cap_limit = (size_t)std::max(64, atoi(f));
-  if (const char *f = getenv("MJPL_UC_CAP")) e->uc_cap_limit = (size_t)std::max(1, atoi(f));
-  if (const char *t = getenv("MJPL_FILTER_TOL")) {
-    const double v = atof(t);
-    if (v > 0.0 && v < 1.0) { e->filter_tol_req = (float)v; e->filter_tol_user = true; }
-  }
+  // (no switch is read from the environment here: mjpl_set_option; MJPL_DEBUG=1 lets the variables of old through, below)
   return MJPL_OK;
 }
 }  // namespace
+
+void apply_debug_environment(mjpl_engine *e);
 
 int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t nallowed,
                 int32_t device, mjpl_engine **out) {
@@ -1928,6 +1949,7 @@ int mjpl_create(const mjpl_model_desc *d, const int32_t *allowed_bodies, int32_t
 
   int rc = engine_from_desc(e, d, allowed_bodies, nallowed);
   if (rc != MJPL_OK) return bail(rc);
+  apply_debug_environment(e);
   rc = compile_program(e);
   if (rc != MJPL_OK) return bail(rc);
   *out = e;
@@ -2021,8 +2043,6 @@ int mjpl_program_dump(const mjpl_model_desc *d, const int32_t *allowed_bodies, i
 }
 
 int mjpl_spec_probe(uint64_t hash, int32_t generic) {
-  if (const char *s = getenv("MJPL_SPEC"))
-    if (atoi(s) == 0) return 0;
   return find_spec(hash, generic != 0) ? 1 : 0;
 }
 
@@ -2208,6 +2228,16 @@ int mjpl_take_status(mjpl_engine *e, int32_t *status) {
 
 // ---- options through the ABI (include/mjpl_hip.h).  One table: name -> how to read it, how to set it.
 namespace {
+double kt_sum(mjpl_engine *e, int c) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1.0;
+  double sum = 0;
+  for (int k = 0; k + 1 < e->kt_used[c]; k += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->kt_ev[c][(size_t)k], e->kt_ev[c][(size_t)k + 1]) != hipSuccess) return -1.0;
+    sum += ms;
+  }
+  return sum;
+}
 struct EngineOption {
   const char *name;
   double (*get)(mjpl_engine *);
@@ -2215,7 +2245,54 @@ struct EngineOption {
 };
 #define MJPL_OPT_BOOL(NAME, FIELD) \
   {NAME, [](mjpl_engine *e) { return (double)(e->FIELD ? 1 : 0); }, [](mjpl_engine *e, double v) { e->FIELD = v != 0.0; return true; }}
+#define MJPL_OPT_INT(NAME, FIELD, LO, HI)                                   \
+  {NAME, [](mjpl_engine *e) { return (double)e->FIELD; }, [](mjpl_engine *e, double v) { \
+     if (!(v >= (double)(LO) && v <= (double)(HI))) return false;            \
+     e->FIELD = (decltype(e->FIELD))v;                                       \
+     return true;                                                            \
+   }}
 const EngineOption kEngineOptions[] = {
+    // ---- what shapes the compiled model or the launch pipeline (take effect at the next mjpl_set_planning / mjpl_set_spec /
+    //      mjpl_set_filter, which compile again; the launch-time ones at the next launch)
+    MJPL_OPT_BOOL("filter", filter),
+    MJPL_OPT_BOOL("two_pass", two_pass),
+    MJPL_OPT_BOOL("force_immediate", force_immediate),
+    MJPL_OPT_BOOL("expand", expand),
+    MJPL_OPT_BOOL("persist", persist),
+    MJPL_OPT_BOOL("tail", fused_tail),
+    MJPL_OPT_BOOL("fused", fused),
+    MJPL_OPT_INT("fused_policy", fused_policy, -1000000, 1000000),
+    MJPL_OPT_BOOL("fused_cert", fused_cert),
+    MJPL_OPT_BOOL("f64_spec", f64_spec),
+    MJPL_OPT_INT("fused_pool", fused_pool_cap, 0, 1 << 30),
+    MJPL_OPT_BOOL("fused_mbox", fused_mbox),
+    MJPL_OPT_BOOL("f64_queued", f64_queued),
+    MJPL_OPT_INT("fused_single", fused_single_max, 0, 1 << 30),
+    MJPL_OPT_INT("fused_kmax", fused_kmax, 2, 1 << 16),
+    MJPL_OPT_INT("item_cap", item_cap_limit, 64, 1ll << 40),
+    MJPL_OPT_INT("uc_cap", uc_cap_limit, 1, 1ll << 40),
+    {"filter_tol", [](mjpl_engine *e) { return (double)e->filter_tol_req; },
+     [](mjpl_engine *e, double v) { if (!(v > 0.0 && v < 1.0)) return false; e->filter_tol_req = (float)v; e->filter_tol_user = true; return true; }},
+    MJPL_OPT_INT("zero_copy_bytes", zero_copy_bytes, 0, 1ll << 40),
+    // ---- projection / IK rows
+    MJPL_OPT_INT("rows_g", rows_g, 0, 64),
+    MJPL_OPT_BOOL("pose_spec", pose_spec),
+    MJPL_OPT_INT("pose_phase_steps", pose_phase_steps, 0, 1 << 20),
+    // ---- the planner (read by mjpl_rrt_create)
+    MJPL_OPT_INT("rrt_trace", rrt_trace, 0, 2),
+    MJPL_OPT_BOOL("rrt_exact_counts", rrt_exact_counts),
+    MJPL_OPT_BOOL("rrt_early_nn", rrt_early_nn),
+    MJPL_OPT_INT("rrt_early_lanes", rrt_early_lanes, 1, 1 << 30),
+    MJPL_OPT_INT("rrt_early_min_nodes", rrt_early_min_nodes, 1, 1ll << 40),
+    MJPL_OPT_BOOL("rrt_early_next", rrt_early_next),
+    MJPL_OPT_INT("rrt_proj_steps", rrt_proj_steps, 1, 1 << 30),
+    MJPL_OPT_INT("rrt_proj_slots", rrt_proj_slots, 1, 1ll << 40),
+    {"rrt_proj_g", [](mjpl_engine *e) { return (double)e->rrt_proj_g; },
+     [](mjpl_engine *e, double v) { const int g = (int)v; e->rrt_proj_g = (g == 1 || g == 4 || g == 8 || g == 16 || g == 64) ? g : 0; return true; }},
+    MJPL_OPT_BOOL("rrt_ahead", rrt_ahead),
+    MJPL_OPT_INT("rrt_ahead_lanes", rrt_ahead_lanes, 1, 1 << 30),
+    MJPL_OPT_INT("rrt_proj_waves", rrt_proj_waves, 1, 1 << 20),
+    // ---- nearest neighbour
     MJPL_OPT_BOOL("nn_cells", nn_cells),
     MJPL_OPT_BOOL("nn_mfma", nn_mfma),
     {"nn_cells_min_nodes", [](mjpl_engine *e) { return (double)e->nn_cells_min; },
@@ -2223,6 +2300,24 @@ const EngineOption kEngineOptions[] = {
     {"nn_sample", [](mjpl_engine *e) { return (double)e->nn_sample; },
      [](mjpl_engine *e, double v) { if (!(v >= 32 && v < 9e15)) return false; e->nn_sample = std::max<int64_t>(1024, (int64_t)v) / 32 * 32; return true; }},
     {"nn_last_cells", [](mjpl_engine *e) { return (double)e->nn_last_cells; }, nullptr},  // (read-only: the last look-up took the cell-ordered scan)
+    {"kernel_timer", [](mjpl_engine *e) { return (double)e->kt_mode; },
+     [](mjpl_engine *e, double v) {
+       if (!(v >= 0 && v <= 3)) return false;
+       e->kt_mode = (int)v;
+       e->kt_used[0] = e->kt_used[1] = 0;
+       for (int c = 0; c < 2; c++)  // (the events of a run's first launches are made here, not inside what is being timed)
+         while (((int)v >> c & 1) && e->kt_ev[c].size() < 1024) {
+           hipEvent_t ev = nullptr;
+           if (hipEventCreate(&ev) != hipSuccess) break;
+           e->kt_ev[c].push_back(ev);
+         }
+       return true;
+     }},
+    {"kernel_timer_launches", [](mjpl_engine *e) { return (double)(e->kt_used[0] / 2); }, nullptr},
+    {"kernel_timer2_launches", [](mjpl_engine *e) { return (double)(e->kt_used[1] / 2); }, nullptr},
+    // (read-only; synchronise the device: the launches may be on the planner's second stream)
+    {"kernel_timer_ms", [](mjpl_engine *e) { return kt_sum(e, 0); }, nullptr},
+    {"kernel_timer2_ms", [](mjpl_engine *e) { return kt_sum(e, 1); }, nullptr},
     {"nn_probe", [](mjpl_engine *e) { return (double)e->nn_probe; }, [](mjpl_engine *e, double v) { e->nn_probe = (int)v; return true; }},
     {"nn_last_exact_pairs",  // (read-only; synchronises; counted only with "nn_probe" = 2)
      [](mjpl_engine *e) {
@@ -2246,6 +2341,7 @@ const EngineOption kEngineOptions[] = {
      },
      nullptr},
 };
+#undef MJPL_OPT_INT
 #undef MJPL_OPT_BOOL
 }  // namespace
 
@@ -2258,6 +2354,34 @@ int mjpl_set_option(mjpl_engine *e, const char *name, double value) {
       return MJPL_OK;
     }
   return fail(MJPL_E_ARG, "mjpl_set_option: unknown option \"%s\"", name);
+}
+
+// MJPL_DEBUG=1 (and only then): every writable option NAME is also taken from the variable MJPL_<NAME> when an engine is
+// made -- for shell tools and A/B scripts (tools/README.md).  The library reads no other switch from the environment.
+void apply_debug_environment(mjpl_engine *e) {
+  const char *dbg = getenv("MJPL_DEBUG");
+  if (!dbg || atoi(dbg) == 0) return;
+  for (const EngineOption &o : kEngineOptions) {
+    if (!o.set) continue;
+    std::string var = "MJPL_";
+    for (const char *c = o.name; *c; c++) var += (char)toupper((unsigned char)*c);
+    if (const char *v = getenv(var.c_str())) (void)o.set(e, atof(v));
+  }
+  e->fused_dbg_path = getenv("MJPL_FUSED_DEBUG");  // (a file the fused kernel's per-wave accounting is written to: tools/fused_debug.py)
+}
+
+int32_t mjpl_option_count(void) { return (int32_t)(sizeof(kEngineOptions) / sizeof(kEngineOptions[0])); }
+
+const char *mjpl_option_name(int32_t index, int32_t *writable) {
+  if (index < 0 || index >= mjpl_option_count()) return nullptr;
+  if (writable) *writable = kEngineOptions[index].set ? 1 : 0;
+  return kEngineOptions[index].name;
+}
+
+int mjpl_set_spec_dir(const char *dir) {
+  std::lock_guard<std::mutex> lock(spec_mutex());
+  spec_dir_store() = dir ? dir : "";
+  return MJPL_OK;
 }
 
 int mjpl_get_option(mjpl_engine *e, const char *name, double *value) {
@@ -2538,6 +2662,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         cs.list = clist; cs.count = ccount; cs.perm_n = perm_n; cs.list_pitch = nsubp; cs.probe = e->nn_probe; cs.counter = xbits + 3; cs.node_rows = 1; cs.query_rows = 1;
         e->nn_last_count = ccount; e->nn_last_waves = (int)((M + 127) / 128); e->nn_last_nsub = nsub;
         const dim3 gm((unsigned)qblocks, (unsigned)nsplit);
+        kt_mark(e, 2, e->stream);
 #define MJPL_NNM_CASE(NPV)                                                                                                           \
         case NPV:                                                                                                                    \
           hipLaunchKernelGGL((k_nearest_mfma<NPV, false, true>), gm, dim3(kNNMWaves * 64), 0, e->stream, (const double *)nodes_s, n, npad, \
@@ -2548,6 +2673,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
           MJPL_NNM_CASE(2) MJPL_NNM_CASE(3) MJPL_NNM_CASE(4) MJPL_NNM_CASE(5) MJPL_NNM_CASE(6) MJPL_NNM_CASE(7)
         }
 #undef MJPL_NNM_CASE
+        kt_mark(e, 2, e->stream);
         // 5. wild coordinates: the binary32 screen over the callers' rows; then the answers in the callers' order
         const int qb32c = kNN32Queries * kNNThreads;
         const int64_t qt32c = (M + qb32c - 1) / qb32c;
@@ -2711,7 +2837,7 @@ int mjpl_check_configs(mjpl_engine *e, const double *Q, int64_t N, int32_t layou
   const size_t qb = (size_t)N * e->qidx.size() * sizeof(double);
   if ((rc = stage_reserve(e, 0, qb)) != MJPL_OK) return rc;
   if ((rc = stage_reserve(e, 2, (size_t)N)) != MJPL_OK) return rc;
-  if (qb + (size_t)N <= zero_copy_bytes()) {
+  if (qb + (size_t)N <= zero_copy_bytes(e)) {
     if ((rc = pin_reserve(e, qb + (size_t)N)) != MJPL_OK) return rc;
     char *pin = (char *)e->h_pin, *dpin = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&dpin, pin, 0));
@@ -2767,7 +2893,7 @@ int mjpl_check_edges(mjpl_engine *e, const double *QA, const double *QB, int64_t
     }
     e->fused_skip_once = std::sqrt(longest2) > 64.0 * step_dist;
   }
-  if (2 * qb + 5 * (size_t)E + 16 <= zero_copy_bytes()) {
+  if (2 * qb + 5 * (size_t)E + 16 <= zero_copy_bytes(e)) {
     const size_t vb = ((size_t)E + 7) & ~(size_t)7, fbb = (size_t)E * sizeof(int32_t);
     if ((rc = pin_reserve(e, 2 * qb + vb + fbb + 8)) != MJPL_OK) return rc;
     char *pin = (char *)e->h_pin, *dpin = nullptr;
@@ -3093,9 +3219,7 @@ uint64_t chain_hash_of(const std::vector<int> &pi, const std::vector<double> &pd
 // which must not wait for a free lane first.  Beyond that one lane per row, and a wave owns ceil(N / 1 024) >= 64 rows:
 // it refills as rows end.  MJPL_ROWS_G: force the lanes per row (A/B timing).
 struct RowsShape { int G; unsigned grid; int64_t per; };
-RowsShape rows_shape(int64_t N) {
-  const char *fv = getenv("MJPL_ROWS_G");  // (read per call: tests compare the three kernels on one batch)
-  const int forced = fv ? atoi(fv) : 0;
+RowsShape rows_shape(int64_t N, int forced = 0) {  // (forced: option "rows_g" -- tests compare the three kernels on one batch)
   const int64_t max_waves = 1024;  // one per SIMD: what the row kernels' registers allow (mjpl_rows.h)
   RowsShape r;
   r.G = N <= 8 * max_waves ? 8 : (N <= 16 * max_waves ? 4 : 1);
@@ -3161,7 +3285,7 @@ int mjpl_pose_create(mjpl_engine *e, const mjpl_pose_desc *d, mjpl_pose **out) {
   int rc = build_chain(m, d->site_body, p->pi, p->pd, &p->nj);
   if (rc != MJPL_OK) return rc;
   p->chain_hash = chain_hash_of(p->pi, p->pd, p->pd.size());
-  if (const char *f = getenv("MJPL_POSE_SPEC")) p->spec_off = atoi(f) == 0;
+  p->spec_off = e->pose_spec == 0;  // (option "pose_spec")
   p->pi[PH_MAXIT] = d->max_iters > 0 ? d->max_iters : 1000;
   p->pi[PH_OFF_TAIL] = (int)p->pd.size();
   p->pd.resize(p->pd.size() + PT_SIZE);
@@ -3210,17 +3334,18 @@ int mjpl_pose_apply_dev(mjpl_pose *p, const double *dQold, const double *dQ, int
   if (N == 0) return MJPL_OK;
   if (!dQold || !dQout || !dok) return fail(MJPL_E_ARG, "NULL pointer");
   HIP_TRY(hipSetDevice(p->e->device));
+  KtScope kt_scope(p->e, 1);  // (option "kernel_timer")
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
   const int k = pose_spec_index(p);
   if (k >= 0) {
-    const RowsShape rs = rows_shape(N);
     mjpl_engine *e = p->e;
+    const RowsShape rs = rows_shape(N, e->rows_g);
     // MJPL_POSE_PHASE_STEPS=k (an experiment, off by default): a batch too large for several lanes per row in two
     // launches (mjpl_rows.h: PosePhase) -- every row's first k Newton steps with one lane per row, then the rows that
     // want more, a list the first launch packs, with eight.  Same bytes; measured SLOWER at 131 072 rows (0.198 ms in
     // one launch; k = 2 / 3 / 4 / 6: 0.352 / 0.283 / 0.247 / 0.206 -- profiles/r05h_pose_phase.json): eight lanes per row
     // cost eight times the lanes for 1.6 times the speed, and 40 % of the rows want more than three steps.
-    static const int phase_steps = [] { const char *v = getenv("MJPL_POSE_PHASE_STEPS"); return v ? atoi(v) : 0; }();
+    const int phase_steps = e->pose_phase_steps;  // (option "pose_phase_steps")
     if (rs.G == 1 && phase_steps > 0) {
       const size_t need = ((size_t)N * 2 + 16) * sizeof(int32_t);
       if ((rc = stage_reserve(e, 6, need)) != MJPL_OK) return rc;
@@ -3331,8 +3456,7 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, i
   // the chain as straight-line code, if the engine's library has it (same results; MJPL_POSE_SPEC=0: interpreted)
   int spec_k = -1;
   {
-    const char *f = getenv("MJPL_POSE_SPEC");
-    if (e->spec && e->spec->pose_count > 0 && !(f && atoi(f) == 0)) {
+    if (e->spec && e->spec->pose_count > 0 && e->pose_spec != 0) {
       const uint64_t h = chain_hash_of(pi, pd, pd.size());
       for (int k = 0; k < e->spec->pose_count && spec_k < 0; k++)
         if (e->spec->pose_hash(k) == h) spec_k = k;
@@ -3355,6 +3479,7 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, i
   const size_t lds = (size_t)kPoseBlock * sizeof(double) * ((size_t)m.nq + 7 * (size_t)nj);  // + the step row
   if (lds > 64 * 1024) return fail(MJPL_E_CAPACITY, "IK: %d qpos + %d chain joints exceed the LDS budget", m.nq, nj);
   HIP_TRY(hipSetDevice(e->device));
+  KtScope kt_scope(e, 1);  // (option "kernel_timer")
   // the program is tiny and changes with every target: staged through the engine's scratch
   const size_t ib = pi.size() * sizeof(int), db = pd.size() * sizeof(double);
   if ((rc = stage_reserve(e, 5, ((ib + 7) & ~(size_t)7) + db)) != MJPL_OK) return rc;
@@ -3365,7 +3490,7 @@ int mjpl_ik_solve_dev(mjpl_engine *e, const mjpl_ik_desc *d, const double *dQ, i
   HIP_TRY(hipMemcpy(d_pd, pd.data(), db, hipMemcpyHostToDevice));
   const unsigned grid = (unsigned)((N + kPoseBlock - 1) / kPoseBlock);
   if (spec_k >= 0) {
-    const RowsShape rs = rows_shape(N);
+    const RowsShape rs = rows_shape(N, e->rows_g);
     const int rc2 = e->spec->ik_solve(spec_k, rs.G, e->stream, rs.grid, d_pi, d_pd, dQ, N, rs.per, dQout, dok, diters, derr,
                                       d->restarts > 0 ? d->restarts : 0, (unsigned long long)d->restart_seed);
     if (rc2 == 0) return MJPL_OK;

@@ -697,8 +697,8 @@ inline unsigned rgrid(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 // MJPL_RRT_TRACE=1: where a round's wall time goes (stderr; synchronises the stream at every mark)
 struct RrtTrace {
-  bool on = getenv("MJPL_RRT_TRACE") != nullptr;  // (MJPL_DEBUG-class switch: tracing only)
-  bool chunks = on && atoi(getenv("MJPL_RRT_TRACE")) >= 2;  // (2: a line per extension chunk -- the stream is synchronised after every chunk)
+  bool on, chunks;  // option "rrt_trace": 1 = the phases, 2 = a line per extension chunk as well (the stream is synchronised at every mark)
+  explicit RrtTrace(const mjpl_engine *e) : on(e->rrt_trace >= 1), chunks(e->rrt_trace >= 2) {}
   void chunk(hipStream_t st, int index, int active, int S, int G, unsigned grid) {
     if (!chunks) return;
     (void)hipStreamSynchronize(st);
@@ -759,7 +759,7 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
   mjpl_engine *e = r->e;
   hipStream_t st = e->stream;
   const int L = r->L, nplan = r->nplan;
-  RrtTrace tr;
+  RrtTrace tr(e);
   tr.mark(st, "(before the extension)");
   int rc = MJPL_OK;
   if (second && r->early_on) {
@@ -901,9 +901,10 @@ int rrt_extend(mjpl_rrt *r, int t, const double *Tgt, int second, int *nnew) {
         const size_t plds = pose_lds(r->pose) + (size_t)kPoseBlock * sizeof(double) * (size_t)r->nq;
         const int pk = pose_spec_index(r->pose);  // (the chain as straight-line code, if the engine's library has it)
         int launched = -1;
+        KtScope kt_scope(e, 1);  // (option "kernel_timer": the generating kernel of every chunk)
         trace_G = 1; trace_grid = (unsigned)((active_bound + kPoseBlock - 1) / kPoseBlock);
         if (pk >= 0) {
-          const RowsShape rs = r->proj_g > 0 ? RowsShape{r->proj_g, 0u, 0} : rows_shape(active_bound);
+          const RowsShape rs = r->proj_g > 0 ? RowsShape{r->proj_g, 0u, 0} : rows_shape(active_bound, e->rows_g);
           // (few rows: sixteen lanes each, the next step's first Newton pass beside this step's closing evaluation -- mjpl_rows.h,
           //  k_rrt_gen_project_ahead; a library without that kernel refuses and the chunk falls back below)
           const int G = (r->proj_g == 0 && r->ahead && active_bound <= r->ahead_lanes) ? (active_bound <= r->proj_waves_max ? 64 : 16) : rs.G;
@@ -1139,10 +1140,9 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
     for (int t = 0; t < 2; t++) {
       RA(r->carry[t].flag, L); RA(r->carry[t].T, (size_t)nplan * L); RA(r->carry[t].goal, L); RA(r->carry[t].node, L);
     }
-  if (const char *v = getenv("MJPL_RRT_EXACT_COUNTS")) r->exact_counts = atoi(v) != 0 ? 1 : 0;
-  if (const char *v = getenv("MJPL_RRT_EARLY_NN")) r->early_nn = atoi(v) != 0 ? 1 : 0;
-  if (const char *v = getenv("MJPL_RRT_EARLY_LANES")) r->early_lanes = std::max(1, atoi(v));
-  if (const char *v = getenv("MJPL_RRT_EARLY_MIN_NODES")) r->early_min_nodes = std::max<int64_t>(1, atoll(v));
+  // (the planner's switches: options of the engine -- "rrt_exact_counts", "rrt_early_nn", ... -- as they stand now)
+  r->exact_counts = e->rrt_exact_counts; r->early_nn = e->rrt_early_nn; r->early_lanes = e->rrt_early_lanes;
+  r->early_min_nodes = e->rrt_early_min_nodes; r->early_next = e->rrt_early_next;
   if (!d->pose) r->early_nn = 0;  // (extensions without a projecting constraint have no such tail)
   if (r->early_nn) {
     RA(r->d_RAe, (size_t)nplan * L); RA(r->d_near_e, L); RA(r->d_late_pos, L); RA(r->d_early, L);
@@ -1150,7 +1150,6 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
     HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&r->ev_tail, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&r->ev_near, hipEventDisableTiming));
-    if (const char *v = getenv("MJPL_RRT_EARLY_NEXT")) r->early_next = atoi(v) != 0 ? 1 : 0;
     if (r->early_next) {
       RA(r->d_Tn, (size_t)nplan * L); RA(r->d_goal_n, L); RA(r->d_first_n, 1); RA(r->d_pre_idx, L); RA(r->d_pre_d2, L);
       HIP_TRY(hipEventCreateWithFlags(&r->ev_pre, hipEventDisableTiming));
@@ -1160,12 +1159,8 @@ int mjpl_rrt_create(mjpl_engine *e, const mjpl_rrt_desc *d, mjpl_rrt **out) {
   HIP_TRY(hipHostMalloc((void **)&r->h_ctr, RC_SIZE * sizeof(int)));
   HIP_TRY(hipHostMalloc((void **)&r->h_ring, 4 * kRingStride * sizeof(int)));
   memset(r->h_ring, 0, 4 * kRingStride * sizeof(int));
-  if (const char *v = getenv("MJPL_RRT_PROJ_STEPS")) r->proj_steps_max = std::max(1, atoi(v));
-  if (const char *v = getenv("MJPL_RRT_PROJ_SLOTS")) r->proj_slots = std::max(1, atoi(v));
-  if (const char *v = getenv("MJPL_RRT_PROJ_G")) { const int g = atoi(v); r->proj_g = (g == 1 || g == 4 || g == 8 || g == 16 || g == 64) ? g : 0; }
-  if (const char *v = getenv("MJPL_RRT_AHEAD")) r->ahead = atoi(v) != 0 ? 1 : 0;
-  if (const char *v = getenv("MJPL_RRT_AHEAD_LANES")) r->ahead_lanes = std::max(1, atoi(v));
-  if (const char *v = getenv("MJPL_RRT_PROJ_WAVES")) r->proj_waves_max = std::max(1, atoi(v));
+  r->proj_steps_max = e->rrt_proj_steps; r->proj_slots = e->rrt_proj_slots; r->proj_g = e->rrt_proj_g;
+  r->ahead = e->rrt_ahead; r->ahead_lanes = e->rrt_ahead_lanes; r->proj_waves_max = e->rrt_proj_waves;
   HIP_TRY(hipHostMalloc((void **)&r->h_heads, 8 * 1024 * sizeof(int)));
   HIP_TRY(hipHostMalloc((void **)&r->h_myhead, 8 * sizeof(int)));
   std::vector<uint8_t> isplan(r->nq, 0);
@@ -1397,7 +1392,7 @@ int mjpl_rrt_round(mjpl_rrt *r, int32_t request_stop, mjpl_rrt_round_info *info)
   if (world > 1 && !e->comm)
     return fail(MJPL_E_ARG, "mjpl_rrt_round: rank %d of %d without a communicator (mjpl_comm_init), use round_begin / round_finish", rank, world);
   hipStream_t st = e->stream;
-  RrtTrace tr;
+  RrtTrace tr(e);
   int rc = rrt_begin(r, request_stop);
   if (rc != MJPL_OK) return rc;
   tr.mark(st, "round_begin");

@@ -146,6 +146,9 @@ ABI = {
     "mjpl_ik_solve_dev": (C.c_int, [_VP, C.POINTER(IKDesc), _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     "mjpl_set_option": (C.c_int, [_VP, C.c_char_p, C.c_double]),
     "mjpl_get_option": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_double)]),
+    "mjpl_option_count": (C.c_int32, []),
+    "mjpl_option_name": (C.c_char_p, [C.c_int32, C.POINTER(C.c_int32)]),
+    "mjpl_set_spec_dir": (C.c_int, [C.c_char_p]),
     "mjpl_rrt_create": (C.c_int, [_VP, C.POINTER(RrtDesc), C.POINTER(_VP)]),
     "mjpl_rrt_destroy": (None, [_VP]),
     "mjpl_rrt_reset": (C.c_int, [_VP, _F64P, _F64P, C.c_int32, C.c_uint64]),
@@ -190,6 +193,51 @@ def load_library(path: str | None = None) -> C.CDLL:
             fn.argtypes = args
     _libs[path] = lib
     return lib
+
+
+# Options every Engine made from now on starts with (name -> value, mjpl_set_option): what the tests and tools switch
+# kernels with.  `options(...)` is the scoped form.  The LIBRARY reads no switch from the environment; this module does,
+# for the convenience of shells and of the test-suite's older cases: a variable MJPL_<NAME> naming a writable option is
+# applied -- through the ABI -- to every engine as it is made, MJPL_SPEC=0 as mjpl_set_spec(0), MJPL_SPEC_DIR as
+# mjpl_set_spec_dir.
+DEFAULT_OPTIONS: dict = {}
+
+
+class options:
+    """with engine.options(filter=0, fused_single=0): ...  -- engines made inside start with these options."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = DEFAULT_OPTIONS.get(k, None)
+            DEFAULT_OPTIONS[k] = v
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                DEFAULT_OPTIONS.pop(k, None)
+            else:
+                DEFAULT_OPTIONS[k] = v
+
+
+def option_names(lib=None, writable_only=False) -> list[str]:
+    lib = lib or load_library()
+    out = []
+    for i in range(lib.mjpl_option_count()):
+        w = C.c_int32(0)
+        name = lib.mjpl_option_name(i, C.byref(w))
+        if name and (w.value or not writable_only):
+            out.append(name.decode())
+    return out
+
+
+def set_spec_dir(path: str | None):
+    """Per-model libraries are looked for there (process-wide; None: beside the library again)."""
+    lib = load_library()
+    lib.mjpl_set_spec_dir(path.encode() if path else None)
 
 
 def device_count() -> int:
@@ -238,7 +286,7 @@ class Engine:
     reference's per-constraint MjData (collision_constraint.py:23)."""
 
     def __init__(self, model: Model, allowed_collision_bodies=(), device: int = 0,
-                 lib_path: str | None = None):
+                 lib_path: str | None = None, options: dict | None = None):
         self.lib = load_library(lib_path)
         self.model = model
         self.h = None
@@ -259,6 +307,33 @@ class Engine:
         self.h = h
         self.nplan = model.nq
         self._projectors: "weakref.WeakSet[PoseProjector]" = weakref.WeakSet()
+        self._apply_start_options(options)
+
+    def _apply_start_options(self, explicit):
+        """DEFAULT_OPTIONS, the MJPL_<NAME> variables of this process, then `explicit` -- all through mjpl_set_option; one
+        compile at the end if anything was set (options that shape the compiled model take effect then)."""
+        todo = dict(DEFAULT_OPTIONS)
+        spec_off = None
+        for name in option_names(self.lib, writable_only=True):
+            v = os.environ.get("MJPL_" + name.upper())
+            if v is not None and name not in todo:
+                try:
+                    todo[name] = float(v)
+                except ValueError:
+                    pass
+        if os.environ.get("MJPL_SPEC") is not None:
+            spec_off = os.environ["MJPL_SPEC"].strip() in ("0", "")
+        if "MJPL_SPEC_DIR" in os.environ or getattr(Engine, "_spec_dir_from_env", None):
+            d = os.environ.get("MJPL_SPEC_DIR")
+            self.lib.mjpl_set_spec_dir(d.encode() if d else None)
+            Engine._spec_dir_from_env = d
+        todo.update(explicit or {})
+        if "spec" in todo:
+            spec_off = not todo.pop("spec")
+        for k, v in todo.items():
+            self._ok(self.lib.mjpl_set_option(self.h, k.encode(), float(v)))
+        if todo or spec_off is not None or getattr(Engine, "_spec_dir_from_env", None) is not None:
+            self._ok(self.lib.mjpl_set_spec(self.h, 0 if spec_off else 1))  # (compiles again, with the options as they stand)
 
     # -- plumbing
     def _ok(self, rc: int):

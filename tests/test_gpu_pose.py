@@ -18,9 +18,9 @@ def test_translation_limit_kat_on_gpu(monkeypatch):
     # (the model's library carries its chain -- two slide joints -- as straight-line code; the interpreting kernel
     #  must give the same projection bit for bit)
     assert pc._proj.spec_loaded()
-    monkeypatch.setenv("MJPL_POSE_SPEC", "0")
+    pc.engine.set_option("pose_spec", 0)  # (through the ABI: mjpl_set_option -- the library reads no environment)
     pi = mjpl.PoseConstraint(m, "ball_site", home, x_translation=(-0.1, 0.1), q_step=np.inf, engine=pc.engine)
-    monkeypatch.delenv("MJPL_POSE_SPEC")
+    pc.engine.set_option("pose_spec", 1)
     assert not pi._proj.spec_loaded()
     rng = np.random.default_rng(2)
     Q = rng.uniform(-0.5, 0.5, size=(4096, 2))
@@ -32,9 +32,9 @@ def test_translation_limit_kat_on_gpu(monkeypatch):
     movable = np.ones(m.njnt, np.uint8)
     args = ("ball_site", home.translation() + np.array([0.15, -0.2, 0.0]), home.rotation().wxyz, Q[:1024], movable)
     ik_gen = pc.engine.ik_solve(*args, iterations=100)
-    monkeypatch.setenv("MJPL_POSE_SPEC", "0")
+    pc.engine.set_option("pose_spec", 0)
     ik_int = pc.engine.ik_solve(*args, iterations=100)
-    monkeypatch.delenv("MJPL_POSE_SPEC")
+    pc.engine.set_option("pose_spec", 1)
     for x, y in zip(ik_gen, ik_int):
         np.testing.assert_array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
     assert ik_gen[1].mean() > 0.9
@@ -307,16 +307,16 @@ def test_row_kernels_give_the_same_bytes_with_one_four_and_eight_lanes_per_row(m
     seeds[:, :7] = rng.uniform(lo[:7], hi[:7], size=(1024, 7))
     out = {}
     for g in ("1", "4", "8"):
-        monkeypatch.setenv("MJPL_ROWS_G", g)
+        eng.set_option("rows_g", int(g))
         out[g] = list(pc.apply_batch(Q_old, Q)) + list(eng.ik_solve("ee_site", target.translation(), target.rotation().wxyz, seeds, movable,
                                                                      iterations=120, restarts=4, restart_seed=5))
-    monkeypatch.delenv("MJPL_ROWS_G")
-    monkeypatch.setenv("MJPL_POSE_SPEC", "0")
+    eng.set_option("rows_g", 0)
+    eng.set_option("pose_spec", 0)
     pi = mjpl.PoseConstraint(m, "ee_site", frame, engine=eng, **kw)
     assert not pi._proj.spec_loaded()
     out["interpreting"] = list(pi.apply_batch(Q_old, Q)) + list(eng.ik_solve("ee_site", target.translation(), target.rotation().wxyz, seeds, movable,
                                                                                iterations=120, restarts=4, restart_seed=5))
-    monkeypatch.delenv("MJPL_POSE_SPEC")
+    eng.set_option("pose_spec", 1)
     assert 0.05 < out["1"][1].mean() < 1.0 and out["1"][4].mean() > 0.5
     for tag in ("4", "8", "interpreting"):
         for x, y in zip(out["1"], out[tag]):

@@ -10,6 +10,11 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mjpl_amd import build as _build  # noqa: E402
+
+# the digest of the kernel sources the counters were captured under (bench.py says so when a line's build has another)
+STAMP = "%016x" % _build.src_stamp()
 # kernels of the next rows' lines: (bench.py --workload, rows per launch, timed steps of the profiled command)
 NEXT_ROWS = {"k_pose_apply_rows": ("pose", 131072, 1), "k_ik_solve_rows": ("ik", 16384, 1),
              "k_rrt_gen_project_rows": ("rrt", 131072, 2), "k_rrt_gen_project_ahead": ("rrt", 131072, 2), "k_nearest_mfma": ("rrt", 131072, 2), "k_filter_configs": ("configs", 65536, 1)}
@@ -54,6 +59,7 @@ def main():
                 if k in fr:
                     rec[k] = fr[k]
             rec["flops_source"] = f"profiles/{os.path.basename(fl)} (tools/profile_next_rows.sh {flops_tag})"
+        rec["src_stamp"] = STAMP
         out[f"{kernel}_{E}_{layout}_f{filt}_s{spec}"] = rec
     # the next rows' lines (bench.py --workload pose / ik / rrt / configs): keyed by kernel and workload size; the
     # duration is the kernel's average in the SAME profiling round's kernel trace (pmc_summary.py: avg_ns, calls)
@@ -70,6 +76,7 @@ def main():
             #  trees, 131 072 lanes all the same: two rounds' launches in the trace)
             rec["calls_per_round"] = r["calls"] / float(timed_steps)
         rec["source"] = f"profiles/{os.path.basename(p)} + profiles/{tag}_{workload}_kernel_stats.csv (tools/profile_next_rows.sh {tag})"
+        rec["src_stamp"] = STAMP
         out[f"{kernel}_{workload}{size}"] = rec
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
