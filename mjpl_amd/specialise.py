@@ -1120,7 +1120,9 @@ def generate_full_exact(ip, fp, dp, info) -> str | None:
     # (outlined: inlined at the pool kernel's one call site the build returned no contact for any waypoint tile while endpoint
     #  tiles were right -- every variant with a second call site, and this outlined form, return the interpreter's verdicts on
     #  all edges; observed with ROCm 7.2's compiler at 222 spilled scalar registers, not explained)
-    o("  static __device__ __attribute__((noinline)) int run(const double *ltab, const double *q, int qstride, double *save, int sstride, bool active,")
+    # (MJPL_SPEC_F64_INLINE=1: the inlined form, for tools/f64_inline_probe.py -- the experiment that looks for what breaks it)
+    attr = "always_inline" if os.environ.get("MJPL_SPEC_F64_INLINE") == "1" else "noinline"
+    o(f"  static __device__ __attribute__(({attr})) int run(const double *ltab, const double *q, int qstride, double *save, int sstride, bool active,")
     o("                                            const mjpl::WaveQueue<double, false> &wq, int item, const mjpl::PatchSink &ps) {")
     o("    using namespace mjpl;")
     o(f"    SlotFile<double, {maxs}> sf;")
