@@ -326,6 +326,8 @@ struct mjpl_engine {
   bool fused = true;
   int fused_policy = 0, fused_kmax = 4096, fused_pool_cap = 0;  // (MJPL_FUSED_POOL: at most that many ring slots)
   bool f64_spec = true;  // the float64 pool kernel around the library's generated check, when it has one (MJPL_F64_SPEC=0: interpreting)
+  const SpecLib *spec_cert = nullptr;  // the model's library built WITH the edge certificate (spec/cert/), if there is one ...
+  int64_t fused_cert_min_edges = (int64_t)1 << 20;  // ... takes the fused launches of at least this many edges (option "fused_cert_min_edges"; 0: never)
   int fused_cert = 1;  // the fused kernel's edge certificate (mjpl_fused.h; MJPL_FUSED_CERT=0: every surviving edge's waypoints are checked)
   bool fused_mbox = false;
   bool f64_queued = true;  // MJPL_F64_QUEUED: the float64 pool kernel checks through the candidate queues (A/B switch)
@@ -429,11 +431,22 @@ std::string spec_dir_override() {
 }
 
 // dlopen <dir>/<prefix><hash>.so and check that it was built for this hash from these headers
-const SpecLib *find_spec(uint64_t hash, bool generic) {
-  const std::string dir_override = spec_dir_override();
+const SpecLib *find_spec(uint64_t hash, bool generic, const char *subdir = nullptr) {
+  std::string dir_override = spec_dir_override();
   std::lock_guard<std::mutex> lock(spec_mutex());
   auto &cache = spec_cache();
   uint64_t key = hash ^ (generic ? 0x9e3779b97f4a7c15ull : 0ull);
+  if (subdir) {  // (a build of another kind beside the default ones: spec/cert/ holds the edge-certificate builds)
+    if (dir_override.empty()) {
+      Dl_info info0;
+      if (dladdr((const void *)&mjpl_version, &info0) && info0.dli_fname) {
+        dir_override = info0.dli_fname;
+        const size_t slash0 = dir_override.rfind('/');
+        dir_override = (slash0 == std::string::npos ? std::string(".") : dir_override.substr(0, slash0)) + "/spec";
+      }
+    }
+    dir_override += std::string("/") + subdir;
+  }
   const char *env_dir = dir_override.empty() ? nullptr : dir_override.c_str();
   if (env_dir)  // (libraries of another directory are other libraries: e.g. the certificate builds under spec/cert)
     for (const char *c = env_dir; *c; c++) key = (key ^ (uint64_t)(unsigned char)*c) * 0x100000001b3ull;
@@ -497,7 +510,14 @@ void load_spec(mjpl_engine *e, bool generic_ok = false, int nstage = 0) {
   e->spec = nullptr;
   e->spec_generic = false;
   if (e->spec_off || e->immediate() || (e->exact_general() && !e->filter_mbox()) || !e->filter_usable) return;  // (the generator covers the queued builds)
+  e->spec_cert = nullptr;
   if (!e->spec_generic_only) e->spec = find_spec(e->program_hash, false);
+  // (round 6: the certificate pays from about a million edges per launch on -- +7 ... 11 % -- and costs 4 % at 262 144,
+  //  profiles/README.md round 5: both builds are loaded, launch_edges picks by the batch's size)
+  if (e->spec && !e->spec->fused_cert) {
+    const SpecLib *c = find_spec(e->program_hash, false, "cert");
+    if (c && c->fused_cert && c->fused_waves == e->spec->fused_waves) e->spec_cert = c;
+  }
   if (e->spec || !generic_ok) return;
   const SpecLib *g = find_spec(e->robot_hash, true);
   if (g && g->generic_rows == kSceneRows && g->generic_stages == nstage) {
@@ -1262,17 +1282,18 @@ int allow_lds(K kernel, size_t bytes) {
 // (twelve = one workgroup per CU at three waves per SIMD; four for the one-wave-per-SIMD build of models with
 // moving boxes), entries of a workgroup's pool (what the CU's LDS leaves, at least 64 per wave: one endpoint tile
 // each) and the dynamic LDS of a workgroup.
-bool fused_plan(const mjpl_engine *e, int *nwaves, size_t *lds, int *ring = nullptr) {
+bool fused_plan(const mjpl_engine *e, int *nwaves, size_t *lds, int *ring = nullptr, const SpecLib *lib = nullptr) {
+  const SpecLib *spec = lib ? lib : e->spec;  // (lib: the certificate build instead of the engine's default library)
   if (!e->fused || !e->filter || !e->filter_usable || !e->two_pass || !e->expand || e->immediate()) return false;
   const int nplan = (int)e->qidx.size();
   const bool mbox = e->filter_mbox();
   // (models with moving boxes run one wave per SIMD: four waves per workgroup, and measured 5 % SLOWER fused than as the
   // two kernels -- 1.63 vs 1.55 ms on Franka-P with the ten pad boxes; MJPL_FUSED_MBOX=1 runs them fused all the same)
-  if (mbox && !e->fused_mbox && !e->spec) return false;
+  if (mbox && !e->fused_mbox && !spec) return false;
   if (!fused_fits(nplan, e->nsave, mbox)) return false;
-  const int nw = e->spec ? e->spec->fused_waves : (mbox ? 4 : kFusedWaves);
+  const int nw = spec ? spec->fused_waves : (mbox ? 4 : kFusedWaves);
   const size_t budget = (size_t)160 * 1024;
-  const bool cert = e->spec && e->spec->fused_cert;
+  const bool cert = spec && spec->fused_cert;
   const size_t base = fused_lds_bytes(nw, nplan, e->nsave, e->fp.size(), mbox, 0, cert);
   if (base + (size_t)(64 * nw + 64) * kFusedEntryBytes > budget) return false;
   int r = (int)std::min<size_t>(kFusedMaxPool, (budget - base) / kFusedEntryBytes / 64 * 64);
@@ -1468,7 +1489,10 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
     ItemBuffers ib = {};
     int fwaves = 0, fring = 0;
     size_t flds = 0;
-    const bool fused = expand && !e->fused_skip_once && fused_plan(e, &fwaves, &flds, &fring);
+    // (a big batch goes to the model's certificate build, if the engine found one: load_spec)
+    const SpecLib *flib = (e->spec_cert && e->fused_cert && e->fused_cert_min_edges > 0 && E >= e->fused_cert_min_edges &&
+                           E > (int64_t)e->fused_single_max) ? e->spec_cert : e->spec;
+    const bool fused = expand && !e->fused_skip_once && fused_plan(e, &fwaves, &flds, &fring, flib);
     e->fused_skip_once = false;  // (set by the host-pointer entry point for the launch that follows it)
     if (expand) {
       // per-edge scratch: walking list, step fractions, claim words of the undecided-edge list
@@ -1551,8 +1575,8 @@ int launch_edges(mjpl_engine *e, const double *dQA, const double *dQB, int64_t E
         HIP_TRY(hipMemsetAsync(e->d_fused_dbg, 0, kFusedDbgWaves * 8 * sizeof(unsigned long long), e->stream));
         fa.dbg = e->d_fused_dbg;
       }
-      if (e->spec) {
-        rc = e->spec->fused(e->stream, fwaves, flds, fa) == 0 ? MJPL_OK : fail(MJPL_E_HIP, "specialised fused kernel failed to launch");
+      if (flib) {
+        rc = flib->fused(e->stream, fwaves, flds, fa) == 0 ? MJPL_OK : fail(MJPL_E_HIP, "specialised fused kernel failed to launch");
       } else {
         rc = dispatch_filter(e, [&](auto S, auto W, auto M) -> int {
           if constexpr (decltype(S)::value <= kQueuedMaxSlots) {
@@ -2263,6 +2287,8 @@ const EngineOption kEngineOptions[] = {
     MJPL_OPT_BOOL("fused", fused),
     MJPL_OPT_INT("fused_policy", fused_policy, -1000000, 1000000),
     MJPL_OPT_BOOL("fused_cert", fused_cert),
+    MJPL_OPT_INT("fused_cert_min_edges", fused_cert_min_edges, 0, 1ll << 40),
+    {"spec_cert_loaded", [](mjpl_engine *e) { return (double)(e->spec_cert ? 1 : 0); }, nullptr},
     MJPL_OPT_BOOL("f64_spec", f64_spec),
     MJPL_OPT_INT("fused_pool", fused_pool_cap, 0, 1 << 30),
     MJPL_OPT_BOOL("fused_mbox", fused_mbox),

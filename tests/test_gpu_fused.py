@@ -251,3 +251,29 @@ def test_generated_float64_check_equals_the_interpreting_kernel(oracle_mod):
     ov, ofb, _ = orc.valid_edges(qa[:n], qb[:n], 0.01, nthreads=8, info=True)
     np.testing.assert_array_equal(res["generated"][0][:n], ov)
     np.testing.assert_array_equal(res["generated"][1][:n], ofb)
+
+
+def test_big_batches_take_the_certificate_build_by_themselves():
+    """Round 6: an engine loads its model's certificate build (spec/cert/) BESIDE the default library and launch_edges
+    hands it the batches of at least `fused_cert_min_edges` edges (default 2^20: the certificate gains 7 ... 11 % from a
+    million edges on and costs 4 % at 262 144 -- profiles/README.md round 5).  Lowered to 100 000 here: a batch of
+    300 000 is certified in part, one of 90 000 not at all; verdicts and first-bad indices are the default library's."""
+    m = scenes.franka_p(obstacles=True)
+    qidx = scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS)
+    base = m.keyframe("home").qpos.copy()
+    ref = _engine(m, qidx, base)
+    if not ref.get_option("spec_cert_loaded"):
+        pytest.skip("no certificate build beside the default library (python -c 'import __graft_entry__ as g; g.build()')")
+    assert ref.get_option("fused_cert_min_edges") == 1 << 20
+    e = eng_mod.Engine(m, options={"fused_cert_min_edges": 100000})
+    e.set_planning(qidx, base)
+    for n, expect in ((300000, True), (90000, False)):
+        qa, qb = random_edges(m, qidx, n, seed=21)
+        want = ref.check_edges(qa, qb, 0.01, first_bad=True)
+        assert ref.last_certified() == 0  # (below a million edges the default library, which has no certificate code)
+        got = e.check_edges(qa, qb, 0.01, first_bad=True)
+        for x, y in zip(got, want):
+            np.testing.assert_array_equal(x, y)
+        assert (e.last_certified() > 0.2 * want[0].sum()) == expect, (n, e.last_certified(), int(want[0].sum()))
+    e.close()
+    ref.close()
