@@ -281,3 +281,28 @@ def test_robot_hash_and_scene_generic_generation():
     assert len({s.split("program hash")[1].split("\n", 1)[1] for s in srcs}) == 1, "generic code must not depend on the scene"
     ex = specialise.generate_exact(ip, dp, info, generic=True)
     assert "kRelative = 1" in ex and "ga == 0 || gb == 0" in ex
+
+
+def test_options_table_is_enumerable_without_a_device_and_documented():
+    """include/mjpl_hip.h: mjpl_option_count / mjpl_option_name need no engine (and no GPU); every name the table
+    holds is in tools/README.md's options section, and the library's sources read the environment in four places only
+    (the MJPL_DEBUG gate and its loop, the debug file of -DMJPL_FUSED_DEBUG builds, one A/B print)."""
+    import re
+    from mjpl_amd import engine
+    names = engine.option_names()
+    assert len(names) == len(set(names)) >= 45
+    for must in ("filter", "fused", "fused_cert_min_edges", "pose_spec", "rows_g", "rrt_early_nn", "nn_cells", "kernel_timer"):
+        assert must in names
+    writable = engine.option_names(writable_only=True)
+    assert "nn_last_cells" in names and "nn_last_cells" not in writable
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tools", "README.md")) as f:
+        doc = f.read()
+    missing = [n for n in names if f"`{n}`" not in doc]
+    assert not missing, missing
+    sites = 0
+    for fn in os.listdir(os.path.join(root, "mjpl_amd", "csrc")):
+        if fn.endswith((".h", ".hip")):
+            with open(os.path.join(root, "mjpl_amd", "csrc", fn)) as f:
+                sites += len(re.findall(r"\bgetenv\(", f.read()))
+    assert sites <= 5, sites
