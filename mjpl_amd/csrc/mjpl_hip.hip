@@ -2687,11 +2687,11 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         NnCells cs{};
         cs.list = clist; cs.count = ccount; cs.perm_n = perm_n; cs.list_pitch = nsubp; cs.probe = e->nn_probe; cs.counter = xbits + 3; cs.node_rows = 1; cs.query_rows = 1;
         e->nn_last_count = ccount; e->nn_last_waves = (int)((M + 127) / 128); e->nn_last_nsub = nsub;
-        const dim3 gm((unsigned)qblocks, (unsigned)nsplit);
+        const dim3 gm((unsigned)(Mpad / 128), (unsigned)nsplit);  // (one wave of 128 queries per workgroup)
         kt_mark(e, 2, e->stream);
 #define MJPL_NNM_CASE(NPV)                                                                                                           \
         case NPV:                                                                                                                    \
-          hipLaunchKernelGGL((k_nearest_mfma<NPV, false, true>), gm, dim3(kNNMWaves * 64), 0, e->stream, (const double *)nodes_s, n, npad, \
+          hipLaunchKernelGGL((k_nearest_mfma<NPV, false, true>), gm, dim3(64), 0, e->stream, (const double *)nodes_s, n, npad, \
                              (const double *)queries_s, M, (const uint4 *)nodes16, (const uint4 *)q16, (const float *)qn,            \
                              (const unsigned *)xbits, (int64_t)0, (int64_t)1, bound2_s, mp_idx, mp_d2, cs);                          \
           break;

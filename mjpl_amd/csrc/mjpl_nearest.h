@@ -416,8 +416,11 @@ struct NnCells {
   int idx_shift;
 };
 
-template <int NP, bool SAMPLE, bool CELLS = false>
-__global__ void __launch_bounds__(kNNMWaves * 64, 2)
+// (NW: waves per workgroup.  The full scan's four waves walk the same chunk and end together; a cell-ordered scan's waves
+//  have lists of their own, and a workgroup held its slot until the slowest of four was through -- half the chip's wave
+//  slots stood empty on average (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES 7.4 against the full scan's 14.2): ONE wave per workgroup there.)
+template <int NP, bool SAMPLE, bool CELLS = false, int NW = CELLS ? 1 : kNNMWaves>
+__global__ void __launch_bounds__(NW * 64, 2)
 k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const double *__restrict__ queries, int64_t M,
                const uint4 *__restrict__ nodes16, const uint4 *__restrict__ queries16, const float *__restrict__ qnorm,
                const unsigned *__restrict__ xbits, int64_t chunk, int64_t stride, double *__restrict__ bound2,
@@ -427,12 +430,12 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
   if (xbits[1] != 0u) return;  // wild coordinates: the binary32 screen (and the float64 sample scan) serve this call
   // a lane's state that the loop itself does not touch lives in LDS (the two accumulator sets, the queries' operands and
   // the tiles in flight leave ~50 registers): the parked pairs, and per set the best exact distance, its node, the bound
-  constexpr int kThreads = kNNMWaves * 64;
+  constexpr int kThreads = NW * 64;
   __shared__ int32_t park[SAMPLE ? 1 : kNNMPark * kThreads];
   __shared__ double best_l[SAMPLE ? 1 : kNNMSets * kThreads], ref2_l[SAMPLE ? 1 : kNNMSets * kThreads];
   __shared__ int32_t bi_l[kNNMSets * kThreads];
   const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, w = threadIdx.x >> 6;
-  const int64_t q0 = ((int64_t)blockIdx.x * kNNMWaves + w) * (kNNMSets * 32) + r;
+  const int64_t q0 = ((int64_t)blockIdx.x * NW + w) * (kNNMSets * 32) + r;
   const double kInf = std::numeric_limits<double>::infinity();
   const double X = (double)__uint_as_float(xbits[0]);
   // The arithmetic allowance `a` of nn_mfma_threshold, per query: the sums lose at most 50 2^-24 (|x~| + |q~|)^2 (comment above);
@@ -611,7 +614,7 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
         for (int i = 0; i < 16; i++) {
           const int64_t node = pbase + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (t[i] <= T[s] && node < hi) {
-            mypark[parked * (kNNMWaves * 64)] = (int32_t)(((node - glo) << 2) | s);
+            mypark[parked * (NW * 64)] = (int32_t)(((node - glo) << 2) | s);
             parked++;
           }
         }
@@ -660,7 +663,7 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     //  its time filling and emptying the pipeline: 3.6 ms where the stream takes 1.3, profiles/README.md round 6.)
     constexpr int kTiles = kNNCellSub / 32;
     static_assert((kTiles & (kTiles - 1)) == 0, "a power of two");
-    const int wq = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kNNMWaves + w));
+    const int wq = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * NW + w));
     const int32_t *list = cells.list + (int64_t)wq * cells.list_pitch;
     const int cnt = __builtin_amdgcn_readfirstlane(cells.count[wq]);
     const int e0 = __builtin_amdgcn_readfirstlane((int)((int64_t)cnt * blockIdx.y / gridDim.y));
