@@ -19,7 +19,7 @@ for W in "pose:--steps 5 --warmup 1" "rrt:--steps 1" "ik:--steps 2 --warmup 1" "
 done
 cd $R
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_pose k_pose_apply_rows gpurun_out/${TAG}_pmc_k_pose_apply_rows.json > /dev/null
-python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt "k_nearest_mfma<7, false>" gpurun_out/${TAG}_pmc_k_nearest_mfma.json > /dev/null  # (the scan; <7, true> is the sample pass)
+python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt "k_nearest_mfma<7, false" gpurun_out/${TAG}_pmc_k_nearest_mfma.json > /dev/null  # (the scan; <7, true> is the sample pass)
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_rrt_gen_project_rows gpurun_out/${TAG}_pmc_k_rrt_gen_project_rows.json > /dev/null
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_rrt k_rrt_gen_project_ahead gpurun_out/${TAG}_pmc_k_rrt_gen_project_ahead.json > /dev/null  # (the tail's rows a step ahead)
 python3 tools/pmc_summary.py gpurun_out/prof_${TAG}_ik k_ik_solve_rows gpurun_out/${TAG}_pmc_k_ik_solve_rows.json > /dev/null
