@@ -356,6 +356,11 @@ struct mjpl_engine {
   int64_t rrt_early_min_nodes = 65536, rrt_proj_slots = 1 << 20;
   int nn_cells = 1;             // the cell-ordered scan for big trees (mjpl_nearest_cells.h); option "nn_cells"
   int64_t nn_cells_min = 131072; // ... from this many nodes on; option "nn_cells_min_nodes"
+  // options, both OFF: every query's bound tightened on its home sub-chunks before the candidate pass; a binary32 second screen
+  // of the parked pairs.  Measured on one box, 14 planner rounds (profiles/README.md round 6): the second screen 21.2 ms per
+  // round against 19.5 without (it evaluates every parked pair twice where the first evaluation decides most), the home pass
+  // 19.6 (what it saves the scan it costs itself).  Kept for trees and batches of other shapes.
+  int nn_home = 0, nn_second_screen = 0;
   int nn_last_cells = 0;        // the last look-up took it
   int nn_probe = 0;             // (timing only) option "nn_probe"
   const int32_t *nn_last_count = nullptr; int nn_last_waves = 0, nn_last_nsub = 0;  // the last cell-ordered scan's candidate counts
@@ -2320,6 +2325,8 @@ const EngineOption kEngineOptions[] = {
     MJPL_OPT_INT("rrt_proj_waves", rrt_proj_waves, 1, 1 << 20),
     // ---- nearest neighbour
     MJPL_OPT_BOOL("nn_cells", nn_cells),
+    MJPL_OPT_BOOL("nn_home", nn_home),
+    MJPL_OPT_BOOL("nn_second_screen", nn_second_screen),
     MJPL_OPT_BOOL("nn_mfma", nn_mfma),
     {"nn_cells_min_nodes", [](mjpl_engine *e) { return (double)e->nn_cells_min; },
      [](mjpl_engine *e, double v) { if (!(v >= 0 && v < 9e15)) return false; e->nn_cells_min = (int64_t)v; return true; }},
@@ -2576,11 +2583,11 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         const size_t b_qf = al((size_t)Mpad * 32), b_k = al((size_t)M * 4), b_pd = al((size_t)mparts * M * 8), b_pi = al((size_t)mparts * M * 4);
         const size_t b_masks = al((size_t)(Mpad / 128) * nwords * 8), b_tmpq = al(sort_tmp_q);
         const size_t b_cnt = al((size_t)(Mpad / 128) * 4);
-        const size_t fixed = 1024 + 2 * b_q16 + 2 * b_qn + b_qs + b_b2 + b_qf + 4 * b_k + b_pd + b_pi + b_tmpq + b_cnt;
+        const size_t fixed = 1024 + 2 * b_q16 + 2 * b_qn + b_qs + b_b2 + 2 * b_qf + 4 * b_k + b_pd + b_pi + b_tmpq + b_cnt;
         auto grows = [&](int64_t np) {  // masks, lists, boxes, keys + permutation (in / out), sort space, sorted rows, packed rows
           const size_t words = (size_t)((np / kNNCellSub + 63) / 64);
           return al((size_t)(Mpad / 128) * words * 8) + al((size_t)(Mpad / 128) * words * 64 * 4) + al(16 * words * 64 * 4) +
-                 4 * al((size_t)np * 4) + al(sort_tmp_n) + al((size_t)8 * np * 8) + al((size_t)np * 32);
+                 4 * al((size_t)np * 4) + al(sort_tmp_n) + al((size_t)8 * np * 8) + 2 * al((size_t)np * 32);
         };
         if (fixed + grows(npad) > e->nn16_bytes) {
           const size_t room = fixed + grows(nres);
@@ -2597,7 +2604,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         uint4 *q16u = (uint4 *)take(b_q16), *q16 = (uint4 *)take(b_q16);
         float *qnu = (float *)take(b_qn), *qn = (float *)take(b_qn);
         double *queries_s = (double *)take(b_qs), *bound2_s = (double *)take(b_b2);
-        float *qf = (float *)take(b_qf);
+        float *qf = (float *)take(b_qf), *q32c = (float *)take(b_qf);
         unsigned *kq_in = (unsigned *)take(b_k), *kq_out = (unsigned *)take(b_k);
         int32_t *pq_in = (int32_t *)take(b_k), *perm_q = (int32_t *)take(b_k);
         mp_d2 = (double *)take(b_pd);
@@ -2612,6 +2619,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         void *tmpn = take(al(sort_tmp_n));
         double *nodes_s = (double *)take(al((size_t)8 * npad * 8));
         uint4 *nodes16 = (uint4 *)take(al((size_t)npad * 32));
+        float *nodes32 = (float *)take(al((size_t)npad * 32));
         // 1. the nodes along the curve
         HIP_TRY(hipMemsetAsync(xbits, 0, 16, e->stream));  // ([3]: option "nn_probe" = 2 counts the exact evaluations here)
         HIP_TRY(hipMemsetAsync(mm, 0xff, 32, e->stream));
@@ -2625,13 +2633,13 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
                                       e->stream) != hipSuccess)
           return fail(MJPL_E_HIP, "nearest: sorting the nodes failed");
         hipLaunchKernelGGL(k_nnc_gather, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, dnodes, cap, (const int32_t *)perm_n, n,
-                           npad, nplan, nodes_s);
+                           npad, nplan, nodes_s, nodes32, (const NncPlan *)plan);
         hipLaunchKernelGGL(k_nnc_boxes, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, e->stream, (const double *)nodes_s, n, nplan, nsub,
                            nsubp, nbox);
         hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((npad + 256 * kNNPackRows - 1) / (256 * kNNPackRows))), dim3(256), 0, e->stream, (const double *)nodes_s, n, (int64_t)1, npad, nplan,
-                           0, nodes16, (float *)nullptr, xbits, (int64_t)8);
+                           0, nodes16, (float *)nullptr, xbits, (int64_t)8, (const float *)plan->ctr);
         hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 256 * kNNPackRows - 1) / (256 * kNNPackRows))), dim3(256), 0, e->stream, dqueries, M, M, Mpad, nplan, 1, q16u, qnu,
-                           xbits);
+                           xbits, (int64_t)1, (const float *)plan->ctr);
         // 2. every query's bound, and where on the curve it was found (wild coordinates: the float64 scan of a sample of the
         //    callers' rows, as in the plain path; either pair of kernels leaves at once when the other serves the call)
         const int64_t msample = std::max<int64_t>(32, std::min<int64_t>(e->nn_sample, n / 16 / 32 * 32));
@@ -2669,6 +2677,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
         hipLaunchKernelGGL(k_nearest_reduce, dim3(rgridM), dim3(kBlock), 0, e->stream, pidx, pd2, M, (int)((nsamp64 + ch0 - 1) / ch0), seed_idx,
                            seed_d2, (const int32_t *)nullptr, (const double *)nullptr, (const unsigned *)xbits);
         if (have_bound) hipLaunchKernelGGL(k_nnc_bound_min, dim3(rgridM), dim3(kBlock), 0, e->stream, seed_d2, outer_d2, M, (const unsigned *)xbits);
+        const unsigned rgridM_home = (unsigned)((M + 255) / 256);
         // 3. the queries in scan order
         hipLaunchKernelGGL(k_nnc_query_keys, dim3(rgridM), dim3(kBlock), 0, e->stream, (const double *)seed_d2, M, kq_in, pq_in);
         size_t tq = sort_tmp_q;
@@ -2676,16 +2685,19 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
             hipSuccess)
           return fail(MJPL_E_HIP, "nearest: sorting the queries failed");
         hipLaunchKernelGGL(k_nnc_gather_queries, dim3((unsigned)((Mpad + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, dqueries,
-                           (const double *)seed_d2, (const int32_t *)perm_q, M, Mpad, nplan, queries_s, bound2_s, qf);
+                           (const double *)seed_d2, (const int32_t *)perm_q, M, Mpad, nplan, queries_s, bound2_s, qf, q32c, (const NncPlan *)plan);
         hipLaunchKernelGGL(k_nn_pack, dim3((unsigned)((Mpad + 256 * kNNPackRows - 1) / (256 * kNNPackRows))), dim3(256), 0, e->stream, (const double *)queries_s, M, (int64_t)1, Mpad, nplan,
-                           1, q16, qn, xbits, (int64_t)8);
+                           1, q16, qn, xbits, (int64_t)8, (const float *)plan->ctr);
+        if (e->nn_home)
+          hipLaunchKernelGGL(k_nnc_home, dim3(rgridM_home), dim3(256), 0, e->stream, (const double *)nodes_s, n, (const double *)queries_s, M, nplan,
+                           mstride, sc.idx_shift, nsub, bound2_s, qf, (const unsigned *)xbits);
         // 4. candidates, scan
         hipLaunchKernelGGL(k_nn_candidates, dim3((unsigned)(Mpad / 128), (unsigned)((nwords + 3) / 4)), dim3(256), 0, e->stream, (const float *)qf,
                            M, (const float *)nbox, nsub, nsubp, nwords, masks, (const unsigned *)xbits);
         hipLaunchKernelGGL(k_nn_compact, dim3((unsigned)((Mpad / 128 + 3) / 4)), dim3(256), 0, e->stream, (const unsigned long long *)masks, nwords,
                            (int)(Mpad / 128), clist, (int64_t)nsubp, ccount, (const unsigned *)xbits);
         NnCells cs{};
-        cs.list = clist; cs.count = ccount; cs.perm_n = perm_n; cs.list_pitch = nsubp; cs.probe = e->nn_probe; cs.counter = xbits + 3; cs.node_rows = 1; cs.query_rows = 1;
+        cs.list = clist; cs.count = ccount; cs.perm_n = perm_n; cs.list_pitch = nsubp; cs.probe = e->nn_probe; cs.counter = xbits + 3; cs.node_rows = 1; cs.query_rows = 1; cs.nodes32 = nodes32; cs.queries32 = q32c; cs.second = e->nn_second_screen;
         e->nn_last_count = ccount; e->nn_last_waves = (int)((M + 127) / 128); e->nn_last_nsub = nsub;
         const dim3 gm((unsigned)(Mpad / 128), (unsigned)nsplit);  // (one wave of 128 queries per workgroup)
         kt_mark(e, 2, e->stream);

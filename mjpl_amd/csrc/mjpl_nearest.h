@@ -299,7 +299,10 @@ constexpr float kNNMWild = 256.0f;
 constexpr int kNNPackRows = 8;  // rows per thread: a launch has ceil(padded / (256 kNNPackRows)) workgroups
 __global__ void __launch_bounds__(256)
 k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int64_t padded, int nplan, int is_query,
-          uint4 *__restrict__ out16, float *__restrict__ nrm, unsigned *__restrict__ xbits, int64_t row_stride = 1) {
+          uint4 *__restrict__ out16, float *__restrict__ nrm, unsigned *__restrict__ xbits, int64_t row_stride = 1,
+          const float *__restrict__ centre = nullptr) {
+  // (centre, the cell-ordered scan: every coordinate relative to the middle of its column's range -- nodes and queries alike,
+  //  so the distances are the same and the magnitudes, and with them the screen's arithmetic allowance, smaller)
   // (coordinate c of row i: src[c * col_stride + i * row_stride] -- columns [nplan][count] by default, rows of eight with (1, 8))
   float mx = 0, n2max = 0;
   bool wild = false;
@@ -313,7 +316,7 @@ k_nn_pack(const double *__restrict__ src, int64_t count, int64_t col_stride, int
     float n2 = 0;
     if (i < count) {
       for (int c = 0; c < nplan; c++) {
-        const double v = src[(int64_t)c * col_stride + i * row_stride];
+        const double v = src[(int64_t)c * col_stride + i * row_stride] - (centre ? (double)centre[c] : 0.0);
         const float f = (float)v;
         if (v != v) wild = true;
         if (fabs(v) < std::numeric_limits<double>::infinity()) {
@@ -408,7 +411,9 @@ struct NnCells {
   const int32_t *count;            // [waves]: how many
   const int32_t *perm_n;           // sorted position -> node id
   int64_t list_pitch;
+  int second;                      // the parked pairs' second screen is on (option "nn_second_screen")
   int node_rows, query_rows;       // the float64 nodes / queries are rows of eight ([count][8]) instead of columns
+  const float *nodes32, *queries32; // the same rows in binary32, centred ([count][8]), for the parked pairs' second screen
   int probe;                       // (timing only, option "nn_probe": 1 = parked pairs are dropped unevaluated -- WRONG answers;
                                    //  2 = the pairs that reach the exact evaluation are counted in counter[0])
   unsigned *counter;
@@ -477,6 +482,24 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
   const nn_f16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t *mypark = park + (SAMPLE ? 0 : threadIdx.x);
   int parked = 0;
+  // (CELLS) the second screen's thresholds: a node within sqrt(b2) of its query in float64 has a direct binary32 squared
+  // distance of at most (sqrt(b2) + d)^2 (1 + 2^-18), d = sqrt(NP) 2^-22 X: both rows were rounded to binary32 (2^-24 |x| each)
+  // and so was their difference -- 2^-22 X per column at most, X the largest magnitude among the centred coordinates (these
+  // rows are centred like the screen's operands); the NP fused multiply-adds lose less than 2^-20 of the sum.
+  float thr32[kNNMSets];
+  auto second_screen = [&](double b2) -> float {
+    if (!(b2 < kInf)) return std::numeric_limits<float>::infinity();
+    const double d = sqrt((double)NP) * 0x1p-22 * X * (1.0 + 1e-6);
+    const double rr = sqrt(b2) + d;
+    const double th = rr * rr * (1.0 + 0x1p-18);
+    float f = (float)th;
+    if ((double)f < th) f = nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+  };
+  if constexpr (CELLS) {
+#pragma unroll
+    for (int s = 0; s < kNNMSets; s++) thr32[s] = second_screen(ref2[s * kThreads]);
+  }
 
   // exact distance of node `node` from query q: k_nearest_part's statements
   auto exact = [&](int64_t node, int64_t q) {
@@ -531,6 +554,24 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
         const int32_t ent = mypark[j * kThreads];
         const int s = ent & 3;
         const int64_t node = glo + (int64_t)(ent >> 2);
+        if (CELLS && cells.second) {
+          // The second screen (round 6).  In a dense tree thousands of nodes lie within the matrix-core screen's arithmetic
+          // allowance of a query's best (0.02 rad where a step is 0.05; 7 10^8 parked pairs per look-up once two trees
+          // mirror each other): the direct binary32 distance, ONE 32-byte row per node, tells all but the near-ties apart.
+          // A pair within ref2 of its query has a binary32 distance of at most thr32 (below); the others cannot win.
+          const float4 *nr = reinterpret_cast<const float4 *>(cells.nodes32 + 8 * node);
+          const float4 *qr = reinterpret_cast<const float4 *>(cells.queries32 + 8 * (q0 + 32 * s));
+          const float4 n0 = nr[0], n1 = nr[1], c0 = qr[0], c1 = qr[1];
+          float d32 = 0, df;
+          df = n0.x - c0.x; d32 = __builtin_fmaf(df, df, d32);
+          if (NP > 1) { df = n0.y - c0.y; d32 = __builtin_fmaf(df, df, d32); }
+          if (NP > 2) { df = n0.z - c0.z; d32 = __builtin_fmaf(df, df, d32); }
+          if (NP > 3) { df = n0.w - c0.w; d32 = __builtin_fmaf(df, df, d32); }
+          if (NP > 4) { df = n1.x - c1.x; d32 = __builtin_fmaf(df, df, d32); }
+          if (NP > 5) { df = n1.y - c1.y; d32 = __builtin_fmaf(df, df, d32); }
+          if (NP > 6) { df = n1.z - c1.z; d32 = __builtin_fmaf(df, df, d32); }
+          if (!(d32 <= thr32[s])) continue;  // (NaN -- an infinite node -- never passes either)
+        }
         const double ex = exact(node, q0 + 32 * s);
         bool better = ex < best[s * kThreads];
         if constexpr (CELLS)  // (sorted rows are not in id order: an equal distance goes to the lower node id)
@@ -538,7 +579,11 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
         if (better) {
           best[s * kThreads] = ex;
           bi[s * kThreads] = (int32_t)node;
-          if (ex < ref2[s * kThreads]) { ref2[s * kThreads] = ex; touched |= 1u << s; }
+          if (ex < ref2[s * kThreads]) {
+            ref2[s * kThreads] = ex;
+            touched |= 1u << s;
+            if constexpr (CELLS) thr32[s] = second_screen(ex);
+          }
         }
       }
     }

@@ -80,6 +80,7 @@ struct NncPlan {
   float lo[8], inv[8];
   int nb[8];
   int col[kNNCKeyBits];
+  float ctr[8];  // the middle of every column's range: the screen's operands are packed relative to it (smaller magnitudes, a smaller allowance)
 };
 __global__ void k_nnc_plan(const unsigned *__restrict__ mm, int nplan, NncPlan *__restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -88,10 +89,12 @@ __global__ void k_nnc_plan(const unsigned *__restrict__ mm, int nplan, NncPlan *
     out->nb[c] = 0;
     out->lo[c] = 0;
     out->inv[c] = 0;
+    out->ctr[c] = 0;
     w[c] = -1.0f;
     if (c < nplan && mm[c] != 0xffffffffu) {
       const float lo = nnc_unord(mm[c]), hi = nnc_unord(mm[8 + c]);
       out->lo[c] = lo;
+      out->ctr[c] = 0.5f * lo + 0.5f * hi;
       w[c] = hi - lo;
       out->inv[c] = w[c] > 0 ? 1.0f / w[c] : 0.0f;
     }
@@ -138,7 +141,7 @@ k_nnc_keys(const double *__restrict__ src, int64_t count, int64_t col_stride, in
 // (rows beyond `count` up to `padded`: +inf -- a node that never wins; slot 7: 0)
 __global__ void __launch_bounds__(256)
 k_nnc_gather(const double *__restrict__ src, int64_t col_stride, const int32_t *__restrict__ perm, int64_t count, int64_t padded,
-             int nplan, double *__restrict__ dst) {
+             int nplan, double *__restrict__ dst, float *__restrict__ dst32, const NncPlan *__restrict__ plan) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= padded) return;
   const int64_t i = j < count ? perm[j] : -1;
@@ -147,6 +150,13 @@ k_nnc_gather(const double *__restrict__ src, int64_t col_stride, const int32_t *
     row[c] = c < nplan ? (i >= 0 ? src[(int64_t)c * col_stride + i] : std::numeric_limits<double>::infinity()) : 0.0;
   double2 *out = reinterpret_cast<double2 *>(dst + 8 * j);
   for (int k = 0; k < 4; k++) out[k] = double2{row[2 * k], row[2 * k + 1]};
+  // ... and the same row in binary32 (32 bytes), relative to the columns' middles like the screen's operands: the parked
+  // pairs' second screen (k_nearest_mfma: work_off) reads these
+  float r32[8];
+  for (int c = 0; c < 8; c++) r32[c] = c < nplan ? (float)(row[c] - (double)plan->ctr[c]) : 0.0f;
+  float4 *o32 = reinterpret_cast<float4 *>(dst32 + 8 * j);
+  o32[0] = float4{r32[0], r32[1], r32[2], r32[3]};
+  o32[1] = float4{r32[4], r32[5], r32[6], r32[7]};
 }
 
 // the box of every sub-chunk of the sorted nodes: nbox[c][s] = min, nbox[8 + c][s] = max (columns beyond nplan: -inf / +inf)
@@ -204,10 +214,12 @@ k_nnc_query_keys(const double *__restrict__ bound2, int64_t M, unsigned *__restr
 // candidate pass: [x (7, columns beyond nplan: 0), the bound rounded up with the pass's own allowance]
 __global__ void __launch_bounds__(kBlock)
 k_nnc_gather_queries(const double *__restrict__ src, const double *__restrict__ bound2, const int32_t *__restrict__ perm, int64_t M,
-                     int64_t Mpad, int nplan, double *__restrict__ dst, double *__restrict__ bound2_s, float *__restrict__ qf) {
+                     int64_t Mpad, int nplan, double *__restrict__ dst, double *__restrict__ bound2_s, float *__restrict__ qf,
+                     float *__restrict__ q32c, const NncPlan *__restrict__ plan) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= Mpad) return;
   float row[8] = {0, 0, 0, 0, 0, 0, 0, -1.0f};  // (a padding row: no sub-chunk is a candidate for it)
+  float rowc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // the row relative to the columns' middles (the second screen's)
   if (j < M) {
     const int64_t i = perm[j];
     float amax = 0;
@@ -216,6 +228,7 @@ k_nnc_gather_queries(const double *__restrict__ src, const double *__restrict__ 
       dst[8 * j + c] = v;  // (rows of eight, as the nodes)
       if (c < nplan) {
         row[c] = (float)v;
+        rowc[c] = (float)(v - (double)plan->ctr[c]);
         amax = fmaxf(amax, fabsf(row[c]));
       }
     }
@@ -232,7 +245,58 @@ k_nnc_gather_queries(const double *__restrict__ src, const double *__restrict__ 
       row[7] = std::numeric_limits<float>::infinity();
     }
   }
-  for (int k = 0; k < 8; k++) qf[8 * j + k] = row[k];
+  for (int k = 0; k < 8; k++) { qf[8 * j + k] = row[k]; q32c[8 * j + k] = rowc[k]; }
+}
+
+// Every query's bound, tightened where its answer is likely to be: the exact float64 distances to the nodes of its HOME
+// sub-chunk -- the one its sample node lies in (the bound's low 16 bits say where on the curve) -- and the two beside it.
+// In a dense tree the strided sample's nearest node is several nodes' spacings away while thousands lie nearer: with the
+// sample's bound alone a connect-phase look-up parked 7 10^8 pairs (every row of the scan's grid works its way down from
+// the same loose bound on its own); the home nodes bring the bound to the answer's neighbourhood before anything is
+// scanned, and the candidate lists shrink with it.  One lane per sorted query -- neighbours on the curve, so a wave's
+// lanes read the same rows -- and the bound of the candidate pass (qf row, slot 7) is made here from the result.
+__global__ void __launch_bounds__(256)
+k_nnc_home(const double *__restrict__ nodes_s, int64_t n, const double *__restrict__ queries_s, int64_t M, int nplan,
+           int64_t mstride, int idx_shift, int nsub, double *__restrict__ bound2_s, float *__restrict__ qf,
+           const unsigned *__restrict__ xbits) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M || xbits[1] != 0u) return;
+  double q[8];
+  const double2 *qp = reinterpret_cast<const double2 *>(queries_s + 8 * j);
+  for (int k = 0; k < 4; k++) { const double2 v = qp[k]; q[2 * k] = v.x; q[2 * k + 1] = v.y; }
+  const double b0 = bound2_s[j];
+  double best = b0;
+  if (b0 < std::numeric_limits<double>::infinity()) {
+    const unsigned long long word = (unsigned long long)__double_as_longlong(b0);
+    const int64_t pos = (int64_t)((word & 0xffffull) << idx_shift) * mstride;
+    int sc = (int)(pos / kNNCellSub);
+    sc = sc < nsub ? sc : nsub - 1;
+    const int64_t lo = (int64_t)(sc > 0 ? sc - 1 : 0) * kNNCellSub;
+    int64_t hi = (int64_t)(sc + 2) * kNNCellSub;
+    hi = hi < n ? hi : n;
+    for (int64_t i = lo; i < hi; i++) {
+      const double2 *np2 = reinterpret_cast<const double2 *>(nodes_s + 8 * i);
+      double x[8];
+      for (int k = 0; k < 4; k++) { const double2 v = np2[k]; x[2 * k] = v.x; x[2 * k + 1] = v.y; }
+      double ex = 0;
+      for (int c = 0; c < 7; c++) {  // (the statements of the exact distance; slots beyond nplan hold zeros on both sides)
+        const double d = x[c] - q[c];
+        ex = ex + d * d;
+      }
+      best = ex < best ? ex : best;
+    }
+    bound2_s[j] = best;
+  }
+  // the candidate pass's bound (see k_nnc_gather_queries for the allowance)
+  float amax = 0;
+  for (int c = 0; c < nplan; c++) amax = fmaxf(amax, fabsf((float)q[c]));
+  float r2 = std::numeric_limits<float>::infinity();
+  if (best < std::numeric_limits<double>::infinity()) {
+    const double e = sqrt((double)nplan) * 0x1p-24 * (double)amax;
+    const double r = sqrt(best) + e;
+    r2 = nnc_up(r * r * (1.0 + 0x1p-18));
+  }
+  qf[8 * j + 7] = r2;
 }
 
 // The candidate pass.  grid (waves of 128 sorted queries, ceil(nwords / 4)), 256 threads: wave w of the workgroup tests the

@@ -497,7 +497,7 @@ def test_nearest_neighbour_over_a_node_range_behind_an_earlier_answer(n0, n, M, 
     e.close()
 
 
-@pytest.mark.parametrize("cells", [1, 0])
+@pytest.mark.parametrize("cells", [1, 0, 2])
 def test_nearest_neighbour_in_a_dense_tree(cells):
     """Queries that lie ON a dense tree (the connect phase of a search that has filled its manifold): 300 000 nodes on a
     two-dimensional sheet in the seven joints, a few thousandths of a radian apart, queries = nodes, nodes moved by 1e-4,
@@ -506,7 +506,10 @@ def test_nearest_neighbour_in_a_dense_tree(cells):
     m = scenes.franka_p()
     e = eng_mod.Engine(m)
     e.set_planning(scenes.planning_index(m, scenes.FRANKA_ARM_JOINTS), m.keyframe("home").qpos)
-    e.set_option("nn_cells", cells)
+    e.set_option("nn_cells", 1 if cells else 0)
+    if cells == 2:  # (the cell-ordered scan with its two optional passes: bounds tightened on the home sub-chunks, the binary32 second screen)
+        e.set_option("nn_home", 1)
+        e.set_option("nn_second_screen", 1)
     rng = np.random.default_rng(77)
     n, M = 300000, 8192
     u, v = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
@@ -521,7 +524,7 @@ def test_nearest_neighbour_in_a_dense_tree(cells):
     dn, dq = e.alloc(nodes.nbytes).upload(nodes), e.alloc(qs.nbytes).upload(qs)
     di, dd = e.alloc(4 * M), e.alloc(8 * M)
     e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
-    assert e.nearest_last_screen() == 2 and e.get_option("nn_last_cells") == cells
+    assert e.nearest_last_screen() == 2 and e.get_option("nn_last_cells") == (1 if cells else 0)
     got, gd = di.download(np.int32, M), dd.download(np.float64, M)
     sel = np.concatenate([np.arange(0, 40), M // 3 + np.arange(0, 40), 2 * M // 3 + np.arange(0, 40), rng.integers(0, M, 120)])
     s = np.zeros((len(sel), n))
