@@ -356,6 +356,8 @@ struct mjpl_engine {
   int64_t rrt_early_min_nodes = 65536, rrt_proj_slots = 1 << 20;
   int nn_cells = 1;             // the cell-ordered scan for big trees (mjpl_nearest_cells.h); option "nn_cells"
   int64_t nn_cells_min = 131072; // ... from this many nodes on; option "nn_cells_min_nodes"
+  int64_t nn_cells_sample = 32768; // ... with bounds from a strided sample of this many nodes ("nn_cells_sample"; measured on the planner's trees,
+                                 //     ms per look-up targets / connect phase: 8 192: 4.79 / 2.83, 16 384: 4.55 / 2.61, 32 768: 4.64 / 2.68, 65 536: 5.02 / 2.83)
   // options, both OFF: every query's bound tightened on its home sub-chunks before the candidate pass; a binary32 second screen
   // of the parked pairs.  Measured on one box, 14 planner rounds (profiles/README.md round 6): the second screen 21.2 ms per
   // round against 19.5 without (it evaluates every parked pair twice where the first evaluation decides most), the home pass
@@ -2330,6 +2332,8 @@ const EngineOption kEngineOptions[] = {
     MJPL_OPT_BOOL("nn_mfma", nn_mfma),
     {"nn_cells_min_nodes", [](mjpl_engine *e) { return (double)e->nn_cells_min; },
      [](mjpl_engine *e, double v) { if (!(v >= 0 && v < 9e15)) return false; e->nn_cells_min = (int64_t)v; return true; }},
+    {"nn_cells_sample", [](mjpl_engine *e) { return (double)e->nn_cells_sample; },
+     [](mjpl_engine *e, double v) { if (!(v >= 32 && v < 9e15)) return false; e->nn_cells_sample = std::max<int64_t>(1024, (int64_t)v) / 32 * 32; return true; }},
     {"nn_sample", [](mjpl_engine *e) { return (double)e->nn_sample; },
      [](mjpl_engine *e, double v) { if (!(v >= 32 && v < 9e15)) return false; e->nn_sample = std::max<int64_t>(1024, (int64_t)v) / 32 * 32; return true; }},
     {"nn_last_cells", [](mjpl_engine *e) { return (double)e->nn_last_cells; }, nullptr},  // (read-only: the last look-up took the cell-ordered scan)
@@ -2546,8 +2550,10 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
       // bound close to its answer.  Then the binary32-screened scan of all nodes, eight queries per
       // lane, which evaluates exactly only what lies within that bound.
       const int64_t stride = std::max<int64_t>(1, n / kSampleNodes);
+      // (chunks of the float64 sample scan: whole multiples of the scan's tile, and never more of them than partial rows --
+      //  16 384 / nc0 rounded DOWN gave one chunk too many for some node counts, whose row was the seed row: ADVICE r05)
       const int64_t nc0 = std::min<int64_t>(maxchunks, kSampleNodes / kNNThreads);
-      const int64_t ch0 = kSampleNodes / nc0;
+      const int64_t ch0 = ((kSampleNodes + nc0 - 1) / nc0 + kNNThreads - 1) / kNNThreads * kNNThreads;
       // the screened scan on the matrix cores (nplan <= 7), unless some coordinate is too large for binary16 -- which the
       // device finds out while it packs the operands: then those kernels return at once and the float64 sample scan and
       // the binary32 screen run (which in turn return at once when the matrix cores serve the call)
@@ -2642,7 +2648,7 @@ static int nearest_core(mjpl_engine *e, const double *dnodes, int64_t n, int64_t
                            xbits, (int64_t)1, (const float *)plan->ctr);
         // 2. every query's bound, and where on the curve it was found (wild coordinates: the float64 scan of a sample of the
         //    callers' rows, as in the plain path; either pair of kernels leaves at once when the other serves the call)
-        const int64_t msample = std::max<int64_t>(32, std::min<int64_t>(e->nn_sample, n / 16 / 32 * 32));
+        const int64_t msample = std::max<int64_t>(32, std::min<int64_t>(e->nn_cells_sample, n / 16 / 32 * 32));
         const int64_t mstride = std::max<int64_t>(1, n / msample);
         const int64_t ssplit = std::max<int64_t>(1, std::min<int64_t>((1024 + qblocks - 1) / qblocks, msample / 256));
         const int64_t schunk = ((msample + ssplit - 1) / ssplit + 31) / 32 * 32;
