@@ -1090,6 +1090,8 @@ def main():
                        "geom_pairs": info["npairs"], "valid_fraction": float(valid.mean()),
                        "float32_filter": filt, "filter_tol_m": info["filter_tol"],
                        "specialised_kernels": bool(spec), "library": {0: "none (interpreting kernels)", 1: "this program's own", 2: "the robot's scene-generic one"}[spec],
+                       "clock_warm_steps": CLOCK_WARM_STEPS,  # untimed launches before the W warm-up steps (the clocks)
+                       "events_in_timed_region": bool(args.steps >= SHORT_REGION_STEPS),  # (shorter regions: per-kernel durations from 32 bracketed launches just before it)
                        "streams": S, "batches_in_flight": S,
                        "streams_note": (f"{S} engines (one HIP stream and one scratch set each) take the steps in turns: the kernels of "
                                         "consecutive batches overlap; ms_per_step = elapsed / steps; one_stream = the same steps on one engine")

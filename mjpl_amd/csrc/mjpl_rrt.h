@@ -735,7 +735,10 @@ int rrt_read_ctr(mjpl_rrt *r) {
 
 int rrt_rank(const mjpl_rrt *r);
 
-// a look-up enqueued on the planner's second stream, with its scratch
+// a look-up enqueued on the planner's second stream, with its scratch.  (The engine's stream and scratch pointers are swapped
+// for the duration of the CALL -- host code, one thread per engine by the ABI's contract, nothing is enqueued in between --
+// not for the duration of the kernels: those run on `side` with the side scratch while the main stream goes on with its own.
+// The side scratch is allocated by its first look-up of a search, sized like the engine's: nn_reserve_nodes.)
 int rrt_side_nearest(mjpl_rrt *r, const double *nodes, int64_t n, const double *queries, int64_t M, int32_t *idx, double *d2) {
   mjpl_engine *e = r->e;
   auto swap_scratch = [&]() {

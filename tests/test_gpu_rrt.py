@@ -396,3 +396,30 @@ def test_look_ups_ahead_at_planner_size_make_the_same_trees():
     for t in (0, 1):
         np.testing.assert_array_equal(trees[0][t][0], trees[1][t][0])
         np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
+
+
+def test_cell_ordered_look_ups_make_the_same_trees_at_planner_size():
+    """Round 6: from 131 072 nodes on the planner's look-ups take the cell-ordered scan (mjpl_nearest_cells.h) -- whole-tree
+    look-ups on both streams AND the ranged look-ups behind an earlier answer.  65 536 lanes, four rounds, trees of several
+    hundred thousand nodes: bit for bit the trees of a planner whose look-ups scan every node (option nn_cells = 0)."""
+    m = scenes.franka_p(obstacles=True)
+    joints = scenes.FRANKA_ARM_JOINTS
+    qidx = scenes.planning_index(m, joints)
+    q_init = m.keyframe("home").qpos.copy()
+    trees = []
+    for cells in (0, 1):
+        with eng_mod.options(nn_cells=cells):
+            cc, pc, q_goal = _constrained(m, q_init, 7)
+        assert cc.engine.get_option("nn_cells") == cells
+        dev = mjpl.DeviceBiRRT(m, joints, cc, q_init, epsilon=0.05, interval_step=0.01, seed=29, goal_biasing_probability=0.05,
+                               batch=65536, capacity=1 << 23, pose=pc)
+        dev.rrt.reset(q_init[qidx], q_goal[qidx][None], 29)
+        infos = [dev.rrt.round() for _ in range(4)]
+        assert infos[-1].nodes[0] > 300000 and infos[-1].nodes[1] > 300000
+        assert cc.engine.get_option("nn_last_cells") == cells
+        trees.append([dev.rrt.tree(t) for t in (0, 1)])
+        dev.rrt.close()
+        cc.engine.close()
+    for t in (0, 1):
+        np.testing.assert_array_equal(trees[0][t][0], trees[1][t][0])
+        np.testing.assert_array_equal(trees[0][t][1], trees[1][t][1])
