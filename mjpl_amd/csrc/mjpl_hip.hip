@@ -351,7 +351,11 @@ struct mjpl_engine {
   int pose_phase_steps = 0;     // "pose_phase_steps"
   int rrt_trace = 0;            // "rrt_trace": 1 = a planner round's phases on stderr, 2 = every extension chunk (synchronises)
   // ... and the planner's (mjpl_rrt_create copies them into the handle it makes)
-  int rrt_exact_counts = 1, rrt_early_nn = 1, rrt_early_lanes = 4096, rrt_early_next = 1, rrt_proj_steps = 1024, rrt_proj_g = 0,
+  // (rrt_early_nn: the look-ups on a second stream beside the first extension's last chunks -- round 5's answer to tails of a
+  //  thousand steps.  With the chains capped the last chunks are a millisecond and the look-ups two or three: rounds of
+  //  13.0 - 13.5 ms with it at any threshold, 13.1 without (profiles/r06_rrt_early_ab.txt, one box): OFF by default from round 6
+  //  on -- one stream, one scratch arena --, still an option and still tested.)
+  int rrt_exact_counts = 1, rrt_early_nn = 0, rrt_early_lanes = 4096, rrt_early_next = 1, rrt_proj_steps = 1024, rrt_proj_g = 0,
       rrt_ahead = 1, rrt_ahead_lanes = 1024, rrt_proj_waves = 1024;
   int64_t rrt_early_min_nodes = 65536, rrt_proj_slots = 1 << 20;
   int nn_cells = 1;             // the cell-ordered scan for big trees (mjpl_nearest_cells.h); option "nn_cells"

@@ -366,7 +366,7 @@ def test_connect_phase_neighbours_looked_up_early_make_the_same_trees(early_lane
 
 def test_look_ups_ahead_at_planner_size_make_the_same_trees():
     """The same comparison at a planner's size -- 65 536 lanes, three rounds, trees of several hundred thousand nodes --
-    with the defaults: the connect phase's and the next round's look-ups on the second stream, the next round's scan of
+    with the look-ups ahead switched on (round 6: off by default) and the other defaults: the connect phase's and the next round's look-ups on the second stream, the next round's scan of
     the appended nodes behind the early answer through the matrix-core screen (nearest_range), every chunk sized by its own
     lane count, the tail's rows a step ahead -- against a planner with all of that off."""
     m = scenes.franka_p(obstacles=True)
@@ -375,7 +375,7 @@ def test_look_ups_ahead_at_planner_size_make_the_same_trees():
     q_init = m.keyframe("home").qpos.copy()
     trees = []
     keys = ("MJPL_RRT_EARLY_NN", "MJPL_RRT_EXACT_COUNTS", "MJPL_RRT_AHEAD")
-    for env in (dict(MJPL_RRT_EARLY_NN="0", MJPL_RRT_EXACT_COUNTS="0", MJPL_RRT_AHEAD="0"), dict()):
+    for env in (dict(MJPL_RRT_EARLY_NN="0", MJPL_RRT_EXACT_COUNTS="0", MJPL_RRT_AHEAD="0"), dict(MJPL_RRT_EARLY_NN="1")):
         old = {k: os.environ.pop(k, None) for k in keys}
         os.environ.update(env)
         try:
