@@ -368,7 +368,7 @@ struct mjpl_engine {
   // 19.6 (what it saves the scan it costs itself).  Kept for trees and batches of other shapes.
   int nn_home = 0, nn_second_screen = 0;
   int nn_last_cells = 0;        // the last look-up took it
-  int nn_probe = 0;             // (timing only) option "nn_probe"
+  int nn_probe = 0;             // option "nn_probe" (2: count the exact evaluations)
   const int32_t *nn_last_count = nullptr; int nn_last_waves = 0, nn_last_nsub = 0;  // the last cell-ordered scan's candidate counts
   int nn_last = 0;              // what the last mjpl_nearest_dev launched: 0 float64 scan, 1 binary32 screen, 2 matrix-core screen (or 1: see its flag)
   size_t uc_cap = 0, uc_cap_limit = 0;
@@ -2359,7 +2359,10 @@ const EngineOption kEngineOptions[] = {
     // (read-only; synchronise the device: the launches may be on the planner's second stream)
     {"kernel_timer_ms", [](mjpl_engine *e) { return kt_sum(e, 0); }, nullptr},
     {"kernel_timer2_ms", [](mjpl_engine *e) { return kt_sum(e, 1); }, nullptr},
-    {"nn_probe", [](mjpl_engine *e) { return (double)e->nn_probe; }, [](mjpl_engine *e, double v) { e->nn_probe = (int)v; return true; }},
+    // (2: the cell-ordered scan counts the pairs that reach their exact evaluation -- "nn_last_exact_pairs"; answers unchanged.
+    //  A switch that dropped them unevaluated, for timing, gave wrong answers by design and is not in the product: see round 5.)
+    {"nn_probe", [](mjpl_engine *e) { return (double)e->nn_probe; },
+     [](mjpl_engine *e, double v) { if (v != 0.0 && v != 2.0) return false; e->nn_probe = (int)v; return true; }},
     {"nn_last_exact_pairs",  // (read-only; synchronises; counted only with "nn_probe" = 2)
      [](mjpl_engine *e) {
        unsigned x[4] = {0, 0, 0, 0};

@@ -414,8 +414,7 @@ struct NnCells {
   int second;                      // the parked pairs' second screen is on (option "nn_second_screen")
   int node_rows, query_rows;       // the float64 nodes / queries are rows of eight ([count][8]) instead of columns
   const float *nodes32, *queries32; // the same rows in binary32, centred ([count][8]), for the parked pairs' second screen
-  int probe;                       // (timing only, option "nn_probe": 1 = parked pairs are dropped unevaluated -- WRONG answers;
-                                   //  2 = the pairs that reach the exact evaluation are counted in counter[0])
+  int probe;                       // (option "nn_probe" = 2: the pairs that reach the exact evaluation are counted in counter[0]; answers unchanged)
   unsigned *counter;
   int pack_idx;                    // (SAMPLE) the low 16 bits of a bound carry the sample position it was found at (scaled by idx_shift)
   int idx_shift;
@@ -541,7 +540,6 @@ k_nearest_mfma(const double *__restrict__ nodes, int64_t n, int64_t cap, const d
     }
     unsigned touched = 0;
     if constexpr (CELLS) {
-      if (cells.probe == 1) most = 0;
       if (cells.probe == 2) {
         int tot = parked;
 #pragma unroll

@@ -50,16 +50,6 @@ def main():
             assert e.get_option("nn_last_cells") == cells
             if cells:
                 frac = e.get_option("nn_last_candidate_fraction")
-                if os.environ.get("NN_PROBE"):  # (timing only: the scan with its exact evaluations dropped)
-                    e.set_option("nn_probe", 1)
-                    e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
-                    e.sync()
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        e.nearest_dev(dn.ptr, n, n, dq.ptr, M, di.ptr, dd.ptr)
-                    e.sync()
-                    print("   probe (no exact evaluations):", (time.perf_counter() - t0) / reps * 1e3, "ms")
-                    e.set_option("nn_probe", 0)
         same = bool(np.array_equal(res[1][1], res[0][1]) and np.array_equal(res[1][2], res[0][2]))
         for j in range(0, M, M // 32):  # ... and a sample against NumPy: sequential-sum squared norms, lowest index wins
             dif = nodes - qs[:, j:j + 1]
