@@ -21,6 +21,8 @@ def main():
     e.set_planning(qidx, m.keyframe("home").qpos.copy())
     rng = np.random.default_rng(0)
     out = {}
+    cells = int(os.environ.get("NN_CELLS", "1"))  # (0: the full scan of round 5 instead of the cell-ordered one)
+    e.set_option("nn_cells", cells)
     for n, M in ((4096, 512), (65536, 4096), (1 << 20, 131072), (1 << 21, 131072)):
         nodes = rng.uniform(-2.5, 2.5, size=(7, n))
         qs = rng.uniform(-2.5, 2.5, size=(7, M))
@@ -40,10 +42,11 @@ def main():
             for c in range(7):
                 s = s + d[c] * d[c]
             assert got[j] == int(np.argmin(s)), (n, M, j)
-        out[f"{n}x{M}"] = {"ms": dt * 1e3, "pair_distances_per_s": n * M / dt}
+        out[f"{n}x{M}"] = {"ms": dt * 1e3, "pair_distances_per_s": n * M / dt, "cell_ordered": bool(e.get_option("nn_last_cells")),
+                           "candidate_fraction": e.get_option("nn_last_candidate_fraction") if e.get_option("nn_last_cells") else None}
         print(n, M, out[f"{n}x{M}"], flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/nn.json", "w") as f:
+    with open("gpurun_out/nn_cells%d.json" % cells, "w") as f:
         json.dump(out, f, indent=1)
 
 
