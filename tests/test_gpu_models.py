@@ -2,6 +2,7 @@
 branching trees, off-centre hinges, margins, contype/conaffinity masks and allowed body pairs,
 each checked bit-exact (verdicts) / 1e-6 (FK) against the CPU oracle through the C ABI."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -534,3 +535,17 @@ def test_nearest_neighbour_in_a_dense_tree(cells):
     np.testing.assert_array_equal(got[sel], s.argmin(1))
     np.testing.assert_array_equal(gd[sel], s.min(1))
     e.close()
+
+
+def test_cell_ordered_scan_differential_stress(monkeypatch, tmp_path):
+    """tools/nn_stress.py, eight of its random cases: the cell-ordered scan against the full scan on uniform, clustered,
+    duplicated and chain-like nodes, planning sets of 2 ... 7 columns, whole and ranged look-ups, a sink node -- indices and
+    distances equal on every query, and a sample of them against NumPy (profiles/r06_nn_stress.txt: 32 cases)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("nn_stress", os.path.join(root, "tools", "nn_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(sys, "argv", ["nn_stress.py", "8"])
+    mod.main()
