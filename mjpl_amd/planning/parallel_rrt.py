@@ -23,6 +23,15 @@ then joint limits; the lane stops when the step is invalid, moves less than 1e-8
 approach the target, or fails the collision check (endpoint + interval waypoints).  Goals are the
 roots of the goal tree (the reference's sink node, rrt.py:179-188, is implicit), so
 ``plan_to_configs`` / ``plan_to_poses`` work as in the reference.
+
+Two rules of the batched planner that the reference's one-edge-at-a-time loop has no need of (round 6;
+DESIGN.md section 7), stated here and implemented in the device planner, trees equal node for node:
+
+* ``max_steps_per_round`` (64): a lane adds at most that many nodes per extension; a lane of the growing
+  tree still under way is CARRIED -- no connect phase this round, and the next time its tree grows it goes on
+  from the node it reached towards the same target instead of drawing a new one (:class:`Carry`).
+* of the lanes whose first extension added nothing and that stand on the same node of the tree, only the
+  lowest runs a connect phase (all of them would add the same chain, node for node).
 """
 from __future__ import annotations
 
